@@ -1,0 +1,340 @@
+"""Weight files for the engine: tensor specs, seeded synthetic weights, BN folding, ``.ttrw`` I/O.
+
+The reference loads two TorchScript archives from ``weights_dir``
+(tuatara.cpp:333 ``craft_traced_torchscript_model.pt``, tuatara.cpp:423
+``parseq_torchscript.bin``).  Those archives are not in the reference tree and
+cannot be fetched here, so the engine reads a flat file per model
+(``craft.ttrw`` / ``parseq.ttrw``) that ``tools/convert_weights.py`` produces
+from the archives' ``state_dict`` and that ``synth_*`` below produces from a
+seed for tests and the benchmark.  State-dict key names are the upstream
+(clovaai/CRAFT-pytorch, baudm/parseq) names so real checkpoints drop in.
+
+numpy only — no torch, no oracle import.
+"""
+from __future__ import annotations
+
+import math
+import os
+import struct
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+State = Dict[str, np.ndarray]
+
+CRAFT_FILE = "craft.ttrw"
+PARSEQ_FILE = "parseq.ttrw"
+
+# ----------------------------------------------------------------------------- CRAFT spec
+# (engine layer name, upstream conv key, upstream BN key or None, cin, cout, ksize)
+_VGG = [  # slice, conv index in torchvision vgg16_bn.features, cin, cout
+    ("slice1", 0, 3, 64), ("slice1", 3, 64, 64), ("slice1", 7, 64, 128), ("slice1", 10, 128, 128),
+    ("slice2", 14, 128, 256), ("slice2", 17, 256, 256),
+    ("slice3", 20, 256, 256), ("slice3", 24, 256, 512), ("slice3", 27, 512, 512),
+    ("slice4", 30, 512, 512), ("slice4", 34, 512, 512), ("slice4", 37, 512, 512),
+]
+
+
+def craft_layers() -> List[Tuple[str, str, str | None, int, int, int]]:
+    """Every conv of CRAFT in execution order."""
+    out = []
+    for sl, idx, cin, cout in _VGG:
+        out.append((f"{sl}.{idx}", f"basenet.{sl}.{idx}", f"basenet.{sl}.{idx + 1}", cin, cout, 3))
+    out.append(("slice5.1", "basenet.slice5.1", None, 512, 1024, 3))
+    out.append(("slice5.2", "basenet.slice5.2", None, 1024, 1024, 1))
+    for n, (cin, mid, cout) in enumerate([(1024, 512, 256), (512, 256, 128), (256, 128, 64), (128, 64, 32)], 1):
+        out.append((f"upconv{n}.0", f"upconv{n}.conv.0", f"upconv{n}.conv.1", cin + mid, mid, 1))
+        out.append((f"upconv{n}.3", f"upconv{n}.conv.3", f"upconv{n}.conv.4", mid, cout, 3))
+    for idx, cin, cout, k in [(0, 32, 32, 3), (2, 32, 32, 3), (4, 32, 16, 3), (6, 16, 16, 1), (8, 16, 2, 1)]:
+        out.append((f"conv_cls.{idx}", f"conv_cls.{idx}", None, cin, cout, k))
+    return out
+
+
+def craft_spec() -> List[Tuple[str, Tuple[int, ...]]]:
+    spec = []
+    for _, conv, bn, cin, cout, k in craft_layers():
+        spec.append((conv + ".weight", (cout, cin, k, k)))
+        spec.append((conv + ".bias", (cout,)))
+        if bn:
+            for s in ("weight", "bias", "running_mean", "running_var"):
+                spec.append((f"{bn}.{s}", (cout,)))
+    return spec
+
+
+# ----------------------------------------------------------------------------- PARSeq spec
+EMBED, ENC_DEPTH, ENC_HEADS, DEC_HEADS, FFN = 384, 12, 6, 12, 1536
+N_PATCH, MAX_LEN, N_CLASSES, N_TOKENS = 128, 25, 95, 97
+
+
+def parseq_spec() -> List[Tuple[str, Tuple[int, ...]]]:
+    E = EMBED
+    spec = [("encoder.pos_embed", (1, N_PATCH, E)),
+            ("encoder.patch_embed.proj.weight", (E, 3, 4, 8)), ("encoder.patch_embed.proj.bias", (E,))]
+    for i in range(ENC_DEPTH):
+        p = f"encoder.blocks.{i}."
+        spec += [(p + "norm1.weight", (E,)), (p + "norm1.bias", (E,)),
+                 (p + "attn.qkv.weight", (3 * E, E)), (p + "attn.qkv.bias", (3 * E,)),
+                 (p + "attn.proj.weight", (E, E)), (p + "attn.proj.bias", (E,)),
+                 (p + "norm2.weight", (E,)), (p + "norm2.bias", (E,)),
+                 (p + "mlp.fc1.weight", (4 * E, E)), (p + "mlp.fc1.bias", (4 * E,)),
+                 (p + "mlp.fc2.weight", (E, 4 * E)), (p + "mlp.fc2.bias", (E,))]
+    spec += [("encoder.norm.weight", (E,)), ("encoder.norm.bias", (E,))]
+    p = "decoder.layers.0."
+    for a in ("self_attn", "cross_attn"):
+        spec += [(p + a + ".in_proj_weight", (3 * E, E)), (p + a + ".in_proj_bias", (3 * E,)),
+                 (p + a + ".out_proj.weight", (E, E)), (p + a + ".out_proj.bias", (E,))]
+    spec += [(p + "linear1.weight", (FFN, E)), (p + "linear1.bias", (FFN,)),
+             (p + "linear2.weight", (E, FFN)), (p + "linear2.bias", (E,))]
+    for n in ("norm1", "norm2", "norm_q", "norm_c"):
+        spec += [(p + n + ".weight", (E,)), (p + n + ".bias", (E,))]
+    spec += [("decoder.norm.weight", (E,)), ("decoder.norm.bias", (E,)),
+             ("head.weight", (N_CLASSES, E)), ("head.bias", (N_CLASSES,)),
+             ("text_embed.embedding.weight", (N_TOKENS, E)), ("pos_queries", (1, MAX_LEN + 1, E))]
+    return spec
+
+
+# ----------------------------------------------------------------------------- synthetic weights
+def synth_craft(seed: int = 0, structured: bool = True) -> State:
+    """Seeded CRAFT weights.  He-scaled random convs keep activations O(1) through
+    the 27 layers.  ``structured`` additionally wires a hand-designed "ink
+    density" pathway (darkness -> blur -> region / affinity channels) on top of
+    the random features so a real page yields word-shaped blobs: channel 0 of
+    every layer on the relu2_2 -> upconv4 -> conv_cls route carries it."""
+    rng = np.random.default_rng(seed)
+    st: State = {}
+    for name, conv, bn, cin, cout, k in craft_layers():
+        fan_in = cin * k * k
+        gain = 2.0 if (bn or name.startswith("conv_cls")) and name != "conv_cls.8" else 1.0
+        st[conv + ".weight"] = (rng.standard_normal((cout, cin, k, k)) * math.sqrt(gain / fan_in)).astype(np.float32)
+        st[conv + ".bias"] = (rng.standard_normal(cout) * 0.05).astype(np.float32)
+        if bn:
+            st[bn + ".weight"] = rng.uniform(0.8, 1.2, cout).astype(np.float32)
+            st[bn + ".bias"] = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+            st[bn + ".running_mean"] = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+            st[bn + ".running_var"] = rng.uniform(0.8, 1.2, cout).astype(np.float32)
+    if structured:
+        _wire_ink_pathway(st)
+    return st
+
+
+def _wire_ink_pathway(st: State, gain: float = 6.0) -> None:
+    """Hand-designed "text-ness" detector on channels 0..3 of the route
+    slice1 -> relu2_2 skip -> upconv4 -> conv_cls, so a real page gives word-shaped blobs.
+
+    ink = 1 - mean(rgb) (input is /255).  conv1_2 takes two high-passes of it,
+    a = relu(ink - hmean3(ink)) (vertical strokes) and b = relu(ink - vmean3(ink))
+    (horizontal strokes); after the 2x2 max-pool they are blurred (3x3 box for
+    the region pair, 1x3 horizontal for the affinity pair).  conv_cls.4/.6/.8
+    form min(gain * min(A, B), 1) = 1 - relu(1 - gain*(A - relu(A - B))): text has
+    strokes both ways, ruled lines and the black padding margin do not.  The four
+    designed channels read only themselves, their BatchNorms are the identity and
+    no random channel reads them; random features add a 2 % texture in conv_cls.8."""
+    D = 4
+
+    def ident_bn(bn: str) -> None:
+        for c in range(D):
+            st[bn + ".weight"][c] = 1.0
+            st[bn + ".bias"][c] = 0.0
+            st[bn + ".running_mean"][c] = 0.0
+            st[bn + ".running_var"][c] = 1.0 - BN_EPS
+
+    def isolate(conv: str, bn: str | None = None, col0: int = 0):
+        w, b = st[conv + ".weight"], st[conv + ".bias"]
+        w[:, col0:col0 + D] = 0.0   # nobody reads the designed channels ...
+        w[0:D] = 0.0                # ... and they read nobody
+        b[0:D] = 0.0
+        if bn:
+            ident_bn(bn)
+        return w, b
+
+    k = w = None
+    ident = np.zeros((3, 3), np.float32); ident[1, 1] = 1.0
+    box = np.full((3, 3), 1.0 / 9.0, np.float32)
+    wide = np.zeros((3, 3), np.float32); wide[1, :] = 1.0 / 3.0
+    hp_h = np.zeros((3, 3), np.float32); hp_h[1, :] = (-1.0 / 3.0, 2.0 / 3.0, -1.0 / 3.0)
+    hp_v = np.ascontiguousarray(hp_h.T)
+
+    def taps(conv: str, bn: str | None, per_channel, col0: int = 0) -> None:
+        w, _ = isolate(conv, bn, col0)
+        for c, t in enumerate(per_channel):
+            if w.shape[-1] == 1:
+                w[c, col0 + c, 0, 0] = t[1, 1]
+            else:
+                w[c, col0 + c] = t
+
+    # conv1_1: channel 0 = ink; channels 1..3 dead
+    w, b = st["basenet.slice1.0.weight"], st["basenet.slice1.0.bias"]
+    w[0:D] = 0.0
+    b[0:D] = 0.0
+    w[0, :, 1, 1] = -1.0 / 3.0
+    b[0] = 1.0
+    ident_bn("basenet.slice1.1")
+    # conv1_2: a, b, a, b from channel 0
+    w, _ = isolate("basenet.slice1.3", "basenet.slice1.4")
+    w[0, 0], w[1, 0], w[2, 0], w[3, 0] = hp_h, hp_v, hp_h, hp_v
+    taps("basenet.slice1.7", "basenet.slice1.8", [box, box, wide, wide])
+    taps("basenet.slice1.10", "basenet.slice1.11", [ident, ident, wide, wide])
+    st["basenet.slice2.14.weight"][:, 0:D] = 0.0  # the trunk does not read them
+    taps("upconv4.conv.0", "upconv4.conv.1", [ident] * D, col0=64)  # skip channels sit after up(y)'s 64
+    taps("upconv4.conv.3", "upconv4.conv.4", [ident] * D)
+    taps("conv_cls.0", None, [ident] * D)
+    taps("conv_cls.2", None, [ident] * D)
+    # conv_cls.4: (A_r, relu(A_r - B_r), A_l, relu(A_l - B_l))
+    w, _ = isolate("conv_cls.4")
+    w[0, 0, 1, 1] = 1.0
+    w[1, 0, 1, 1], w[1, 1, 1, 1] = 1.0, -1.0
+    w[2, 2, 1, 1] = 1.0
+    w[3, 2, 1, 1], w[3, 3, 1, 1] = 1.0, -1.0
+    # conv_cls.6: u = relu(1 - gain * min(A, B))
+    w, b = isolate("conv_cls.6")
+    w[0, 0, 0, 0], w[0, 1, 0, 0] = -gain, gain
+    w[1, 2, 0, 0], w[1, 3, 0, 0] = -gain, gain
+    b[0:2] = 1.0
+    # conv_cls.8: y = 1 - u (+ faint random texture from the other channels)
+    w = st["conv_cls.8.weight"]
+    w *= 0.02
+    w[:, 0:D] = 0.0
+    w[0, 0, 0, 0] = -1.0
+    w[1, 1, 0, 0] = -1.0
+    st["conv_cls.8.bias"][:] = 1.0
+
+
+def synth_parseq(seed: int = 0, eos_shift: float = 1.7, head_gain: float = 6.0, sharp: float = 3.0) -> State:
+    """Seeded PARSeq weights.  1/sqrt(fan_in) linears (O(1) residual updates),
+    LayerNorm near identity, q/k projections scaled by ``sharp`` so attention is
+    peaked and the output depends on the image (with diffuse attention a random
+    model decodes the same string for every crop), a head gain so logits have
+    std ~``head_gain`` and an EOS shift so decoded strings have realistic lengths."""
+    rng = np.random.default_rng(seed + 1000)
+    st: State = {}
+    E = EMBED
+    for name, shape in parseq_spec():
+        if ("norm" in name) and name.endswith(".weight"):
+            v = rng.uniform(0.8, 1.2, shape)
+        elif name.endswith("bias"):
+            v = rng.standard_normal(shape) * 0.05
+        elif name == "encoder.pos_embed":
+            v = rng.standard_normal(shape) * 0.5
+        elif name == "pos_queries":
+            v = rng.standard_normal(shape) * 0.2
+        elif name == "text_embed.embedding.weight":
+            v = rng.standard_normal(shape) * (1.0 / math.sqrt(E))  # x sqrt(E) at lookup -> O(1)
+        elif name == "encoder.patch_embed.proj.weight":
+            v = rng.standard_normal(shape) * (2.0 / math.sqrt(96))
+        else:
+            v = rng.standard_normal(shape) * (1.0 / math.sqrt(shape[-1]))
+        v = v.astype(np.float32)
+        if name.endswith("attn.qkv.weight") or name.endswith("in_proj_weight"):
+            v[: 2 * E] *= np.float32(sharp)
+        if name.endswith("cross_attn.out_proj.weight"):
+            v *= np.float32(sharp)
+        st[name] = v
+    st["head.weight"] *= np.float32(head_gain)
+    st["head.bias"][0] += np.float32(eos_shift * head_gain)
+    return st
+
+
+# ----------------------------------------------------------------------------- export (engine layout)
+BN_EPS = 1e-5
+
+
+def fold_craft(st: State) -> State:
+    """Fold eval-mode BatchNorm into the preceding conv (fp64 fold, fp32 store) and
+    permute OIHW -> O,kh,kw,I (K contiguous = tap-major, channel-minor)."""
+    out: State = {}
+    for name, conv, bn, cin, cout, k in craft_layers():
+        w = st[conv + ".weight"].astype(np.float64)
+        b = st[conv + ".bias"].astype(np.float64)
+        if bn:
+            g = st[bn + ".weight"].astype(np.float64)
+            beta = st[bn + ".bias"].astype(np.float64)
+            mu = st[bn + ".running_mean"].astype(np.float64)
+            var = st[bn + ".running_var"].astype(np.float64)
+            s = g / np.sqrt(var + BN_EPS)
+            w = w * s[:, None, None, None]
+            b = (b - mu) * s + beta
+        out[name + ".w"] = np.ascontiguousarray(w.transpose(0, 2, 3, 1)).astype(np.float32)
+        out[name + ".b"] = b.astype(np.float32)
+    return out
+
+
+def pack_parseq(st: State) -> State:
+    """Engine layout: linears stay [out,in]; patch-embed weight becomes
+    [384, (dy,dx,c)=96] to match NHWC crops; token embedding pre-scaled by
+    sqrt(E) exactly as ``TokenEmbedding.forward`` does in fp32."""
+    out: State = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in st.items()}
+    w = st["encoder.patch_embed.proj.weight"]  # [E,3,4,8]
+    out["encoder.patch_embed.proj.weight"] = np.ascontiguousarray(w.transpose(0, 2, 3, 1).reshape(EMBED, 96))
+    out["encoder.pos_embed"] = np.ascontiguousarray(st["encoder.pos_embed"].reshape(N_PATCH, EMBED))
+    out["pos_queries"] = np.ascontiguousarray(st["pos_queries"].reshape(MAX_LEN + 1, EMBED))
+    out["text_embed.embedding.weight"] = (np.float32(math.sqrt(EMBED)) * st["text_embed.embedding.weight"]).astype(np.float32)
+    return out
+
+
+MAGIC = b"TTRW0001"
+
+
+def write_ttrw(path: str, tensors: State) -> None:
+    names = list(tensors.keys())
+    table = bytearray()
+    off = 0
+    blobs = []
+    for n in names:
+        a = np.ascontiguousarray(tensors[n], dtype=np.float32)
+        nb = a.nbytes
+        nm = n.encode()
+        table += struct.pack("<H", len(nm)) + nm + struct.pack("<BB", 0, a.ndim)
+        table += struct.pack(f"<{a.ndim}I", *a.shape) + struct.pack("<QQ", off, nb)
+        blobs.append(a.tobytes())
+        off += (nb + 63) // 64 * 64
+    head = MAGIC + struct.pack("<I", len(names)) + bytes(table)
+    pad = (-len(head) - 8) % 64
+    tmp = path + ".tmp"
+    with open(tmp, "wb") as f:
+        f.write(head)
+        f.write(struct.pack("<Q", len(head) + 8 + pad))  # absolute data start
+        f.write(b"\0" * pad)
+        for bl in blobs:
+            f.write(bl)
+            f.write(b"\0" * ((-len(bl)) % 64))
+    os.replace(tmp, path)
+
+
+def read_ttrw(path: str) -> State:
+    with open(path, "rb") as f:
+        buf = f.read()
+    assert buf[:8] == MAGIC, "not a .ttrw file"
+    (n,) = struct.unpack_from("<I", buf, 8)
+    p = 12
+    ent = []
+    for _ in range(n):
+        (ln,) = struct.unpack_from("<H", buf, p); p += 2
+        name = buf[p:p + ln].decode(); p += ln
+        dt, nd = struct.unpack_from("<BB", buf, p); p += 2
+        dims = struct.unpack_from(f"<{nd}I", buf, p); p += 4 * nd
+        off, nb = struct.unpack_from("<QQ", buf, p); p += 16
+        ent.append((name, dims, off, nb))
+    (data0,) = struct.unpack_from("<Q", buf, p)
+    return {name: np.frombuffer(buf, np.float32, nb // 4, data0 + off).reshape(dims).copy() for name, dims, off, nb in ent}
+
+
+def export_craft(st: State, weights_dir: str) -> str:
+    os.makedirs(weights_dir, exist_ok=True)
+    path = os.path.join(weights_dir, CRAFT_FILE)
+    write_ttrw(path, fold_craft(st))
+    return path
+
+
+def export_parseq(st: State, weights_dir: str) -> str:
+    os.makedirs(weights_dir, exist_ok=True)
+    path = os.path.join(weights_dir, PARSEQ_FILE)
+    write_ttrw(path, pack_parseq(st))
+    return path
+
+
+def make_synthetic_weights(weights_dir: str, seed: int = 0, structured: bool = True) -> Tuple[State, State]:
+    """Write ``craft.ttrw`` + ``parseq.ttrw`` for ``seed`` (idempotent) and return the raw state dicts."""
+    c, p = synth_craft(seed, structured), synth_parseq(seed)
+    export_craft(c, weights_dir)
+    export_parseq(p, weights_dir)
+    return c, p
