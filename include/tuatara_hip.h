@@ -1,0 +1,116 @@
+/* C ABI of the MI355X-native tuatara engine (libtuatara_hip.so).
+ *
+ * This is the drop-in boundary for the reference's one hot path,
+ *   std::vector<OutputItem> image_to_data(cv::Mat, std::string, std::string)
+ *   (/root/reference/tuatara.h:8-13, implemented at tuatara.cpp:314-512),
+ * exported as plain C so any host language can bind it (INTEGRATION.md shows the
+ * C++ shim that keeps tuatara.h's signature and the pybind11 module `pytuatara`
+ * of bindings/python.cpp:43-58).  No exceptions cross this boundary: every call
+ * returns 0 on success or a negative code and ttr_last_error() holds the message.
+ * Inputs are borrowed for the duration of the call; results are engine-allocated
+ * and released with ttr_result_free.
+ */
+#ifndef TUATARA_HIP_H
+#define TUATARA_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ttr_engine ttr_engine;
+typedef struct ttr_result ttr_result;
+
+enum { TTR_PREC_BF16 = 0, TTR_PREC_F32 = 1 };
+enum { TTR_ORDER_AS_IS = 0 };  /* channel order: the engine reproduces "swap, detect; swap back, recognise"
+                                  (tuatara.cpp:349, :441) relative to whatever the caller passes */
+
+/* The constants the reference hard-codes (tuatara.cpp:352-353, :397-399, :148). */
+typedef struct ttr_config {
+  int precision;         /* TTR_PREC_BF16 (throughput) or TTR_PREC_F32 (parity mode: fp32 MFMA) */
+  int device;            /* HIP device ordinal */
+  int canvas_size;       /* 1024   tuatara.cpp:352 */
+  float mag_ratio;       /* 1.0    tuatara.cpp:353 */
+  float text_threshold;  /* 0.7    tuatara.cpp:397 */
+  float link_threshold;  /* 0.4    tuatara.cpp:398 */
+  float low_text;        /* 0.4    tuatara.cpp:399 */
+  int min_area;          /* 10     tuatara.cpp:148 */
+  int strict_crops;      /* 0: clamp crops to the image; 1: fail like the reference's cv::Exception at :416 */
+  int max_components;    /* capacity for CCL candidates per page (default 4096) */
+  int verbose;
+} ttr_config;
+
+void ttr_config_default(ttr_config* cfg);
+
+/* weights_dir holds craft.ttrw + parseq.ttrw (tools/convert_weights.py makes them from the
+ * reference's craft_traced_torchscript_model.pt / parseq_torchscript.bin, tuatara.cpp:333,:423). */
+ttr_engine* ttr_create(const char* weights_dir, const ttr_config* cfg);
+void ttr_destroy(ttr_engine* e);
+const char* ttr_last_error(void);
+const char* ttr_version(void);
+
+/* ---- the hot path: replaces image_to_data (tuatara.cpp:314-512) ---------------------------- */
+/* Host image, u8 HWC 3 channels, row_stride in bytes.  Not modified (the reference swaps
+ * the caller's channels in place at :349; callers never rely on that). */
+int ttr_image_to_data(ttr_engine* e, const uint8_t* hwc_u8, int h, int w, int row_stride, ttr_result** out);
+/* Batch of n same-sized pages already resident in device memory (contiguous [n][h][w][3] u8).
+ * out[i] receives page i's result. */
+int ttr_pages_to_data_dev(ttr_engine* e, const uint8_t* d_pages, int n, int h, int w, ttr_result** out);
+
+int ttr_result_count(const ttr_result* r);
+const char* ttr_result_text(const ttr_result* r, int i);
+const float* ttr_result_bbox(const ttr_result* r, int i);   /* {x1,y1,x2,y2}, tuatara.cpp:272 */
+const int32_t* ttr_result_ids(const ttr_result* r, int i);  /* 26 argmax token ids of crop i */
+void ttr_result_free(ttr_result* r);
+
+/* ---- stage-level entry points (BASELINE.json configs 2-3; used by the parity tests) -------- */
+/* CRAFT forward (tuatara.cpp:363-394): canvas u8 [H][W][3] (H,W multiples of 32, already resized,
+ * padded and in the channel order CRAFT must see) -> heat f32 [H/2][W/2][2]. */
+int ttr_craft_heatmap(ttr_engine* e, const uint8_t* canvas, int H, int W, float* heat);
+/* get_detected_boxes (tuatara.cpp:119-204): heat f32 [H2][W2][2] -> rects {cx,cy,w,h,angle} in heat-map
+ * pixels, ordered by component label (raster order of first pixel).  Returns count in *n. */
+int ttr_ccl_boxes(ttr_engine* e, const float* heat, int H2, int W2, float* rects5, int max_rects, int* n);
+/* resize_aspect_ratio + channel swap (tuatara.cpp:349, :206-234): image -> canvas u8 [*H][*W][3] */
+int ttr_resize_canvas(ttr_engine* e, const uint8_t* hwc_u8, int h, int w, int row_stride, uint8_t* canvas, size_t canvas_cap,
+                      int* H, int* W, float* ratio);
+/* adjust_result_coordinates + boundingRect + crop + cv::resize (tuatara.cpp:406-418, :436-441):
+ * rects in heat-map pixels -> crops u8 [n][32][128][3] in the order PARSeq sees; boxes_out (optional)
+ * receives the adjusted rects {cx,cy,w,h,angle} in image pixels. */
+int ttr_pack_crops(ttr_engine* e, const uint8_t* hwc_u8, int h, int w, int row_stride, const float* rects5, int n,
+                   float ratio, uint8_t* crops, float* boxes_out);
+/* PARSeq forward (tuatara.cpp:443-446 + :307): crops u8 [n][32][128][3] -> logits f32 [n][26][95];
+ * ar_logits (optional) receives the autoregressive pass's logits, ids (optional) the argmax ids [n][26]. */
+int ttr_parseq_logits(ttr_engine* e, const uint8_t* crops, int n, float* logits, float* ar_logits, int32_t* ids);
+/* Tokenizer::decode + EOS cut (tuatara.cpp:61-78, :497-502) on 26 ids; buf needs >= 27 bytes. */
+int ttr_decode_ids(const int32_t* ids, int n, char* buf);
+
+/* ---- debug / unit-test hook: one implicit-GEMM conv layer on host tensors ------------------- */
+/* in f32 NHWC [B][H][W][C0] (+ optional in1 [..][C1] virtual concat), wgt f32 [Cout][ks][ks][C0+C1],
+ * out f32 NHWC [B][H][W][Cout].  act: 0 none, 1 relu, 2 gelu. */
+int ttr_dbg_conv(ttr_engine* e, const float* in0, int C0, const float* in1, int C1, int relu0, int relu1, int B, int H, int W,
+                 int ks, int dil, const float* wgt, const float* bias, int Cout, int act, float* out);
+
+/* ---- host-side geometry hooks (no GPU touched; used by the CPU test-suite) -------------------- */
+/* cv::minAreaRect stand-in used at tuatara.cpp:179,:248: n points (x,y) float32 -> {cx,cy,w,h,angle}. */
+int ttr_dbg_min_area_rect(const float* xy, int n, float* rect5);
+/* tuatara.cpp:162-179 for one component given its stats and per-row x extremes
+ * rows[(y1-y0+1)][2] = {min x, max x} ({INT_MAX,-1} = empty row).  Returns 1 if a rect was produced. */
+int ttr_dbg_component_rect(int area, int x0, int y0, int x1, int y1, const int32_t* rows, int H, int W, float* rect5);
+/* adjust_result_coordinates + boundingRect + format (tuatara.cpp:236-274, :416): rect5 in heat-map
+ * pixels -> adjusted rect5, crop xywh (unclamped) and the tesseract bbox. */
+int ttr_dbg_box_geometry(const float* rect5, float ratio, float* adjusted5, int32_t* xywh, float* bbox4);
+
+/* ---- device memory helpers (so callers need no HIP bindings) -------------------------------- */
+void* ttr_dev_alloc(size_t bytes);
+void ttr_dev_free(void* p);
+int ttr_dev_upload(void* dst, const void* src, size_t bytes);
+int ttr_dev_download(void* dst, const void* src, size_t bytes);
+int ttr_dev_sync(ttr_engine* e);
+/* last batch: milliseconds spent in each stage on the GPU stream (hipEvents): {craft, post, pack, parseq} */
+int ttr_last_stage_ms(ttr_engine* e, float ms[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TUATARA_HIP_H */

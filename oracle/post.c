@@ -214,10 +214,9 @@ void orc_tesseract_bbox(const float *r, float *bbox) {
   bbox[0] = roundf(min_x); bbox[1] = roundf(min_y); bbox[2] = roundf(max_x); bbox[3] = roundf(max_y);
 }
 
-/* [OpenCV] cv::minAreaRect on n points (x,y doubles): convex hull + smallest enclosing
- * rectangle with a side collinear to a hull edge (exhaustive over edges, in double),
- * packed into float32 {center,size,angle} the way minAreaRect packs the calipers'
- * (corner, edge1, edge2) output. */
+/* [OpenCV] cv::minAreaRect on n points: convex hull, then the smallest enclosing rectangle
+ * with a side collinear to a hull edge, packed into float32 {center,size,angle} the way
+ * minAreaRect packs the calipers' (corner, edge1, edge2) output. */
 typedef struct { double x, y; } orc_pt;
 static int orc_pt_cmp(const void *a, const void *b) {
   const orc_pt *p = (const orc_pt *)a, *q = (const orc_pt *)b;
@@ -242,41 +241,129 @@ static int orc_convex_hull(orc_pt *p, int n, orc_pt *h) {
   return k - 1;
 }
 
-void orc_min_area_rect(const double *xy, int n, float *rect) {
+/* [OpenCV] rotatingCalipers(), CALIPERS_MINAREARECT, float32 as in OpenCV: the four
+ * calipers sides are (a,b), (-b,a), (-a,-b), (b,-a); each step makes the side with the
+ * smallest angle to its polygon edge flush with it and evaluates width*height.
+ * out = corner, edge vector 1, edge vector 2. */
+static void orc_rotating_calipers(const float *px, const float *py, int n, float *out) {
+  float minarea = 3.402823466e+38F;
+  float *inv = (float *)malloc(sizeof(float) * n), *vx = (float *)malloc(sizeof(float) * n), *vy = (float *)malloc(sizeof(float) * n);
+  int left = 0, bottom = 0, right = 0, top = 0, seq[4];
+  float orientation = 0.f, base_a, base_b = 0.f;
+  float p0x = px[0], p0y = py[0];
+  float left_x = p0x, right_x = p0x, top_y = p0y, bottom_y = p0y;
+  for (int i = 0; i < n; ++i) {
+    if (p0x < left_x) { left_x = p0x; left = i; }
+    if (p0x > right_x) { right_x = p0x; right = i; }
+    if (p0y > top_y) { top_y = p0y; top = i; }
+    if (p0y < bottom_y) { bottom_y = p0y; bottom = i; }
+    int j = i + 1 < n ? i + 1 : 0;
+    double dx = px[j] - p0x, dy = py[j] - p0y;
+    vx[i] = (float)dx; vy[i] = (float)dy;
+    inv[i] = (float)(1. / sqrt(dx * dx + dy * dy));
+    p0x = px[j]; p0y = py[j];
+  }
+  {
+    double ax = vx[n - 1], ay = vy[n - 1];
+    for (int i = 0; i < n; ++i) {
+      double bx = vx[i], by = vy[i];
+      double convexity = ax * by - ay * bx;
+      if (convexity != 0) { orientation = convexity > 0 ? 1.f : -1.f; break; }
+      ax = bx; ay = by;
+    }
+  }
+  base_a = orientation;
+  seq[0] = bottom; seq[1] = right; seq[2] = top; seq[3] = left;
+  int bl = 0, bb = 0;
+  float ba = 1.f, bbv = 0.f, bw = 0.f, bh = 0.f;
+  for (int k = 0; k < n; ++k) {
+    float dp[4];
+    dp[0] = +base_a * vx[seq[0]] + base_b * vy[seq[0]];
+    dp[1] = -base_b * vx[seq[1]] + base_a * vy[seq[1]];
+    dp[2] = -base_a * vx[seq[2]] - base_b * vy[seq[2]];
+    dp[3] = +base_b * vx[seq[3]] - base_a * vy[seq[3]];
+    float maxcos = dp[0] * inv[seq[0]];
+    int me = 0;
+    for (int i = 1; i < 4; ++i) {
+      float c = dp[i] * inv[seq[i]];
+      if (c > maxcos) { me = i; maxcos = c; }
+    }
+    {
+      int pi = seq[me];
+      float lx = vx[pi] * inv[pi], ly = vy[pi] * inv[pi];
+      switch (me) {
+        case 0: base_a = lx; base_b = ly; break;
+        case 1: base_a = ly; base_b = -lx; break;
+        case 2: base_a = -lx; base_b = -ly; break;
+        default: base_a = -ly; base_b = lx; break;
+      }
+    }
+    seq[me] += 1;
+    if (seq[me] == n) seq[me] = 0;
+    float dx = px[seq[1]] - px[seq[3]], dy = py[seq[1]] - py[seq[3]];
+    float width = dx * base_a + dy * base_b;
+    dx = px[seq[2]] - px[seq[0]]; dy = py[seq[2]] - py[seq[0]];
+    float height = -dx * base_b + dy * base_a;
+    float area = width * height;
+    if (area <= minarea) { minarea = area; bl = seq[3]; bb = seq[0]; ba = base_a; bbv = base_b; bw = width; bh = height; }
+  }
+  float A1 = ba, B1 = bbv, A2 = -bbv, B2 = ba;
+  float C1 = A1 * px[bl] + py[bl] * B1;
+  float C2 = A2 * px[bb] + py[bb] * B2;
+  float idet = 1.f / (A1 * B2 - A2 * B1);
+  out[0] = (C1 * B2 - C2 * B1) * idet;
+  out[1] = (A1 * C2 - A2 * C1) * idet;
+  out[2] = A1 * bw; out[3] = B1 * bw;
+  out[4] = A2 * bh; out[5] = B2 * bh;
+  free(inv); free(vx); free(vy);
+}
+
+/* mode 0: OpenCV-style float32 rotating calipers (what the reference runs).
+ * mode 1: exhaustive search over hull edges in double (independent cross-check for tests). */
+static void orc_min_area_rect_mode(const double *xy, int n, float *rect, int mode) {
   orc_pt *p = (orc_pt *)malloc(sizeof(orc_pt) * (n + 1)), *h = (orc_pt *)malloc(sizeof(orc_pt) * (2 * n + 2));
-  for (int i = 0; i < n; ++i) { p[i].x = xy[2 * i]; p[i].y = xy[2 * i + 1]; }
+  for (int i = 0; i < n; ++i) { p[i].x = (float)xy[2 * i]; p[i].y = (float)xy[2 * i + 1]; }  /* hull.convertTo(CV_32F) */
   int hn = orc_convex_hull(p, n, h);
   rect[0] = rect[1] = rect[2] = rect[3] = rect[4] = 0.f;
   if (hn > 2) {
-    double best = -1, o0x = 0, o0y = 0, o1x = 0, o1y = 0, o2x = 0, o2y = 0;
-    for (int i = 0; i < hn; ++i) {
-      orc_pt a = h[i], b = h[(i + 1) % hn];
-      double dx = b.x - a.x, dy = b.y - a.y, len = sqrt(dx * dx + dy * dy);
-      double ux = dx / len, uy = dy / len, nx = -uy, ny = ux;
-      double mnu = 1e300, mxu = -1e300, mnn = 1e300, mxn = -1e300;
-      for (int j = 0; j < hn; ++j) {
-        double pu = h[j].x * ux + h[j].y * uy, pn = h[j].x * nx + h[j].y * ny;
-        if (pu < mnu) mnu = pu; if (pu > mxu) mxu = pu;
-        if (pn < mnn) mnn = pn; if (pn > mxn) mxn = pn;
+    float f0x, f0y, f1x, f1y, f2x, f2y;
+    if (mode == 0) {
+      float *hx = (float *)malloc(sizeof(float) * hn), *hy = (float *)malloc(sizeof(float) * hn), out[6];
+      for (int i = 0; i < hn; ++i) { hx[i] = (float)h[i].x; hy[i] = (float)h[i].y; }
+      orc_rotating_calipers(hx, hy, hn, out);
+      f0x = out[0]; f0y = out[1]; f1x = out[2]; f1y = out[3]; f2x = out[4]; f2y = out[5];
+      free(hx); free(hy);
+    } else {
+      double best = -1, o0x = 0, o0y = 0, o1x = 0, o1y = 0, o2x = 0, o2y = 0;
+      for (int i = 0; i < hn; ++i) {
+        orc_pt a = h[i], b = h[(i + 1) % hn];
+        double dx = b.x - a.x, dy = b.y - a.y, len = sqrt(dx * dx + dy * dy);
+        double ux = dx / len, uy = dy / len, nx = -uy, ny = ux;
+        double mnu = 1e300, mxu = -1e300, mnn = 1e300, mxn = -1e300;
+        for (int j = 0; j < hn; ++j) {
+          double pu = h[j].x * ux + h[j].y * uy, pn = h[j].x * nx + h[j].y * ny;
+          if (pu < mnu) mnu = pu; if (pu > mxu) mxu = pu;
+          if (pn < mnn) mnn = pn; if (pn > mxn) mxn = pn;
+        }
+        double area = (mxu - mnu) * (mxn - mnn);
+        if (best < 0 || area < best) {
+          best = area;
+          o0x = ux * mnu + nx * mnn; o0y = uy * mnu + ny * mnn;
+          o1x = ux * (mxu - mnu); o1y = uy * (mxu - mnu);
+          o2x = nx * (mxn - mnn); o2y = ny * (mxn - mnn);
+        }
       }
-      double area = (mxu - mnu) * (mxn - mnn);
-      if (best < 0 || area < best) {
-        best = area;
-        o0x = ux * mnu + nx * mnn; o0y = uy * mnu + ny * mnn;
-        o1x = ux * (mxu - mnu); o1y = uy * (mxu - mnu);
-        o2x = nx * (mxn - mnn); o2y = ny * (mxn - mnn);
-      }
+      f0x = (float)o0x; f0y = (float)o0y; f1x = (float)o1x; f1y = (float)o1y; f2x = (float)o2x; f2y = (float)o2y;
     }
-    float f0x = (float)o0x, f0y = (float)o0y, f1x = (float)o1x, f1y = (float)o1y, f2x = (float)o2x, f2y = (float)o2y;
     rect[0] = f0x + (f1x + f2x) * 0.5f;
     rect[1] = f0y + (f1y + f2y) * 0.5f;
     rect[2] = (float)sqrt((double)f1x * f1x + (double)f1y * f1y);
     rect[3] = (float)sqrt((double)f2x * f2x + (double)f2y * f2y);
     rect[4] = (float)atan2((double)f1y, (double)f1x);
   } else if (hn == 2) {
-    rect[0] = (float)((h[0].x + h[1].x) * 0.5);
-    rect[1] = (float)((h[0].y + h[1].y) * 0.5);
-    double dx = h[1].x - h[0].x, dy = h[1].y - h[0].y;
+    rect[0] = ((float)h[0].x + (float)h[1].x) * 0.5f;
+    rect[1] = ((float)h[0].y + (float)h[1].y) * 0.5f;
+    double dx = (float)h[1].x - (float)h[0].x, dy = (float)h[1].y - (float)h[0].y;
     rect[2] = (float)sqrt(dx * dx + dy * dy);
     rect[3] = 0;
     rect[4] = (float)atan2(dy, dx);
@@ -286,6 +373,9 @@ void orc_min_area_rect(const double *xy, int n, float *rect) {
   rect[4] = (float)(rect[4] * 180 / ORC_PI);
   free(p); free(h);
 }
+
+void orc_min_area_rect(const double *xy, int n, float *rect) { orc_min_area_rect_mode(xy, n, rect, 0); }
+void orc_min_area_rect_exhaustive(const double *xy, int n, float *rect) { orc_min_area_rect_mode(xy, n, rect, 1); }
 
 /* ------------------------------------------------------------------ connected components
  * [OpenCV] connectedComponentsWithStats(img8u, labels32S, stats, centroids, 4): two-pass

@@ -140,10 +140,12 @@ def tesseract_bbox(rect):
     return [float(v) for v in out]
 
 
-def min_area_rect(points) -> np.ndarray:
+def min_area_rect(points, exhaustive: bool = False) -> np.ndarray:
+    """exhaustive=True: double-precision search over all hull edges (independent cross-check)."""
     pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 2)
     out = np.zeros(5, np.float32)
-    lib().orc_min_area_rect(_p(pts, C.c_double), C.c_int(len(pts)), _p(out, C.c_float))
+    fn = lib().orc_min_area_rect_exhaustive if exhaustive else lib().orc_min_area_rect
+    fn(_p(pts, C.c_double), C.c_int(len(pts)), _p(out, C.c_float))
     return out
 
 

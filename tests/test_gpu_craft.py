@@ -1,0 +1,56 @@
+"""-m gpu: BASELINE.json config 3 (first half) — CRAFT heat map, engine vs CPU fp32 oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engines_random(weights_random):
+    from tests.conftest import _engine
+    return _engine(weights_random["dir"], "f32"), _engine(weights_random["dir"], "bf16")
+
+
+def test_craft_small_vs_golden(engines_random):
+    e32, _ = engines_random
+    canvas = np.random.default_rng(1).integers(0, 256, (64, 96, 3), dtype=np.uint8)
+    heat = e32.craft_heatmap(canvas)
+    g = np.load(os.path.join(GOLDEN, "g6_craft.npz"))["heat"]
+    assert heat.shape == g.shape == (32, 48, 2)
+    assert np.abs(heat - g).max() < 1e-3, np.abs(heat - g).max()
+
+
+@pytest.mark.parametrize("hw", [(256, 192), (96, 160)])
+def test_craft_f32_vs_oracle_random_weights(engines_random, weights_random, hw):
+    """Fully random weights: every one of the 27 convs, the pools, the upsamples and the concats
+    contributes to the output, so a wrong layer cannot hide."""
+    from oracle import pipeline
+    e32, ebf = engines_random
+    craft, _ = pipeline.load_models(weights_random["craft"], weights_random["parseq"])
+    canvas = np.random.default_rng(hw[0]).integers(0, 256, (*hw, 3), dtype=np.uint8)
+    ref = pipeline.craft_heatmap(craft, canvas)
+    got = e32.craft_heatmap(canvas)
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() < 1e-3 * max(1.0, scale), (np.abs(got - ref).max(), scale)
+    gb = ebf.craft_heatmap(canvas)
+    rel = np.abs(gb - ref).max() / scale
+    print(f"bf16 CRAFT heat map {hw}: max|d|/max|ref| = {rel:.4f}")
+    assert rel < 0.08
+
+
+def test_craft_full_page_f32_and_bf16(eng_f32, eng_bf16, oracle_models, funsd):
+    """1024x768 canvas of the FUNSD page, structured weights: heat map within 1e-3 (f32); bf16 reported."""
+    from oracle import pipeline, post
+    canvas, _ = post.resize_aspect_ratio(np.ascontiguousarray(funsd[:, :, ::-1]))
+    assert canvas.shape == (1024, 768, 3)
+    ref = pipeline.craft_heatmap(oracle_models[0], canvas)
+    got = eng_f32.craft_heatmap(canvas)
+    assert got.shape == (512, 384, 2)
+    assert np.abs(got - ref).max() < 1e-3, np.abs(got - ref).max()
+    gb = eng_bf16.craft_heatmap(canvas)
+    print(f"bf16 CRAFT full page: max|d| = {np.abs(gb - ref).max():.4f}")
+    assert np.abs(gb - ref).max() < 0.06

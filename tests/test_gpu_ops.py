@@ -1,0 +1,73 @@
+"""-m gpu: op-level parity of the implicit-GEMM kernel (through the C ABI) against fp32 torch."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_conv(x0, w, b, ks, dil, act, x1=None, relu0=False, relu1=False):
+    xs = [torch.from_numpy(x0).permute(0, 3, 1, 2)]
+    if relu0:
+        xs[0] = xs[0].relu()
+    if x1 is not None:
+        t = torch.from_numpy(x1).permute(0, 3, 1, 2)
+        xs.append(t.relu() if relu1 else t)
+    x = torch.cat(xs, 1)
+    wt = torch.from_numpy(w).permute(0, 3, 1, 2).contiguous()  # [Cout,kh,kw,Cin] -> OIHW
+    y = F.conv2d(x, wt, torch.from_numpy(b) if b is not None else None, padding=dil * (ks // 2), dilation=dil)
+    if act == 1:
+        y = y.relu()
+    elif act == 2:
+        y = F.gelu(y)
+    return y.permute(0, 2, 3, 1).contiguous().numpy()
+
+
+CASES = [
+    # B, H, W, C0, C1, Cout, ks, dil, act, relu0
+    (1, 8, 16, 32, 0, 64, 3, 1, 1, False),
+    (2, 12, 20, 64, 0, 128, 3, 1, 0, True),     # ragged M (480), batch, relu-on-load
+    (1, 16, 16, 64, 0, 96, 3, 6, 0, False),     # dilation 6 (slice5.1), Cout not a tile multiple
+    (1, 10, 12, 64, 32, 64, 1, 1, 1, False),    # virtual concat 1x1 (up-blocks)
+    (1, 1, 300, 96, 0, 384, 1, 1, 0, False),    # linear: patch embed shape
+    (1, 1, 70, 384, 0, 95, 1, 1, 2, False),     # skinny GEMM + GELU, Cout 95
+    (1, 24, 24, 32, 0, 2, 1, 1, 0, False),      # head: Cout 2
+    (1, 24, 24, 32, 0, 32, 3, 1, 1, False),     # head 3x3 narrow
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_f32_exact(eng_f32, case):
+    B, H, W, C0, C1, Cout, ks, dil, act, relu0 = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x0 = rng.standard_normal((B, H, W, C0)).astype(np.float32)
+    x1 = rng.standard_normal((B, H, W, C1)).astype(np.float32) if C1 else None
+    w = (rng.standard_normal((Cout, ks, ks, C0 + C1)) / np.sqrt(ks * ks * (C0 + C1))).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    got = eng_f32.dbg_conv(x0, w, b, ks, dil, act, x1=x1, relu0=relu0)
+    ref = _ref_conv(x0, w, b, ks, dil, act, x1, relu0)
+    assert np.abs(got - ref).max() < 2e-5
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_bf16(eng_bf16, case):
+    B, H, W, C0, C1, Cout, ks, dil, act, relu0 = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    bf = lambda a: torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy()
+    x0 = bf(rng.standard_normal((B, H, W, C0)).astype(np.float32))
+    x1 = bf(rng.standard_normal((B, H, W, C1)).astype(np.float32)) if C1 else None
+    w = bf((rng.standard_normal((Cout, ks, ks, C0 + C1)) / np.sqrt(ks * ks * (C0 + C1))).astype(np.float32))
+    b = rng.standard_normal(Cout).astype(np.float32)
+    got = eng_bf16.dbg_conv(x0, w, b, ks, dil, act, x1=x1, relu0=relu0)
+    ref = _ref_conv(x0, w, b, ks, dil, act, x1, relu0)   # inputs are exactly representable in bf16: only accumulation order differs
+    assert np.abs(got - ref).max() < 2e-4
+
+
+def test_conv_identity_asymmetric(eng_f32):
+    """A = I check with an asymmetric B (catches a transposed C write)."""
+    K = 64
+    x = np.eye(K, dtype=np.float32).reshape(1, 1, K, K)
+    w = np.arange(K * K, dtype=np.float32).reshape(K, 1, 1, K) / 100.0
+    got = eng_f32.dbg_conv(x, w, None, 1)
+    assert np.array_equal(got[0, 0], w.reshape(K, K).T)

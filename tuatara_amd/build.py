@@ -1,0 +1,84 @@
+"""In-tree build of the native engine for gfx950.
+
+  tuatara_amd/lib/libtuatara_hip.so   HIP kernels + C++ host engine + C ABI (include/tuatara_hip.h)
+  build/bindings/pytuatara*.so        pybind11 module (same place the reference puts it,
+                                      /root/reference/bindings/run_ocr.py:6)
+
+hipcc cross-compiles without a GPU.  Objects are cached under build/obj and only rebuilt
+when a source or header is newer.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+import sysconfig
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "tuatara_amd", "csrc")
+LIBDIR = os.path.join(ROOT, "tuatara_amd", "lib")
+OBJDIR = os.path.join(ROOT, "build", "obj")
+BINDDIR = os.path.join(ROOT, "build", "bindings")
+LIB = os.path.join(LIBDIR, "libtuatara_hip.so")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+SOURCES = ["igemm.hip", "craft_ops.hip", "parseq_ops.hip", "post_ops.hip", "engine.cpp", "geometry.cpp", "tuatara.cpp"]
+COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
+    return hs
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src: str) -> str:
+    obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
+    path = os.path.join(CSRC, src)
+    if _stale(obj, [path] + _headers()):
+        cmd = [HIPCC] + COMMON + (["-x", "hip"] if src.endswith(".cpp") and src == "engine.cpp" else []) + ["-c", path, "-o", obj]
+        subprocess.check_call(cmd)
+    return obj
+
+
+def build_lib(verbose: bool = False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(_compile, SOURCES))
+    if _stale(LIB, objs):
+        subprocess.check_call([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs)
+    return LIB
+
+
+def build_pytuatara() -> str:
+    import pybind11
+
+    os.makedirs(BINDDIR, exist_ok=True)
+    ext = sysconfig.get_config_var("EXT_SUFFIX")
+    out = os.path.join(BINDDIR, "pytuatara" + ext)
+    src = os.path.join(ROOT, "bindings", "python.cpp")
+    if _stale(out, [src, LIB] + _headers()):
+        cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", pybind11.get_include(), "-I", sysconfig.get_paths()["include"],
+               src, "-o", out, "-L", LIBDIR, "-ltuatara_hip", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,$ORIGIN/../../tuatara_amd/lib"]
+        subprocess.check_call(cmd)
+    return out
+
+
+def build_all() -> None:
+    build_lib()
+    build_pytuatara()
+
+
+if __name__ == "__main__":
+    build_all()
+    print(LIB)

@@ -1,0 +1,46 @@
+// Shared device/host definitions for the tuatara MI355X (gfx950) engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ttr {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+enum Precision { kBF16 = 0, kF32 = 1 };
+enum Act { kActNone = 0, kActRelu = 1, kActGelu = 2 };
+
+// Implicit-GEMM convolution / linear layer.  Activations are NHWC, weights are
+// [Cout][taps][Cin] (K contiguous), so both MFMA operands are read K-major.
+struct ConvParams {
+  const void* in0; int C0;   // source 0 (T, NHWC) and its channel count
+  const void* in1; int C1;   // optional source 1: virtual channel concat [in0 | in1]
+  int relu0, relu1;          // apply ReLU while loading that source
+  int B, H, W;               // spatial size (stride 1, "same" padding)
+  int ks, dil;               // kernel size 1 or 3; dilation
+  const void* wgt;           // T [Cout][ks*ks*(C0+C1)]
+  const float* bias;         // f32 [Cout] or null
+  void* out; int out_ld;     // T output, row stride in elements (may be null)
+  float* out_f32; int out_f32_ld;  // optional f32 output
+  const float* resid; int resid_ld; int resid_mod;  // f32 residual added before act; row = m % resid_mod if resid_mod
+  int Cout, M, act;
+};
+
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+
+}  // namespace ttr
+
+#define TTR_HIP_CHECK(expr)                                                                       \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) ttr::hip_fail(#expr, _e, __FILE__, __LINE__);                           \
+  } while (0)
+
+namespace ttr {
+void hip_fail(const char* what, hipError_t e, const char* file, int line);  // throws std::runtime_error
+}

@@ -1,0 +1,184 @@
+// CRAFT-side data-movement kernels (HBM-bound, 16-byte vectorised NHWC):
+// page resize/pad/channel-swap (tuatara.cpp:349, :206-234), first-layer im2col with
+// the /255 normalisation (:363-370), max-pools, bilinear x2 upsample and the heat-map
+// channel extraction (:393-394).  The convolutions themselves are igemm.hip.
+#include "common.h"
+#include "kernels.h"
+#include "resize_dev.h"
+
+namespace ttr {
+
+// ------------------------------------------------------------------ resize + pad + swap
+__global__ void resize_pad_u8_kernel(const uint8_t* src, int sstride, ResizeGeom g, uint8_t* dst, int H, int W, int swap_rb) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  uint8_t px[3] = {0, 0, 0};
+  if (y < g.dh && x < g.dw) resize_pixel_u8c3(src, sstride, g, y, x, px);
+  uint8_t* d = dst + ((size_t)y * W + x) * 3;
+  d[0] = swap_rb ? px[2] : px[0]; d[1] = px[1]; d[2] = swap_rb ? px[0] : px[2];
+}
+
+void launch_resize_pad_u8(const uint8_t* src, int sh, int sw, int sstride, uint8_t* dst, int th, int tw, int H, int W, int swap_rb, hipStream_t s) {
+  ResizeGeom g = make_resize_geom(sh, sw, th, tw);
+  hipLaunchKernelGGL(resize_pad_u8_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, src, sstride, g, dst, H, W, swap_rb);
+}
+
+// ------------------------------------------------------------------ first layer im2col
+// k = (ky*3+kx)*3 + c for k < 27, zero for k in [27,32); value = u8 / 255 (fp32 division as torch does)
+template <typename T>
+__global__ void im2col_l1_kernel(const uint8_t* __restrict__ canvas, T* __restrict__ out, int B, int H, int W) {
+  int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t M = (int64_t)B * H * W;
+  if (m >= M) return;
+  int r = (int)(m % ((int64_t)H * W));
+  int y = r / W, x = r % W;
+  T vals[32];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      int yy = y + ky - 1, xx = x + kx - 1;
+      bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const uint8_t* p = canvas + (m + (int64_t)(ky - 1) * W + (kx - 1)) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) vals[(ky * 3 + kx) * 3 + c] = ok ? (T)((float)p[c] / 255.0f) : (T)0.f;
+    }
+#pragma unroll
+  for (int k = 27; k < 32; ++k) vals[k] = (T)0.f;
+  uint4* o = reinterpret_cast<uint4*>(out + m * 32);
+  const uint4* v = reinterpret_cast<const uint4*>(vals);
+#pragma unroll
+  for (int i = 0; i < (int)(32 * sizeof(T) / 16); ++i) o[i] = v[i];
+}
+
+void launch_im2col_l1(Precision prec, const uint8_t* canvas, void* out, int B, int H, int W, hipStream_t s) {
+  int64_t M = (int64_t)B * H * W;
+  dim3 grid((unsigned)((M + 255) / 256));
+  if (prec == kBF16) hipLaunchKernelGGL(im2col_l1_kernel<bf16>, grid, dim3(256), 0, s, canvas, (bf16*)out, B, H, W);
+  else hipLaunchKernelGGL(im2col_l1_kernel<float>, grid, dim3(256), 0, s, canvas, (float*)out, B, H, W);
+}
+
+// ------------------------------------------------------------------ pools / upsample (one 16-byte chunk per thread)
+template <typename T> struct Chunk {
+  static constexpr int N = 16 / sizeof(T);
+  T v[N];
+};
+template <typename T> __device__ __forceinline__ Chunk<T> ld_chunk(const T* p) { Chunk<T> c; *reinterpret_cast<uint4*>(c.v) = *reinterpret_cast<const uint4*>(p); return c; }
+template <typename T> __device__ __forceinline__ void st_chunk(T* p, const Chunk<T>& c) { *reinterpret_cast<uint4*>(p) = *reinterpret_cast<const uint4*>(c.v); }
+
+template <typename T>
+__global__ void maxpool2x2_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C, int relu) {
+  constexpr int N = Chunk<T>::N;
+  const int Ho = H / 2, Wo = W / 2, Cc = C / N;
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)B * Ho * Wo * Cc;
+  if (idx >= total) return;
+  int cc = (int)(idx % Cc); int64_t t = idx / Cc;
+  int xo = (int)(t % Wo); t /= Wo;
+  int yo = (int)(t % Ho); int b = (int)(t / Ho);
+  const T* p = in + (((int64_t)b * H + 2 * yo) * W + 2 * xo) * C + cc * N;
+  Chunk<T> a = ld_chunk(p), b1 = ld_chunk(p + C), c = ld_chunk(p + (int64_t)W * C), d = ld_chunk(p + (int64_t)W * C + C), o;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    float m = fmaxf(fmaxf((float)a.v[i], (float)b1.v[i]), fmaxf((float)c.v[i], (float)d.v[i]));
+    if (relu) m = fmaxf(m, 0.f);
+    o.v[i] = (T)m;
+  }
+  st_chunk(out + (((int64_t)b * Ho + yo) * Wo + xo) * C + cc * N, o);
+}
+
+template <typename T>
+__global__ void maxpool3x3s1_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C) {
+  constexpr int N = Chunk<T>::N;
+  const int Cc = C / N;
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)B * H * W * Cc;
+  if (idx >= total) return;
+  int cc = (int)(idx % Cc); int64_t t = idx / Cc;
+  int x = (int)(t % W); t /= W;
+  int y = (int)(t % H); int b = (int)(t / H);
+  float m[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) m[i] = -INFINITY;
+  for (int dy = -1; dy <= 1; ++dy)
+    for (int dx = -1; dx <= 1; ++dx) {
+      int yy = y + dy, xx = x + dx;
+      if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+      Chunk<T> v = ld_chunk(in + (((int64_t)b * H + yy) * W + xx) * C + cc * N);
+#pragma unroll
+      for (int i = 0; i < N; ++i) m[i] = fmaxf(m[i], (float)v.v[i]);
+    }
+  Chunk<T> o;
+#pragma unroll
+  for (int i = 0; i < N; ++i) o.v[i] = (T)m[i];
+  st_chunk(out + (((int64_t)b * H + y) * W + x) * C + cc * N, o);
+}
+
+// F.interpolate(mode='bilinear', align_corners=False) for an exact x2: src = 0.5*(dst+0.5)-0.5 clamped at 0
+template <typename T>
+__global__ void upsample2x_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C) {
+  constexpr int N = Chunk<T>::N;
+  const int Ho = 2 * H, Wo = 2 * W, Cc = C / N;
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)B * Ho * Wo * Cc;
+  if (idx >= total) return;
+  int cc = (int)(idx % Cc); int64_t t = idx / Cc;
+  int xo = (int)(t % Wo); t /= Wo;
+  int yo = (int)(t % Ho); int b = (int)(t / Ho);
+  float sy = fmaxf(0.5f * ((float)yo + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * ((float)xo + 0.5f) - 0.5f, 0.f);
+  int y0 = (int)sy, x0 = (int)sx;
+  int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+  float ly1 = sy - (float)y0, ly0 = 1.f - ly1, lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+  const T* base = in + (int64_t)b * H * W * C + cc * N;
+  Chunk<T> v00 = ld_chunk(base + ((int64_t)y0 * W + x0) * C), v01 = ld_chunk(base + ((int64_t)y0 * W + x1) * C);
+  Chunk<T> v10 = ld_chunk(base + ((int64_t)y1 * W + x0) * C), v11 = ld_chunk(base + ((int64_t)y1 * W + x1) * C), o;
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    o.v[i] = (T)(ly0 * (lx0 * (float)v00.v[i] + lx1 * (float)v01.v[i]) + ly1 * (lx0 * (float)v10.v[i] + lx1 * (float)v11.v[i]));
+  st_chunk(out + (((int64_t)b * Ho + yo) * Wo + xo) * C + cc * N, o);
+}
+
+template <typename T>
+__global__ void extract_heat_kernel(const T* __restrict__ in, int ld, float* __restrict__ out, int M) {
+  int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  out[2 * m] = (float)in[(int64_t)m * ld];
+  out[2 * m + 1] = (float)in[(int64_t)m * ld + 1];
+}
+
+#define TTR_DISPATCH(prec, kern, grid, block, s, ...)                                            \
+  do {                                                                                           \
+    if ((prec) == kBF16) hipLaunchKernelGGL(kern<bf16>, grid, block, 0, s, __VA_ARGS__);         \
+    else hipLaunchKernelGGL(kern<float>, grid, block, 0, s, __VA_ARGS__);                        \
+  } while (0)
+
+static inline int chunk_elems(Precision p) { return p == kBF16 ? 8 : 4; }
+
+void launch_maxpool2x2(Precision prec, const void* in, void* out, int B, int H, int W, int C, int relu, hipStream_t s) {
+  if (C % chunk_elems(prec) || (H | W) & 1) throw std::runtime_error("maxpool2x2: bad shape");
+  int64_t total = (int64_t)B * (H / 2) * (W / 2) * (C / chunk_elems(prec));
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (prec == kBF16) hipLaunchKernelGGL(maxpool2x2_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)in, (bf16*)out, B, H, W, C, relu);
+  else hipLaunchKernelGGL(maxpool2x2_kernel<float>, grid, dim3(256), 0, s, (const float*)in, (float*)out, B, H, W, C, relu);
+}
+void launch_maxpool3x3s1(Precision prec, const void* in, void* out, int B, int H, int W, int C, hipStream_t s) {
+  if (C % chunk_elems(prec)) throw std::runtime_error("maxpool3x3: bad shape");
+  int64_t total = (int64_t)B * H * W * (C / chunk_elems(prec));
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (prec == kBF16) hipLaunchKernelGGL(maxpool3x3s1_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)in, (bf16*)out, B, H, W, C);
+  else hipLaunchKernelGGL(maxpool3x3s1_kernel<float>, grid, dim3(256), 0, s, (const float*)in, (float*)out, B, H, W, C);
+}
+void launch_upsample2x(Precision prec, const void* in, void* out, int B, int H, int W, int C, hipStream_t s) {
+  if (C % chunk_elems(prec)) throw std::runtime_error("upsample2x: bad shape");
+  int64_t total = (int64_t)B * 4 * H * W * (C / chunk_elems(prec));
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (prec == kBF16) hipLaunchKernelGGL(upsample2x_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)in, (bf16*)out, B, H, W, C);
+  else hipLaunchKernelGGL(upsample2x_kernel<float>, grid, dim3(256), 0, s, (const float*)in, (float*)out, B, H, W, C);
+}
+void launch_extract_heat(Precision prec, const void* in, int ld, float* out, int M, hipStream_t s) {
+  dim3 grid((M + 255) / 256);
+  if (prec == kBF16) hipLaunchKernelGGL(extract_heat_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)in, ld, out, M);
+  else hipLaunchKernelGGL(extract_heat_kernel<float>, grid, dim3(256), 0, s, (const float*)in, ld, out, M);
+}
+
+}  // namespace ttr

@@ -1,0 +1,823 @@
+// Host orchestration + C ABI of the MI355X-native tuatara engine.
+//
+// Re-implements the reference's pipeline function image_to_data (tuatara.cpp:314-512):
+//   resize/pad/swap (:349-358) -> CRAFT (:363-394) -> get_detected_boxes (:400) ->
+//   adjust_result_coordinates (:406) -> crop (:408-418) -> resize 128x32 (:436-448) ->
+//   PARSeq (:450-485) -> argmax + Tokenizer (:486-505) -> format_output (:511)
+// with every tensor op on the GPU (igemm.hip, craft_ops.hip, parseq_ops.hip, post_ops.hip)
+// and only the per-component calipers + string decoding on the host (geometry.cpp).
+// Differences by design: models are loaded once per engine (the reference reloads both
+// per call, :336, :428), crops of all pages of a batch run as one PARSeq batch (the
+// reference chunks by 4 over 6 threads, :452-475; logits are batch-invariant), the AR
+// decoder keeps a K/V cache and runs a fixed 25+1 steps (no data-dependent break).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iterator>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/tuatara_hip.h"
+#include "common.h"
+#include "geometry.h"
+#include "kernels.h"
+
+namespace ttr {
+
+void hip_fail(const char* what, hipError_t e, const char* file, int line) {
+  char buf[512];
+  snprintf(buf, sizeof buf, "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+  throw std::runtime_error(buf);
+}
+
+static thread_local std::string g_last_error;
+
+// ------------------------------------------------------------------ small utilities
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  void ensure(size_t bytes) {
+    if (bytes <= cap) return;
+    if (p) TTR_HIP_CHECK(hipFree(p));
+    p = nullptr; cap = 0;
+    size_t want = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+    TTR_HIP_CHECK(hipMalloc(&p, want));
+    cap = want;
+  }
+  template <typename U> U* as() const { return reinterpret_cast<U*>(p); }
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+};
+
+static inline uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u; memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+struct HostTensor { std::vector<uint32_t> dims; std::vector<float> data; };
+
+struct WeightFile {
+  std::map<std::string, HostTensor> t;
+  explicit WeightFile(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open weight file " + path);
+    std::vector<char> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    if (buf.size() < 12 || memcmp(buf.data(), "TTRW0001", 8) != 0) throw std::runtime_error("not a .ttrw file: " + path);
+    size_t p = 8;
+    auto rd = [&](void* dst, size_t n) { if (p + n > buf.size()) throw std::runtime_error("truncated .ttrw: " + path); memcpy(dst, buf.data() + p, n); p += n; };
+    uint32_t n; rd(&n, 4);
+    struct Ent { std::string name; std::vector<uint32_t> dims; uint64_t off, nb; };
+    std::vector<Ent> ents(n);
+    for (auto& e : ents) {
+      uint16_t ln; rd(&ln, 2);
+      e.name.resize(ln); rd(&e.name[0], ln);
+      uint8_t dt, nd; rd(&dt, 1); rd(&nd, 1);
+      if (dt != 0) throw std::runtime_error("unsupported dtype in " + path);
+      e.dims.resize(nd); rd(e.dims.data(), 4 * nd);
+      rd(&e.off, 8); rd(&e.nb, 8);
+    }
+    uint64_t data0; rd(&data0, 8);
+    for (auto& e : ents) {
+      if (data0 + e.off + e.nb > buf.size()) throw std::runtime_error("tensor out of range in " + path);
+      HostTensor ht; ht.dims = e.dims; ht.data.resize(e.nb / 4);
+      memcpy(ht.data.data(), buf.data() + data0 + e.off, e.nb);
+      t[e.name] = std::move(ht);
+    }
+  }
+  const HostTensor& get(const std::string& name, size_t numel) const {
+    auto it = t.find(name);
+    if (it == t.end()) throw std::runtime_error("weight tensor missing: " + name);
+    if (it->second.data.size() != numel) throw std::runtime_error("weight tensor has wrong size: " + name);
+    return it->second;
+  }
+};
+
+// A GEMM-shaped weight on the device: T [Cout_pad][K_pad] + f32 bias
+struct Linear {
+  DevBuf w, b;
+  int cout = 0, k = 0;  // padded sizes as the kernel sees them
+};
+
+// ------------------------------------------------------------------ the engine
+struct CraftConv { const char* name; int cin, cout, ks, dil; };
+
+struct Result {
+  std::vector<std::string> text;
+  std::vector<float> bbox;   // 4 per item
+  std::vector<int32_t> ids;  // 26 per item
+};
+
+struct PageCcl {
+  DevBuf tnorm, flags, parent, mm, area, bbox, maxt, cand_slot, cand, counters, rows;
+  CclBuffers view(int max_cand) {
+    CclBuffers b;
+    b.tnorm = tnorm.as<float>(); b.flags = flags.as<uint8_t>(); b.parent = parent.as<int>(); b.mm = mm.as<unsigned>();
+    b.area = area.as<int>(); b.bbox = bbox.as<int>(); b.maxt = maxt.as<unsigned>(); b.cand_slot = cand_slot.as<int>();
+    b.cand = cand.as<int>(); b.counters = counters.as<int>(); b.rowmin = nullptr; b.rowmax = nullptr;
+    b.rows_packed = rows.as<int>(); b.max_cand = max_cand;
+    return b;
+  }
+  void ensure(int npx, int max_cand) {
+    tnorm.ensure((size_t)npx * 4); flags.ensure(npx); parent.ensure((size_t)npx * 4); mm.ensure(64);
+    area.ensure((size_t)npx * 4); bbox.ensure((size_t)npx * 16); maxt.ensure((size_t)npx * 4); cand_slot.ensure((size_t)npx * 4);
+    cand.ensure((size_t)max_cand * 32); counters.ensure(64); rows.ensure((size_t)npx * 8);
+  }
+};
+
+struct Engine {
+  ttr_config cfg;
+  Precision prec;
+  size_t es;  // element size of T
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  Tokenizer tok;
+
+  // CRAFT
+  std::map<std::string, Linear> craft;
+  // PARSeq
+  std::map<std::string, Linear> pq;               // linears by upstream name
+  std::map<std::string, DevBuf> pqf;              // f32 vectors (LayerNorm params, pos embed, ...)
+  DevBuf qself;                                   // f32 [26][384]
+
+  // workspaces
+  std::vector<std::unique_ptr<DevBuf>> craft_ws;  // per-layer activations
+  DevBuf pq_ws[16];
+  DevBuf canvas, heat, staging_img, crops, rects_dev, logits, ar_logits, ids_dev, tokens;
+  std::vector<std::unique_ptr<PageCcl>> ccl;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  float stage_ms[4] = {0, 0, 0, 0};
+
+  // ---- construction
+  void upload_linear(Linear& L, const float* w, int cout, int k, const float* bias, int cout_pad, int k_pad,
+                     const std::vector<int>* kmap = nullptr) {
+    // kmap: for each padded k index the source k index or -1
+    std::vector<float> wp((size_t)cout_pad * k_pad, 0.f);
+    for (int o = 0; o < cout; ++o)
+      for (int kk = 0; kk < k_pad; ++kk) {
+        int src = kmap ? (*kmap)[kk] : (kk < k ? kk : -1);
+        if (src >= 0) wp[(size_t)o * k_pad + kk] = w[(size_t)o * k + src];
+      }
+    L.cout = cout_pad; L.k = k_pad;
+    L.w.ensure(wp.size() * es);
+    if (prec == kBF16) {
+      std::vector<uint16_t> h(wp.size());
+      for (size_t i = 0; i < wp.size(); ++i) h[i] = f32_to_bf16_rne(wp[i]);
+      TTR_HIP_CHECK(hipMemcpy(L.w.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    } else {
+      TTR_HIP_CHECK(hipMemcpy(L.w.p, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
+    }
+    std::vector<float> bp(cout_pad, 0.f);
+    if (bias) memcpy(bp.data(), bias, sizeof(float) * cout);
+    L.b.ensure(bp.size() * 4);
+    TTR_HIP_CHECK(hipMemcpy(L.b.p, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+  }
+  void upload_f32(DevBuf& d, const float* p, size_t n) {
+    d.ensure(n * 4);
+    TTR_HIP_CHECK(hipMemcpy(d.p, p, n * 4, hipMemcpyHostToDevice));
+  }
+
+  static const std::vector<CraftConv>& craft_convs() {
+    static const std::vector<CraftConv> v = {
+        {"slice1.0", 3, 64, 3, 1},     {"slice1.3", 64, 64, 3, 1},    {"slice1.7", 64, 128, 3, 1},   {"slice1.10", 128, 128, 3, 1},
+        {"slice2.14", 128, 256, 3, 1}, {"slice2.17", 256, 256, 3, 1}, {"slice3.20", 256, 256, 3, 1}, {"slice3.24", 256, 512, 3, 1},
+        {"slice3.27", 512, 512, 3, 1}, {"slice4.30", 512, 512, 3, 1}, {"slice4.34", 512, 512, 3, 1}, {"slice4.37", 512, 512, 3, 1},
+        {"slice5.1", 512, 1024, 3, 6}, {"slice5.2", 1024, 1024, 1, 1},
+        {"upconv1.0", 1536, 512, 1, 1}, {"upconv1.3", 512, 256, 3, 1}, {"upconv2.0", 768, 256, 1, 1}, {"upconv2.3", 256, 128, 3, 1},
+        {"upconv3.0", 384, 128, 1, 1},  {"upconv3.3", 128, 64, 3, 1},  {"upconv4.0", 192, 64, 1, 1},  {"upconv4.3", 64, 32, 3, 1},
+        {"conv_cls.0", 32, 32, 3, 1},   {"conv_cls.2", 32, 32, 3, 1},  {"conv_cls.4", 32, 16, 3, 1},  {"conv_cls.6", 16, 16, 1, 1},
+        {"conv_cls.8", 16, 2, 1, 1}};
+    return v;
+  }
+
+  void load_craft(const std::string& dir) {
+    WeightFile wf(dir + "/craft.ttrw");
+    for (const auto& c : craft_convs()) {
+      const int taps = c.ks * c.ks;
+      const auto& w = wf.get(std::string(c.name) + ".w", (size_t)c.cout * taps * c.cin);
+      const auto& b = wf.get(std::string(c.name) + ".b", (size_t)c.cout);
+      Linear& L = craft[c.name];
+      if (std::string(c.name) == "slice1.0") {
+        upload_linear(L, w.data.data(), c.cout, 27, b.data.data(), c.cout, 32);  // im2col K 27 -> 32
+        continue;
+      }
+      // channel padding to multiples of 32 (only the 16-channel head tensors need it)
+      const int cin_pad = (c.cin + 31) / 32 * 32;
+      int cout_pad = c.cout;
+      if (std::string(c.name) == "conv_cls.4" || std::string(c.name) == "conv_cls.6") cout_pad = 32;  // feeds a padded-Cin layer
+      std::vector<int> kmap((size_t)taps * cin_pad, -1);
+      for (int t = 0; t < taps; ++t)
+        for (int ci = 0; ci < c.cin; ++ci) kmap[(size_t)t * cin_pad + ci] = t * c.cin + ci;
+      upload_linear(L, w.data.data(), c.cout, taps * c.cin, b.data.data(), cout_pad, taps * cin_pad, &kmap);
+    }
+  }
+
+  void load_parseq(const std::string& dir) {
+    WeightFile wf(dir + "/parseq.ttrw");
+    auto lin = [&](const std::string& key, const std::string& wname, const std::string& bname, int cout, int k, int row0 = 0, int rows_total = -1) {
+      if (rows_total < 0) rows_total = cout;
+      const auto& w = wf.get(wname, (size_t)rows_total * k);
+      const auto& b = wf.get(bname, (size_t)rows_total);
+      upload_linear(pq[key], w.data.data() + (size_t)row0 * k, cout, k, b.data.data() + row0, cout, k);
+    };
+    auto vec = [&](const std::string& name, size_t n) { upload_f32(pqf[name], wf.get(name, n).data.data(), n); };
+    const int E = 384;
+    lin("patch", "encoder.patch_embed.proj.weight", "encoder.patch_embed.proj.bias", E, 96);
+    vec("encoder.pos_embed", 128 * E);
+    for (int i = 0; i < 12; ++i) {
+      std::string p = "encoder.blocks." + std::to_string(i) + ".";
+      vec(p + "norm1.weight", E); vec(p + "norm1.bias", E); vec(p + "norm2.weight", E); vec(p + "norm2.bias", E);
+      lin(p + "qkv", p + "attn.qkv.weight", p + "attn.qkv.bias", 3 * E, E);
+      lin(p + "proj", p + "attn.proj.weight", p + "attn.proj.bias", E, E);
+      lin(p + "fc1", p + "mlp.fc1.weight", p + "mlp.fc1.bias", 4 * E, E);
+      lin(p + "fc2", p + "mlp.fc2.weight", p + "mlp.fc2.bias", E, 4 * E);
+    }
+    vec("encoder.norm.weight", E); vec("encoder.norm.bias", E);
+    const std::string d = "decoder.layers.0.";
+    lin("self_kv", d + "self_attn.in_proj_weight", d + "self_attn.in_proj_bias", 2 * E, E, E, 3 * E);
+    lin("self_out", d + "self_attn.out_proj.weight", d + "self_attn.out_proj.bias", E, E);
+    lin("cross_q", d + "cross_attn.in_proj_weight", d + "cross_attn.in_proj_bias", E, E, 0, 3 * E);
+    lin("cross_kv", d + "cross_attn.in_proj_weight", d + "cross_attn.in_proj_bias", 2 * E, E, E, 3 * E);
+    lin("cross_out", d + "cross_attn.out_proj.weight", d + "cross_attn.out_proj.bias", E, E);
+    lin("ffn1", d + "linear1.weight", d + "linear1.bias", 4 * E, E);
+    lin("ffn2", d + "linear2.weight", d + "linear2.bias", E, 4 * E);
+    for (const char* n : {"norm1", "norm2", "norm_q", "norm_c"}) { vec(d + n + ".weight", E); vec(d + n + ".bias", E); }
+    vec("decoder.norm.weight", E); vec("decoder.norm.bias", E);
+    lin("head", "head.weight", "head.bias", 95, E);
+    vec("text_embed.embedding.weight", 97 * E);
+    vec("pos_queries", 26 * E);
+    // Qself[i] = Wq . norm_q(pos_queries[i]) + bq : crop independent, computed once on the host in fp32
+    {
+      const auto& pos = wf.get("pos_queries", 26 * E).data;
+      const auto& g = wf.get(d + "norm_q.weight", E).data;
+      const auto& bt = wf.get(d + "norm_q.bias", E).data;
+      const auto& w = wf.get(d + "self_attn.in_proj_weight", (size_t)3 * E * E).data;
+      const auto& b = wf.get(d + "self_attn.in_proj_bias", 3 * E).data;
+      std::vector<float> q((size_t)26 * E), ln(E);
+      for (int i = 0; i < 26; ++i) {
+        float mean = 0.f;
+        for (int c = 0; c < E; ++c) mean += pos[i * E + c];
+        mean /= E;
+        float var = 0.f;
+        for (int c = 0; c < E; ++c) { float dd = pos[i * E + c] - mean; var += dd * dd; }
+        var /= E;
+        float rstd = 1.0f / std::sqrt(var + 1e-5f);
+        for (int c = 0; c < E; ++c) ln[c] = (pos[i * E + c] - mean) * rstd * g[c] + bt[c];
+        for (int o = 0; o < E; ++o) {
+          float acc = 0.f;
+          for (int c = 0; c < E; ++c) acc += w[(size_t)o * E + c] * ln[c];
+          q[(size_t)i * E + o] = acc + b[o];
+        }
+      }
+      upload_f32(qself, q.data(), q.size());
+    }
+  }
+
+  Engine(const std::string& dir, const ttr_config& c) : cfg(c) {
+    prec = cfg.precision == TTR_PREC_F32 ? kF32 : kBF16;
+    es = prec == kBF16 ? 2 : 4;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) throw std::runtime_error("no HIP device available: the tuatara engine has no CPU fallback");
+    TTR_HIP_CHECK(hipSetDevice(cfg.device));
+    TTR_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    for (auto& x : ev) TTR_HIP_CHECK(hipEventCreate(&x));
+    load_craft(dir);
+    load_parseq(dir);
+  }
+  ~Engine() {
+    for (auto& x : ev) if (x) (void)hipEventDestroy(x);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+
+  // ---- CRAFT
+  DevBuf& ws(size_t idx, size_t bytes) {
+    while (craft_ws.size() <= idx) craft_ws.emplace_back(new DevBuf());
+    craft_ws[idx]->ensure(bytes);
+    return *craft_ws[idx];
+  }
+
+  void conv(const char* name, const void* in0, int C0, const void* in1, int C1, int relu0, int B, int H, int W, void* out, int act,
+            float* out_f32 = nullptr) {
+    const Linear& L = craft.at(name);
+    ConvParams p{};
+    p.in0 = in0; p.C0 = C0; p.in1 = in1; p.C1 = C1; p.relu0 = relu0; p.relu1 = 0;
+    p.B = B; p.H = H; p.W = W;
+    const int Ct = C0 + C1;
+    p.ks = (L.k == Ct) ? 1 : 3;
+    if (L.k != p.ks * p.ks * Ct) throw std::runtime_error(std::string("conv shape mismatch at ") + name);
+    p.dil = std::string(name) == "slice5.1" ? 6 : 1;
+    p.wgt = L.w.p; p.bias = L.b.as<float>();
+    p.out = out; p.out_ld = L.cout; p.out_f32 = out_f32; p.out_f32_ld = L.cout;
+    p.Cout = L.cout; p.M = B * H * W; p.act = act;
+    launch_igemm(prec, p, stream);
+  }
+
+  // canvas u8 [B][H][W][3] (device) -> heat f32 [B][H/2][W/2][2] (device)
+  void craft_forward(const uint8_t* d_canvas, int B, int H, int W, float* d_heat) {
+    if (H % 32 || W % 32) throw std::runtime_error("CRAFT canvas must be a multiple of 32");
+    const size_t M0 = (size_t)B * H * W, M1 = M0 / 4, M2 = M1 / 4, M3 = M2 / 4, M4 = M3 / 4;
+    const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8, H4 = H / 16, W4 = W / 16;
+    size_t k = 0;
+    auto buf = [&](size_t rows, int C) -> void* { return ws(k++, rows * C * es).p; };
+    void* a0 = buf(M0, 32);
+    launch_im2col_l1(prec, d_canvas, a0, B, H, W, stream);
+    void* c11 = buf(M0, 64);  conv("slice1.0", a0, 32, nullptr, 0, 0, 1, 1, (int)M0, c11, kActRelu);
+    void* c12 = buf(M0, 64);  conv("slice1.3", c11, 64, nullptr, 0, 0, B, H, W, c12, kActRelu);
+    void* p1 = buf(M1, 64);   launch_maxpool2x2(prec, c12, p1, B, H, W, 64, 0, stream);
+    void* c21 = buf(M1, 128); conv("slice1.7", p1, 64, nullptr, 0, 0, B, H1, W1, c21, kActRelu);
+    void* c22 = buf(M1, 128); conv("slice1.10", c21, 128, nullptr, 0, 0, B, H1, W1, c22, kActNone);   // relu2_2 skip (pre-ReLU)
+    void* p2 = buf(M2, 128);  launch_maxpool2x2(prec, c22, p2, B, H1, W1, 128, 1, stream);
+    void* c31 = buf(M2, 256); conv("slice2.14", p2, 128, nullptr, 0, 0, B, H2, W2, c31, kActRelu);
+    void* c32 = buf(M2, 256); conv("slice2.17", c31, 256, nullptr, 0, 0, B, H2, W2, c32, kActNone);   // relu3_2 skip
+    void* c33 = buf(M2, 256); conv("slice3.20", c32, 256, nullptr, 0, 1, B, H2, W2, c33, kActRelu);
+    void* p3 = buf(M3, 256);  launch_maxpool2x2(prec, c33, p3, B, H2, W2, 256, 0, stream);
+    void* c41 = buf(M3, 512); conv("slice3.24", p3, 256, nullptr, 0, 0, B, H3, W3, c41, kActRelu);
+    void* c42 = buf(M3, 512); conv("slice3.27", c41, 512, nullptr, 0, 0, B, H3, W3, c42, kActNone);   // relu4_3 skip
+    void* c43 = buf(M3, 512); conv("slice4.30", c42, 512, nullptr, 0, 1, B, H3, W3, c43, kActRelu);
+    void* p4 = buf(M4, 512);  launch_maxpool2x2(prec, c43, p4, B, H3, W3, 512, 0, stream);
+    void* c51 = buf(M4, 512); conv("slice4.34", p4, 512, nullptr, 0, 0, B, H4, W4, c51, kActRelu);
+    void* c52 = buf(M4, 512); conv("slice4.37", c51, 512, nullptr, 0, 0, B, H4, W4, c52, kActNone);   // relu5_3 skip
+    void* mp = buf(M4, 512);  launch_maxpool3x3s1(prec, c52, mp, B, H4, W4, 512, stream);
+    void* c6 = buf(M4, 1024); conv("slice5.1", mp, 512, nullptr, 0, 0, B, H4, W4, c6, kActNone);
+    void* fc7 = buf(M4, 1024); conv("slice5.2", c6, 1024, nullptr, 0, 0, B, H4, W4, fc7, kActNone);
+    void* u1a = buf(M4, 512); conv("upconv1.0", fc7, 1024, c52, 512, 0, B, H4, W4, u1a, kActRelu);
+    void* u1b = buf(M4, 256); conv("upconv1.3", u1a, 512, nullptr, 0, 0, B, H4, W4, u1b, kActRelu);
+    void* up1 = buf(M3, 256); launch_upsample2x(prec, u1b, up1, B, H4, W4, 256, stream);
+    void* u2a = buf(M3, 256); conv("upconv2.0", up1, 256, c42, 512, 0, B, H3, W3, u2a, kActRelu);
+    void* u2b = buf(M3, 128); conv("upconv2.3", u2a, 256, nullptr, 0, 0, B, H3, W3, u2b, kActRelu);
+    void* up2 = buf(M2, 128); launch_upsample2x(prec, u2b, up2, B, H3, W3, 128, stream);
+    void* u3a = buf(M2, 128); conv("upconv3.0", up2, 128, c32, 256, 0, B, H2, W2, u3a, kActRelu);
+    void* u3b = buf(M2, 64);  conv("upconv3.3", u3a, 128, nullptr, 0, 0, B, H2, W2, u3b, kActRelu);
+    void* up3 = buf(M1, 64);  launch_upsample2x(prec, u3b, up3, B, H2, W2, 64, stream);
+    void* u4a = buf(M1, 64);  conv("upconv4.0", up3, 64, c22, 128, 0, B, H1, W1, u4a, kActRelu);
+    void* u4b = buf(M1, 32);  conv("upconv4.3", u4a, 64, nullptr, 0, 0, B, H1, W1, u4b, kActRelu);
+    void* h0 = buf(M1, 32);   conv("conv_cls.0", u4b, 32, nullptr, 0, 0, B, H1, W1, h0, kActRelu);
+    void* h2 = buf(M1, 32);   conv("conv_cls.2", h0, 32, nullptr, 0, 0, B, H1, W1, h2, kActRelu);
+    void* h4 = buf(M1, 32);   conv("conv_cls.4", h2, 32, nullptr, 0, 0, B, H1, W1, h4, kActRelu);   // 16 real + 16 zero channels
+    void* h6 = buf(M1, 32);   conv("conv_cls.6", h4, 32, nullptr, 0, 0, B, H1, W1, h6, kActRelu);
+    conv("conv_cls.8", h6, 32, nullptr, 0, 0, B, H1, W1, nullptr, kActNone, d_heat);
+  }
+
+  // ---- PARSeq
+  void gemm(const Linear& L, const void* in, int M, void* out, int out_ld, int act, float* out_f32 = nullptr, int out_f32_ld = 0,
+            const float* resid = nullptr, int resid_ld = 0, int resid_mod = 0) {
+    ConvParams p{};
+    p.in0 = in; p.C0 = L.k; p.B = 1; p.H = 1; p.W = M; p.ks = 1; p.dil = 1;
+    p.wgt = L.w.p; p.bias = L.b.as<float>();
+    p.out = out; p.out_ld = out_ld; p.out_f32 = out_f32; p.out_f32_ld = out_f32_ld;
+    p.resid = resid; p.resid_ld = resid_ld; p.resid_mod = resid_mod;
+    p.Cout = L.cout; p.M = M; p.act = act;
+    launch_igemm(prec, p, stream);
+  }
+  void ln(const float* x, const std::string& name, float eps, void* out, int M) {
+    launch_layernorm(prec, x, 384, pqf.at(name + ".weight").as<float>(), pqf.at(name + ".bias").as<float>(), eps, out, 384, M, 384, stream);
+  }
+
+  // decoder tail shared by the AR steps (R = 1) and the refinement pass (R = 26):
+  // sa T [rows][384] -> logits f32 (row stride logits_ld)
+  void decoder_tail(const void* sa, int N, int R, const float* resid_pos, int resid_mod, float* tgt, void* t384, void* t384b, void* t1536,
+                    const void* kvmem, float* logits_out, int logits_ld) {
+    const int rows = N * R;
+    const std::string d = "decoder.layers.0.";
+    gemm(pq.at("self_out"), sa, rows, nullptr, 0, kActNone, tgt, 384, resid_pos, 384, resid_mod);      // tgt = query + self_attn
+    ln(tgt, d + "norm1", 1e-5f, t384, rows);
+    gemm(pq.at("cross_q"), t384, rows, t384b, 384, kActNone);
+    launch_dec_cross_attn(prec, t384b, kvmem, t384, N, R, stream);
+    gemm(pq.at("cross_out"), t384, rows, nullptr, 0, kActNone, tgt, 384, tgt, 384, 0);                 // tgt += cross_attn
+    ln(tgt, d + "norm2", 1e-5f, t384, rows);
+    gemm(pq.at("ffn1"), t384, rows, t1536, 1536, kActGelu);
+    gemm(pq.at("ffn2"), t1536, rows, nullptr, 0, kActNone, tgt, 384, tgt, 384, 0);                     // tgt += ffn
+    ln(tgt, "decoder.norm", 1e-5f, t384, rows);
+    gemm(pq.at("head"), t384, rows, nullptr, 0, kActNone, logits_out, logits_ld);
+  }
+
+  // crops u8 [N][32][128][3] (device) -> logits f32 [N][26][95], ids i32 [N][26] (device); d_ar optional
+  void parseq_forward(const uint8_t* d_crops, int N, float* d_logits, float* d_ar, int* d_ids) {
+    if (N <= 0) return;
+    const int M = N * 128, E = 384;
+    void* patches = (pq_ws[0].ensure((size_t)M * 96 * es), pq_ws[0].p);
+    float* x = (float*)(pq_ws[1].ensure((size_t)M * E * 4), pq_ws[1].p);
+    void* t384 = (pq_ws[2].ensure((size_t)std::max(M, N * 26) * E * es), pq_ws[2].p);
+    void* tbig = (pq_ws[3].ensure((size_t)M * 1536 * es), pq_ws[3].p);
+    void* att = (pq_ws[4].ensure((size_t)std::max(M, N * 26) * E * es), pq_ws[4].p);
+    launch_patchify(prec, d_crops, patches, N, stream);
+    gemm(pq.at("patch"), patches, M, nullptr, 0, kActNone, x, E, pqf.at("encoder.pos_embed").as<float>(), E, 128);
+    for (int l = 0; l < 12; ++l) {
+      std::string p = "encoder.blocks." + std::to_string(l) + ".";
+      ln(x, p + "norm1", 1e-6f, t384, M);
+      gemm(pq.at(p + "qkv"), t384, M, tbig, 3 * E, kActNone);
+      launch_attn_enc(prec, tbig, att, N, stream);
+      gemm(pq.at(p + "proj"), att, M, nullptr, 0, kActNone, x, E, x, E, 0);
+      ln(x, p + "norm2", 1e-6f, t384, M);
+      gemm(pq.at(p + "fc1"), t384, M, tbig, 4 * E, kActGelu);
+      gemm(pq.at(p + "fc2"), tbig, M, nullptr, 0, kActNone, x, E, x, E, 0);
+    }
+    ln(x, "encoder.norm", 1e-6f, t384, M);                       // memory
+    void* kvmem = (pq_ws[5].ensure((size_t)M * 768 * es), pq_ws[5].p);
+    gemm(pq.at("cross_kv"), t384, M, kvmem, 768, kActNone);
+
+    // ---- decoder
+    void* kvcache = (pq_ws[6].ensure((size_t)N * 26 * 768 * es), pq_ws[6].p);
+    float* tgt = (float*)(pq_ws[7].ensure((size_t)N * 26 * E * 4), pq_ws[7].p);
+    void* d384b = (pq_ws[8].ensure((size_t)N * 26 * E * es), pq_ws[8].p);
+    void* d1536 = (pq_ws[9].ensure((size_t)N * 26 * 1536 * es), pq_ws[9].p);
+    float* step_logits = (float*)(pq_ws[10].ensure((size_t)N * 26 * 95 * 4), pq_ws[10].p);
+    tokens.ensure((size_t)N * 26 * 4);
+    int* tk = tokens.as<int>();
+    launch_fill_i32(tk, 96, N * 26, 1, stream);   // PAD
+    launch_fill_i32(tk, 95, N, 26, stream);       // BOS at position 0
+    const float* emb = pqf.at("text_embed.embedding.weight").as<float>();
+    const float* posq = pqf.at("pos_queries").as<float>();
+    const std::string d = "decoder.layers.0.";
+    const float* gc = pqf.at(d + "norm_c.weight").as<float>();
+    const float* bc = pqf.at(d + "norm_c.bias").as<float>();
+    float* ar = d_ar ? d_ar : step_logits;
+    const int nsteps = d_ar ? 26 : 25;  // the 26th AR step only feeds logits the refinement pass discards
+    for (int i = 0; i < 26; ++i) {
+      launch_dec_embed_ln(prec, tk, emb, posq, gc, bc, 1e-5f, t384, N, i, i + 1, stream);
+      gemm(pq.at("self_kv"), t384, N, (char*)kvcache + (size_t)i * 768 * es, 26 * 768, kActNone);
+      if (i >= nsteps) break;
+      launch_dec_self_attn(prec, qself.as<float>(), kvcache, tk, att, N, 1, i, 0, stream);
+      decoder_tail(att, N, 1, posq + (size_t)i * E, 1, tgt, t384, d384b, d1536, kvmem, ar + (size_t)i * 95, 26 * 95);
+      if (i + 1 < 26) launch_argmax(ar + (size_t)i * 95, 26 * 95, 95, tk, 26, i + 1, N, stream);
+    }
+    // ---- refinement pass (cloze mask + EOS key padding), R = 26 query rows per crop
+    launch_dec_self_attn(prec, qself.as<float>(), kvcache, tk, att, N, 26, 0, 1, stream);
+    decoder_tail(att, N, 26, posq, 26, tgt, t384, d384b, d1536, kvmem, d_logits, 95);
+    launch_argmax(d_logits, 95, 95, d_ids, 1, 0, N * 26, stream);
+  }
+
+  // ---- post-processing of one page's heat map: GPU CCL + host calipers
+  struct PageBoxes { std::vector<RRect> det; };
+
+  void ccl_launch(PageCcl& pc, const float* d_heat, int H2, int W2) {
+    pc.ensure(H2 * W2, cfg.max_components);
+    launch_ccl(d_heat, H2, W2, cfg.text_threshold, cfg.link_threshold, cfg.low_text, cfg.min_area, pc.view(cfg.max_components), stream);
+  }
+  // after the stream is synchronised up to the CCL kernels
+  void ccl_collect(PageCcl& pc, int H2, int W2, std::vector<RRect>& det) {
+    int counters[2];
+    TTR_HIP_CHECK(hipMemcpyAsync(counters, pc.counters.p, 8, hipMemcpyDeviceToHost, stream));
+    TTR_HIP_CHECK(hipStreamSynchronize(stream));
+    if (counters[0] > cfg.max_components) throw std::runtime_error("too many text components on a page; raise ttr_config.max_components");
+    const int n = counters[0], rows = counters[1];
+    det.clear();
+    if (n == 0) return;
+    std::vector<int> cand((size_t)n * 8), rw((size_t)rows * 2);
+    TTR_HIP_CHECK(hipMemcpyAsync(cand.data(), pc.cand.p, cand.size() * 4, hipMemcpyDeviceToHost, stream));
+    TTR_HIP_CHECK(hipMemcpyAsync(rw.data(), pc.rows.p, rw.size() * 4, hipMemcpyDeviceToHost, stream));
+    TTR_HIP_CHECK(hipStreamSynchronize(stream));
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return cand[8 * a] < cand[8 * b]; });  // label order = ascending root
+    for (int i : order) {
+      const int* c = &cand[8 * i];
+      Component comp{c[0], c[1], c[2], c[3], c[4], c[5], &rw[2 * (size_t)c[6]]};
+      RRect r;
+      if (component_to_rect(comp, H2, W2, &r)) det.push_back(r);
+    }
+  }
+
+  // ---- the hot path over a batch of same-sized device pages
+  void run_pages(const uint8_t* d_pages, int n, int h, int w, std::vector<Result>& results) {
+    results.assign(n, Result());
+    if (n <= 0) return;
+    if (h <= 0 || w <= 0) throw std::runtime_error("Error reading image from file");  // image.empty(), tuatara.cpp:344
+    const CanvasGeom g = canvas_geometry(h, w, cfg.canvas_size, cfg.mag_ratio);
+    if (g.target_h <= 0 || g.target_w <= 0) throw std::runtime_error("image too thin to resize");
+    const int H = g.h32, W = g.w32, H2 = H / 2, W2 = W / 2;
+    const size_t page_bytes = (size_t)h * w * 3;
+    canvas.ensure((size_t)n * H * W * 3);
+    heat.ensure((size_t)n * H2 * W2 * 2 * 4);
+    TTR_HIP_CHECK(hipEventRecord(ev[0], stream));
+    for (int i = 0; i < n; ++i)
+      launch_resize_pad_u8(d_pages + i * page_bytes, h, w, w * 3, canvas.as<uint8_t>() + (size_t)i * H * W * 3, g.target_h, g.target_w, H, W, 1, stream);
+    craft_forward(canvas.as<uint8_t>(), n, H, W, heat.as<float>());
+    TTR_HIP_CHECK(hipEventRecord(ev[1], stream));
+    while ((int)ccl.size() < n) ccl.emplace_back(new PageCcl());
+    for (int i = 0; i < n; ++i) ccl_launch(*ccl[i], heat.as<float>() + (size_t)i * H2 * W2 * 2, H2, W2);
+    TTR_HIP_CHECK(hipEventRecord(ev[2], stream));
+
+    // host: boxes -> crop rectangles
+    const float ratio_w = 1.f / g.ratio, ratio_h = 1.f / g.ratio;   // tuatara.cpp:360-361
+    std::vector<int> rects;                 // x0,y0,x1,y1 per crop
+    std::vector<int> page_of;               // page index per crop
+    std::vector<std::vector<RRect>> boxes(n);
+    std::vector<RRect> det;
+    for (int i = 0; i < n; ++i) {
+      ccl_collect(*ccl[i], H2, W2, det);
+      for (const RRect& r : det) {
+        RRect b = adjust_coordinates(r, ratio_w, ratio_h);            // :406
+        int xywh[4];
+        bounding_rect(b, xywh);                                       // :416
+        int x0 = xywh[0], y0 = xywh[1], x1 = xywh[0] + xywh[2], y1 = xywh[1] + xywh[3];
+        if (cfg.strict_crops) {
+          if (x0 < 0 || y0 < 0 || x1 > w || y1 > h) throw std::runtime_error("text box leaves the image (cv::Exception in the reference, tuatara.cpp:416)");
+        } else {
+          x0 = std::max(x0, 0); y0 = std::max(y0, 0); x1 = std::min(x1, w); y1 = std::min(y1, h);
+        }
+        if (x1 <= x0 || y1 <= y0) continue;
+        boxes[i].push_back(b);
+        rects.insert(rects.end(), {x0, y0, x1, y1});
+        page_of.push_back(i);
+      }
+    }
+    const int N = (int)page_of.size();
+    std::vector<int32_t> ids((size_t)N * 26);
+    if (N > 0) {
+      rects_dev.ensure(rects.size() * 4);
+      crops.ensure((size_t)N * 32 * 128 * 3);
+      logits.ensure((size_t)N * 26 * 95 * 4);
+      ids_dev.ensure((size_t)N * 26 * 4);
+      TTR_HIP_CHECK(hipMemcpyAsync(rects_dev.p, rects.data(), rects.size() * 4, hipMemcpyHostToDevice, stream));
+      int c0 = 0;
+      for (int i = 0; i < n; ++i) {
+        int cnt = (int)boxes[i].size();
+        launch_pack_crops(d_pages + i * page_bytes, h, w, w * 3, rects_dev.as<int>() + 4 * c0, crops.as<uint8_t>() + (size_t)c0 * 32 * 128 * 3, cnt, stream);
+        c0 += cnt;
+      }
+      TTR_HIP_CHECK(hipEventRecord(ev[3], stream));
+      parseq_forward(crops.as<uint8_t>(), N, logits.as<float>(), nullptr, ids_dev.as<int>());
+      TTR_HIP_CHECK(hipEventRecord(ev[4], stream));
+      TTR_HIP_CHECK(hipMemcpyAsync(ids.data(), ids_dev.p, ids.size() * 4, hipMemcpyDeviceToHost, stream));
+    } else {
+      TTR_HIP_CHECK(hipEventRecord(ev[3], stream));
+      TTR_HIP_CHECK(hipEventRecord(ev[4], stream));
+    }
+    TTR_HIP_CHECK(hipStreamSynchronize(stream));
+    for (int s = 0; s < 4; ++s) (void)hipEventElapsedTime(&stage_ms[s], ev[s], ev[s + 1]);
+    std::vector<int> k_of(n, 0);
+    for (int c = 0; c < N; ++c) {
+      int pg = page_of[c];
+      Result& r = results[pg];
+      r.text.push_back(tok.decode(&ids[(size_t)c * 26], 26));           // :486-505
+      float bb[4];
+      tesseract_bbox(boxes[pg][k_of[pg]++], bb);                        // :511
+      r.bbox.insert(r.bbox.end(), bb, bb + 4);
+      r.ids.insert(r.ids.end(), &ids[(size_t)c * 26], &ids[(size_t)c * 26] + 26);
+    }
+  }
+};
+
+}  // namespace ttr
+
+// ====================================================================== C ABI
+using namespace ttr;
+
+struct ttr_engine { std::unique_ptr<Engine> e; };
+struct ttr_result { Result r; };
+
+#define TTR_GUARD_BEGIN try {
+#define TTR_GUARD_END(rc)                                   \
+  }                                                         \
+  catch (const std::exception& ex) { g_last_error = ex.what(); return rc; } \
+  catch (...) { g_last_error = "unknown error"; return rc; }
+
+extern "C" {
+
+void ttr_config_default(ttr_config* c) {
+  c->precision = TTR_PREC_BF16; c->device = 0; c->canvas_size = 1024; c->mag_ratio = 1.0f;
+  c->text_threshold = 0.7f; c->link_threshold = 0.4f; c->low_text = 0.4f; c->min_area = 10;
+  c->strict_crops = 0; c->max_components = 4096; c->verbose = 0;
+}
+
+const char* ttr_last_error(void) { return g_last_error.c_str(); }
+const char* ttr_version(void) { return "tuatara-mi355x 0.1 (gfx950)"; }
+
+ttr_engine* ttr_create(const char* weights_dir, const ttr_config* cfg) {
+  TTR_GUARD_BEGIN
+  if (!weights_dir || !*weights_dir) throw std::runtime_error("Please provide a value for weights_dir");  // tuatara.cpp:315-318
+  ttr_config c;
+  if (cfg) c = *cfg; else ttr_config_default(&c);
+  if (c.max_components <= 0) c.max_components = 4096;
+  std::unique_ptr<ttr_engine> h(new ttr_engine());
+  h->e.reset(new Engine(weights_dir, c));
+  return h.release();
+  TTR_GUARD_END(nullptr)
+}
+
+void ttr_destroy(ttr_engine* e) { delete e; }
+
+static void run_locked(ttr_engine* e, const uint8_t* d_pages, int n, int h, int w, ttr_result** out) {
+  std::vector<Result> res;
+  e->e->run_pages(d_pages, n, h, w, res);
+  for (int i = 0; i < n; ++i) { out[i] = new ttr_result(); out[i]->r = std::move(res[i]); }
+}
+
+int ttr_pages_to_data_dev(ttr_engine* e, const uint8_t* d_pages, int n, int h, int w, ttr_result** out) {
+  TTR_GUARD_BEGIN
+  if (!e || !out) throw std::runtime_error("null argument");
+  std::lock_guard<std::mutex> lk(e->e->mu);
+  run_locked(e, d_pages, n, h, w, out);
+  return 0;
+  TTR_GUARD_END(-1)
+}
+
+int ttr_image_to_data(ttr_engine* e, const uint8_t* img, int h, int w, int row_stride, ttr_result** out) {
+  TTR_GUARD_BEGIN
+  if (!e || !out) throw std::runtime_error("null argument");
+  if (!img || h <= 0 || w <= 0) throw std::runtime_error("Error reading image from file");  // tuatara.cpp:344-347
+  Engine& E = *e->e;
+  std::lock_guard<std::mutex> lk(E.mu);
+  E.staging_img.ensure((size_t)h * w * 3);
+  TTR_HIP_CHECK(hipMemcpy2DAsync(E.staging_img.p, (size_t)w * 3, img, row_stride, (size_t)w * 3, h, hipMemcpyHostToDevice, E.stream));
+  run_locked(e, E.staging_img.as<uint8_t>(), 1, h, w, out);
+  return 0;
+  TTR_GUARD_END(-1)
+}
+
+int ttr_result_count(const ttr_result* r) { return r ? (int)r->r.text.size() : 0; }
+const char* ttr_result_text(const ttr_result* r, int i) { return r->r.text[i].c_str(); }
+const float* ttr_result_bbox(const ttr_result* r, int i) { return &r->r.bbox[4 * (size_t)i]; }
+const int32_t* ttr_result_ids(const ttr_result* r, int i) { return &r->r.ids[26 * (size_t)i]; }
+void ttr_result_free(ttr_result* r) { delete r; }
+
+int ttr_craft_heatmap(ttr_engine* e, const uint8_t* canvas, int H, int W, float* heat_out) {
+  TTR_GUARD_BEGIN
+  Engine& E = *e->e;
+  std::lock_guard<std::mutex> lk(E.mu);
+  E.canvas.ensure((size_t)H * W * 3);
+  E.heat.ensure((size_t)H * W / 4 * 2 * 4);
+  TTR_HIP_CHECK(hipMemcpyAsync(E.canvas.p, canvas, (size_t)H * W * 3, hipMemcpyHostToDevice, E.stream));
+  E.craft_forward(E.canvas.as<uint8_t>(), 1, H, W, E.heat.as<float>());
+  TTR_HIP_CHECK(hipMemcpyAsync(heat_out, E.heat.p, (size_t)H * W / 4 * 2 * 4, hipMemcpyDeviceToHost, E.stream));
+  TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
+  return 0;
+  TTR_GUARD_END(-1)
+}
+
+int ttr_ccl_boxes(ttr_engine* e, const float* heat, int H2, int W2, float* rects5, int max_rects, int* n) {
+  TTR_GUARD_BEGIN
+  Engine& E = *e->e;
+  std::lock_guard<std::mutex> lk(E.mu);
+  E.heat.ensure((size_t)H2 * W2 * 2 * 4);
+  TTR_HIP_CHECK(hipMemcpyAsync(E.heat.p, heat, (size_t)H2 * W2 * 2 * 4, hipMemcpyHostToDevice, E.stream));
+  if (E.ccl.empty()) E.ccl.emplace_back(new PageCcl());
+  E.ccl_launch(*E.ccl[0], E.heat.as<float>(), H2, W2);
+  std::vector<RRect> det;
+  E.ccl_collect(*E.ccl[0], H2, W2, det);
+  *n = (int)det.size();
+  for (int i = 0; i < (int)det.size() && i < max_rects; ++i) {
+    rects5[5 * i] = det[i].cx; rects5[5 * i + 1] = det[i].cy; rects5[5 * i + 2] = det[i].w; rects5[5 * i + 3] = det[i].h; rects5[5 * i + 4] = det[i].angle;
+  }
+  return 0;
+  TTR_GUARD_END(-1)
+}
+
+int ttr_resize_canvas(ttr_engine* e, const uint8_t* img, int h, int w, int row_stride, uint8_t* canvas, size_t cap, int* H, int* W, float* ratio) {
+  TTR_GUARD_BEGIN
+  Engine& E = *e->e;
+  std::lock_guard<std::mutex> lk(E.mu);
+  const CanvasGeom g = canvas_geometry(h, w, E.cfg.canvas_size, E.cfg.mag_ratio);
+  *H = g.h32; *W = g.w32; *ratio = g.ratio;
+  const size_t need = (size_t)g.h32 * g.w32 * 3;
+  if (cap < need) throw std::runtime_error("canvas buffer too small");
+  E.staging_img.ensure((size_t)h * w * 3);
+  E.canvas.ensure(need);
+  TTR_HIP_CHECK(hipMemcpy2DAsync(E.staging_img.p, (size_t)w * 3, img, row_stride, (size_t)w * 3, h, hipMemcpyHostToDevice, E.stream));
+  launch_resize_pad_u8(E.staging_img.as<uint8_t>(), h, w, w * 3, E.canvas.as<uint8_t>(), g.target_h, g.target_w, g.h32, g.w32, 1, E.stream);
+  TTR_HIP_CHECK(hipMemcpyAsync(canvas, E.canvas.p, need, hipMemcpyDeviceToHost, E.stream));
+  TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
+  return 0;
+  TTR_GUARD_END(-1)
+}
+
+int ttr_pack_crops(ttr_engine* e, const uint8_t* img, int h, int w, int row_stride, const float* rects5, int n, float ratio, uint8_t* crops_out,
+                   float* boxes_out) {
+  TTR_GUARD_BEGIN
+  Engine& E = *e->e;
+  std::lock_guard<std::mutex> lk(E.mu);
+  if (n <= 0) return 0;
+  std::vector<int> rects((size_t)n * 4);
+  for (int i = 0; i < n; ++i) {
+    RRect r{rects5[5 * i], rects5[5 * i + 1], rects5[5 * i + 2], rects5[5 * i + 3], rects5[5 * i + 4]};
+    RRect b = adjust_coordinates(r, 1.f / ratio, 1.f / ratio);
+    if (boxes_out) { boxes_out[5 * i] = b.cx; boxes_out[5 * i + 1] = b.cy; boxes_out[5 * i + 2] = b.w; boxes_out[5 * i + 3] = b.h; boxes_out[5 * i + 4] = b.angle; }
+    int xywh[4];
+    bounding_rect(b, xywh);
+    rects[4 * i] = std::max(xywh[0], 0); rects[4 * i + 1] = std::max(xywh[1], 0);
+    rects[4 * i + 2] = std::min(xywh[0] + xywh[2], w); rects[4 * i + 3] = std::min(xywh[1] + xywh[3], h);
+  }
+  E.staging_img.ensure((size_t)h * w * 3);
+  E.rects_dev.ensure(rects.size() * 4);
+  E.crops.ensure((size_t)n * 32 * 128 * 3);
+  TTR_HIP_CHECK(hipMemcpy2DAsync(E.staging_img.p, (size_t)w * 3, img, row_stride, (size_t)w * 3, h, hipMemcpyHostToDevice, E.stream));
+  TTR_HIP_CHECK(hipMemcpyAsync(E.rects_dev.p, rects.data(), rects.size() * 4, hipMemcpyHostToDevice, E.stream));
+  launch_pack_crops(E.staging_img.as<uint8_t>(), h, w, w * 3, E.rects_dev.as<int>(), E.crops.as<uint8_t>(), n, E.stream);
+  TTR_HIP_CHECK(hipMemcpyAsync(crops_out, E.crops.p, (size_t)n * 32 * 128 * 3, hipMemcpyDeviceToHost, E.stream));
+  TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
+  return 0;
+  TTR_GUARD_END(-1)
+}
+
+int ttr_parseq_logits(ttr_engine* e, const uint8_t* crops, int n, float* logits, float* ar_logits, int32_t* ids) {
+  TTR_GUARD_BEGIN
+  Engine& E = *e->e;
+  std::lock_guard<std::mutex> lk(E.mu);
+  if (n <= 0) return 0;
+  E.crops.ensure((size_t)n * 32 * 128 * 3);
+  E.logits.ensure((size_t)n * 26 * 95 * 4);
+  E.ids_dev.ensure((size_t)n * 26 * 4);
+  if (ar_logits) E.ar_logits.ensure((size_t)n * 26 * 95 * 4);
+  TTR_HIP_CHECK(hipMemcpyAsync(E.crops.p, crops, (size_t)n * 32 * 128 * 3, hipMemcpyHostToDevice, E.stream));
+  E.parseq_forward(E.crops.as<uint8_t>(), n, E.logits.as<float>(), ar_logits ? E.ar_logits.as<float>() : nullptr, E.ids_dev.as<int>());
+  TTR_HIP_CHECK(hipMemcpyAsync(logits, E.logits.p, (size_t)n * 26 * 95 * 4, hipMemcpyDeviceToHost, E.stream));
+  if (ar_logits) TTR_HIP_CHECK(hipMemcpyAsync(ar_logits, E.ar_logits.p, (size_t)n * 26 * 95 * 4, hipMemcpyDeviceToHost, E.stream));
+  if (ids) TTR_HIP_CHECK(hipMemcpyAsync(ids, E.ids_dev.p, (size_t)n * 26 * 4, hipMemcpyDeviceToHost, E.stream));
+  TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
+  return 0;
+  TTR_GUARD_END(-1)
+}
+
+int ttr_decode_ids(const int32_t* ids, int n, char* buf) {
+  TTR_GUARD_BEGIN
+  static const Tokenizer tok;
+  std::string s = tok.decode(ids, n);
+  memcpy(buf, s.c_str(), s.size() + 1);
+  return (int)s.size();
+  TTR_GUARD_END(-1)
+}
+
+int ttr_dbg_conv(ttr_engine* e, const float* in0, int C0, const float* in1, int C1, int relu0, int relu1, int B, int H, int W, int ks, int dil,
+                 const float* wgt, const float* bias, int Cout, int act, float* out) {
+  TTR_GUARD_BEGIN
+  Engine& E = *e->e;
+  std::lock_guard<std::mutex> lk(E.mu);
+  const size_t M = (size_t)B * H * W;
+  const int K = ks * ks * (C0 + C1);
+  DevBuf d0, d1, dout;
+  Linear L;
+  auto up = [&](DevBuf& d, const float* src, size_t nel) {
+    d.ensure(nel * E.es);
+    if (E.prec == kBF16) {
+      std::vector<uint16_t> hbuf(nel);
+      for (size_t i = 0; i < nel; ++i) hbuf[i] = f32_to_bf16_rne(src[i]);
+      TTR_HIP_CHECK(hipMemcpy(d.p, hbuf.data(), nel * 2, hipMemcpyHostToDevice));
+    } else TTR_HIP_CHECK(hipMemcpy(d.p, src, nel * 4, hipMemcpyHostToDevice));
+  };
+  up(d0, in0, M * C0);
+  if (C1) up(d1, in1, M * C1);
+  E.upload_linear(L, wgt, Cout, K, bias, Cout, K);
+  dout.ensure(M * Cout * 4);
+  ConvParams p{};
+  p.in0 = d0.p; p.C0 = C0; p.in1 = C1 ? d1.p : nullptr; p.C1 = C1; p.relu0 = relu0; p.relu1 = relu1;
+  p.B = B; p.H = H; p.W = W; p.ks = ks; p.dil = dil; p.wgt = L.w.p; p.bias = bias ? L.b.as<float>() : nullptr;
+  p.out = nullptr; p.out_f32 = dout.as<float>(); p.out_f32_ld = Cout; p.Cout = Cout; p.M = (int)M; p.act = act;
+  launch_igemm(E.prec, p, E.stream);
+  TTR_HIP_CHECK(hipMemcpyAsync(out, dout.p, M * Cout * 4, hipMemcpyDeviceToHost, E.stream));
+  TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
+  return 0;
+  TTR_GUARD_END(-1)
+}
+
+int ttr_dbg_min_area_rect(const float* xy, int n, float* r5) {
+  TTR_GUARD_BEGIN
+  std::vector<Pt2f> p(n);
+  for (int i = 0; i < n; ++i) p[i] = Pt2f{xy[2 * i], xy[2 * i + 1]};
+  RRect r = min_area_rect(p.data(), n);
+  r5[0] = r.cx; r5[1] = r.cy; r5[2] = r.w; r5[3] = r.h; r5[4] = r.angle;
+  return 0;
+  TTR_GUARD_END(-1)
+}
+
+int ttr_dbg_component_rect(int area, int x0, int y0, int x1, int y1, const int32_t* rows, int H, int W, float* r5) {
+  TTR_GUARD_BEGIN
+  Component c{0, area, x0, y0, x1, y1, rows};
+  RRect r;
+  if (!component_to_rect(c, H, W, &r)) return 0;
+  r5[0] = r.cx; r5[1] = r.cy; r5[2] = r.w; r5[3] = r.h; r5[4] = r.angle;
+  return 1;
+  TTR_GUARD_END(-1)
+}
+
+int ttr_dbg_box_geometry(const float* r5, float ratio, float* adj5, int32_t* xywh, float* bbox4) {
+  TTR_GUARD_BEGIN
+  RRect r{r5[0], r5[1], r5[2], r5[3], r5[4]};
+  RRect b = adjust_coordinates(r, 1.f / ratio, 1.f / ratio);
+  adj5[0] = b.cx; adj5[1] = b.cy; adj5[2] = b.w; adj5[3] = b.h; adj5[4] = b.angle;
+  int q[4];
+  bounding_rect(b, q);
+  for (int i = 0; i < 4; ++i) xywh[i] = q[i];
+  tesseract_bbox(b, bbox4);
+  return 0;
+  TTR_GUARD_END(-1)
+}
+
+void* ttr_dev_alloc(size_t bytes) { void* p = nullptr; return hipMalloc(&p, bytes) == hipSuccess ? p : nullptr; }
+void ttr_dev_free(void* p) { if (p) (void)hipFree(p); }
+int ttr_dev_upload(void* dst, const void* src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1; }
+int ttr_dev_download(void* dst, const void* src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
+int ttr_dev_sync(ttr_engine* e) { return hipStreamSynchronize(e->e->stream) == hipSuccess ? 0 : -1; }
+int ttr_last_stage_ms(ttr_engine* e, float ms[4]) { memcpy(ms, e->e->stage_ms, sizeof(float) * 4); return 0; }
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// Host-callable launchers for every HIP kernel of the engine (definitions in *.hip).
+#pragma once
+#include <stdexcept>
+#include "common.h"
+
+namespace ttr {
+
+// ---- igemm.hip
+const char* igemm_check(const ConvParams& p);
+void launch_igemm(Precision prec, const ConvParams& p, hipStream_t s);
+
+// ---- craft_ops.hip
+// OpenCV-style 8-bit INTER_LINEAR resize of src[sh,sw,3] to [th,tw], zero pad to [H,W], optional channel swap.
+void launch_resize_pad_u8(const uint8_t* src, int sh, int sw, int sstride, uint8_t* dst, int th, int tw, int H, int W, int swap_rb, hipStream_t s);
+// canvas u8 [B,H,W,3] -> first-layer im2col matrix T [B*H*W][32] (27 taps*channels, /255, zero padded)
+void launch_im2col_l1(Precision prec, const uint8_t* canvas, void* out, int B, int H, int W, hipStream_t s);
+void launch_maxpool2x2(Precision prec, const void* in, void* out, int B, int H, int W, int C, int relu, hipStream_t s);
+void launch_maxpool3x3s1(Precision prec, const void* in, void* out, int B, int H, int W, int C, hipStream_t s);
+void launch_upsample2x(Precision prec, const void* in, void* out, int B, int H, int W, int C, hipStream_t s);  // in [B,H,W,C] -> out [B,2H,2W,C]
+// T [M][ld] -> f32 [M][2] (the two heat-map channels)
+void launch_extract_heat(Precision prec, const void* in, int ld, float* out, int M, hipStream_t s);
+
+// ---- parseq_ops.hip
+void launch_patchify(Precision prec, const uint8_t* crops, void* out, int N, hipStream_t s);
+void launch_layernorm(Precision prec, const float* in, int in_ld, const float* gamma, const float* beta, float eps, void* out, int out_ld, int M, int D, hipStream_t s);
+void launch_attn_enc(Precision prec, const void* qkv, void* out, int N, hipStream_t s);  // qkv T [N*128][1152] -> out T [N*128][384]
+// content token embedding + norm_c.  rows (n, i) for i in [i0,i1): out row n*(i1-i0)+(i-i0)
+void launch_dec_embed_ln(Precision prec, const int* tokens, const float* emb, const float* pos_q, const float* gamma, const float* beta, float eps,
+                         void* out, int N, int i0, int i1, hipStream_t s);
+// self attention of R query rows per crop against the K/V cache [N][26][768].
+// mode 0 (AR): R == 1, query index qi0, keys 0..qi0.  mode 1 (refine): R == 26, cloze mask + EOS key padding.
+void launch_dec_self_attn(Precision prec, const float* q /*[26][384] f32*/, const void* kvcache, const int* tokens, void* out, int N, int R, int qi0, int mode, hipStream_t s);
+// cross attention of rows [N*R] (Q: T [N*R][384]) against kvmem T [N*128][768]
+void launch_dec_cross_attn(Precision prec, const void* q, const void* kvmem, void* out, int N, int R, hipStream_t s);
+// tokens[n*tok_ld + col] = argmax over C of logits[n*ld ..]
+void launch_argmax(const float* logits, int ld, int C, int* tokens, int tok_ld, int col, int N, hipStream_t s);
+void launch_fill_i32(int* p, int value, int n, int stride, hipStream_t s);
+
+// ---- post_ops.hip
+struct CclBuffers {
+  // all device pointers; sized for H*W pixels and max_cand candidates
+  float* tnorm; uint8_t* flags; int* parent; unsigned* mm;  // mm: 4 ordered-uint min/max words
+  int* area; int* bbox;   // bbox: 4 ints per root (minx,miny,maxx,maxy)
+  unsigned* maxt;         // per root max of tnorm (as uint bits; tnorm >= 0)
+  int* cand_slot;         // per pixel: slot of the candidate rooted here, or -1
+  int* cand;              // [max_cand][8]: root, area, minx, miny, maxx, maxy, row_offset, pad
+  int* counters;          // [0]=n_cand, [1]=total_rows
+  unsigned* rowmin; unsigned* rowmax;  // [max_cand][H]
+  int* rows_packed;       // [total_rows][2]
+  int max_cand;
+};
+void launch_ccl(const float* heat /*[H][W][2]*/, int H, int W, float text_threshold, float link_threshold, float low_text, int min_area, const CclBuffers& b, hipStream_t s);
+// crops: rect[n] = {x0,y0,x1,y1} (already clamped, x1/y1 exclusive) of image u8 [h,w,3] -> out u8 [N][32][128][3]
+void launch_pack_crops(const uint8_t* image, int h, int w, int stride, const int* rects, uint8_t* out, int N, hipStream_t s);
+
+}  // namespace ttr

@@ -1,0 +1,386 @@
+// PARSeq-side kernels other than the GEMMs (igemm.hip): crop patchify with the /255
+// normalisation (tuatara.cpp:443-446), wavefront-level LayerNorm, the fused encoder
+// attention (QK^T -> softmax -> PV on MFMA tiles, one workgroup per crop x head), and
+// the small decoder kernels of the 26-step autoregressive loop + refinement pass that
+// run inside the TorchScript module the reference calls at tuatara.cpp:307.
+#include "common.h"
+#include "kernels.h"
+
+namespace ttr {
+
+// ------------------------------------------------------------------ patchify
+// crops u8 [N][32][128][3] -> A [N*128][96], token = py*16+px (4x8 patches), k = (dy*8+dx)*3+c
+template <typename T>
+__global__ void patchify_kernel(const uint8_t* __restrict__ crops, T* __restrict__ out, int N) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (token row, dy): 24 contiguous bytes
+  int total = N * 128 * 4;
+  if (idx >= total) return;
+  int dy = idx & 3, row = idx >> 2;
+  int n = row >> 7, tok = row & 127, py = tok >> 4, px = tok & 15;
+  const uint8_t* src = crops + (((size_t)n * 32 + py * 4 + dy) * 128 + px * 8) * 3;
+  T* dst = out + (size_t)row * 96 + dy * 24;
+#pragma unroll
+  for (int i = 0; i < 24; ++i) dst[i] = (T)((float)src[i] / 255.0f);
+}
+
+void launch_patchify(Precision prec, const uint8_t* crops, void* out, int N, hipStream_t s) {
+  if (N <= 0) return;
+  dim3 grid((N * 128 * 4 + 255) / 256);
+  if (prec == kBF16) hipLaunchKernelGGL(patchify_kernel<bf16>, grid, dim3(256), 0, s, crops, (bf16*)out, N);
+  else hipLaunchKernelGGL(patchify_kernel<float>, grid, dim3(256), 0, s, crops, (float*)out, N);
+}
+
+// ------------------------------------------------------------------ LayerNorm: one wave64 per row
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <typename T, int PER_LANE>
+__global__ void layernorm_kernel(const float* __restrict__ in, int in_ld, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 float eps, T* __restrict__ out, int out_ld, int M) {
+  constexpr int D = PER_LANE * 64;
+  int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* x = in + (int64_t)row * in_ld;
+  float v[PER_LANE], s = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER_LANE; ++i) { v[i] = x[lane + 64 * i]; s += v[i]; }
+  const float mean = wave_sum(s) * (1.0f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER_LANE; ++i) { float d = v[i] - mean; q += d * d; }
+  const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
+  T* o = out + (int64_t)row * out_ld;
+#pragma unroll
+  for (int i = 0; i < PER_LANE; ++i) { int c = lane + 64 * i; o[c] = (T)((v[i] - mean) * rstd * gamma[c] + beta[c]); }
+}
+
+void launch_layernorm(Precision prec, const float* in, int in_ld, const float* gamma, const float* beta, float eps, void* out, int out_ld, int M, int D, hipStream_t s) {
+  if (D != 384) throw std::runtime_error("layernorm: D must be 384");
+  if (M <= 0) return;
+  dim3 grid((M + 3) / 4);
+  if (prec == kBF16) hipLaunchKernelGGL((layernorm_kernel<bf16, 6>), grid, dim3(256), 0, s, in, in_ld, gamma, beta, eps, (bf16*)out, out_ld, M);
+  else hipLaunchKernelGGL((layernorm_kernel<float, 6>), grid, dim3(256), 0, s, in, in_ld, gamma, beta, eps, (float*)out, out_ld, M);
+}
+
+// ------------------------------------------------------------------ encoder attention
+// One workgroup (4 waves) per (crop, head): S = 128 tokens, d = 64.  Wave w owns query
+// rows 32w..32w+31.  Q/K tiles and V^T are staged in LDS; S = QK^T accumulates in MFMA
+// tiles, softmax runs in registers with 16-lane shuffles, P goes through LDS (re-using
+// the Q/K space) to become the A operand of P.V.
+template <typename T> struct FragT;
+template <> struct FragT<bf16> { bf16x8 v; };
+template <> struct FragT<float> { float v[8]; };
+template <typename T> __device__ __forceinline__ f32x4 mma16x(const FragT<T>& a, const FragT<T>& b, f32x4 c);
+template <> __device__ __forceinline__ f32x4 mma16x<bf16>(const FragT<bf16>& a, const FragT<bf16>& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4 mma16x<float>(const FragT<float>& a, const FragT<float>& b, f32x4 c) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], c, 0, 0, 0);
+  return c;
+}
+// 8 consecutive elements starting at p (16-byte aligned for bf16, 32-byte for f32)
+template <typename T> __device__ __forceinline__ FragT<T> ld_frag(const T* p) {
+  FragT<T> f;
+  if constexpr (sizeof(T) == 2) { uint4 v = *reinterpret_cast<const uint4*>(p); f.v = *reinterpret_cast<bf16x8*>(&v); }
+  else { *reinterpret_cast<uint4*>(&f.v[0]) = *reinterpret_cast<const uint4*>(p); *reinterpret_cast<uint4*>(&f.v[4]) = *reinterpret_cast<const uint4*>(p + 4); }
+  return f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_enc_kernel(const T* __restrict__ qkv, T* __restrict__ out) {
+  constexpr int S = 128, DH = 64, E = 384, LDQ = DH + 8, LDV = S + 8, LDP = S + 8;  // +8 elements: 16-byte row skew
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* sQ = reinterpret_cast<T*>(smem);            // [128][LDQ]
+  T* sK = sQ + S * LDQ;                          // [128][LDQ]
+  T* sVt = sK + S * LDQ;                         // [64][LDV]   V transposed: [d][key]
+  T* sP = sQ;                                    // [4 waves][32][LDP] aliases Q/K after S is done
+  static_assert(4 * 32 * LDP <= 2 * S * LDQ, "P must fit in the Q/K space");
+
+  const int n = blockIdx.x / 6, h = blockIdx.x % 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const T* base = qkv + (int64_t)n * S * (3 * E) + h * DH;
+  constexpr int EPC = 16 / sizeof(T), CPR = DH / EPC;  // chunks per row
+  for (int q = tid; q < S * CPR; q += 256) {
+    int row = q / CPR, c = q % CPR;
+    const T* g = base + (int64_t)row * (3 * E) + c * EPC;
+    *reinterpret_cast<uint4*>(sQ + row * LDQ + c * EPC) = *reinterpret_cast<const uint4*>(g);
+    *reinterpret_cast<uint4*>(sK + row * LDQ + c * EPC) = *reinterpret_cast<const uint4*>(g + E);
+    T v[EPC];
+    *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(g + 2 * E);
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) sVt[(c * EPC + i) * LDV + row] = v[i];
+  }
+  __syncthreads();
+
+  const int fr = lane & 15, fg = lane >> 4;
+  f32x4 sacc[2][8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < DH / 32; ++ks) {
+    FragT<T> a[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = ld_frag<T>(sQ + (wave * 32 + i * 16 + fr) * LDQ + ks * 32 + fg * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      FragT<T> b = ld_frag<T>(sK + (j * 16 + fr) * LDQ + ks * 32 + fg * 8);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) sacc[i][j] = mma16x<T>(a[i], b, sacc[i][j]);
+    }
+  }
+  __syncthreads();  // every wave is done reading Q/K before P overwrites them
+
+  // softmax over keys; element (i, j, r): row = i*16 + fg*4 + r, key = j*16 + fr.  scale = 1/sqrt(64)
+  T* myP = sP + wave * 32 * LDP;
+  float rinv[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mx = fmaxf(mx, sacc[i][j][r]);
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float e = __expf((sacc[i][j][r] - mx) * 0.125f);
+        T et = (T)e;
+        sum += (float)et;  // normalise by what P.V will actually sum
+        myP[(i * 16 + fg * 4 + r) * LDP + j * 16 + fr] = et;
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      rinv[i][r] = 1.0f / sum;
+    }
+  __syncthreads();
+
+  f32x4 oacc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < S / 32; ++ks) {
+    FragT<T> a[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = ld_frag<T>(myP + (i * 16 + fr) * LDP + ks * 32 + fg * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      FragT<T> b = ld_frag<T>(sVt + (j * 16 + fr) * LDV + ks * 32 + fg * 8);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) oacc[i][j] = mma16x<T>(a[i], b, oacc[i][j]);
+    }
+  }
+  T* o = out + (int64_t)n * S * E + h * DH;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int row = wave * 32 + i * 16 + fg * 4 + r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[(int64_t)row * E + j * 16 + fr] = (T)(oacc[i][j][r] * rinv[i][r]);
+    }
+}
+
+void launch_attn_enc(Precision prec, const void* qkv, void* out, int N, hipStream_t s) {
+  if (N <= 0) return;
+  auto lds_bytes = [](size_t es) { return (2 * 128 * (64 + 8) + 64 * (128 + 8)) * es; };
+  if (prec == kBF16) {
+    hipLaunchKernelGGL(attn_enc_kernel<bf16>, dim3(N * 6), dim3(256), lds_bytes(2), s, (const bf16*)qkv, (bf16*)out);
+  } else {
+    static bool once = false;
+    if (!once) { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)attn_enc_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(4))); once = true; }
+    hipLaunchKernelGGL(attn_enc_kernel<float>, dim3(N * 6), dim3(256), lds_bytes(4), s, (const float*)qkv, (float*)out);
+  }
+}
+
+// ------------------------------------------------------------------ decoder: content embedding + norm_c
+// token i of crop n: i == 0 -> emb[tok] (null context, no position), else pos_q[i-1] + emb[tok].
+// emb is pre-scaled by sqrt(384) at export.  One wave per row.
+template <typename T>
+__global__ void dec_embed_ln_kernel(const int* __restrict__ tokens, const float* __restrict__ emb, const float* __restrict__ pos_q,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, T* __restrict__ out, int N, int i0, int i1) {
+  const int R = i1 - i0;
+  int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= N * R) return;
+  int n = row / R, i = i0 + row % R;
+  int tok = tokens[n * 26 + i];
+  tok = tok < 0 ? 0 : (tok > 96 ? 96 : tok);
+  float v[6], s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    int c = lane + 64 * k;
+    v[k] = emb[tok * 384 + c];
+    if (i > 0) v[k] = pos_q[(i - 1) * 384 + c] + v[k];
+    s += v[k];
+  }
+  const float mean = wave_sum(s) * (1.0f / 384);
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { float d = v[k] - mean; q += d * d; }
+  const float rstd = rsqrtf(wave_sum(q) * (1.0f / 384) + eps);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { int c = lane + 64 * k; out[(int64_t)row * 384 + c] = (T)((v[k] - mean) * rstd * gamma[c] + beta[c]); }
+}
+
+void launch_dec_embed_ln(Precision prec, const int* tokens, const float* emb, const float* pos_q, const float* gamma, const float* beta, float eps,
+                         void* out, int N, int i0, int i1, hipStream_t s) {
+  int rows = N * (i1 - i0);
+  if (rows <= 0) return;
+  dim3 grid((rows + 3) / 4);
+  if (prec == kBF16) hipLaunchKernelGGL(dec_embed_ln_kernel<bf16>, grid, dim3(256), 0, s, tokens, emb, pos_q, gamma, beta, eps, (bf16*)out, N, i0, i1);
+  else hipLaunchKernelGGL(dec_embed_ln_kernel<float>, grid, dim3(256), 0, s, tokens, emb, pos_q, gamma, beta, eps, (float*)out, N, i0, i1);
+}
+
+// ------------------------------------------------------------------ decoder self attention
+// 12 heads x 32 dims, <= 26 keys.  One 384-thread workgroup per (crop, query row); thread = (head, dim).
+// q: f32 [26][384] = Wq.norm_q(pos_queries)+bq (crop independent, precomputed at engine creation).
+// kvcache: T [N][26][768] (K | V).  Masks (PARSeq.forward):
+//   mode 0 (AR step qi): keys 0..qi visible.
+//   mode 1 (refine): key j hidden iff j == qi+1 (cloze) or tokens[n][0..j] contains EOS (key padding).
+template <typename T>
+__global__ __launch_bounds__(384) void dec_self_attn_kernel(const float* __restrict__ q, const T* __restrict__ kv, const int* __restrict__ tokens,
+                                                            T* __restrict__ out, int R, int qi0, int mode) {
+  __shared__ float sq[384];
+  __shared__ float sp[12][28];
+  __shared__ int visible[26];
+  const int row = blockIdx.x, n = row / R, qi = (mode == 0) ? qi0 : row % R;
+  const int nkeys = (mode == 0) ? qi + 1 : 26;
+  const int t = threadIdx.x;
+  sq[t] = q[qi * 384 + t];
+  if (t < 26) {
+    int vis = t < nkeys;
+    if (mode == 1) {
+      if (t == qi + 1) vis = 0;
+      for (int j = 0; j <= t; ++j) if (tokens[n * 26 + j] == 0) vis = 0;
+    }
+    visible[t] = vis;
+  }
+  __syncthreads();
+  const T* kvn = kv + (int64_t)n * 26 * 768;
+  if (t < 12 * 26) {
+    int h = t / 26, j = t % 26;
+    float s = -INFINITY;
+    if (visible[j]) {
+      s = 0.f;
+      const T* k = kvn + j * 768 + h * 32;
+#pragma unroll
+      for (int d = 0; d < 32; ++d) s += sq[h * 32 + d] * (float)k[d];
+      s *= 0.17677669529663687f;  // 1/sqrt(32)
+    }
+    sp[h][j] = s;
+  }
+  __syncthreads();
+  if (t < 12) {
+    float mx = -INFINITY;
+    for (int j = 0; j < 26; ++j) mx = fmaxf(mx, sp[t][j]);
+    float sum = 0.f;
+    for (int j = 0; j < 26; ++j) { float e = visible[j] ? __expf(sp[t][j] - mx) : 0.f; sp[t][j] = e; sum += e; }
+    float inv = 1.0f / sum;
+    for (int j = 0; j < 26; ++j) sp[t][j] *= inv;
+  }
+  __syncthreads();
+  {
+    int h = t >> 5;
+    float acc = 0.f;
+    for (int j = 0; j < nkeys; ++j) acc += sp[h][j] * (float)kvn[j * 768 + 384 + t];
+    out[(int64_t)row * 384 + t] = (T)acc;
+  }
+}
+
+void launch_dec_self_attn(Precision prec, const float* q, const void* kvcache, const int* tokens, void* out, int N, int R, int qi0, int mode, hipStream_t s) {
+  if (N <= 0) return;
+  dim3 grid(N * R);
+  if (prec == kBF16) hipLaunchKernelGGL(dec_self_attn_kernel<bf16>, grid, dim3(384), 0, s, q, (const bf16*)kvcache, tokens, (bf16*)out, R, qi0, mode);
+  else hipLaunchKernelGGL(dec_self_attn_kernel<float>, grid, dim3(384), 0, s, q, (const float*)kvcache, tokens, (float*)out, R, qi0, mode);
+}
+
+// ------------------------------------------------------------------ decoder cross attention
+// one 384-thread workgroup per query row; 12 heads x 32 dims against the crop's 128 memory tokens.
+template <typename T>
+__global__ __launch_bounds__(384) void dec_cross_attn_kernel(const T* __restrict__ q, const T* __restrict__ kvmem, T* __restrict__ out, int R) {
+  __shared__ float sq[384];
+  __shared__ float sp[12][128];
+  const int row = blockIdx.x, n = row / R, t = threadIdx.x;
+  sq[t] = (float)q[(int64_t)row * 384 + t];
+  __syncthreads();
+  const T* kvn = kvmem + (int64_t)n * 128 * 768;
+  for (int idx = t; idx < 12 * 128; idx += 384) {
+    int h = idx >> 7, j = idx & 127;
+    const T* k = kvn + j * 768 + h * 32;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) s += sq[h * 32 + d] * (float)k[d];
+    sp[h][j] = s * 0.17677669529663687f;
+  }
+  __syncthreads();
+  {  // softmax: 32 lanes per head row (12 heads = 384 threads)
+    int h = t >> 5, l = t & 31;
+    float v[4], mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = sp[h][l + 32 * i]; mx = fmaxf(mx, v[i]); }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = __expf(v[i] - mx); sum += v[i]; }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    float inv = 1.0f / sum;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sp[h][l + 32 * i] = v[i] * inv;
+  }
+  __syncthreads();
+  {
+    int h = t >> 5;
+    float acc = 0.f;
+    for (int j = 0; j < 128; ++j) acc += sp[h][j] * (float)kvn[j * 768 + 384 + t];
+    out[(int64_t)row * 384 + t] = (T)acc;
+  }
+}
+
+void launch_dec_cross_attn(Precision prec, const void* q, const void* kvmem, void* out, int N, int R, hipStream_t s) {
+  if (N <= 0) return;
+  dim3 grid(N * R);
+  if (prec == kBF16) hipLaunchKernelGGL(dec_cross_attn_kernel<bf16>, grid, dim3(384), 0, s, (const bf16*)q, (const bf16*)kvmem, (bf16*)out, R);
+  else hipLaunchKernelGGL(dec_cross_attn_kernel<float>, grid, dim3(384), 0, s, (const float*)q, (const float*)kvmem, (float*)out, R);
+}
+
+// ------------------------------------------------------------------ argmax (first maximal index, like torch.argmax on CPU)
+__global__ void argmax_kernel(const float* __restrict__ logits, int ld, int C, int* __restrict__ tokens, int tok_ld, int col, int N) {
+  int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  const float* x = logits + (int64_t)n * ld;
+  float best = -INFINITY; int bi = 0x7fffffff;
+  for (int c = lane; c < C; c += 64) { float v = x[c]; if (v > best) { best = v; bi = c; } }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(best, o); int oi = __shfl_xor(bi, o);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) tokens[n * tok_ld + col] = bi;
+}
+
+void launch_argmax(const float* logits, int ld, int C, int* tokens, int tok_ld, int col, int N, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(argmax_kernel, dim3((N + 3) / 4), dim3(256), 0, s, logits, ld, C, tokens, tok_ld, col, N);
+}
+
+__global__ void fill_i32_kernel(int* p, int value, int n, int stride) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[(int64_t)i * stride] = value;
+}
+void launch_fill_i32(int* p, int value, int n, int stride, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(fill_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, value, n, stride);
+}
+
+}  // namespace ttr

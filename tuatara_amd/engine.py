@@ -1,0 +1,277 @@
+"""ctypes binding of the C ABI in include/tuatara_hip.h (libtuatara_hip.so).
+
+Thin by design: numpy arrays in, numpy arrays / python lists out; every compute call
+runs the HIP engine.  There is no CPU fallback — loading fails loudly when the shared
+library is missing and ``Engine(...)`` raises when no GPU is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_LIBPATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtuatara_hip.so")
+_lib = None
+
+PREC_BF16, PREC_F32 = 0, 1
+
+
+class Config(C.Structure):
+    _fields_ = [("precision", C.c_int), ("device", C.c_int), ("canvas_size", C.c_int), ("mag_ratio", C.c_float),
+                ("text_threshold", C.c_float), ("link_threshold", C.c_float), ("low_text", C.c_float), ("min_area", C.c_int),
+                ("strict_crops", C.c_int), ("max_components", C.c_int), ("verbose", C.c_int)]
+
+
+# every symbol include/tuatara_hip.h declares: (name, restype, argtypes)
+_VP, _I, _F = C.c_void_p, C.c_int, C.c_float
+_PU8, _PF, _PI = C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_int32)
+SYMBOLS = [
+    ("ttr_config_default", None, [C.POINTER(Config)]),
+    ("ttr_create", _VP, [C.c_char_p, C.POINTER(Config)]),
+    ("ttr_destroy", None, [_VP]),
+    ("ttr_last_error", C.c_char_p, []),
+    ("ttr_version", C.c_char_p, []),
+    ("ttr_image_to_data", _I, [_VP, _PU8, _I, _I, _I, C.POINTER(_VP)]),
+    ("ttr_pages_to_data_dev", _I, [_VP, _VP, _I, _I, _I, C.POINTER(_VP)]),
+    ("ttr_result_count", _I, [_VP]),
+    ("ttr_result_text", C.c_char_p, [_VP, _I]),
+    ("ttr_result_bbox", _PF, [_VP, _I]),
+    ("ttr_result_ids", _PI, [_VP, _I]),
+    ("ttr_result_free", None, [_VP]),
+    ("ttr_craft_heatmap", _I, [_VP, _PU8, _I, _I, _PF]),
+    ("ttr_ccl_boxes", _I, [_VP, _PF, _I, _I, _PF, _I, _PI]),
+    ("ttr_resize_canvas", _I, [_VP, _PU8, _I, _I, _I, _PU8, C.c_size_t, _PI, _PI, _PF]),
+    ("ttr_pack_crops", _I, [_VP, _PU8, _I, _I, _I, _PF, _I, _F, _PU8, _PF]),
+    ("ttr_parseq_logits", _I, [_VP, _PU8, _I, _PF, _PF, _PI]),
+    ("ttr_decode_ids", _I, [_PI, _I, C.c_char_p]),
+    ("ttr_dbg_conv", _I, [_VP, _PF, _I, _PF, _I, _I, _I, _I, _I, _I, _I, _I, _PF, _PF, _I, _I, _PF]),
+    ("ttr_dbg_min_area_rect", _I, [_PF, _I, _PF]),
+    ("ttr_dbg_component_rect", _I, [_I, _I, _I, _I, _I, _PI, _I, _I, _PF]),
+    ("ttr_dbg_box_geometry", _I, [_PF, _F, _PF, _PI, _PF]),
+    ("ttr_dev_alloc", _VP, [C.c_size_t]),
+    ("ttr_dev_free", None, [_VP]),
+    ("ttr_dev_upload", _I, [_VP, _VP, C.c_size_t]),
+    ("ttr_dev_download", _I, [_VP, _VP, C.c_size_t]),
+    ("ttr_dev_sync", _I, [_VP]),
+    ("ttr_last_stage_ms", _I, [_VP, _PF]),
+]
+
+
+def lib_path() -> str:
+    return _LIBPATH
+
+
+def load():
+    """Load libtuatara_hip.so (no GPU needed for loading)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIBPATH):
+            raise RuntimeError(f"{_LIBPATH} is missing: run `python -m tuatara_amd.build` (or __graft_entry__.build()) first")
+        lib = C.CDLL(_LIBPATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _u8(a):
+    return a.ctypes.data_as(_PU8)
+
+
+def _f(a):
+    return a.ctypes.data_as(_PF)
+
+
+def _i(a):
+    return a.ctypes.data_as(_PI)
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def decode_ids(ids: Sequence[int]) -> str:
+    a = np.ascontiguousarray(ids, dtype=np.int32)
+    buf = C.create_string_buffer(len(a) + 2)
+    load().ttr_decode_ids(_i(a), len(a), buf)
+    return buf.value.decode("latin1")
+
+
+def min_area_rect(points) -> np.ndarray:
+    """Engine host geometry (no GPU): cv::minAreaRect stand-in."""
+    pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 2)
+    out = np.zeros(5, np.float32)
+    load().ttr_dbg_min_area_rect(_f(pts), len(pts), _f(out))
+    return out
+
+
+def component_rect(area: int, x0: int, y0: int, x1: int, y1: int, rows: np.ndarray, H: int, W: int):
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    out = np.zeros(5, np.float32)
+    ok = load().ttr_dbg_component_rect(area, x0, y0, x1, y1, _i(rows), H, W, _f(out))
+    return out if ok == 1 else None
+
+
+def box_geometry(rect5, ratio: float):
+    r = np.ascontiguousarray(rect5, dtype=np.float32)
+    adj, xywh, bbox = np.zeros(5, np.float32), np.zeros(4, np.int32), np.zeros(4, np.float32)
+    load().ttr_dbg_box_geometry(_f(r), C.c_float(ratio), _f(adj), _i(xywh), _f(bbox))
+    return adj, tuple(int(v) for v in xywh), [float(v) for v in bbox]
+
+
+class DeviceBuffer:
+    def __init__(self, nbytes: int):
+        self.ptr = load().ttr_dev_alloc(nbytes)
+        if not self.ptr:
+            raise EngineError("device allocation failed")
+        self.nbytes = nbytes
+
+    def upload(self, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        if load().ttr_dev_upload(self.ptr, arr.ctypes.data_as(C.c_void_p), arr.nbytes) != 0:
+            raise EngineError("upload failed")
+
+    def free(self):
+        if self.ptr:
+            load().ttr_dev_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    def __init__(self, weights_dir: str, precision: str = "bf16", device: int = 0, strict_crops: bool = False, **overrides):
+        self.lib = load()
+        cfg = Config()
+        self.lib.ttr_config_default(C.byref(cfg))
+        cfg.precision = PREC_F32 if precision in ("f32", "fp32", PREC_F32) else PREC_BF16
+        cfg.device = device
+        cfg.strict_crops = int(strict_crops)
+        for k, v in overrides.items():
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        self.h = self.lib.ttr_create(weights_dir.encode(), C.byref(cfg))
+        if not self.h:
+            raise EngineError(self.lib.ttr_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ttr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(self.lib.ttr_last_error().decode())
+
+    def _take(self, r) -> List[dict]:
+        out = []
+        for i in range(self.lib.ttr_result_count(r)):
+            bb = self.lib.ttr_result_bbox(r, i)
+            ids = self.lib.ttr_result_ids(r, i)
+            out.append({"text": self.lib.ttr_result_text(r, i).decode("latin1"), "bbox": [float(bb[j]) for j in range(4)],
+                        "ids": [int(ids[j]) for j in range(26)]})
+        self.lib.ttr_result_free(r)
+        return out
+
+    # ---- hot path
+    def image_to_data(self, image: np.ndarray) -> List[dict]:
+        if image.ndim != 3:
+            raise RuntimeError("Input array should have 3 dimensions")
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        r = C.c_void_p()
+        self._check(self.lib.ttr_image_to_data(self.h, _u8(image), image.shape[0], image.shape[1], image.shape[1] * 3, C.byref(r)))
+        return self._take(r)
+
+    def pages_to_data_dev(self, d_pages, n: int, h: int, w: int, keep: bool = True):
+        """d_pages: DeviceBuffer or raw device pointer holding [n][h][w][3] u8."""
+        ptr = d_pages.ptr if isinstance(d_pages, DeviceBuffer) else d_pages
+        arr = (C.c_void_p * n)()
+        self._check(self.lib.ttr_pages_to_data_dev(self.h, ptr, n, h, w, arr))
+        if keep:
+            return [self._take(arr[i]) for i in range(n)]
+        counts = []
+        for i in range(n):
+            counts.append(self.lib.ttr_result_count(arr[i]))
+            self.lib.ttr_result_free(arr[i])
+        return counts
+
+    def last_stage_ms(self):
+        ms = (C.c_float * 4)()
+        self.lib.ttr_last_stage_ms(self.h, ms)
+        return dict(craft=ms[0], post=ms[1], pack=ms[2], parseq=ms[3])
+
+    # ---- stages
+    def craft_heatmap(self, canvas: np.ndarray) -> np.ndarray:
+        canvas = np.ascontiguousarray(canvas, dtype=np.uint8)
+        H, W = canvas.shape[:2]
+        heat = np.zeros((H // 2, W // 2, 2), np.float32)
+        self._check(self.lib.ttr_craft_heatmap(self.h, _u8(canvas), H, W, _f(heat)))
+        return heat
+
+    def ccl_boxes(self, heat: np.ndarray, max_rects: int = 8192) -> np.ndarray:
+        heat = np.ascontiguousarray(heat, dtype=np.float32)
+        H2, W2 = heat.shape[:2]
+        rects = np.zeros((max_rects, 5), np.float32)
+        n = C.c_int32()
+        self._check(self.lib.ttr_ccl_boxes(self.h, _f(heat), H2, W2, _f(rects), max_rects, C.byref(n)))
+        return rects[: n.value].copy()
+
+    def resize_canvas(self, image: np.ndarray):
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        cap = 1056 * 1056 * 3 * 4
+        buf = np.zeros(cap, np.uint8)
+        H, W, ratio = C.c_int32(), C.c_int32(), C.c_float()
+        self._check(self.lib.ttr_resize_canvas(self.h, _u8(image), image.shape[0], image.shape[1], image.shape[1] * 3, _u8(buf), cap,
+                                               C.byref(H), C.byref(W), C.byref(ratio)))
+        return buf[: H.value * W.value * 3].reshape(H.value, W.value, 3).copy(), ratio.value
+
+    def pack_crops(self, image: np.ndarray, rects: np.ndarray, ratio: float):
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        rects = np.ascontiguousarray(rects, dtype=np.float32).reshape(-1, 5)
+        n = len(rects)
+        crops = np.zeros((n, 32, 128, 3), np.uint8)
+        boxes = np.zeros((n, 5), np.float32)
+        self._check(self.lib.ttr_pack_crops(self.h, _u8(image), image.shape[0], image.shape[1], image.shape[1] * 3, _f(rects), n,
+                                            C.c_float(ratio), _u8(crops), _f(boxes)))
+        return crops, boxes
+
+    def parseq_logits(self, crops: np.ndarray, want_ar: bool = False):
+        crops = np.ascontiguousarray(crops, dtype=np.uint8)
+        n = len(crops)
+        logits = np.zeros((n, 26, 95), np.float32)
+        ar = np.zeros((n, 26, 95), np.float32) if want_ar else None
+        ids = np.zeros((n, 26), np.int32)
+        self._check(self.lib.ttr_parseq_logits(self.h, _u8(crops), n, _f(logits), _f(ar) if want_ar else None, _i(ids)))
+        return (logits, ar, ids) if want_ar else (logits, ids)
+
+    def dbg_conv(self, x0: np.ndarray, w: np.ndarray, bias: Optional[np.ndarray], ks: int, dil: int = 1, act: int = 0,
+                 x1: Optional[np.ndarray] = None, relu0: bool = False, relu1: bool = False) -> np.ndarray:
+        """x0 f32 NHWC [B,H,W,C0], w f32 [Cout,ks,ks,C0+C1] -> f32 NHWC [B,H,W,Cout]."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float32)
+        B, H, W_, C0 = x0.shape
+        C1 = 0
+        if x1 is not None:
+            x1 = np.ascontiguousarray(x1, dtype=np.float32)
+            C1 = x1.shape[-1]
+        w = np.ascontiguousarray(w, dtype=np.float32)
+        Cout = w.shape[0]
+        out = np.zeros((B, H, W_, Cout), np.float32)
+        b = np.ascontiguousarray(bias, dtype=np.float32) if bias is not None else None
+        self._check(self.lib.ttr_dbg_conv(self.h, _f(x0), C0, _f(x1) if x1 is not None else None, C1, int(relu0), int(relu1), B, H, W_, ks, dil,
+                                          _f(w), _f(b) if b is not None else None, Cout, act, _f(out)))
+        return out
