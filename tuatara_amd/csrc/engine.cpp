@@ -156,6 +156,33 @@ struct Engine {
   std::vector<std::unique_ptr<PageCcl>> ccl;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   float stage_ms[4] = {0, 0, 0, 0};
+  // optional per-launch timing of the igemm kernel (bench.py's roofline): events bracket every launch
+  bool profiling = false;
+  int prof_stage = 0;                                  // 0 = CRAFT convs, 1 = PARSeq GEMMs
+  std::vector<hipEvent_t> prof_pool;
+  struct ProfRec { int stage; double flops; };
+  std::vector<ProfRec> prof_recs;
+  double prof_ms[2] = {0, 0}, prof_flops[2] = {0, 0};
+  long prof_launches[2] = {0, 0};
+
+  void igemm(const ConvParams& p, double true_flops) {
+    if (!profiling) { launch_igemm(prec, p, stream); return; }
+    const size_t i = prof_recs.size();
+    while (prof_pool.size() < 2 * (i + 1)) { hipEvent_t e; TTR_HIP_CHECK(hipEventCreate(&e)); prof_pool.push_back(e); }
+    TTR_HIP_CHECK(hipEventRecord(prof_pool[2 * i], stream));
+    launch_igemm(prec, p, stream);
+    TTR_HIP_CHECK(hipEventRecord(prof_pool[2 * i + 1], stream));
+    prof_recs.push_back(ProfRec{prof_stage, true_flops});
+  }
+  void prof_collect() {  // after a stream sync
+    for (size_t i = 0; i < prof_recs.size(); ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, prof_pool[2 * i], prof_pool[2 * i + 1]) == hipSuccess) {
+        prof_ms[prof_recs[i].stage] += ms; prof_flops[prof_recs[i].stage] += prof_recs[i].flops; prof_launches[prof_recs[i].stage]++;
+      }
+    }
+    prof_recs.clear();
+  }
 
   // ---- construction
   void upload_linear(Linear& L, const float* w, int cout, int k, const float* bias, int cout_pad, int k_pad,
@@ -296,6 +323,7 @@ struct Engine {
   }
   ~Engine() {
     for (auto& x : ev) if (x) (void)hipEventDestroy(x);
+    for (auto& x : prof_pool) (void)hipEventDestroy(x);
     if (stream) (void)hipStreamDestroy(stream);
   }
 
@@ -319,12 +347,15 @@ struct Engine {
     p.wgt = L.w.p; p.bias = L.b.as<float>();
     p.out = out; p.out_ld = L.cout; p.out_f32 = out_f32; p.out_f32_ld = L.cout;
     p.Cout = L.cout; p.M = B * H * W; p.act = act;
-    launch_igemm(prec, p, stream);
+    double flops = 0;   // algorithmic: 2 * M * Cout * K of the *unpadded* layer
+    for (const auto& c : craft_convs()) if (std::string(c.name) == name) flops = 2.0 * p.M * c.cout * c.ks * c.ks * c.cin;
+    igemm(p, flops);
   }
 
   // canvas u8 [B][H][W][3] (device) -> heat f32 [B][H/2][W/2][2] (device)
   void craft_forward(const uint8_t* d_canvas, int B, int H, int W, float* d_heat) {
     if (H % 32 || W % 32) throw std::runtime_error("CRAFT canvas must be a multiple of 32");
+    prof_stage = 0;
     const size_t M0 = (size_t)B * H * W, M1 = M0 / 4, M2 = M1 / 4, M3 = M2 / 4, M4 = M3 / 4;
     const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8, H4 = H / 16, W4 = W / 16;
     size_t k = 0;
@@ -377,7 +408,7 @@ struct Engine {
     p.out = out; p.out_ld = out_ld; p.out_f32 = out_f32; p.out_f32_ld = out_f32_ld;
     p.resid = resid; p.resid_ld = resid_ld; p.resid_mod = resid_mod;
     p.Cout = L.cout; p.M = M; p.act = act;
-    launch_igemm(prec, p, stream);
+    igemm(p, 2.0 * M * L.cout * L.k);
   }
   void ln(const float* x, const std::string& name, float eps, void* out, int M) {
     launch_layernorm(prec, x, 384, pqf.at(name + ".weight").as<float>(), pqf.at(name + ".bias").as<float>(), eps, out, 384, M, 384, stream);
@@ -404,6 +435,7 @@ struct Engine {
   // crops u8 [N][32][128][3] (device) -> logits f32 [N][26][95], ids i32 [N][26] (device); d_ar optional
   void parseq_forward(const uint8_t* d_crops, int N, float* d_logits, float* d_ar, int* d_ids) {
     if (N <= 0) return;
+    prof_stage = 1;
     const int M = N * 128, E = 384;
     void* patches = (pq_ws[0].ensure((size_t)M * 96 * es), pq_ws[0].p);
     float* x = (float*)(pq_ws[1].ensure((size_t)M * E * 4), pq_ws[1].p);
@@ -556,6 +588,7 @@ struct Engine {
     }
     TTR_HIP_CHECK(hipStreamSynchronize(stream));
     for (int s = 0; s < 4; ++s) (void)hipEventElapsedTime(&stage_ms[s], ev[s], ev[s + 1]);
+    if (profiling) prof_collect();
     std::vector<int> k_of(n, 0);
     for (int c = 0; c < N; ++c) {
       int pg = page_of[c];
@@ -818,6 +851,20 @@ void ttr_dev_free(void* p) { if (p) (void)hipFree(p); }
 int ttr_dev_upload(void* dst, const void* src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1; }
 int ttr_dev_download(void* dst, const void* src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
 int ttr_dev_sync(ttr_engine* e) { return hipStreamSynchronize(e->e->stream) == hipSuccess ? 0 : -1; }
+int ttr_set_profiling(ttr_engine* e, int on) {
+  Engine& E = *e->e;
+  std::lock_guard<std::mutex> lk(E.mu);
+  E.profiling = on != 0;
+  E.prof_recs.clear();
+  for (int i = 0; i < 2; ++i) { E.prof_ms[i] = 0; E.prof_flops[i] = 0; E.prof_launches[i] = 0; }
+  return 0;
+}
+int ttr_get_profile(ttr_engine* e, double ms[2], double flops[2], long long launches[2]) {
+  Engine& E = *e->e;
+  std::lock_guard<std::mutex> lk(E.mu);
+  for (int i = 0; i < 2; ++i) { ms[i] = E.prof_ms[i]; flops[i] = E.prof_flops[i]; launches[i] = E.prof_launches[i]; }
+  return 0;
+}
 int ttr_last_stage_ms(ttr_engine* e, float ms[4]) { memcpy(ms, e->e->stage_ms, sizeof(float) * 4); return 0; }
 
 }  // extern "C"

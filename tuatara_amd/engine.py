@@ -56,6 +56,8 @@ SYMBOLS = [
     ("ttr_dev_download", _I, [_VP, _VP, C.c_size_t]),
     ("ttr_dev_sync", _I, [_VP]),
     ("ttr_last_stage_ms", _I, [_VP, _PF]),
+    ("ttr_set_profiling", _I, [_VP, _I]),
+    ("ttr_get_profile", _I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
 ]
 
 
@@ -214,6 +216,14 @@ class Engine:
         ms = (C.c_float * 4)()
         self.lib.ttr_last_stage_ms(self.h, ms)
         return dict(craft=ms[0], post=ms[1], pack=ms[2], parseq=ms[3])
+
+    def set_profiling(self, on: bool):
+        self.lib.ttr_set_profiling(self.h, int(on))
+
+    def get_profile(self):
+        ms, fl, n = (C.c_double * 2)(), (C.c_double * 2)(), (C.c_longlong * 2)()
+        self.lib.ttr_get_profile(self.h, ms, fl, n)
+        return {"craft": dict(ms=ms[0], flops=fl[0], launches=n[0]), "parseq": dict(ms=ms[1], flops=fl[1], launches=n[1])}
 
     # ---- stages
     def craft_heatmap(self, canvas: np.ndarray) -> np.ndarray:
