@@ -91,6 +91,15 @@ int ttr_decode_ids(const int32_t* ids, int n, char* buf);
 int ttr_dbg_conv(ttr_engine* e, const float* in0, int C0, const float* in1, int C1, int relu0, int relu1, int B, int H, int W,
                  int ks, int dil, const float* wgt, const float* bias, int Cout, int act, float* out);
 
+/* Which kernel serves bf16 layers: -1 = first-generation igemm only, 0 = automatic (default),
+ * 1..6 = force that gemm2 tile configuration where it applies.  Process-wide; for tuning and tests. */
+void ttr_set_gemm_config(int cfg);
+/* Times one conv / linear layer on device-generated random data (no host traffic): average
+ * microseconds per launch over `iters` back-to-back launches.  f32_resid != 0 selects the PARSeq
+ * residual form (f32 residual in, f32 out) instead of a bf16/T output. */
+int ttr_bench_conv(ttr_engine* e, int B, int H, int W, int C0, int C1, int ks, int dil, int Cout, int act, int f32_resid,
+                   int iters, float* avg_us);
+
 /* ---- host-side geometry hooks (no GPU touched; used by the CPU test-suite) -------------------- */
 /* cv::minAreaRect stand-in used at tuatara.cpp:179,:248: n points (x,y) float32 -> {cx,cy,w,h,angle}. */
 int ttr_dbg_min_area_rect(const float* xy, int n, float* rect5);

@@ -71,3 +71,51 @@ def test_conv_identity_asymmetric(eng_f32):
     w = np.arange(K * K, dtype=np.float32).reshape(K, 1, 1, K) / 100.0
     got = eng_f32.dbg_conv(x, w, None, 1)
     assert np.array_equal(got[0, 0], w.reshape(K, K).T)
+
+
+# ---- gemm2.hip (LDS-DMA staged bf16 kernel): every tile configuration, same reference
+G2_CASES = [
+    # B, H, W, C0, C1, Cout, ks, dil, act
+    (1, 20, 24, 64, 0, 64, 3, 1, 1),
+    (2, 13, 17, 128, 0, 136, 3, 1, 0),      # ragged M, ragged Cout, halos at the batch boundary
+    (1, 16, 20, 64, 0, 256, 3, 6, 0),       # dilation 6 (slice5.1)
+    (1, 9, 31, 128, 64, 128, 1, 1, 1),      # virtual concat 1x1 (up-blocks)
+    (1, 12, 12, 64, 64, 72, 3, 1, 2),       # concat + 3x3 + GELU
+    (1, 1, 700, 384, 0, 1152, 1, 1, 0),     # PARSeq qkv shape
+    (1, 1, 300, 1536, 0, 384, 1, 1, 2),     # PARSeq fc2 shape (+GELU)
+]
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("case", G2_CASES)
+def test_gemm2_configs(eng_bf16, case, cfg):
+    B, H, W, C0, C1, Cout, ks, dil, act = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    bf = lambda a: torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy()
+    x0 = bf(rng.standard_normal((B, H, W, C0)).astype(np.float32))
+    x1 = bf(rng.standard_normal((B, H, W, C1)).astype(np.float32)) if C1 else None
+    w = bf((rng.standard_normal((Cout, ks, ks, C0 + C1)) / np.sqrt(ks * ks * (C0 + C1))).astype(np.float32))
+    b = rng.standard_normal(Cout).astype(np.float32)
+    ref = _ref_conv(x0, w, b, ks, dil, act, x1)
+    try:
+        eng_bf16.lib.ttr_set_gemm_config(cfg)
+        got = eng_bf16.dbg_conv(x0, w, b, ks, dil, act, x1=x1)
+    finally:
+        eng_bf16.lib.ttr_set_gemm_config(0)
+    assert np.abs(got - ref).max() < 2e-4
+
+
+def test_gemm2_matches_first_generation_kernel(eng_bf16):
+    """Same bf16 inputs, fp32 accumulation in both kernels: results agree to summation-order noise."""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((1, 40, 36, 128)).astype(np.float32)
+    w = (rng.standard_normal((256, 3, 3, 128)) / 34.0).astype(np.float32)
+    b = rng.standard_normal(256).astype(np.float32)
+    try:
+        eng_bf16.lib.ttr_set_gemm_config(-1)
+        old = eng_bf16.dbg_conv(x, w, b, 3, 1, 1)
+        eng_bf16.lib.ttr_set_gemm_config(0)
+        new = eng_bf16.dbg_conv(x, w, b, 3, 1, 1)
+    finally:
+        eng_bf16.lib.ttr_set_gemm_config(0)
+    assert np.abs(old - new).max() < 1e-4

@@ -24,6 +24,7 @@ struct ConvParams {
   const float* bias;         // f32 [Cout] or null
   void* out; int out_ld;     // T output, row stride in elements (may be null)
   float* out_f32; int out_f32_ld;  // optional f32 output
+  void* out_relu;            // optional second T output (row stride out_ld): max(value, 0) of what `out` receives
   const float* resid; int resid_ld; int resid_mod;  // f32 residual added before act; row = m % resid_mod if resid_mod
   int Cout, M, act;
 };

@@ -335,7 +335,7 @@ struct Engine {
   }
 
   void conv(const char* name, const void* in0, int C0, const void* in1, int C1, int relu0, int B, int H, int W, void* out, int act,
-            float* out_f32 = nullptr) {
+            float* out_f32 = nullptr, void* out_relu = nullptr) {
     const Linear& L = craft.at(name);
     ConvParams p{};
     p.in0 = in0; p.C0 = C0; p.in1 = in1; p.C1 = C1; p.relu0 = relu0; p.relu1 = 0;
@@ -345,7 +345,7 @@ struct Engine {
     if (L.k != p.ks * p.ks * Ct) throw std::runtime_error(std::string("conv shape mismatch at ") + name);
     p.dil = std::string(name) == "slice5.1" ? 6 : 1;
     p.wgt = L.w.p; p.bias = L.b.as<float>();
-    p.out = out; p.out_ld = L.cout; p.out_f32 = out_f32; p.out_f32_ld = L.cout;
+    p.out = out; p.out_ld = L.cout; p.out_f32 = out_f32; p.out_f32_ld = L.cout; p.out_relu = out_relu;
     p.Cout = L.cout; p.M = B * H * W; p.act = act;
     double flops = 0;   // algorithmic: 2 * M * Cout * K of the *unpadded* layer
     for (const auto& c : craft_convs()) if (std::string(c.name) == name) flops = 2.0 * p.M * c.cout * c.ks * c.ks * c.cin;
@@ -369,12 +369,14 @@ struct Engine {
     void* c22 = buf(M1, 128); conv("slice1.10", c21, 128, nullptr, 0, 0, B, H1, W1, c22, kActNone);   // relu2_2 skip (pre-ReLU)
     void* p2 = buf(M2, 128);  launch_maxpool2x2(prec, c22, p2, B, H1, W1, 128, 1, stream);
     void* c31 = buf(M2, 256); conv("slice2.14", p2, 128, nullptr, 0, 0, B, H2, W2, c31, kActRelu);
-    void* c32 = buf(M2, 256); conv("slice2.17", c31, 256, nullptr, 0, 0, B, H2, W2, c32, kActNone);   // relu3_2 skip
-    void* c33 = buf(M2, 256); conv("slice3.20", c32, 256, nullptr, 0, 1, B, H2, W2, c33, kActRelu);
+    void* c32 = buf(M2, 256); void* c32r = buf(M2, 256);
+    conv("slice2.17", c31, 256, nullptr, 0, 0, B, H2, W2, c32, kActNone, nullptr, c32r);                // relu3_2 skip (pre-ReLU) + its ReLU
+    void* c33 = buf(M2, 256); conv("slice3.20", c32r, 256, nullptr, 0, 0, B, H2, W2, c33, kActRelu);
     void* p3 = buf(M3, 256);  launch_maxpool2x2(prec, c33, p3, B, H2, W2, 256, 0, stream);
     void* c41 = buf(M3, 512); conv("slice3.24", p3, 256, nullptr, 0, 0, B, H3, W3, c41, kActRelu);
-    void* c42 = buf(M3, 512); conv("slice3.27", c41, 512, nullptr, 0, 0, B, H3, W3, c42, kActNone);   // relu4_3 skip
-    void* c43 = buf(M3, 512); conv("slice4.30", c42, 512, nullptr, 0, 1, B, H3, W3, c43, kActRelu);
+    void* c42 = buf(M3, 512); void* c42r = buf(M3, 512);
+    conv("slice3.27", c41, 512, nullptr, 0, 0, B, H3, W3, c42, kActNone, nullptr, c42r);                // relu4_3 skip + its ReLU
+    void* c43 = buf(M3, 512); conv("slice4.30", c42r, 512, nullptr, 0, 0, B, H3, W3, c43, kActRelu);
     void* p4 = buf(M4, 512);  launch_maxpool2x2(prec, c43, p4, B, H3, W3, 512, 0, stream);
     void* c51 = buf(M4, 512); conv("slice4.34", p4, 512, nullptr, 0, 0, B, H4, W4, c51, kActRelu);
     void* c52 = buf(M4, 512); conv("slice4.37", c51, 512, nullptr, 0, 0, B, H4, W4, c52, kActNone);   // relu5_3 skip
@@ -809,6 +811,44 @@ int ttr_dbg_conv(ttr_engine* e, const float* in0, int C0, const float* in1, int 
   launch_igemm(E.prec, p, E.stream);
   TTR_HIP_CHECK(hipMemcpyAsync(out, dout.p, M * Cout * 4, hipMemcpyDeviceToHost, E.stream));
   TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
+  return 0;
+  TTR_GUARD_END(-1)
+}
+
+void ttr_set_gemm_config(int cfg) { set_gemm_config(cfg); }
+
+int ttr_bench_conv(ttr_engine* e, int B, int H, int W, int C0, int C1, int ks, int dil, int Cout, int act, int f32_resid, int iters, float* avg_us) {
+  TTR_GUARD_BEGIN
+  Engine& E = *e->e;
+  std::lock_guard<std::mutex> lk(E.mu);
+  const size_t M = (size_t)B * H * W;
+  const int K = ks * ks * (C0 + C1);
+  DevBuf d0, d1, dw, db, dout, dres;
+  d0.ensure(M * C0 * E.es); launch_fill_random(E.prec, d0.p, M * C0, 1u, 1.0f, E.stream);
+  if (C1) { d1.ensure(M * C1 * E.es); launch_fill_random(E.prec, d1.p, M * C1, 2u, 1.0f, E.stream); }
+  dw.ensure((size_t)Cout * K * E.es); launch_fill_random(E.prec, dw.p, (size_t)Cout * K, 3u, 1.0f / std::sqrt((float)K), E.stream);
+  db.ensure((size_t)Cout * 4); launch_fill_random(kF32, db.p, Cout, 4u, 1.0f, E.stream);
+  ConvParams p{};
+  p.in0 = d0.p; p.C0 = C0; p.in1 = C1 ? d1.p : nullptr; p.C1 = C1;
+  p.B = B; p.H = H; p.W = W; p.ks = ks; p.dil = dil; p.wgt = dw.p; p.bias = db.as<float>();
+  p.Cout = Cout; p.M = (int)M; p.act = act;
+  if (f32_resid) {   // the PARSeq residual-stream form: f32 in, f32 out
+    dres.ensure(M * Cout * 4); launch_fill_random(kF32, dres.p, M * Cout, 5u, 1.0f, E.stream);
+    p.out_f32 = dres.as<float>(); p.out_f32_ld = Cout; p.resid = dres.as<float>(); p.resid_ld = Cout;
+  } else {
+    dout.ensure(M * Cout * E.es); p.out = dout.p; p.out_ld = Cout;
+  }
+  for (int i = 0; i < 2; ++i) launch_igemm(E.prec, p, E.stream);
+  hipEvent_t a, b;
+  TTR_HIP_CHECK(hipEventCreate(&a)); TTR_HIP_CHECK(hipEventCreate(&b));
+  TTR_HIP_CHECK(hipEventRecord(a, E.stream));
+  for (int i = 0; i < iters; ++i) launch_igemm(E.prec, p, E.stream);
+  TTR_HIP_CHECK(hipEventRecord(b, E.stream));
+  TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
+  float ms = 0.f;
+  TTR_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  *avg_us = ms * 1e3f / iters;
   return 0;
   TTR_GUARD_END(-1)
 }

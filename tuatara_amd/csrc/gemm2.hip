@@ -1,0 +1,318 @@
+// bf16 implicit-GEMM convolution / linear kernel, second generation (gfx950 / MI355X).
+//
+//   out[m][n] = act( sum_k X[m][k] * Wt[n][k] + bias[n] (+ resid) )
+//
+// Same contract as igemm.hip (ConvParams; replaces the LibTorch conv/linear calls inside the
+// TorchScript modules run at tuatara.cpp:376 and tuatara.cpp:307) but built around the
+// CDNA4 LDS-DMA path:
+//   * both operand tiles go global -> LDS with `buffer_load_dwordx4 ... lds` (no VGPR staging,
+//     no ds_write); the conv halo, ragged M and ragged Cout are zero-filled by the buffer
+//     resource's out-of-range rule (voffset 0x80000000), so there is no branch in the loader;
+//   * BK = 64 (one full 128-byte line per tile row), two LDS stages, ONE barrier per K step:
+//     tile t+1 streams in while tile t is multiplied;
+//   * the LDS image is lane-linear per wave instruction (8 rows x 128 B); bank conflicts are
+//     removed by permuting the 16-byte chunks of each row on the *source* side
+//     (chunk ^= (row>>1)&7) and applying the same XOR on the ds_read_b128 side;
+//   * the MFMA is issued transposed (A = weights, B = activations) so that a lane ends up
+//     holding 4 consecutive output channels of one pixel; weight rows are permuted while
+//     staging so two adjacent MFMA tiles give 8 consecutive channels -> one 16-byte store;
+//   * XCD-aware tile order (bijective remap): the N tiles of an M tile and neighbouring M
+//     tiles run on one XCD and share its L2.
+#include <algorithm>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace ttr {
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+// erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7): plenty for a bf16 result
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float e = 1.0f - poly * __expf(-z * z);
+  return 0.5f * x * (1.0f + copysignf(e, x));
+}
+
+template <int BM, int BN, int WM, int WN>
+struct G2Cfg {
+  static constexpr int NW = WM * WN, NT = NW * 64;
+  static constexpr int TM = BM / WM, TN = BN / WN;   // wave tile
+  static constexpr int MI = TM / 16, NJ = TN / 16;
+  static constexpr int XP = BM / 8, WP = BN / 8;     // 1-KiB pieces (8 rows x 128 B) per operand tile
+  static constexpr int XPW = XP / NW, WPW = WP / NW;  // pieces per wave
+  static constexpr int STAGE = (BM + BN) * 128;
+  static constexpr int LDS = 2 * STAGE;
+  static_assert(XP % NW == 0 && WP % NW == 0, "tile pieces must divide over the waves");
+  static_assert(TN % 32 == 0 && TM % 16 == 0, "wave tile");
+};
+
+template <int BM, int BN, int WM, int WN, int MINB>
+__global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p) {
+  using C = G2Cfg<BM, BN, WM, WN>;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  // ---- XCD-aware tile order
+  const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
+  const int T = tilesM * tilesN;
+  int tile;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    const int q = T >> 3, r = T & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = tile / tilesN, tn = tile - tm * tilesN;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int Ctot = p.C0 + p.C1;
+  const int K = p.ks * p.ks * Ctot;
+  const int nk = K >> 6;
+  const int HW = p.H * p.W;
+
+  const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(p.in0, (unsigned)((size_t)p.M * p.C0 * 2));
+  const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(p.C1 ? p.in1 : p.in0, (unsigned)((size_t)p.M * (p.C1 ? p.C1 : p.C0) * 2));
+  const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.wgt, (unsigned)((size_t)p.Cout * K * 2));
+  constexpr unsigned OOB = 0x80000000u;
+
+  // ---- per-lane loader state.  Piece q = i*NW + wave covers tile rows 8q..8q+7; this lane owns
+  // row 8q + (lane>>3) and LDS chunk (lane&7), which holds global chunk (lane&7) ^ ((row>>1)&7).
+  unsigned xb0[C::XPW], xb1[C::XPW];   // byte offset of (pixel, chunk) in source 0 / 1
+  unsigned xmask[C::XPW];              // bit t: tap t stays inside the image (bit 0 only for 1x1)
+#pragma unroll
+  for (int i = 0; i < C::XPW; ++i) {
+    const int row = (i * C::NW + wave) * 8 + (lane >> 3);
+    const int g = (lane & 7) ^ ((row >> 1) & 7);
+    const int m = m0 + row;
+    unsigned mask = 0;
+    if (m < p.M) {
+      if (p.ks == 3) {
+        const int r = m % HW, y = r / p.W, x = r - y * p.W;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int yy = y + (t / 3 - 1) * p.dil, xx = x + (t % 3 - 1) * p.dil;
+          if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) mask |= 1u << t;
+        }
+      } else mask = 1u;
+    }
+    xmask[i] = mask;
+    xb0[i] = ((unsigned)m * (unsigned)p.C0 + g * 8) * 2u;
+    xb1[i] = ((unsigned)m * (unsigned)p.C1 + g * 8) * 2u;
+  }
+  unsigned wb[C::WPW];                 // byte offset of (weight row, chunk), or OOB
+#pragma unroll
+  for (int j = 0; j < C::WPW; ++j) {
+    const int piece = j * C::NW + wave;
+    const int row = piece * 8 + (lane >> 3);       // LDS row of the weight tile
+    const int g = (lane & 7) ^ ((row >> 1) & 7);
+    const int q16 = row & 15;
+    const int nl = (row & ~31) + (q16 >> 2) * 8 + ((row >> 4) & 1) * 4 + (q16 & 3);   // channel held by that LDS row
+    const int n = n0 + nl;
+    wb[j] = (n < p.Cout) ? ((unsigned)n * (unsigned)K + g * 8) * 2u : OOB;
+  }
+
+  int tap = 0, cc = 0;   // K cursor of the next tile to stage
+  auto stage_tile = [&](int buf) {
+    unsigned char* sb = smem + buf * C::STAGE;
+    const bool s1 = cc >= p.C0;
+    int dpix = 0;
+    if (p.ks == 3) { const int ky = tap / 3, kx = tap - ky * 3; dpix = ((ky - 1) * p.W + (kx - 1)) * p.dil; }
+    const int Cs = s1 ? p.C1 : p.C0;
+    const unsigned soff = (unsigned)((dpix * Cs + (s1 ? cc - p.C0 : cc)) * 2);
+    const unsigned bit = 1u << tap;
+#pragma unroll
+    for (int i = 0; i < C::XPW; ++i) {
+      const unsigned vo = (xmask[i] & bit) ? (s1 ? xb1[i] : xb0[i]) + soff : OOB;
+      lds_ptr dst = (lds_ptr)(sb + (i * C::NW + wave) * 1024);
+      if (s1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, vo, 0, 0, 0);
+      else    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, vo, 0, 0, 0);
+    }
+    const unsigned koff = (unsigned)((tap * Ctot + cc) * 2);
+#pragma unroll
+    for (int j = 0; j < C::WPW; ++j) {
+      const unsigned vo = wb[j] == OOB ? OOB : wb[j] + koff;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sb + BM * 128 + (j * C::NW + wave) * 1024), 16, vo, 0, 0, 0);
+    }
+    cc += 64;
+    if (cc == Ctot) { cc = 0; ++tap; }
+  };
+
+  f32x4 acc[C::NJ][C::MI];
+#pragma unroll
+  for (int j = 0; j < C::NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < C::MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addressing: row = tile-aligned base + (lane&15), so (row>>1)&7 == (lane>>1)&7
+  const int frag_lane = (lane & 15) * 128 + ((((lane >> 4)) ^ ((lane >> 1) & 7)) << 4);
+  const unsigned char* xfrag[2];
+  const unsigned char* wfrag[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    xfrag[kk] = smem + wm * C::TM * 128 + (frag_lane ^ (kk * 64));
+    wfrag[kk] = smem + BM * 128 + wn * C::TN * 128 + (frag_lane ^ (kk * 64));
+  }
+
+  stage_tile(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int so = (kt & 1) * C::STAGE;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of tile kt have landed
+    __builtin_amdgcn_s_barrier();                      // everyone's have; everyone is done reading the other stage
+    // all fragment reads of this K step are issued up front (their latency hides behind the
+    // loader's address arithmetic), then the MFMAs run back to back
+    bf16x8 fx[2][C::MI], fw[2][C::NJ];
+#pragma unroll
+    for (int j = 0; j < C::NJ; ++j) fw[0][j] = *reinterpret_cast<const bf16x8*>(wfrag[0] + so + j * 2048);
+#pragma unroll
+    for (int i = 0; i < C::MI; ++i) fx[0][i] = *reinterpret_cast<const bf16x8*>(xfrag[0] + so + i * 2048);
+    if (kt + 1 < nk) stage_tile((kt & 1) ^ 1);
+#pragma unroll
+    for (int j = 0; j < C::NJ; ++j) fw[1][j] = *reinterpret_cast<const bf16x8*>(wfrag[1] + so + j * 2048);
+#pragma unroll
+    for (int i = 0; i < C::MI; ++i) fx[1][i] = *reinterpret_cast<const bf16x8*>(xfrag[1] + so + i * 2048);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+        for (int j = 0; j < C::NJ; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[kk][j], fx[kk][i], acc[j][i], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // ---- epilogue: lane holds channels n = nb + 32t + (lane>>4)*8 + 0..7 of pixel m = mb + 16i + (lane&15)
+  const int fg = lane >> 4, fr = lane & 15;
+#pragma unroll
+  for (int t = 0; t < C::NJ / 2; ++t) {
+    const int n = n0 + wn * C::TN + t * 32 + fg * 8;
+    if (n >= p.Cout) continue;
+    float bv[8];
+    if (p.bias) {
+      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+      bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < C::MI; ++i) {
+      const int m = m0 + wm * C::TM + i * 16 + fr;
+      if (m >= p.M) continue;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = acc[2 * t][i][e] + bv[e]; v[4 + e] = acc[2 * t + 1][i][e] + bv[4 + e]; }
+      if (p.resid) {
+        const float* rp = p.resid + (int64_t)(p.resid_mod ? m % p.resid_mod : m) * p.resid_ld + n;
+        const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+      }
+      if (p.act == kActRelu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      } else if (p.act == kActGelu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+      }
+      if (p.out) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out) + (int64_t)m * p.out_ld + n) = o;
+      }
+      if (p.out_relu) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)fmaxf(v[e], 0.f);
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out_relu) + (int64_t)m * p.out_ld + n) = o;
+      }
+      if (p.out_f32) {
+        float* op = p.out_f32 + (int64_t)m * p.out_f32_ld + n;
+        *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int MINB>
+static void launch_g2(const ConvParams& p, hipStream_t s) {
+  using C = G2Cfg<BM, BN, WM, WN>;
+  const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
+  static bool once = false;
+  if (!once) {
+    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WM, WN, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+    once = true;
+  }
+  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM, WN, MINB>), dim3(tilesM * tilesN), dim3(C::NT), C::LDS, s, p);
+}
+
+const char* gemm2_check(const ConvParams& p) {
+  const int Ctot = p.C0 + p.C1;
+  if (p.ks != 1 && p.ks != 3) return "gemm2: ks must be 1 or 3";
+  if (Ctot % 64 || p.C0 % 64) return "gemm2: channel counts must be multiples of 64";
+  if (p.Cout % 8) return "gemm2: Cout must be a multiple of 8";
+  if (p.relu0 || p.relu1) return "gemm2: ReLU-on-load is not supported";
+  if (p.out && (p.out_ld % 8 || ((uintptr_t)p.out & 15))) return "gemm2: bf16 output must be 16-byte aligned";
+  if (p.out_relu && (!p.out || ((uintptr_t)p.out_relu & 15))) return "gemm2: out_relu needs out and 16-byte alignment";
+  if (p.out_f32 && (p.out_f32_ld % 4 || ((uintptr_t)p.out_f32 & 15))) return "gemm2: f32 output must be 16-byte aligned";
+  if (p.resid && (p.resid_ld % 4 || ((uintptr_t)p.resid & 15))) return "gemm2: residual must be 16-byte aligned";
+  if (p.bias && ((uintptr_t)p.bias & 15)) return "gemm2: bias must be 16-byte aligned";
+  if (((uintptr_t)p.in0 & 15) || ((uintptr_t)p.wgt & 15) || (p.C1 && ((uintptr_t)p.in1 & 15))) return "gemm2: operands must be 16-byte aligned";
+  const size_t lim = (size_t)1 << 31;   // buffer offsets: valid lanes < 2^31, 0x80000000 is the out-of-range marker
+  const int K = p.ks * p.ks * Ctot;
+  if ((size_t)p.M * p.C0 * 2 >= lim || (size_t)p.M * p.C1 * 2 >= lim || (size_t)p.Cout * K * 2 >= lim) return "gemm2: tensor too large for 32-bit buffer offsets";
+  if (p.M != p.B * p.H * p.W || p.M <= 0 || p.Cout <= 0) return "gemm2: bad shape";
+  return nullptr;
+}
+
+// cfg: 0 auto, 1 = 256x256/8w, 2 = 256x128/8w, 3 = 128x128/4w, 4 = 256x64/4w, 5 = 128x64/4w, 6 = 128x256/8w
+void launch_gemm2(const ConvParams& p, int cfg, hipStream_t s) {
+  if (const char* e = gemm2_check(p)) throw std::runtime_error(e);
+  if (cfg == 0) {   // measured on MI355X (tools/gemm_sweep.py, profiles/r01_gemm_sweep.txt)
+    if (p.Cout <= 64) cfg = 5;
+    else {
+      cfg = 3;
+      if (p.Cout % 256 == 0) {   // 256x256 tiles pay when they fill the 256 CUs evenly
+        const int64_t tiles = (int64_t)((p.M + 255) / 256) * (p.Cout / 256);
+        const double eff = (double)tiles / (double)(((tiles + 255) / 256) * 256);
+        if (tiles >= 1024 || (tiles <= 256 && eff >= 0.74) || eff >= 0.85) cfg = 1;
+      }
+    }
+  }
+  switch (cfg) {
+    case 1: return launch_g2<256, 256, 2, 4, 1>(p, s);
+    case 2: return launch_g2<256, 128, 4, 2, 1>(p, s);
+    case 3: return launch_g2<128, 128, 2, 2, 2>(p, s);
+    case 4: return launch_g2<256, 64, 4, 1, 2>(p, s);
+    case 5: return launch_g2<128, 64, 2, 2, 2>(p, s);
+    case 6: return launch_g2<128, 256, 2, 4, 1>(p, s);
+    default: throw std::runtime_error("gemm2: unknown configuration");
+  }
+}
+
+template <typename T>
+__global__ void fill_random_kernel(T* p, size_t n, unsigned seed, float scale) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u ^ (unsigned)(i >> 32) ^ (seed * 0x9E3779B9u);
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    p[i] = (T)(((float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale);
+  }
+}
+
+void launch_fill_random(Precision prec, void* p, size_t n, unsigned seed, float scale, hipStream_t s) {
+  if (n == 0) return;
+  const int grid = (int)std::min<size_t>((n + 255) / 256, 65536);
+  if (prec == kBF16) hipLaunchKernelGGL(fill_random_kernel<bf16>, dim3(grid), dim3(256), 0, s, (bf16*)p, n, seed, scale);
+  else hipLaunchKernelGGL(fill_random_kernel<float>, dim3(grid), dim3(256), 0, s, (float*)p, n, seed, scale);
+}
+
+}  // namespace ttr

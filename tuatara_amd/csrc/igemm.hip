@@ -209,6 +209,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvParams p) {
         if (p.act == kActRelu) v = fmaxf(v, 0.f);
         else if (p.act == kActGelu) v = gelu_exact(v);
         if (p.out) reinterpret_cast<T*>(p.out)[(int64_t)m * p.out_ld + n] = (T)v;
+        if (p.out_relu) reinterpret_cast<T*>(p.out_relu)[(int64_t)m * p.out_ld + n] = (T)fmaxf(v, 0.f);
         if (p.out_f32) p.out_f32[(int64_t)m * p.out_f32_ld + n] = v;
       }
     }
@@ -248,8 +249,13 @@ const char* igemm_check(const ConvParams& p) {
   return nullptr;
 }
 
+static int g_gemm_cfg = 0;
+void set_gemm_config(int cfg) { g_gemm_cfg = cfg; }
+int gemm_config() { return g_gemm_cfg; }
+
 void launch_igemm(Precision prec, const ConvParams& p, hipStream_t s) {
   if (const char* e = igemm_check(p)) throw std::runtime_error(e);
+  if (prec == kBF16 && g_gemm_cfg >= 0 && gemm2_check(p) == nullptr) return launch_gemm2(p, g_gemm_cfg, s);
   if (prec == kBF16) launch_t<bf16>(p, s); else launch_t<float>(p, s);
 }
 

@@ -8,6 +8,15 @@ namespace ttr {
 // ---- igemm.hip
 const char* igemm_check(const ConvParams& p);
 void launch_igemm(Precision prec, const ConvParams& p, hipStream_t s);
+// which kernel serves bf16 problems: -1 = igemm.hip only, 0 = automatic, 1..6 = force that gemm2 tile configuration
+void set_gemm_config(int cfg);
+int gemm_config();
+
+// ---- gemm2.hip (bf16, LDS-DMA staged)
+const char* gemm2_check(const ConvParams& p);   // nullptr when gemm2 can run the problem
+void launch_gemm2(const ConvParams& p, int cfg, hipStream_t s);
+// n pseudo-random values, uniform in [-scale, scale) (benchmark inputs)
+void launch_fill_random(Precision prec, void* p, size_t n, unsigned seed, float scale, hipStream_t s);
 
 // ---- craft_ops.hip
 // OpenCV-style 8-bit INTER_LINEAR resize of src[sh,sw,3] to [th,tw], zero pad to [H,W], optional channel swap.

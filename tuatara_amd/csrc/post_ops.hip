@@ -75,6 +75,14 @@ __device__ __forceinline__ int uf_find(int* parent, int i) {
   }
   return i;
 }
+// Read-only find for the passes that run after all unions are done.  (A halving find here could
+// overwrite another thread's final `parent[i] = root` store with a mere ancestor, and the passes
+// after this one treat parent[i] as the root: that lost pixels of a component once in a while.)
+__device__ __forceinline__ int uf_find_ro(const int* parent, int i) {
+  int p = uf_load(&parent[i]);
+  while (p != i) { i = p; p = uf_load(&parent[i]); }
+  return i;
+}
 __device__ __forceinline__ void uf_union(int* parent, int a, int b) {
   while (true) {
     a = uf_find(parent, a); b = uf_find(parent, b);
@@ -97,8 +105,8 @@ __global__ void ccl_merge_kernel(int* parent, int H, int W) {
 __global__ void ccl_flatten_stats_kernel(int* parent, int H, int W, const float* __restrict__ tnorm, int* area, int* bbox, unsigned* maxt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= H * W || parent[i] < 0) return;
-  int r = uf_find(parent, i);
-  __hip_atomic_store(&parent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // benign race: roots are fixed in this kernel
+  int r = uf_find_ro(parent, i);
+  __hip_atomic_store(&parent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // readers see the old ancestor or the root: both lead to r
   int x = i % W, y = i / W;
   atomicAdd(&area[r], 1);
   atomicMin(&bbox[4 * r], x); atomicMin(&bbox[4 * r + 1], y);
