@@ -94,6 +94,9 @@ int ttr_dbg_conv(ttr_engine* e, const float* in0, int C0, const float* in1, int 
 /* Which kernel serves bf16 layers: -1 = first-generation igemm only, 0 = automatic (default),
  * 1..6 = force that gemm2 tile configuration where it applies.  Process-wide; for tuning and tests. */
 void ttr_set_gemm_config(int cfg);
+/* PARSeq autoregressive loop in bf16 mode: 0 = one kernel per op (the f32 mode's schedule), 4 / 8 / 16 = the
+ * fused persistent kernel with that many crops per workgroup, anything else = automatic (default). */
+void ttr_set_decoder_mode(int mode);
 /* Times one conv / linear layer on device-generated random data (no host traffic): average
  * microseconds per launch over `iters` back-to-back launches.  f32_resid != 0 selects the PARSeq
  * residual form (f32 residual in, f32 out) instead of a bf16/T output. */

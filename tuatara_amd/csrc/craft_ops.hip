@@ -2,6 +2,8 @@
 // page resize/pad/channel-swap (tuatara.cpp:349, :206-234), first-layer im2col with
 // the /255 normalisation (:363-370), max-pools, bilinear x2 upsample and the heat-map
 // channel extraction (:393-394).  The convolutions themselves are igemm.hip.
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 #include "resize_dev.h"
@@ -56,6 +58,81 @@ void launch_im2col_l1(Precision prec, const uint8_t* canvas, void* out, int B, i
   dim3 grid((unsigned)((M + 255) / 256));
   if (prec == kBF16) hipLaunchKernelGGL(im2col_l1_kernel<bf16>, grid, dim3(256), 0, s, canvas, (bf16*)out, B, H, W);
   else hipLaunchKernelGGL(im2col_l1_kernel<float>, grid, dim3(256), 0, s, canvas, (float*)out, B, H, W);
+}
+
+// ------------------------------------------------------------------ first layer, direct (bf16)
+// conv1_1 (3 -> 64, 3x3) without the im2col round trip: each wave builds the MFMA operand of 64
+// pixels in registers (lane = pixel l&15, k = 8*(l>>4)..+7 with k = (ky*3+kx)*3+c, the same K
+// order and the same bf16 values (u8/255) as im2col_l1_kernel), multiplies by the [64][32]
+// weight held in 4 fragments, adds bias, applies ReLU and stores 16 bytes per lane.  Transposed
+// MFMA + channel permutation as in gemm2.hip.  HBM-bound on the 128 B/pixel it writes.
+__global__ __launch_bounds__(256) void conv1_direct_kernel(const uint8_t* __restrict__ canvas, const bf16* __restrict__ wgt /*[64][32]*/,
+                                                          const float* __restrict__ bias, bf16* __restrict__ out, int B, int H, int W) {
+  const int lane = threadIdx.x & 63, fr = lane & 15, fg = lane >> 4;
+  const int64_t M = (int64_t)B * H * W;
+  const int HW = H * W;
+  bf16x8 fw[4];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int n = 32 * (jj >> 1) + (fr >> 2) * 8 + (jj & 1) * 4 + (fr & 3);
+    fw[jj] = *reinterpret_cast<const bf16x8*>(wgt + n * 32 + fg * 8);
+  }
+  float bv[2][8];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[t][e] = bias[32 * t + fg * 8 + e];
+  // the 8 (tap, channel) pairs this lane contributes
+  int dy[8], dx[8], ch[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = fg * 8 + e, tap = k / 3;
+    ch[e] = k - tap * 3; dy[e] = tap / 3 - 1; dx[e] = tap % 3 - 1;   // k >= 27: masked below
+  }
+  const int64_t nwaves = (int64_t)gridDim.x * 4, wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  for (int64_t g = wave0; g * 64 < M; g += nwaves) {
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = g * 64 + i * 16 + fr;
+      bf16x8 fx;
+      if (m < M) {
+        const int r = (int)(m % HW), y = r / W, x = r - y * W;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int yy = y + dy[e], xx = x + dx[e];
+          const bool ok = (fg * 8 + e < 27) && yy >= 0 && yy < H && xx >= 0 && xx < W;
+          fx[e] = ok ? (bf16)((float)canvas[(m + (int64_t)dy[e] * W + dx[e]) * 3 + ch[e]] / 255.0f) : (bf16)0.f;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fx[e] = (bf16)0.f;
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) acc[jj][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[jj], fx, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = g * 64 + i * 16 + fr;
+      if (m >= M) continue;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (bf16)fmaxf(acc[2 * t][i][e] + bv[t][e], 0.f);
+          o[4 + e] = (bf16)fmaxf(acc[2 * t + 1][i][e] + bv[t][4 + e], 0.f);
+        }
+        *reinterpret_cast<bf16x8*>(out + m * 64 + 32 * t + fg * 8) = o;
+      }
+    }
+  }
+}
+
+void launch_conv1_direct(const uint8_t* canvas, const void* wgt, const float* bias, void* out, int B, int H, int W, hipStream_t s) {
+  const int64_t M = (int64_t)B * H * W;
+  const int grid = (int)std::min<int64_t>((M + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(conv1_direct_kernel, dim3(grid), dim3(256), 0, s, canvas, (const bf16*)wgt, bias, (bf16*)out, B, H, W);
 }
 
 // ------------------------------------------------------------------ pools / upsample (one 16-byte chunk per thread)

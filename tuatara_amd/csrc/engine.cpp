@@ -37,6 +37,7 @@ void hip_fail(const char* what, hipError_t e, const char* file, int line) {
 }
 
 static thread_local std::string g_last_error;
+static int g_decoder_mode = 1;   // 0 = kernel-per-op AR loop, 4/8/16 = fused kernel with that many crops per workgroup, else automatic
 
 // ------------------------------------------------------------------ small utilities
 struct DevBuf {
@@ -117,20 +118,22 @@ struct Result {
   std::vector<int32_t> ids;  // 26 per item
 };
 
-struct PageCcl {
+struct CclBatch {   // device workspaces of the CCL stage for a batch of equally sized pages
   DevBuf tnorm, flags, parent, mm, area, bbox, maxt, cand_slot, cand, counters, rows;
-  CclBuffers view(int max_cand) {
+  int pages = 0, npx = 0, max_cand = 0;
+  CclBuffers view() {
     CclBuffers b;
     b.tnorm = tnorm.as<float>(); b.flags = flags.as<uint8_t>(); b.parent = parent.as<int>(); b.mm = mm.as<unsigned>();
     b.area = area.as<int>(); b.bbox = bbox.as<int>(); b.maxt = maxt.as<unsigned>(); b.cand_slot = cand_slot.as<int>();
-    b.cand = cand.as<int>(); b.counters = counters.as<int>(); b.rowmin = nullptr; b.rowmax = nullptr;
-    b.rows_packed = rows.as<int>(); b.max_cand = max_cand;
+    b.cand = cand.as<int>(); b.counters = counters.as<int>(); b.rows_packed = rows.as<int>(); b.max_cand = max_cand;
     return b;
   }
-  void ensure(int npx, int max_cand) {
-    tnorm.ensure((size_t)npx * 4); flags.ensure(npx); parent.ensure((size_t)npx * 4); mm.ensure(64);
-    area.ensure((size_t)npx * 4); bbox.ensure((size_t)npx * 16); maxt.ensure((size_t)npx * 4); cand_slot.ensure((size_t)npx * 4);
-    cand.ensure((size_t)max_cand * 32); counters.ensure(64); rows.ensure((size_t)npx * 8);
+  void ensure(int pages_, int npx_, int max_cand_) {
+    pages = pages_; npx = npx_; max_cand = max_cand_;
+    const size_t n = (size_t)pages * npx;
+    tnorm.ensure(n * 4); flags.ensure(n); parent.ensure(n * 4); mm.ensure((size_t)pages * 16);
+    area.ensure(n * 4); bbox.ensure(n * 16); maxt.ensure(n * 4); cand_slot.ensure(n * 4);
+    cand.ensure((size_t)pages * max_cand * 32); counters.ensure((size_t)pages * 8); rows.ensure(n * 8);
   }
 };
 
@@ -153,7 +156,7 @@ struct Engine {
   std::vector<std::unique_ptr<DevBuf>> craft_ws;  // per-layer activations
   DevBuf pq_ws[16];
   DevBuf canvas, heat, staging_img, crops, rects_dev, logits, ar_logits, ids_dev, tokens;
-  std::vector<std::unique_ptr<PageCcl>> ccl;
+  CclBatch ccl;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   float stage_ms[4] = {0, 0, 0, 0};
   // optional per-launch timing of the igemm kernel (bench.py's roofline): events bracket every launch
@@ -165,15 +168,16 @@ struct Engine {
   double prof_ms[2] = {0, 0}, prof_flops[2] = {0, 0};
   long prof_launches[2] = {0, 0};
 
-  void igemm(const ConvParams& p, double true_flops) {
-    if (!profiling) { launch_igemm(prec, p, stream); return; }
+  template <class F> void timed(double true_flops, F&& launch) {
+    if (!profiling) { launch(); return; }
     const size_t i = prof_recs.size();
     while (prof_pool.size() < 2 * (i + 1)) { hipEvent_t e; TTR_HIP_CHECK(hipEventCreate(&e)); prof_pool.push_back(e); }
     TTR_HIP_CHECK(hipEventRecord(prof_pool[2 * i], stream));
-    launch_igemm(prec, p, stream);
+    launch();
     TTR_HIP_CHECK(hipEventRecord(prof_pool[2 * i + 1], stream));
     prof_recs.push_back(ProfRec{prof_stage, true_flops});
   }
+  void igemm(const ConvParams& p, double true_flops) { timed(true_flops, [&] { launch_igemm(prec, p, stream); }); }
   void prof_collect() {  // after a stream sync
     for (size_t i = 0; i < prof_recs.size(); ++i) {
       float ms = 0.f;
@@ -360,9 +364,15 @@ struct Engine {
     const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8, H4 = H / 16, W4 = W / 16;
     size_t k = 0;
     auto buf = [&](size_t rows, int C) -> void* { return ws(k++, rows * C * es).p; };
-    void* a0 = buf(M0, 32);
-    launch_im2col_l1(prec, d_canvas, a0, B, H, W, stream);
-    void* c11 = buf(M0, 64);  conv("slice1.0", a0, 32, nullptr, 0, 0, 1, 1, (int)M0, c11, kActRelu);
+    void* a0 = buf(prec == kBF16 ? 0 : M0, 32);
+    void* c11 = buf(M0, 64);
+    if (prec == kBF16) {   // conv1_1 straight from the u8 canvas
+      const Linear& L = craft.at("slice1.0");
+      timed(2.0 * M0 * 64 * 27, [&] { launch_conv1_direct(d_canvas, L.w.p, L.b.as<float>(), c11, B, H, W, stream); });
+    } else {
+      launch_im2col_l1(prec, d_canvas, a0, B, H, W, stream);
+      conv("slice1.0", a0, 32, nullptr, 0, 0, 1, 1, (int)M0, c11, kActRelu);
+    }
     void* c12 = buf(M0, 64);  conv("slice1.3", c11, 64, nullptr, 0, 0, B, H, W, c12, kActRelu);
     void* p1 = buf(M1, 64);   launch_maxpool2x2(prec, c12, p1, B, H, W, 64, 0, stream);
     void* c21 = buf(M1, 128); conv("slice1.7", p1, 64, nullptr, 0, 0, B, H1, W1, c21, kActRelu);
@@ -477,6 +487,28 @@ struct Engine {
     const float* bc = pqf.at(d + "norm_c.bias").as<float>();
     float* ar = d_ar ? d_ar : step_logits;
     const int nsteps = d_ar ? 26 : 25;  // the 26th AR step only feeds logits the refinement pass discards
+    // Fused persistent AR kernel (dec_fused.hip): per-step cost ~constant in N (each workgroup is latency-bound on its own
+    // weight/K-V streams), so it wins for big crop batches; the kernel-per-op loop is faster below ~384 crops (measured).
+    const bool fused_ar = prec == kBF16 && g_decoder_mode != 0 && (g_decoder_mode == 4 || g_decoder_mode == 8 || g_decoder_mode == 16 || N >= 384);
+    if (fused_ar) {
+      DecArParams q{};
+      auto W = [&](const char* k) { return pq.at(k).w.as<bf16>(); };
+      auto Bv = [&](const char* k) { return pq.at(k).b.as<float>(); };
+      auto V = [&](const std::string& k) { return pqf.at(k).as<float>(); };
+      q.w_selfkv = W("self_kv"); q.w_selfout = W("self_out"); q.w_crossq = W("cross_q"); q.w_crossout = W("cross_out");
+      q.w_ffn1 = W("ffn1"); q.w_ffn2 = W("ffn2"); q.w_head = W("head");
+      q.b_selfkv = Bv("self_kv"); q.b_selfout = Bv("self_out"); q.b_crossq = Bv("cross_q"); q.b_crossout = Bv("cross_out");
+      q.b_ffn1 = Bv("ffn1"); q.b_ffn2 = Bv("ffn2"); q.b_head = Bv("head");
+      q.emb = emb; q.posq = posq; q.qself = qself.as<float>();
+      q.g_c = gc; q.b_c = bc;
+      q.g_1 = V(d + "norm1.weight"); q.b_1 = V(d + "norm1.bias"); q.g_2 = V(d + "norm2.weight"); q.b_2 = V(d + "norm2.bias");
+      q.g_f = V("decoder.norm.weight"); q.b_f = V("decoder.norm.bias");
+      q.kvmem = (const bf16*)kvmem; q.kvcache = (bf16*)kvcache; q.tokens = tk; q.ar_logits = d_ar;
+      q.N = N; q.nsteps = nsteps;
+      int G = g_decoder_mode;
+      if (G != 4 && G != 8 && G != 16) G = N <= 1024 ? 4 : 8;
+      launch_dec_ar(q, G, stream);
+    } else
     for (int i = 0; i < 26; ++i) {
       launch_dec_embed_ln(prec, tk, emb, posq, gc, bc, 1e-5f, t384, N, i, i + 1, stream);
       gemm(pq.at("self_kv"), t384, N, (char*)kvcache + (size_t)i * 768 * es, 26 * 768, kActNone);
@@ -494,31 +526,37 @@ struct Engine {
   // ---- post-processing of one page's heat map: GPU CCL + host calipers
   struct PageBoxes { std::vector<RRect> det; };
 
-  void ccl_launch(PageCcl& pc, const float* d_heat, int H2, int W2) {
-    pc.ensure(H2 * W2, cfg.max_components);
-    launch_ccl(d_heat, H2, W2, cfg.text_threshold, cfg.link_threshold, cfg.low_text, cfg.min_area, pc.view(cfg.max_components), stream);
+  void ccl_launch(const float* d_heat, int pages, int H2, int W2) {
+    ccl.ensure(pages, H2 * W2, cfg.max_components);
+    launch_ccl(d_heat, pages, H2, W2, cfg.text_threshold, cfg.link_threshold, cfg.low_text, cfg.min_area, ccl.view(), stream);
   }
-  // after the stream is synchronised up to the CCL kernels
-  void ccl_collect(PageCcl& pc, int H2, int W2, std::vector<RRect>& det) {
-    int counters[2];
-    TTR_HIP_CHECK(hipMemcpyAsync(counters, pc.counters.p, 8, hipMemcpyDeviceToHost, stream));
+  // boxes of every page of the batch: two stream syncs in all (counters, then candidates + row extremes)
+  void ccl_collect(int pages, int H2, int W2, std::vector<std::vector<RRect>>& det) {
+    std::vector<int> counters((size_t)pages * 2);
+    TTR_HIP_CHECK(hipMemcpyAsync(counters.data(), ccl.counters.p, counters.size() * 4, hipMemcpyDeviceToHost, stream));
     TTR_HIP_CHECK(hipStreamSynchronize(stream));
-    if (counters[0] > cfg.max_components) throw std::runtime_error("too many text components on a page; raise ttr_config.max_components");
-    const int n = counters[0], rows = counters[1];
-    det.clear();
-    if (n == 0) return;
-    std::vector<int> cand((size_t)n * 8), rw((size_t)rows * 2);
-    TTR_HIP_CHECK(hipMemcpyAsync(cand.data(), pc.cand.p, cand.size() * 4, hipMemcpyDeviceToHost, stream));
-    TTR_HIP_CHECK(hipMemcpyAsync(rw.data(), pc.rows.p, rw.size() * 4, hipMemcpyDeviceToHost, stream));
+    std::vector<std::vector<int>> cand(pages), rw(pages);
+    for (int pg = 0; pg < pages; ++pg) {
+      const int n = counters[2 * pg], rows = counters[2 * pg + 1];
+      if (n > cfg.max_components) throw std::runtime_error("too many text components on a page; raise ttr_config.max_components");
+      if (n == 0) continue;
+      cand[pg].resize((size_t)n * 8); rw[pg].resize((size_t)rows * 2);
+      TTR_HIP_CHECK(hipMemcpyAsync(cand[pg].data(), ccl.cand.as<int>() + (size_t)pg * ccl.max_cand * 8, cand[pg].size() * 4, hipMemcpyDeviceToHost, stream));
+      TTR_HIP_CHECK(hipMemcpyAsync(rw[pg].data(), ccl.rows.as<int>() + (size_t)pg * ccl.npx * 2, rw[pg].size() * 4, hipMemcpyDeviceToHost, stream));
+    }
     TTR_HIP_CHECK(hipStreamSynchronize(stream));
-    std::vector<int> order(n);
-    for (int i = 0; i < n; ++i) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](int a, int b) { return cand[8 * a] < cand[8 * b]; });  // label order = ascending root
-    for (int i : order) {
-      const int* c = &cand[8 * i];
-      Component comp{c[0], c[1], c[2], c[3], c[4], c[5], &rw[2 * (size_t)c[6]]};
-      RRect r;
-      if (component_to_rect(comp, H2, W2, &r)) det.push_back(r);
+    det.assign(pages, std::vector<RRect>());
+    for (int pg = 0; pg < pages; ++pg) {
+      const int n = counters[2 * pg];
+      std::vector<int> order(n);
+      for (int i = 0; i < n; ++i) order[i] = i;
+      std::sort(order.begin(), order.end(), [&](int a, int b) { return cand[pg][8 * a] < cand[pg][8 * b]; });  // label order = ascending root
+      for (int i : order) {
+        const int* c = &cand[pg][8 * i];
+        Component comp{c[0], c[1], c[2], c[3], c[4], c[5], &rw[pg][2 * (size_t)c[6]]};
+        RRect r;
+        if (component_to_rect(comp, H2, W2, &r)) det[pg].push_back(r);
+      }
     }
   }
 
@@ -536,21 +574,23 @@ struct Engine {
     TTR_HIP_CHECK(hipEventRecord(ev[0], stream));
     for (int i = 0; i < n; ++i)
       launch_resize_pad_u8(d_pages + i * page_bytes, h, w, w * 3, canvas.as<uint8_t>() + (size_t)i * H * W * 3, g.target_h, g.target_w, H, W, 1, stream);
-    craft_forward(canvas.as<uint8_t>(), n, H, W, heat.as<float>());
+    // CRAFT in groups of <= 16 pages: bounds the activation workspace (~0.5 GB/page) and keeps every tensor
+    // inside the 2 GiB window gemm2's 32-bit buffer offsets address
+    for (int p0 = 0; p0 < n; p0 += 16)
+      craft_forward(canvas.as<uint8_t>() + (size_t)p0 * H * W * 3, std::min(16, n - p0), H, W, heat.as<float>() + (size_t)p0 * H2 * W2 * 2);
     TTR_HIP_CHECK(hipEventRecord(ev[1], stream));
-    while ((int)ccl.size() < n) ccl.emplace_back(new PageCcl());
-    for (int i = 0; i < n; ++i) ccl_launch(*ccl[i], heat.as<float>() + (size_t)i * H2 * W2 * 2, H2, W2);
+    ccl_launch(heat.as<float>(), n, H2, W2);
     TTR_HIP_CHECK(hipEventRecord(ev[2], stream));
 
     // host: boxes -> crop rectangles
     const float ratio_w = 1.f / g.ratio, ratio_h = 1.f / g.ratio;   // tuatara.cpp:360-361
-    std::vector<int> rects;                 // x0,y0,x1,y1 per crop
+    std::vector<int> rects;                 // x0,y0,x1,y1,page per crop
     std::vector<int> page_of;               // page index per crop
     std::vector<std::vector<RRect>> boxes(n);
-    std::vector<RRect> det;
+    std::vector<std::vector<RRect>> dets;
+    ccl_collect(n, H2, W2, dets);
     for (int i = 0; i < n; ++i) {
-      ccl_collect(*ccl[i], H2, W2, det);
-      for (const RRect& r : det) {
+      for (const RRect& r : dets[i]) {
         RRect b = adjust_coordinates(r, ratio_w, ratio_h);            // :406
         int xywh[4];
         bounding_rect(b, xywh);                                       // :416
@@ -562,7 +602,7 @@ struct Engine {
         }
         if (x1 <= x0 || y1 <= y0) continue;
         boxes[i].push_back(b);
-        rects.insert(rects.end(), {x0, y0, x1, y1});
+        rects.insert(rects.end(), {x0, y0, x1, y1, i});
         page_of.push_back(i);
       }
     }
@@ -574,12 +614,7 @@ struct Engine {
       logits.ensure((size_t)N * 26 * 95 * 4);
       ids_dev.ensure((size_t)N * 26 * 4);
       TTR_HIP_CHECK(hipMemcpyAsync(rects_dev.p, rects.data(), rects.size() * 4, hipMemcpyHostToDevice, stream));
-      int c0 = 0;
-      for (int i = 0; i < n; ++i) {
-        int cnt = (int)boxes[i].size();
-        launch_pack_crops(d_pages + i * page_bytes, h, w, w * 3, rects_dev.as<int>() + 4 * c0, crops.as<uint8_t>() + (size_t)c0 * 32 * 128 * 3, cnt, stream);
-        c0 += cnt;
-      }
+      launch_pack_crops(d_pages, page_bytes, w * 3, rects_dev.as<int>(), crops.as<uint8_t>(), N, stream);
       TTR_HIP_CHECK(hipEventRecord(ev[3], stream));
       parseq_forward(crops.as<uint8_t>(), N, logits.as<float>(), nullptr, ids_dev.as<int>());
       TTR_HIP_CHECK(hipEventRecord(ev[4], stream));
@@ -697,10 +732,10 @@ int ttr_ccl_boxes(ttr_engine* e, const float* heat, int H2, int W2, float* rects
   std::lock_guard<std::mutex> lk(E.mu);
   E.heat.ensure((size_t)H2 * W2 * 2 * 4);
   TTR_HIP_CHECK(hipMemcpyAsync(E.heat.p, heat, (size_t)H2 * W2 * 2 * 4, hipMemcpyHostToDevice, E.stream));
-  if (E.ccl.empty()) E.ccl.emplace_back(new PageCcl());
-  E.ccl_launch(*E.ccl[0], E.heat.as<float>(), H2, W2);
-  std::vector<RRect> det;
-  E.ccl_collect(*E.ccl[0], H2, W2, det);
+  E.ccl_launch(E.heat.as<float>(), 1, H2, W2);
+  std::vector<std::vector<RRect>> dets;
+  E.ccl_collect(1, H2, W2, dets);
+  const std::vector<RRect>& det = dets[0];
   *n = (int)det.size();
   for (int i = 0; i < (int)det.size() && i < max_rects; ++i) {
     rects5[5 * i] = det[i].cx; rects5[5 * i + 1] = det[i].cy; rects5[5 * i + 2] = det[i].w; rects5[5 * i + 3] = det[i].h; rects5[5 * i + 4] = det[i].angle;
@@ -733,22 +768,22 @@ int ttr_pack_crops(ttr_engine* e, const uint8_t* img, int h, int w, int row_stri
   Engine& E = *e->e;
   std::lock_guard<std::mutex> lk(E.mu);
   if (n <= 0) return 0;
-  std::vector<int> rects((size_t)n * 4);
+  std::vector<int> rects((size_t)n * 5, 0);
   for (int i = 0; i < n; ++i) {
     RRect r{rects5[5 * i], rects5[5 * i + 1], rects5[5 * i + 2], rects5[5 * i + 3], rects5[5 * i + 4]};
     RRect b = adjust_coordinates(r, 1.f / ratio, 1.f / ratio);
     if (boxes_out) { boxes_out[5 * i] = b.cx; boxes_out[5 * i + 1] = b.cy; boxes_out[5 * i + 2] = b.w; boxes_out[5 * i + 3] = b.h; boxes_out[5 * i + 4] = b.angle; }
     int xywh[4];
     bounding_rect(b, xywh);
-    rects[4 * i] = std::max(xywh[0], 0); rects[4 * i + 1] = std::max(xywh[1], 0);
-    rects[4 * i + 2] = std::min(xywh[0] + xywh[2], w); rects[4 * i + 3] = std::min(xywh[1] + xywh[3], h);
+    rects[5 * i] = std::max(xywh[0], 0); rects[5 * i + 1] = std::max(xywh[1], 0);
+    rects[5 * i + 2] = std::min(xywh[0] + xywh[2], w); rects[5 * i + 3] = std::min(xywh[1] + xywh[3], h);
   }
   E.staging_img.ensure((size_t)h * w * 3);
   E.rects_dev.ensure(rects.size() * 4);
   E.crops.ensure((size_t)n * 32 * 128 * 3);
   TTR_HIP_CHECK(hipMemcpy2DAsync(E.staging_img.p, (size_t)w * 3, img, row_stride, (size_t)w * 3, h, hipMemcpyHostToDevice, E.stream));
   TTR_HIP_CHECK(hipMemcpyAsync(E.rects_dev.p, rects.data(), rects.size() * 4, hipMemcpyHostToDevice, E.stream));
-  launch_pack_crops(E.staging_img.as<uint8_t>(), h, w, w * 3, E.rects_dev.as<int>(), E.crops.as<uint8_t>(), n, E.stream);
+  launch_pack_crops(E.staging_img.as<uint8_t>(), 0, w * 3, E.rects_dev.as<int>(), E.crops.as<uint8_t>(), n, E.stream);
   TTR_HIP_CHECK(hipMemcpyAsync(crops_out, E.crops.p, (size_t)n * 32 * 128 * 3, hipMemcpyDeviceToHost, E.stream));
   TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
   return 0;
@@ -816,6 +851,7 @@ int ttr_dbg_conv(ttr_engine* e, const float* in0, int C0, const float* in1, int 
 }
 
 void ttr_set_gemm_config(int cfg) { set_gemm_config(cfg); }
+void ttr_set_decoder_mode(int mode) { g_decoder_mode = mode; }
 
 int ttr_bench_conv(ttr_engine* e, int B, int H, int W, int C0, int C1, int ks, int dil, int Cout, int act, int f32_resid, int iters, float* avg_us) {
   TTR_GUARD_BEGIN

@@ -31,15 +31,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
-// erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7): plenty for a bf16 result
-__device__ __forceinline__ float gelu_fast(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * z);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float e = 1.0f - poly * __expf(-z * z);
-  return 0.5f * x * (1.0f + copysignf(e, x));
-}
-
 template <int BM, int BN, int WM, int WN>
 struct G2Cfg {
   static constexpr int NW = WM * WN, NT = NW * 64;

@@ -23,6 +23,8 @@ void launch_fill_random(Precision prec, void* p, size_t n, unsigned seed, float 
 void launch_resize_pad_u8(const uint8_t* src, int sh, int sw, int sstride, uint8_t* dst, int th, int tw, int H, int W, int swap_rb, hipStream_t s);
 // canvas u8 [B,H,W,3] -> first-layer im2col matrix T [B*H*W][32] (27 taps*channels, /255, zero padded)
 void launch_im2col_l1(Precision prec, const uint8_t* canvas, void* out, int B, int H, int W, hipStream_t s);
+// bf16 only: conv1_1 + bias + ReLU straight from the u8 canvas (same arithmetic as im2col_l1 + igemm, no [M][32] round trip)
+void launch_conv1_direct(const uint8_t* canvas, const void* wgt /*bf16 [64][32]*/, const float* bias, void* out /*bf16 [M][64]*/, int B, int H, int W, hipStream_t s);
 void launch_maxpool2x2(Precision prec, const void* in, void* out, int B, int H, int W, int C, int relu, hipStream_t s);
 void launch_maxpool3x3s1(Precision prec, const void* in, void* out, int B, int H, int W, int C, hipStream_t s);
 void launch_upsample2x(Precision prec, const void* in, void* out, int B, int H, int W, int C, hipStream_t s);  // in [B,H,W,C] -> out [B,2H,2W,C]
@@ -45,21 +47,37 @@ void launch_dec_cross_attn(Precision prec, const void* q, const void* kvmem, voi
 void launch_argmax(const float* logits, int ld, int C, int* tokens, int tok_ld, int col, int N, hipStream_t s);
 void launch_fill_i32(int* p, int value, int n, int stride, hipStream_t s);
 
+// ---- dec_fused.hip: the whole autoregressive decode (<= 26 steps) of PARSeq as one persistent kernel (bf16)
+struct DecArParams {
+  const bf16 *w_selfkv, *w_selfout, *w_crossq, *w_crossout, *w_ffn1, *w_ffn2, *w_head;   // [N][K] row-major
+  const float *b_selfkv, *b_selfout, *b_crossq, *b_crossout, *b_ffn1, *b_ffn2, *b_head;
+  const float *emb, *posq, *qself;                 // [97][384] (pre-scaled), [26][384], [26][384] = Wq.norm_q(pos_q)+bq
+  const float *g_c, *b_c, *g_1, *b_1, *g_2, *b_2, *g_f, *b_f;   // norm_c, norm1, norm2, decoder.norm
+  const bf16* kvmem;     // [N][128][768] cross-attention K|V of the encoder memory
+  bf16* kvcache;         // [N][26][768]  self-attention K|V of the content stream (out: all 26 rows)
+  int* tokens;           // [N][26] out: BOS, then the greedy tokens
+  float* ar_logits;      // optional [N][26][95]
+  int N, nsteps;         // nsteps: 25 (logits of the 26th step are never used) or 26
+};
+void launch_dec_ar(const DecArParams& p, int crops_per_workgroup, hipStream_t s);
+
 // ---- post_ops.hip
 struct CclBuffers {
-  // all device pointers; sized for H*W pixels and max_cand candidates
-  float* tnorm; uint8_t* flags; int* parent; unsigned* mm;  // mm: 4 ordered-uint min/max words
+  // device arrays for a batch of pages, each strided by the page: [pages][npx] unless noted
+  float* tnorm; uint8_t* flags; int* parent;
+  unsigned* mm;           // [pages][4] ordered-uint min/max of the two maps
   int* area; int* bbox;   // bbox: 4 ints per root (minx,miny,maxx,maxy)
   unsigned* maxt;         // per root max of tnorm (as uint bits; tnorm >= 0)
   int* cand_slot;         // per pixel: slot of the candidate rooted here, or -1
-  int* cand;              // [max_cand][8]: root, area, minx, miny, maxx, maxy, row_offset, pad
-  int* counters;          // [0]=n_cand, [1]=total_rows
-  unsigned* rowmin; unsigned* rowmax;  // [max_cand][H]
-  int* rows_packed;       // [total_rows][2]
+  int* cand;              // [pages][max_cand][8]: root, area, minx, miny, maxx, maxy, row_offset, pad
+  int* counters;          // [pages][2]: n_cand, total_rows
+  int* rows_packed;       // [pages][npx][2]: per candidate row {min x, max x} of the link-masked pixels
   int max_cand;
 };
-void launch_ccl(const float* heat /*[H][W][2]*/, int H, int W, float text_threshold, float link_threshold, float low_text, int min_area, const CclBuffers& b, hipStream_t s);
-// crops: rect[n] = {x0,y0,x1,y1} (already clamped, x1/y1 exclusive) of image u8 [h,w,3] -> out u8 [N][32][128][3]
-void launch_pack_crops(const uint8_t* image, int h, int w, int stride, const int* rects, uint8_t* out, int N, hipStream_t s);
+void launch_ccl(const float* heat /*[pages][H][W][2]*/, int pages, int H, int W, float text_threshold, float link_threshold, float low_text, int min_area,
+                const CclBuffers& b, hipStream_t s);
+// crops: rects5[n] = {x0,y0,x1,y1,page} (clamped, x1/y1 exclusive) of images u8 [pages][h,w,3] (page stride page_bytes)
+// -> out u8 [N][32][128][3]; one launch for the crops of every page of a batch
+void launch_pack_crops(const uint8_t* images, size_t page_bytes, int stride, const int* rects5, uint8_t* out, int N, hipStream_t s);
 
 }  // namespace ttr

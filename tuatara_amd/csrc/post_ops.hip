@@ -22,14 +22,41 @@ namespace ttr {
 __device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float ord2f(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
 
-__global__ void ccl_init_kernel(unsigned* mm, int* counters) {
-  if (threadIdx.x == 0) { mm[0] = 0xFFFFFFFFu; mm[1] = 0u; mm[2] = 0xFFFFFFFFu; mm[3] = 0u; counters[0] = 0; counters[1] = 0; }
+// All CCL kernels run over a batch of pages at once: blockIdx.y = page, every per-page array is
+// strided by the page (npx pixels, max_cand candidates).
+struct CclPage {
+  const float* heat; float* tnorm; uint8_t* flags; int* parent; unsigned* mm; int* area; int* bbox; unsigned* maxt;
+  int* cand_slot; int* cand; int* counters; int* rows_packed;
+};
+__device__ __forceinline__ CclPage ccl_page(const CclBuffers& b, const float* heat, int npx) {
+  const size_t pg = blockIdx.y;
+  CclPage c;
+  c.heat = heat + pg * npx * 2; c.tnorm = b.tnorm + pg * npx; c.flags = b.flags + pg * npx; c.parent = b.parent + pg * npx;
+  c.mm = b.mm + pg * 4; c.area = b.area + pg * npx; c.bbox = b.bbox + pg * npx * 4; c.maxt = b.maxt + pg * npx;
+  c.cand_slot = b.cand_slot + pg * npx; c.cand = b.cand + pg * b.max_cand * 8; c.counters = b.counters + pg * 2;
+  c.rows_packed = b.rows_packed + pg * npx * 2;
+  return c;
 }
 
-__global__ void minmax_kernel(const float* __restrict__ heat, int npx, unsigned* mm) {
+__global__ void ccl_init_kernel(CclBuffers b, int pages) {
+  int pg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pg >= pages) return;
+  unsigned* mm = b.mm + pg * 4; int* counters = b.counters + pg * 2;
+  mm[0] = 0xFFFFFFFFu; mm[1] = 0u; mm[2] = 0xFFFFFFFFu; mm[3] = 0u; counters[0] = 0; counters[1] = 0;
+}
+
+// one workgroup reduction, then 4 atomics per workgroup (the per-wave form spent 48 us per page serialising on 4 words)
+__global__ __launch_bounds__(256) void minmax_kernel(CclBuffers b, const float* __restrict__ heat_all, int npx) {
+  const CclPage c = ccl_page(b, heat_all, npx);
   float tmin = INFINITY, tmax = -INFINITY, lmin = INFINITY, lmax = -INFINITY;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
-    float2 v = reinterpret_cast<const float2*>(heat)[i];
+  const float4* h4 = reinterpret_cast<const float4*>(c.heat);   // two pixels per load (npx is even: H, W multiples of 16)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npx / 2; i += gridDim.x * blockDim.x) {
+    float4 v = h4[i];
+    tmin = fminf(tmin, fminf(v.x, v.z)); tmax = fmaxf(tmax, fmaxf(v.x, v.z));
+    lmin = fminf(lmin, fminf(v.y, v.w)); lmax = fmaxf(lmax, fmaxf(v.y, v.w));
+  }
+  if ((npx & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    float2 v = reinterpret_cast<const float2*>(c.heat)[npx - 1];
     tmin = fminf(tmin, v.x); tmax = fmaxf(tmax, v.x); lmin = fminf(lmin, v.y); lmax = fmaxf(lmax, v.y);
   }
 #pragma unroll
@@ -37,27 +64,31 @@ __global__ void minmax_kernel(const float* __restrict__ heat, int npx, unsigned*
     tmin = fminf(tmin, __shfl_xor(tmin, o)); tmax = fmaxf(tmax, __shfl_xor(tmax, o));
     lmin = fminf(lmin, __shfl_xor(lmin, o)); lmax = fmaxf(lmax, __shfl_xor(lmax, o));
   }
-  if ((threadIdx.x & 63) == 0) {
-    atomicMin(&mm[0], f2ord(tmin)); atomicMax(&mm[1], f2ord(tmax));
-    atomicMin(&mm[2], f2ord(lmin)); atomicMax(&mm[3], f2ord(lmax));
+  __shared__ float red[4][4];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[w][0] = tmin; red[w][1] = tmax; red[w][2] = lmin; red[w][3] = lmax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k) { tmin = fminf(tmin, red[k][0]); tmax = fmaxf(tmax, red[k][1]); lmin = fminf(lmin, red[k][2]); lmax = fmaxf(lmax, red[k][3]); }
+    atomicMin(&c.mm[0], f2ord(tmin)); atomicMax(&c.mm[1], f2ord(tmax));
+    atomicMin(&c.mm[2], f2ord(lmin)); atomicMax(&c.mm[3], f2ord(lmax));
   }
 }
 
 // flags: bit0 text_score, bit1 link_score, bit2 combined
-__global__ void binarize_kernel(const float* __restrict__ heat, int npx, const unsigned* __restrict__ mm, float low_text, float link_threshold,
-                                float* __restrict__ tnorm, uint8_t* __restrict__ flags, int* __restrict__ parent,
-                                int* __restrict__ area, int* __restrict__ bbox, unsigned* __restrict__ maxt, int* __restrict__ cand_slot) {
+__global__ void binarize_kernel(CclBuffers b, const float* __restrict__ heat_all, int npx, float low_text, float link_threshold) {
+  const CclPage c = ccl_page(b, heat_all, npx);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npx) return;
-  const float tmin = ord2f(mm[0]), tmax = ord2f(mm[1]), lmin = ord2f(mm[2]), lmax = ord2f(mm[3]);
-  float2 v = reinterpret_cast<const float2*>(heat)[i];
+  const float tmin = ord2f(c.mm[0]), tmax = ord2f(c.mm[1]), lmin = ord2f(c.mm[2]), lmax = ord2f(c.mm[3]);
+  float2 v = reinterpret_cast<const float2*>(c.heat)[i];
   float tn = __fdiv_rn(v.x - tmin, tmax - tmin), ln = __fdiv_rn(v.y - lmin, lmax - lmin);  // IEEE division like torch
   int ts = tn > low_text, ls = ln > link_threshold, comb = ts | ls;
-  tnorm[i] = tn;
-  flags[i] = (uint8_t)(ts | (ls << 1) | (comb << 2));
-  parent[i] = comb ? i : -1;
-  area[i] = 0; maxt[i] = 0u; cand_slot[i] = -1;
-  bbox[4 * i] = 0x7fffffff; bbox[4 * i + 1] = 0x7fffffff; bbox[4 * i + 2] = -1; bbox[4 * i + 3] = -1;
+  c.tnorm[i] = tn;
+  c.flags[i] = (uint8_t)(ts | (ls << 1) | (comb << 2));
+  c.parent[i] = comb ? i : -1;
+  c.area[i] = 0; c.maxt[i] = 0u; c.cand_slot[i] = -1;
+  c.bbox[4 * i] = 0x7fffffff; c.bbox[4 * i + 1] = 0x7fffffff; c.bbox[4 * i + 2] = -1; c.bbox[4 * i + 3] = -1;
 }
 
 // Lock-free union-find (ECL-CC style).  Hooking is a CAS on a *true* root (parent[a]==a),
@@ -94,7 +125,8 @@ __device__ __forceinline__ void uf_union(int* parent, int a, int b) {
   }
 }
 
-__global__ void ccl_merge_kernel(int* parent, int H, int W) {
+__global__ void ccl_merge_kernel(CclBuffers b, int H, int W) {
+  int* parent = b.parent + (size_t)blockIdx.y * H * W;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= H * W || parent[i] < 0) return;
   int x = i % W, y = i / W;
@@ -102,79 +134,80 @@ __global__ void ccl_merge_kernel(int* parent, int H, int W) {
   if (y > 0 && parent[i - W] >= 0) uf_union(parent, i, i - W);
 }
 
-__global__ void ccl_flatten_stats_kernel(int* parent, int H, int W, const float* __restrict__ tnorm, int* area, int* bbox, unsigned* maxt) {
+__global__ void ccl_flatten_stats_kernel(CclBuffers b, int H, int W) {
+  const CclPage c = ccl_page(b, nullptr, H * W);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= H * W || parent[i] < 0) return;
-  int r = uf_find_ro(parent, i);
-  __hip_atomic_store(&parent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // readers see the old ancestor or the root: both lead to r
+  if (i >= H * W || c.parent[i] < 0) return;
+  int r = uf_find_ro(c.parent, i);
+  __hip_atomic_store(&c.parent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // readers see the old ancestor or the root: both lead to r
   int x = i % W, y = i / W;
-  atomicAdd(&area[r], 1);
-  atomicMin(&bbox[4 * r], x); atomicMin(&bbox[4 * r + 1], y);
-  atomicMax(&bbox[4 * r + 2], x); atomicMax(&bbox[4 * r + 3], y);
-  atomicMax(&maxt[r], __float_as_uint(fmaxf(tnorm[i], 0.f)));
+  atomicAdd(&c.area[r], 1);
+  atomicMin(&c.bbox[4 * r], x); atomicMin(&c.bbox[4 * r + 1], y);
+  atomicMax(&c.bbox[4 * r + 2], x); atomicMax(&c.bbox[4 * r + 3], y);
+  atomicMax(&c.maxt[r], __float_as_uint(fmaxf(c.tnorm[i], 0.f)));
 }
 
-__global__ void candidates_kernel(const int* __restrict__ parent, int npx, const int* __restrict__ area, const int* __restrict__ bbox,
-                                  const unsigned* __restrict__ maxt, float text_threshold, int min_area, int* cand_slot, int* cand, int* counters, int max_cand) {
+__global__ void candidates_kernel(CclBuffers b, int npx, float text_threshold, int min_area) {
+  const CclPage c = ccl_page(b, nullptr, npx);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= npx || parent[i] != i) return;
-  if (area[i] < min_area) return;                                   // :148
-  if (__uint_as_float(maxt[i]) < text_threshold) return;            // :154
-  int slot = atomicAdd(&counters[0], 1);
-  if (slot >= max_cand) return;
-  int h = bbox[4 * i + 3] - bbox[4 * i + 1] + 1;
-  int off = atomicAdd(&counters[1], h);
-  cand_slot[i] = slot;
-  int* c = cand + 8 * slot;
-  c[0] = i; c[1] = area[i]; c[2] = bbox[4 * i]; c[3] = bbox[4 * i + 1]; c[4] = bbox[4 * i + 2]; c[5] = bbox[4 * i + 3]; c[6] = off; c[7] = 0;
+  if (i >= npx || c.parent[i] != i) return;
+  if (c.area[i] < min_area) return;                                   // :148
+  if (__uint_as_float(c.maxt[i]) < text_threshold) return;            // :154
+  int slot = atomicAdd(&c.counters[0], 1);
+  if (slot >= b.max_cand) return;
+  int h = c.bbox[4 * i + 3] - c.bbox[4 * i + 1] + 1;
+  int off = atomicAdd(&c.counters[1], h);
+  c.cand_slot[i] = slot;
+  int* cd = c.cand + 8 * slot;
+  cd[0] = i; cd[1] = c.area[i]; cd[2] = c.bbox[4 * i]; cd[3] = c.bbox[4 * i + 1]; cd[4] = c.bbox[4 * i + 2]; cd[5] = c.bbox[4 * i + 3]; cd[6] = off; cd[7] = 0;
 }
 
-__global__ void rowext_init_kernel(const int* __restrict__ cand, const int* __restrict__ counters, int max_cand, int* rows_packed) {
-  int slot = blockIdx.x;
-  int n = min(counters[0], max_cand);
-  if (slot >= n) return;
-  const int* c = cand + 8 * slot;
-  int h = c[5] - c[3] + 1, off = c[6];
-  for (int r = threadIdx.x; r < h; r += blockDim.x) { rows_packed[2 * (off + r)] = 0x7fffffff; rows_packed[2 * (off + r) + 1] = -1; }
+// rows_packed[r] = {INT_MAX, -1} for every row of every candidate (total rows <= npx)
+__global__ void rowext_init_kernel(CclBuffers b, int npx) {
+  const CclPage c = ccl_page(b, nullptr, npx);
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c.counters[1] || i >= npx) return;
+  c.rows_packed[2 * i] = 0x7fffffff; c.rows_packed[2 * i + 1] = -1;
 }
 
-__global__ void rowext_kernel(const int* __restrict__ parent, const uint8_t* __restrict__ flags, int H, int W, const int* __restrict__ cand_slot,
-                              const int* __restrict__ cand, int* rows_packed) {
+__global__ void rowext_kernel(CclBuffers b, int H, int W) {
+  const CclPage c = ccl_page(b, nullptr, H * W);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= H * W) return;
-  int r = parent[i];
+  int r = c.parent[i];
   if (r < 0) return;
-  int slot = cand_slot[r];
+  int slot = c.cand_slot[r];
   if (slot < 0) return;
-  uint8_t f = flags[i];
+  uint8_t f = c.flags[i];
   if ((f & 2) && !(f & 1)) return;  // segmap.setTo(0, link_score==1 & text_score==0)  (:160)
-  const int* c = cand + 8 * slot;
+  const int* cd = c.cand + 8 * slot;
   int x = i % W, y = i / W;
-  int idx = c[6] + (y - c[3]);
-  atomicMin(&rows_packed[2 * idx], x);
-  atomicMax(&rows_packed[2 * idx + 1], x);
+  int idx = cd[6] + (y - cd[3]);
+  atomicMin(&c.rows_packed[2 * idx], x);
+  atomicMax(&c.rows_packed[2 * idx + 1], x);
 }
 
-void launch_ccl(const float* heat, int H, int W, float text_threshold, float link_threshold, float low_text, int min_area, const CclBuffers& b, hipStream_t s) {
+void launch_ccl(const float* heat, int pages, int H, int W, float text_threshold, float link_threshold, float low_text, int min_area, const CclBuffers& b, hipStream_t s) {
   const int npx = H * W;
-  const dim3 blk(256), grid((npx + 255) / 256);
-  hipLaunchKernelGGL(ccl_init_kernel, dim3(1), dim3(64), 0, s, b.mm, b.counters);
-  hipLaunchKernelGGL(minmax_kernel, dim3(256), blk, 0, s, heat, npx, b.mm);
-  hipLaunchKernelGGL(binarize_kernel, grid, blk, 0, s, heat, npx, b.mm, low_text, link_threshold, b.tnorm, b.flags, b.parent, b.area, b.bbox, b.maxt, b.cand_slot);
-  hipLaunchKernelGGL(ccl_merge_kernel, grid, blk, 0, s, b.parent, H, W);
-  hipLaunchKernelGGL(ccl_flatten_stats_kernel, grid, blk, 0, s, b.parent, H, W, b.tnorm, b.area, b.bbox, b.maxt);
-  hipLaunchKernelGGL(candidates_kernel, grid, blk, 0, s, b.parent, npx, b.area, b.bbox, b.maxt, text_threshold, min_area, b.cand_slot, b.cand, b.counters, b.max_cand);
-  hipLaunchKernelGGL(rowext_init_kernel, dim3(b.max_cand), dim3(64), 0, s, b.cand, b.counters, b.max_cand, b.rows_packed);
-  hipLaunchKernelGGL(rowext_kernel, grid, blk, 0, s, b.parent, b.flags, H, W, b.cand_slot, b.cand, b.rows_packed);
+  const dim3 blk(256), grid((npx + 255) / 256, pages);
+  hipLaunchKernelGGL(ccl_init_kernel, dim3((pages + 63) / 64), dim3(64), 0, s, b, pages);
+  hipLaunchKernelGGL(minmax_kernel, dim3(32, pages), blk, 0, s, b, heat, npx);
+  hipLaunchKernelGGL(binarize_kernel, grid, blk, 0, s, b, heat, npx, low_text, link_threshold);
+  hipLaunchKernelGGL(ccl_merge_kernel, grid, blk, 0, s, b, H, W);
+  hipLaunchKernelGGL(ccl_flatten_stats_kernel, grid, blk, 0, s, b, H, W);
+  hipLaunchKernelGGL(candidates_kernel, grid, blk, 0, s, b, npx, text_threshold, min_area);
+  hipLaunchKernelGGL(rowext_init_kernel, grid, blk, 0, s, b, npx);
+  hipLaunchKernelGGL(rowext_kernel, grid, blk, 0, s, b, H, W);
 }
 
 // ------------------------------------------------------------------ crop-batch packer
 // One workgroup per crop: OpenCV fixed-point bilinear resample of image[y0:y1, x0:x1] to 32x128.
 // The reference swaps channels before cropping (:349) and again after the resize (:441); the
 // resize is per channel, so the net effect is the caller's channel order — no swap here.
-__global__ void pack_crops_kernel(const uint8_t* __restrict__ image, int stride, const int* __restrict__ rects, uint8_t* __restrict__ out) {
+__global__ void pack_crops_kernel(const uint8_t* __restrict__ images, size_t page_bytes, int stride, const int* __restrict__ rects, uint8_t* __restrict__ out) {
   const int n = blockIdx.x;
-  const int x0 = rects[4 * n], y0 = rects[4 * n + 1], x1 = rects[4 * n + 2], y1 = rects[4 * n + 3];
+  const int x0 = rects[5 * n], y0 = rects[5 * n + 1], x1 = rects[5 * n + 2], y1 = rects[5 * n + 3];
+  const uint8_t* image = images + (size_t)rects[5 * n + 4] * page_bytes;
   uint8_t* o = out + (size_t)n * 32 * 128 * 3;
   if (x1 <= x0 || y1 <= y0) {
     for (int p = threadIdx.x; p < 32 * 128 * 3; p += blockDim.x) o[p] = 0;
@@ -189,10 +222,9 @@ __global__ void pack_crops_kernel(const uint8_t* __restrict__ image, int stride,
   }
 }
 
-void launch_pack_crops(const uint8_t* image, int h, int w, int stride, const int* rects, uint8_t* out, int N, hipStream_t s) {
-  (void)h; (void)w;
+void launch_pack_crops(const uint8_t* images, size_t page_bytes, int stride, const int* rects5, uint8_t* out, int N, hipStream_t s) {
   if (N <= 0) return;
-  hipLaunchKernelGGL(pack_crops_kernel, dim3(N), dim3(256), 0, s, image, stride, rects, out);
+  hipLaunchKernelGGL(pack_crops_kernel, dim3(N), dim3(256), 0, s, images, page_bytes, stride, rects5, out);
 }
 
 }  // namespace ttr

@@ -58,6 +58,7 @@ SYMBOLS = [
     ("ttr_last_stage_ms", _I, [_VP, _PF]),
     ("ttr_set_profiling", _I, [_VP, _I]),
     ("ttr_set_gemm_config", None, [_I]),
+    ("ttr_set_decoder_mode", None, [_I]),
     ("ttr_bench_conv", _I, [_VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _PF]),
     ("ttr_get_profile", _I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
 ]
