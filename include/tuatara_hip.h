@@ -91,6 +91,10 @@ int ttr_decode_ids(const int32_t* ids, int n, char* buf);
 int ttr_dbg_conv(ttr_engine* e, const float* in0, int C0, const float* in1, int C1, int relu0, int relu1, int B, int H, int W,
                  int ks, int dil, const float* wgt, const float* bias, int Cout, int act, float* out);
 
+/* bf16 engines: one conv layer (single source) with the 2x2 max-pool fused into its epilogue, as CRAFT's trunk uses it.
+ * out_full (optional) f32 [B][H][W][Cout] and out_pool f32 [B][H/2][W/2][Cout] receive the bf16 results widened to f32. */
+int ttr_dbg_conv_pool(ttr_engine* e, const float* in0, int C0, int B, int H, int W, int ks, const float* wgt, const float* bias,
+                      int Cout, int act, int pool_relu, float* out_full, float* out_pool);
 /* Which kernel serves bf16 layers: -1 = first-generation igemm only, 0 = automatic (default),
  * 1..6 = force that gemm2 tile configuration where it applies.  Process-wide; for tuning and tests. */
 void ttr_set_gemm_config(int cfg);

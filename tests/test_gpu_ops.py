@@ -119,3 +119,28 @@ def test_gemm2_matches_first_generation_kernel(eng_bf16):
     finally:
         eng_bf16.lib.ttr_set_gemm_config(0)
     assert np.abs(old - new).max() < 1e-4
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 3, 5])
+@pytest.mark.parametrize("case", [(1, 12, 40, 64, 64, 1, False), (2, 6, 10, 128, 136, 0, True), (1, 18, 14, 64, 256, 1, False)])
+def test_gemm2_fused_maxpool(eng_bf16, case, cfg):
+    """CRAFT's trunk pools: the 2x2 max-pool fused into the conv epilogue equals pooling the conv's own bf16 output
+    bit for bit (max commutes with rounding), and that output matches the fp32 reference."""
+    B, H, W, C0, Cout, act, pool_relu = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    bf = lambda a: torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy()
+    x = bf(rng.standard_normal((B, H, W, C0)).astype(np.float32))
+    w = bf((rng.standard_normal((Cout, 3, 3, C0)) / np.sqrt(9 * C0)).astype(np.float32))
+    b = rng.standard_normal(Cout).astype(np.float32)
+    try:
+        eng_bf16.lib.ttr_set_gemm_config(cfg)
+        full, pool = eng_bf16.dbg_conv_pool(x, w, b, 3, act, pool_relu)
+        _, pool_only = eng_bf16.dbg_conv_pool(x, w, b, 3, act, pool_relu, want_full=False)
+    finally:
+        eng_bf16.lib.ttr_set_gemm_config(0)
+    ref = _ref_conv(x, w, b, 3, 1, act)
+    assert np.abs(full - ref).max() < 0.03                 # bf16 output rounding
+    src = np.maximum(full, 0) if pool_relu else full
+    want = src.reshape(B, H // 2, 2, W // 2, 2, Cout).max(axis=(2, 4))
+    assert np.array_equal(pool, want)
+    assert np.array_equal(pool_only, want)

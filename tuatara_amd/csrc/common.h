@@ -25,6 +25,7 @@ struct ConvParams {
   void* out; int out_ld;     // T output, row stride in elements (may be null)
   float* out_f32; int out_f32_ld;  // optional f32 output
   void* out_relu;            // optional second T output (row stride out_ld): max(value, 0) of what `out` receives
+  void* out_pool; int pool_relu;   // gemm2 only: optional 2x2/stride-2 max-pooled T output [B][H/2][W/2][Cout] (row stride out_ld), ReLU first if pool_relu
   const float* resid; int resid_ld; int resid_mod;  // f32 residual added before act; row = m % resid_mod if resid_mod
   int Cout, M, act;
 };

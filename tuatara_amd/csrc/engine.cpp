@@ -339,7 +339,7 @@ struct Engine {
   }
 
   void conv(const char* name, const void* in0, int C0, const void* in1, int C1, int relu0, int B, int H, int W, void* out, int act,
-            float* out_f32 = nullptr, void* out_relu = nullptr) {
+            float* out_f32 = nullptr, void* out_relu = nullptr, void* out_pool = nullptr, int pool_relu = 0) {
     const Linear& L = craft.at(name);
     ConvParams p{};
     p.in0 = in0; p.C0 = C0; p.in1 = in1; p.C1 = C1; p.relu0 = relu0; p.relu1 = 0;
@@ -349,7 +349,7 @@ struct Engine {
     if (L.k != p.ks * p.ks * Ct) throw std::runtime_error(std::string("conv shape mismatch at ") + name);
     p.dil = std::string(name) == "slice5.1" ? 6 : 1;
     p.wgt = L.w.p; p.bias = L.b.as<float>();
-    p.out = out; p.out_ld = L.cout; p.out_f32 = out_f32; p.out_f32_ld = L.cout; p.out_relu = out_relu;
+    p.out = out; p.out_ld = L.cout; p.out_f32 = out_f32; p.out_f32_ld = L.cout; p.out_relu = out_relu; p.out_pool = out_pool; p.pool_relu = pool_relu;
     p.Cout = L.cout; p.M = B * H * W; p.act = act;
     double flops = 0;   // algorithmic: 2 * M * Cout * K of the *unpadded* layer
     for (const auto& c : craft_convs()) if (std::string(c.name) == name) flops = 2.0 * p.M * c.cout * c.ks * c.ks * c.cin;
@@ -373,21 +373,27 @@ struct Engine {
       launch_im2col_l1(prec, d_canvas, a0, B, H, W, stream);
       conv("slice1.0", a0, 32, nullptr, 0, 0, 1, 1, (int)M0, c11, kActRelu);
     }
-    void* c12 = buf(M0, 64);  conv("slice1.3", c11, 64, nullptr, 0, 0, B, H, W, c12, kActRelu);
-    void* p1 = buf(M1, 64);   launch_maxpool2x2(prec, c12, p1, B, H, W, 64, 0, stream);
+    // 2x2 max-pools: fused into the producing conv's epilogue in bf16 mode (gemm2), a separate kernel in f32 mode
+    const bool fp = prec == kBF16 && gemm_config() >= 0;
+    void* c12 = buf(fp ? 0 : M0, 64); void* p1 = buf(M1, 64);
+    if (fp) conv("slice1.3", c11, 64, nullptr, 0, 0, B, H, W, nullptr, kActRelu, nullptr, nullptr, p1);
+    else { conv("slice1.3", c11, 64, nullptr, 0, 0, B, H, W, c12, kActRelu); launch_maxpool2x2(prec, c12, p1, B, H, W, 64, 0, stream); }
     void* c21 = buf(M1, 128); conv("slice1.7", p1, 64, nullptr, 0, 0, B, H1, W1, c21, kActRelu);
-    void* c22 = buf(M1, 128); conv("slice1.10", c21, 128, nullptr, 0, 0, B, H1, W1, c22, kActNone);   // relu2_2 skip (pre-ReLU)
-    void* p2 = buf(M2, 128);  launch_maxpool2x2(prec, c22, p2, B, H1, W1, 128, 1, stream);
+    void* c22 = buf(M1, 128); void* p2 = buf(M2, 128);                                                   // relu2_2 skip (pre-ReLU)
+    if (fp) conv("slice1.10", c21, 128, nullptr, 0, 0, B, H1, W1, c22, kActNone, nullptr, nullptr, p2, 1);
+    else { conv("slice1.10", c21, 128, nullptr, 0, 0, B, H1, W1, c22, kActNone); launch_maxpool2x2(prec, c22, p2, B, H1, W1, 128, 1, stream); }
     void* c31 = buf(M2, 256); conv("slice2.14", p2, 128, nullptr, 0, 0, B, H2, W2, c31, kActRelu);
     void* c32 = buf(M2, 256); void* c32r = buf(M2, 256);
     conv("slice2.17", c31, 256, nullptr, 0, 0, B, H2, W2, c32, kActNone, nullptr, c32r);                // relu3_2 skip (pre-ReLU) + its ReLU
-    void* c33 = buf(M2, 256); conv("slice3.20", c32r, 256, nullptr, 0, 0, B, H2, W2, c33, kActRelu);
-    void* p3 = buf(M3, 256);  launch_maxpool2x2(prec, c33, p3, B, H2, W2, 256, 0, stream);
+    void* c33 = buf(fp ? 0 : M2, 256); void* p3 = buf(M3, 256);
+    if (fp) conv("slice3.20", c32r, 256, nullptr, 0, 0, B, H2, W2, nullptr, kActRelu, nullptr, nullptr, p3);
+    else { conv("slice3.20", c32r, 256, nullptr, 0, 0, B, H2, W2, c33, kActRelu); launch_maxpool2x2(prec, c33, p3, B, H2, W2, 256, 0, stream); }
     void* c41 = buf(M3, 512); conv("slice3.24", p3, 256, nullptr, 0, 0, B, H3, W3, c41, kActRelu);
     void* c42 = buf(M3, 512); void* c42r = buf(M3, 512);
     conv("slice3.27", c41, 512, nullptr, 0, 0, B, H3, W3, c42, kActNone, nullptr, c42r);                // relu4_3 skip + its ReLU
-    void* c43 = buf(M3, 512); conv("slice4.30", c42r, 512, nullptr, 0, 0, B, H3, W3, c43, kActRelu);
-    void* p4 = buf(M4, 512);  launch_maxpool2x2(prec, c43, p4, B, H3, W3, 512, 0, stream);
+    void* c43 = buf(fp ? 0 : M3, 512); void* p4 = buf(M4, 512);
+    if (fp) conv("slice4.30", c42r, 512, nullptr, 0, 0, B, H3, W3, nullptr, kActRelu, nullptr, nullptr, p4);
+    else { conv("slice4.30", c42r, 512, nullptr, 0, 0, B, H3, W3, c43, kActRelu); launch_maxpool2x2(prec, c43, p4, B, H3, W3, 512, 0, stream); }
     void* c51 = buf(M4, 512); conv("slice4.34", p4, 512, nullptr, 0, 0, B, H4, W4, c51, kActRelu);
     void* c52 = buf(M4, 512); conv("slice4.37", c51, 512, nullptr, 0, 0, B, H4, W4, c52, kActNone);   // relu5_3 skip
     void* mp = buf(M4, 512);  launch_maxpool3x3s1(prec, c52, mp, B, H4, W4, 512, stream);
@@ -846,6 +852,39 @@ int ttr_dbg_conv(ttr_engine* e, const float* in0, int C0, const float* in1, int 
   launch_igemm(E.prec, p, E.stream);
   TTR_HIP_CHECK(hipMemcpyAsync(out, dout.p, M * Cout * 4, hipMemcpyDeviceToHost, E.stream));
   TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
+  return 0;
+  TTR_GUARD_END(-1)
+}
+
+int ttr_dbg_conv_pool(ttr_engine* e, const float* in0, int C0, int B, int H, int W, int ks, const float* wgt, const float* bias, int Cout, int act,
+                      int pool_relu, float* out_full, float* out_pool) {
+  TTR_GUARD_BEGIN
+  Engine& E = *e->e;
+  std::lock_guard<std::mutex> lk(E.mu);
+  if (E.prec != kBF16) throw std::runtime_error("ttr_dbg_conv_pool: bf16 engines only (the fused pool lives in gemm2)");
+  const size_t M = (size_t)B * H * W, Mp = M / 4;
+  const int K = ks * ks * C0;
+  DevBuf d0, dfull, dpool;
+  Linear L;
+  std::vector<uint16_t> hbuf(M * C0);
+  for (size_t i = 0; i < hbuf.size(); ++i) hbuf[i] = f32_to_bf16_rne(in0[i]);
+  d0.ensure(hbuf.size() * 2);
+  TTR_HIP_CHECK(hipMemcpy(d0.p, hbuf.data(), hbuf.size() * 2, hipMemcpyHostToDevice));
+  E.upload_linear(L, wgt, Cout, K, bias, Cout, K);
+  dfull.ensure(M * Cout * 2); dpool.ensure(Mp * Cout * 2);
+  ConvParams p{};
+  p.in0 = d0.p; p.C0 = C0; p.B = B; p.H = H; p.W = W; p.ks = ks; p.dil = 1; p.wgt = L.w.p; p.bias = bias ? L.b.as<float>() : nullptr;
+  p.out = out_full ? dfull.p : nullptr; p.out_ld = Cout; p.out_pool = dpool.p; p.pool_relu = pool_relu;
+  p.Cout = Cout; p.M = (int)M; p.act = act;
+  launch_igemm(E.prec, p, E.stream);
+  auto down = [&](const DevBuf& d, size_t n, float* dst) {
+    std::vector<uint16_t> h(n);
+    TTR_HIP_CHECK(hipMemcpyAsync(h.data(), d.p, n * 2, hipMemcpyDeviceToHost, E.stream));
+    TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
+    for (size_t i = 0; i < n; ++i) { uint32_t u = (uint32_t)h[i] << 16; memcpy(&dst[i], &u, 4); }
+  };
+  if (out_full) down(dfull, M * Cout, out_full);
+  down(dpool, Mp * Cout, out_pool);
   return 0;
   TTR_GUARD_END(-1)
 }

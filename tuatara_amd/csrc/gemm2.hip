@@ -75,6 +75,16 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
   const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.wgt, (unsigned)((size_t)p.Cout * K * 2));
   constexpr unsigned OOB = 0x80000000u;
 
+  // Tile row -> pixel.  Normally the identity (tile rows are consecutive pixels).  With a fused 2x2 max-pool the
+  // tile is BM/4 consecutive *pooled* pixels: row r is sub-pixel (dy, dx) = (r>>1 & 1, r & 1) of pooled pixel r>>2,
+  // so the four partners of a pool window sit in four neighbouring lanes of one MFMA tile.
+  auto row_to_pixel = [&](int grow) -> int {
+    if (!p.out_pool) return grow;
+    const int q = grow >> 2, sub = grow & 3, Wo = p.W >> 1, Ho = p.H >> 1;
+    const int xo = q % Wo, t = q / Wo, yo = t % Ho, b = t / Ho;
+    return (b * p.H + 2 * yo + (sub >> 1)) * p.W + 2 * xo + (sub & 1);
+  };
+
   // ---- per-lane loader state.  Piece q = i*NW + wave covers tile rows 8q..8q+7; this lane owns
   // row 8q + (lane>>3) and LDS chunk (lane&7), which holds global chunk (lane&7) ^ ((row>>1)&7).
   unsigned xb0[C::XPW], xb1[C::XPW];   // byte offset of (pixel, chunk) in source 0 / 1
@@ -83,9 +93,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
   for (int i = 0; i < C::XPW; ++i) {
     const int row = (i * C::NW + wave) * 8 + (lane >> 3);
     const int g = (lane & 7) ^ ((row >> 1) & 7);
-    const int m = m0 + row;
+    const int m = row_to_pixel(m0 + row);
     unsigned mask = 0;
-    if (m < p.M) {
+    if (m0 + row < p.M) {
       if (p.ks == 3) {
         const int r = m % HW, y = r / p.W, x = r - y * p.W;
 #pragma unroll
@@ -196,12 +206,13 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
     }
 #pragma unroll
     for (int i = 0; i < C::MI; ++i) {
-      const int m = m0 + wm * C::TM + i * 16 + fr;
-      if (m >= p.M) continue;
+      const int grow = m0 + wm * C::TM + i * 16 + fr;
+      const bool valid = grow < p.M;                 // uniform over each group of 4 lanes when pooling (M % 4 == 0)
+      const int m = row_to_pixel(valid ? grow : 0);
       float v[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = acc[2 * t][i][e] + bv[e]; v[4 + e] = acc[2 * t + 1][i][e] + bv[4 + e]; }
-      if (p.resid) {
+      if (p.resid && valid) {
         const float* rp = p.resid + (int64_t)(p.resid_mod ? m % p.resid_mod : m) * p.resid_ld + n;
         const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
         v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
@@ -213,22 +224,33 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
       }
-      if (p.out) {
+      if (p.out && valid) {
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
         *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out) + (int64_t)m * p.out_ld + n) = o;
       }
-      if (p.out_relu) {
+      if (p.out_relu && valid) {
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (bf16)fmaxf(v[e], 0.f);
         *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out_relu) + (int64_t)m * p.out_ld + n) = o;
       }
-      if (p.out_f32) {
+      if (p.out_f32 && valid) {
         float* op = p.out_f32 + (int64_t)m * p.out_f32_ld + n;
         *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+      if (p.out_pool) {   // 2x2 max over lanes fr, fr^1, fr^2, fr^3; rounding to bf16 commutes with max
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float x = p.pool_relu ? fmaxf(v[e], 0.f) : v[e];
+          x = fmaxf(x, __shfl_xor(x, 1));
+          x = fmaxf(x, __shfl_xor(x, 2));
+          o[e] = (bf16)x;
+        }
+        if (valid && (fr & 3) == 0) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out_pool) + (int64_t)(grow >> 2) * p.out_ld + n) = o;
       }
     }
   }
@@ -254,6 +276,7 @@ const char* gemm2_check(const ConvParams& p) {
   if (p.relu0 || p.relu1) return "gemm2: ReLU-on-load is not supported";
   if (p.out && (p.out_ld % 8 || ((uintptr_t)p.out & 15))) return "gemm2: bf16 output must be 16-byte aligned";
   if (p.out_relu && (!p.out || ((uintptr_t)p.out_relu & 15))) return "gemm2: out_relu needs out and 16-byte alignment";
+  if (p.out_pool && ((p.H | p.W) & 1 || p.out_ld % 8 || ((uintptr_t)p.out_pool & 15))) return "gemm2: fused max-pool needs even H, W and a 16-byte aligned output";
   if (p.out_f32 && (p.out_f32_ld % 4 || ((uintptr_t)p.out_f32 & 15))) return "gemm2: f32 output must be 16-byte aligned";
   if (p.resid && (p.resid_ld % 4 || ((uintptr_t)p.resid & 15))) return "gemm2: residual must be 16-byte aligned";
   if (p.bias && ((uintptr_t)p.bias & 15)) return "gemm2: bias must be 16-byte aligned";

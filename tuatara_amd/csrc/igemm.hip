@@ -245,6 +245,7 @@ const char* igemm_check(const ConvParams& p) {
   if (!p.in0 || !p.wgt) return "igemm: null operand";
   if (p.M != p.B * p.H * p.W) return "igemm: M != B*H*W";
   if (p.M <= 0 || p.Cout <= 0) return "igemm: empty problem";
+  if (p.out_pool && (p.relu0 || p.relu1 || (p.C0 + p.C1) % 64 || p.C0 % 64 || p.Cout % 8)) return "igemm: the fused max-pool output needs a gemm2-eligible layer";
   if ((int64_t)p.M * (int64_t)(Ctot > p.Cout ? Ctot : p.Cout) >= (1ll << 40)) return "igemm: problem too large";
   return nullptr;
 }
@@ -256,6 +257,7 @@ int gemm_config() { return g_gemm_cfg; }
 void launch_igemm(Precision prec, const ConvParams& p, hipStream_t s) {
   if (const char* e = igemm_check(p)) throw std::runtime_error(e);
   if (prec == kBF16 && g_gemm_cfg >= 0 && gemm2_check(p) == nullptr) return launch_gemm2(p, g_gemm_cfg, s);
+  if (p.out_pool) throw std::runtime_error("igemm: fused max-pool output is only available in the bf16 gemm2 kernel");
   if (prec == kBF16) launch_t<bf16>(p, s); else launch_t<float>(p, s);
 }
 

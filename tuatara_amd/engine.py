@@ -57,6 +57,7 @@ SYMBOLS = [
     ("ttr_dev_sync", _I, [_VP]),
     ("ttr_last_stage_ms", _I, [_VP, _PF]),
     ("ttr_set_profiling", _I, [_VP, _I]),
+    ("ttr_dbg_conv_pool", _I, [_VP, _PF, _I, _I, _I, _I, _I, _PF, _PF, _I, _I, _I, _PF, _PF]),
     ("ttr_set_gemm_config", None, [_I]),
     ("ttr_set_decoder_mode", None, [_I]),
     ("ttr_bench_conv", _I, [_VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _PF]),
@@ -271,6 +272,20 @@ class Engine:
         ids = np.zeros((n, 26), np.int32)
         self._check(self.lib.ttr_parseq_logits(self.h, _u8(crops), n, _f(logits), _f(ar) if want_ar else None, _i(ids)))
         return (logits, ar, ids) if want_ar else (logits, ids)
+
+    def dbg_conv_pool(self, x0: np.ndarray, w: np.ndarray, bias: Optional[np.ndarray], ks: int, act: int = 0, pool_relu: bool = False,
+                      want_full: bool = True):
+        """bf16 engines: conv + fused 2x2 max-pool -> (full f32 [B,H,W,Cout] or None, pooled f32 [B,H/2,W/2,Cout])."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float32)
+        B, H, W_, C0 = x0.shape
+        w = np.ascontiguousarray(w, dtype=np.float32)
+        Cout = w.shape[0]
+        full = np.zeros((B, H, W_, Cout), np.float32) if want_full else None
+        pool = np.zeros((B, H // 2, W_ // 2, Cout), np.float32)
+        b = np.ascontiguousarray(bias, dtype=np.float32) if bias is not None else None
+        self._check(self.lib.ttr_dbg_conv_pool(self.h, _f(x0), C0, B, H, W_, ks, _f(w), _f(b) if b is not None else None, Cout, act,
+                                               int(pool_relu), _f(full) if want_full else None, _f(pool)))
+        return full, pool
 
     def dbg_conv(self, x0: np.ndarray, w: np.ndarray, bias: Optional[np.ndarray], ks: int, dil: int = 1, act: int = 0,
                  x1: Optional[np.ndarray] = None, relu0: bool = False, relu1: bool = False) -> np.ndarray:
