@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-iters", type=int, default=20)
+    ap.add_argument("--tune", action="append", default=[], help="engine tuning knob key=value (ttr_set_tuning), repeatable")
     ap.add_argument("--decoder-mode", type=int, default=None, help="ttr_set_decoder_mode override (0 = kernel per op, 4/8/16 = fused)")
     args = ap.parse_args()
 
@@ -100,6 +101,9 @@ def main():
     eng = engs[0]
     if args.decoder_mode is not None:
         eng.lib.ttr_set_decoder_mode(args.decoder_mode)
+    for kv in args.tune:
+        k, v = kv.split("=")
+        assert eng.lib.ttr_set_tuning(k.encode(), int(v)) == 0, kv
     pages = [synth.synthetic_page(1000 * rank + i, H, Wd, n_words=args.words) for i in range(P)]
     # each context owns a contiguous share of the step's pages, resident in HBM before the timed region
     share = [P // NC + (1 if c < P % NC else 0) for c in range(NC)]

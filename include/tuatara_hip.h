@@ -63,6 +63,11 @@ const char* ttr_result_text(const ttr_result* r, int i);
 const float* ttr_result_bbox(const ttr_result* r, int i);   /* {x1,y1,x2,y2}, tuatara.cpp:272 */
 const int32_t* ttr_result_ids(const ttr_result* r, int i);  /* 26 argmax token ids of crop i */
 void ttr_result_free(ttr_result* r);
+/* bulk views for bindings (valid until ttr_result_free): all boxes [count][4], all ids [count][26]; the texts of all
+ * items, each followed by '\n' (no token maps to '\n'), copied into buf when cap suffices; returns the bytes needed. */
+const float* ttr_result_bboxes(const ttr_result* r);
+const int32_t* ttr_result_ids_all(const ttr_result* r);
+int ttr_result_texts(const ttr_result* r, char* buf, size_t cap);
 
 /* ---- stage-level entry points (BASELINE.json configs 2-3; used by the parity tests) -------- */
 /* CRAFT forward (tuatara.cpp:363-394): canvas u8 [H][W][3] (H,W multiples of 32, already resized,
@@ -101,6 +106,9 @@ void ttr_set_gemm_config(int cfg);
 /* PARSeq autoregressive loop in bf16 mode: 0 = one kernel per op (the f32 mode's schedule), 4 / 8 / 16 = the
  * fused persistent kernel with that many crops per workgroup, anything else = automatic (default). */
 void ttr_set_decoder_mode(int mode);
+/* Process-wide tuning knobs by name: "gemm_config", "decoder_mode" (as above), "enc_chunk" (crops per PARSeq
+ * encoder group, 0 = all at once).  Returns 0, or -1 for an unknown key.  Results do not depend on any of them. */
+int ttr_set_tuning(const char* key, int value);
 /* Times one conv / linear layer on device-generated random data (no host traffic): average
  * microseconds per launch over `iters` back-to-back launches.  f32_resid != 0 selects the PARSeq
  * residual form (f32 residual in, f32 out) instead of a bf16/T output. */

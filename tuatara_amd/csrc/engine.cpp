@@ -37,6 +37,7 @@ void hip_fail(const char* what, hipError_t e, const char* file, int line) {
 }
 
 static thread_local std::string g_last_error;
+static int g_enc_chunk = 0;        // crops per encoder group (0 = all crops at once)
 static int g_decoder_mode = 1;   // 0 = kernel-per-op AR loop, 4/8/16 = fused kernel with that many crops per workgroup, else automatic
 
 // ------------------------------------------------------------------ small utilities
@@ -462,15 +463,22 @@ struct Engine {
     void* att = (pq_ws[4].ensure((size_t)std::max(M, N * 26) * E * es), pq_ws[4].p);
     launch_patchify(prec, d_crops, patches, N, stream);
     gemm(pq.at("patch"), patches, M, nullptr, 0, kActNone, x, E, pqf.at("encoder.pos_embed").as<float>(), E, 128);
-    for (int l = 0; l < 12; ++l) {
-      std::string p = "encoder.blocks." + std::to_string(l) + ".";
-      ln(x, p + "norm1", 1e-6f, t384, M);
-      gemm(pq.at(p + "qkv"), t384, M, tbig, 3 * E, kActNone);
-      launch_attn_enc(prec, tbig, att, N, stream);
-      gemm(pq.at(p + "proj"), att, M, nullptr, 0, kActNone, x, E, x, E, 0);
-      ln(x, p + "norm2", 1e-6f, t384, M);
-      gemm(pq.at(p + "fc1"), t384, M, tbig, 4 * E, kActGelu);
-      gemm(pq.at(p + "fc2"), tbig, M, nullptr, 0, kActNone, x, E, x, E, 0);
+    // The 12 encoder blocks run over groups of crops so that a group's widest intermediates (qkv, the MLP hidden) are
+    // re-read from the 256 MiB Infinity Cache rather than from HBM (g_enc_chunk crops per group; 0 = one group).
+    const int CH = g_enc_chunk > 0 ? g_enc_chunk : N;
+    for (int c0 = 0; c0 < N; c0 += CH) {
+      const int nc = std::min(CH, N - c0), Mc = nc * 128;
+      float* xc = x + (size_t)c0 * 128 * E;
+      for (int l = 0; l < 12; ++l) {
+        std::string p = "encoder.blocks." + std::to_string(l) + ".";
+        ln(xc, p + "norm1", 1e-6f, t384, Mc);
+        gemm(pq.at(p + "qkv"), t384, Mc, tbig, 3 * E, kActNone);
+        launch_attn_enc(prec, tbig, att, nc, stream);
+        gemm(pq.at(p + "proj"), att, Mc, nullptr, 0, kActNone, xc, E, xc, E, 0);
+        ln(xc, p + "norm2", 1e-6f, t384, Mc);
+        gemm(pq.at(p + "fc1"), t384, Mc, tbig, 4 * E, kActGelu);
+        gemm(pq.at(p + "fc2"), tbig, Mc, nullptr, 0, kActNone, xc, E, xc, E, 0);
+      }
     }
     ln(x, "encoder.norm", 1e-6f, t384, M);                       // memory
     void* kvmem = (pq_ws[5].ensure((size_t)M * 768 * es), pq_ws[5].p);
@@ -717,6 +725,17 @@ const char* ttr_result_text(const ttr_result* r, int i) { return r->r.text[i].c_
 const float* ttr_result_bbox(const ttr_result* r, int i) { return &r->r.bbox[4 * (size_t)i]; }
 const int32_t* ttr_result_ids(const ttr_result* r, int i) { return &r->r.ids[26 * (size_t)i]; }
 void ttr_result_free(ttr_result* r) { delete r; }
+const float* ttr_result_bboxes(const ttr_result* r) { return r && !r->r.bbox.empty() ? r->r.bbox.data() : nullptr; }
+const int32_t* ttr_result_ids_all(const ttr_result* r) { return r && !r->r.ids.empty() ? r->r.ids.data() : nullptr; }
+int ttr_result_texts(const ttr_result* r, char* buf, size_t cap) {
+  if (!r) return 0;
+  size_t need = 0;
+  for (const auto& t : r->r.text) need += t.size() + 1;
+  if (!buf || cap < need) return (int)need;
+  size_t o = 0;
+  for (const auto& t : r->r.text) { memcpy(buf + o, t.data(), t.size()); o += t.size(); buf[o++] = '\n'; }
+  return (int)need;
+}
 
 int ttr_craft_heatmap(ttr_engine* e, const uint8_t* canvas, int H, int W, float* heat_out) {
   TTR_GUARD_BEGIN
@@ -891,6 +910,14 @@ int ttr_dbg_conv_pool(ttr_engine* e, const float* in0, int C0, int B, int H, int
 
 void ttr_set_gemm_config(int cfg) { set_gemm_config(cfg); }
 void ttr_set_decoder_mode(int mode) { g_decoder_mode = mode; }
+int ttr_set_tuning(const char* key, int value) {
+  const std::string k = key ? key : "";
+  if (k == "gemm_config") set_gemm_config(value);
+  else if (k == "decoder_mode") g_decoder_mode = value;
+  else if (k == "enc_chunk") g_enc_chunk = value;
+  else return -1;
+  return 0;
+}
 
 int ttr_bench_conv(ttr_engine* e, int B, int H, int W, int C0, int C1, int ks, int dil, int Cout, int act, int f32_resid, int iters, float* avg_us) {
   TTR_GUARD_BEGIN

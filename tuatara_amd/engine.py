@@ -40,6 +40,9 @@ SYMBOLS = [
     ("ttr_result_bbox", _PF, [_VP, _I]),
     ("ttr_result_ids", _PI, [_VP, _I]),
     ("ttr_result_free", None, [_VP]),
+    ("ttr_result_bboxes", _PF, [_VP]),
+    ("ttr_result_ids_all", _PI, [_VP]),
+    ("ttr_result_texts", _I, [_VP, C.c_char_p, C.c_size_t]),
     ("ttr_craft_heatmap", _I, [_VP, _PU8, _I, _I, _PF]),
     ("ttr_ccl_boxes", _I, [_VP, _PF, _I, _I, _PF, _I, _PI]),
     ("ttr_resize_canvas", _I, [_VP, _PU8, _I, _I, _I, _PU8, C.c_size_t, _PI, _PI, _PF]),
@@ -60,6 +63,7 @@ SYMBOLS = [
     ("ttr_dbg_conv_pool", _I, [_VP, _PF, _I, _I, _I, _I, _I, _PF, _PF, _I, _I, _I, _PF, _PF]),
     ("ttr_set_gemm_config", None, [_I]),
     ("ttr_set_decoder_mode", None, [_I]),
+    ("ttr_set_tuning", _I, [C.c_char_p, _I]),
     ("ttr_bench_conv", _I, [_VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _PF]),
     ("ttr_get_profile", _I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
 ]
@@ -185,12 +189,17 @@ class Engine:
             raise EngineError(self.lib.ttr_last_error().decode())
 
     def _take(self, r) -> List[dict]:
+        """ttr_result -> the reference's list of {"text", "bbox"} dicts (+ "ids"), through the bulk getters."""
+        n = self.lib.ttr_result_count(r)
         out = []
-        for i in range(self.lib.ttr_result_count(r)):
-            bb = self.lib.ttr_result_bbox(r, i)
-            ids = self.lib.ttr_result_ids(r, i)
-            out.append({"text": self.lib.ttr_result_text(r, i).decode("latin1"), "bbox": [float(bb[j]) for j in range(4)],
-                        "ids": [int(ids[j]) for j in range(26)]})
+        if n:
+            bb = np.ctypeslib.as_array(self.lib.ttr_result_bboxes(r), (n, 4)).tolist()
+            ids = np.ctypeslib.as_array(self.lib.ttr_result_ids_all(r), (n, 26)).tolist()
+            need = self.lib.ttr_result_texts(r, None, 0)
+            buf = C.create_string_buffer(need)
+            self.lib.ttr_result_texts(r, buf, need)
+            texts = buf.raw[:need].decode("latin1").split("\n")
+            out = [{"text": texts[i], "bbox": bb[i], "ids": ids[i]} for i in range(n)]
         self.lib.ttr_result_free(r)
         return out
 
