@@ -83,10 +83,13 @@ G2_CASES = [
     (1, 12, 12, 64, 64, 72, 3, 1, 2),       # concat + 3x3 + GELU
     (1, 1, 700, 384, 0, 1152, 1, 1, 0),     # PARSeq qkv shape
     (1, 1, 300, 1536, 0, 384, 1, 1, 2),     # PARSeq fc2 shape (+GELU)
+    (1, 16, 64, 64, 0, 64, 3, 1, 1),        # conv3p-eligible (H % 8, W % 32): image-border halos on every side
+    (2, 8, 32, 128, 0, 136, 3, 1, 0),       # one patch per image, two channel chunks, ragged Cout
+    (1, 24, 96, 64, 0, 256, 3, 1, 1),       # 3 x 3 patches, BN 256
 ]
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("case", G2_CASES)
 def test_gemm2_configs(eng_bf16, case, cfg):
     B, H, W, C0, C1, Cout, ks, dil, act = case
@@ -121,8 +124,9 @@ def test_gemm2_matches_first_generation_kernel(eng_bf16):
     assert np.abs(old - new).max() < 1e-4
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 3, 5])
-@pytest.mark.parametrize("case", [(1, 12, 40, 64, 64, 1, False), (2, 6, 10, 128, 136, 0, True), (1, 18, 14, 64, 256, 1, False)])
+@pytest.mark.parametrize("cfg", [0, 1, 3, 5, 7])
+@pytest.mark.parametrize("case", [(1, 12, 40, 64, 64, 1, False), (2, 6, 10, 128, 136, 0, True), (1, 18, 14, 64, 256, 1, False),
+                                  (1, 16, 64, 64, 64, 1, False), (2, 8, 32, 128, 136, 0, True), (1, 24, 96, 64, 256, 1, False)])
 def test_gemm2_fused_maxpool(eng_bf16, case, cfg):
     """CRAFT's trunk pools: the 2x2 max-pool fused into the conv epilogue equals pooling the conv's own bf16 output
     bit for bit (max commutes with rounding), and that output matches the fp32 reference."""

@@ -53,6 +53,9 @@ CHECKS = [  # B, H, W, C0, C1, ks, dil, Cout, act
     (1, 12, 12, 64, 64, 3, 1, 72, 2),       # concat + 3x3 + gelu + ragged Cout
     (1, 1, 700, 384, 0, 1, 1, 1152, 0),     # linear layer
     (1, 1, 300, 1536, 0, 1, 1, 384, 2),
+    (1, 16, 64, 64, 0, 3, 1, 64, 1),        # conv3p-eligible shapes (H % 8, W % 32)
+    (2, 8, 32, 128, 0, 3, 1, 136, 0),
+    (1, 24, 96, 64, 0, 3, 1, 256, 1),
 ]
 
 LAYERS = [  # name, per-page H, W (0 = PARSeq rows), C0, C1, ks, dil, Cout, act, f32_resid
@@ -88,7 +91,7 @@ def main():
     ap.add_argument("--crops", type=int, default=320)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--skip-check", action="store_true")
-    ap.add_argument("--cfgs", default="-1,1,2,3,4,5,6")
+    ap.add_argument("--cfgs", default="-1,1,2,3,4,5,6,7")
     args = ap.parse_args()
     cfgs = [int(c) for c in args.cfgs.split(",")]
 

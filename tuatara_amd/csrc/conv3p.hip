@@ -1,0 +1,273 @@
+// 3x3 (stride 1, pad 1, dilation 1) NHWC bf16 convolution with a *patch-stationary* input tile (gfx950).
+//
+// gemm2.hip treats a 3x3 conv as a GEMM over K = 9*Cin and re-stages the activation tile for every
+// tap, i.e. it pulls every input pixel through L2 -> LDS nine times.  For the layers with few output
+// channels (CRAFT's slice1.*: Cout 64/128) that traffic, not the MFMA pipe, is the limit.  Here the
+// workgroup owns an 8 x 32 pixel patch of one image: for each 64-channel chunk the (8+2) x (32+2)
+// halo patch is brought into LDS ONCE (LDS-DMA, out-of-image pixels zero-filled by the buffer
+// resource's range rule) and the nine taps read their shifted MFMA fragments from it; only the
+// 64-channel x tap weight tile streams per K step (double buffered, one barrier per step).
+// L2 -> LDS bytes per MFMA drop by 1.7x (Cout 256) to 4x (Cout 64).
+//
+// Same ConvParams contract, same transposed-MFMA / 16-byte-store epilogue (bias, ReLU, optional
+// ReLU copy, optional fused 2x2 max-pool) as gemm2.hip; replaces LibTorch's conv2d inside the CRAFT
+// TorchScript module run at tuatara.cpp:376.
+#include "common.h"
+#include "kernels.h"
+
+namespace ttr {
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+constexpr int PH = 8, PW = 32, HW2 = PW + 2;          // patch, halo row length
+constexpr int XSLOTS = 344;                           // (PH+2)*(PW+2) = 340 pixel slots, padded to 43 pieces of 8
+constexpr int XPIECES = XSLOTS / 8;
+constexpr int XSTAGE = XSLOTS * 128;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+template <int BN, int WM, int WN>
+struct C3 {
+  static constexpr int NW = WM * WN, NT = NW * 64;
+  static constexpr int TM = 256 / WM, TN = BN / WN, MI = TM / 16, NJ = TN / 16;
+  static constexpr int XPW = (XPIECES + NW - 1) / NW;   // X pieces per wave (last ones may be past the end)
+  static constexpr int WP = BN / 8, WPW = WP / NW;
+  static constexpr int WSTAGE = BN * 128;
+  static constexpr int LDS = 2 * XSTAGE + 2 * WSTAGE;
+  static_assert(NW == 8 && TM % 64 == 0 && TN % 32 == 0 && WP % NW == 0, "conv3p tiling");
+};
+
+}  // namespace
+
+template <int BN, int WM, int WN>
+__global__ __launch_bounds__(512) void conv3p_kernel(ConvParams p) {
+  using C = C3<BN, WM, WN>;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  unsigned char* const xs = smem;                 // [2][XSLOTS][128 B]  slot pi = pr*34 + pc, chunk c holds channels 8*(c ^ (pi&7))..
+  unsigned char* const ws = smem + 2 * XSTAGE;    // [2][BN][128 B]      as in gemm2.hip
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  // ---- XCD-aware tile order (as gemm2.hip): consecutive tiles = N tiles of one patch, then the next patch
+  const int ptx = p.W / PW, pty = p.H / PH;
+  const int tilesM = p.B * pty * ptx, tilesN = (p.Cout + BN - 1) / BN;
+  const int T = tilesM * tilesN;
+  int tile;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    const int q = T >> 3, r = T & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = tile / tilesN, tn = tile - tm * tilesN;
+  const int n0 = tn * BN;
+  const int b = tm / (pty * ptx), trem = tm - b * pty * ptx, ty = trem / ptx, tx = trem - ty * ptx;
+  const int y0 = ty * PH, x0 = tx * PW;
+
+  const int Cin = p.C0, K = 9 * Cin, nchunks = Cin >> 6, nsteps = nchunks * 9;
+  const __amdgpu_buffer_rsrc_t rsx = mk_rsrc(p.in0, (unsigned)((size_t)p.M * Cin * 2));
+  const __amdgpu_buffer_rsrc_t rsw = mk_rsrc(p.wgt, (unsigned)((size_t)p.Cout * K * 2));
+  constexpr unsigned OOB = 0x80000000u;
+
+  // ---- loader state: X piece q = i*8 + wave covers halo slots 8q..8q+7; this lane owns slot 8q + (lane>>3), LDS chunk lane&7
+  unsigned xo[C::XPW];
+#pragma unroll
+  for (int i = 0; i < C::XPW; ++i) {
+    const int pi = (i * C::NW + wave) * 8 + (lane >> 3);
+    const int pr = pi / HW2, pc = pi - pr * HW2;
+    const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+    const int g = (lane & 7) ^ (pi & 7);
+    const bool ok = pi < (PH + 2) * HW2 && y >= 0 && y < p.H && x >= 0 && x < p.W;
+    xo[i] = ok ? (unsigned)((((b * p.H + y) * p.W + x) * Cin + g * 8) * 2) : OOB;
+  }
+  unsigned wb[C::WPW];
+#pragma unroll
+  for (int j = 0; j < C::WPW; ++j) {
+    const int row = (j * C::NW + wave) * 8 + (lane >> 3);
+    const int g = (lane & 7) ^ ((row >> 1) & 7);
+    const int q16 = row & 15;
+    const int n = n0 + (row & ~31) + (q16 >> 2) * 8 + ((row >> 4) & 1) * 4 + (q16 & 3);
+    wb[j] = n < p.Cout ? (unsigned)((n * K + g * 8) * 2) : OOB;
+  }
+  auto stage_x = [&](int chunk) {
+    unsigned char* sb = xs + (chunk & 1) * XSTAGE;
+    const unsigned co = (unsigned)(chunk * 64 * 2);
+#pragma unroll
+    for (int i = 0; i < C::XPW; ++i) {
+      const int piece = i * C::NW + wave;
+      if (piece < XPIECES) {
+        const unsigned vo = xo[i] == OOB ? OOB : xo[i] + co;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(sb + piece * 1024), 16, vo, 0, 0, 0);
+      }
+    }
+  };
+  auto stage_w = [&](int step) {   // step = chunk*9 + tap; weights are [Cout][tap][Cin]
+    unsigned char* sb = ws + (step & 1) * C::WSTAGE;
+    const int chunk = step / 9, tap = step - chunk * 9;
+    const unsigned ko = (unsigned)((tap * Cin + chunk * 64) * 2);
+#pragma unroll
+    for (int j = 0; j < C::WPW; ++j) {
+      const unsigned vo = wb[j] == OOB ? OOB : wb[j] + ko;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sb + (j * C::NW + wave) * 1024), 16, vo, 0, 0, 0);
+    }
+  };
+
+  // ---- fragment addressing.  Tile row r = wm*TM + 16i + fr is patch pixel (r>>5, r&31); tap (ky,kx) reads halo slot
+  // pi = (py+ky)*34 + px+kx, 16-byte chunk (4kk + fg) ^ (pi & 7): conflict-free for any 16 consecutive slots.
+  int pi0[C::MI];
+#pragma unroll
+  for (int i = 0; i < C::MI; ++i) {
+    const int r = wm * C::TM + i * 16 + fr;
+    pi0[i] = (r >> 5) * HW2 + (r & 31);
+  }
+  const int wfl = (lane & 15) * 128 + (((lane >> 4) ^ ((lane >> 1) & 7)) << 4) + wn * C::TN * 128;
+
+  f32x4 acc[C::NJ][C::MI];
+#pragma unroll
+  for (int j = 0; j < C::NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < C::MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage_x(0);
+  stage_w(0);
+  int chunk = 0, tap = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* xb = xs + (chunk & 1) * XSTAGE;
+    const unsigned char* wbuf = ws + (s & 1) * C::WSTAGE;
+    const int tapoff = (tap / 3) * HW2 + (tap % 3);
+    bf16x8 fx[2][C::MI], fw[2][C::NJ];
+#pragma unroll
+    for (int j = 0; j < C::NJ; ++j) fw[0][j] = *reinterpret_cast<const bf16x8*>(wbuf + wfl + j * 2048);
+    int xa[C::MI];
+#pragma unroll
+    for (int i = 0; i < C::MI; ++i) {
+      const int pi = pi0[i] + tapoff;
+      xa[i] = pi * 128 + ((fg ^ (pi & 7)) << 4);
+      fx[0][i] = *reinterpret_cast<const bf16x8*>(xb + xa[i]);
+    }
+    if (s + 1 < nsteps) stage_w(s + 1);
+    if (tap == 0 && chunk + 1 < nchunks) stage_x(chunk + 1);
+#pragma unroll
+    for (int j = 0; j < C::NJ; ++j) fw[1][j] = *reinterpret_cast<const bf16x8*>(wbuf + (wfl ^ 64) + j * 2048);
+#pragma unroll
+    for (int i = 0; i < C::MI; ++i) fx[1][i] = *reinterpret_cast<const bf16x8*>(xb + (xa[i] ^ 64));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+        for (int j = 0; j < C::NJ; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[kk][j], fx[kk][i], acc[j][i], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (++tap == 9) { tap = 0; ++chunk; }
+  }
+
+  // ---- epilogue: lane holds channels n..n+7 of patch pixel (py, px) for every i; i^2 is the pixel below / above
+#pragma unroll
+  for (int t = 0; t < C::NJ / 2; ++t) {
+    const int n = n0 + wn * C::TN + t * 32 + fg * 8;
+    if (n >= p.Cout) continue;
+    float bv[8];
+    if (p.bias) {
+      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+      bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+    }
+    float pooled[C::MI][8];   // only the even-row entries are used (and only when pooling)
+#pragma unroll
+    for (int i = 0; i < C::MI; ++i) {
+      const int r = wm * C::TM + i * 16 + fr;
+      const int y = y0 + (r >> 5), x = x0 + (r & 31);
+      const int64_t m = ((int64_t)b * p.H + y) * p.W + x;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = acc[2 * t][i][e] + bv[e]; v[4 + e] = acc[2 * t + 1][i][e] + bv[4 + e]; }
+      if (p.act == kActRelu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (p.out) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out) + m * p.out_ld + n) = o;
+      }
+      if (p.out_relu) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)fmaxf(v[e], 0.f);
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out_relu) + m * p.out_ld + n) = o;
+      }
+      if (p.out_pool) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float xv = p.pool_relu ? fmaxf(v[e], 0.f) : v[e];
+          xv = fmaxf(xv, __shfl_xor(xv, 1));           // horizontal partner: px ^ 1
+          pooled[i][e] = xv;
+        }
+      }
+    }
+    if (p.out_pool) {
+#pragma unroll
+      for (int i = 0; i < C::MI; ++i) {
+        if ((i & 2) == 0) {                            // patch row py = 2k: partner row py + 1 is i + 2
+          const int r = wm * C::TM + i * 16 + fr;
+          const int yo = (y0 + (r >> 5)) >> 1, xo2 = (x0 + (r & 31)) >> 1;
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16)fmaxf(pooled[i][e], pooled[i + 2][e]);
+          if ((fr & 1) == 0)
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out_pool) + (((int64_t)b * (p.H >> 1) + yo) * (p.W >> 1) + xo2) * p.out_ld + n) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int BN, int WM, int WN>
+static void launch_c3(const ConvParams& p, hipStream_t s) {
+  using C = C3<BN, WM, WN>;
+  const int tilesM = p.B * (p.H / PH) * (p.W / PW), tilesN = (p.Cout + BN - 1) / BN;
+  static bool once = false;
+  if (!once) {
+    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_kernel<BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+    once = true;
+  }
+  hipLaunchKernelGGL((conv3p_kernel<BN, WM, WN>), dim3(tilesM * tilesN), dim3(512), C::LDS, s, p);
+}
+
+const char* conv3p_check(const ConvParams& p) {
+  if (p.ks != 3 || p.dil != 1) return "conv3p: 3x3, dilation 1 only";
+  if (p.C1 || p.relu0 || p.relu1) return "conv3p: single source, no ReLU on load";
+  if (p.C0 % 64 || p.Cout % 8) return "conv3p: Cin % 64, Cout % 8";
+  if (p.H % PH || p.W % PW) return "conv3p: H % 8, W % 32";
+  if (p.resid || p.out_f32 || p.act == kActGelu) return "conv3p: conv epilogues only";
+  if (p.out && (p.out_ld % 8 || ((uintptr_t)p.out & 15))) return "conv3p: output alignment";
+  if (p.out_relu && (!p.out || ((uintptr_t)p.out_relu & 15))) return "conv3p: out_relu alignment";
+  if (p.out_pool && (p.out_ld % 8 || ((uintptr_t)p.out_pool & 15))) return "conv3p: out_pool alignment";
+  if (!p.out && !p.out_pool) return "conv3p: no output";
+  if (p.bias && ((uintptr_t)p.bias & 15)) return "conv3p: bias alignment";
+  if (((uintptr_t)p.in0 & 15) || ((uintptr_t)p.wgt & 15)) return "conv3p: operand alignment";
+  const size_t lim = (size_t)1 << 31;
+  if ((size_t)p.M * p.C0 * 2 >= lim || (size_t)p.Cout * 9 * p.C0 * 2 >= lim) return "conv3p: tensor too large for 32-bit buffer offsets";
+  if (p.M != p.B * p.H * p.W || p.M <= 0) return "conv3p: bad shape";
+  return nullptr;
+}
+
+void launch_conv3p(const ConvParams& p, hipStream_t s) {
+  if (const char* e = conv3p_check(p)) throw std::runtime_error(e);
+  if (p.Cout <= 64) return launch_c3<64, 4, 2>(p, s);
+  if (p.Cout <= 128 || p.Cout % 256) return launch_c3<128, 4, 2>(p, s);
+  return launch_c3<256, 2, 4>(p, s);
+}
+
+}  // namespace ttr

@@ -8,13 +8,17 @@ namespace ttr {
 // ---- igemm.hip
 const char* igemm_check(const ConvParams& p);
 void launch_igemm(Precision prec, const ConvParams& p, hipStream_t s);
-// which kernel serves bf16 problems: -1 = igemm.hip only, 0 = automatic, 1..6 = force that gemm2 tile configuration
+// which kernel serves bf16 problems: -1 = igemm.hip only, 0 = automatic, 1..6 = force that gemm2 tile configuration,
+// 7 = conv3p wherever it applies (gemm2 automatic elsewhere), 8 = never conv3p (gemm2 automatic)
 void set_gemm_config(int cfg);
 int gemm_config();
 
 // ---- gemm2.hip (bf16, LDS-DMA staged)
 const char* gemm2_check(const ConvParams& p);   // nullptr when gemm2 can run the problem
 void launch_gemm2(const ConvParams& p, int cfg, hipStream_t s);
+// ---- conv3p.hip (bf16 3x3 conv with a patch-stationary input tile)
+const char* conv3p_check(const ConvParams& p);   // nullptr when conv3p can run the layer
+void launch_conv3p(const ConvParams& p, hipStream_t s);
 // n pseudo-random values, uniform in [-scale, scale) (benchmark inputs)
 void launch_fill_random(Precision prec, void* p, size_t n, unsigned seed, float scale, hipStream_t s);
 
