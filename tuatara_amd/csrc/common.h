@@ -28,6 +28,7 @@ struct ConvParams {
   void* out_pool; int pool_relu;   // gemm2 only: optional 2x2/stride-2 max-pooled T output [B][H/2][W/2][Cout] (row stride out_ld), ReLU first if pool_relu
   const float* resid; int resid_ld; int resid_mod;  // f32 residual added before act; row = m % resid_mod if resid_mod
   int Cout, M, act;
+  const void* gelu_lut;      // set by launch_gemm2: float2 [1024] = {Phi(x_i), Phi(x_i+1) - Phi(x_i)}, x_i = -8 + i/64
 };
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -39,6 +40,15 @@ __device__ __forceinline__ float gelu_fast(float x) {
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float e = 1.0f - poly * __expf(-z * z);
   return 0.5f * x * (1.0f + copysignf(e, x));
+}
+
+// GELU(x) = x * Phi(x), Phi by linear interpolation in the float2[1024] table {Phi(x_i), Phi(x_i+1) - Phi(x_i)}, x_i = -8 + i/64
+// (|error| <= 7.4e-6 |x|: two orders below a bf16 ulp)
+__device__ __forceinline__ float gelu_lut(float x, const float2* lut) {
+  const float u = fmaf(__builtin_amdgcn_fmed3f(x, -8.0f, 7.984375f), 64.0f, 512.0f);
+  const float fl = floorf(u);
+  const float2 t = lut[(int)fl];
+  return x * fmaf(u - fl, t.y, t.x);
 }
 
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }

@@ -43,6 +43,7 @@ struct Smem {
   float tgt[16 * LDT];
   float logits[16 * 96];
   int tok[16 * 26];
+  float2 glut[1024];
 };
 
 // out^T[N][16 crops] = W[N][K] . X^T : tile t (16 output features) belongs to wave t % 8; a wave
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_ar_kernel(DecArParams p, int G) 
   for (int i = tid; i < (int)(sizeof(Smem) / 4); i += NTHREADS) reinterpret_cast<uint32_t*>(smem_raw)[i] = 0u;
   __syncthreads();
   for (int i = tid; i < 16 * 26; i += NTHREADS) S.tok[i] = (i % 26 == 0) ? 95 : 96;   // BOS, then PAD
+  for (int i = tid; i < 512; i += NTHREADS) reinterpret_cast<uint4*>(S.glut)[i] = reinterpret_cast<const uint4*>(p.gelu_lut)[i];
   __syncthreads();
   for (int i = tid; i < rows * 26; i += NTHREADS) p.tokens[(size_t)n0 * 26 + i] = S.tok[i];
 
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_ar_kernel(DecArParams p, int G) 
       const float4 b = *reinterpret_cast<const float4*>(p.b_ffn1 + n);
       typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
       bf16x4 o;
-      o[0] = (bf16)gelu_fast(a[0] + b.x); o[1] = (bf16)gelu_fast(a[1] + b.y); o[2] = (bf16)gelu_fast(a[2] + b.z); o[3] = (bf16)gelu_fast(a[3] + b.w);
+      o[0] = (bf16)gelu_lut(a[0] + b.x, S.glut); o[1] = (bf16)gelu_lut(a[1] + b.y, S.glut); o[2] = (bf16)gelu_lut(a[2] + b.z, S.glut); o[3] = (bf16)gelu_lut(a[3] + b.w, S.glut);
       *reinterpret_cast<bf16x4*>(S.h + crop * LDH + n) = o;
     });
     __syncthreads();

@@ -518,6 +518,7 @@ struct Engine {
       q.g_1 = V(d + "norm1.weight"); q.b_1 = V(d + "norm1.bias"); q.g_2 = V(d + "norm2.weight"); q.b_2 = V(d + "norm2.bias");
       q.g_f = V("decoder.norm.weight"); q.b_f = V("decoder.norm.bias");
       q.kvmem = (const bf16*)kvmem; q.kvcache = (bf16*)kvcache; q.tokens = tk; q.ar_logits = d_ar;
+      q.gelu_lut = gelu_lut_for_current_device();
       q.N = N; q.nsteps = nsteps;
       int G = g_decoder_mode;
       if (G != 4 && G != 8 && G != 16) G = N <= 1024 ? 4 : 8;

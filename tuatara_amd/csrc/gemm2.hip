@@ -19,6 +19,9 @@
 //   * XCD-aware tile order (bijective remap): the N tiles of an M tile and neighbouring M
 //     tiles run on one XCD and share its L2.
 #include <algorithm>
+#include <cmath>
+#include <mutex>
+#include <vector>
 
 #include "common.h"
 #include "kernels.h"
@@ -52,6 +55,13 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+
+  // GELU epilogue: Phi(x) by linear interpolation in an 8 KiB table kept in LDS behind the operand stages (the
+  // erf polynomial + exp + rcp form made the epilogue, not the MFMAs, the longest part of the K = 384 PARSeq GEMMs)
+  float2* const glut = reinterpret_cast<float2*>(smem + C::LDS);
+  if (p.act == kActGelu) {
+    for (int i = tid; i < 512; i += C::NT) reinterpret_cast<uint4*>(glut)[i] = reinterpret_cast<const uint4*>(p.gelu_lut)[i];
+  }   // visible after the first K-step barrier
 
   // ---- XCD-aware tile order
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
@@ -222,7 +232,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
       } else if (p.act == kActGelu) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+        for (int e = 0; e < 8; ++e) v[e] = gelu_lut(v[e], glut);
       }
       if (p.out && valid) {
         bf16x8 o;
@@ -262,10 +272,34 @@ static void launch_g2(const ConvParams& p, hipStream_t s) {
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
   static bool once = false;
   if (!once) {
-    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WM, WN, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WM, WN, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + 8192));
     once = true;
   }
-  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM, WN, MINB>), dim3(tilesM * tilesN), dim3(C::NT), C::LDS, s, p);
+  const size_t lds = C::LDS + (p.act == kActGelu ? 8192 : 0);
+  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM, WN, MINB>), dim3(tilesM * tilesN), dim3(C::NT), lds, s, p);
+}
+
+// Phi table of the GELU epilogue, one per device, built on first use (host erf in double)
+const void* gelu_lut_for_current_device() {
+  static std::mutex mu;
+  static const void* lut[64] = {nullptr};
+  int dev = 0;
+  TTR_HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  if (dev < 0 || dev >= 64) throw std::runtime_error("gemm2: device index out of range");
+  if (!lut[dev]) {
+    std::vector<float> h(2048);
+    for (int i = 0; i < 1024; ++i) {
+      const double x0 = -8.0 + i / 64.0, x1 = x0 + 1.0 / 64.0;
+      const double p0 = 0.5 * (1.0 + std::erf(x0 * 0.70710678118654752440)), p1 = 0.5 * (1.0 + std::erf(x1 * 0.70710678118654752440));
+      h[2 * i] = (float)p0; h[2 * i + 1] = (float)(p1 - p0);
+    }
+    void* d = nullptr;
+    TTR_HIP_CHECK(hipMalloc(&d, 8192));
+    TTR_HIP_CHECK(hipMemcpy(d, h.data(), 8192, hipMemcpyHostToDevice));
+    lut[dev] = d;
+  }
+  return lut[dev];
 }
 
 const char* gemm2_check(const ConvParams& p) {
@@ -289,8 +323,10 @@ const char* gemm2_check(const ConvParams& p) {
 }
 
 // cfg: 0 auto, 1 = 256x256/8w, 2 = 256x128/8w, 3 = 128x128/4w, 4 = 256x64/4w, 5 = 128x64/4w, 6 = 128x256/8w
-void launch_gemm2(const ConvParams& p, int cfg, hipStream_t s) {
-  if (const char* e = gemm2_check(p)) throw std::runtime_error(e);
+void launch_gemm2(const ConvParams& p_in, int cfg, hipStream_t s) {
+  if (const char* e = gemm2_check(p_in)) throw std::runtime_error(e);
+  ConvParams p = p_in;
+  p.gelu_lut = p.act == kActGelu ? gelu_lut_for_current_device() : nullptr;
   if (cfg == 0) {   // measured on MI355X (tools/gemm_sweep.py, profiles/r01_gemm_sweep.txt)
     if (p.Cout <= 64) cfg = 5;
     else {

@@ -16,6 +16,9 @@ int gemm_config();
 // ---- gemm2.hip (bf16, LDS-DMA staged)
 const char* gemm2_check(const ConvParams& p);   // nullptr when gemm2 can run the problem
 void launch_gemm2(const ConvParams& p, int cfg, hipStream_t s);
+// device table float2[1024] {Phi(x_i), Phi(x_i + 1/64) - Phi(x_i)}, x_i = -8 + i/64, of the GELU epilogues (built on first use)
+const void* gelu_lut_for_current_device();
+// GELU by that table (g = the table, in LDS)
 // ---- conv3p.hip (bf16 3x3 conv with a patch-stationary input tile)
 const char* conv3p_check(const ConvParams& p);   // nullptr when conv3p can run the layer
 void launch_conv3p(const ConvParams& p, hipStream_t s);
@@ -61,6 +64,7 @@ struct DecArParams {
   bf16* kvcache;         // [N][26][768]  self-attention K|V of the content stream (out: all 26 rows)
   int* tokens;           // [N][26] out: BOS, then the greedy tokens
   float* ar_logits;      // optional [N][26][95]
+  const void* gelu_lut;  // gelu_lut_for_current_device()
   int N, nsteps;         // nsteps: 25 (logits of the 26th step are never used) or 26
 };
 void launch_dec_ar(const DecArParams& p, int crops_per_workgroup, hipStream_t s);
