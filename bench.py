@@ -169,6 +169,14 @@ def main():
     p50 = float(np.median(lat)) if lat else None
 
     if rank == 0:
+        # HBM bytes of the CRAFT conv kernels per launch, from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE,
+        # gfx950 corrections applied; profiles/r01_pmc_craft.json says how) -- counters cannot be read from inside this process
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_craft.json")) as f:
+                traffic = json.load(f)["craft_conv_kernels"]["hbm_bytes_per_launch"] * P   # per launch of a P-page batch
+        except Exception:
+            pass
         total_pages = world * P * args.steps
         peak = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
         c = prof["craft"]
@@ -185,12 +193,12 @@ def main():
                        "parallelism": f"dp{world}"},
             "p50_page_latency_ms": p50,
             "stage_ms_last_step": {k: round(v, 3) for k, v in stage.items()},
-            "roofline": {"kernel": "igemm_kernel (CRAFT implicit-GEMM convolutions)", "bound": "mfma",
+            "roofline": {"kernel": "CRAFT convolutions: conv3p_kernel / gemm2_kernel / conv1_direct_kernel (+ igemm_kernel for the 32-channel head)", "bound": "mfma",
                          "achieved": craft_tflops, "peak": peak, "unit": "TFLOP/s",
-                         "frac": (craft_tflops / peak) if craft_tflops else None, "traffic": None,
+                         "frac": (craft_tflops / peak) if craft_tflops else None, "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, 1-page runs scaled to the batch)",
                          "launches_per_step": c["launches"] / max(1, args.steps * NC), "avg_launch_us": c["ms"] * 1e3 / max(1, c["launches"]),
                          "algorithmic_gflop_per_page": CRAFT_GFLOP_PER_PAGE},
-            "roofline_parseq_gemm": {"kernel": "igemm_kernel (PARSeq GEMMs)", "bound": "mfma", "achieved": pq_tflops, "peak": peak,
+            "roofline_parseq_gemm": {"kernel": "gemm2_kernel (PARSeq GEMMs outside the fused AR decoder)", "bound": "mfma", "achieved": pq_tflops, "peak": peak,
                                      "unit": "TFLOP/s", "frac": (pq_tflops / peak) if pq_tflops else None,
                                      "launches_per_step": q["launches"] / max(1, args.steps)},
         }

@@ -68,6 +68,9 @@ void launch_im2col_l1(Precision prec, const uint8_t* canvas, void* out, int B, i
 // MFMA + channel permutation as in gemm2.hip.  HBM-bound on the 128 B/pixel it writes.
 __global__ __launch_bounds__(256) void conv1_direct_kernel(const uint8_t* __restrict__ canvas, const bf16* __restrict__ wgt /*[64][32]*/,
                                                           const float* __restrict__ bias, bf16* __restrict__ out, int B, int H, int W) {
+  __shared__ bf16 lut[256];     // bf16(u8 / 255.0f): the division runs 256 times per workgroup instead of 27 times per pixel
+  lut[threadIdx.x] = (bf16)((float)threadIdx.x / 255.0f);
+  __syncthreads();
   const int lane = threadIdx.x & 63, fr = lane & 15, fg = lane >> 4;
   const int64_t M = (int64_t)B * H * W;
   const int HW = H * W;
@@ -82,12 +85,13 @@ __global__ __launch_bounds__(256) void conv1_direct_kernel(const uint8_t* __rest
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int e = 0; e < 8; ++e) bv[t][e] = bias[32 * t + fg * 8 + e];
-  // the 8 (tap, channel) pairs this lane contributes
-  int dy[8], dx[8], ch[8];
+  // the 8 (tap, channel) pairs this lane contributes: byte offset relative to the pixel's first byte, and the tap's (dy, dx)
+  int off[8], dy[8], dx[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int k = fg * 8 + e, tap = k / 3;
-    ch[e] = k - tap * 3; dy[e] = tap / 3 - 1; dx[e] = tap % 3 - 1;   // k >= 27: masked below
+    dy[e] = tap / 3 - 1; dx[e] = tap % 3 - 1;   // k >= 27: masked below
+    off[e] = (dy[e] * W + dx[e]) * 3 + (k - tap * 3);
   }
   const int64_t nwaves = (int64_t)gridDim.x * 4, wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   for (int64_t g = wave0; g * 64 < M; g += nwaves) {
@@ -96,17 +100,14 @@ __global__ __launch_bounds__(256) void conv1_direct_kernel(const uint8_t* __rest
     for (int i = 0; i < 4; ++i) {
       const int64_t m = g * 64 + i * 16 + fr;
       bf16x8 fx;
-      if (m < M) {
-        const int r = (int)(m % HW), y = r / W, x = r - y * W;
+      const bool mv = m < M;
+      const int r = (int)((mv ? m : 0) % HW), y = r / W, x = r - y * W;
+      const uint8_t* px = canvas + (mv ? m : 0) * 3;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int yy = y + dy[e], xx = x + dx[e];
-          const bool ok = (fg * 8 + e < 27) && yy >= 0 && yy < H && xx >= 0 && xx < W;
-          fx[e] = ok ? (bf16)((float)canvas[(m + (int64_t)dy[e] * W + dx[e]) * 3 + ch[e]] / 255.0f) : (bf16)0.f;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) fx[e] = (bf16)0.f;
+      for (int e = 0; e < 8; ++e) {
+        const int yy = y + dy[e], xx = x + dx[e];
+        const bool ok = mv && (fg * 8 + e < 27) && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        fx[e] = ok ? lut[px[off[e]]] : (bf16)0.f;
       }
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) acc[jj][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[jj], fx, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
