@@ -109,6 +109,9 @@ void ttr_set_decoder_mode(int mode);
 /* Process-wide tuning knobs by name: "gemm_config", "decoder_mode" (as above), "enc_chunk" (crops per PARSeq
  * encoder group, 0 = all at once).  Returns 0, or -1 for an unknown key.  Results do not depend on any of them. */
 int ttr_set_tuning(const char* key, int value);
+/* diagnostics: after ttr_set_tuning("dec_stamps", 1) the fused AR kernel's workgroup 0 records shader-clock stamps
+ * [26 steps][16 phases]; this copies them out.  Returns -1 when stamps are off. */
+int ttr_dbg_dec_stamps(unsigned long long* out);
 /* Times one conv / linear layer on device-generated random data (no host traffic): average
  * microseconds per launch over `iters` back-to-back launches.  f32_resid != 0 selects the PARSeq
  * residual form (f32 residual in, f32 out) instead of a bf16/T output. */

@@ -67,6 +67,7 @@ __device__ __forceinline__ void dec_gemm(const bf16* __restrict__ W, int N, cons
 #pragma unroll
         for (int u = 0; u < 12; ++u) a[g][u] = *reinterpret_cast<const bf16x8*>(wp + u * 32);
       }
+      __builtin_amdgcn_sched_barrier(0);   // all 36 loads in flight before the first MFMA (hipcc otherwise sinks each load to its use)
 #pragma unroll
       for (int u = 0; u < 12; ++u) {
         const bf16x8 b = *reinterpret_cast<const bf16x8*>(X + fr * LD + kc + u * 32 + fg * 8);
@@ -125,8 +126,11 @@ __global__ __launch_bounds__(NTHREADS) void dec_ar_kernel(DecArParams p, int G) 
   for (int i = tid; i < rows * 26; i += NTHREADS) p.tokens[(size_t)n0 * 26 + i] = S.tok[i];
 
   const float kScale = 0.17677669529663687f;   // 1/sqrt(32)
+  // optional phase stamps (diagnostic builds of the caller only): dbg[step*16 + phase] = shader clock, workgroup 0, thread 0
+#define DEC_STAMP(ph) do { if (p.dbg && blockIdx.x == 0 && tid == 0) p.dbg[i * 16 + (ph)] = __builtin_readcyclecounter(); } while (0)
 
   for (int i = 0; i < 26; ++i) {
+    DEC_STAMP(0);
     // ---- content row i: emb[tok] (+ pos_q[i-1]) -> norm_c -> xa
     for (int r = wave; r < rows; r += NWAVES) {
       int tok = S.tok[r * 26 + i];
@@ -148,6 +152,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_ar_kernel(DecArParams p, int G) 
       for (int k = 0; k < 6; ++k) { const int c = lane + 64 * k; S.xa[r * LDX + c] = (bf16)((v[k] - mean) * rstd * p.g_c[c] + p.b_c[c]); }
     }
     __syncthreads();
+    DEC_STAMP(1);
     // ---- K/V of content row i -> cache row i (global; the refinement pass needs all 26 rows)
     dec_gemm<E, LDX>(p.w_selfkv, 2 * E, S.xa, wave, lane, [&](int n, int crop, const f32x4& a) {
       if (crop < rows) {
@@ -162,6 +167,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_ar_kernel(DecArParams p, int G) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's cache stores have reached L2
     __syncthreads();
 
+    DEC_STAMP(2);
     // ---- self attention: query qself[i] against cache rows 0..i -> xb.  Lanes 0..47 hold 8 dims each (head = lane/4).
     for (int r = wave; r < rows; r += NWAVES) {
       const int ln = lane < 48 ? lane : 47;
@@ -216,6 +222,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_ar_kernel(DecArParams p, int G) 
       }
     }
     __syncthreads();
+    DEC_STAMP(3);
     // ---- tgt = pos_q[i] + self_out(sa)
     dec_gemm<E, LDX>(p.w_selfout, E, S.xb, wave, lane, [&](int n, int crop, const f32x4& a) {
       const float4 b = *reinterpret_cast<const float4*>(p.b_selfout + n);
@@ -225,6 +232,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_ar_kernel(DecArParams p, int G) 
     __syncthreads();
     dec_ln(S.tgt, LDT, p.g_1, p.b_1, 1e-5f, S.xa, rows, wave, lane);
     __syncthreads();
+    DEC_STAMP(4);
     // ---- cross attention query
     dec_gemm<E, LDX>(p.w_crossq, E, S.xa, wave, lane, [&](int n, int crop, const f32x4& a) {
       const float4 b = *reinterpret_cast<const float4*>(p.b_crossq + n);
@@ -234,6 +242,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_ar_kernel(DecArParams p, int G) 
       *reinterpret_cast<bf16x4*>(S.xb + crop * LDX + n) = o;
     });
     __syncthreads();
+    DEC_STAMP(5);
     // ---- cross attention over the crop's 128 memory tokens (online softmax, 8 keys per chunk, double buffered) -> xa
     for (int r = wave; r < rows; r += NWAVES) {
       const int ln = lane < 48 ? lane : 47;
@@ -311,6 +320,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_ar_kernel(DecArParams p, int G) 
       }
     }
     __syncthreads();
+    DEC_STAMP(6);
     // ---- tgt += cross_out(ca)
     dec_gemm<E, LDX>(p.w_crossout, E, S.xa, wave, lane, [&](int n, int crop, const f32x4& a) {
       const float4 b = *reinterpret_cast<const float4*>(p.b_crossout + n);
@@ -321,6 +331,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_ar_kernel(DecArParams p, int G) 
     __syncthreads();
     dec_ln(S.tgt, LDT, p.g_2, p.b_2, 1e-5f, S.xb, rows, wave, lane);
     __syncthreads();
+    DEC_STAMP(7);
     // ---- FFN
     dec_gemm<E, LDX>(p.w_ffn1, FF, S.xb, wave, lane, [&](int n, int crop, const f32x4& a) {
       const float4 b = *reinterpret_cast<const float4*>(p.b_ffn1 + n);
@@ -330,6 +341,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_ar_kernel(DecArParams p, int G) 
       *reinterpret_cast<bf16x4*>(S.h + crop * LDH + n) = o;
     });
     __syncthreads();
+    DEC_STAMP(8);
     dec_gemm<FF, LDH>(p.w_ffn2, E, S.h, wave, lane, [&](int n, int crop, const f32x4& a) {
       const float4 b = *reinterpret_cast<const float4*>(p.b_ffn2 + n);
       float4* t = reinterpret_cast<float4*>(S.tgt + crop * LDT + n);
@@ -339,6 +351,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_ar_kernel(DecArParams p, int G) 
     __syncthreads();
     dec_ln(S.tgt, LDT, p.g_f, p.b_f, 1e-5f, S.xa, rows, wave, lane);
     __syncthreads();
+    DEC_STAMP(9);
     // ---- head -> logits (LDS, optionally global), argmax -> next token
     dec_gemm<E, LDX>(p.w_head, 95, S.xa, wave, lane, [&](int n, int crop, const f32x4& a) {
 #pragma unroll
@@ -362,6 +375,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_ar_kernel(DecArParams p, int G) 
       if (lane == 0 && i + 1 < 26) { S.tok[r * 26 + i + 1] = bi; p.tokens[(size_t)(n0 + r) * 26 + i + 1] = bi; }
     }
     __syncthreads();
+    DEC_STAMP(10);
   }
 }
 

@@ -37,6 +37,7 @@ void hip_fail(const char* what, hipError_t e, const char* file, int line) {
 }
 
 static thread_local std::string g_last_error;
+static unsigned long long* g_dec_dbg = nullptr;   // device buffer for dec_ar phase stamps (diagnostics)
 static int g_enc_chunk = 0;        // crops per encoder group (0 = all crops at once)
 static int g_decoder_mode = 1;   // 0 = kernel-per-op AR loop, 4/8/16 = fused kernel with that many crops per workgroup, else automatic
 
@@ -519,6 +520,7 @@ struct Engine {
       q.g_f = V("decoder.norm.weight"); q.b_f = V("decoder.norm.bias");
       q.kvmem = (const bf16*)kvmem; q.kvcache = (bf16*)kvcache; q.tokens = tk; q.ar_logits = d_ar;
       q.gelu_lut = gelu_lut_for_current_device();
+      q.dbg = g_dec_dbg;
       q.N = N; q.nsteps = nsteps;
       int G = g_decoder_mode;
       if (G != 4 && G != 8 && G != 16) G = N <= 1024 ? 4 : 8;
@@ -911,11 +913,16 @@ int ttr_dbg_conv_pool(ttr_engine* e, const float* in0, int C0, int B, int H, int
 
 void ttr_set_gemm_config(int cfg) { set_gemm_config(cfg); }
 void ttr_set_decoder_mode(int mode) { g_decoder_mode = mode; }
+int ttr_dbg_dec_stamps(unsigned long long* out) { return g_dec_dbg && hipMemcpy(out, g_dec_dbg, 26 * 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
 int ttr_set_tuning(const char* key, int value) {
   const std::string k = key ? key : "";
   if (k == "gemm_config") set_gemm_config(value);
   else if (k == "decoder_mode") g_decoder_mode = value;
   else if (k == "enc_chunk") g_enc_chunk = value;
+  else if (k == "dec_stamps") {   // value != 0: allocate the stamp buffer; read it back with ttr_dev_download via ttr_dbg_dec_stamps
+    if (value && !g_dec_dbg) { void* d = nullptr; if (hipMalloc(&d, 26 * 16 * 8) != hipSuccess) return -1; (void)hipMemset(d, 0, 26 * 16 * 8); g_dec_dbg = (unsigned long long*)d; }
+    if (!value) g_dec_dbg = nullptr;
+  }
   else return -1;
   return 0;
 }

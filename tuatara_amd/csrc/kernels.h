@@ -65,6 +65,7 @@ struct DecArParams {
   int* tokens;           // [N][26] out: BOS, then the greedy tokens
   float* ar_logits;      // optional [N][26][95]
   const void* gelu_lut;  // gelu_lut_for_current_device()
+  unsigned long long* dbg;   // optional [26][16] phase stamps of workgroup 0 (diagnostics), else null
   int N, nsteps;         // nsteps: 25 (logits of the 26th step are never used) or 26
 };
 void launch_dec_ar(const DecArParams& p, int crops_per_workgroup, hipStream_t s);

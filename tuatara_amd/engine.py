@@ -64,6 +64,7 @@ SYMBOLS = [
     ("ttr_set_gemm_config", None, [_I]),
     ("ttr_set_decoder_mode", None, [_I]),
     ("ttr_set_tuning", _I, [C.c_char_p, _I]),
+    ("ttr_dbg_dec_stamps", _I, [C.POINTER(C.c_ulonglong)]),
     ("ttr_bench_conv", _I, [_VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _PF]),
     ("ttr_get_profile", _I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
 ]
