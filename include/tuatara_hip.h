@@ -107,7 +107,7 @@ void ttr_set_gemm_config(int cfg);
  * fused persistent kernel with that many crops per workgroup, anything else = automatic (default). */
 void ttr_set_decoder_mode(int mode);
 /* Process-wide tuning knobs by name: "gemm_config", "decoder_mode" (as above), "enc_chunk" (crops per PARSeq
- * encoder group, 0 = all at once).  Returns 0, or -1 for an unknown key.  Results do not depend on any of them. */
+ * encoder group, 0 = all at once), "sk_max_rows" (linears with at most this many rows use the skinny GEMM kernel).  Returns 0, or -1 for an unknown key.  Results do not depend on any of them. */
 int ttr_set_tuning(const char* key, int value);
 /* diagnostics: after ttr_set_tuning("dec_stamps", 1) the fused AR kernel's workgroup 0 records shader-clock stamps
  * [26 steps][16 phases]; this copies them out.  Returns -1 when stamps are off. */

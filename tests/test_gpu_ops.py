@@ -148,3 +148,30 @@ def test_gemm2_fused_maxpool(eng_bf16, case, cfg):
     want = src.reshape(B, H // 2, 2, W // 2, 2, Cout).max(axis=(2, 4))
     assert np.array_equal(pool, want)
     assert np.array_equal(pool_only, want)
+
+
+SK_CASES = [
+    # M, K, Cout, act   (B=1, H=1, W=M linear layers: the decoder's per-step GEMMs)
+    (614, 384, 768, 0), (40, 384, 384, 0), (333, 384, 1536, 2), (333, 1536, 384, 0), (70, 384, 95, 0), (1, 128, 4, 1),
+]
+
+
+@pytest.mark.parametrize("case", SK_CASES)
+def test_gemm_skinny(eng_bf16, case):
+    """gemm_sk.hip (whole-K-resident skinny GEMM) against fp32 torch, and against gemm2 on the same inputs."""
+    M, K, Cout, act = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    bf = lambda a: torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy()
+    x = bf(rng.standard_normal((1, 1, M, K)).astype(np.float32))
+    w = bf((rng.standard_normal((Cout, 1, 1, K)) / np.sqrt(K)).astype(np.float32))
+    b = rng.standard_normal(Cout).astype(np.float32)
+    ref = _ref_conv(x, w, b, 1, 1, act)
+    try:
+        assert eng_bf16.lib.ttr_set_tuning(b"sk_max_rows", 2048) == 0
+        got = eng_bf16.dbg_conv(x, w, b, 1, 1, act)
+        eng_bf16.lib.ttr_set_tuning(b"sk_max_rows", 0)
+        other = eng_bf16.dbg_conv(x, w, b, 1, 1, act)
+    finally:
+        eng_bf16.lib.ttr_set_tuning(b"sk_max_rows", 2048)
+    assert np.abs(got - ref).max() < 2e-4
+    assert np.abs(got - other).max() < 1e-4

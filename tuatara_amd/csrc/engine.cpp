@@ -502,9 +502,10 @@ struct Engine {
     const float* bc = pqf.at(d + "norm_c.bias").as<float>();
     float* ar = d_ar ? d_ar : step_logits;
     const int nsteps = d_ar ? 26 : 25;  // the 26th AR step only feeds logits the refinement pass discards
-    // Fused persistent AR kernel (dec_fused.hip): per-step cost ~constant in N (each workgroup is latency-bound on its own
-    // weight/K-V streams), so it wins for big crop batches; the kernel-per-op loop is faster below ~384 crops (measured).
-    const bool fused_ar = prec == kBF16 && g_decoder_mode != 0 && (g_decoder_mode == 4 || g_decoder_mode == 8 || g_decoder_mode == 16 || N >= 384);
+    // Fused persistent AR kernel (dec_fused.hip): ~150 us per step whatever N is (every workgroup is bound by its own
+    // ~12 B/clk fetch rate on the weight and K/V streams).  With the skinny per-step GEMMs (gemm_sk.hip) the kernel-per-op
+    // loop is faster up to ~1200 crops (measured at 40 / 320 / 614 crops), so the fused kernel is only picked beyond that.
+    const bool fused_ar = prec == kBF16 && g_decoder_mode != 0 && (g_decoder_mode == 4 || g_decoder_mode == 8 || g_decoder_mode == 16 || N > 2048);
     if (fused_ar) {
       DecArParams q{};
       auto W = [&](const char* k) { return pq.at(k).w.as<bf16>(); };
@@ -919,6 +920,7 @@ int ttr_set_tuning(const char* key, int value) {
   if (k == "gemm_config") set_gemm_config(value);
   else if (k == "decoder_mode") g_decoder_mode = value;
   else if (k == "enc_chunk") g_enc_chunk = value;
+  else if (k == "sk_max_rows") set_skinny_max_rows(value);
   else if (k == "dec_stamps") {   // value != 0: allocate the stamp buffer; read it back with ttr_dev_download via ttr_dbg_dec_stamps
     if (value && !g_dec_dbg) { void* d = nullptr; if (hipMalloc(&d, 26 * 16 * 8) != hipSuccess) return -1; (void)hipMemset(d, 0, 26 * 16 * 8); g_dec_dbg = (unsigned long long*)d; }
     if (!value) g_dec_dbg = nullptr;

@@ -251,12 +251,15 @@ const char* igemm_check(const ConvParams& p) {
 }
 
 static int g_gemm_cfg = 0;
+static int g_sk_max_rows = 2048;
+void set_skinny_max_rows(int m) { g_sk_max_rows = m; }
 void set_gemm_config(int cfg) { g_gemm_cfg = cfg; }
 int gemm_config() { return g_gemm_cfg; }
 
 void launch_igemm(Precision prec, const ConvParams& p, hipStream_t s) {
   if (const char* e = igemm_check(p)) throw std::runtime_error(e);
   if (prec == kBF16 && g_gemm_cfg >= 0) {
+    if ((g_gemm_cfg == 0 || g_gemm_cfg >= 7) && p.M <= g_sk_max_rows && gemm_sk_check(p) == nullptr) return launch_gemm_sk(p, s);
     // 3x3 layers whose image tiles into 8x32 patches: the patch-stationary kernel moves 1.7-4x fewer bytes L2 -> LDS
     // (measured +5..17 % over gemm2 on every such CRAFT layer with Cout >= 64; profiles/r01_gemm_sweep_v2.txt)
     if ((g_gemm_cfg == 7 || (g_gemm_cfg == 0 && p.Cout >= 64)) && conv3p_check(p) == nullptr) return launch_conv3p(p, s);

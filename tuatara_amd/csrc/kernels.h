@@ -19,6 +19,10 @@ void launch_gemm2(const ConvParams& p, int cfg, hipStream_t s);
 // device table float2[1024] {Phi(x_i), Phi(x_i + 1/64) - Phi(x_i)}, x_i = -8 + i/64, of the GELU epilogues (built on first use)
 const void* gelu_lut_for_current_device();
 // GELU by that table (g = the table, in LDS)
+// ---- gemm_sk.hip (bf16 skinny GEMM, whole K resident: the per-step decoder linears)
+const char* gemm_sk_check(const ConvParams& p);
+void launch_gemm_sk(const ConvParams& p, hipStream_t s);
+void set_skinny_max_rows(int m);   // problems with M <= m rows go to gemm_sk (0 = never)
 // ---- conv3p.hip (bf16 3x3 conv with a patch-stationary input tile)
 const char* conv3p_check(const ConvParams& p);   // nullptr when conv3p can run the layer
 void launch_conv3p(const ConvParams& p, hipStream_t s);
