@@ -67,6 +67,25 @@ static inline uint16_t f32_to_bf16_rne(float f) {
   return (uint16_t)(u >> 16);
 }
 
+// grow-only pinned host buffer: async copies to / from it need no staging and do not serialise the stream
+struct PinnedBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  void ensure(size_t bytes) {
+    if (bytes <= cap) return;
+    if (p) TTR_HIP_CHECK(hipHostFree(p));
+    p = nullptr; cap = 0;
+    size_t want = (bytes + 65535) & ~(size_t)65535;
+    TTR_HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+    cap = want;
+  }
+  template <typename U> U* as() const { return reinterpret_cast<U*>(p); }
+  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+  PinnedBuf() = default;
+  PinnedBuf(const PinnedBuf&) = delete;
+  PinnedBuf& operator=(const PinnedBuf&) = delete;
+};
+
 struct HostTensor { std::vector<uint32_t> dims; std::vector<float> data; };
 
 struct WeightFile {
@@ -159,6 +178,7 @@ struct Engine {
   DevBuf pq_ws[16];
   DevBuf canvas, heat, staging_img, crops, rects_dev, logits, ar_logits, ids_dev, tokens;
   CclBatch ccl;
+  PinnedBuf h_counters, h_cand, h_rows, h_rects, h_ids;   // pinned staging of the small host <-> device transfers
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   float stage_ms[4] = {0, 0, 0, 0};
   // optional per-launch timing of the igemm kernel (bench.py's roofline): events bracket every launch
@@ -550,28 +570,37 @@ struct Engine {
   }
   // boxes of every page of the batch: two stream syncs in all (counters, then candidates + row extremes)
   void ccl_collect(int pages, int H2, int W2, std::vector<std::vector<RRect>>& det) {
-    std::vector<int> counters((size_t)pages * 2);
-    TTR_HIP_CHECK(hipMemcpyAsync(counters.data(), ccl.counters.p, counters.size() * 4, hipMemcpyDeviceToHost, stream));
+    h_counters.ensure((size_t)pages * 8);
+    int* counters = h_counters.as<int>();
+    TTR_HIP_CHECK(hipMemcpyAsync(counters, ccl.counters.p, (size_t)pages * 8, hipMemcpyDeviceToHost, stream));
     TTR_HIP_CHECK(hipStreamSynchronize(stream));
-    std::vector<std::vector<int>> cand(pages), rw(pages);
+    size_t tot_c = 0, tot_r = 0;
+    std::vector<size_t> off_c(pages), off_r(pages);
+    for (int pg = 0; pg < pages; ++pg) {
+      if (counters[2 * pg] > cfg.max_components) throw std::runtime_error("too many text components on a page; raise ttr_config.max_components");
+      off_c[pg] = tot_c; off_r[pg] = tot_r;
+      tot_c += (size_t)counters[2 * pg] * 8; tot_r += (size_t)counters[2 * pg + 1] * 2;
+    }
+    h_cand.ensure(tot_c * 4 + 4); h_rows.ensure(tot_r * 4 + 4);
+    int* cand = h_cand.as<int>();
+    int* rw = h_rows.as<int>();
     for (int pg = 0; pg < pages; ++pg) {
       const int n = counters[2 * pg], rows = counters[2 * pg + 1];
-      if (n > cfg.max_components) throw std::runtime_error("too many text components on a page; raise ttr_config.max_components");
       if (n == 0) continue;
-      cand[pg].resize((size_t)n * 8); rw[pg].resize((size_t)rows * 2);
-      TTR_HIP_CHECK(hipMemcpyAsync(cand[pg].data(), ccl.cand.as<int>() + (size_t)pg * ccl.max_cand * 8, cand[pg].size() * 4, hipMemcpyDeviceToHost, stream));
-      TTR_HIP_CHECK(hipMemcpyAsync(rw[pg].data(), ccl.rows.as<int>() + (size_t)pg * ccl.npx * 2, rw[pg].size() * 4, hipMemcpyDeviceToHost, stream));
+      TTR_HIP_CHECK(hipMemcpyAsync(cand + off_c[pg], ccl.cand.as<int>() + (size_t)pg * ccl.max_cand * 8, (size_t)n * 32, hipMemcpyDeviceToHost, stream));
+      TTR_HIP_CHECK(hipMemcpyAsync(rw + off_r[pg], ccl.rows.as<int>() + (size_t)pg * ccl.npx * 2, (size_t)rows * 8, hipMemcpyDeviceToHost, stream));
     }
     TTR_HIP_CHECK(hipStreamSynchronize(stream));
     det.assign(pages, std::vector<RRect>());
     for (int pg = 0; pg < pages; ++pg) {
       const int n = counters[2 * pg];
+      const int* cd = cand + off_c[pg];
       std::vector<int> order(n);
       for (int i = 0; i < n; ++i) order[i] = i;
-      std::sort(order.begin(), order.end(), [&](int a, int b) { return cand[pg][8 * a] < cand[pg][8 * b]; });  // label order = ascending root
+      std::sort(order.begin(), order.end(), [&](int a, int b) { return cd[8 * a] < cd[8 * b]; });  // label order = ascending root
       for (int i : order) {
-        const int* c = &cand[pg][8 * i];
-        Component comp{c[0], c[1], c[2], c[3], c[4], c[5], &rw[pg][2 * (size_t)c[6]]};
+        const int* c = &cd[8 * i];
+        Component comp{c[0], c[1], c[2], c[3], c[4], c[5], rw + off_r[pg] + 2 * (size_t)c[6]};
         RRect r;
         if (component_to_rect(comp, H2, W2, &r)) det[pg].push_back(r);
       }
@@ -625,18 +654,21 @@ struct Engine {
       }
     }
     const int N = (int)page_of.size();
-    std::vector<int32_t> ids((size_t)N * 26);
+    h_ids.ensure((size_t)N * 26 * 4 + 4);
+    int32_t* ids = h_ids.as<int32_t>();
     if (N > 0) {
       rects_dev.ensure(rects.size() * 4);
+      h_rects.ensure(rects.size() * 4);
+      memcpy(h_rects.p, rects.data(), rects.size() * 4);
       crops.ensure((size_t)N * 32 * 128 * 3);
       logits.ensure((size_t)N * 26 * 95 * 4);
       ids_dev.ensure((size_t)N * 26 * 4);
-      TTR_HIP_CHECK(hipMemcpyAsync(rects_dev.p, rects.data(), rects.size() * 4, hipMemcpyHostToDevice, stream));
+      TTR_HIP_CHECK(hipMemcpyAsync(rects_dev.p, h_rects.p, rects.size() * 4, hipMemcpyHostToDevice, stream));
       launch_pack_crops(d_pages, page_bytes, w * 3, rects_dev.as<int>(), crops.as<uint8_t>(), N, stream);
       TTR_HIP_CHECK(hipEventRecord(ev[3], stream));
       parseq_forward(crops.as<uint8_t>(), N, logits.as<float>(), nullptr, ids_dev.as<int>());
       TTR_HIP_CHECK(hipEventRecord(ev[4], stream));
-      TTR_HIP_CHECK(hipMemcpyAsync(ids.data(), ids_dev.p, ids.size() * 4, hipMemcpyDeviceToHost, stream));
+      TTR_HIP_CHECK(hipMemcpyAsync(ids, ids_dev.p, (size_t)N * 26 * 4, hipMemcpyDeviceToHost, stream));
     } else {
       TTR_HIP_CHECK(hipEventRecord(ev[3], stream));
       TTR_HIP_CHECK(hipEventRecord(ev[4], stream));
