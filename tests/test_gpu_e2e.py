@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import pytest
 
-from tests.conftest import GOLDEN, ROOT
+from tests.conftest import DATA, GOLDEN, ROOT
 
 pytestmark = pytest.mark.gpu
 G = json.load(open(os.path.join(GOLDEN, "golden.json")))
@@ -98,3 +98,32 @@ def test_empty_and_blank_inputs(eng_f32):
     assert isinstance(r, list)
     with pytest.raises(RuntimeError):
         eng_f32.image_to_data(np.zeros((8, 8), np.uint8))
+
+
+def test_cpp_cli_and_pytuatara_callers(weights, funsd, tmp_path):
+    """The two caller shapes of the reference: the C++ CLI (BGR from its own PNG reader, examples/resume.cpp) and
+    pytuatara.image_to_data (RGB array, bindings/run_ocr.py:88-92) — both through the cached-engine C++ shim."""
+    import subprocess
+    import sys
+    from tuatara_amd import build as B
+    from tuatara_amd.engine import Engine
+    B.build_all()
+    env = dict(os.environ, TUATARA_PRECISION="f32")
+    png = os.path.join(DATA, "funsd_0001129658.png")
+    out = subprocess.run([os.path.join(B.ROOT, "build", "examples", "ocr_cli"), png, weights["dir"], str(tmp_path)], capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stderr
+    lines = [ln.split("\t") for ln in out.stdout.splitlines()]
+    eng = Engine(weights["dir"], precision="f32")
+    ref = eng.image_to_data(np.ascontiguousarray(funsd[:, :, ::-1]))       # the CLI feeds BGR
+    assert len(lines) == len(ref) > 20
+    for (bb, text), r in zip(lines, ref):
+        assert [float(v) for v in bb.split()] == r["bbox"] and text == r["text"]
+    # pytuatara in a child process (it caches an engine per weights dir for the life of the process)
+    code = ("import sys, numpy as np; from PIL import Image; sys.path.insert(0, %r); import pytuatara;"
+            "r = pytuatara.image_to_data(np.array(Image.open(%r).convert('RGB')), %r, %r); print(len(r)); print(r[0])"
+            % (os.path.join(B.ROOT, "build", "bindings"), png, weights["dir"], str(tmp_path)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stderr
+    ref_rgb = eng.image_to_data(funsd)
+    assert int(out.stdout.splitlines()[0]) == len(ref_rgb)
+    assert ref_rgb[0]["text"] in out.stdout.splitlines()[1]

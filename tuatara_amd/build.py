@@ -74,9 +74,23 @@ def build_pytuatara() -> str:
     return out
 
 
+def build_examples() -> str:
+    """build/examples/ocr_cli: counterpart of the reference's examples/resume.cpp / table.cpp (own PNG reader, zlib)."""
+    outdir = os.path.join(ROOT, "build", "examples")
+    os.makedirs(outdir, exist_ok=True)
+    out = os.path.join(outdir, "ocr_cli")
+    srcs = [os.path.join(ROOT, "examples", "ocr_cli.cpp"), os.path.join(ROOT, "examples", "png_decode.h")]
+    if _stale(out, srcs + [LIB] + _headers()):
+        cmd = ["g++", "-O2", "-std=c++17", srcs[0], "-o", out, "-L", LIBDIR, "-ltuatara_hip", "-lz", f"-Wl,-rpath,{LIBDIR}",
+               "-Wl,-rpath,$ORIGIN/../../tuatara_amd/lib"]
+        subprocess.check_call(cmd)
+    return out
+
+
 def build_all() -> None:
     build_lib()
     build_pytuatara()
+    build_examples()
 
 
 if __name__ == "__main__":
