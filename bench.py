@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pages", type=int, default=16, help="pages per GPU per step")
+    ap.add_argument("--pages", type=int, default=32, help="pages per GPU per step (CRAFT runs in groups of 16, PARSeq over all crops of the step)")
     ap.add_argument("--words", type=int, default=28, help="words drawn per synthetic page (28 words -> ~40 detected crops/page with the synthetic detector)")
     ap.add_argument("--contexts", type=int, default=1, help="engine contexts (HIP streams + host threads) per GPU; a step's pages are split between them")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])

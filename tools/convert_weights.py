@@ -6,8 +6,9 @@
 Reads <weights_dir>/craft_traced_torchscript_model.pt (tuatara.cpp:333) and
 <weights_dir>/parseq_torchscript.bin (tuatara.cpp:423) with torch.jit.load (CPU), takes their
 state_dict (upstream CRAFT / PARSeq parameter names), folds BatchNorm and writes craft.ttrw /
-parseq.ttrw next to them.  Untested against the real archives (they are not obtainable offline);
-the key/shape check below fails loudly if the archives do not match the upstream architectures.
+parseq.ttrw next to them.  The real archives are not obtainable offline; tests/test_convert_cpu.py runs this script on
+archives of the same layout traced from the oracle models and requires bit-identical .ttrw files.  The key/shape check
+below fails loudly if an archive does not match the upstream architectures.
 """
 import os
 import sys
