@@ -144,7 +144,7 @@ def main():
         res = step()
     fence()
     dt = time.perf_counter() - t0
-    prof = {"craft": {"ms": 0.0, "flops": 0.0, "launches": 0}, "parseq": {"ms": 0.0, "flops": 0.0, "launches": 0}}
+    prof = {k: {"ms": 0.0, "flops": 0.0, "launches": 0} for k in ("craft", "parseq", "parseq_ar")}
     for e in engs:
         pe = e.get_profile()
         for k in prof:
@@ -174,7 +174,7 @@ def main():
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_craft.json")) as f:
-                traffic = json.load(f)["craft_conv_kernels"]["hbm_bytes_per_launch"] * P   # per launch of a P-page batch
+                traffic = json.load(f)["craft_conv_kernels"]["hbm_bytes_per_launch"] * min(P, 16)   # CRAFT launches cover <= 16 pages
         except Exception:
             pass
         total_pages = world * P * args.steps
@@ -198,9 +198,12 @@ def main():
                          "frac": (craft_tflops / peak) if craft_tflops else None, "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, 1-page runs scaled to the batch)",
                          "launches_per_step": c["launches"] / max(1, args.steps * NC), "avg_launch_us": c["ms"] * 1e3 / max(1, c["launches"]),
                          "algorithmic_gflop_per_page": CRAFT_GFLOP_PER_PAGE},
-            "roofline_parseq_gemm": {"kernel": "gemm2_kernel (PARSeq GEMMs outside the fused AR decoder)", "bound": "mfma", "achieved": pq_tflops, "peak": peak,
+            "roofline_parseq_gemm": {"kernel": "gemm2_kernel: the ViT encoder GEMMs (+ cross-attention K/V projection and the refinement pass)", "bound": "mfma", "achieved": pq_tflops, "peak": peak,
                                      "unit": "TFLOP/s", "frac": (pq_tflops / peak) if pq_tflops else None,
                                      "launches_per_step": q["launches"] / max(1, args.steps)},
+            "roofline_parseq_ar_gemm": {"kernel": "gemm_sk_kernel: per-step autoregressive decoder linears (M = crops in flight; latency-bound)",
+                                        "achieved": (prof["parseq_ar"]["flops"] / (prof["parseq_ar"]["ms"] * 1e-3) / 1e12) if prof["parseq_ar"]["ms"] else None,
+                                        "unit": "TFLOP/s", "launches_per_step": prof["parseq_ar"]["launches"] / max(1, args.steps)},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -137,9 +137,9 @@ int ttr_dev_sync(ttr_engine* e);
 /* last batch: milliseconds spent in each stage on the GPU stream (hipEvents): {craft, post, pack, parseq} */
 int ttr_last_stage_ms(ttr_engine* e, float ms[4]);
 /* per-launch HIP-event timing of the implicit-GEMM kernel, accumulated over calls while on:
- * index 0 = CRAFT convolutions, 1 = PARSeq GEMMs.  flops = algorithmic 2*M*N*K of the unpadded layers. */
+ * index 0 = CRAFT convolutions, 1 = PARSeq encoder (ViT) and batched decoder GEMMs, 2 = the per-step AR decoder GEMMs.  flops = algorithmic 2*M*N*K of the unpadded layers. */
 int ttr_set_profiling(ttr_engine* e, int on);
-int ttr_get_profile(ttr_engine* e, double ms[2], double flops[2], long long launches[2]);
+int ttr_get_profile(ttr_engine* e, double ms[3], double flops[3], long long launches[3]);
 
 #ifdef __cplusplus
 }

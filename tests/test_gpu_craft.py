@@ -54,3 +54,22 @@ def test_craft_full_page_f32_and_bf16(eng_f32, eng_bf16, oracle_models, funsd):
     gb = eng_bf16.craft_heatmap(canvas)
     print(f"bf16 CRAFT full page: max|d| = {np.abs(gb - ref).max():.4f}")
     assert np.abs(gb - ref).max() < 0.06
+
+
+@pytest.mark.parametrize("hw", [(256, 192), (64, 96), (1024, 768)])
+def test_craft_bf16_kernel_generations_agree(engines_random, hw):
+    """bf16 mode, random weights: the second-generation kernels (conv3p / gemm2 with fused pools / conv3s head /
+    conv1_direct) against the first-generation path (igemm for every conv, separate pool kernels).  Same rounding
+    points (bf16 activations between layers), so the heat maps differ only by fp32 summation order and the bf16
+    boundary flips that causes."""
+    _, ebf = engines_random
+    canvas = np.random.default_rng(hw[1]).integers(0, 256, (*hw, 3), dtype=np.uint8)
+    try:
+        ebf.lib.ttr_set_gemm_config(-1)
+        old = ebf.craft_heatmap(canvas)
+    finally:
+        ebf.lib.ttr_set_gemm_config(0)
+    new = ebf.craft_heatmap(canvas)
+    rel = np.abs(new - old).max() / np.abs(old).max()
+    print(f"bf16 CRAFT {hw}: second vs first generation kernels max|d|/max = {rel:.5f}")
+    assert rel < 0.02

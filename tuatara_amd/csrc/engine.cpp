@@ -183,12 +183,12 @@ struct Engine {
   float stage_ms[4] = {0, 0, 0, 0};
   // optional per-launch timing of the igemm kernel (bench.py's roofline): events bracket every launch
   bool profiling = false;
-  int prof_stage = 0;                                  // 0 = CRAFT convs, 1 = PARSeq GEMMs
+  int prof_stage = 0;                                  // 0 = CRAFT convs, 1 = PARSeq encoder (ViT) + batched decoder GEMMs, 2 = per-step AR decoder GEMMs
   std::vector<hipEvent_t> prof_pool;
   struct ProfRec { int stage; double flops; };
   std::vector<ProfRec> prof_recs;
-  double prof_ms[2] = {0, 0}, prof_flops[2] = {0, 0};
-  long prof_launches[2] = {0, 0};
+  double prof_ms[3] = {0, 0, 0}, prof_flops[3] = {0, 0, 0};
+  long prof_launches[3] = {0, 0, 0};
 
   template <class F> void timed(double true_flops, F&& launch) {
     if (!profiling) { launch(); return; }
@@ -432,11 +432,31 @@ struct Engine {
     void* up3 = buf(M1, 64);  launch_upsample2x(prec, u3b, up3, B, H2, W2, 64, stream);
     void* u4a = buf(M1, 64);  conv("upconv4.0", up3, 64, c22, 128, 0, B, H1, W1, u4a, kActRelu);
     void* u4b = buf(M1, 32);  conv("upconv4.3", u4a, 64, nullptr, 0, 0, B, H1, W1, u4b, kActRelu);
-    void* h0 = buf(M1, 32);   conv("conv_cls.0", u4b, 32, nullptr, 0, 0, B, H1, W1, h0, kActRelu);
-    void* h2 = buf(M1, 32);   conv("conv_cls.2", h0, 32, nullptr, 0, 0, B, H1, W1, h2, kActRelu);
-    void* h4 = buf(M1, 32);   conv("conv_cls.4", h2, 32, nullptr, 0, 0, B, H1, W1, h4, kActRelu);   // 16 real + 16 zero channels
-    void* h6 = buf(M1, 32);   conv("conv_cls.6", h4, 32, nullptr, 0, 0, B, H1, W1, h6, kActRelu);
-    conv("conv_cls.8", h6, 32, nullptr, 0, 0, B, H1, W1, nullptr, kActNone, d_heat);
+    void* h0 = buf(M1, 32); void* h2 = buf(M1, 32);
+    if (fp && H1 % 8 == 0 && W1 % 32 == 0 && M1 * 64 < ((size_t)1 << 31)) {
+      // 32-channel head: conv3s.hip (patch-resident 3x3; conv_cls.4 + .6 + .8 as one kernel writing the f32 heat map)
+      auto head = [&](const char* name, const void* in, void* out, bool tail) {
+        const Linear& L = craft.at(name);
+        Conv3sParams q{};
+        q.in = (const bf16*)in; q.wgt = L.w.as<bf16>(); q.bias = L.b.as<float>(); q.out = (bf16*)out; q.B = B; q.H = H1; q.W = W1;
+        double flops = 2.0 * M1 * 32 * 288;
+        if (tail) {
+          const Linear& L6 = craft.at("conv_cls.6"); const Linear& L8 = craft.at("conv_cls.8");
+          q.w6 = L6.w.as<bf16>(); q.b6 = L6.b.as<float>(); q.w8 = L8.w.as<bf16>(); q.b8 = L8.b.as<float>(); q.heat = d_heat; q.out = nullptr;
+          flops = 2.0 * M1 * (16 * 288 + 16 * 16 + 2 * 16);
+        }
+        timed(flops, [&] { launch_conv3s(q, stream); });
+      };
+      head("conv_cls.0", u4b, h0, false);
+      head("conv_cls.2", h0, h2, false);
+      head("conv_cls.4", h2, nullptr, true);
+    } else {
+      conv("conv_cls.0", u4b, 32, nullptr, 0, 0, B, H1, W1, h0, kActRelu);
+      conv("conv_cls.2", h0, 32, nullptr, 0, 0, B, H1, W1, h2, kActRelu);
+      void* h4 = buf(M1, 32);   conv("conv_cls.4", h2, 32, nullptr, 0, 0, B, H1, W1, h4, kActRelu);   // 16 real + 16 zero channels
+      void* h6 = buf(M1, 32);   conv("conv_cls.6", h4, 32, nullptr, 0, 0, B, H1, W1, h6, kActRelu);
+      conv("conv_cls.8", h6, 32, nullptr, 0, 0, B, H1, W1, nullptr, kActNone, d_heat);
+    }
   }
 
   // ---- PARSeq
@@ -546,7 +566,8 @@ struct Engine {
       int G = g_decoder_mode;
       if (G != 4 && G != 8 && G != 16) G = N <= 1024 ? 4 : 8;
       launch_dec_ar(q, G, stream);
-    } else
+    } else {
+    prof_stage = 2;
     for (int i = 0; i < 26; ++i) {
       launch_dec_embed_ln(prec, tk, emb, posq, gc, bc, 1e-5f, t384, N, i, i + 1, stream);
       gemm(pq.at("self_kv"), t384, N, (char*)kvcache + (size_t)i * 768 * es, 26 * 768, kActNone);
@@ -554,6 +575,8 @@ struct Engine {
       launch_dec_self_attn(prec, qself.as<float>(), kvcache, tk, att, N, 1, i, 0, stream);
       decoder_tail(att, N, 1, posq + (size_t)i * E, 1, tgt, t384, d384b, d1536, kvmem, ar + (size_t)i * 95, 26 * 95);
       if (i + 1 < 26) launch_argmax(ar + (size_t)i * 95, 26 * 95, 95, tk, 26, i + 1, N, stream);
+    }
+    prof_stage = 1;
     }
     // ---- refinement pass (cloze mask + EOS key padding), R = 26 query rows per crop
     launch_dec_self_attn(prec, qself.as<float>(), kvcache, tk, att, N, 26, 0, 1, stream);
@@ -1040,13 +1063,13 @@ int ttr_set_profiling(ttr_engine* e, int on) {
   std::lock_guard<std::mutex> lk(E.mu);
   E.profiling = on != 0;
   E.prof_recs.clear();
-  for (int i = 0; i < 2; ++i) { E.prof_ms[i] = 0; E.prof_flops[i] = 0; E.prof_launches[i] = 0; }
+  for (int i = 0; i < 3; ++i) { E.prof_ms[i] = 0; E.prof_flops[i] = 0; E.prof_launches[i] = 0; }
   return 0;
 }
-int ttr_get_profile(ttr_engine* e, double ms[2], double flops[2], long long launches[2]) {
+int ttr_get_profile(ttr_engine* e, double ms[3], double flops[3], long long launches[3]) {
   Engine& E = *e->e;
   std::lock_guard<std::mutex> lk(E.mu);
-  for (int i = 0; i < 2; ++i) { ms[i] = E.prof_ms[i]; flops[i] = E.prof_flops[i]; launches[i] = E.prof_launches[i]; }
+  for (int i = 0; i < 3; ++i) { ms[i] = E.prof_ms[i]; flops[i] = E.prof_flops[i]; launches[i] = E.prof_launches[i]; }
   return 0;
 }
 int ttr_last_stage_ms(ttr_engine* e, float ms[4]) { memcpy(ms, e->e->stage_ms, sizeof(float) * 4); return 0; }

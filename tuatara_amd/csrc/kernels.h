@@ -23,6 +23,19 @@ const void* gelu_lut_for_current_device();
 const char* gemm_sk_check(const ConvParams& p);
 void launch_gemm_sk(const ConvParams& p, hipStream_t s);
 void set_skinny_max_rows(int m);   // problems with M <= m rows go to gemm_sk (0 = never)
+// ---- conv3s.hip (bf16, CRAFT's 32-channel head: 3x3 conv, optionally with the two 1x1 layers behind it fused)
+struct Conv3sParams {
+  const bf16* in;        // [B][H][W][32]
+  const bf16* wgt;       // [32][9][32]  (output channels beyond the layer's own are zero rows)
+  const float* bias;     // [32]
+  bf16* out;             // [B][H][W][32] = relu(conv3x3)                      (when heat == nullptr)
+  const bf16* w6; const float* b6;   // tail: 1x1 16->16 (+ReLU), weights [32][32] zero padded
+  const bf16* w8; const float* b8;   // tail: 1x1 16->2, weights [2][32] zero padded
+  float* heat;           // tail output f32 [B][H][W][2]; non-null selects the fused conv_cls.4 + .6 + .8 kernel
+  int B, H, W;
+};
+const char* conv3s_check(const Conv3sParams& p);
+void launch_conv3s(const Conv3sParams& p, hipStream_t s);
 // ---- conv3p.hip (bf16 3x3 conv with a patch-stationary input tile)
 const char* conv3p_check(const ConvParams& p);   // nullptr when conv3p can run the layer
 void launch_conv3p(const ConvParams& p, hipStream_t s);

@@ -235,9 +235,10 @@ class Engine:
         self.lib.ttr_set_profiling(self.h, int(on))
 
     def get_profile(self):
-        ms, fl, n = (C.c_double * 2)(), (C.c_double * 2)(), (C.c_longlong * 2)()
+        ms, fl, n = (C.c_double * 3)(), (C.c_double * 3)(), (C.c_longlong * 3)()
         self.lib.ttr_get_profile(self.h, ms, fl, n)
-        return {"craft": dict(ms=ms[0], flops=fl[0], launches=n[0]), "parseq": dict(ms=ms[1], flops=fl[1], launches=n[1])}
+        return {"craft": dict(ms=ms[0], flops=fl[0], launches=n[0]), "parseq": dict(ms=ms[1], flops=fl[1], launches=n[1]),
+                "parseq_ar": dict(ms=ms[2], flops=fl[2], launches=n[2])}
 
     # ---- stages
     def craft_heatmap(self, canvas: np.ndarray) -> np.ndarray:
