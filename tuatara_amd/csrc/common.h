@@ -28,6 +28,7 @@ struct ConvParams {
   void* out_pool; int pool_relu;   // gemm2 only: optional 2x2/stride-2 max-pooled T output [B][H/2][W/2][Cout] (row stride out_ld), ReLU first if pool_relu
   const float* resid; int resid_ld; int resid_mod;  // f32 residual added before act; row = m % resid_mod if resid_mod
   int Cout, M, act;
+  const void* pre_wgt; const float* pre_bias;   // conv3p only: fuse CRAFT's conv1_1 in front (in0 = u8 canvas [B][H][W][3], pre_wgt = T [64][32])
   const void* gelu_lut;      // set by launch_gemm2: float2 [1024] = {Phi(x_i), Phi(x_i+1) - Phi(x_i)}, x_i = -8 + i/64
 };
 

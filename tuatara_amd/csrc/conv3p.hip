@@ -42,12 +42,16 @@ struct C3 {
 
 }  // namespace
 
-template <int BN, int WM, int WN>
-__global__ __launch_bounds__(512) void conv3p_kernel(ConvParams p) {
+// FIRST (BN = 64, Cin = 64 only): the input tensor does not exist.  p.in0 is the u8 canvas [B][H][W][3] and the 64-channel
+// halo patch is computed in the prologue: conv1_1 (3 -> 64, 3x3, ReLU; weights p.pre_wgt [64][32] with k = (ky*3+kx)*3+c as
+// in conv1_direct_kernel, bias p.pre_bias) evaluated on the 10 x 34 halo pixels and written straight into the LDS patch.
+// That removes CRAFT's largest tensor (100 MB per page written and read back) and the conv1_1 launch.
+template <int BN, int WM, int WN, bool FIRST, int XS>   // XS: patch stages (1 when Cin = 64: a single chunk, and two workgroups fit a CU)
+__global__ __launch_bounds__(512, XS == 1 && BN == 64 ? 4 : 2) void conv3p_kernel(ConvParams p) {
   using C = C3<BN, WM, WN>;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* const xs = smem;                 // [2][XSLOTS][128 B]  slot pi = pr*34 + pc, chunk c holds channels 8*(c ^ (pi&7))..
-  unsigned char* const ws = smem + 2 * XSTAGE;    // [2][BN][128 B]      as in gemm2.hip
+  unsigned char* const ws = smem + XS * XSTAGE;   // [2][BN][128 B]      as in gemm2.hip
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(512) void conv3p_kernel(ConvParams p) {
   const int y0 = ty * PH, x0 = tx * PW;
 
   const int Cin = p.C0, K = 9 * Cin, nchunks = Cin >> 6, nsteps = nchunks * 9;
-  const __amdgpu_buffer_rsrc_t rsx = mk_rsrc(p.in0, (unsigned)((size_t)p.M * Cin * 2));
+  const __amdgpu_buffer_rsrc_t rsx = mk_rsrc(p.in0, FIRST ? 16u : (unsigned)((size_t)p.M * Cin * 2));
   const __amdgpu_buffer_rsrc_t rsw = mk_rsrc(p.wgt, (unsigned)((size_t)p.Cout * K * 2));
   constexpr unsigned OOB = 0x80000000u;
 
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(512) void conv3p_kernel(ConvParams p) {
     wb[j] = n < p.Cout ? (unsigned)((n * K + g * 8) * 2) : OOB;
   }
   auto stage_x = [&](int chunk) {
-    unsigned char* sb = xs + (chunk & 1) * XSTAGE;
+    unsigned char* sb = xs + (chunk & (XS - 1)) * XSTAGE;
     const unsigned co = (unsigned)(chunk * 64 * 2);
 #pragma unroll
     for (int i = 0; i < C::XPW; ++i) {
@@ -133,13 +137,68 @@ __global__ __launch_bounds__(512) void conv3p_kernel(ConvParams p) {
 #pragma unroll
     for (int i = 0; i < C::MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  stage_x(0);
   stage_w(0);
+  if constexpr (!FIRST) {
+    stage_x(0);
+  } else {
+    // ---- conv1_1 on the halo patch -> xs stage 0 (the LDS behind the operand stages holds the u8 canvas patch and a u8/255 table)
+    unsigned char* cv = smem + XS * XSTAGE + 2 * C::WSTAGE;  // [12][36*3] canvas bytes around the halo (zero outside the image)
+    bf16* lut = reinterpret_cast<bf16*>(cv + 1536);    // bf16(v / 255.0f), v = 0..255
+    const uint8_t* canvas = reinterpret_cast<const uint8_t*>(p.in0);
+    for (int q = tid; q < 12 * 108; q += C::NT) {
+      const int rr = q / 108, cc = q - rr * 108, px = cc / 3;
+      const int y = y0 - 2 + rr, x = x0 - 2 + px;
+      cv[q] = (y >= 0 && y < p.H && x >= 0 && x < p.W) ? canvas[(((int64_t)b * p.H + y) * p.W + x) * 3 + (cc - px * 3)] : (uint8_t)0;
+    }
+    if (tid < 256) lut[tid] = (bf16)((float)tid / 255.0f);
+    bf16x8 f1[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int n = 32 * (jj >> 1) + (fr >> 2) * 8 + (jj & 1) * 4 + (fr & 3);
+      f1[jj] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.pre_wgt) + n * 32 + fg * 8);
+    }
+    float b1[2][8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) b1[t][e] = p.pre_bias[32 * t + fg * 8 + e];
+    int koff[8];                                       // byte offset of this lane's 8 (tap, channel) pairs inside the canvas patch
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = fg * 8 + e, tp = k / 3;
+      koff[e] = k < 27 ? (tp / 3) * 108 + (tp % 3) * 3 + (k - tp * 3) : -1;
+    }
+    __syncthreads();
+    for (int mt = wave; mt * 16 < XSLOTS; mt += C::NW) {
+      const int pi = mt * 16 + fr;
+      const int pr = pi / HW2, pc = pi - pr * HW2;
+      const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+      const bool inside = pi < (PH + 2) * HW2 && y >= 0 && y < p.H && x >= 0 && x < p.W;
+      const unsigned char* base = cv + pr * 108 + pc * 3;   // canvas pixel (y-1, x-1)
+      bf16x8 fx;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) fx[e] = (koff[e] >= 0 && pi < (PH + 2) * HW2) ? lut[base[koff[e]]] : (bf16)0.f;
+      f32x4 a1[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) a1[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1[jj], fx, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = inside ? (bf16)fmaxf(a1[2 * t][e] + b1[t][e], 0.f) : (bf16)0.f;       // outside the image: conv1_2's zero padding
+          o[4 + e] = inside ? (bf16)fmaxf(a1[2 * t + 1][e] + b1[t][4 + e], 0.f) : (bf16)0.f;
+        }
+        if (pi < XSLOTS) *reinterpret_cast<bf16x8*>(xs + pi * 128 + (((4 * t + fg) ^ (pi & 7)) << 4)) = o;
+      }
+    }
+    __syncthreads();   // the patch is written with ds_write: the K loop's raw s_barrier would not wait for it
+  }
   int chunk = 0, tap = 0;
   for (int s = 0; s < nsteps; ++s) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    const unsigned char* xb = xs + (chunk & 1) * XSTAGE;
+    const unsigned char* xb = xs + (chunk & (XS - 1)) * XSTAGE;
     const unsigned char* wbuf = ws + (s & 1) * C::WSTAGE;
     const int tapoff = (tap / 3) * HW2 + (tap % 3);
     bf16x8 fx[2][C::MI], fw[2][C::NJ];
@@ -233,16 +292,17 @@ __global__ __launch_bounds__(512) void conv3p_kernel(ConvParams p) {
   }
 }
 
-template <int BN, int WM, int WN>
+template <int BN, int WM, int WN, bool FIRST = false, int XS = 2>
 static void launch_c3(const ConvParams& p, hipStream_t s) {
   using C = C3<BN, WM, WN>;
   const int tilesM = p.B * (p.H / PH) * (p.W / PW), tilesN = (p.Cout + BN - 1) / BN;
+  constexpr int lds = XS * XSTAGE + 2 * C::WSTAGE + (FIRST ? 2048 : 0);
   static bool once = false;
   if (!once) {
-    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_kernel<BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_kernel<BN, WM, WN, FIRST, XS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     once = true;
   }
-  hipLaunchKernelGGL((conv3p_kernel<BN, WM, WN>), dim3(tilesM * tilesN), dim3(512), C::LDS, s, p);
+  hipLaunchKernelGGL((conv3p_kernel<BN, WM, WN, FIRST, XS>), dim3(tilesM * tilesN), dim3(512), lds, s, p);
 }
 
 const char* conv3p_check(const ConvParams& p) {
@@ -256,7 +316,7 @@ const char* conv3p_check(const ConvParams& p) {
   if (p.out_pool && (p.out_ld % 8 || ((uintptr_t)p.out_pool & 15))) return "conv3p: out_pool alignment";
   if (!p.out && !p.out_pool) return "conv3p: no output";
   if (p.bias && ((uintptr_t)p.bias & 15)) return "conv3p: bias alignment";
-  if (((uintptr_t)p.in0 & 15) || ((uintptr_t)p.wgt & 15)) return "conv3p: operand alignment";
+  if ((!p.pre_wgt && ((uintptr_t)p.in0 & 15)) || ((uintptr_t)p.wgt & 15) || ((uintptr_t)p.pre_wgt & 15)) return "conv3p: operand alignment";
   const size_t lim = (size_t)1 << 31;
   if ((size_t)p.M * p.C0 * 2 >= lim || (size_t)p.Cout * 9 * p.C0 * 2 >= lim) return "conv3p: tensor too large for 32-bit buffer offsets";
   if (p.M != p.B * p.H * p.W || p.M <= 0) return "conv3p: bad shape";
@@ -265,7 +325,11 @@ const char* conv3p_check(const ConvParams& p) {
 
 void launch_conv3p(const ConvParams& p, hipStream_t s) {
   if (const char* e = conv3p_check(p)) throw std::runtime_error(e);
-  if (p.Cout <= 64) return launch_c3<64, 4, 2>(p, s);
+  if (p.pre_wgt) {
+    if (p.C0 != 64 || p.Cout > 64 || !p.pre_bias) throw std::runtime_error("conv3p: the fused first layer needs Cin = 64, Cout <= 64");
+    return launch_c3<64, 4, 2, true, 1>(p, s);
+  }
+  if (p.Cout <= 64) return p.C0 == 64 ? launch_c3<64, 4, 2, false, 1>(p, s) : launch_c3<64, 4, 2>(p, s);
   if (p.Cout <= 128 || p.Cout % 256) return launch_c3<128, 4, 2>(p, s);
   return launch_c3<256, 2, 4>(p, s);
 }

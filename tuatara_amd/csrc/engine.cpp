@@ -38,6 +38,7 @@ void hip_fail(const char* what, hipError_t e, const char* file, int line) {
 
 static thread_local std::string g_last_error;
 static unsigned long long* g_dec_dbg = nullptr;   // device buffer for dec_ar phase stamps (diagnostics)
+static int g_fuse_first = 1;       // bf16: CRAFT conv1_1 fused into conv1_2's loader (conv3p FIRST)
 static int g_enc_chunk = 0;        // crops per encoder group (0 = all crops at once)
 static int g_decoder_mode = 1;   // 0 = kernel-per-op AR loop, 4/8/16 = fused kernel with that many crops per workgroup, else automatic
 
@@ -386,20 +387,30 @@ struct Engine {
     const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8, H4 = H / 16, W4 = W / 16;
     size_t k = 0;
     auto buf = [&](size_t rows, int C) -> void* { return ws(k++, rows * C * es).p; };
-    void* a0 = buf(prec == kBF16 ? 0 : M0, 32);
-    void* c11 = buf(M0, 64);
-    if (prec == kBF16) {   // conv1_1 straight from the u8 canvas
-      const Linear& L = craft.at("slice1.0");
-      timed(2.0 * M0 * 64 * 27, [&] { launch_conv1_direct(d_canvas, L.w.p, L.b.as<float>(), c11, B, H, W, stream); });
-    } else {
-      launch_im2col_l1(prec, d_canvas, a0, B, H, W, stream);
-      conv("slice1.0", a0, 32, nullptr, 0, 0, 1, 1, (int)M0, c11, kActRelu);
-    }
-    // 2x2 max-pools: fused into the producing conv's epilogue in bf16 mode (gemm2), a separate kernel in f32 mode
+    // 2x2 max-pools: fused into the producing conv's epilogue in bf16 mode (gemm2 / conv3p), a separate kernel in f32 mode
     const bool fp = prec == kBF16 && gemm_config() >= 0;
+    const bool first_fused = fp && g_fuse_first && H % 8 == 0 && W % 32 == 0;   // conv1_1 computed inside conv1_2's loader (conv3p FIRST)
+    void* a0 = buf(prec == kBF16 ? 0 : M0, 32);
+    void* c11 = buf(first_fused ? 0 : M0, 64);
     void* c12 = buf(fp ? 0 : M0, 64); void* p1 = buf(M1, 64);
-    if (fp) conv("slice1.3", c11, 64, nullptr, 0, 0, B, H, W, nullptr, kActRelu, nullptr, nullptr, p1);
-    else { conv("slice1.3", c11, 64, nullptr, 0, 0, B, H, W, c12, kActRelu); launch_maxpool2x2(prec, c12, p1, B, H, W, 64, 0, stream); }
+    if (first_fused) {
+      const Linear& L0 = craft.at("slice1.0"); const Linear& L = craft.at("slice1.3");
+      ConvParams p{};
+      p.in0 = d_canvas; p.C0 = 64; p.B = B; p.H = H; p.W = W; p.ks = 3; p.dil = 1;
+      p.pre_wgt = L0.w.p; p.pre_bias = L0.b.as<float>();
+      p.wgt = L.w.p; p.bias = L.b.as<float>(); p.out_ld = 64; p.out_pool = p1; p.Cout = 64; p.M = (int)M0; p.act = kActRelu;
+      timed(2.0 * M0 * 64 * (27 + 576), [&] { launch_conv3p(p, stream); });
+    } else {
+      if (prec == kBF16) {   // conv1_1 straight from the u8 canvas
+        const Linear& L = craft.at("slice1.0");
+        timed(2.0 * M0 * 64 * 27, [&] { launch_conv1_direct(d_canvas, L.w.p, L.b.as<float>(), c11, B, H, W, stream); });
+      } else {
+        launch_im2col_l1(prec, d_canvas, a0, B, H, W, stream);
+        conv("slice1.0", a0, 32, nullptr, 0, 0, 1, 1, (int)M0, c11, kActRelu);
+      }
+      if (fp) conv("slice1.3", c11, 64, nullptr, 0, 0, B, H, W, nullptr, kActRelu, nullptr, nullptr, p1);
+      else { conv("slice1.3", c11, 64, nullptr, 0, 0, B, H, W, c12, kActRelu); launch_maxpool2x2(prec, c12, p1, B, H, W, 64, 0, stream); }
+    }
     void* c21 = buf(M1, 128); conv("slice1.7", p1, 64, nullptr, 0, 0, B, H1, W1, c21, kActRelu);
     void* c22 = buf(M1, 128); void* p2 = buf(M2, 128);                                                   // relu2_2 skip (pre-ReLU)
     if (fp) conv("slice1.10", c21, 128, nullptr, 0, 0, B, H1, W1, c22, kActNone, nullptr, nullptr, p2, 1);
@@ -975,6 +986,7 @@ int ttr_set_tuning(const char* key, int value) {
   if (k == "gemm_config") set_gemm_config(value);
   else if (k == "decoder_mode") g_decoder_mode = value;
   else if (k == "enc_chunk") g_enc_chunk = value;
+  else if (k == "fuse_first") g_fuse_first = value;
   else if (k == "sk_max_rows") set_skinny_max_rows(value);
   else if (k == "dec_stamps") {   // value != 0: allocate the stamp buffer; read it back with ttr_dev_download via ttr_dbg_dec_stamps
     if (value && !g_dec_dbg) { void* d = nullptr; if (hipMalloc(&d, 26 * 16 * 8) != hipSuccess) return -1; (void)hipMemset(d, 0, 26 * 16 * 8); g_dec_dbg = (unsigned long long*)d; }
