@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--skip-check", action="store_true")
     ap.add_argument("--cfgs", default="-1,1,2,3,4,5,6,7")
+    ap.add_argument("--tune", action="append", default=[], help="ttr_set_tuning key=value, repeatable")
     args = ap.parse_args()
     cfgs = [int(c) for c in args.cfgs.split(",")]
 
@@ -99,6 +100,9 @@ def main():
     W.make_synthetic_weights(d, seed=0, structured=False)
     eng = Engine(d, precision="bf16")
     rng = np.random.default_rng(0)
+    for kv in args.tune:
+        k, v = kv.split("=")
+        assert eng.lib.ttr_set_tuning(k.encode(), int(v)) == 0, kv
 
     if not args.skip_check:
         print("== correctness (max |err| / max |ref|) ==")

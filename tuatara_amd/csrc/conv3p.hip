@@ -47,7 +47,7 @@ struct C3 {
 // in conv1_direct_kernel, bias p.pre_bias) evaluated on the 10 x 34 halo pixels and written straight into the LDS patch.
 // That removes CRAFT's largest tensor (100 MB per page written and read back) and the conv1_1 launch.
 template <int BN, int WM, int WN, bool FIRST, int XS>   // XS: patch stages (1 when Cin = 64: a single chunk, and two workgroups fit a CU)
-__global__ __launch_bounds__(512, XS == 1 && BN == 64 ? 4 : 2) void conv3p_kernel(ConvParams p) {
+__global__ __launch_bounds__(512, XS == 1 && BN <= 128 ? 4 : 2) void conv3p_kernel(ConvParams p) {
   using C = C3<BN, WM, WN>;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* const xs = smem;                 // [2][XSLOTS][128 B]  slot pi = pr*34 + pc, chunk c holds channels 8*(c ^ (pi&7))..
@@ -198,10 +198,16 @@ __global__ __launch_bounds__(512, XS == 1 && BN == 64 ? 4 : 2) void conv3p_kerne
   for (int s = 0; s < nsteps; ++s) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (XS == 1 && tap == 0 && chunk > 0) {   // single patch stage: the next chunk's patch can only be fetched now (its latency is
+      stage_x(chunk);                         // covered by the CU's other workgroup, which is what the single stage buys)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
     const unsigned char* xb = xs + (chunk & (XS - 1)) * XSTAGE;
     const unsigned char* wbuf = ws + (s & 1) * C::WSTAGE;
     const int tapoff = (tap / 3) * HW2 + (tap % 3);
-    bf16x8 fx[2][C::MI], fw[2][C::NJ];
+    constexpr bool EARLY = !(XS == 1 && BN <= 128);   // the two-workgroups-per-CU variants have 128 VGPRs: one fragment set at a time
+    bf16x8 fx[EARLY ? 2 : 1][C::MI], fw[EARLY ? 2 : 1][C::NJ];
 #pragma unroll
     for (int j = 0; j < C::NJ; ++j) fw[0][j] = *reinterpret_cast<const bf16x8*>(wbuf + wfl + j * 2048);
     int xa[C::MI];
@@ -212,19 +218,35 @@ __global__ __launch_bounds__(512, XS == 1 && BN == 64 ? 4 : 2) void conv3p_kerne
       fx[0][i] = *reinterpret_cast<const bf16x8*>(xb + xa[i]);
     }
     if (s + 1 < nsteps) stage_w(s + 1);
-    if (tap == 0 && chunk + 1 < nchunks) stage_x(chunk + 1);
+    if (XS == 2 && tap == 0 && chunk + 1 < nchunks) stage_x(chunk + 1);
+    if constexpr (EARLY) {
 #pragma unroll
-    for (int j = 0; j < C::NJ; ++j) fw[1][j] = *reinterpret_cast<const bf16x8*>(wbuf + (wfl ^ 64) + j * 2048);
+      for (int j = 0; j < C::NJ; ++j) fw[1][j] = *reinterpret_cast<const bf16x8*>(wbuf + (wfl ^ 64) + j * 2048);
 #pragma unroll
-    for (int i = 0; i < C::MI; ++i) fx[1][i] = *reinterpret_cast<const bf16x8*>(xb + (xa[i] ^ 64));
-    __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < C::MI; ++i) fx[1][i] = *reinterpret_cast<const bf16x8*>(xb + (xa[i] ^ 64));
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+      for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int i = 0; i < C::MI; ++i)
+        for (int i = 0; i < C::MI; ++i)
 #pragma unroll
-        for (int j = 0; j < C::NJ; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[kk][j], fx[kk][i], acc[j][i], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
+          for (int j = 0; j < C::NJ; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[kk][j], fx[kk][i], acc[j][i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        if (kk) {
+#pragma unroll
+          for (int j = 0; j < C::NJ; ++j) fw[0][j] = *reinterpret_cast<const bf16x8*>(wbuf + (wfl ^ 64) + j * 2048);
+#pragma unroll
+          for (int i = 0; i < C::MI; ++i) fx[0][i] = *reinterpret_cast<const bf16x8*>(xb + (xa[i] ^ 64));
+        }
+#pragma unroll
+        for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+          for (int j = 0; j < C::NJ; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0][j], fx[0][i], acc[j][i], 0, 0, 0);
+      }
+    }
     if (++tap == 9) { tap = 0; ++chunk; }
   }
 
@@ -305,6 +327,12 @@ static void launch_c3(const ConvParams& p, hipStream_t s) {
   hipLaunchKernelGGL((conv3p_kernel<BN, WM, WN, FIRST, XS>), dim3(tilesM * tilesN), dim3(512), lds, s, p);
 }
 
+static int g_force_bn128 = 1;     // BN = 128 single-stage tiles, two workgroups per CU, for every Cout > 64 (0: BN = 256, one per CU, for Cout % 256 == 0):
+                                  // measured +5..17 % on CRAFT's 256/512-channel layers (1.19-1.40 PFLOP/s)
+void set_conv3p_force_bn128(int v) { g_force_bn128 = v; }
+static int g_xs1_max_cin = 1 << 20;   // layers with Cout <= 128 and Cin up to this use one patch stage and two workgroups per CU
+void set_conv3p_single_stage_max_cin(int c) { g_xs1_max_cin = c; }
+
 const char* conv3p_check(const ConvParams& p) {
   if (p.ks != 3 || p.dil != 1) return "conv3p: 3x3, dilation 1 only";
   if (p.C1 || p.relu0 || p.relu1) return "conv3p: single source, no ReLU on load";
@@ -329,8 +357,8 @@ void launch_conv3p(const ConvParams& p, hipStream_t s) {
     if (p.C0 != 64 || p.Cout > 64 || !p.pre_bias) throw std::runtime_error("conv3p: the fused first layer needs Cin = 64, Cout <= 64");
     return launch_c3<64, 4, 2, true, 1>(p, s);
   }
-  if (p.Cout <= 64) return p.C0 == 64 ? launch_c3<64, 4, 2, false, 1>(p, s) : launch_c3<64, 4, 2>(p, s);
-  if (p.Cout <= 128 || p.Cout % 256) return launch_c3<128, 4, 2>(p, s);
+  if (p.Cout <= 64) return p.C0 <= g_xs1_max_cin ? launch_c3<64, 4, 2, false, 1>(p, s) : launch_c3<64, 4, 2>(p, s);
+  if (p.Cout <= 128 || p.Cout % 256 || g_force_bn128) return p.C0 <= g_xs1_max_cin ? launch_c3<128, 4, 2, false, 1>(p, s) : launch_c3<128, 4, 2>(p, s);
   return launch_c3<256, 2, 4>(p, s);
 }
 

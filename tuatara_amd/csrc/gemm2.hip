@@ -63,17 +63,21 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
     for (int i = tid; i < 512; i += C::NT) reinterpret_cast<uint4*>(glut)[i] = reinterpret_cast<const uint4*>(p.gelu_lut)[i];
   }   // visible after the first K-step barrier
 
-  // ---- XCD-aware tile order
+  // ---- persistent, XCD-aware tile schedule.  Workgroups bid and bid+8 share an XCD (round-robin placement, speed only);
+  // XCD x owns a contiguous run of the tile list (N tiles of one M tile adjacent) and its J = gridDim/8 workgroups walk
+  // that run with stride J.  While a tile's last K step computes, the first stage of the workgroup's NEXT tile is already
+  // streaming in, so the epilogue and the next tile's load latency overlap (the K = 384 PARSeq GEMMs have only 6 K steps).
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
   const int T = tilesM * tilesN;
-  int tile;
+  const int xcd = blockIdx.x & 7, J = gridDim.x >> 3;
+  int xcd_first, xcd_count;
   {
-    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
     const int q = T >> 3, r = T & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    xcd_first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    xcd_count = q + (xcd < r ? 1 : 0);
   }
-  const int tm = tile / tilesN, tn = tile - tm * tilesN;
-  const int m0 = tm * BM, n0 = tn * BN;
+  int idx = blockIdx.x >> 3;
+  if (idx >= xcd_count) return;
 
   const int Ctot = p.C0 + p.C1;
   const int K = p.ks * p.ks * Ctot;
@@ -95,43 +99,47 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
     return (b * p.H + 2 * yo + (sub >> 1)) * p.W + 2 * xo + (sub & 1);
   };
 
-  // ---- per-lane loader state.  Piece q = i*NW + wave covers tile rows 8q..8q+7; this lane owns
+  // ---- per-lane loader state of the tile being staged.  Piece q = i*NW + wave covers tile rows 8q..8q+7; this lane owns
   // row 8q + (lane>>3) and LDS chunk (lane&7), which holds global chunk (lane&7) ^ ((row>>1)&7).
+  int m0 = 0, n0 = 0;
   unsigned xb0[C::XPW], xb1[C::XPW];   // byte offset of (pixel, chunk) in source 0 / 1
   unsigned xmask[C::XPW];              // bit t: tap t stays inside the image (bit 0 only for 1x1)
-#pragma unroll
-  for (int i = 0; i < C::XPW; ++i) {
-    const int row = (i * C::NW + wave) * 8 + (lane >> 3);
-    const int g = (lane & 7) ^ ((row >> 1) & 7);
-    const int m = row_to_pixel(m0 + row);
-    unsigned mask = 0;
-    if (m0 + row < p.M) {
-      if (p.ks == 3) {
-        const int r = m % HW, y = r / p.W, x = r - y * p.W;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const int yy = y + (t / 3 - 1) * p.dil, xx = x + (t % 3 - 1) * p.dil;
-          if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) mask |= 1u << t;
-        }
-      } else mask = 1u;
-    }
-    xmask[i] = mask;
-    xb0[i] = ((unsigned)m * (unsigned)p.C0 + g * 8) * 2u;
-    xb1[i] = ((unsigned)m * (unsigned)p.C1 + g * 8) * 2u;
-  }
   unsigned wb[C::WPW];                 // byte offset of (weight row, chunk), or OOB
+  int tap = 0, cc = 0;                 // K cursor of the next stage
+  auto setup_tile = [&](int tile) {
+    const int tm = tile / tilesN, tn = tile - tm * tilesN;
+    m0 = tm * BM; n0 = tn * BN;
+    tap = 0; cc = 0;
 #pragma unroll
-  for (int j = 0; j < C::WPW; ++j) {
-    const int piece = j * C::NW + wave;
-    const int row = piece * 8 + (lane >> 3);       // LDS row of the weight tile
-    const int g = (lane & 7) ^ ((row >> 1) & 7);
-    const int q16 = row & 15;
-    const int nl = (row & ~31) + (q16 >> 2) * 8 + ((row >> 4) & 1) * 4 + (q16 & 3);   // channel held by that LDS row
-    const int n = n0 + nl;
-    wb[j] = (n < p.Cout) ? ((unsigned)n * (unsigned)K + g * 8) * 2u : OOB;
-  }
-
-  int tap = 0, cc = 0;   // K cursor of the next tile to stage
+    for (int i = 0; i < C::XPW; ++i) {
+      const int row = (i * C::NW + wave) * 8 + (lane >> 3);
+      const int g = (lane & 7) ^ ((row >> 1) & 7);
+      const int m = row_to_pixel(m0 + row);
+      unsigned mask = 0;
+      if (m0 + row < p.M) {
+        if (p.ks == 3) {
+          const int r = m % HW, y = r / p.W, x = r - y * p.W;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const int yy = y + (t / 3 - 1) * p.dil, xx = x + (t % 3 - 1) * p.dil;
+            if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) mask |= 1u << t;
+          }
+        } else mask = 1u;
+      }
+      xmask[i] = mask;
+      xb0[i] = ((unsigned)m * (unsigned)p.C0 + g * 8) * 2u;
+      xb1[i] = ((unsigned)m * (unsigned)p.C1 + g * 8) * 2u;
+    }
+#pragma unroll
+    for (int j = 0; j < C::WPW; ++j) {
+      const int row = (j * C::NW + wave) * 8 + (lane >> 3);       // LDS row of the weight tile
+      const int g = (lane & 7) ^ ((row >> 1) & 7);
+      const int q16 = row & 15;
+      const int nl = (row & ~31) + (q16 >> 2) * 8 + ((row >> 4) & 1) * 4 + (q16 & 3);   // channel held by that LDS row
+      const int n = n0 + nl;
+      wb[j] = (n < p.Cout) ? ((unsigned)n * (unsigned)K + g * 8) * 2u : OOB;
+    }
+  };
   auto stage_tile = [&](int buf) {
     unsigned char* sb = smem + buf * C::STAGE;
     const bool s1 = cc >= p.C0;
@@ -157,12 +165,6 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
     if (cc == Ctot) { cc = 0; ++tap; }
   };
 
-  f32x4 acc[C::NJ][C::MI];
-#pragma unroll
-  for (int j = 0; j < C::NJ; ++j)
-#pragma unroll
-    for (int i = 0; i < C::MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
   // fragment addressing: row = tile-aligned base + (lane&15), so (row>>1)&7 == (lane>>1)&7
   const int frag_lane = (lane & 15) * 128 + ((((lane >> 4)) ^ ((lane >> 1) & 7)) << 4);
   const unsigned char* xfrag[2];
@@ -172,98 +174,128 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
     xfrag[kk] = smem + wm * C::TM * 128 + (frag_lane ^ (kk * 64));
     wfrag[kk] = smem + BM * 128 + wn * C::TN * 128 + (frag_lane ^ (kk * 64));
   }
-
-  stage_tile(0);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int so = (kt & 1) * C::STAGE;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of tile kt have landed
-    __builtin_amdgcn_s_barrier();                      // everyone's have; everyone is done reading the other stage
-    // all fragment reads of this K step are issued up front (their latency hides behind the
-    // loader's address arithmetic), then the MFMAs run back to back
-    bf16x8 fx[2][C::MI], fw[2][C::NJ];
-#pragma unroll
-    for (int j = 0; j < C::NJ; ++j) fw[0][j] = *reinterpret_cast<const bf16x8*>(wfrag[0] + so + j * 2048);
-#pragma unroll
-    for (int i = 0; i < C::MI; ++i) fx[0][i] = *reinterpret_cast<const bf16x8*>(xfrag[0] + so + i * 2048);
-    if (kt + 1 < nk) stage_tile((kt & 1) ^ 1);
-#pragma unroll
-    for (int j = 0; j < C::NJ; ++j) fw[1][j] = *reinterpret_cast<const bf16x8*>(wfrag[1] + so + j * 2048);
-#pragma unroll
-    for (int i = 0; i < C::MI; ++i) fx[1][i] = *reinterpret_cast<const bf16x8*>(xfrag[1] + so + i * 2048);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < C::MI; ++i)
-#pragma unroll
-        for (int j = 0; j < C::NJ; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[kk][j], fx[kk][i], acc[j][i], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-
-  // ---- epilogue: lane holds channels n = nb + 32t + (lane>>4)*8 + 0..7 of pixel m = mb + 16i + (lane&15)
   const int fg = lane >> 4, fr = lane & 15;
+
+  setup_tile(xcd_first + idx);
+  int par = 0;                         // LDS stage of the next K step
+  stage_tile(par);
+  while (true) {
+    f32x4 acc[C::NJ][C::MI];
 #pragma unroll
-  for (int t = 0; t < C::NJ / 2; ++t) {
-    const int n = n0 + wn * C::TN + t * 32 + fg * 8;
-    if (n >= p.Cout) continue;
-    float bv[8];
-    if (p.bias) {
-      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
-      bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
-    } else {
+    for (int j = 0; j < C::NJ; ++j)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+      for (int i = 0; i < C::MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int m0c = m0, n0c = n0;      // the tile being computed (setup_tile below moves m0 / n0 on to the next one)
+    bool has_next = false;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int so = par * C::STAGE;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of this K step have landed
+      __builtin_amdgcn_s_barrier();                      // everyone's have; everyone is done reading the other stage
+      // all fragment reads of this K step are issued up front (their latency hides behind the
+      // loader's address arithmetic), then the MFMAs run back to back
+      bf16x8 fx[2][C::MI], fw[2][C::NJ];
+#pragma unroll
+      for (int j = 0; j < C::NJ; ++j) fw[0][j] = *reinterpret_cast<const bf16x8*>(wfrag[0] + so + j * 2048);
+#pragma unroll
+      for (int i = 0; i < C::MI; ++i) fx[0][i] = *reinterpret_cast<const bf16x8*>(xfrag[0] + so + i * 2048);
+      if (kt + 1 < nk) stage_tile(par ^ 1);
+      else if (idx + J < xcd_count) {                    // last K step: start the next tile's first stage
+        has_next = true;
+        idx += J;
+        setup_tile(xcd_first + idx);
+        stage_tile(par ^ 1);
+      }
+#pragma unroll
+      for (int j = 0; j < C::NJ; ++j) fw[1][j] = *reinterpret_cast<const bf16x8*>(wfrag[1] + so + j * 2048);
+#pragma unroll
+      for (int i = 0; i < C::MI; ++i) fx[1][i] = *reinterpret_cast<const bf16x8*>(xfrag[1] + so + i * 2048);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+          for (int j = 0; j < C::NJ; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[kk][j], fx[kk][i], acc[j][i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      par ^= 1;
     }
-#pragma unroll
-    for (int i = 0; i < C::MI; ++i) {
-      const int grow = m0 + wm * C::TM + i * 16 + fr;
-      const bool valid = grow < p.M;                 // uniform over each group of 4 lanes when pooling (M % 4 == 0)
-      const int m = row_to_pixel(valid ? grow : 0);
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] = acc[2 * t][i][e] + bv[e]; v[4 + e] = acc[2 * t + 1][i][e] + bv[4 + e]; }
-      if (p.resid && valid) {
-        const float* rp = p.resid + (int64_t)(p.resid_mod ? m % p.resid_mod : m) * p.resid_ld + n;
-        const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
-        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+
+    // ---- epilogue: lane holds channels n = nb + 32t + (lane>>4)*8 + 0..7 of pixel m = mb + 16i + (lane&15)
+  #pragma unroll
+    for (int t = 0; t < C::NJ / 2; ++t) {
+      const int n = n0c + wn * C::TN + t * 32 + fg * 8;
+      if (n >= p.Cout) continue;
+      float bv[8];
+      if (p.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+      } else {
+  #pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = 0.f;
       }
-      if (p.act == kActRelu) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-      } else if (p.act == kActGelu) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_lut(v[e], glut);
-      }
-      if (p.out && valid) {
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out) + (int64_t)m * p.out_ld + n) = o;
-      }
-      if (p.out_relu && valid) {
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16)fmaxf(v[e], 0.f);
-        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out_relu) + (int64_t)m * p.out_ld + n) = o;
-      }
-      if (p.out_f32 && valid) {
-        float* op = p.out_f32 + (int64_t)m * p.out_f32_ld + n;
-        *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
-      }
-      if (p.out_pool) {   // 2x2 max over lanes fr, fr^1, fr^2, fr^3; rounding to bf16 commutes with max
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float x = p.pool_relu ? fmaxf(v[e], 0.f) : v[e];
-          x = fmaxf(x, __shfl_xor(x, 1));
-          x = fmaxf(x, __shfl_xor(x, 2));
-          o[e] = (bf16)x;
+  #pragma unroll
+      for (int i = 0; i < C::MI; ++i) {
+        const int grow = m0c + wm * C::TM + i * 16 + fr;
+        const bool valid = grow < p.M;                 // uniform over each group of 4 lanes when pooling (M % 4 == 0)
+        const int m = row_to_pixel(valid ? grow : 0);
+        float v[8];
+  #pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = acc[2 * t][i][e] + bv[e]; v[4 + e] = acc[2 * t + 1][i][e] + bv[4 + e]; }
+        if (p.resid && valid) {
+          const float* rp = p.resid + (int64_t)(p.resid_mod ? m % p.resid_mod : m) * p.resid_ld + n;
+          const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+          v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
         }
-        if (valid && (fr & 3) == 0) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out_pool) + (int64_t)(grow >> 2) * p.out_ld + n) = o;
+        if (p.act == kActRelu) {
+  #pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (p.act == kActGelu) {
+  #pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = gelu_lut(v[e], glut);
+        }
+        if (p.out && valid) {
+          bf16x8 o;
+  #pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out) + (int64_t)m * p.out_ld + n) = o;
+        }
+        if (p.out_relu && valid) {
+          bf16x8 o;
+  #pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16)fmaxf(v[e], 0.f);
+          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out_relu) + (int64_t)m * p.out_ld + n) = o;
+        }
+        if (p.out_f32 && valid) {
+          float* op = p.out_f32 + (int64_t)m * p.out_f32_ld + n;
+          *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        if (p.out_pool) {   // 2x2 max over lanes fr, fr^1, fr^2, fr^3; rounding to bf16 commutes with max
+          bf16x8 o;
+  #pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float x = p.pool_relu ? fmaxf(v[e], 0.f) : v[e];
+            x = fmaxf(x, __shfl_xor(x, 1));
+            x = fmaxf(x, __shfl_xor(x, 2));
+            o[e] = (bf16)x;
+          }
+          if (valid && (fr & 3) == 0) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out_pool) + (int64_t)(grow >> 2) * p.out_ld + n) = o;
+        }
       }
     }
+    if (!has_next) break;
   }
+}
+
+static int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+    else n = 256;
+  }
+  return n;
 }
 
 template <int BM, int BN, int WM, int WN, int MINB>
@@ -276,7 +308,11 @@ static void launch_g2(const ConvParams& p, hipStream_t s) {
     once = true;
   }
   const size_t lds = C::LDS + (p.act == kActGelu ? 8192 : 0);
-  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM, WN, MINB>), dim3(tilesM * tilesN), dim3(C::NT), lds, s, p);
+  // persistent grid: as many workgroups as fit the chip at once (a multiple of 8: one share per XCD), never more than tiles
+  const int per_cu = std::max(1, std::min((int)(160 * 1024 / lds), 2048 / C::NT));
+  const int cap = num_cus() * per_cu / 8 * 8;
+  const int grid = std::min((tilesM * tilesN + 7) / 8 * 8, std::max(cap, 8));
+  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM, WN, MINB>), dim3(grid), dim3(C::NT), lds, s, p);
 }
 
 // Phi table of the GELU epilogue, one per device, built on first use (host erf in double)

@@ -39,6 +39,8 @@ void launch_conv3s(const Conv3sParams& p, hipStream_t s);
 // ---- conv3p.hip (bf16 3x3 conv with a patch-stationary input tile)
 const char* conv3p_check(const ConvParams& p);   // nullptr when conv3p can run the layer
 void launch_conv3p(const ConvParams& p, hipStream_t s);
+void set_conv3p_single_stage_max_cin(int c);
+void set_conv3p_force_bn128(int v);
 // n pseudo-random values, uniform in [-scale, scale) (benchmark inputs)
 void launch_fill_random(Precision prec, void* p, size_t n, unsigned seed, float scale, hipStream_t s);
 
