@@ -37,7 +37,7 @@ struct C3 {
   static constexpr int WP = BN / 8, WPW = WP / NW;
   static constexpr int WSTAGE = BN * 128;
   static constexpr int LDS = 2 * XSTAGE + 2 * WSTAGE;
-  static_assert(NW == 8 && TM % 64 == 0 && TN % 32 == 0 && WP % NW == 0, "conv3p tiling");
+  static_assert((NW == 8 || NW == 4) && TM % 64 == 0 && TN % 32 == 0 && WP % NW == 0, "conv3p tiling");
 };
 
 }  // namespace
@@ -47,7 +47,7 @@ struct C3 {
 // in conv1_direct_kernel, bias p.pre_bias) evaluated on the 10 x 34 halo pixels and written straight into the LDS patch.
 // That removes CRAFT's largest tensor (100 MB per page written and read back) and the conv1_1 launch.
 template <int BN, int WM, int WN, bool FIRST, int XS>   // XS: patch stages (1 when Cin = 64: a single chunk, and two workgroups fit a CU)
-__global__ __launch_bounds__(512, XS == 1 && BN <= 128 ? 4 : 2) void conv3p_kernel(ConvParams p) {
+__global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM * WN == 4 ? 1 : 1)) void conv3p_kernel(ConvParams p) {
   using C = C3<BN, WM, WN>;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* const xs = smem;                 // [2][XSLOTS][128 B]  slot pi = pr*34 + pc, chunk c holds channels 8*(c ^ (pi&7))..
@@ -324,9 +324,11 @@ static void launch_c3(const ConvParams& p, hipStream_t s) {
     TTR_HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_kernel<BN, WM, WN, FIRST, XS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     once = true;
   }
-  hipLaunchKernelGGL((conv3p_kernel<BN, WM, WN, FIRST, XS>), dim3(tilesM * tilesN), dim3(512), lds, s, p);
+  hipLaunchKernelGGL((conv3p_kernel<BN, WM, WN, FIRST, XS>), dim3(tilesM * tilesN), dim3(C::NT), lds, s, p);
 }
 
+static int g_c64_waves = 8;        // Cout <= 64 tiles: 8 waves (wave tile 64x32) or 4 waves (wave tile 64x64, fewer LDS fragment reads per MFMA)
+void set_conv3p_c64_waves(int w) { g_c64_waves = w; }
 static int g_force_bn128 = 1;     // BN = 128 single-stage tiles, two workgroups per CU, for every Cout > 64 (0: BN = 256, one per CU, for Cout % 256 == 0):
                                   // measured +5..17 % on CRAFT's 256/512-channel layers (1.19-1.40 PFLOP/s)
 void set_conv3p_force_bn128(int v) { g_force_bn128 = v; }
@@ -357,7 +359,10 @@ void launch_conv3p(const ConvParams& p, hipStream_t s) {
     if (p.C0 != 64 || p.Cout > 64 || !p.pre_bias) throw std::runtime_error("conv3p: the fused first layer needs Cin = 64, Cout <= 64");
     return launch_c3<64, 4, 2, true, 1>(p, s);
   }
-  if (p.Cout <= 64) return p.C0 <= g_xs1_max_cin ? launch_c3<64, 4, 2, false, 1>(p, s) : launch_c3<64, 4, 2>(p, s);
+  if (p.Cout <= 64) {
+    if (g_c64_waves == 4) return launch_c3<64, 4, 1, false, 1>(p, s);
+    return p.C0 <= g_xs1_max_cin ? launch_c3<64, 4, 2, false, 1>(p, s) : launch_c3<64, 4, 2>(p, s);
+  }
   if (p.Cout <= 128 || p.Cout % 256 || g_force_bn128) return p.C0 <= g_xs1_max_cin ? launch_c3<128, 4, 2, false, 1>(p, s) : launch_c3<128, 4, 2>(p, s);
   return launch_c3<256, 2, 4>(p, s);
 }

@@ -41,6 +41,7 @@ const char* conv3p_check(const ConvParams& p);   // nullptr when conv3p can run 
 void launch_conv3p(const ConvParams& p, hipStream_t s);
 void set_conv3p_single_stage_max_cin(int c);
 void set_conv3p_force_bn128(int v);
+void set_conv3p_c64_waves(int w);
 // n pseudo-random values, uniform in [-scale, scale) (benchmark inputs)
 void launch_fill_random(Precision prec, void* p, size_t n, unsigned seed, float scale, hipStream_t s);
 
