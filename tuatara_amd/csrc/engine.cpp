@@ -987,6 +987,7 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "decoder_mode") g_decoder_mode = value;
   else if (k == "enc_chunk") g_enc_chunk = value;
   else if (k == "fuse_first") g_fuse_first = value;
+  else if (k == "g2_x_ring3") set_gemm2_x_ring3(value);
   else if (k == "c3_xs1_max_cin") set_conv3p_single_stage_max_cin(value);
   else if (k == "c3_force_bn128") set_conv3p_force_bn128(value);
   else if (k == "c3_c64_waves") set_conv3p_c64_waves(value);

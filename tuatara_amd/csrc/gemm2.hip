@@ -34,22 +34,25 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int XST = 2>
 struct G2Cfg {
   static constexpr int NW = WM * WN, NT = NW * 64;
   static constexpr int TM = BM / WM, TN = BN / WN;   // wave tile
   static constexpr int MI = TM / 16, NJ = TN / 16;
   static constexpr int XP = BM / 8, WP = BN / 8;     // 1-KiB pieces (8 rows x 128 B) per operand tile
   static constexpr int XPW = XP / NW, WPW = WP / NW;  // pieces per wave
-  static constexpr int STAGE = (BM + BN) * 128;
-  static constexpr int LDS = 2 * STAGE;
+  static constexpr int XBYTES = BM * 128, WBYTES = BN * 128;   // one stage of each operand
+  static constexpr int LDS = XST * XBYTES + 2 * WBYTES;        // X ring of XST stages, W ring of 2
   static_assert(XP % NW == 0 && WP % NW == 0, "tile pieces must divide over the waves");
   static_assert(TN % 32 == 0 && TM % 16 == 0, "wave tile");
 };
 
-template <int BM, int BN, int WM, int WN, int MINB>
+// XST = 3: the activation tiles run TWO K steps ahead of the MFMAs (the weight tiles one).  Activations are streamed once, so
+// every X tile is a first-touch HBM miss (~2 us); one K step of MFMA work is shorter than that and the one-step-ahead form
+// spent 37-51 % of its wave cycles parked on vmcnt (SQ_WAIT_ANY).  Weights stay L2 resident and need only one step.
+template <int BM, int BN, int WM, int WN, int MINB, int XST>
 __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p) {
-  using C = G2Cfg<BM, BN, WM, WN>;
+  using C = G2Cfg<BM, BN, WM, WN, XST>;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -99,17 +102,19 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
     return (b * p.H + 2 * yo + (sub >> 1)) * p.W + 2 * xo + (sub & 1);
   };
 
-  // ---- per-lane loader state of the tile being staged.  Piece q = i*NW + wave covers tile rows 8q..8q+7; this lane owns
-  // row 8q + (lane>>3) and LDS chunk (lane&7), which holds global chunk (lane&7) ^ ((row>>1)&7).
-  int m0 = 0, n0 = 0;
-  unsigned xb0[C::XPW], xb1[C::XPW];   // byte offset of (pixel, chunk) in source 0 / 1
+  // ---- two loader streams walk the workgroup's (tile, K step) sequence ahead of the MFMAs.  Piece q = i*NW + wave of a stage
+  // covers tile rows 8q..8q+7; this lane owns row 8q + (lane>>3) and LDS chunk (lane&7), which holds global chunk
+  // (lane&7) ^ ((row>>1)&7).
+  unsigned char* const xring = smem;
+  unsigned char* const wring = smem + XST * C::XBYTES;
+  unsigned xb0[C::XPW], xb1[C::XPW];   // X stream: byte offset of (pixel, chunk) in source 0 / 1 for its current tile
   unsigned xmask[C::XPW];              // bit t: tap t stays inside the image (bit 0 only for 1x1)
-  unsigned wb[C::WPW];                 // byte offset of (weight row, chunk), or OOB
-  int tap = 0, cc = 0;                 // K cursor of the next stage
-  auto setup_tile = [&](int tile) {
-    const int tm = tile / tilesN, tn = tile - tm * tilesN;
-    m0 = tm * BM; n0 = tn * BN;
-    tap = 0; cc = 0;
+  unsigned wb[C::WPW];                 // W stream: byte offset of (weight row, chunk), or OOB
+  int x_idx = idx, x_k = 0, x_slot = 0; bool x_ok = true;
+  int w_idx = idx, w_k = 0, w_slot = 0; bool w_ok = true;
+  auto setup_x = [&](int li) {
+    const int tile = xcd_first + li, tm = tile / tilesN;
+    const int m0 = tm * BM;
 #pragma unroll
     for (int i = 0; i < C::XPW; ++i) {
       const int row = (i * C::NW + wave) * 8 + (lane >> 3);
@@ -130,6 +135,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
       xb0[i] = ((unsigned)m * (unsigned)p.C0 + g * 8) * 2u;
       xb1[i] = ((unsigned)m * (unsigned)p.C1 + g * 8) * 2u;
     }
+  };
+  auto setup_w = [&](int li) {
+    const int tile = xcd_first + li, tm = tile / tilesN, n0 = (tile - tm * tilesN) * BN;
 #pragma unroll
     for (int j = 0; j < C::WPW; ++j) {
       const int row = (j * C::NW + wave) * 8 + (lane >> 3);       // LDS row of the weight tile
@@ -140,8 +148,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
       wb[j] = (n < p.Cout) ? ((unsigned)n * (unsigned)K + g * 8) * 2u : OOB;
     }
   };
-  auto stage_tile = [&](int buf) {
-    unsigned char* sb = smem + buf * C::STAGE;
+  auto issue_x = [&]() {               // loads of (x_idx, x_k) into ring slot x_slot, then advance the stream
+    unsigned char* sb = xring + x_slot * C::XBYTES;
+    const int k0 = x_k << 6, tap = k0 / Ctot, cc = k0 - tap * Ctot;
     const bool s1 = cc >= p.C0;
     int dpix = 0;
     if (p.ks == 3) { const int ky = tap / 3, kx = tap - ky * 3; dpix = ((ky - 1) * p.W + (kx - 1)) * p.dil; }
@@ -155,14 +164,19 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
       if (s1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, vo, 0, 0, 0);
       else    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, vo, 0, 0, 0);
     }
-    const unsigned koff = (unsigned)((tap * Ctot + cc) * 2);
+    x_slot = x_slot + 1 == XST ? 0 : x_slot + 1;
+    if (++x_k == nk) { x_k = 0; x_idx += J; x_ok = x_idx < xcd_count; if (x_ok) setup_x(x_idx); }
+  };
+  auto issue_w = [&]() {
+    unsigned char* sb = wring + w_slot * C::WBYTES;
+    const unsigned koff = (unsigned)(w_k << 7);          // k0 * 2 bytes: weights are [Cout][taps][Cin] = K contiguous
 #pragma unroll
     for (int j = 0; j < C::WPW; ++j) {
       const unsigned vo = wb[j] == OOB ? OOB : wb[j] + koff;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sb + BM * 128 + (j * C::NW + wave) * 1024), 16, vo, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sb + (j * C::NW + wave) * 1024), 16, vo, 0, 0, 0);
     }
-    cc += 64;
-    if (cc == Ctot) { cc = 0; ++tap; }
+    w_slot ^= 1;
+    if (++w_k == nk) { w_k = 0; w_idx += J; w_ok = w_idx < xcd_count; if (w_ok) setup_w(w_idx); }
   };
 
   // fragment addressing: row = tile-aligned base + (lane&15), so (row>>1)&7 == (lane>>1)&7
@@ -171,44 +185,44 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
   const unsigned char* wfrag[2];
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) {
-    xfrag[kk] = smem + wm * C::TM * 128 + (frag_lane ^ (kk * 64));
-    wfrag[kk] = smem + BM * 128 + wn * C::TN * 128 + (frag_lane ^ (kk * 64));
+    xfrag[kk] = xring + wm * C::TM * 128 + (frag_lane ^ (kk * 64));
+    wfrag[kk] = wring + wn * C::TN * 128 + (frag_lane ^ (kk * 64));
   }
   const int fg = lane >> 4, fr = lane & 15;
 
-  setup_tile(xcd_first + idx);
-  int par = 0;                         // LDS stage of the next K step
-  stage_tile(par);
+  setup_x(idx); setup_w(idx);
+  issue_x(); issue_w();                                  // X(0), W(0)
+  bool x_ahead = false;                                  // an X stage younger than the step about to run is in flight
+  if (XST == 3 && x_ok) { issue_x(); x_ahead = true; }   // X(1)
+  int xr = 0, wr = 0;                                    // ring slots the MFMAs read next
   while (true) {
     f32x4 acc[C::NJ][C::MI];
 #pragma unroll
     for (int j = 0; j < C::NJ; ++j)
 #pragma unroll
       for (int i = 0; i < C::MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int m0c = m0, n0c = n0;      // the tile being computed (setup_tile below moves m0 / n0 on to the next one)
-    bool has_next = false;
+    const int ctile = xcd_first + idx;
+    const int m0c = (ctile / tilesN) * BM, n0c = (ctile % tilesN) * BN;
     for (int kt = 0; kt < nk; ++kt) {
-      const int so = par * C::STAGE;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of this K step have landed
-      __builtin_amdgcn_s_barrier();                      // everyone's have; everyone is done reading the other stage
+      const int xo = xr * C::XBYTES, wo = wr * C::WBYTES;
+      // my pieces of this K step have landed (loads retire in order: only the younger X stage may still be in flight)
+      if (XST == 3 && x_ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::XPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                      // everyone's have; everyone is done reading the slots refilled below
       // all fragment reads of this K step are issued up front (their latency hides behind the
       // loader's address arithmetic), then the MFMAs run back to back
       bf16x8 fx[2][C::MI], fw[2][C::NJ];
 #pragma unroll
-      for (int j = 0; j < C::NJ; ++j) fw[0][j] = *reinterpret_cast<const bf16x8*>(wfrag[0] + so + j * 2048);
+      for (int j = 0; j < C::NJ; ++j) fw[0][j] = *reinterpret_cast<const bf16x8*>(wfrag[0] + wo + j * 2048);
 #pragma unroll
-      for (int i = 0; i < C::MI; ++i) fx[0][i] = *reinterpret_cast<const bf16x8*>(xfrag[0] + so + i * 2048);
-      if (kt + 1 < nk) stage_tile(par ^ 1);
-      else if (idx + J < xcd_count) {                    // last K step: start the next tile's first stage
-        has_next = true;
-        idx += J;
-        setup_tile(xcd_first + idx);
-        stage_tile(par ^ 1);
-      }
+      for (int i = 0; i < C::MI; ++i) fx[0][i] = *reinterpret_cast<const bf16x8*>(xfrag[0] + xo + i * 2048);
+      if (w_ok) issue_w();                               // W one step ahead, issued BEFORE the younger X stage
+      x_ahead = x_ok;
+      if (x_ok) issue_x();                               // X two steps ahead (one when XST == 2)
 #pragma unroll
-      for (int j = 0; j < C::NJ; ++j) fw[1][j] = *reinterpret_cast<const bf16x8*>(wfrag[1] + so + j * 2048);
+      for (int j = 0; j < C::NJ; ++j) fw[1][j] = *reinterpret_cast<const bf16x8*>(wfrag[1] + wo + j * 2048);
 #pragma unroll
-      for (int i = 0; i < C::MI; ++i) fx[1][i] = *reinterpret_cast<const bf16x8*>(xfrag[1] + so + i * 2048);
+      for (int i = 0; i < C::MI; ++i) fx[1][i] = *reinterpret_cast<const bf16x8*>(xfrag[1] + xo + i * 2048);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
@@ -217,10 +231,13 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
 #pragma unroll
           for (int j = 0; j < C::NJ; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[kk][j], fx[kk][i], acc[j][i], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      par ^= 1;
+      xr = xr + 1 == XST ? 0 : xr + 1;
+      wr ^= 1;
     }
+    idx += J;
+    const bool has_next = idx < xcd_count;
 
-    // ---- epilogue: lane holds channels n = nb + 32t + (lane>>4)*8 + 0..7 of pixel m = mb + 16i + (lane&15)
+  // ---- epilogue: lane holds channels n = nb + 32t + (lane>>4)*8 + 0..7 of pixel m = mb + 16i + (lane&15)
   #pragma unroll
     for (int t = 0; t < C::NJ / 2; ++t) {
       const int n = n0c + wn * C::TN + t * 32 + fg * 8;
@@ -298,13 +315,13 @@ static int num_cus() {
   return n;
 }
 
-template <int BM, int BN, int WM, int WN, int MINB>
+template <int BM, int BN, int WM, int WN, int MINB, int XST>
 static void launch_g2(const ConvParams& p, hipStream_t s) {
-  using C = G2Cfg<BM, BN, WM, WN>;
+  using C = G2Cfg<BM, BN, WM, WN, XST>;
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
   static bool once = false;
   if (!once) {
-    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WM, WN, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + 8192));
+    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WM, WN, MINB, XST>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + (XST == 2 ? 8192 : 0)));
     once = true;
   }
   const size_t lds = C::LDS + (p.act == kActGelu ? 8192 : 0);
@@ -312,7 +329,7 @@ static void launch_g2(const ConvParams& p, hipStream_t s) {
   const int per_cu = std::max(1, std::min((int)(160 * 1024 / lds), 2048 / C::NT));
   const int cap = num_cus() * per_cu / 8 * 8;
   const int grid = std::min((tilesM * tilesN + 7) / 8 * 8, std::max(cap, 8));
-  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM, WN, MINB>), dim3(grid), dim3(C::NT), lds, s, p);
+  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM, WN, MINB, XST>), dim3(grid), dim3(C::NT), lds, s, p);
 }
 
 // Phi table of the GELU epilogue, one per device, built on first use (host erf in double)
@@ -337,6 +354,9 @@ const void* gelu_lut_for_current_device() {
   }
   return lut[dev];
 }
+
+static int g_x_ring3 = 1;
+void set_gemm2_x_ring3(int v) { g_x_ring3 = v; }
 
 const char* gemm2_check(const ConvParams& p) {
   const int Ctot = p.C0 + p.C1;
@@ -372,15 +392,20 @@ void launch_gemm2(const ConvParams& p_in, int cfg, hipStream_t s) {
         const double eff = (double)tiles / (double)(((tiles + 255) / 256) * 256);
         if (tiles >= 1024 || (tiles <= 256 && eff >= 0.74) || eff >= 0.85) cfg = 1;
       }
+      // plenty of 256x128 tiles: one per CU with the deeper X ring edges out two 128x128 per CU (fc2 +4 %, qkv +4 %)
+      if (cfg == 3 && g_x_ring3 && p.act != kActGelu && (int64_t)((p.M + 255) / 256) * ((p.Cout + 127) / 128) >= 512) cfg = 2;
     }
   }
+  // X ring depth: 3 (activation tiles two K steps ahead) wherever the LDS budget keeps the configuration's workgroups-per-CU;
+  // the GELU table (8 KiB) pushes the 256x256 and 128x128 tiles back to 2
+  const bool deep = g_x_ring3 && p.act != kActGelu;
   switch (cfg) {
-    case 1: return launch_g2<256, 256, 2, 4, 1>(p, s);
-    case 2: return launch_g2<256, 128, 4, 2, 1>(p, s);
-    case 3: return launch_g2<128, 128, 2, 2, 2>(p, s);
-    case 4: return launch_g2<256, 64, 4, 1, 2>(p, s);
-    case 5: return launch_g2<128, 64, 2, 2, 2>(p, s);
-    case 6: return launch_g2<128, 256, 2, 4, 1>(p, s);
+    case 1: return deep ? launch_g2<256, 256, 2, 4, 1, 3>(p, s) : launch_g2<256, 256, 2, 4, 1, 2>(p, s);
+    case 2: return deep ? launch_g2<256, 128, 4, 2, 1, 3>(p, s) : launch_g2<256, 128, 4, 2, 1, 2>(p, s);
+    case 3: return deep ? launch_g2<128, 128, 2, 2, 2, 3>(p, s) : launch_g2<128, 128, 2, 2, 2, 2>(p, s);
+    case 4: return launch_g2<256, 64, 4, 1, 2, 2>(p, s);
+    case 5: return launch_g2<128, 64, 2, 2, 2, 2>(p, s);
+    case 6: return deep ? launch_g2<128, 256, 2, 4, 1, 3>(p, s) : launch_g2<128, 256, 2, 4, 1, 2>(p, s);
     default: throw std::runtime_error("gemm2: unknown configuration");
   }
 }

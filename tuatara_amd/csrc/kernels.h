@@ -16,6 +16,7 @@ int gemm_config();
 // ---- gemm2.hip (bf16, LDS-DMA staged)
 const char* gemm2_check(const ConvParams& p);   // nullptr when gemm2 can run the problem
 void launch_gemm2(const ConvParams& p, int cfg, hipStream_t s);
+void set_gemm2_x_ring3(int v);   // 1 (default): activation tiles two K steps ahead where LDS allows; 0: one step (measurement)
 // device table float2[1024] {Phi(x_i), Phi(x_i + 1/64) - Phi(x_i)}, x_i = -8 + i/64, of the GELU epilogues (built on first use)
 const void* gelu_lut_for_current_device();
 // GELU by that table (g = the table, in LDS)
