@@ -347,10 +347,89 @@ __global__ __launch_bounds__(384) void dec_cross_attn_kernel(const T* __restrict
   }
 }
 
+// bf16 fast path: a K (or V) row of the crop's memory is 768 bytes = 48 lanes x 16 bytes, so one wave instruction fetches one
+// whole row (the kernel above reads 2 bytes per lane at a 1.5 KB stride).  4 waves x 32 keys each, online softmax per wave,
+// partial (max, sum, out) merged through LDS.  Lane c < 48 holds dims 8c..8c+7, head = c / 4.
+__global__ __launch_bounds__(256) void dec_cross_attn_rows_kernel(const bf16* __restrict__ q, const bf16* __restrict__ kvmem, bf16* __restrict__ out, int R) {
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  __shared__ float sm[4][48], sl[4][48], so[4][48][8];
+  const int row = blockIdx.x, n = row / R, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ln = lane < 48 ? lane : 47;
+  float qf[8];
+  {
+    const bf16x8 qb = *reinterpret_cast<const bf16x8*>(q + (int64_t)row * 384 + ln * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qf[e] = (float)qb[e];
+  }
+  const bf16* kv = kvmem + ((int64_t)n * 128 + wave * 32) * 768 + ln * 8;
+  float m = -INFINITY, l = 0.f, o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll 1
+  for (int c = 0; c < 2; ++c) {          // 2 chunks of 16 keys: 32 row loads in flight per wave
+    u32x4 kb[16], vb[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      kb[j] = *reinterpret_cast<const u32x4*>(kv + (int64_t)(c * 16 + j) * 768);
+      vb[j] = *reinterpret_cast<const u32x4*>(kv + (int64_t)(c * 16 + j) * 768 + 384);
+    }
+    float sc[16], cm = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const bf16x8 kk = *reinterpret_cast<const bf16x8*>(&kb[j]);
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d += qf[e] * (float)kk[e];
+      d += __shfl_xor(d, 1);
+      d += __shfl_xor(d, 2);
+      sc[j] = d * 0.17677669529663687f;
+      cm = fmaxf(cm, sc[j]);
+    }
+    const float mn = fmaxf(m, cm), scale = __expf(m - mn);
+    l *= scale;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] *= scale;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float pj = __expf(sc[j] - mn);
+      l += pj;
+      const bf16x8 vv = *reinterpret_cast<const bf16x8*>(&vb[j]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += pj * (float)vv[e];
+    }
+    m = mn;
+  }
+  if (lane < 48) {
+    sm[wave][lane] = m; sl[wave][lane] = l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) so[wave][lane][e] = o[e];
+  }
+  __syncthreads();
+  if (threadIdx.x < 48) {
+    const int c = threadIdx.x;
+    float mm = fmaxf(fmaxf(sm[0][c], sm[1][c]), fmaxf(sm[2][c], sm[3][c]));
+    float ll = 0.f, acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = __expf(sm[w][c] - mm);
+      ll += sl[w][c] * f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += so[w][c][e] * f;
+    }
+    const float inv = 1.0f / ll;
+    bf16x8 ob;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ob[e] = (bf16)(acc[e] * inv);
+    *reinterpret_cast<bf16x8*>(out + (int64_t)row * 384 + c * 8) = ob;
+  }
+}
+
 void launch_dec_cross_attn(Precision prec, const void* q, const void* kvmem, void* out, int N, int R, hipStream_t s) {
   if (N <= 0) return;
   dim3 grid(N * R);
-  if (prec == kBF16) hipLaunchKernelGGL(dec_cross_attn_kernel<bf16>, grid, dim3(384), 0, s, (const bf16*)q, (const bf16*)kvmem, (bf16*)out, R);
+  if (prec == kBF16) hipLaunchKernelGGL(dec_cross_attn_rows_kernel, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)kvmem, (bf16*)out, R);
   else hipLaunchKernelGGL(dec_cross_attn_kernel<float>, grid, dim3(384), 0, s, (const float*)q, (const float*)kvmem, (float*)out, R);
 }
 
