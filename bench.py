@@ -137,7 +137,7 @@ def main():
             e.lib.ttr_dev_sync(e.h)
 
     for e in engs:
-        e.set_profiling(True)
+        e.set_profiling(1)     # timed region: HIP events around the dominant kernels only (the CRAFT convolutions)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -153,6 +153,20 @@ def main():
         e.set_profiling(False)
     stage = eng.last_stage_ms()
     crops_per_page = float(np.mean([len(r) for r in res]))
+    # secondary rooflines (ViT / decoder GEMMs): two more steps with every launch bracketed by events, outside the timed
+    # region (1400 event records per step cost ~8 % of throughput, so they stay out of `value`)
+    for e in engs:
+        e.set_profiling(2)
+    for _ in range(2):
+        step()
+    fence()
+    for e in engs:
+        pe = e.get_profile()
+        for k in ("parseq", "parseq_ar"):
+            for f in prof[k]:
+                prof[k][f] += pe[k][f]
+        e.set_profiling(0)
+    SEC_STEPS = 2
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -200,10 +214,10 @@ def main():
                          "algorithmic_gflop_per_page": CRAFT_GFLOP_PER_PAGE},
             "roofline_parseq_gemm": {"kernel": "gemm2_kernel: the ViT encoder GEMMs (+ cross-attention K/V projection and the refinement pass)", "bound": "mfma", "achieved": pq_tflops, "peak": peak,
                                      "unit": "TFLOP/s", "frac": (pq_tflops / peak) if pq_tflops else None,
-                                     "launches_per_step": q["launches"] / max(1, args.steps)},
+                                     "launches_per_step": q["launches"] / SEC_STEPS, "measured": "2 extra steps after the timed region"},
             "roofline_parseq_ar_gemm": {"kernel": "gemm_sk_kernel: per-step autoregressive decoder linears (M = crops in flight; latency-bound)",
                                         "achieved": (prof["parseq_ar"]["flops"] / (prof["parseq_ar"]["ms"] * 1e-3) / 1e12) if prof["parseq_ar"]["ms"] else None,
-                                        "unit": "TFLOP/s", "launches_per_step": prof["parseq_ar"]["launches"] / max(1, args.steps)},
+                                        "unit": "TFLOP/s", "launches_per_step": prof["parseq_ar"]["launches"] / SEC_STEPS},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

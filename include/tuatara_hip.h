@@ -136,7 +136,8 @@ int ttr_dev_download(void* dst, const void* src, size_t bytes);
 int ttr_dev_sync(ttr_engine* e);
 /* last batch: milliseconds spent in each stage on the GPU stream (hipEvents): {craft, post, pack, parseq} */
 int ttr_last_stage_ms(ttr_engine* e, float ms[4]);
-/* per-launch HIP-event timing of the implicit-GEMM kernel, accumulated over calls while on:
+/* per-launch HIP-event timing of the conv / GEMM kernels, accumulated over calls while on (on = 1: the CRAFT convolution launches
+ * only, ~100 events per 32-page step; on = 2: every launch, ~1400 events, which costs ~8 % of throughput):
  * index 0 = CRAFT convolutions, 1 = PARSeq encoder (ViT) and batched decoder GEMMs, 2 = the per-step AR decoder GEMMs.  flops = algorithmic 2*M*N*K of the unpadded layers. */
 int ttr_set_profiling(ttr_engine* e, int on);
 int ttr_get_profile(ttr_engine* e, double ms[3], double flops[3], long long launches[3]);

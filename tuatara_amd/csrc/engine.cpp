@@ -183,7 +183,7 @@ struct Engine {
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   float stage_ms[4] = {0, 0, 0, 0};
   // optional per-launch timing of the igemm kernel (bench.py's roofline): events bracket every launch
-  bool profiling = false;
+  int profiling = 0;                                   // 0 off, 1 = CRAFT conv launches only, 2 = every conv / GEMM launch
   int prof_stage = 0;                                  // 0 = CRAFT convs, 1 = PARSeq encoder (ViT) + batched decoder GEMMs, 2 = per-step AR decoder GEMMs
   std::vector<hipEvent_t> prof_pool;
   struct ProfRec { int stage; double flops; };
@@ -192,7 +192,7 @@ struct Engine {
   long prof_launches[3] = {0, 0, 0};
 
   template <class F> void timed(double true_flops, F&& launch) {
-    if (!profiling) { launch(); return; }
+    if (!profiling || (profiling == 1 && prof_stage != 0)) { launch(); return; }
     const size_t i = prof_recs.size();
     while (prof_pool.size() < 2 * (i + 1)) { hipEvent_t e; TTR_HIP_CHECK(hipEventCreate(&e)); prof_pool.push_back(e); }
     TTR_HIP_CHECK(hipEventRecord(prof_pool[2 * i], stream));
@@ -1077,7 +1077,7 @@ int ttr_dev_sync(ttr_engine* e) { return hipStreamSynchronize(e->e->stream) == h
 int ttr_set_profiling(ttr_engine* e, int on) {
   Engine& E = *e->e;
   std::lock_guard<std::mutex> lk(E.mu);
-  E.profiling = on != 0;
+  E.profiling = on < 0 ? 0 : (on > 2 ? 2 : on);
   E.prof_recs.clear();
   for (int i = 0; i < 3; ++i) { E.prof_ms[i] = 0; E.prof_flops[i] = 0; E.prof_launches[i] = 0; }
   return 0;

@@ -261,8 +261,8 @@ void launch_igemm(Precision prec, const ConvParams& p, hipStream_t s) {
   if (prec == kBF16 && g_gemm_cfg >= 0) {
     if ((g_gemm_cfg == 0 || g_gemm_cfg >= 7) && p.M <= g_sk_max_rows && gemm_sk_check(p) == nullptr) return launch_gemm_sk(p, s);
     // 3x3 layers whose image tiles into 8x32 patches: the patch-stationary kernel moves 1.7-4x fewer bytes L2 -> LDS
-    // (measured +5..17 % over gemm2 on every such CRAFT layer with Cout >= 64; profiles/r01_gemm_sweep_v2.txt)
-    if ((g_gemm_cfg == 7 || (g_gemm_cfg == 0 && p.Cout >= 64)) && conv3p_check(p) == nullptr) return launch_conv3p(p, s);
+    // (measured +5..47 % over gemm2 on every such CRAFT layer; profiles/r01_gemm_sweep_v2.txt)
+    if ((g_gemm_cfg == 7 || (g_gemm_cfg == 0 && p.Cout >= 32)) && conv3p_check(p) == nullptr) return launch_conv3p(p, s);
     if (gemm2_check(p) == nullptr) return launch_gemm2(p, g_gemm_cfg >= 7 ? 0 : g_gemm_cfg, s);
   }
   if (p.out_pool) throw std::runtime_error("igemm: fused max-pool output is only available in the bf16 gemm2 kernel");

@@ -231,7 +231,8 @@ class Engine:
         self.lib.ttr_last_stage_ms(self.h, ms)
         return dict(craft=ms[0], post=ms[1], pack=ms[2], parseq=ms[3])
 
-    def set_profiling(self, on: bool):
+    def set_profiling(self, on):
+        """0 / False off, 1 / True CRAFT conv launches only, 2 every conv / GEMM launch."""
         self.lib.ttr_set_profiling(self.h, int(on))
 
     def get_profile(self):
