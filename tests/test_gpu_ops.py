@@ -175,3 +175,32 @@ def test_gemm_skinny(eng_bf16, case):
         eng_bf16.lib.ttr_set_tuning(b"sk_max_rows", 2048)
     assert np.abs(got - ref).max() < 2e-4
     assert np.abs(got - other).max() < 1e-4
+
+
+WS_CASES = [
+    # M, K, Cout, act   (linear layers, K <= 384: the ViT qkv / proj / fc1 and the batched decoder linears)
+    (700, 384, 1152, 0), (300, 384, 384, 0), (1500, 384, 1536, 2), (130, 384, 768, 0), (515, 128, 72, 1), (4100, 320, 264, 0),
+]
+
+
+@pytest.mark.parametrize("case", WS_CASES)
+def test_gemm_weight_stationary(eng_bf16, case):
+    """gemm_ws.hip (weights resident in registers, activations streamed) against fp32 torch and against gemm2."""
+    M, K, Cout, act = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    bf = lambda a: torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy()
+    x = bf(rng.standard_normal((1, 1, M, K)).astype(np.float32))
+    w = bf((rng.standard_normal((Cout, 1, 1, K)) / np.sqrt(K)).astype(np.float32))
+    b = rng.standard_normal(Cout).astype(np.float32)
+    ref = _ref_conv(x, w, b, 1, 1, act)
+    try:
+        eng_bf16.lib.ttr_set_tuning(b"sk_max_rows", 0)
+        eng_bf16.lib.ttr_set_tuning(b"ws_min_rows", 1)
+        got = eng_bf16.dbg_conv(x, w, b, 1, 1, act)
+        eng_bf16.lib.ttr_set_tuning(b"ws_min_rows", 0)
+        other = eng_bf16.dbg_conv(x, w, b, 1, 1, act)
+    finally:
+        eng_bf16.lib.ttr_set_tuning(b"sk_max_rows", 2048)
+        eng_bf16.lib.ttr_set_tuning(b"ws_min_rows", 8192)
+    assert np.abs(got - ref).max() < 2e-4
+    assert np.abs(got - other).max() < 1e-4

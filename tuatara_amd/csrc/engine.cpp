@@ -992,6 +992,7 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "c3_force_bn128") set_conv3p_force_bn128(value);
   else if (k == "c3_c64_waves") set_conv3p_c64_waves(value);
   else if (k == "sk_max_rows") set_skinny_max_rows(value);
+  else if (k == "ws_min_rows") set_gemm_ws_min_rows(value);
   else if (k == "dec_stamps") {   // value != 0: allocate the stamp buffer; read it back with ttr_dev_download via ttr_dbg_dec_stamps
     if (value && !g_dec_dbg) { void* d = nullptr; if (hipMalloc(&d, 26 * 16 * 8) != hipSuccess) return -1; (void)hipMemset(d, 0, 26 * 16 * 8); g_dec_dbg = (unsigned long long*)d; }
     if (!value) g_dec_dbg = nullptr;

@@ -252,6 +252,8 @@ const char* igemm_check(const ConvParams& p) {
 
 static int g_gemm_cfg = 0;
 static int g_sk_max_rows = 2048;
+static int g_ws_min_rows = 8192;
+void set_gemm_ws_min_rows(int m) { g_ws_min_rows = m; }
 void set_skinny_max_rows(int m) { g_sk_max_rows = m; }
 void set_gemm_config(int cfg) { g_gemm_cfg = cfg; }
 int gemm_config() { return g_gemm_cfg; }
@@ -260,6 +262,8 @@ void launch_igemm(Precision prec, const ConvParams& p, hipStream_t s) {
   if (const char* e = igemm_check(p)) throw std::runtime_error(e);
   if (prec == kBF16 && g_gemm_cfg >= 0) {
     if ((g_gemm_cfg == 0 || g_gemm_cfg >= 7) && p.M <= g_sk_max_rows && gemm_sk_check(p) == nullptr) return launch_gemm_sk(p, s);
+    if ((g_gemm_cfg == 0 || g_gemm_cfg >= 7) && g_ws_min_rows > 0 && p.M >= g_ws_min_rows && p.Cout >= 512 && gemm_ws_check(p) == nullptr)
+      return launch_gemm_ws(p, s);   // K <= 384, wide N: weights in registers (qkv +18 %, fc1 +13 % over gemm2; N = 384 is better off in gemm2)
     // 3x3 layers whose image tiles into 8x32 patches: the patch-stationary kernel moves 1.7-4x fewer bytes L2 -> LDS
     // (measured +5..47 % over gemm2 on every such CRAFT layer; profiles/r01_gemm_sweep_v2.txt)
     if ((g_gemm_cfg == 7 || (g_gemm_cfg == 0 && p.Cout >= 32)) && conv3p_check(p) == nullptr) return launch_conv3p(p, s);

@@ -24,6 +24,10 @@ const void* gelu_lut_for_current_device();
 const char* gemm_sk_check(const ConvParams& p);
 void launch_gemm_sk(const ConvParams& p, hipStream_t s);
 void set_skinny_max_rows(int m);   // problems with M <= m rows go to gemm_sk (0 = never)
+// ---- gemm_ws.hip (bf16 linear, K <= 384, weights resident in registers: the ViT encoder's qkv / proj / fc1)
+const char* gemm_ws_check(const ConvParams& p);
+void launch_gemm_ws(const ConvParams& p, hipStream_t s);
+void set_gemm_ws_min_rows(int m);   // linears with K <= 384 and at least this many rows use gemm_ws (0 = never)
 // ---- conv3s.hip (bf16, CRAFT's 32-channel head: 3x3 conv, optionally with the two 1x1 layers behind it fused)
 struct Conv3sParams {
   const bf16* in;        // [B][H][W][32]
