@@ -19,6 +19,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -626,7 +627,8 @@ struct Engine {
     }
     TTR_HIP_CHECK(hipStreamSynchronize(stream));
     det.assign(pages, std::vector<RRect>());
-    for (int pg = 0; pg < pages; ++pg) {
+    // the calipers of a page depend on nothing but that page: a few host threads share the batch while the GPU waits
+    parallel_pages(pages, [&](int pg) {
       const int n = counters[2 * pg];
       const int* cd = cand + off_c[pg];
       std::vector<int> order(n);
@@ -638,7 +640,22 @@ struct Engine {
         RRect r;
         if (component_to_rect(comp, H2, W2, &r)) det[pg].push_back(r);
       }
-    }
+    });
+  }
+  // run f(page) for every page on up to 8 host threads (the first exception is rethrown on the caller's thread)
+  template <class F> static void parallel_pages(int pages, F&& f) {
+    const int nthreads = std::min(pages, std::min(8, (int)std::max(1u, std::thread::hardware_concurrency())));
+    if (nthreads <= 1) { for (int pg = 0; pg < pages; ++pg) f(pg); return; }
+    std::exception_ptr err;
+    std::mutex emu;
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t)
+      th.emplace_back([&, t] {
+        try { for (int pg = t; pg < pages; pg += nthreads) f(pg); }
+        catch (...) { std::lock_guard<std::mutex> lk(emu); if (!err) err = std::current_exception(); }
+      });
+    for (auto& x : th) x.join();
+    if (err) std::rethrow_exception(err);
   }
 
   // ---- the hot path over a batch of same-sized device pages
