@@ -68,6 +68,10 @@ void ttr_result_free(ttr_result* r);
 const float* ttr_result_bboxes(const ttr_result* r);
 const int32_t* ttr_result_ids_all(const ttr_result* r);
 int ttr_result_texts(const ttr_result* r, char* buf, size_t cap);
+/* the same for a batch of results in one call (any output may be NULL): counts[n], bboxes[total][4], ids[total][26], texts as
+ * above ('\n' after each item, copied when texts_cap >= *texts_need).  Returns the total item count. */
+int ttr_results_gather(ttr_result* const* rs, int n, int32_t* counts, float* bboxes, int32_t* ids, char* texts, size_t texts_cap,
+                       size_t* texts_need);
 
 /* ---- stage-level entry points (BASELINE.json configs 2-3; used by the parity tests) -------- */
 /* CRAFT forward (tuatara.cpp:363-394): canvas u8 [H][W][3] (H,W multiples of 32, already resized,

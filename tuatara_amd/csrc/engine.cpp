@@ -609,23 +609,23 @@ struct Engine {
     int* counters = h_counters.as<int>();
     TTR_HIP_CHECK(hipMemcpyAsync(counters, ccl.counters.p, (size_t)pages * 8, hipMemcpyDeviceToHost, stream));
     TTR_HIP_CHECK(hipStreamSynchronize(stream));
-    size_t tot_c = 0, tot_r = 0;
-    std::vector<size_t> off_c(pages), off_r(pages);
+    // two strided copies bring every page's candidates and row extremes over (width = the busiest page's share)
+    int max_c = 0, max_r = 0;
     for (int pg = 0; pg < pages; ++pg) {
       if (counters[2 * pg] > cfg.max_components) throw std::runtime_error("too many text components on a page; raise ttr_config.max_components");
-      off_c[pg] = tot_c; off_r[pg] = tot_r;
-      tot_c += (size_t)counters[2 * pg] * 8; tot_r += (size_t)counters[2 * pg + 1] * 2;
+      max_c = std::max(max_c, counters[2 * pg]); max_r = std::max(max_r, counters[2 * pg + 1]);
     }
-    h_cand.ensure(tot_c * 4 + 4); h_rows.ensure(tot_r * 4 + 4);
+    const size_t pitch_c = (size_t)max_c * 32, pitch_r = (size_t)max_r * 8;
+    std::vector<size_t> off_c(pages), off_r(pages);
+    for (int pg = 0; pg < pages; ++pg) { off_c[pg] = pg * (pitch_c / 4); off_r[pg] = pg * (pitch_r / 4); }
+    h_cand.ensure(pitch_c * pages + 4); h_rows.ensure(pitch_r * pages + 4);
     int* cand = h_cand.as<int>();
     int* rw = h_rows.as<int>();
-    for (int pg = 0; pg < pages; ++pg) {
-      const int n = counters[2 * pg], rows = counters[2 * pg + 1];
-      if (n == 0) continue;
-      TTR_HIP_CHECK(hipMemcpyAsync(cand + off_c[pg], ccl.cand.as<int>() + (size_t)pg * ccl.max_cand * 8, (size_t)n * 32, hipMemcpyDeviceToHost, stream));
-      TTR_HIP_CHECK(hipMemcpyAsync(rw + off_r[pg], ccl.rows.as<int>() + (size_t)pg * ccl.npx * 2, (size_t)rows * 8, hipMemcpyDeviceToHost, stream));
+    if (max_c > 0) {
+      TTR_HIP_CHECK(hipMemcpy2DAsync(cand, pitch_c, ccl.cand.p, (size_t)ccl.max_cand * 32, pitch_c, pages, hipMemcpyDeviceToHost, stream));
+      TTR_HIP_CHECK(hipMemcpy2DAsync(rw, pitch_r, ccl.rows.p, (size_t)ccl.npx * 8, pitch_r, pages, hipMemcpyDeviceToHost, stream));
+      TTR_HIP_CHECK(hipStreamSynchronize(stream));
     }
-    TTR_HIP_CHECK(hipStreamSynchronize(stream));
     det.assign(pages, std::vector<RRect>());
     // the calipers of a page depend on nothing but that page: a few host threads share the batch while the GPU waits
     parallel_pages(pages, [&](int pg) {
@@ -814,6 +814,26 @@ const int32_t* ttr_result_ids(const ttr_result* r, int i) { return &r->r.ids[26 
 void ttr_result_free(ttr_result* r) { delete r; }
 const float* ttr_result_bboxes(const ttr_result* r) { return r && !r->r.bbox.empty() ? r->r.bbox.data() : nullptr; }
 const int32_t* ttr_result_ids_all(const ttr_result* r) { return r && !r->r.ids.empty() ? r->r.ids.data() : nullptr; }
+int ttr_results_gather(ttr_result* const* rs, int n, int32_t* counts, float* bboxes, int32_t* ids, char* texts, size_t texts_cap, size_t* texts_need) {
+  if (!rs || n < 0) return -1;
+  size_t total = 0, need = 0;
+  for (int i = 0; i < n; ++i) {
+    const size_t c = rs[i] ? rs[i]->r.text.size() : 0;
+    if (counts) counts[i] = (int32_t)c;
+    total += c;
+    if (rs[i]) for (const auto& t : rs[i]->r.text) need += t.size() + 1;
+  }
+  if (texts_need) *texts_need = need;
+  size_t ob = 0, oi = 0, ot = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!rs[i]) continue;
+    const Result& r = rs[i]->r;
+    if (bboxes && !r.bbox.empty()) { memcpy(bboxes + ob, r.bbox.data(), r.bbox.size() * 4); ob += r.bbox.size(); }
+    if (ids && !r.ids.empty()) { memcpy(ids + oi, r.ids.data(), r.ids.size() * 4); oi += r.ids.size(); }
+    if (texts && texts_cap >= need) for (const auto& t : r.text) { memcpy(texts + ot, t.data(), t.size()); ot += t.size(); texts[ot++] = '\n'; }
+  }
+  return (int)total;
+}
 int ttr_result_texts(const ttr_result* r, char* buf, size_t cap) {
   if (!r) return 0;
   size_t need = 0;

@@ -43,6 +43,7 @@ SYMBOLS = [
     ("ttr_result_bboxes", _PF, [_VP]),
     ("ttr_result_ids_all", _PI, [_VP]),
     ("ttr_result_texts", _I, [_VP, C.c_char_p, C.c_size_t]),
+    ("ttr_results_gather", _I, [C.POINTER(_VP), _I, _PI, _PF, _PI, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("ttr_craft_heatmap", _I, [_VP, _PU8, _I, _I, _PF]),
     ("ttr_ccl_boxes", _I, [_VP, _PF, _I, _I, _PF, _I, _PI]),
     ("ttr_resize_canvas", _I, [_VP, _PU8, _I, _I, _I, _PU8, C.c_size_t, _PI, _PI, _PF]),
@@ -204,6 +205,25 @@ class Engine:
         self.lib.ttr_result_free(r)
         return out
 
+    def _take_many(self, arr, n: int) -> List[List[dict]]:
+        """A batch of ttr_results -> list (per page) of lists of {"text", "bbox", "ids"}: one gather call for the whole batch."""
+        counts = np.zeros(n, np.int32)
+        need = C.c_size_t()
+        total = self.lib.ttr_results_gather(arr, n, _i(counts), None, None, None, 0, C.byref(need))
+        bb = np.zeros((max(total, 1), 4), np.float32)
+        ids = np.zeros((max(total, 1), 26), np.int32)
+        buf = C.create_string_buffer(max(need.value, 1))
+        self.lib.ttr_results_gather(arr, n, None, _f(bb), _i(ids), buf, need.value, None)
+        texts = buf.raw[:need.value].decode("latin1").split("\n")
+        bbl, idl = bb.tolist(), ids.tolist()
+        out, k = [], 0
+        for i in range(n):
+            c = int(counts[i])
+            out.append([{"text": texts[j], "bbox": bbl[j], "ids": idl[j]} for j in range(k, k + c)])
+            k += c
+            self.lib.ttr_result_free(arr[i])
+        return out
+
     # ---- hot path
     def image_to_data(self, image: np.ndarray) -> List[dict]:
         if image.ndim != 3:
@@ -219,7 +239,7 @@ class Engine:
         arr = (C.c_void_p * n)()
         self._check(self.lib.ttr_pages_to_data_dev(self.h, ptr, n, h, w, arr))
         if keep:
-            return [self._take(arr[i]) for i in range(n)]
+            return self._take_many(arr, n)
         counts = []
         for i in range(n):
             counts.append(self.lib.ttr_result_count(arr[i]))
