@@ -86,6 +86,8 @@ G2_CASES = [
     (1, 16, 64, 64, 0, 64, 3, 1, 1),        # conv3p-eligible (H % 8, W % 32): image-border halos on every side
     (2, 8, 32, 128, 0, 136, 3, 1, 0),       # one patch per image, two channel chunks, ragged Cout
     (1, 24, 96, 64, 0, 256, 3, 1, 1),       # 3 x 3 patches, BN 256
+    (1, 16, 48, 64, 0, 64, 3, 1, 1),        # width not a multiple of 32: conv3p's 16 x 16 patches (CRAFT's 64 x 48 level)
+    (2, 32, 16, 128, 0, 136, 3, 1, 0),      # 16 x 16 patches, two images, two channel chunks, ragged Cout
 ]
 
 
@@ -126,7 +128,8 @@ def test_gemm2_matches_first_generation_kernel(eng_bf16):
 
 @pytest.mark.parametrize("cfg", [0, 1, 3, 5, 7])
 @pytest.mark.parametrize("case", [(1, 12, 40, 64, 64, 1, False), (2, 6, 10, 128, 136, 0, True), (1, 18, 14, 64, 256, 1, False),
-                                  (1, 16, 64, 64, 64, 1, False), (2, 8, 32, 128, 136, 0, True), (1, 24, 96, 64, 256, 1, False)])
+                                  (1, 16, 64, 64, 64, 1, False), (2, 8, 32, 128, 136, 0, True), (1, 24, 96, 64, 256, 1, False),
+                                  (1, 16, 48, 64, 64, 1, False), (2, 32, 16, 128, 136, 0, True)])
 def test_gemm2_fused_maxpool(eng_bf16, case, cfg):
     """CRAFT's trunk pools: the 2x2 max-pool fused into the conv epilogue equals pooling the conv's own bf16 output
     bit for bit (max commutes with rounding), and that output matches the fp32 reference."""

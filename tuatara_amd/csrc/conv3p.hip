@@ -20,17 +20,21 @@ namespace ttr {
 namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
-constexpr int PH = 8, PW = 32, HW2 = PW + 2;          // patch, halo row length
-constexpr int XSLOTS = 344;                           // (PH+2)*(PW+2) = 340 pixel slots, padded to 43 pieces of 8
-constexpr int XPIECES = XSLOTS / 8;
-constexpr int XSTAGE = XSLOTS * 128;
+// Patch geometry: 256 output pixels as 8 x 32 (LPW = 5) or, for maps whose width is not a multiple of 32 (CRAFT's 64 x 48
+// level), 16 x 16 (LPW = 4).  Halo patch (PH+2) x (PW+2) pixel slots of 128 B, padded to whole 1-KiB pieces of 8 slots.
+template <int LPW> struct Geo {
+  static constexpr int PW = 1 << LPW, PH = 256 / PW, HW2 = PW + 2, NHALO = (PH + 2) * HW2;
+  static constexpr int XSLOTS = (NHALO + 7) / 8 * 8, XPIECES = XSLOTS / 8, XSTAGE = XSLOTS * 128;
+};
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
-template <int BN, int WM, int WN>
+template <int BN, int WM, int WN, int LPW = 5>
 struct C3 {
+  using G = Geo<LPW>;
+  static constexpr int XPIECES = G::XPIECES, XSTAGE = G::XSTAGE;
   static constexpr int NW = WM * WN, NT = NW * 64;
   static constexpr int TM = 256 / WM, TN = BN / WN, MI = TM / 16, NJ = TN / 16;
   static constexpr int XPW = (XPIECES + NW - 1) / NW;   // X pieces per wave (last ones may be past the end)
@@ -46,9 +50,12 @@ struct C3 {
 // halo patch is computed in the prologue: conv1_1 (3 -> 64, 3x3, ReLU; weights p.pre_wgt [64][32] with k = (ky*3+kx)*3+c as
 // in conv1_direct_kernel, bias p.pre_bias) evaluated on the 10 x 34 halo pixels and written straight into the LDS patch.
 // That removes CRAFT's largest tensor (100 MB per page written and read back) and the conv1_1 launch.
-template <int BN, int WM, int WN, bool FIRST, int XS>   // XS: patch stages (1 when Cin = 64: a single chunk, and two workgroups fit a CU)
+template <int BN, int WM, int WN, bool FIRST, int XS, int LPW>   // XS: patch stages (1 when Cin = 64: a single chunk, and two workgroups fit a CU)
 __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM * WN == 4 ? 1 : 1)) void conv3p_kernel(ConvParams p) {
-  using C = C3<BN, WM, WN>;
+  using C = C3<BN, WM, WN, LPW>;
+  using G = Geo<LPW>;
+  constexpr int PH = G::PH, PW = G::PW, HW2 = G::HW2, XSLOTS = G::XSLOTS, XPIECES = G::XPIECES, XSTAGE = G::XSTAGE, NHALO = G::NHALO;
+  static_assert(!FIRST || LPW == 5, "the fused first layer uses 8 x 32 patches");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* const xs = smem;                 // [2][XSLOTS][128 B]  slot pi = pr*34 + pc, chunk c holds channels 8*(c ^ (pi&7))..
   unsigned char* const ws = smem + XS * XSTAGE;   // [2][BN][128 B]      as in gemm2.hip
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
     const int pr = pi / HW2, pc = pi - pr * HW2;
     const int y = y0 - 1 + pr, x = x0 - 1 + pc;
     const int g = (lane & 7) ^ (pi & 7);
-    const bool ok = pi < (PH + 2) * HW2 && y >= 0 && y < p.H && x >= 0 && x < p.W;
+    const bool ok = pi < NHALO && y >= 0 && y < p.H && x >= 0 && x < p.W;
     xo[i] = ok ? (unsigned)((((b * p.H + y) * p.W + x) * Cin + g * 8) * 2) : OOB;
   }
   unsigned wb[C::WPW];
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
 #pragma unroll
   for (int i = 0; i < C::MI; ++i) {
     const int r = wm * C::TM + i * 16 + fr;
-    pi0[i] = (r >> 5) * HW2 + (r & 31);
+    pi0[i] = (r >> LPW) * HW2 + (r & (PW - 1));
   }
   const int wfl = (lane & 15) * 128 + (((lane >> 4) ^ ((lane >> 1) & 7)) << 4) + wn * C::TN * 128;
 
@@ -173,11 +180,11 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
       const int pi = mt * 16 + fr;
       const int pr = pi / HW2, pc = pi - pr * HW2;
       const int y = y0 - 1 + pr, x = x0 - 1 + pc;
-      const bool inside = pi < (PH + 2) * HW2 && y >= 0 && y < p.H && x >= 0 && x < p.W;
+      const bool inside = pi < NHALO && y >= 0 && y < p.H && x >= 0 && x < p.W;
       const unsigned char* base = cv + pr * 108 + pc * 3;   // canvas pixel (y-1, x-1)
       bf16x8 fx;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) fx[e] = (koff[e] >= 0 && pi < (PH + 2) * HW2) ? lut[base[koff[e]]] : (bf16)0.f;
+      for (int e = 0; e < 8; ++e) fx[e] = (koff[e] >= 0 && pi < NHALO) ? lut[base[koff[e]]] : (bf16)0.f;
       f32x4 a1[4];
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) a1[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1[jj], fx, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
 #pragma unroll
     for (int i = 0; i < C::MI; ++i) {
       const int r = wm * C::TM + i * 16 + fr;
-      const int y = y0 + (r >> 5), x = x0 + (r & 31);
+      const int y = y0 + (r >> LPW), x = x0 + (r & (PW - 1));
       const int64_t m = ((int64_t)b * p.H + y) * p.W + x;
       float v[8];
 #pragma unroll
@@ -300,12 +307,13 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
     if (p.out_pool) {
 #pragma unroll
       for (int i = 0; i < C::MI; ++i) {
-        if ((i & 2) == 0) {                            // patch row py = 2k: partner row py + 1 is i + 2
+        constexpr int PD = PW / 16;                    // m-tiles per patch row: the pixel below is PD tiles further
+        if ((i & PD) == 0) {                           // even patch row: partner row is tile i + PD
           const int r = wm * C::TM + i * 16 + fr;
-          const int yo = (y0 + (r >> 5)) >> 1, xo2 = (x0 + (r & 31)) >> 1;
+          const int yo = (y0 + (r >> LPW)) >> 1, xo2 = (x0 + (r & (PW - 1))) >> 1;
           bf16x8 o;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = (bf16)fmaxf(pooled[i][e], pooled[i + 2][e]);
+          for (int e = 0; e < 8; ++e) o[e] = (bf16)fmaxf(pooled[i][e], pooled[i + PD][e]);
           if ((fr & 1) == 0)
             *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out_pool) + (((int64_t)b * (p.H >> 1) + yo) * (p.W >> 1) + xo2) * p.out_ld + n) = o;
         }
@@ -314,17 +322,18 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
   }
 }
 
-template <int BN, int WM, int WN, bool FIRST = false, int XS = 2>
+template <int BN, int WM, int WN, bool FIRST = false, int XS = 2, int LPW = 5>
 static void launch_c3(const ConvParams& p, hipStream_t s) {
-  using C = C3<BN, WM, WN>;
-  const int tilesM = p.B * (p.H / PH) * (p.W / PW), tilesN = (p.Cout + BN - 1) / BN;
-  constexpr int lds = XS * XSTAGE + 2 * C::WSTAGE + (FIRST ? 2048 : 0);
+  using C = C3<BN, WM, WN, LPW>;
+  using G = Geo<LPW>;
+  const int tilesM = p.B * (p.H / G::PH) * (p.W / G::PW), tilesN = (p.Cout + BN - 1) / BN;
+  constexpr int lds = XS * G::XSTAGE + 2 * C::WSTAGE + (FIRST ? 2048 : 0);
   static bool once = false;
   if (!once) {
-    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_kernel<BN, WM, WN, FIRST, XS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_kernel<BN, WM, WN, FIRST, XS, LPW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     once = true;
   }
-  hipLaunchKernelGGL((conv3p_kernel<BN, WM, WN, FIRST, XS>), dim3(tilesM * tilesN), dim3(C::NT), lds, s, p);
+  hipLaunchKernelGGL((conv3p_kernel<BN, WM, WN, FIRST, XS, LPW>), dim3(tilesM * tilesN), dim3(C::NT), lds, s, p);
 }
 
 static int g_c64_waves = 8;        // Cout <= 64 tiles: 8 waves (wave tile 64x32) or 4 waves (wave tile 64x64, fewer LDS fragment reads per MFMA)
@@ -339,7 +348,7 @@ const char* conv3p_check(const ConvParams& p) {
   if (p.ks != 3 || p.dil != 1) return "conv3p: 3x3, dilation 1 only";
   if (p.C1 || p.relu0 || p.relu1) return "conv3p: single source, no ReLU on load";
   if (p.C0 % 64 || p.Cout % 8) return "conv3p: Cin % 64, Cout % 8";
-  if (p.H % PH || p.W % PW) return "conv3p: H % 8, W % 32";
+  if (!((p.H % 8 == 0 && p.W % 32 == 0) || (p.H % 16 == 0 && p.W % 16 == 0))) return "conv3p: the map must tile into 8x32 or 16x16 patches";
   if (p.resid || p.out_f32 || p.act == kActGelu) return "conv3p: conv epilogues only";
   if (p.out && (p.out_ld % 8 || ((uintptr_t)p.out & 15))) return "conv3p: output alignment";
   if (p.out_relu && (!p.out || ((uintptr_t)p.out_relu & 15))) return "conv3p: out_relu alignment";
@@ -359,10 +368,13 @@ void launch_conv3p(const ConvParams& p, hipStream_t s) {
     if (p.C0 != 64 || p.Cout > 64 || !p.pre_bias) throw std::runtime_error("conv3p: the fused first layer needs Cin = 64, Cout <= 64");
     return launch_c3<64, 4, 2, true, 1>(p, s);
   }
+  const bool wide = p.H % 8 == 0 && p.W % 32 == 0;   // 8 x 32 patches; else 16 x 16 (checked above)
   if (p.Cout <= 64) {
+    if (!wide) return launch_c3<64, 4, 2, false, 1, 4>(p, s);
     if (g_c64_waves == 4) return launch_c3<64, 4, 1, false, 1>(p, s);
     return p.C0 <= g_xs1_max_cin ? launch_c3<64, 4, 2, false, 1>(p, s) : launch_c3<64, 4, 2>(p, s);
   }
+  if (!wide) return launch_c3<128, 4, 2, false, 1, 4>(p, s);
   if (p.Cout <= 128 || p.Cout % 256 || g_force_bn128) return p.C0 <= g_xs1_max_cin ? launch_c3<128, 4, 2, false, 1>(p, s) : launch_c3<128, 4, 2>(p, s);
   return launch_c3<256, 2, 4>(p, s);
 }
