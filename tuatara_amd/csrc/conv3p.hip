@@ -12,6 +12,8 @@
 // Same ConvParams contract, same transposed-MFMA / 16-byte-store epilogue (bias, ReLU, optional
 // ReLU copy, optional fused 2x2 max-pool) as gemm2.hip; replaces LibTorch's conv2d inside the CRAFT
 // TorchScript module run at tuatara.cpp:376.
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
       const unsigned char* base = cv + pr * 108 + pc * 3;   // canvas pixel (y-1, x-1)
       bf16x8 fx;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) fx[e] = (koff[e] >= 0 && pi < NHALO) ? lut[base[koff[e]]] : (bf16)0.f;
+      for (int e = 0; e < 8; ++e) fx[e] = (koff[e] >= 0 && pi < NHALO) ? (bf16)((float)base[koff[e]] * 0.00392156862745098f)   /* == bf16(v / 255.0f) for all 256 byte values */ : (bf16)0.f;
       f32x4 a1[4];
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) a1[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1[jj], fx, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -322,6 +324,241 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// CRAFT's first two convolutions as one PERSISTENT kernel (conv1_1 3->64 + ReLU, conv1_2 64->64 + ReLU, optional 2x2 max
+// pool): the FIRST variant above spends 9 barriers and 72 KB of weight staging on every 8x32 patch.  Here all nine taps of
+// conv1_2's weights (72 KB) are staged into LDS once per workgroup and stay; a workgroup walks patches with stride gridDim.
+// Per patch a wave has two independent jobs: the 144 MFMAs of conv1_2 on patch p (LDS -> matrix pipe) and conv1_1 on the
+// 10x34 halo of patch p+1 into the other patch buffer (byte gathers, VALU, LDS writes).  Waves 0-3 run them in that order,
+// waves 4-7 in the opposite order: the two waves that share a SIMD (w and w+4) then occupy complementary pipes instead of
+// queueing for the same one (measured per patch before: 6.0k cycles of prologue + 4.2k of MFMA, all waves in lock step).
+__global__ __launch_bounds__(512) void conv3p_first2_kernel(ConvParams p) {
+  using G = Geo<5>;
+  constexpr int PH = G::PH, PW = G::PW, HW2 = G::HW2, NHALO = G::NHALO;
+  constexpr int XB = NHALO * 128;                       // one patch buffer (340 slots, no padding: 2 buffers + weights = 160 KB)
+  constexpr int NW = 8, TM = 64, MI = 4;                // 8 waves as 4 (pixels) x 2 (channels): wave tile 64 px x 32 ch
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  unsigned char* const wsm = smem;                      // [9 taps][64 rows][128 B]   conv1_2 weights, gemm2 row/chunk permutation
+  unsigned char* const xs = smem + 9 * 8192;            // [2][340][128 B]            conv1_1 output on the halo patch
+  unsigned char* const cv = xs + 2 * XB;                // [12][108] canvas bytes of the patch whose conv1_1 runs next
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int ptx = p.W / PW, pty = p.H / PH, npatch = p.B * pty * ptx;
+
+  // ---- resident conv1_2 weights: tap t tile = rows n (permuted as in gemm2) x 64 k; 8 pieces of 1 KiB per tap, one per wave
+  {
+    const __amdgpu_buffer_rsrc_t rsw = mk_rsrc(p.wgt, (unsigned)((size_t)p.Cout * 576 * 2));
+    const int row = wave * 8 + (lane >> 3);
+    const int g = (lane & 7) ^ ((row >> 1) & 7);
+    const int q16 = row & 15;
+    const int n = (row & ~31) + (q16 >> 2) * 8 + ((row >> 4) & 1) * 4 + (q16 & 3);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const unsigned vo = n < p.Cout ? (unsigned)((n * 576 + t * 64 + g * 8) * 2) : 0x80000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(wsm + t * 8192 + wave * 1024), 16, vo, 0, 0, 0);
+    }
+  }
+  // conv1_1 operands (registers, for the whole launch)
+  bf16x8 f1[4];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int n = 32 * (jj >> 1) + (fr >> 2) * 8 + (jj & 1) * 4 + (fr & 3);
+    f1[jj] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.pre_wgt) + n * 32 + fg * 8);
+  }
+  float b1[2][8];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b1[t][e] = p.pre_bias[32 * t + fg * 8 + e];
+  int koff[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = fg * 8 + e, tp = k / 3;
+    koff[e] = k < 27 ? (tp / 3) * 108 + (tp % 3) * 3 + (k - tp * 3) : 0;   // k >= 27 multiplies a zero weight column: any byte will do
+  }
+  // the (up to) three halo m-tiles of this wave: slot, canvas offset and halo coordinates do not depend on the patch
+  int h_pi[3], h_off[3], h_pr[3], h_pc[3];
+#pragma unroll
+  for (int t3 = 0; t3 < 3; ++t3) {
+    const int pi = (wave + NW * t3) * 16 + fr;
+    h_pi[t3] = pi; h_pr[t3] = pi / HW2; h_pc[t3] = pi - h_pr[t3] * HW2;
+    h_off[t3] = pi < NHALO ? h_pr[t3] * 108 + h_pc[t3] * 3 : 0;
+  }
+  float bv[8];                                           // conv1_2 bias of this lane's 8 channels
+  {
+    const int n = wn * 32 + fg * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = (p.bias && n + e < p.Cout) ? p.bias[n + e] : 0.f;
+  }
+  int pi0[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) { const int r = wm * TM + i * 16 + fr; pi0[i] = (r >> 5) * HW2 + (r & 31); }
+  const int wfl = (lane & 15) * 128 + (((lane >> 4) ^ ((lane >> 1) & 7)) << 4) + wn * 32 * 128;
+
+  const uint8_t* canvas = reinterpret_cast<const uint8_t*>(p.in0);
+  auto patch_origin = [&](int patch, int& b, int& y0, int& x0) {
+    b = patch / (pty * ptx);
+    const int trem = patch - b * pty * ptx, ty = trem / ptx;
+    y0 = ty * PH; x0 = (trem - ty * ptx) * PW;
+  };
+  // canvas bytes: thread tid owns bytes tid, tid+512, tid+1024 of the 12 x 108 byte patch around the halo
+  auto canvas_byte = [&](int patch, int q) -> uint8_t {
+    int b, y0, x0;
+    patch_origin(patch, b, y0, x0);
+    const int rr = q / 108, cc = q - rr * 108, px = cc / 3;
+    const int y = y0 - 2 + rr, x = x0 - 2 + px;
+    return (q < 12 * 108 && y >= 0 && y < p.H && x >= 0 && x < p.W) ? canvas[(((int64_t)b * p.H + y) * p.W + x) * 3 + (cc - px * 3)] : (uint8_t)0;
+  };
+  // conv1_1 (+ bias, ReLU; zero outside the image = conv1_2's padding) on the halo of `patch` from cv into patch buffer xb
+  auto prologue = [&](int patch, unsigned char* xb) {
+    int b, y0, x0;
+    patch_origin(patch, b, y0, x0);
+#pragma unroll
+    for (int t3 = 0; t3 < 3; ++t3) {
+      if ((wave + NW * t3) * 16 < NHALO) {               // wave-uniform
+        const int pi = h_pi[t3];
+        const int y = y0 - 1 + h_pr[t3], x = x0 - 1 + h_pc[t3];
+        const bool inside = pi < NHALO && y >= 0 && y < p.H && x >= 0 && x < p.W;
+        const unsigned char* base = cv + h_off[t3];
+        bf16x8 fx;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fx[e] = (bf16)((float)base[koff[e]] * 0.00392156862745098f);   // == bf16(v / 255.0f) for every byte value
+        f32x4 a1[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) a1[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1[jj], fx, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[e] = inside ? (bf16)fmaxf(a1[2 * t][e] + b1[t][e], 0.f) : (bf16)0.f;
+            o[4 + e] = inside ? (bf16)fmaxf(a1[2 * t + 1][e] + b1[t][4 + e], 0.f) : (bf16)0.f;
+          }
+          if (pi < NHALO) *reinterpret_cast<bf16x8*>(xb + pi * 128 + (((4 * t + fg) ^ (pi & 7)) << 4)) = o;
+        }
+      }
+    }
+  };
+
+  int patch = blockIdx.x;
+  uint8_t cb[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) cb[k] = patch < npatch ? canvas_byte(patch, tid + 512 * k) : (uint8_t)0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) if (tid + 512 * k < 12 * 108) cv[tid + 512 * k] = cb[k];
+  __syncthreads();
+  if (patch < npatch) prologue(patch, xs);
+  if (patch + (int)gridDim.x < npatch) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cb[k] = canvas_byte(patch + gridDim.x, tid + 512 * k);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the resident weights have landed
+
+  for (int it = 0; patch < npatch; patch += gridDim.x, ++it) {
+    int b, y0, x0;
+    patch_origin(patch, b, y0, x0);
+    const int nextp = patch + gridDim.x;
+    const unsigned char* xcur = xs + (it & 1) * XB;
+    unsigned char* xnext = xs + ((it + 1) & 1) * XB;
+    __syncthreads();                                     // A: everyone finished the previous iteration (its cv and patch-buffer reads)
+    if (nextp < npatch) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) if (tid + 512 * k < 12 * 108) cv[tid + 512 * k] = cb[k];
+      if (nextp + (int)gridDim.x < npatch) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) cb[k] = canvas_byte(nextp + gridDim.x, tid + 512 * k);   // in flight for a whole iteration
+      }
+    }
+    __syncthreads();                                     // B: cv (patch p+1) and the patch buffer of p are complete
+
+    f32x4 acc[2][MI];
+    auto mfma_phase = [&]() {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int tapoff = (t / 3) * HW2 + (t % 3);
+        int xa[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) { const int pi = pi0[i] + tapoff; xa[i] = pi * 128 + ((fg ^ (pi & 7)) << 4); }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          bf16x8 fw[2], fx[MI];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(wsm + t * 8192 + (wfl ^ (kk * 64)) + j * 2048);
+#pragma unroll
+          for (int i = 0; i < MI; ++i) fx[i] = *reinterpret_cast<const bf16x8*>(xcur + (xa[i] ^ (kk * 64)));
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fx[i], acc[j][i], 0, 0, 0);
+        }
+      }
+    };
+    if (wave < 4) {
+      mfma_phase();
+      if (nextp < npatch) prologue(nextp, xnext);
+    } else {
+      if (nextp < npatch) prologue(nextp, xnext);
+      mfma_phase();
+    }
+    // ---- epilogue: lane holds channels n..n+7 of patch pixel (py, px) for every i; tile i + 2 is the pixel below
+    const int n = wn * 32 + fg * 8;
+    if (n < p.Cout) {
+      float pooled[MI][8];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int r = wm * TM + i * 16 + fr;
+        const int64_t m = ((int64_t)b * p.H + y0 + (r >> 5)) * p.W + x0 + (r & 31);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = fmaxf(acc[0][i][e] + bv[e], 0.f); v[4 + e] = fmaxf(acc[1][i][e] + bv[4 + e], 0.f); }
+        if (p.out) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out) + m * p.out_ld + n) = o;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pooled[i][e] = fmaxf(v[e], __shfl_xor(v[e], 1));
+      }
+      if (p.out_pool) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          if ((i & 2) == 0) {
+            const int r = wm * TM + i * 16 + fr;
+            const int yo = (y0 + (r >> 5)) >> 1, xo2 = (x0 + (r & 31)) >> 1;
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)fmaxf(pooled[i][e], pooled[i + 2][e]);
+            if ((fr & 1) == 0)
+              *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out_pool) + (((int64_t)b * (p.H >> 1) + yo) * (p.W >> 1) + xo2) * p.out_ld + n) = o;
+          }
+        }
+      }
+    }
+  }
+}
+
+static void launch_first2(const ConvParams& p, hipStream_t s) {
+  using G = Geo<5>;
+  constexpr int lds = 9 * 8192 + 2 * G::NHALO * 128 + 1408;   // 162,176 B of the 163,840
+  static bool once = false;
+  if (!once) {
+    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_first2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    once = true;
+  }
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  const int npatch = p.B * (p.H / G::PH) * (p.W / G::PW);
+  hipLaunchKernelGGL(conv3p_first2_kernel, dim3(std::min(npatch, cus)), dim3(512), lds, s, p);
+}
+
 template <int BN, int WM, int WN, bool FIRST = false, int XS = 2, int LPW = 5>
 static void launch_c3(const ConvParams& p, hipStream_t s) {
   using C = C3<BN, WM, WN, LPW>;
@@ -336,6 +573,8 @@ static void launch_c3(const ConvParams& p, hipStream_t s) {
   hipLaunchKernelGGL((conv3p_kernel<BN, WM, WN, FIRST, XS, LPW>), dim3(tilesM * tilesN), dim3(C::NT), lds, s, p);
 }
 
+static int g_first_persistent = 1;   // fused conv1_1 + conv1_2: persistent weight-resident kernel (0: per-patch FIRST variant)
+void set_conv3p_first_persistent(int v) { g_first_persistent = v; }
 static int g_c64_waves = 8;        // Cout <= 64 tiles: 8 waves (wave tile 64x32) or 4 waves (wave tile 64x64, fewer LDS fragment reads per MFMA)
 void set_conv3p_c64_waves(int w) { g_c64_waves = w; }
 static int g_force_bn128 = 1;     // BN = 128 single-stage tiles, two workgroups per CU, for every Cout > 64 (0: BN = 256, one per CU, for Cout % 256 == 0):
@@ -366,6 +605,7 @@ void launch_conv3p(const ConvParams& p, hipStream_t s) {
   if (const char* e = conv3p_check(p)) throw std::runtime_error(e);
   if (p.pre_wgt) {
     if (p.C0 != 64 || p.Cout > 64 || !p.pre_bias) throw std::runtime_error("conv3p: the fused first layer needs Cin = 64, Cout <= 64");
+    if (g_first_persistent && p.act == kActRelu && !p.out_relu && p.H % 8 == 0 && p.W % 32 == 0) return launch_first2(p, s);
     return launch_c3<64, 4, 2, true, 1>(p, s);
   }
   const bool wide = p.H % 8 == 0 && p.W % 32 == 0;   // 8 x 32 patches; else 16 x 16 (checked above)

@@ -47,6 +47,7 @@ void launch_conv3p(const ConvParams& p, hipStream_t s);
 void set_conv3p_single_stage_max_cin(int c);
 void set_conv3p_force_bn128(int v);
 void set_conv3p_c64_waves(int w);
+void set_conv3p_first_persistent(int v);
 // n pseudo-random values, uniform in [-scale, scale) (benchmark inputs)
 void launch_fill_random(Precision prec, void* p, size_t n, unsigned seed, float scale, hipStream_t s);
 
