@@ -29,6 +29,8 @@ struct ConvParams {
   const float* resid; int resid_ld; int resid_mod;  // f32 residual added before act; row = m % resid_mod if resid_mod
   int Cout, M, act;
   const void* pre_wgt; const float* pre_bias;   // conv3p only: fuse CRAFT's conv1_1 in front (in0 = u8 canvas [B][H][W][3], pre_wgt = T [64][32])
+  // gemm_sk only: take the activation rows from LayerNorm(ln_in) instead of in0 (f32 [M][384] rows, stride ln_ld)
+  const float* ln_in; int ln_ld; const float* ln_gamma; const float* ln_beta; float ln_eps;
   const void* gelu_lut;      // set by launch_gemm2: float2 [1024] = {Phi(x_i), Phi(x_i+1) - Phi(x_i)}, x_i = -8 + i/64
 };
 

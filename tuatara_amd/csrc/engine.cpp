@@ -39,6 +39,7 @@ void hip_fail(const char* what, hipError_t e, const char* file, int line) {
 
 static thread_local std::string g_last_error;
 static unsigned long long* g_dec_dbg = nullptr;   // device buffer for dec_ar phase stamps (diagnostics)
+static int g_ln_fuse = 1;          // bf16 decoder steps: LayerNorm computed inside the skinny GEMM's loader (gemm_sk ln_in)
 static int g_fuse_first = 1;       // bf16: CRAFT conv1_1 fused into conv1_2's loader (conv3p FIRST)
 static int g_enc_chunk = 0;        // crops per encoder group (0 = all crops at once)
 static int g_decoder_mode = 1;   // 0 = kernel-per-op AR loop, 4/8/16 = fused kernel with that many crops per workgroup, else automatic
@@ -472,6 +473,23 @@ struct Engine {
   }
 
   // ---- PARSeq
+  // out = L(LayerNorm(x)) for the decoder's per-step rows: the skinny GEMM normalises its own activation rows (bf16, few rows);
+  // otherwise the LayerNorm kernel writes `scratch` and the plain GEMM follows
+  void ln_gemm(const float* x, const std::string& ln_name, float eps, void* scratch, const Linear& L, int M, void* out, int out_ld, int act,
+               float* out_f32 = nullptr, int out_f32_ld = 0) {
+    if (g_ln_fuse && prec == kBF16 && L.k == 384 && M <= skinny_max_rows()) {
+      ConvParams p{};
+      p.ln_in = x; p.ln_ld = 384; p.ln_gamma = pqf.at(ln_name + ".weight").as<float>(); p.ln_beta = pqf.at(ln_name + ".bias").as<float>(); p.ln_eps = eps;
+      p.C0 = L.k; p.B = 1; p.H = 1; p.W = M; p.ks = 1; p.dil = 1;
+      p.wgt = L.w.p; p.bias = L.b.as<float>();
+      p.out = out; p.out_ld = out_ld; p.out_f32 = out_f32; p.out_f32_ld = out_f32_ld;
+      p.Cout = L.cout; p.M = M; p.act = act;
+      igemm(p, 2.0 * M * L.cout * L.k);
+      return;
+    }
+    ln(x, ln_name, eps, scratch, M);
+    gemm(L, scratch, M, out, out_ld, act, out_f32, out_f32_ld);
+  }
   void gemm(const Linear& L, const void* in, int M, void* out, int out_ld, int act, float* out_f32 = nullptr, int out_f32_ld = 0,
             const float* resid = nullptr, int resid_ld = 0, int resid_mod = 0) {
     ConvParams p{};
@@ -493,15 +511,12 @@ struct Engine {
     const int rows = N * R;
     const std::string d = "decoder.layers.0.";
     gemm(pq.at("self_out"), sa, rows, nullptr, 0, kActNone, tgt, 384, resid_pos, 384, resid_mod);      // tgt = query + self_attn
-    ln(tgt, d + "norm1", 1e-5f, t384, rows);
-    gemm(pq.at("cross_q"), t384, rows, t384b, 384, kActNone);
+    ln_gemm(tgt, d + "norm1", 1e-5f, t384, pq.at("cross_q"), rows, t384b, 384, kActNone);
     launch_dec_cross_attn(prec, t384b, kvmem, t384, N, R, stream);
     gemm(pq.at("cross_out"), t384, rows, nullptr, 0, kActNone, tgt, 384, tgt, 384, 0);                 // tgt += cross_attn
-    ln(tgt, d + "norm2", 1e-5f, t384, rows);
-    gemm(pq.at("ffn1"), t384, rows, t1536, 1536, kActGelu);
+    ln_gemm(tgt, d + "norm2", 1e-5f, t384, pq.at("ffn1"), rows, t1536, 1536, kActGelu);
     gemm(pq.at("ffn2"), t1536, rows, nullptr, 0, kActNone, tgt, 384, tgt, 384, 0);                     // tgt += ffn
-    ln(tgt, "decoder.norm", 1e-5f, t384, rows);
-    gemm(pq.at("head"), t384, rows, nullptr, 0, kActNone, logits_out, logits_ld);
+    ln_gemm(tgt, "decoder.norm", 1e-5f, t384, pq.at("head"), rows, nullptr, 0, kActNone, logits_out, logits_ld);
   }
 
   // crops u8 [N][32][128][3] (device) -> logits f32 [N][26][95], ids i32 [N][26] (device); d_ar optional
@@ -1024,6 +1039,7 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "decoder_mode") g_decoder_mode = value;
   else if (k == "enc_chunk") g_enc_chunk = value;
   else if (k == "fuse_first") g_fuse_first = value;
+  else if (k == "ln_fuse") g_ln_fuse = value;
   else if (k == "g2_x_ring3") set_gemm2_x_ring3(value);
   else if (k == "c3_xs1_max_cin") set_conv3p_single_stage_max_cin(value);
   else if (k == "c3_force_bn128") set_conv3p_force_bn128(value);

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(ConvParams p) {
   const int npieces = (SK_BM * CPR) >> 6;          // 1-KiB pieces per panel
   unsigned char* const xs = smem;                  // [32][KC] bf16
   unsigned char* const ws = smem + SK_BM * KC * 2; // [32][KC] bf16
-  const __amdgpu_buffer_rsrc_t rsx = sk_rsrc(p.in0, (unsigned)((size_t)p.M * K * 2));
+  const __amdgpu_buffer_rsrc_t rsx = sk_rsrc(p.ln_in ? p.wgt : p.in0, p.ln_in ? 16u : (unsigned)((size_t)p.M * K * 2));
   const __amdgpu_buffer_rsrc_t rsw = sk_rsrc(p.wgt, (unsigned)((size_t)p.Cout * K * 2));
   constexpr unsigned OOB = 0x80000000u;
 
@@ -49,8 +49,58 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(ConvParams p) {
       const int m = m0 + row, n = n0 + row;
       const unsigned xo = m < p.M ? (unsigned)((m * K + kc0 + g * 8) * 2) : OOB;
       const unsigned wo = n < p.Cout ? (unsigned)((n * K + kc0 + g * 8) * 2) : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(xs + pc * 1024), 16, xo, 0, 0, 0);
+      if (!p.ln_in) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(xs + pc * 1024), 16, xo, 0, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(ws + pc * 1024), 16, wo, 0, 0, 0);
+    }
+    if (p.ln_in) {
+      // fused LayerNorm prologue (K == 384 == one panel): wave w normalises tile rows 8w..8w+7 in one pass, 8 lanes per row,
+      // lane j of a row owning the 16-byte chunks j, j+8, .. j+40; each chunk lands at the swizzled position the fragment
+      // reads expect
+      const int row = wave * 8 + (lane >> 3), m = m0 + row, j = lane & 7;
+      const bool live = m < p.M;
+      float v[6][8];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (live) {
+          const float* src = p.ln_in + (int64_t)m * p.ln_ld + (c * 8 + j) * 8;
+          a = *reinterpret_cast<const float4*>(src); b = *reinterpret_cast<const float4*>(src + 4);
+        }
+        v[c][0] = a.x; v[c][1] = a.y; v[c][2] = a.z; v[c][3] = a.w; v[c][4] = b.x; v[c][5] = b.y; v[c][6] = b.z; v[c][7] = b.w;
+      }
+      float sum = 0.f;
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += v[c][e];
+#pragma unroll
+      for (int o = 4; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      const float mean = sum * (1.f / 384.f);
+      float q2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; q2 += d * d; }
+#pragma unroll
+      for (int o = 4; o > 0; o >>= 1) q2 += __shfl_xor(q2, o);
+      const float rstd = rsqrtf(q2 * (1.f / 384.f) + p.ln_eps);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const int ch = c * 8 + j;
+        bf16x8 ob;
+        if (live) {
+          const float4 g0 = *reinterpret_cast<const float4*>(p.ln_gamma + ch * 8), g1 = *reinterpret_cast<const float4*>(p.ln_gamma + ch * 8 + 4);
+          const float4 t0 = *reinterpret_cast<const float4*>(p.ln_beta + ch * 8), t1 = *reinterpret_cast<const float4*>(p.ln_beta + ch * 8 + 4);
+          const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ob[e] = (bf16)((v[c][e] - mean) * rstd * gg[e] + bb[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ob[e] = (bf16)0.f;
+        }
+        const int cidx = (ch & ~15) | ((ch & 15) ^ (row & 15));
+        *reinterpret_cast<bf16x8*>(xs + row * KC * 2 + cidx * 16) = ob;
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -115,9 +165,11 @@ const char* gemm_sk_check(const ConvParams& p) {
   if (vec && p.out_f32 && ((uintptr_t)p.out_f32 & 15)) return "gemm_sk: f32 output alignment";
   if (vec && p.resid && ((uintptr_t)p.resid & 15)) return "gemm_sk: residual alignment";
   if (p.bias && ((uintptr_t)p.bias & 15)) return "gemm_sk: bias alignment";
-  if (((uintptr_t)p.in0 & 15) || ((uintptr_t)p.wgt & 15)) return "gemm_sk: operand alignment";
+  if ((!p.ln_in && ((uintptr_t)p.in0 & 15)) || ((uintptr_t)p.wgt & 15)) return "gemm_sk: operand alignment";
+  if (p.ln_in && (p.C0 != 384 || p.ln_ld % 4 || ((uintptr_t)p.ln_in & 15) || !p.ln_gamma || !p.ln_beta || ((uintptr_t)p.ln_gamma & 15) || ((uintptr_t)p.ln_beta & 15)))
+    return "gemm_sk: fused LayerNorm needs K == 384 and 16-byte aligned f32 rows / parameters";
   const size_t lim = (size_t)1 << 31;
-  if ((size_t)p.M * p.C0 * 2 >= lim || (size_t)p.Cout * p.C0 * 2 >= lim) return "gemm_sk: tensor too large";
+  if ((!p.ln_in && (size_t)p.M * p.C0 * 2 >= lim) || (size_t)p.Cout * p.C0 * 2 >= lim) return "gemm_sk: tensor too large";
   if (p.M <= 0 || p.Cout <= 0) return "gemm_sk: bad shape";
   return nullptr;
 }

@@ -242,7 +242,7 @@ const char* igemm_check(const ConvParams& p) {
   if (p.ks != 1 && p.ks != 3) return "igemm: ks must be 1 or 3";
   if (Ctot % 32 || p.C0 % 32) return "igemm: channel counts must be multiples of 32";
   if (p.C1 && !p.in1) return "igemm: in1 missing";
-  if (!p.in0 || !p.wgt) return "igemm: null operand";
+  if ((!p.in0 && !p.ln_in) || !p.wgt) return "igemm: null operand";
   if (p.M != p.B * p.H * p.W) return "igemm: M != B*H*W";
   if (p.M <= 0 || p.Cout <= 0) return "igemm: empty problem";
   if (p.out_pool && (p.relu0 || p.relu1 || (p.C0 + p.C1) % 64 || p.C0 % 64 || p.Cout % 8)) return "igemm: the fused max-pool output needs a gemm2-eligible layer";
@@ -255,11 +255,16 @@ static int g_sk_max_rows = 2048;
 static int g_ws_min_rows = 8192;
 void set_gemm_ws_min_rows(int m) { g_ws_min_rows = m; }
 void set_skinny_max_rows(int m) { g_sk_max_rows = m; }
+int skinny_max_rows() { return g_gemm_cfg == 0 || g_gemm_cfg >= 7 ? g_sk_max_rows : 0; }
 void set_gemm_config(int cfg) { g_gemm_cfg = cfg; }
 int gemm_config() { return g_gemm_cfg; }
 
 void launch_igemm(Precision prec, const ConvParams& p, hipStream_t s) {
   if (const char* e = igemm_check(p)) throw std::runtime_error(e);
+  if (p.ln_in) {   // LayerNorm fused into the GEMM prologue: only the skinny kernel implements it
+    if (prec != kBF16) throw std::runtime_error("igemm: fused LayerNorm input is bf16-only");
+    return launch_gemm_sk(p, s);
+  }
   if (prec == kBF16 && g_gemm_cfg >= 0) {
     if ((g_gemm_cfg == 0 || g_gemm_cfg >= 7) && p.M <= g_sk_max_rows && gemm_sk_check(p) == nullptr) return launch_gemm_sk(p, s);
     if ((g_gemm_cfg == 0 || g_gemm_cfg >= 7) && g_ws_min_rows > 0 && p.M >= g_ws_min_rows && p.Cout >= 512 && gemm_ws_check(p) == nullptr)

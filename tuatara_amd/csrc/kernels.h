@@ -24,6 +24,7 @@ const void* gelu_lut_for_current_device();
 const char* gemm_sk_check(const ConvParams& p);
 void launch_gemm_sk(const ConvParams& p, hipStream_t s);
 void set_skinny_max_rows(int m);   // problems with M <= m rows go to gemm_sk (0 = never)
+int skinny_max_rows();             // the current threshold (0 when gemm_sk is not in use)
 // ---- gemm_ws.hip (bf16 linear, K <= 384, weights resident in registers: the ViT encoder's qkv / proj / fc1)
 const char* gemm_ws_check(const ConvParams& p);
 void launch_gemm_ws(const ConvParams& p, hipStream_t s);
