@@ -115,6 +115,10 @@ void ttr_set_decoder_mode(int mode);
 int ttr_set_tuning(const char* key, int value);
 /* diagnostics: after ttr_set_tuning("dec_stamps", 1) the fused AR kernel's workgroup 0 records shader-clock stamps
  * [26 steps][16 phases]; this copies them out.  Returns -1 when stamps are off. */
+/* host wall-clock splits (microseconds) of the engine's last batch: [0] enqueue resize+CRAFT+CCL, [1] wait for the component
+ * counters, [2] wait for candidates / row extremes, [3] calipers, [4] crop rectangles + PARSeq enqueue, [5] wait for the GPU,
+ * [6] event read-back, [7] token decode */
+void ttr_last_host_us(ttr_engine* e, float out[8]);
 int ttr_dbg_dec_stamps(unsigned long long* out);
 /* Times one conv / linear layer on device-generated random data (no host traffic): average
  * microseconds per launch over `iters` back-to-back launches.  f32_resid != 0 selects the PARSeq

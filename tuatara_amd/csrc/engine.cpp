@@ -19,6 +19,10 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <chrono>
+#include <atomic>
+#include <functional>
+#include <condition_variable>
 #include <thread>
 #include <stdexcept>
 #include <string>
@@ -145,11 +149,13 @@ struct Result {
 struct CclBatch {   // device workspaces of the CCL stage for a batch of equally sized pages
   DevBuf tnorm, flags, parent, mm, area, bbox, maxt, cand_slot, cand, counters, rows;
   int pages = 0, npx = 0, max_cand = 0;
-  CclBuffers view() {
+  CclBuffers view(int p0 = 0) {   // the slices of pages p0.. (every array is strided by the page)
     CclBuffers b;
-    b.tnorm = tnorm.as<float>(); b.flags = flags.as<uint8_t>(); b.parent = parent.as<int>(); b.mm = mm.as<unsigned>();
-    b.area = area.as<int>(); b.bbox = bbox.as<int>(); b.maxt = maxt.as<unsigned>(); b.cand_slot = cand_slot.as<int>();
-    b.cand = cand.as<int>(); b.counters = counters.as<int>(); b.rows_packed = rows.as<int>(); b.max_cand = max_cand;
+    const size_t o = (size_t)p0 * npx;
+    b.tnorm = tnorm.as<float>() + o; b.flags = flags.as<uint8_t>() + o; b.parent = parent.as<int>() + o; b.mm = mm.as<unsigned>() + (size_t)p0 * 4;
+    b.area = area.as<int>() + o; b.bbox = bbox.as<int>() + o * 4; b.maxt = maxt.as<unsigned>() + o; b.cand_slot = cand_slot.as<int>() + o;
+    b.cand = cand.as<int>() + (size_t)p0 * max_cand * 8; b.counters = counters.as<int>() + (size_t)p0 * 2; b.rows_packed = rows.as<int>() + o * 2;
+    b.max_cand = max_cand;
     return b;
   }
   void ensure(int pages_, int npx_, int max_cand_) {
@@ -161,11 +167,87 @@ struct CclBatch {   // device workspaces of the CCL stage for a batch of equally
   }
 };
 
+// A few persistent host threads for the per-page host work (calipers, token decode): spawning threads per batch cost more
+// than the work itself.  run(n, f) calls f(0..n-1) across the workers and the caller; the first exception is rethrown.
+class HostPool {
+ public:
+  explicit HostPool(int workers) {
+    for (int t = 0; t < workers; ++t) th_.emplace_back([this] { loop(); });
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++gen_; }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  void run(int n, const std::function<void(int)>& f) {
+    if (n <= 0) return;
+    if (n == 1 || th_.empty()) { for (int i = 0; i < n; ++i) f(i); return; }
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn_ = &f; n_ = n; next_.store(0); pending_ = n; err_ = nullptr; ++gen_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [this] { return pending_ == 0 && busy_ == 0; });
+    fn_ = nullptr;
+    if (err_) std::rethrow_exception(err_);
+  }
+
+ private:
+  void work() {
+    int finished = 0;
+    std::exception_ptr err;
+    for (;;) {
+      const int i = next_.fetch_add(1);
+      if (i >= n_) break;
+      try { (*fn_)(i); } catch (...) { if (!err) err = std::current_exception(); }
+      ++finished;
+    }
+    if (finished || err) {
+      std::lock_guard<std::mutex> lk(mu_);
+      pending_ -= finished;
+      if (err && !err_) err_ = err;
+    }
+  }
+  void loop() {
+    unsigned long long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (stop_) return;
+        if (!fn_) continue;
+        ++busy_;
+      }
+      work();
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        --busy_;
+        if (pending_ == 0 && busy_ == 0) done_.notify_all();
+      }
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)>* fn_ = nullptr;
+  std::atomic<int> next_{0};
+  int n_ = 0, pending_ = 0, busy_ = 0;
+  unsigned long long gen_ = 0;
+  bool stop_ = false;
+  std::exception_ptr err_;
+};
+
 struct Engine {
   ttr_config cfg;
   Precision prec;
   size_t es;  // element size of T
   hipStream_t stream = nullptr;
+  std::unique_ptr<HostPool> host_pool;
+  hipStream_t copy_stream = nullptr;              // device -> host copies of one page group's components while the next group's CRAFT runs
+  std::vector<hipEvent_t> group_ev;               // per page group: component counters are on the host
   std::mutex mu;
   Tokenizer tok;
 
@@ -184,6 +266,8 @@ struct Engine {
   PinnedBuf h_counters, h_cand, h_rows, h_rects, h_ids;   // pinned staging of the small host <-> device transfers
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   float stage_ms[4] = {0, 0, 0, 0};
+  float host_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // host wall-clock splits of the last run_pages (ttr_last_host_us)
+  static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
   // optional per-launch timing of the igemm kernel (bench.py's roofline): events bracket every launch
   int profiling = 0;                                   // 0 off, 1 = CRAFT conv launches only, 2 = every conv / GEMM launch
   int prof_stage = 0;                                  // 0 = CRAFT convs, 1 = PARSeq encoder (ViT) + batched decoder GEMMs, 2 = per-step AR decoder GEMMs
@@ -346,6 +430,8 @@ struct Engine {
     if (e != hipSuccess || ndev <= 0) throw std::runtime_error("no HIP device available: the tuatara engine has no CPU fallback");
     TTR_HIP_CHECK(hipSetDevice(cfg.device));
     TTR_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    TTR_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    host_pool.reset(new HostPool(std::min(15, std::max(1, (int)std::thread::hardware_concurrency() - 1))));
     for (auto& x : ev) TTR_HIP_CHECK(hipEventCreate(&x));
     load_craft(dir);
     load_parseq(dir);
@@ -353,6 +439,8 @@ struct Engine {
   ~Engine() {
     for (auto& x : ev) if (x) (void)hipEventDestroy(x);
     for (auto& x : prof_pool) (void)hipEventDestroy(x);
+    for (auto& x : group_ev) (void)hipEventDestroy(x);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (stream) (void)hipStreamDestroy(stream);
   }
 
@@ -614,16 +702,22 @@ struct Engine {
   // ---- post-processing of one page's heat map: GPU CCL + host calipers
   struct PageBoxes { std::vector<RRect> det; };
 
-  void ccl_launch(const float* d_heat, int pages, int H2, int W2) {
-    ccl.ensure(pages, H2 * W2, cfg.max_components);
-    launch_ccl(d_heat, pages, H2, W2, cfg.text_threshold, cfg.link_threshold, cfg.low_text, cfg.min_area, ccl.view(), stream);
+  // CCL kernels of pages [p0, p0 + pages) of a batch of `total` pages, then their component counters -> host; group `g`'s event
+  // fires when the counters have landed
+  void ccl_launch(const float* d_heat, int p0, int pages, int total, int g, int H2, int W2) {
+    if (p0 == 0) { ccl.ensure(total, H2 * W2, cfg.max_components); h_counters.ensure((size_t)total * 8); }
+    launch_ccl(d_heat, pages, H2, W2, cfg.text_threshold, cfg.link_threshold, cfg.low_text, cfg.min_area, ccl.view(p0), stream);
+    TTR_HIP_CHECK(hipMemcpyAsync(h_counters.as<int>() + 2 * p0, ccl.counters.as<int>() + 2 * p0, (size_t)pages * 8, hipMemcpyDeviceToHost, stream));
+    while ((int)group_ev.size() <= g) { hipEvent_t e; TTR_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); group_ev.push_back(e); }
+    TTR_HIP_CHECK(hipEventRecord(group_ev[g], stream));
   }
-  // boxes of every page of the batch: two stream syncs in all (counters, then candidates + row extremes)
-  void ccl_collect(int pages, int H2, int W2, std::vector<std::vector<RRect>>& det) {
-    h_counters.ensure((size_t)pages * 8);
-    int* counters = h_counters.as<int>();
-    TTR_HIP_CHECK(hipMemcpyAsync(counters, ccl.counters.p, (size_t)pages * 8, hipMemcpyDeviceToHost, stream));
-    TTR_HIP_CHECK(hipStreamSynchronize(stream));
+  // boxes of pages [p0, p0 + pages): waits for the group's counters, pulls candidates + row extremes over on the copy stream
+  // (the main stream may already be running the next group's CRAFT), then the host calipers
+  void ccl_collect(int p0, int pages, int g, int H2, int W2, std::vector<std::vector<RRect>>& det) {
+    const int* counters = h_counters.as<int>() + 2 * p0;
+    const double tc0 = now_us();
+    TTR_HIP_CHECK(hipEventSynchronize(group_ev[g]));
+    const double tc1 = now_us();
     // two strided copies bring every page's candidates and row extremes over (width = the busiest page's share)
     int max_c = 0, max_r = 0;
     for (int pg = 0; pg < pages; ++pg) {
@@ -637,12 +731,13 @@ struct Engine {
     int* cand = h_cand.as<int>();
     int* rw = h_rows.as<int>();
     if (max_c > 0) {
-      TTR_HIP_CHECK(hipMemcpy2DAsync(cand, pitch_c, ccl.cand.p, (size_t)ccl.max_cand * 32, pitch_c, pages, hipMemcpyDeviceToHost, stream));
-      TTR_HIP_CHECK(hipMemcpy2DAsync(rw, pitch_r, ccl.rows.p, (size_t)ccl.npx * 8, pitch_r, pages, hipMemcpyDeviceToHost, stream));
-      TTR_HIP_CHECK(hipStreamSynchronize(stream));
+      const CclBuffers v = ccl.view(p0);
+      TTR_HIP_CHECK(hipMemcpy2DAsync(cand, pitch_c, v.cand, (size_t)ccl.max_cand * 32, pitch_c, pages, hipMemcpyDeviceToHost, copy_stream));
+      TTR_HIP_CHECK(hipMemcpy2DAsync(rw, pitch_r, v.rows_packed, (size_t)ccl.npx * 8, pitch_r, pages, hipMemcpyDeviceToHost, copy_stream));
+      TTR_HIP_CHECK(hipStreamSynchronize(copy_stream));
     }
-    det.assign(pages, std::vector<RRect>());
-    // the calipers of a page depend on nothing but that page: a few host threads share the batch while the GPU waits
+    const double tc2 = now_us();
+    // the calipers of a page depend on nothing but that page: a few host threads share the group
     parallel_pages(pages, [&](int pg) {
       const int n = counters[2 * pg];
       const int* cd = cand + off_c[pg];
@@ -653,30 +748,19 @@ struct Engine {
         const int* c = &cd[8 * i];
         Component comp{c[0], c[1], c[2], c[3], c[4], c[5], rw + off_r[pg] + 2 * (size_t)c[6]};
         RRect r;
-        if (component_to_rect(comp, H2, W2, &r)) det[pg].push_back(r);
+        if (component_to_rect(comp, H2, W2, &r)) det[p0 + pg].push_back(r);
       }
     });
+    host_us[1] += (float)(tc1 - tc0); host_us[2] += (float)(tc2 - tc1); host_us[3] += (float)(now_us() - tc2);
   }
-  // run f(page) for every page on up to 8 host threads (the first exception is rethrown on the caller's thread)
-  template <class F> static void parallel_pages(int pages, F&& f) {
-    const int nthreads = std::min(pages, std::min(8, (int)std::max(1u, std::thread::hardware_concurrency())));
-    if (nthreads <= 1) { for (int pg = 0; pg < pages; ++pg) f(pg); return; }
-    std::exception_ptr err;
-    std::mutex emu;
-    std::vector<std::thread> th;
-    for (int t = 0; t < nthreads; ++t)
-      th.emplace_back([&, t] {
-        try { for (int pg = t; pg < pages; pg += nthreads) f(pg); }
-        catch (...) { std::lock_guard<std::mutex> lk(emu); if (!err) err = std::current_exception(); }
-      });
-    for (auto& x : th) x.join();
-    if (err) std::rethrow_exception(err);
-  }
+  // run f(page) for every page on the engine's host threads
+  void parallel_pages(int pages, const std::function<void(int)>& f) { host_pool->run(pages, f); }
 
   // ---- the hot path over a batch of same-sized device pages
   void run_pages(const uint8_t* d_pages, int n, int h, int w, std::vector<Result>& results) {
     results.assign(n, Result());
     if (n <= 0) return;
+    const double th0 = now_us();
     if (h <= 0 || w <= 0) throw std::runtime_error("Error reading image from file");  // image.empty(), tuatara.cpp:344
     const CanvasGeom g = canvas_geometry(h, w, cfg.canvas_size, cfg.mag_ratio);
     if (g.target_h <= 0 || g.target_w <= 0) throw std::runtime_error("image too thin to resize");
@@ -688,11 +772,15 @@ struct Engine {
     for (int i = 0; i < n; ++i)
       launch_resize_pad_u8(d_pages + i * page_bytes, h, w, w * 3, canvas.as<uint8_t>() + (size_t)i * H * W * 3, g.target_h, g.target_w, H, W, 1, stream);
     // CRAFT in groups of <= 16 pages: bounds the activation workspace (~0.5 GB/page) and keeps every tensor
-    // inside the 2 GiB window gemm2's 32-bit buffer offsets address
-    for (int p0 = 0; p0 < n; p0 += 16)
-      craft_forward(canvas.as<uint8_t>() + (size_t)p0 * H * W * 3, std::min(16, n - p0), H, W, heat.as<float>() + (size_t)p0 * H2 * W2 * 2);
-    TTR_HIP_CHECK(hipEventRecord(ev[1], stream));
-    ccl_launch(heat.as<float>(), n, H2, W2);
+    // inside the 2 GiB window gemm2's 32-bit buffer offsets address.  Each group's CCL follows its CRAFT, so the host reads
+    // group g's components back (and runs its calipers) while the GPU is busy with group g + 1.
+    const int groups = (n + 15) / 16;
+    for (int gi = 0; gi < groups; ++gi) {
+      const int p0 = gi * 16, cnt = std::min(16, n - p0);
+      craft_forward(canvas.as<uint8_t>() + (size_t)p0 * H * W * 3, cnt, H, W, heat.as<float>() + (size_t)p0 * H2 * W2 * 2);
+      if (gi == groups - 1) TTR_HIP_CHECK(hipEventRecord(ev[1], stream));
+      ccl_launch(heat.as<float>() + (size_t)p0 * H2 * W2 * 2, p0, cnt, n, gi, H2, W2);
+    }
     TTR_HIP_CHECK(hipEventRecord(ev[2], stream));
 
     // host: boxes -> crop rectangles
@@ -701,7 +789,11 @@ struct Engine {
     std::vector<int> page_of;               // page index per crop
     std::vector<std::vector<RRect>> boxes(n);
     std::vector<std::vector<RRect>> dets;
-    ccl_collect(n, H2, W2, dets);
+    host_us[0] = (float)(now_us() - th0);
+    host_us[1] = host_us[2] = host_us[3] = 0.f;
+    dets.assign(n, std::vector<RRect>());
+    for (int gi = 0; gi < groups; ++gi) ccl_collect(gi * 16, std::min(16, n - gi * 16), gi, H2, W2, dets);
+    const double th1 = now_us();
     for (int i = 0; i < n; ++i) {
       for (const RRect& r : dets[i]) {
         RRect b = adjust_coordinates(r, ratio_w, ratio_h);            // :406
@@ -739,19 +831,31 @@ struct Engine {
       TTR_HIP_CHECK(hipEventRecord(ev[3], stream));
       TTR_HIP_CHECK(hipEventRecord(ev[4], stream));
     }
+    const double th2 = now_us();
     TTR_HIP_CHECK(hipStreamSynchronize(stream));
+    const double th3 = now_us();
     for (int s = 0; s < 4; ++s) (void)hipEventElapsedTime(&stage_ms[s], ev[s], ev[s + 1]);
     if (profiling) prof_collect();
-    std::vector<int> k_of(n, 0);
-    for (int c = 0; c < N; ++c) {
-      int pg = page_of[c];
+    const double th4 = now_us();
+    // crops are ordered by page: page pg owns crops [first[pg], first[pg + 1]); pages decode independently
+    std::vector<int> first(n + 1, 0);
+    for (int c = 0; c < N; ++c) first[page_of[c] + 1]++;
+    for (int pg = 0; pg < n; ++pg) first[pg + 1] += first[pg];
+    auto decode_page = [&](int pg) {
       Result& r = results[pg];
-      r.text.push_back(tok.decode(&ids[(size_t)c * 26], 26));           // :486-505
-      float bb[4];
-      tesseract_bbox(boxes[pg][k_of[pg]++], bb);                        // :511
-      r.bbox.insert(r.bbox.end(), bb, bb + 4);
-      r.ids.insert(r.ids.end(), &ids[(size_t)c * 26], &ids[(size_t)c * 26] + 26);
-    }
+      const int c0 = first[pg], cnt = first[pg + 1] - c0;
+      r.text.reserve(cnt); r.bbox.reserve((size_t)cnt * 4);
+      r.ids.assign(&ids[(size_t)c0 * 26], &ids[(size_t)(c0 + cnt) * 26]);
+      for (int k = 0; k < cnt; ++k) {
+        r.text.push_back(tok.decode(&ids[(size_t)(c0 + k) * 26], 26));   // :486-505
+        float bb[4];
+        tesseract_bbox(boxes[pg][k], bb);                                 // :511
+        r.bbox.insert(r.bbox.end(), bb, bb + 4);
+      }
+    };
+    if (N >= 256) parallel_pages(n, decode_page);
+    else for (int pg = 0; pg < n; ++pg) decode_page(pg);
+    host_us[4] = (float)(th2 - th1); host_us[5] = (float)(th3 - th2); host_us[6] = (float)(th4 - th3); host_us[7] = (float)(now_us() - th4);
   }
 };
 
@@ -879,9 +983,10 @@ int ttr_ccl_boxes(ttr_engine* e, const float* heat, int H2, int W2, float* rects
   std::lock_guard<std::mutex> lk(E.mu);
   E.heat.ensure((size_t)H2 * W2 * 2 * 4);
   TTR_HIP_CHECK(hipMemcpyAsync(E.heat.p, heat, (size_t)H2 * W2 * 2 * 4, hipMemcpyHostToDevice, E.stream));
-  E.ccl_launch(E.heat.as<float>(), 1, H2, W2);
+  E.ccl_launch(E.heat.as<float>(), 0, 1, 1, 0, H2, W2);
   std::vector<std::vector<RRect>> dets;
-  E.ccl_collect(1, H2, W2, dets);
+  dets.assign(1, std::vector<RRect>());
+  E.ccl_collect(0, 1, 0, H2, W2, dets);
   const std::vector<RRect>& det = dets[0];
   *n = (int)det.size();
   for (int i = 0; i < (int)det.size() && i < max_rects; ++i) {
@@ -1032,6 +1137,7 @@ int ttr_dbg_conv_pool(ttr_engine* e, const float* in0, int C0, int B, int H, int
 
 void ttr_set_gemm_config(int cfg) { set_gemm_config(cfg); }
 void ttr_set_decoder_mode(int mode) { g_decoder_mode = mode; }
+void ttr_last_host_us(ttr_engine* e, float out[8]) { for (int i = 0; i < 8; ++i) out[i] = e ? e->e->host_us[i] : 0.f; }
 int ttr_dbg_dec_stamps(unsigned long long* out) { return g_dec_dbg && hipMemcpy(out, g_dec_dbg, 26 * 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
 int ttr_set_tuning(const char* key, int value) {
   const std::string k = key ? key : "";

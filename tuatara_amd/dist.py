@@ -32,6 +32,11 @@ def pack_records(results: Sequence[Sequence[dict]], max_crops: int = MAX_CROPS) 
     """results[page][crop]["ids"] -> int32 [pages, max_crops, 26], -1 padded."""
     rec = np.full((len(results), max_crops, L), -1, np.int32)
     for i, r in enumerate(results):
+        ids = getattr(r, "ids", None)
+        if isinstance(ids, np.ndarray):            # engine.PageResult: the id array the C ABI filled
+            k = min(len(ids), max_crops)
+            rec[i, :k] = ids[:k]
+            continue
         for j, item in enumerate(r[:max_crops]):
             rec[i, j] = item["ids"]
     return rec

@@ -6,6 +6,7 @@ library is missing and ``Engine(...)`` raises when no GPU is present.
 """
 from __future__ import annotations
 
+import collections.abc
 import ctypes as C
 import os
 from typing import List, Optional, Sequence
@@ -65,6 +66,7 @@ SYMBOLS = [
     ("ttr_set_gemm_config", None, [_I]),
     ("ttr_set_decoder_mode", None, [_I]),
     ("ttr_set_tuning", _I, [C.c_char_p, _I]),
+    ("ttr_last_host_us", None, [_VP, _PF]),
     ("ttr_dbg_dec_stamps", _I, [C.POINTER(C.c_ulonglong)]),
     ("ttr_bench_conv", _I, [_VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _PF]),
     ("ttr_get_profile", _I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
@@ -133,6 +135,34 @@ def box_geometry(rect5, ratio: float):
     adj, xywh, bbox = np.zeros(5, np.float32), np.zeros(4, np.int32), np.zeros(4, np.float32)
     load().ttr_dbg_box_geometry(_f(r), C.c_float(ratio), _f(adj), _i(xywh), _f(bbox))
     return adj, tuple(int(v) for v in xywh), [float(v) for v in bbox]
+
+
+class PageResult(collections.abc.Sequence):
+    """One page's words as the list of {"text", "bbox", "ids"} dicts pytuatara.image_to_data returns, materialised on access:
+    the batch hand-over keeps the arrays the C ABI filled (`texts`, `bbox` f32 [n,4], `ids` i32 [n,26]) and builds dicts only
+    for the items a caller touches."""
+    __slots__ = ("texts", "bbox", "ids")
+
+    def __init__(self, texts, bbox, ids):
+        self.texts, self.bbox, self.ids = texts, bbox, ids
+
+    def __len__(self):
+        return len(self.texts)
+
+    def __getitem__(self, j):
+        if isinstance(j, slice):
+            return [self[i] for i in range(*j.indices(len(self)))]
+        if j < 0:
+            j += len(self)
+        if not 0 <= j < len(self):
+            raise IndexError(j)
+        return {"text": self.texts[j], "bbox": self.bbox[j].tolist(), "ids": self.ids[j].tolist()}
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+    def __repr__(self):
+        return repr(list(self))
 
 
 class DeviceBuffer:
@@ -215,11 +245,10 @@ class Engine:
         buf = C.create_string_buffer(max(need.value, 1))
         self.lib.ttr_results_gather(arr, n, None, _f(bb), _i(ids), buf, need.value, None)
         texts = buf.raw[:need.value].decode("latin1").split("\n")
-        bbl, idl = bb.tolist(), ids.tolist()
         out, k = [], 0
         for i in range(n):
             c = int(counts[i])
-            out.append([{"text": texts[j], "bbox": bbl[j], "ids": idl[j]} for j in range(k, k + c)])
+            out.append(PageResult(texts[k:k + c], bb[k:k + c], ids[k:k + c]))
             k += c
             self.lib.ttr_result_free(arr[i])
         return out
@@ -250,6 +279,11 @@ class Engine:
         ms = (C.c_float * 4)()
         self.lib.ttr_last_stage_ms(self.h, ms)
         return dict(craft=ms[0], post=ms[1], pack=ms[2], parseq=ms[3])
+
+    def last_host_us(self):
+        us = (C.c_float * 8)()
+        self.lib.ttr_last_host_us(self.h, us)
+        return [round(float(x), 1) for x in us]
 
     def set_profiling(self, on):
         """0 / False off, 1 / True CRAFT conv launches only, 2 every conv / GEMM launch."""
