@@ -79,15 +79,9 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(ConvParams p, int nslices,
   };
   const int frag_lane = (lane & 15) * 128 + (((lane >> 4) ^ ((lane >> 1) & 7)) << 4);
 
-  for (int a = 0; a < 2 && it < nt; ++a) issue_x();       // two panels ahead
-  for (int t = 0; t < nt; ++t) {
-    // panel t has landed once at most (issued - t - 1) younger panels (NK loads each, in order) remain in flight
-    if (it - t - 1 >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NK) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                          // everyone's pieces landed; slot (t+2)%3 = (t-1)%3 is free again
-    if (it < nt) issue_x();
+  f32x4 acc[4][2];
+  auto mfma_phase = [&](int t) {
     const unsigned char* xb = smem + (t % WS_SLOTS) * SLOT;
-    f32x4 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
@@ -103,19 +97,19 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(ConvParams p, int nslices,
           for (int jj = 0; jj < 2; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks * 2 + kk][jj], fx[i], acc[i][jj], 0, 0, 0);
       }
     }
-
-    // ---- epilogue of this M tile: lane holds columns n..n+7 of row m for every i
-    const int m0 = (mgroup + t * mgroups) * WS_BM;
-    const int n = n0 + wave * 32 + fg * 8;
-    if (n >= p.Cout) continue;
-    float bv[8];
-    if (p.bias) {
-      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
-      bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
-    } else {
+  };
+  // epilogue of M tile t: lane holds columns n..n+7 of row m for every i
+  const int n = n0 + wave * 32 + fg * 8;
+  float bv[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) bv[e] = 0.f;
-    }
+  for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+  if (p.bias && n < p.Cout) {
+    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+    bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+  }
+  auto epilogue = [&](int t) {
+    const int m0 = (mgroup + t * mgroups) * WS_BM;
+    if (n >= p.Cout) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m0 + i * 16 + fr;
@@ -147,7 +141,24 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(ConvParams p, int nslices,
         *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
       }
     }
+  };
+
+  // Waves w and w + 4 share a SIMD.  Waves 0-3 run [MFMA(t), epilogue(t)] after barrier t; waves 4-7 run [epilogue(t-1),
+  // MFMA(t)]: the SIMD's matrix pipe works on one wave's panel while its vector ALU finishes the other wave's previous panel
+  // (bias / GELU / stores), instead of both waves queueing for the same unit.  The epilogue's stores and residual loads
+  // retire in order with the X stream, so the counted wait below only ever waits for older operations too.
+  const bool late = wave >= 4;
+  for (int a = 0; a < 2 && it < nt; ++a) issue_x();       // two panels ahead
+  for (int t = 0; t < nt; ++t) {
+    // panel t has landed once at most (issued - t - 1) younger panels (NK loads each, in order) remain in flight
+    if (it - t - 1 >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NK) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // everyone's pieces landed; slot (t+2)%3 = (t-1)%3 is free again
+    if (it < nt) issue_x();
+    if (!late) { mfma_phase(t); epilogue(t); }
+    else { if (t > 0) epilogue(t - 1); mfma_phase(t); }
   }
+  if (late && nt > 0) epilogue(nt - 1);
 }
 
 const char* gemm_ws_check(const ConvParams& p) {
