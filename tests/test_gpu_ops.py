@@ -207,3 +207,32 @@ def test_gemm_weight_stationary(eng_bf16, case):
         eng_bf16.lib.ttr_set_tuning(b"ws_min_rows", 8192)
     assert np.abs(got - ref).max() < 2e-4
     assert np.abs(got - other).max() < 1e-4
+
+
+@pytest.mark.parametrize("case", [(40 * 64 * 7 + 29, 384, 1536, 2), (20000, 384, 1152, 0), (9000, 256, 520, 1)])
+def test_gemm_weight_stationary_bf16_output_long_streams(eng_bf16, case):
+    """The engine's use of gemm_ws: bf16 output through counted buffer stores (the activation-panel wait counts past the
+    epilogue's stores), every workgroup streaming several panels, ragged last panel and ragged last column slice.
+    bf16 results must equal gemm2's up to fp32 summation order (<= 1 bf16 ulp on a few elements)."""
+    M, K, Cout, act = case
+    rng = np.random.default_rng(5)
+    bf = lambda a: torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy()
+    x = bf(rng.standard_normal((1, 1, M, K)).astype(np.float32))
+    w = bf((rng.standard_normal((Cout, 1, 1, K)) / np.sqrt(K)).astype(np.float32))
+    b = rng.standard_normal(Cout).astype(np.float32)
+    try:
+        eng_bf16.lib.ttr_set_tuning(b"dbg_bf16_out", 1)
+        eng_bf16.lib.ttr_set_tuning(b"ws_min_rows", 1)
+        got = eng_bf16.dbg_conv(x, w, b, 1, 1, act)
+        again = eng_bf16.dbg_conv(x, w, b, 1, 1, act)
+        eng_bf16.lib.ttr_set_tuning(b"ws_min_rows", 0)
+        other = eng_bf16.dbg_conv(x, w, b, 1, 1, act)
+    finally:
+        eng_bf16.lib.ttr_set_tuning(b"dbg_bf16_out", 0)
+        eng_bf16.lib.ttr_set_tuning(b"ws_min_rows", 8192)
+    assert np.array_equal(got, again)                                   # no race: run to run identical
+    scale = np.maximum(np.abs(other), 1.0)
+    assert (np.abs(got - other) / scale).max() < 2 ** -6                # one bf16 ulp
+    assert (got != other).mean() < 0.02
+    ref = _ref_conv(x[:, :, :512], w, b, 1, 1, act)
+    assert np.abs(got[:, :, :512] - ref).max() < 0.04

@@ -31,6 +31,9 @@ struct ConvParams {
   const void* pre_wgt; const float* pre_bias;   // conv3p only: fuse CRAFT's conv1_1 in front (in0 = u8 canvas [B][H][W][3], pre_wgt = T [64][32])
   // gemm_sk only: take the activation rows from LayerNorm(ln_in) instead of in0 (f32 [M][384] rows, stride ln_ld)
   const float* ln_in; int ln_ld; const float* ln_gamma; const float* ln_beta; float ln_eps;
+  unsigned long long* dbg;   // gemm_ws diagnostics: shader-clock stamps of workgroup 0 (null = off)
+  int store_policy;          // set by the launchers: 0 default, 1 nt, 2 sc0 sc1 nt on the big streaming output stores
+  int dbg_flags;             // gemm_ws diagnostics (timing experiments only, results are wrong): 1 = no output stores, 2 = no activation loads
   const void* gelu_lut;      // set by launch_gemm2: float2 [1024] = {Phi(x_i), Phi(x_i+1) - Phi(x_i)}, x_i = -8 + i/64
 };
 
@@ -48,10 +51,9 @@ __device__ __forceinline__ float gelu_fast(float x) {
 // GELU(x) = x * Phi(x), Phi by linear interpolation in the float2[1024] table {Phi(x_i), Phi(x_i+1) - Phi(x_i)}, x_i = -8 + i/64
 // (|error| <= 7.4e-6 |x|: two orders below a bf16 ulp)
 __device__ __forceinline__ float gelu_lut(float x, const float2* lut) {
-  const float u = fmaf(__builtin_amdgcn_fmed3f(x, -8.0f, 7.984375f), 64.0f, 512.0f);
-  const float fl = floorf(u);
-  const float2 t = lut[(int)fl];
-  return x * fmaf(u - fl, t.y, t.x);
+  const float u = fmaf(__builtin_amdgcn_fmed3f(x, -8.0f, 7.984375f), 64.0f, 512.0f);   // 0 <= u < 1024
+  const float2 t = lut[(int)u];                                                          // u >= 0: truncation is floor
+  return x * fmaf(__builtin_amdgcn_fractf(u), t.y, t.x);                                 // fract(u) == u - floor(u) exactly
 }
 
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }

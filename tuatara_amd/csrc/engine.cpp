@@ -43,6 +43,7 @@ void hip_fail(const char* what, hipError_t e, const char* file, int line) {
 
 static thread_local std::string g_last_error;
 static unsigned long long* g_dec_dbg = nullptr;   // device buffer for dec_ar phase stamps (diagnostics)
+static int g_dbg_bf16_out = 0;     // ttr_dbg_conv on a bf16 engine: take the kernel's bf16 output (the path the engine uses) instead of the f32 one
 static int g_ln_fuse = 1;          // bf16 decoder steps: LayerNorm computed inside the skinny GEMM's loader (gemm_sk ln_in)
 static int g_fuse_first = 1;       // bf16: CRAFT conv1_1 fused into conv1_2's loader (conv3p FIRST)
 static int g_enc_chunk = 0;        // crops per encoder group (0 = all crops at once)
@@ -1095,7 +1096,16 @@ int ttr_dbg_conv(ttr_engine* e, const float* in0, int C0, const float* in1, int 
   p.in0 = d0.p; p.C0 = C0; p.in1 = C1 ? d1.p : nullptr; p.C1 = C1; p.relu0 = relu0; p.relu1 = relu1;
   p.B = B; p.H = H; p.W = W; p.ks = ks; p.dil = dil; p.wgt = L.w.p; p.bias = bias ? L.b.as<float>() : nullptr;
   p.out = nullptr; p.out_f32 = dout.as<float>(); p.out_f32_ld = Cout; p.Cout = Cout; p.M = (int)M; p.act = act;
+  const bool bf16_out = g_dbg_bf16_out && E.prec == kBF16;
+  if (bf16_out) { p.out = dout.p; p.out_ld = Cout; p.out_f32 = nullptr; p.out_f32_ld = 0; }
   launch_igemm(E.prec, p, E.stream);
+  if (bf16_out) {
+    std::vector<uint16_t> hb(M * Cout);
+    TTR_HIP_CHECK(hipMemcpyAsync(hb.data(), dout.p, M * Cout * 2, hipMemcpyDeviceToHost, E.stream));
+    TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
+    for (size_t i = 0; i < hb.size(); ++i) { const uint32_t u = (uint32_t)hb[i] << 16; memcpy(&out[i], &u, 4); }
+    return 0;
+  }
   TTR_HIP_CHECK(hipMemcpyAsync(out, dout.p, M * Cout * 4, hipMemcpyDeviceToHost, E.stream));
   TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
   return 0;
@@ -1146,6 +1156,10 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "enc_chunk") g_enc_chunk = value;
   else if (k == "fuse_first") g_fuse_first = value;
   else if (k == "ln_fuse") g_ln_fuse = value;
+  else if (k == "ws_dbg_flags") set_gemm_ws_dbg_flags(value);
+  else if (k == "ws_lean") set_gemm_ws_lean(value);
+  else if (k == "store_policy") set_store_policy(value);
+  else if (k == "dbg_bf16_out") g_dbg_bf16_out = value;
   else if (k == "g2_x_ring3") set_gemm2_x_ring3(value);
   else if (k == "c3_xs1_max_cin") set_conv3p_single_stage_max_cin(value);
   else if (k == "c3_force_bn128") set_conv3p_force_bn128(value);
@@ -1156,6 +1170,7 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "dec_stamps") {   // value != 0: allocate the stamp buffer; read it back with ttr_dev_download via ttr_dbg_dec_stamps
     if (value && !g_dec_dbg) { void* d = nullptr; if (hipMalloc(&d, 26 * 16 * 8) != hipSuccess) return -1; (void)hipMemset(d, 0, 26 * 16 * 8); g_dec_dbg = (unsigned long long*)d; }
     if (!value) g_dec_dbg = nullptr;
+    set_gemm_ws_stamps(value == 2 ? g_dec_dbg : nullptr);   // 2: the same buffer takes gemm_ws stamps instead
   }
   else return -1;
   return 0;

@@ -255,6 +255,8 @@ static int g_sk_max_rows = 2048;
 static int g_ws_min_rows = 8192;
 void set_gemm_ws_min_rows(int m) { g_ws_min_rows = m; }
 void set_skinny_max_rows(int m) { g_sk_max_rows = m; }
+int g_store_policy = 1;
+void set_store_policy(int v) { g_store_policy = v; }
 int skinny_max_rows() { return g_gemm_cfg == 0 || g_gemm_cfg >= 7 ? g_sk_max_rows : 0; }
 void set_gemm_config(int cfg) { g_gemm_cfg = cfg; }
 int gemm_config() { return g_gemm_cfg; }

@@ -24,6 +24,11 @@ const void* gelu_lut_for_current_device();
 const char* gemm_sk_check(const ConvParams& p);
 void launch_gemm_sk(const ConvParams& p, hipStream_t s);
 void set_skinny_max_rows(int m);   // problems with M <= m rows go to gemm_sk (0 = never)
+void set_gemm_ws_stamps(unsigned long long* dev_buf);   // >= 2*24*8 u64, or null: phase stamps of gemm_ws workgroup 0
+extern int g_store_policy;          // cache policy of the big streaming output stores: 0 default, 1 nt, 2 sc0 sc1 nt
+void set_store_policy(int v);
+void set_gemm_ws_dbg_flags(int f);
+void set_gemm_ws_lean(int v);      // 0: always the run-time-activation epilogue (A/B and tests)
 int skinny_max_rows();             // the current threshold (0 when gemm_sk is not in use)
 // ---- gemm_ws.hip (bf16 linear, K <= 384, weights resident in registers: the ViT encoder's qkv / proj / fc1)
 const char* gemm_ws_check(const ConvParams& p);
