@@ -56,6 +56,25 @@ __device__ __forceinline__ float gelu_lut(float x, const float2* lut) {
   return x * fmaf(__builtin_amdgcn_fractf(u), t.y, t.x);                                 // fract(u) == u - floor(u) exactly
 }
 
+// GELU of 8 values with the table in LDS at byte address lut_lds.  The table reads are inline asm: hipcc orders every LDS
+// read it can see behind all in-flight LDS-DMA loads AND stores of the wave (s_waitcnt vmcnt(0) — it cannot prove that the
+// DMA does not write the table), which drains the activation prefetch and waits for write acknowledgements 4x per epilogue.
+// Same arithmetic as gelu_lut().
+__device__ __forceinline__ void gelu_lut8_lds(float (&v)[8], unsigned lut_lds) {
+  float u[8];
+  float2 t[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    u[e] = fmaf(__builtin_amdgcn_fmed3f(v[e], -8.0f, 7.984375f), 64.0f, 512.0f);
+    const unsigned a = lut_lds + ((unsigned)(int)u[e] << 3);
+    asm volatile("ds_read_b64 %0, %1" : "=v"(t[e]) : "v"(a));
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = v[e] * fmaf(__builtin_amdgcn_fractf(u[e]), t[e].y, t[e].x);
+}
+
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
 

@@ -32,6 +32,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(ConvParams p, int nslices,
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   constexpr int K = NK * 64, SLOT = WS_BM * K * 2;       // K-step sub-tile ks of a slot: [64 rows][128 B] at ks * 8192
   float2* const glut = reinterpret_cast<float2*>(smem + WS_SLOTS * SLOT);
+  const unsigned glut_lds = (unsigned)(size_t)(lds_ptr)glut;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
@@ -136,8 +137,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(ConvParams p, int nslices,
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         } else if (act == kActGelu) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_lut(v[e], glut);
+          gelu_lut8_lds(v, glut_lds);
         }
         union { bf16x8 h; u32x4 u; } o;
 #pragma unroll
