@@ -119,6 +119,10 @@ int ttr_set_tuning(const char* key, int value);
  * counters, [2] wait for candidates / row extremes, [3] calipers, [4] crop rectangles + PARSeq enqueue, [5] wait for the GPU,
  * [6] event read-back, [7] token decode */
 void ttr_last_host_us(ttr_engine* e, float out[8]);
+/* test hook for mlp_fused.hip (bf16 engines): x_out = x + fc2(GELU(fc1(LayerNorm(x)))) over f32 rows [M][384] with weights
+ * w1 [1536][384], w2 [384][1536] (rounded to bf16 inside); nln_out (may be NULL) = LayerNorm(x_out; nln_g, nln_b), bf16 values as f32 */
+int ttr_dbg_mlp(ttr_engine* e, const float* x, int M, const float* ln_g, const float* ln_b, float eps, const float* w1, const float* b1, const float* w2,
+                const float* b2, const float* nln_g, const float* nln_b, float* x_out, float* nln_out);
 int ttr_dbg_dec_stamps(unsigned long long* out);
 /* Times one conv / linear layer on device-generated random data (no host traffic): average
  * microseconds per launch over `iters` back-to-back launches.  f32_resid != 0 selects the PARSeq

@@ -1,0 +1,46 @@
+"""mlp_fused.hip against a float64 numpy restatement with the kernel's rounding points (bf16 LayerNorm output, bf16
+hidden activation, fp32 everything else)."""
+import numpy as np
+import pytest
+import torch
+from scipy.special import erf
+
+pytestmark = pytest.mark.gpu
+
+
+def bf(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+def ln(x, g, b, eps):
+    x = x.astype(np.float64)
+    mu = x.mean(-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(-1, keepdims=True)
+    return (x - mu) / np.sqrt(var + eps) * g + b
+
+
+def ref_mlp(x, ln_g, ln_b, w1, b1, w2, b2, nln_g, nln_b, eps=1e-6):
+    y = bf(ln(x, ln_g, ln_b, eps)).astype(np.float64)
+    h = y @ bf(w1).astype(np.float64).T + b1
+    h = bf(0.5 * h * (1 + erf(h / np.sqrt(2)))).astype(np.float64)
+    out = x.astype(np.float64) + h @ bf(w2).astype(np.float64).T + b2
+    return out, ln(out, nln_g, nln_b, eps)
+
+
+@pytest.mark.parametrize("M", [128, 37, 128 * 300 + 77])
+def test_mlp_fused_against_numpy(eng_bf16, M):
+    rng = np.random.default_rng(M)
+    x = rng.standard_normal((M, 384)).astype(np.float32) * 1.5 + rng.standard_normal((1, 384)).astype(np.float32)
+    ln_g = (1 + 0.2 * rng.standard_normal(384)).astype(np.float32); ln_b = (0.1 * rng.standard_normal(384)).astype(np.float32)
+    w1 = (rng.standard_normal((1536, 384)) / np.sqrt(384)).astype(np.float32); b1 = (0.2 * rng.standard_normal(1536)).astype(np.float32)
+    w2 = (rng.standard_normal((384, 1536)) / np.sqrt(1536)).astype(np.float32); b2 = (0.2 * rng.standard_normal(384)).astype(np.float32)
+    ng = (1 + 0.2 * rng.standard_normal(384)).astype(np.float32); nb = (0.1 * rng.standard_normal(384)).astype(np.float32)
+    out, nout = eng_bf16.dbg_mlp(x, ln_g, ln_b, w1, b1, w2, b2, ng, nb)
+    rows = slice(0, M) if M < 1000 else np.r_[0:300, M - 300:M]
+    ro, rn = ref_mlp(x[rows], ln_g, ln_b, w1, b1, w2, b2, ng, nb)
+    # bf16 boundary flips of single hidden units move an output by <= |w2| * ulp ~ 1e-3
+    assert np.abs(out[rows] - ro).max() < 0.02, np.abs(out[rows] - ro).max()
+    assert np.abs(nout[rows] - rn).max() < 0.04
+    assert np.isfinite(out).all()
+    out2, _ = eng_bf16.dbg_mlp(x, ln_g, ln_b, w1, b1, w2, b2)
+    assert np.array_equal(out, out2)

@@ -107,3 +107,28 @@ def test_layernorm_fused_into_skinny_gemm_matches_separate_kernels(eng_bf16):
     assert same_path.mean() >= 0.9
     assert np.abs(a1[same_path] - a0[same_path]).max() < 0.25
     assert np.array_equal(i0[same_path], i1[same_path])
+
+
+@pytest.mark.parametrize("n", [45, 3])
+def test_fused_mlp_block_matches_separate_kernels(eng_bf16, n):
+    """mlp_fused.hip (norm2 + fc1 + GELU + fc2 + residual + next LayerNorm in one kernel, hidden activation in registers) vs
+    layernorm_kernel + gemm_ws + gemm2: same rounding points, fp32 summation order differs.  45 crops = 45 row panels;
+    3 crops = fewer panels than CUs."""
+    rng = np.random.default_rng(13)
+    crops = rng.integers(0, 256, (n, 32, 128, 3), dtype=np.uint8)
+    try:
+        assert eng_bf16.lib.ttr_set_tuning(b"mlp_fused", 0) == 0
+        l0, a0, i0 = eng_bf16.parseq_logits(crops, want_ar=True)
+        assert eng_bf16.lib.ttr_set_tuning(b"mlp_fused", 2) == 0          # 2: also below the row count where it pays
+        l1, a1, i1 = eng_bf16.parseq_logits(crops, want_ar=True)
+        l2, a2, i2 = eng_bf16.parseq_logits(crops, want_ar=True)
+    finally:
+        eng_bf16.lib.ttr_set_tuning(b"mlp_fused", 1)
+    assert np.isfinite(a1).all() and np.isfinite(l1).all()
+    assert np.array_equal(a1, a2) and np.array_equal(l1, l2)              # run to run identical (no race in the weight ring)
+    # A changed fp32 summation order anywhere in the 12-block encoder moves these random-noise crops' logits by ~0.25 (the same
+    # spread as between the two GEMM kernel generations); the kernel's own accuracy is pinned in test_gpu_mlp.py.
+    assert np.abs(a1[:, 0] - a0[:, 0]).max() < 0.6                        # step 0: no token feedback yet
+    same_path = (a0.argmax(-1) == a1.argmax(-1)).all(1)
+    assert same_path.mean() >= 0.5
+    assert np.abs(a1[same_path] - a0[same_path]).max() < 0.6

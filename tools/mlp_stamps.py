@@ -1,0 +1,24 @@
+"""GPU box tool: phase stamps of mlp_fused (workgroup 0, wave 0, first panel) + launch time."""
+import ctypes as C, os, sys, tempfile, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tuatara_amd import weights as W
+from tuatara_amd.engine import Engine
+d = tempfile.mkdtemp(); W.make_synthetic_weights(d, seed=0, structured=False)
+eng = Engine(d, precision="bf16")
+assert eng.lib.ttr_set_tuning(b"dec_stamps", 3) == 0
+M = (int(sys.argv[1]) if len(sys.argv) > 1 else 1280) * 128
+rng = np.random.default_rng(0)
+x = rng.standard_normal((M, 384)).astype(np.float32)
+g = np.ones(384, np.float32); b = np.zeros(384, np.float32)
+w1 = (rng.standard_normal((1536, 384)) / 20).astype(np.float32); b1 = np.zeros(1536, np.float32)
+w2 = (rng.standard_normal((384, 1536)) / 40).astype(np.float32); b2 = np.zeros(384, np.float32)
+eng.dbg_mlp(x, g, b, w1, b1, w2, b2, g, b)
+buf = (C.c_ulonglong * (26 * 16))()
+assert eng.lib.ttr_dbg_dec_stamps(buf) == 0
+t = np.array(buf[:384], dtype=np.uint64).reshape(48, 8).astype(np.float64)
+names = ["wait+barrier", "issue 12 DMA", "GEMM1", "GELU", "GEMM2"]
+dt = np.diff(t[4:44, :6], axis=1)
+print("per-chunk period", np.diff(t[4:44, 0]).mean(), "cycles")
+for n, v in zip(names, dt.mean(0)):
+    print(f"   {n:14s} {v:8.0f}")

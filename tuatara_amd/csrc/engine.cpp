@@ -44,6 +44,8 @@ void hip_fail(const char* what, hipError_t e, const char* file, int line) {
 static thread_local std::string g_last_error;
 static unsigned long long* g_dec_dbg = nullptr;   // device buffer for dec_ar phase stamps (diagnostics)
 static int g_dbg_bf16_out = 0;     // ttr_dbg_conv on a bf16 engine: take the kernel's bf16 output (the path the engine uses) instead of the f32 one
+static int g_mlp_min_rows = 49152;   // = 384 crops
+static int g_mlp_fused = 1;        // bf16 encoder: norm2 + fc1 + GELU + fc2 + residual (+ the next LayerNorm) as one kernel (mlp_fused.hip)
 static int g_ln_fuse = 1;          // bf16 decoder steps: LayerNorm computed inside the skinny GEMM's loader (gemm_sk ln_in)
 static int g_fuse_first = 1;       // bf16: CRAFT conv1_1 fused into conv1_2's loader (conv3p FIRST)
 static int g_enc_chunk = 0;        // crops per encoder group (0 = all crops at once)
@@ -257,6 +259,7 @@ struct Engine {
   // PARSeq
   std::map<std::string, Linear> pq;               // linears by upstream name
   std::map<std::string, DevBuf> pqf;              // f32 vectors (LayerNorm params, pos embed, ...)
+  DevBuf fc2_packed[12];                          // bf16 engines: encoder fc2 weights chunk-major [48][384][32] for mlp_fused.hip
   DevBuf qself;                                   // f32 [26][384]
 
   // workspaces
@@ -381,6 +384,15 @@ struct Engine {
       lin(p + "proj", p + "attn.proj.weight", p + "attn.proj.bias", E, E);
       lin(p + "fc1", p + "mlp.fc1.weight", p + "mlp.fc1.bias", 4 * E, E);
       lin(p + "fc2", p + "mlp.fc2.weight", p + "mlp.fc2.bias", E, 4 * E);
+      if (prec == kBF16) {   // W2p[c][o][j] = W2[o][32 c + j]: the 32 hidden units of chunk c are one contiguous 24 KiB slab
+        const auto& w = wf.get(p + "mlp.fc2.weight", (size_t)E * 4 * E);
+        std::vector<uint16_t> h((size_t)E * 4 * E);
+        for (int c = 0; c < 48; ++c)
+          for (int o = 0; o < E; ++o)
+            for (int j = 0; j < 32; ++j) h[((size_t)c * E + o) * 32 + j] = f32_to_bf16_rne(w.data[(size_t)o * 4 * E + c * 32 + j]);
+        fc2_packed[i].ensure(h.size() * 2);
+        TTR_HIP_CHECK(hipMemcpy(fc2_packed[i].p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+      }
     }
     vec("encoder.norm.weight", E); vec("encoder.norm.bias", E);
     const std::string d = "decoder.layers.0.";
@@ -622,22 +634,38 @@ struct Engine {
     gemm(pq.at("patch"), patches, M, nullptr, 0, kActNone, x, E, pqf.at("encoder.pos_embed").as<float>(), E, 128);
     // The 12 encoder blocks run over groups of crops so that a group's widest intermediates (qkv, the MLP hidden) are
     // re-read from the 256 MiB Infinity Cache rather than from HBM (g_enc_chunk crops per group; 0 = one group).
-    const int CH = g_enc_chunk > 0 ? g_enc_chunk : N;
+    // the fused MLP block needs a panel of 128 rows per CU to fill the chip: below ~2 panels per CU the separate GEMMs win
+    const bool mlp_fused = prec == kBF16 && gemm_config() >= 0 && (g_mlp_fused == 2 || (g_mlp_fused == 1 && M >= g_mlp_min_rows));
+    const int CH = (g_enc_chunk > 0 && !mlp_fused) ? g_enc_chunk : N;
     for (int c0 = 0; c0 < N; c0 += CH) {
       const int nc = std::min(CH, N - c0), Mc = nc * 128;
       float* xc = x + (size_t)c0 * 128 * E;
+      if (mlp_fused) ln(xc, "encoder.blocks.0.norm1", 1e-6f, t384, Mc);
       for (int l = 0; l < 12; ++l) {
         std::string p = "encoder.blocks." + std::to_string(l) + ".";
-        ln(xc, p + "norm1", 1e-6f, t384, Mc);
+        if (!mlp_fused) ln(xc, p + "norm1", 1e-6f, t384, Mc);
         gemm(pq.at(p + "qkv"), t384, Mc, tbig, 3 * E, kActNone);
         launch_attn_enc(prec, tbig, att, nc, stream);
         gemm(pq.at(p + "proj"), att, Mc, nullptr, 0, kActNone, xc, E, xc, E, 0);
+        if (mlp_fused) {
+          // norm2 + fc1 + GELU + fc2 + residual in one kernel; it also leaves the next LayerNorm (the next block's norm1, or
+          // the encoder's final norm = the decoder's memory) in t384
+          const std::string nx = l < 11 ? "encoder.blocks." + std::to_string(l + 1) + ".norm1" : std::string("encoder.norm");
+          MlpParams q{};
+          q.x = xc; q.x_out = xc; q.M = Mc;
+          q.ln_g = pqf.at(p + "norm2.weight").as<float>(); q.ln_b = pqf.at(p + "norm2.bias").as<float>(); q.ln_eps = 1e-6f;
+          q.w1 = pq.at(p + "fc1").w.as<bf16>(); q.b1 = pq.at(p + "fc1").b.as<float>();
+          q.w2p = fc2_packed[l].as<bf16>(); q.b2 = pq.at(p + "fc2").b.as<float>();
+          q.nln_g = pqf.at(nx + ".weight").as<float>(); q.nln_b = pqf.at(nx + ".bias").as<float>(); q.nln_eps = 1e-6f; q.nln_out = (bf16*)t384;
+          timed(2.0 * Mc * E * 4 * E * 2, [&] { launch_mlp_fused(q, stream); });
+          continue;
+        }
         ln(xc, p + "norm2", 1e-6f, t384, Mc);
         gemm(pq.at(p + "fc1"), t384, Mc, tbig, 4 * E, kActGelu);
         gemm(pq.at(p + "fc2"), tbig, Mc, nullptr, 0, kActNone, xc, E, xc, E, 0);
       }
     }
-    ln(x, "encoder.norm", 1e-6f, t384, M);                       // memory
+    if (!mlp_fused) ln(x, "encoder.norm", 1e-6f, t384, M);       // memory
     void* kvmem = (pq_ws[5].ensure((size_t)M * 768 * es), pq_ws[5].p);
     gemm(pq.at("cross_kv"), t384, M, kvmem, 768, kActNone);
 
@@ -1112,6 +1140,41 @@ int ttr_dbg_conv(ttr_engine* e, const float* in0, int C0, const float* in1, int 
   TTR_GUARD_END(-1)
 }
 
+int ttr_dbg_mlp(ttr_engine* e, const float* x, int M, const float* ln_g, const float* ln_b, float eps, const float* w1, const float* b1, const float* w2,
+                const float* b2, const float* nln_g, const float* nln_b, float* x_out, float* nln_out) {
+  TTR_GUARD_BEGIN
+  Engine& E = *e->e;
+  std::lock_guard<std::mutex> lk(E.mu);
+  if (E.prec != kBF16) throw std::runtime_error("ttr_dbg_mlp: bf16 engines only");
+  const int D = 384, H = 1536;
+  DevBuf dx, dout, dg, db, dw1, db1, dw2, db2, dng, dnb, dn;
+  auto upf = [&](DevBuf& d, const float* src, size_t n) { d.ensure(n * 4); TTR_HIP_CHECK(hipMemcpy(d.p, src, n * 4, hipMemcpyHostToDevice)); };
+  upf(dx, x, (size_t)M * D); upf(dg, ln_g, D); upf(db, ln_b, D); upf(db1, b1, H); upf(db2, b2, D);
+  if (nln_out) { upf(dng, nln_g, D); upf(dnb, nln_b, D); dn.ensure((size_t)M * D * 2); }
+  std::vector<uint16_t> h((size_t)H * D);
+  for (size_t i = 0; i < h.size(); ++i) h[i] = f32_to_bf16_rne(w1[i]);
+  dw1.ensure(h.size() * 2); TTR_HIP_CHECK(hipMemcpy(dw1.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  for (int c = 0; c < 48; ++c)
+    for (int o = 0; o < D; ++o)
+      for (int j = 0; j < 32; ++j) h[((size_t)c * D + o) * 32 + j] = f32_to_bf16_rne(w2[(size_t)o * H + c * 32 + j]);
+  dw2.ensure(h.size() * 2); TTR_HIP_CHECK(hipMemcpy(dw2.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  dout.ensure((size_t)M * D * 4);
+  MlpParams q{};
+  q.x = dx.as<float>(); q.x_out = dout.as<float>(); q.M = M; q.ln_g = dg.as<float>(); q.ln_b = db.as<float>(); q.ln_eps = eps;
+  q.w1 = dw1.as<bf16>(); q.b1 = db1.as<float>(); q.w2p = dw2.as<bf16>(); q.b2 = db2.as<float>();
+  if (nln_out) { q.nln_g = dng.as<float>(); q.nln_b = dnb.as<float>(); q.nln_eps = eps; q.nln_out = dn.as<bf16>(); }
+  launch_mlp_fused(q, E.stream);
+  TTR_HIP_CHECK(hipMemcpyAsync(x_out, dout.p, (size_t)M * D * 4, hipMemcpyDeviceToHost, E.stream));
+  TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
+  if (nln_out) {
+    std::vector<uint16_t> hb((size_t)M * D);
+    TTR_HIP_CHECK(hipMemcpy(hb.data(), dn.p, hb.size() * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < hb.size(); ++i) { const uint32_t u = (uint32_t)hb[i] << 16; memcpy(&nln_out[i], &u, 4); }
+  }
+  return 0;
+  TTR_GUARD_END(-1)
+}
+
 int ttr_dbg_conv_pool(ttr_engine* e, const float* in0, int C0, int B, int H, int W, int ks, const float* wgt, const float* bias, int Cout, int act,
                       int pool_relu, float* out_full, float* out_pool) {
   TTR_GUARD_BEGIN
@@ -1156,6 +1219,8 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "enc_chunk") g_enc_chunk = value;
   else if (k == "fuse_first") g_fuse_first = value;
   else if (k == "ln_fuse") g_ln_fuse = value;
+  else if (k == "mlp_fused") g_mlp_fused = value;   // 0 off, 1 from mlp_min_rows rows on, 2 always
+  else if (k == "mlp_min_rows") g_mlp_min_rows = value;
   else if (k == "ws_dbg_flags") set_gemm_ws_dbg_flags(value);
   else if (k == "ws_lean") set_gemm_ws_lean(value);
   else if (k == "store_policy") set_store_policy(value);
@@ -1170,7 +1235,8 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "dec_stamps") {   // value != 0: allocate the stamp buffer; read it back with ttr_dev_download via ttr_dbg_dec_stamps
     if (value && !g_dec_dbg) { void* d = nullptr; if (hipMalloc(&d, 26 * 16 * 8) != hipSuccess) return -1; (void)hipMemset(d, 0, 26 * 16 * 8); g_dec_dbg = (unsigned long long*)d; }
     if (!value) g_dec_dbg = nullptr;
-    set_gemm_ws_stamps(value == 2 ? g_dec_dbg : nullptr);   // 2: the same buffer takes gemm_ws stamps instead
+    set_gemm_ws_stamps(value == 2 ? g_dec_dbg : nullptr);
+    set_mlp_stamps(value == 3 ? g_dec_dbg : nullptr);       // 3: ... or mlp_fused stamps   // 2: the same buffer takes gemm_ws stamps instead
   }
   else return -1;
   return 0;

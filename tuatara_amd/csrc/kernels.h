@@ -24,6 +24,7 @@ const void* gelu_lut_for_current_device();
 const char* gemm_sk_check(const ConvParams& p);
 void launch_gemm_sk(const ConvParams& p, hipStream_t s);
 void set_skinny_max_rows(int m);   // problems with M <= m rows go to gemm_sk (0 = never)
+void set_mlp_stamps(unsigned long long* dev_buf);       // >= 48*8 u64 or null
 void set_gemm_ws_stamps(unsigned long long* dev_buf);   // >= 2*24*8 u64, or null: phase stamps of gemm_ws workgroup 0
 extern int g_store_policy;          // cache policy of the big streaming output stores: 0 default, 1 nt, 2 sc0 sc1 nt
 void set_store_policy(int v);
@@ -85,6 +86,20 @@ void launch_dec_cross_attn(Precision prec, const void* q, const void* kvmem, voi
 // tokens[n*tok_ld + col] = argmax over C of logits[n*ld ..]
 void launch_argmax(const float* logits, int ld, int C, int* tokens, int tok_ld, int col, int N, hipStream_t s);
 void launch_fill_i32(int* p, int value, int n, int stride, hipStream_t s);
+
+// ---- mlp_fused.hip: x_out = x + fc2(GELU(fc1(LayerNorm(x)))) [+ y = LayerNorm_next(x_out)] for the ViT encoder blocks (bf16, E = 384)
+struct MlpParams {
+  const float* x;          // [M][384] f32 residual stream
+  float* x_out;            // [M][384] f32; may be x (every row is read and written by one wave)
+  const float *ln_g, *ln_b; float ln_eps;            // the block's norm2
+  const bf16* w1; const float* b1;                   // fc1 [1536][384], [1536]
+  const bf16* w2p; const float* b2;                  // fc2 packed [48][384][32] (pack_fc2_chunks), [384]
+  const float *nln_g, *nln_b; float nln_eps; bf16* nln_out;   // optional: LayerNorm of x_out -> bf16 [M][384]
+  const void* gelu_lut;    // set by the launcher
+  unsigned long long* dbg; // optional [48][8] shader-clock stamps of workgroup 0 / wave 0 over its first panel (diagnostics)
+  int M;
+};
+void launch_mlp_fused(const MlpParams& p, hipStream_t s);
 
 // ---- dec_fused.hip: the whole autoregressive decode (<= 26 steps) of PARSeq as one persistent kernel (bf16)
 struct DecArParams {

@@ -1,0 +1,383 @@
+// The MLP half of a PARSeq ViT encoder block as ONE kernel (bf16 MFMA, f32 residual stream):
+//
+//   x_out = x + fc2( GELU( fc1( LayerNorm_2(x) ) ) )            and, optionally,  y = LayerNorm_next(x_out)  (bf16)
+//
+// (timm Block.forward second half, run inside the TorchScript module called at tuatara.cpp:307; 12 blocks, E = 384,
+// hidden = 1536).  As separate launches (layernorm_kernel, gemm_ws fc1, gemm2 fc2) this is 2.0 GB of HBM traffic per
+// block at 1280 crops — the [M][1536] hidden activation alone is written and read back (1.0 GB) — and fc2 / the
+// LayerNorm run at the HBM roofline.  Fused, a row panel's hidden activation never leaves the registers:
+//
+//   * a workgroup = 4 waves (one per SIMD, so each wave may use the whole 512-entry register file) owns a panel of
+//     128 rows, wave w rows 32w .. 32w+31 as two MFMA column tiles.  The wave normalises its rows straight from the f32
+//     residual stream into MFMA B fragments (96 VGPRs, k = all 384 channels) — LayerNorm costs no extra pass.
+//   * the hidden dimension is walked in 48 chunks of 32 units.  Per chunk GEMM1 (A = 32 rows of W1 x 384 k, 48 MFMAs)
+//     leaves, per lane, 8 consecutive hidden units of one row in the accumulators (weight rows are permuted while
+//     staging, as in gemm2.hip); bias is the MFMA's C operand, GELU and the bf16 rounding happen in registers and the
+//     result IS the B fragment (k = 8 (lane>>4) + e) of GEMM2 (A = 384 rows of W2 x 32 k, 48 MFMAs) — no LDS round trip.
+//     The [32 rows x 384] f32 output tile of the wave lives in 192 accumulator registers for the whole panel.
+//   * only the weights stream: chunk c = W1[32c..32c+31][:] (24 KiB, contiguous) + W2[:, 32c..32c+31] (24 KiB, from a
+//     chunk-major copy packed at load time) go global -> LDS by LDS-DMA into a 3-slot ring, two chunks ahead, ONE barrier
+//     per chunk (= per 96 MFMAs of a wave).  Every workgroup streams the same 2.4 MB in the same order: L2 hits.
+//   * epilogue: + bias2 + residual (f32, re-read), f32 store (128 bytes per row per instruction), and the next
+//     LayerNorm (next block's norm1, or the encoder's final norm) on the rows still in registers.
+//
+// Rounding points are those of the separate kernels: LayerNorm output and the hidden activation are rounded to bf16,
+// sums are fp32, the residual stream is fp32.  Results differ from the unfused path by fp32 summation order only.
+#include "common.h"
+#include "kernels.h"
+
+namespace ttr {
+
+namespace {
+typedef __attribute__((address_space(3))) void* lds_ptr;
+constexpr int E = 384, HID = 1536, CH = 32, NCH = HID / CH;   // 48 chunks of 32 hidden units
+constexpr int W1B = CH * E * 2;                               // W1 chunk image [32 rows][768 B]
+constexpr int W2B = E * CH * 2;                               // W2 chunk image [384 rows][64 B]
+constexpr int SLOT = W1B + W2B, NSLOT = 3;
+constexpr int LUT_OFF = NSLOT * SLOT;                         // GELU table, 8 KiB
+constexpr int B1_OFF = LUT_OFF + 8192;                        // fc1 bias, f32 [1536]
+constexpr int MLP_LDS = B1_OFF + HID * 4;                     // 161,792 B of the 160 KiB
+constexpr int BM = 128;
+static_assert(MLP_LDS <= 160 * 1024, "LDS budget");
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t m_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+// LDS reads as inline asm: hipcc puts s_waitcnt vmcnt(0) in front of every LDS read it can see once LDS-DMA loads are in
+// flight (it cannot prove they do not alias), which would serialise the weight stream.  Waits are placed by hand below.
+#define MLP_RD128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define MLP_WAIT8(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]))
+}  // namespace
+
+__global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane & 15, g = lane >> 4;
+  const int npanels = (p.M + BM - 1) / BM;
+  if ((int)blockIdx.x >= npanels) return;
+  const int my_n = (npanels - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = my_n * (NCH + 1);                          // ring items this workgroup walks: 49 per panel (see the chunk loop)
+
+  for (int i = tid; i < 512; i += 256) reinterpret_cast<uint4*>(smem + LUT_OFF)[i] = reinterpret_cast<const uint4*>(p.gelu_lut)[i];
+  for (int i = tid; i < HID / 4; i += 256) reinterpret_cast<float4*>(smem + B1_OFF)[i] = reinterpret_cast<const float4*>(p.b1)[i];
+
+  // ---- weight stream: this wave's 6 + 6 one-KiB pieces of a chunk.  Source offsets are relative to the chunk's base.
+  // W1 image: LDS row R = 16 jj + q' holds hidden unit (q'>>2)*8 + jj*4 + (q'&3) of the chunk; 16-byte chunk ch of a row sits
+  // at position (ch & ~15) | ((ch & 15) ^ (R & 15))   (768-byte rows: every row starts on bank 0)
+  // W2 image: LDS row R' = 16 ot + q' holds output channel (ot>>1)*32 + (q'>>2)*8 + (ot&1)*4 + (q'&3); chunk gch of the
+  // 64-byte row sits at position gch ^ ((R'>>1) & 3)
+  const __amdgpu_buffer_rsrc_t rs1 = m_rsrc(p.w1, (unsigned)(HID * E * 2));
+  const __amdgpu_buffer_rsrc_t rs2 = m_rsrc(p.w2p, (unsigned)(HID * E * 2));
+  unsigned src1[6], src2;   // the wave's W2 pieces are 4,096 source bytes apart (two output-channel tiles): one offset + a scalar
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int pp = wave + 4 * j;
+    const int o = pp * 1024 + lane * 16;
+    const int R = o / 768, cp = (o - R * 768) >> 4;
+    const int ch = (cp & ~15) | ((cp & 15) ^ (R & 15));
+    const int nl = ((R & 15) >> 2) * 8 + (R >> 4) * 4 + (R & 3);
+    src1[j] = (unsigned)((nl * E + ch * 8) * 2);
+  }
+  {
+    const int R2 = wave * 16 + (lane >> 2), ot = R2 >> 4, q2 = R2 & 15;
+    const int oc = (ot >> 1) * 32 + (q2 >> 2) * 8 + (ot & 1) * 4 + (q2 & 3);
+    const int gsrc = (lane & 3) ^ ((R2 >> 1) & 3);
+    src2 = (unsigned)((oc * CH + gsrc * 8) * 2);
+  }
+  auto issue = [&](int Gi) {                                   // item Gi: W1 chunk i (i < 48) and W2 chunk i - 1 (i >= 1) of its panel
+    const int ii = Gi % (NCH + 1), slot = Gi % NSLOT;
+    unsigned char* sb = smem + slot * SLOT + wave * 1024;
+    if (ii < NCH) {
+      const int cb = ii * W1B;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr)(sb + j * 4096), 16, src1[j], cb, 0, 0);
+    }
+    if (ii >= 1) {
+      const int cb = (ii - 1) * W2B;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_ptr)(sb + W1B + j * 4096), 16, src2, cb + j * 4096, 0, 0);
+    }
+  };
+
+  // ---- fragment read addresses relative to a slot
+  unsigned w1a[4];
+#pragma unroll
+  for (int k3 = 0; k3 < 4; ++k3) w1a[k3] = (unsigned)(q * 768 + (((k3 * 4 + g) ^ q) << 4));
+  const unsigned w2a = (unsigned)(W1B + q * 64 + ((g ^ ((q >> 1) & 3)) << 4));
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smem;
+  const unsigned lut_lds = lds0 + LUT_OFF;
+  const unsigned b1_lds = lds0 + B1_OFF + (unsigned)(g * 8 * 4);
+
+  issue(0);
+  if (total > 1) issue(1);
+  __syncthreads();                                             // table and bias staged
+
+  int G = 0;
+  for (int pi = 0; pi < my_n; ++pi) {
+    const int panel = (int)blockIdx.x + pi * (int)gridDim.x;
+    const int row0 = panel * BM + wave * 32;
+
+    // ---- LayerNorm of this wave's 32 rows -> B fragments.  Lane (q, g) holds, of row 16 rt + q, channels 32 ks + 8 g + e.
+    bf16x8 xf[2][12];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int row = min(row0 + rt * 16 + q, p.M - 1);
+      const float* xr = p.x + (size_t)row * E + g * 8;
+      float v[12][8];
+#pragma unroll
+      for (int ks = 0; ks < 12; ++ks) {
+        const float4 a = *reinterpret_cast<const float4*>(xr + ks * 32), b = *reinterpret_cast<const float4*>(xr + ks * 32 + 4);
+        v[ks][0] = a.x; v[ks][1] = a.y; v[ks][2] = a.z; v[ks][3] = a.w; v[ks][4] = b.x; v[ks][5] = b.y; v[ks][6] = b.z; v[ks][7] = b.w;
+      }
+      float s = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 12; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[ks][e];
+      s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+      const float mean = s * (1.f / E);
+      float s2 = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 12; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[ks][e] - mean; s2 += d * d; }
+      s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+      const float rstd = rsqrtf(s2 * (1.f / E) + p.ln_eps);
+#pragma unroll
+      for (int ks = 0; ks < 12; ++ks) {
+        const float4 g0 = *reinterpret_cast<const float4*>(p.ln_g + ks * 32 + g * 8), g1 = *reinterpret_cast<const float4*>(p.ln_g + ks * 32 + g * 8 + 4);
+        const float4 t0 = *reinterpret_cast<const float4*>(p.ln_b + ks * 32 + g * 8), t1 = *reinterpret_cast<const float4*>(p.ln_b + ks * 32 + g * 8 + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)((v[ks][e] - mean) * rstd * gg[e] + bb[e]);
+        xf[rt][ks] = o;
+      }
+    }
+
+    f32x4 acc2[2][24];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ot = 0; ot < 24; ++ot) acc2[rt][ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#define MLP_STAMP(ph) do { if (p.dbg && blockIdx.x == 0 && tid == 0 && pi == 0 && i < NCH) p.dbg[i * 8 + (ph)] = __builtin_readcyclecounter(); } while (0)
+// Fragment groups of 4 (8 MFMAs each), three register buffers, reads two groups ahead.  GEMM1 group n = k-steps 2n, 2n+1 x the
+// two 16-row weight tiles; GEMM2 group n = output-channel tiles 4n .. 4n+3.
+#define MLP_G1(dst, n)                                                                                                   \
+  MLP_RD128(dst[0], a1v[(2 * (n)) & 3], ((2 * (n)) >> 2) * 256);     MLP_RD128(dst[1], a1v[(2 * (n)) & 3], 12288 + ((2 * (n)) >> 2) * 256); \
+  MLP_RD128(dst[2], a1v[(2 * (n) + 1) & 3], ((2 * (n) + 1) >> 2) * 256); MLP_RD128(dst[3], a1v[(2 * (n) + 1) & 3], 12288 + ((2 * (n) + 1) >> 2) * 256);
+#define MLP_G2(dst, n)                                                                                                   \
+  MLP_RD128(dst[0], a2, (4 * (n) + 0) * 1024); MLP_RD128(dst[1], a2, (4 * (n) + 1) * 1024);                              \
+  MLP_RD128(dst[2], a2, (4 * (n) + 2) * 1024); MLP_RD128(dst[3], a2, (4 * (n) + 3) * 1024);
+#define MLP_M1(src, n)                                                                                                   \
+  _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2)                                                                       \
+    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                                     \
+      _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                                                   \
+        accn[rt][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(src[k2 * 2 + jj], xf[rt][2 * (n) + k2], accn[rt][jj], 0, 0, 0);
+#define MLP_M2(src, n)                                                                                                   \
+  _Pragma("unroll") for (int o4 = 0; o4 < 4; ++o4)                                                                       \
+    _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                                                     \
+      acc2[rt][4 * (n) + o4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(src[o4], hf[rt], acc2[rt][4 * (n) + o4], 0, 0, 0);
+#define MLP_WAITF(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]))
+#define MLP_WAITFT(n, f, t) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]))
+    // GELU of one quarter (4 hidden units of one row tile) around its table read: A = index + read request, B = interpolate,
+    // multiply, round to bf16 into half of the row tile's B fragment
+    float u4[4];
+    float2 t4[4];
+    auto gelu_a = [&](const f32x4& acc) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        u4[e] = fmaf(__builtin_amdgcn_fmed3f(acc[e], -8.0f, 7.984375f), 64.0f, 512.0f);
+        const unsigned ad = lut_lds + ((unsigned)(int)u4[e] << 3);
+        asm volatile("ds_read_b64 %0, %1" : "=v"(t4[e]) : "v"(ad));
+      }
+    };
+    auto gelu_b = [&](const f32x4& acc, bf16x8& o, int half) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[half * 4 + e] = (bf16)(acc[e] * fmaf(__builtin_amdgcn_fractf(u4[e]), t4[e].y, t4[e].x));
+    };
+
+    // Software pipeline over the 48 hidden chunks: iteration i runs GEMM1 of chunk i with the GELU of chunk i-1 in the
+    // shadow of its MFMAs, then GEMM2 of chunk i-1.  Ring item G (49 per panel, G counts over the whole launch) =
+    // {W1 chunk i if i < 48, W2 chunk i-1 if i >= 1} in slot G % 3.
+    f32x4 accp[2][2];                                           // GEMM1 result of the previous iteration, before the activation
+    f32x4 accn[2][2];
+    bf16x8 f0[4], f1[4], f2[4];
+    bf16x8 hf[2];
+    unsigned a1v[4], a2;
+    // top of an iteration: item G has landed once at most the pieces of item G + 1 (12, or 6 at a panel edge) are still in
+    // flight — loads retire in order, and whatever the epilogue / prologue put on the queue since is younger still
+#define MLP_TOP()                                                                                          \
+  {                                                                                                        \
+    MLP_STAMP(0);                                                                                          \
+    if (G + 1 < total) {                                                                                   \
+      const int in = (G + 1) % (NCH + 1);                                                                  \
+      if (in == 0 || in == NCH) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                           \
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                               \
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+    __builtin_amdgcn_s_barrier(); /* everyone's pieces landed; slot (G+2)%3 = (G-1)%3 is free again */     \
+    MLP_STAMP(1);                                                                                          \
+    const unsigned sbase = lds0 + (unsigned)((G % NSLOT) * SLOT);                                          \
+    a1v[0] = sbase + w1a[0]; a1v[1] = sbase + w1a[1]; a1v[2] = sbase + w1a[2]; a1v[3] = sbase + w1a[3];    \
+    a2 = sbase + w2a;                                                                                      \
+  }
+    // the first fragments are requested before the DMA issue, whose ~80 cycles per piece hide their latency.  (The CU's address
+    // unit takes 16-20 cycles per 1-KiB piece and the four waves queue behind one another; issuing a third of the item after
+    // every fourth MFMA group instead, one wave at a time, cost more in spills than it saved.)
+#define MLP_HEAD1()                                                                                        \
+  {                                                                                                        \
+    const unsigned ba = b1_lds + (unsigned)(i * CH * 4);                                                   \
+    MLP_RD128(accn[0][0], ba, 0);                                                                          \
+    MLP_RD128(accn[0][1], ba, 16);                                                                         \
+    MLP_G1(f0, 0)                                                                                          \
+    MLP_G1(f1, 1)                                                                                          \
+    if (G + 2 < total) issue(G + 2);                                                                       \
+    MLP_STAMP(2);                                                                                          \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(accn[0][0]), "+v"(accn[0][1]), "+v"(f0[0]), "+v"(f0[1]), "+v"(f0[2]), "+v"(f0[3]), "+v"(f1[0]), "+v"(f1[1]), "+v"(f1[2]), "+v"(f1[3])); \
+    accn[1][0] = accn[0][0]; accn[1][1] = accn[0][1];                                                      \
+  }
+    int i = 0;
+    {                                                           // chunk 0: GEMM1 only
+      MLP_TOP()
+      MLP_HEAD1()
+      MLP_G1(f2, 2)  MLP_M1(f0, 0)
+      MLP_G1(f0, 3)  MLP_M1(f1, 1)
+      MLP_G1(f1, 4)  MLP_WAITF(8, f2);  MLP_M1(f2, 2)
+      MLP_G1(f2, 5)  MLP_WAITF(8, f0);  MLP_M1(f0, 3)
+      MLP_WAITF(4, f1);  MLP_M1(f1, 4)
+      MLP_WAITF(0, f2);  MLP_M1(f2, 5)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) { accp[rt][0] = accn[rt][0]; accp[rt][1] = accn[rt][1]; }
+      MLP_STAMP(5);
+      ++G;
+    }
+    for (i = 1; i < NCH; ++i, ++G) {                             // GEMM1(i) with GELU(i-1) in its shadow, then GEMM2(i-1)
+      MLP_TOP()
+      MLP_HEAD1()
+      // waits below: the group about to be multiplied and the table reads of the quarter about to be finished were issued
+      // before the newest 4 fragment reads, and LDS returns in order
+      MLP_G1(f2, 2)  gelu_a(accp[0][0]);                                   MLP_M1(f0, 0)
+      MLP_G1(f0, 3)  MLP_WAITFT(4, f2, t4);  gelu_b(accp[0][0], hf[0], 0);  gelu_a(accp[0][1]);  MLP_M1(f1, 1)
+      MLP_G1(f1, 4)  MLP_WAITFT(4, f0, t4);  gelu_b(accp[0][1], hf[0], 1);  gelu_a(accp[1][0]);  MLP_M1(f2, 2)
+      MLP_G1(f2, 5)  MLP_WAITFT(4, f1, t4);  gelu_b(accp[1][0], hf[1], 0);  gelu_a(accp[1][1]);  MLP_M1(f0, 3)
+      MLP_G2(f0, 0)  MLP_WAITFT(4, f2, t4);  gelu_b(accp[1][1], hf[1], 1);                       MLP_M1(f1, 4)
+      MLP_G2(f1, 1)  MLP_WAITF(8, f2);  MLP_M1(f2, 5)
+      MLP_STAMP(3);
+      MLP_G2(f2, 2)  MLP_WAITF(8, f0);  MLP_M2(f0, 0)
+      MLP_G2(f0, 3)  MLP_WAITF(8, f1);  MLP_M2(f1, 1)
+      MLP_G2(f1, 4)  MLP_WAITF(8, f2);  MLP_M2(f2, 2)
+      MLP_G2(f2, 5)  MLP_WAITF(8, f0);  MLP_M2(f0, 3)
+      MLP_WAITF(4, f1);  MLP_M2(f1, 4)
+      MLP_WAITF(0, f2);  MLP_M2(f2, 5)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) { accp[rt][0] = accn[rt][0]; accp[rt][1] = accn[rt][1]; }
+      MLP_STAMP(5);
+    }
+    {                                                           // after the last chunk: GELU + GEMM2 of chunk 47
+      MLP_TOP()
+      MLP_G2(f0, 0)
+      MLP_G2(f1, 1)
+      if (G + 2 < total) issue(G + 2);
+      gelu_a(accp[0][0]);  MLP_WAITFT(0, f0, t4);  gelu_b(accp[0][0], hf[0], 0);
+      gelu_a(accp[0][1]);  MLP_WAITFT(0, f1, t4);  gelu_b(accp[0][1], hf[0], 1);
+      gelu_a(accp[1][0]);  MLP_WAITFT(0, f0, t4);  gelu_b(accp[1][0], hf[1], 0);
+      gelu_a(accp[1][1]);  MLP_WAITFT(0, f1, t4);  gelu_b(accp[1][1], hf[1], 1);
+      MLP_G2(f2, 2)  MLP_M2(f0, 0)
+      MLP_G2(f0, 3)  MLP_M2(f1, 1)
+      MLP_G2(f1, 4)  MLP_WAITF(8, f2);  MLP_M2(f2, 2)
+      MLP_G2(f2, 5)  MLP_WAITF(8, f0);  MLP_M2(f0, 3)
+      MLP_WAITF(4, f1);  MLP_M2(f1, 4)
+      MLP_WAITF(0, f2);  MLP_M2(f2, 5)
+      __builtin_amdgcn_sched_barrier(0);
+      ++G;
+    }
+
+    // ---- epilogue: + bias2 + residual -> f32; lane holds, of row 16 rt + q, channels 32 pp + 8 g + e (pp = 0..11)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int row = row0 + rt * 16 + q;
+      const bool live = row < p.M;
+      const size_t ro = (size_t)min(row, p.M - 1) * E + g * 8;
+      float v[12][8];
+#pragma unroll
+      for (int pp = 0; pp < 12; ++pp) {
+        const float4 r0 = *reinterpret_cast<const float4*>(p.x + ro + pp * 32), r1 = *reinterpret_cast<const float4*>(p.x + ro + pp * 32 + 4);
+        const float4 c0 = *reinterpret_cast<const float4*>(p.b2 + pp * 32 + g * 8), c1 = *reinterpret_cast<const float4*>(p.b2 + pp * 32 + g * 8 + 4);
+        v[pp][0] = acc2[rt][2 * pp][0] + c0.x + r0.x; v[pp][1] = acc2[rt][2 * pp][1] + c0.y + r0.y;
+        v[pp][2] = acc2[rt][2 * pp][2] + c0.z + r0.z; v[pp][3] = acc2[rt][2 * pp][3] + c0.w + r0.w;
+        v[pp][4] = acc2[rt][2 * pp + 1][0] + c1.x + r1.x; v[pp][5] = acc2[rt][2 * pp + 1][1] + c1.y + r1.y;
+        v[pp][6] = acc2[rt][2 * pp + 1][2] + c1.z + r1.z; v[pp][7] = acc2[rt][2 * pp + 1][3] + c1.w + r1.w;
+      }
+      if (live) {
+#pragma unroll
+        for (int pp = 0; pp < 12; ++pp) {
+          float* op = p.x_out + ro + pp * 32;
+          *reinterpret_cast<float4*>(op) = make_float4(v[pp][0], v[pp][1], v[pp][2], v[pp][3]);
+          *reinterpret_cast<float4*>(op + 4) = make_float4(v[pp][4], v[pp][5], v[pp][6], v[pp][7]);
+        }
+      }
+      if (p.nln_out) {                                          // uniform
+        float s = 0.f;
+#pragma unroll
+        for (int pp = 0; pp < 12; ++pp)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s += v[pp][e];
+        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        const float mean = s * (1.f / E);
+        float s2 = 0.f;
+#pragma unroll
+        for (int pp = 0; pp < 12; ++pp)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float d = v[pp][e] - mean; s2 += d * d; }
+        s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+        const float rstd = rsqrtf(s2 * (1.f / E) + p.nln_eps);
+#pragma unroll
+        for (int pp = 0; pp < 12; ++pp) {
+          const float4 g0 = *reinterpret_cast<const float4*>(p.nln_g + pp * 32 + g * 8), g1 = *reinterpret_cast<const float4*>(p.nln_g + pp * 32 + g * 8 + 4);
+          const float4 t0 = *reinterpret_cast<const float4*>(p.nln_b + pp * 32 + g * 8), t1 = *reinterpret_cast<const float4*>(p.nln_b + pp * 32 + g * 8 + 4);
+          const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16)((v[pp][e] - mean) * rstd * gg[e] + bb[e]);
+          if (live) *reinterpret_cast<bf16x8*>(p.nln_out + ro + pp * 32) = o;
+        }
+      }
+    }
+  }
+}
+
+static unsigned long long* g_mlp_dbg = nullptr;
+void set_mlp_stamps(unsigned long long* d) { g_mlp_dbg = d; }
+
+const char* mlp_fused_check(const MlpParams& p) {
+  if (p.M <= 0) return "mlp_fused: bad row count";
+  if (!p.x || !p.x_out || !p.ln_g || !p.ln_b || !p.w1 || !p.b1 || !p.w2p || !p.b2 || !p.gelu_lut) return "mlp_fused: null operand";
+  if (p.nln_out && (!p.nln_g || !p.nln_b)) return "mlp_fused: next LayerNorm parameters";
+  const uintptr_t a = (uintptr_t)p.x | (uintptr_t)p.x_out | (uintptr_t)p.ln_g | (uintptr_t)p.ln_b | (uintptr_t)p.w1 | (uintptr_t)p.b1 | (uintptr_t)p.w2p |
+                      (uintptr_t)p.b2 | (uintptr_t)p.nln_out | (uintptr_t)p.nln_g | (uintptr_t)p.nln_b | (uintptr_t)p.gelu_lut;
+  if (a & 15) return "mlp_fused: operands must be 16-byte aligned";
+  return nullptr;
+}
+
+void launch_mlp_fused(const MlpParams& p_in, hipStream_t s) {
+  MlpParams p = p_in;
+  p.gelu_lut = gelu_lut_for_current_device();
+  p.dbg = g_mlp_dbg;
+  if (const char* e = mlp_fused_check(p)) throw std::runtime_error(e);
+  static bool once = false;
+  if (!once) {
+    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
+    once = true;
+  }
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  const int npanels = (p.M + BM - 1) / BM;
+  hipLaunchKernelGGL(mlp_fused_kernel, dim3(std::min(cus, npanels)), dim3(256), MLP_LDS, s, p);
+}
+
+}  // namespace ttr
