@@ -184,11 +184,11 @@ def main():
 
     if rank == 0:
         # HBM bytes of the CRAFT conv kernels per launch, from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE,
-        # gfx950 corrections applied; profiles/r01_pmc_craft.json says how) -- counters cannot be read from inside this process
+        # gfx950 corrections applied; profiles/r01_pmc_craft_b16.json says how) -- counters cannot be read from inside this process
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_craft.json")) as f:
-                traffic = json.load(f)["craft_conv_kernels"]["hbm_bytes_per_launch"] * min(P, 16)   # CRAFT launches cover <= 16 pages
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_craft_b16.json")) as f:   # measured on 16-page CRAFT groups
+                traffic = json.load(f)["craft_conv_kernels"]["hbm_bytes_per_launch"] * min(P, 16) / 16.0
         except Exception:
             pass
         total_pages = world * P * args.steps
@@ -209,7 +209,7 @@ def main():
             "stage_ms_last_step": {k: round(v, 3) for k, v in stage.items()},
             "roofline": {"kernel": "CRAFT convolutions: conv3p_kernel / gemm2_kernel / conv1_direct_kernel (+ igemm_kernel for the 32-channel head)", "bound": "mfma",
                          "achieved": craft_tflops, "peak": peak, "unit": "TFLOP/s",
-                         "frac": (craft_tflops / peak) if craft_tflops else None, "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, 1-page runs scaled to the batch)",
+                         "frac": (craft_tflops / peak) if craft_tflops else None, "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes over 16-page CRAFT groups, profiles/r01_pmc_craft_b16.json)",
                          "launches_per_step": c["launches"] / max(1, args.steps * NC), "avg_launch_us": c["ms"] * 1e3 / max(1, c["launches"]),
                          "algorithmic_gflop_per_page": CRAFT_GFLOP_PER_PAGE},
             "roofline_parseq_gemm": {"kernel": "gemm2_kernel: the ViT encoder GEMMs (+ cross-attention K/V projection and the refinement pass)", "bound": "mfma", "achieved": pq_tflops, "peak": peak,

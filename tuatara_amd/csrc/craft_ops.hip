@@ -11,18 +11,22 @@
 namespace ttr {
 
 // ------------------------------------------------------------------ resize + pad + swap
-__global__ void resize_pad_u8_kernel(const uint8_t* src, int sstride, ResizeGeom g, uint8_t* dst, int H, int W, int swap_rb) {
+// blockIdx.z = page of a batch of equally sized pages (source pages src_page bytes apart, canvases H*W*3 apart)
+__global__ void resize_pad_u8_kernel(const uint8_t* src, size_t src_page, int sstride, ResizeGeom g, uint8_t* dst, int H, int W, int swap_rb) {
   int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
   if (x >= W) return;
+  src += (size_t)blockIdx.z * src_page;
+  dst += (size_t)blockIdx.z * H * W * 3;
   uint8_t px[3] = {0, 0, 0};
   if (y < g.dh && x < g.dw) resize_pixel_u8c3(src, sstride, g, y, x, px);
   uint8_t* d = dst + ((size_t)y * W + x) * 3;
   d[0] = swap_rb ? px[2] : px[0]; d[1] = px[1]; d[2] = swap_rb ? px[0] : px[2];
 }
 
-void launch_resize_pad_u8(const uint8_t* src, int sh, int sw, int sstride, uint8_t* dst, int th, int tw, int H, int W, int swap_rb, hipStream_t s) {
+void launch_resize_pad_u8(const uint8_t* src, int sh, int sw, int sstride, uint8_t* dst, int th, int tw, int H, int W, int swap_rb, hipStream_t s,
+                          int pages, size_t src_page) {
   ResizeGeom g = make_resize_geom(sh, sw, th, tw);
-  hipLaunchKernelGGL(resize_pad_u8_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, src, sstride, g, dst, H, W, swap_rb);
+  hipLaunchKernelGGL(resize_pad_u8_kernel, dim3((W + 255) / 256, H, pages), dim3(256), 0, s, src, src_page, sstride, g, dst, H, W, swap_rb);
 }
 
 // ------------------------------------------------------------------ first layer im2col

@@ -276,7 +276,9 @@ struct Engine {
   int profiling = 0;                                   // 0 off, 1 = CRAFT conv launches only, 2 = every conv / GEMM launch
   int prof_stage = 0;                                  // 0 = CRAFT convs, 1 = PARSeq encoder (ViT) + batched decoder GEMMs, 2 = per-step AR decoder GEMMs
   std::vector<hipEvent_t> prof_pool;
-  struct ProfRec { int stage; double flops; };
+  struct ProfRec { int stage; double flops; int launches; };
+  bool seg_open = false;                               // profiling == 1: an event pair brackets a RUN of consecutive CRAFT conv launches
+  double seg_flops = 0; int seg_launches = 0;          // (an event record between two kernels costs ~8 us of idle GPU)
   std::vector<ProfRec> prof_recs;
   double prof_ms[3] = {0, 0, 0}, prof_flops[3] = {0, 0, 0};
   long prof_launches[3] = {0, 0, 0};
@@ -285,17 +287,29 @@ struct Engine {
     if (!profiling || (profiling == 1 && prof_stage != 0)) { launch(); return; }
     const size_t i = prof_recs.size();
     while (prof_pool.size() < 2 * (i + 1)) { hipEvent_t e; TTR_HIP_CHECK(hipEventCreate(&e)); prof_pool.push_back(e); }
+    if (profiling == 1) {   // the timed region of bench.py: one event pair per run of convolutions, closed by prof_break()
+      if (!seg_open) { TTR_HIP_CHECK(hipEventRecord(prof_pool[2 * i], stream)); seg_open = true; seg_flops = 0; seg_launches = 0; }
+      launch();
+      seg_flops += true_flops; ++seg_launches;
+      return;
+    }
     TTR_HIP_CHECK(hipEventRecord(prof_pool[2 * i], stream));
     launch();
     TTR_HIP_CHECK(hipEventRecord(prof_pool[2 * i + 1], stream));
-    prof_recs.push_back(ProfRec{prof_stage, true_flops});
+    prof_recs.push_back(ProfRec{prof_stage, true_flops, 1});
+  }
+  void prof_break() {       // call before any kernel that is not a CRAFT convolution, and at the end of CRAFT
+    if (!seg_open) return;
+    TTR_HIP_CHECK(hipEventRecord(prof_pool[2 * prof_recs.size() + 1], stream));
+    prof_recs.push_back(ProfRec{0, seg_flops, seg_launches});
+    seg_open = false;
   }
   void igemm(const ConvParams& p, double true_flops) { timed(true_flops, [&] { launch_igemm(prec, p, stream); }); }
   void prof_collect() {  // after a stream sync
     for (size_t i = 0; i < prof_recs.size(); ++i) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, prof_pool[2 * i], prof_pool[2 * i + 1]) == hipSuccess) {
-        prof_ms[prof_recs[i].stage] += ms; prof_flops[prof_recs[i].stage] += prof_recs[i].flops; prof_launches[prof_recs[i].stage]++;
+        prof_ms[prof_recs[i].stage] += ms; prof_flops[prof_recs[i].stage] += prof_recs[i].flops; prof_launches[prof_recs[i].stage] += prof_recs[i].launches;
       }
     }
     prof_recs.clear();
@@ -508,42 +522,42 @@ struct Engine {
         const Linear& L = craft.at("slice1.0");
         timed(2.0 * M0 * 64 * 27, [&] { launch_conv1_direct(d_canvas, L.w.p, L.b.as<float>(), c11, B, H, W, stream); });
       } else {
-        launch_im2col_l1(prec, d_canvas, a0, B, H, W, stream);
+        prof_break(), launch_im2col_l1(prec, d_canvas, a0, B, H, W, stream);
         conv("slice1.0", a0, 32, nullptr, 0, 0, 1, 1, (int)M0, c11, kActRelu);
       }
       if (fp) conv("slice1.3", c11, 64, nullptr, 0, 0, B, H, W, nullptr, kActRelu, nullptr, nullptr, p1);
-      else { conv("slice1.3", c11, 64, nullptr, 0, 0, B, H, W, c12, kActRelu); launch_maxpool2x2(prec, c12, p1, B, H, W, 64, 0, stream); }
+      else { conv("slice1.3", c11, 64, nullptr, 0, 0, B, H, W, c12, kActRelu); prof_break(), launch_maxpool2x2(prec, c12, p1, B, H, W, 64, 0, stream); }
     }
     void* c21 = buf(M1, 128); conv("slice1.7", p1, 64, nullptr, 0, 0, B, H1, W1, c21, kActRelu);
     void* c22 = buf(M1, 128); void* p2 = buf(M2, 128);                                                   // relu2_2 skip (pre-ReLU)
     if (fp) conv("slice1.10", c21, 128, nullptr, 0, 0, B, H1, W1, c22, kActNone, nullptr, nullptr, p2, 1);
-    else { conv("slice1.10", c21, 128, nullptr, 0, 0, B, H1, W1, c22, kActNone); launch_maxpool2x2(prec, c22, p2, B, H1, W1, 128, 1, stream); }
+    else { conv("slice1.10", c21, 128, nullptr, 0, 0, B, H1, W1, c22, kActNone); prof_break(), launch_maxpool2x2(prec, c22, p2, B, H1, W1, 128, 1, stream); }
     void* c31 = buf(M2, 256); conv("slice2.14", p2, 128, nullptr, 0, 0, B, H2, W2, c31, kActRelu);
     void* c32 = buf(M2, 256); void* c32r = buf(M2, 256);
     conv("slice2.17", c31, 256, nullptr, 0, 0, B, H2, W2, c32, kActNone, nullptr, c32r);                // relu3_2 skip (pre-ReLU) + its ReLU
     void* c33 = buf(fp ? 0 : M2, 256); void* p3 = buf(M3, 256);
     if (fp) conv("slice3.20", c32r, 256, nullptr, 0, 0, B, H2, W2, nullptr, kActRelu, nullptr, nullptr, p3);
-    else { conv("slice3.20", c32r, 256, nullptr, 0, 0, B, H2, W2, c33, kActRelu); launch_maxpool2x2(prec, c33, p3, B, H2, W2, 256, 0, stream); }
+    else { conv("slice3.20", c32r, 256, nullptr, 0, 0, B, H2, W2, c33, kActRelu); prof_break(), launch_maxpool2x2(prec, c33, p3, B, H2, W2, 256, 0, stream); }
     void* c41 = buf(M3, 512); conv("slice3.24", p3, 256, nullptr, 0, 0, B, H3, W3, c41, kActRelu);
     void* c42 = buf(M3, 512); void* c42r = buf(M3, 512);
     conv("slice3.27", c41, 512, nullptr, 0, 0, B, H3, W3, c42, kActNone, nullptr, c42r);                // relu4_3 skip + its ReLU
     void* c43 = buf(fp ? 0 : M3, 512); void* p4 = buf(M4, 512);
     if (fp) conv("slice4.30", c42r, 512, nullptr, 0, 0, B, H3, W3, nullptr, kActRelu, nullptr, nullptr, p4);
-    else { conv("slice4.30", c42r, 512, nullptr, 0, 0, B, H3, W3, c43, kActRelu); launch_maxpool2x2(prec, c43, p4, B, H3, W3, 512, 0, stream); }
+    else { conv("slice4.30", c42r, 512, nullptr, 0, 0, B, H3, W3, c43, kActRelu); prof_break(), launch_maxpool2x2(prec, c43, p4, B, H3, W3, 512, 0, stream); }
     void* c51 = buf(M4, 512); conv("slice4.34", p4, 512, nullptr, 0, 0, B, H4, W4, c51, kActRelu);
     void* c52 = buf(M4, 512); conv("slice4.37", c51, 512, nullptr, 0, 0, B, H4, W4, c52, kActNone);   // relu5_3 skip
-    void* mp = buf(M4, 512);  launch_maxpool3x3s1(prec, c52, mp, B, H4, W4, 512, stream);
+    void* mp = buf(M4, 512);  prof_break(), launch_maxpool3x3s1(prec, c52, mp, B, H4, W4, 512, stream);
     void* c6 = buf(M4, 1024); conv("slice5.1", mp, 512, nullptr, 0, 0, B, H4, W4, c6, kActNone);
     void* fc7 = buf(M4, 1024); conv("slice5.2", c6, 1024, nullptr, 0, 0, B, H4, W4, fc7, kActNone);
     void* u1a = buf(M4, 512); conv("upconv1.0", fc7, 1024, c52, 512, 0, B, H4, W4, u1a, kActRelu);
     void* u1b = buf(M4, 256); conv("upconv1.3", u1a, 512, nullptr, 0, 0, B, H4, W4, u1b, kActRelu);
-    void* up1 = buf(M3, 256); launch_upsample2x(prec, u1b, up1, B, H4, W4, 256, stream);
+    void* up1 = buf(M3, 256); prof_break(), launch_upsample2x(prec, u1b, up1, B, H4, W4, 256, stream);
     void* u2a = buf(M3, 256); conv("upconv2.0", up1, 256, c42, 512, 0, B, H3, W3, u2a, kActRelu);
     void* u2b = buf(M3, 128); conv("upconv2.3", u2a, 256, nullptr, 0, 0, B, H3, W3, u2b, kActRelu);
-    void* up2 = buf(M2, 128); launch_upsample2x(prec, u2b, up2, B, H3, W3, 128, stream);
+    void* up2 = buf(M2, 128); prof_break(), launch_upsample2x(prec, u2b, up2, B, H3, W3, 128, stream);
     void* u3a = buf(M2, 128); conv("upconv3.0", up2, 128, c32, 256, 0, B, H2, W2, u3a, kActRelu);
     void* u3b = buf(M2, 64);  conv("upconv3.3", u3a, 128, nullptr, 0, 0, B, H2, W2, u3b, kActRelu);
-    void* up3 = buf(M1, 64);  launch_upsample2x(prec, u3b, up3, B, H2, W2, 64, stream);
+    void* up3 = buf(M1, 64);  prof_break(), launch_upsample2x(prec, u3b, up3, B, H2, W2, 64, stream);
     void* u4a = buf(M1, 64);  conv("upconv4.0", up3, 64, c22, 128, 0, B, H1, W1, u4a, kActRelu);
     void* u4b = buf(M1, 32);  conv("upconv4.3", u4a, 64, nullptr, 0, 0, B, H1, W1, u4b, kActRelu);
     void* h0 = buf(M1, 32); void* h2 = buf(M1, 32);
@@ -571,6 +585,7 @@ struct Engine {
       void* h6 = buf(M1, 32);   conv("conv_cls.6", h4, 32, nullptr, 0, 0, B, H1, W1, h6, kActRelu);
       conv("conv_cls.8", h6, 32, nullptr, 0, 0, B, H1, W1, nullptr, kActNone, d_heat);
     }
+    prof_break();
   }
 
   // ---- PARSeq
@@ -798,8 +813,7 @@ struct Engine {
     canvas.ensure((size_t)n * H * W * 3);
     heat.ensure((size_t)n * H2 * W2 * 2 * 4);
     TTR_HIP_CHECK(hipEventRecord(ev[0], stream));
-    for (int i = 0; i < n; ++i)
-      launch_resize_pad_u8(d_pages + i * page_bytes, h, w, w * 3, canvas.as<uint8_t>() + (size_t)i * H * W * 3, g.target_h, g.target_w, H, W, 1, stream);
+    launch_resize_pad_u8(d_pages, h, w, w * 3, canvas.as<uint8_t>(), g.target_h, g.target_w, H, W, 1, stream, n, page_bytes);
     // CRAFT in groups of <= 16 pages: bounds the activation workspace (~0.5 GB/page) and keeps every tensor
     // inside the 2 GiB window gemm2's 32-bit buffer offsets address.  Each group's CCL follows its CRAFT, so the host reads
     // group g's components back (and runs its calipers) while the GPU is busy with group g + 1.

@@ -60,7 +60,9 @@ void launch_fill_random(Precision prec, void* p, size_t n, unsigned seed, float 
 
 // ---- craft_ops.hip
 // OpenCV-style 8-bit INTER_LINEAR resize of src[sh,sw,3] to [th,tw], zero pad to [H,W], optional channel swap.
-void launch_resize_pad_u8(const uint8_t* src, int sh, int sw, int sstride, uint8_t* dst, int th, int tw, int H, int W, int swap_rb, hipStream_t s);
+// `pages` equally sized pages in one launch: sources src_page bytes apart, canvases H*W*3 bytes apart
+void launch_resize_pad_u8(const uint8_t* src, int sh, int sw, int sstride, uint8_t* dst, int th, int tw, int H, int W, int swap_rb, hipStream_t s,
+                          int pages = 1, size_t src_page = 0);
 // canvas u8 [B,H,W,3] -> first-layer im2col matrix T [B*H*W][32] (27 taps*channels, /255, zero padded)
 void launch_im2col_l1(Precision prec, const uint8_t* canvas, void* out, int B, int H, int W, hipStream_t s);
 // bf16 only: conv1_1 + bias + ReLU straight from the u8 canvas (same arithmetic as im2col_l1 + igemm, no [M][32] round trip)
