@@ -110,11 +110,14 @@ void ttr_set_gemm_config(int cfg);
 /* PARSeq autoregressive loop in bf16 mode: 0 = one kernel per op (the f32 mode's schedule), 4 / 8 / 16 = the
  * fused persistent kernel with that many crops per workgroup, anything else = automatic (default). */
 void ttr_set_decoder_mode(int mode);
-/* Process-wide tuning knobs by name: "gemm_config", "decoder_mode" (as above), "enc_chunk" (crops per PARSeq
- * encoder group, 0 = all at once), "sk_max_rows" (linears with at most this many rows use the skinny GEMM kernel).  Returns 0, or -1 for an unknown key.  Results do not depend on any of them. */
+/* Process-wide tuning knobs by name.  Kernel selection: "gemm_config", "decoder_mode" (as above), "enc_chunk" (crops per PARSeq
+ * encoder group, 0 = all at once), "sk_max_rows" / "ws_min_rows" (row counts up to / from which linears use the skinny / the
+ * weight-stationary GEMM), "mlp_fused" (0 off, 1 = from "mlp_min_rows" rows on (default), 2 = always), "ln_fuse" (decoder
+ * LayerNorms inside the skinny GEMM), "fuse_first", "ws_lean", "store_policy" (0 default, 1 streaming, 2 system-scope streaming
+ * output stores), "g2_x_ring3", "c3_*" (conv3p variants).  Diagnostics: "dec_stamps" (1 fused decoder, 2 gemm_ws, 3 mlp_fused
+ * phase stamps, read back with ttr_dbg_dec_stamps), "dbg_bf16_out", "ws_dbg_flags".
+ * Returns 0, or -1 for an unknown key.  Selection knobs change fp32 summation order at most (never a rounding point). */
 int ttr_set_tuning(const char* key, int value);
-/* diagnostics: after ttr_set_tuning("dec_stamps", 1) the fused AR kernel's workgroup 0 records shader-clock stamps
- * [26 steps][16 phases]; this copies them out.  Returns -1 when stamps are off. */
 /* host wall-clock splits (microseconds) of the engine's last batch: [0] enqueue resize+CRAFT+CCL, [1] wait for the component
  * counters, [2] wait for candidates / row extremes, [3] calipers, [4] crop rectangles + PARSeq enqueue, [5] wait for the GPU,
  * [6] event read-back, [7] token decode */
@@ -123,6 +126,9 @@ void ttr_last_host_us(ttr_engine* e, float out[8]);
  * w1 [1536][384], w2 [384][1536] (rounded to bf16 inside); nln_out (may be NULL) = LayerNorm(x_out; nln_g, nln_b), bf16 values as f32 */
 int ttr_dbg_mlp(ttr_engine* e, const float* x, int M, const float* ln_g, const float* ln_b, float eps, const float* w1, const float* b1, const float* w2,
                 const float* b2, const float* nln_g, const float* nln_b, float* x_out, float* nln_out);
+/* diagnostics: after ttr_set_tuning("dec_stamps", 1 / 2 / 3) workgroup 0 of the fused AR kernel / gemm_ws / mlp_fused records
+ * shader-clock stamps into a 416-entry buffer ([26 steps][16 phases], [2 waves][24 panels][8], [48 chunks][8]); this copies them out.
+ * Returns -1 when stamps are off. */
 int ttr_dbg_dec_stamps(unsigned long long* out);
 /* Times one conv / linear layer on device-generated random data (no host traffic): average
  * microseconds per launch over `iters` back-to-back launches.  f32_resid != 0 selects the PARSeq
