@@ -123,9 +123,11 @@ int ttr_set_tuning(const char* key, int value);
  * [6] event read-back, [7] token decode */
 void ttr_last_host_us(ttr_engine* e, float out[8]);
 /* test hook for mlp_fused.hip (bf16 engines): x_out = x + fc2(GELU(fc1(LayerNorm(x)))) over f32 rows [M][384] with weights
- * w1 [1536][384], w2 [384][1536] (rounded to bf16 inside); nln_out (may be NULL) = LayerNorm(x_out; nln_g, nln_b), bf16 values as f32 */
+ * w1 [1536][384], w2 [384][1536] (rounded to bf16 inside); nln_out (may be NULL) = LayerNorm(x_out; nln_g, nln_b), bf16 values as f32.
+ * With att != NULL the attention output projection runs first in the same launch: x is replaced by x + att . wp^T + bp
+ * (att f32 [M][384] and wp [384][384] rounded to bf16). */
 int ttr_dbg_mlp(ttr_engine* e, const float* x, int M, const float* ln_g, const float* ln_b, float eps, const float* w1, const float* b1, const float* w2,
-                const float* b2, const float* nln_g, const float* nln_b, float* x_out, float* nln_out);
+                const float* b2, const float* nln_g, const float* nln_b, float* x_out, float* nln_out, const float* att, const float* wp, const float* bp);
 /* diagnostics: after ttr_set_tuning("dec_stamps", 1 / 2 / 3) workgroup 0 of the fused AR kernel / gemm_ws / mlp_fused records
  * shader-clock stamps into a 416-entry buffer ([26 steps][16 phases], [2 waves][24 panels][8], [48 chunks][8]); this copies them out.
  * Returns -1 when stamps are off. */

@@ -44,3 +44,25 @@ def test_mlp_fused_against_numpy(eng_bf16, M):
     assert np.isfinite(out).all()
     out2, _ = eng_bf16.dbg_mlp(x, ln_g, ln_b, w1, b1, w2, b2)
     assert np.array_equal(out, out2)
+
+
+@pytest.mark.parametrize("M", [128, 61, 128 * 260 + 5])
+def test_mlp_fused_with_projection_against_numpy(eng_bf16, M):
+    """PROJ variant: x' = x + att . Wp^T + bp in front of the MLP, in the same launch."""
+    rng = np.random.default_rng(M + 1)
+    x = rng.standard_normal((M, 384)).astype(np.float32) * 1.5
+    att = rng.standard_normal((M, 384)).astype(np.float32)
+    wp = (rng.standard_normal((384, 384)) / np.sqrt(384)).astype(np.float32); bp = (0.2 * rng.standard_normal(384)).astype(np.float32)
+    ln_g = (1 + 0.2 * rng.standard_normal(384)).astype(np.float32); ln_b = (0.1 * rng.standard_normal(384)).astype(np.float32)
+    w1 = (rng.standard_normal((1536, 384)) / np.sqrt(384)).astype(np.float32); b1 = (0.2 * rng.standard_normal(1536)).astype(np.float32)
+    w2 = (rng.standard_normal((384, 1536)) / np.sqrt(1536)).astype(np.float32); b2 = (0.2 * rng.standard_normal(384)).astype(np.float32)
+    ng = (1 + 0.2 * rng.standard_normal(384)).astype(np.float32); nb = (0.1 * rng.standard_normal(384)).astype(np.float32)
+    out, nout = eng_bf16.dbg_mlp(x, ln_g, ln_b, w1, b1, w2, b2, ng, nb, att=att, wp=wp, bp=bp)
+    rows = np.r_[0:M] if M < 1000 else np.r_[0:300, M - 300:M]
+    x1 = (x[rows].astype(np.float64) + bf(att[rows]).astype(np.float64) @ bf(wp).astype(np.float64).T + bp).astype(np.float32)
+    ro, rn = ref_mlp(x1, ln_g, ln_b, w1, b1, w2, b2, ng, nb)
+    assert np.abs(out[rows] - ro).max() < 0.02, np.abs(out[rows] - ro).max()
+    assert np.abs(nout[rows] - rn).max() < 0.04
+    assert np.isfinite(out).all()
+    out2, _ = eng_bf16.dbg_mlp(x, ln_g, ln_b, w1, b1, w2, b2, att=att, wp=wp, bp=bp)
+    assert np.array_equal(out, out2)

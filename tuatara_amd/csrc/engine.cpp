@@ -44,6 +44,7 @@ void hip_fail(const char* what, hipError_t e, const char* file, int line) {
 static thread_local std::string g_last_error;
 static unsigned long long* g_dec_dbg = nullptr;   // device buffer for dec_ar phase stamps (diagnostics)
 static int g_dbg_bf16_out = 0;     // ttr_dbg_conv on a bf16 engine: take the kernel's bf16 output (the path the engine uses) instead of the f32 one
+static int g_mlp_proj = 1;           // ... with the attention output projection in front of it in the same launch
 static int g_mlp_min_rows = 49152;   // = 384 crops
 static int g_mlp_fused = 1;        // bf16 encoder: norm2 + fc1 + GELU + fc2 + residual (+ the next LayerNorm) as one kernel (mlp_fused.hip)
 static int g_ln_fuse = 1;          // bf16 decoder steps: LayerNorm computed inside the skinny GEMM's loader (gemm_sk ln_in)
@@ -259,6 +260,7 @@ struct Engine {
   // PARSeq
   std::map<std::string, Linear> pq;               // linears by upstream name
   std::map<std::string, DevBuf> pqf;              // f32 vectors (LayerNorm params, pos embed, ...)
+  DevBuf proj_packed[12];                         // bf16 engines: encoder attn.proj weights k-step-major [12][384][32] (mlp_fused.hip, PROJ)
   DevBuf fc2_packed[12];                          // bf16 engines: encoder fc2 weights chunk-major [48][384][32] for mlp_fused.hip
   DevBuf qself;                                   // f32 [26][384]
 
@@ -406,6 +408,13 @@ struct Engine {
             for (int j = 0; j < 32; ++j) h[((size_t)c * E + o) * 32 + j] = f32_to_bf16_rne(w.data[(size_t)o * 4 * E + c * 32 + j]);
         fc2_packed[i].ensure(h.size() * 2);
         TTR_HIP_CHECK(hipMemcpy(fc2_packed[i].p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        const auto& wp = wf.get(p + "attn.proj.weight", (size_t)E * E);
+        std::vector<uint16_t> hp((size_t)E * E);
+        for (int c = 0; c < 12; ++c)
+          for (int o = 0; o < E; ++o)
+            for (int j = 0; j < 32; ++j) hp[((size_t)c * E + o) * 32 + j] = f32_to_bf16_rne(wp.data[(size_t)o * E + c * 32 + j]);
+        proj_packed[i].ensure(hp.size() * 2);
+        TTR_HIP_CHECK(hipMemcpy(proj_packed[i].p, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
       }
     }
     vec("encoder.norm.weight", E); vec("encoder.norm.bias", E);
@@ -661,7 +670,8 @@ struct Engine {
         if (!mlp_fused) ln(xc, p + "norm1", 1e-6f, t384, Mc);
         gemm(pq.at(p + "qkv"), t384, Mc, tbig, 3 * E, kActNone);
         launch_attn_enc(prec, tbig, att, nc, stream);
-        gemm(pq.at(p + "proj"), att, Mc, nullptr, 0, kActNone, xc, E, xc, E, 0);
+        const bool proj_in = mlp_fused && g_mlp_proj;            // the projection runs inside the fused block kernel
+        if (!proj_in) gemm(pq.at(p + "proj"), att, Mc, nullptr, 0, kActNone, xc, E, xc, E, 0);
         if (mlp_fused) {
           // norm2 + fc1 + GELU + fc2 + residual in one kernel; it also leaves the next LayerNorm (the next block's norm1, or
           // the encoder's final norm = the decoder's memory) in t384
@@ -672,7 +682,8 @@ struct Engine {
           q.w1 = pq.at(p + "fc1").w.as<bf16>(); q.b1 = pq.at(p + "fc1").b.as<float>();
           q.w2p = fc2_packed[l].as<bf16>(); q.b2 = pq.at(p + "fc2").b.as<float>();
           q.nln_g = pqf.at(nx + ".weight").as<float>(); q.nln_b = pqf.at(nx + ".bias").as<float>(); q.nln_eps = 1e-6f; q.nln_out = (bf16*)t384;
-          timed(2.0 * Mc * E * 4 * E * 2, [&] { launch_mlp_fused(q, stream); });
+          if (proj_in) { q.att = (const bf16*)att; q.wpp = proj_packed[l].as<bf16>(); q.bp = pq.at(p + "proj").b.as<float>(); }
+          timed(2.0 * Mc * E * 4 * E * 2 + (proj_in ? 2.0 * Mc * E * E : 0.0), [&] { launch_mlp_fused(q, stream); });
           continue;
         }
         ln(xc, p + "norm2", 1e-6f, t384, Mc);
@@ -1155,7 +1166,7 @@ int ttr_dbg_conv(ttr_engine* e, const float* in0, int C0, const float* in1, int 
 }
 
 int ttr_dbg_mlp(ttr_engine* e, const float* x, int M, const float* ln_g, const float* ln_b, float eps, const float* w1, const float* b1, const float* w2,
-                const float* b2, const float* nln_g, const float* nln_b, float* x_out, float* nln_out) {
+                const float* b2, const float* nln_g, const float* nln_b, float* x_out, float* nln_out, const float* att, const float* wp, const float* bp) {
   TTR_GUARD_BEGIN
   Engine& E = *e->e;
   std::lock_guard<std::mutex> lk(E.mu);
@@ -1177,6 +1188,18 @@ int ttr_dbg_mlp(ttr_engine* e, const float* x, int M, const float* ln_g, const f
   q.x = dx.as<float>(); q.x_out = dout.as<float>(); q.M = M; q.ln_g = dg.as<float>(); q.ln_b = db.as<float>(); q.ln_eps = eps;
   q.w1 = dw1.as<bf16>(); q.b1 = db1.as<float>(); q.w2p = dw2.as<bf16>(); q.b2 = db2.as<float>();
   if (nln_out) { q.nln_g = dng.as<float>(); q.nln_b = dnb.as<float>(); q.nln_eps = eps; q.nln_out = dn.as<bf16>(); }
+  DevBuf datt, dwp, dbp;
+  if (att) {
+    std::vector<uint16_t> ha((size_t)M * D), hw((size_t)D * D);
+    for (size_t i = 0; i < ha.size(); ++i) ha[i] = f32_to_bf16_rne(att[i]);
+    for (int c = 0; c < 12; ++c)
+      for (int o = 0; o < D; ++o)
+        for (int j = 0; j < 32; ++j) hw[((size_t)c * D + o) * 32 + j] = f32_to_bf16_rne(wp[(size_t)o * D + c * 32 + j]);
+    datt.ensure(ha.size() * 2); TTR_HIP_CHECK(hipMemcpy(datt.p, ha.data(), ha.size() * 2, hipMemcpyHostToDevice));
+    dwp.ensure(hw.size() * 2); TTR_HIP_CHECK(hipMemcpy(dwp.p, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    upf(dbp, bp, D);
+    q.att = datt.as<bf16>(); q.wpp = dwp.as<bf16>(); q.bp = dbp.as<float>();
+  }
   launch_mlp_fused(q, E.stream);
   TTR_HIP_CHECK(hipMemcpyAsync(x_out, dout.p, (size_t)M * D * 4, hipMemcpyDeviceToHost, E.stream));
   TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
@@ -1235,6 +1258,7 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "ln_fuse") g_ln_fuse = value;
   else if (k == "mlp_fused") g_mlp_fused = value;   // 0 off, 1 from mlp_min_rows rows on, 2 always
   else if (k == "mlp_min_rows") g_mlp_min_rows = value;
+  else if (k == "mlp_proj") g_mlp_proj = value;
   else if (k == "ws_dbg_flags") set_gemm_ws_dbg_flags(value);
   else if (k == "ws_lean") set_gemm_ws_lean(value);
   else if (k == "store_policy") set_store_policy(value);

@@ -97,6 +97,7 @@ struct MlpParams {
   const bf16* w1; const float* b1;                   // fc1 [1536][384], [1536]
   const bf16* w2p; const float* b2;                  // fc2 packed [48][384][32] (pack_fc2_chunks), [384]
   const float *nln_g, *nln_b; float nln_eps; bf16* nln_out;   // optional: LayerNorm of x_out -> bf16 [M][384]
+  const bf16* att; const bf16* wpp; const float* bp;  // optional: x' = x + att . Wp^T + bp first (att bf16 [M][384], Wp packed [12][384][32])
   const void* gelu_lut;    // set by the launcher
   unsigned long long* dbg; // optional [48][8] shader-clock stamps of workgroup 0 / wave 0 over its first panel (diagnostics)
   int M;

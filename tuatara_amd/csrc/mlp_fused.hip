@@ -31,7 +31,7 @@ namespace ttr {
 namespace {
 typedef __attribute__((address_space(3))) void* lds_ptr;
 constexpr int E = 384, HID = 1536, CH = 32, NCH = HID / CH;   // 48 chunks of 32 hidden units
-constexpr int W1B = CH * E * 2;                               // W1 chunk image [32 rows][768 B]
+constexpr int W1B = CH * E * 2;                               // W1 chunk image [3 k-segments][32 rows][256 B]
 constexpr int W2B = E * CH * 2;                               // W2 chunk image [384 rows][64 B]
 constexpr int SLOT = W1B + W2B, NSLOT = 3;
 constexpr int LUT_OFF = NSLOT * SLOT;                         // GELU table, 8 KiB
@@ -49,7 +49,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t m_rsrc(const void* base, unsig
 #define MLP_WAIT8(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]))
 }  // namespace
 
+// PROJ: the block's attention output projection runs in front, in the same launch: x' = x + att . Wp^T + bp is accumulated in the
+// registers that then hold the MLP's output tile, so the residual stream is read once and written once per block (12 more ring
+// items per panel: the [384 x 32] k-step slabs of a chunk-major copy of Wp, in the W2 half of a slot)
+template <bool PROJ>
 __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
+  constexpr int NPJ = PROJ ? E / CH : 0, ITEMS = NPJ + NCH + 1;   // ring items per panel
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -57,54 +62,69 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
   const int npanels = (p.M + BM - 1) / BM;
   if ((int)blockIdx.x >= npanels) return;
   const int my_n = (npanels - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int total = my_n * (NCH + 1);                          // ring items this workgroup walks: 49 per panel (see the chunk loop)
+  const int total = my_n * ITEMS;                              // ring items this workgroup walks (see the chunk loop)
 
   for (int i = tid; i < 512; i += 256) reinterpret_cast<uint4*>(smem + LUT_OFF)[i] = reinterpret_cast<const uint4*>(p.gelu_lut)[i];
   for (int i = tid; i < HID / 4; i += 256) reinterpret_cast<float4*>(smem + B1_OFF)[i] = reinterpret_cast<const float4*>(p.b1)[i];
 
-  // ---- weight stream: this wave's 6 + 6 one-KiB pieces of a chunk.  Source offsets are relative to the chunk's base.
-  // W1 image: LDS row R = 16 jj + q' holds hidden unit (q'>>2)*8 + jj*4 + (q'&3) of the chunk; 16-byte chunk ch of a row sits
-  // at position (ch & ~15) | ((ch & 15) ^ (R & 15))   (768-byte rows: every row starts on bank 0)
-  // W2 image: LDS row R' = 16 ot + q' holds output channel (ot>>1)*32 + (q'>>2)*8 + (ot&1)*4 + (q'&3); chunk gch of the
-  // 64-byte row sits at position gch ^ ((R'>>1) & 3)
+  // ---- weight stream: this wave's 6 + 6 one-KiB pieces of a chunk; source offsets are relative to the chunk's base
   const __amdgpu_buffer_rsrc_t rs1 = m_rsrc(p.w1, (unsigned)(HID * E * 2));
   const __amdgpu_buffer_rsrc_t rs2 = m_rsrc(p.w2p, (unsigned)(HID * E * 2));
-  unsigned src1[6], src2;   // the wave's W2 pieces are 4,096 source bytes apart (two output-channel tiles): one offset + a scalar
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const int pp = wave + 4 * j;
-    const int o = pp * 1024 + lane * 16;
-    const int R = o / 768, cp = (o - R * 768) >> 4;
-    const int ch = (cp & ~15) | ((cp & 15) ^ (R & 15));
-    const int nl = ((R & 15) >> 2) * 8 + (R >> 4) * 4 + (R & 3);
-    src1[j] = (unsigned)((nl * E + ch * 8) * 2);
-  }
-  {
-    const int R2 = wave * 16 + (lane >> 2), ot = R2 >> 4, q2 = R2 & 15;
-    const int oc = (ot >> 1) * 32 + (q2 >> 2) * 8 + (ot & 1) * 4 + (q2 & 3);
-    const int gsrc = (lane & 3) ^ ((R2 >> 1) & 3);
-    src2 = (unsigned)((oc * CH + gsrc * 8) * 2);
-  }
-  auto issue = [&](int Gi) {                                   // item Gi: W1 chunk i (i < 48) and W2 chunk i - 1 (i >= 1) of its panel
-    const int ii = Gi % (NCH + 1), slot = Gi % NSLOT;
+  // Source offsets of the wave's pieces (a wave's six pieces of either operand differ by wave-uniform byte offsets only).  They are
+  // recomputed from the lane id at every issue — six integer instructions — because a register that lives across the whole
+  // chunk loop gets spilled here, and the wait for a spill reload (a vector-memory load) drains the LDS-DMA prefetch.
+  //   W1 image, segment-major: [3 k-segments of 256 B][32 rows][256 B]; LDS row R = 16 jj + q' holds hidden unit
+  //   (q'>>2)*8 + jj*4 + (q'&3) of the chunk, and 16-byte chunk c (0..15) of a segment sits at position c ^ (R & 15) (every
+  //   row of a segment starts on bank 0).  Piece (segment s, row group r) = rows 4r .. 4r+3 of segment s; wave w's pieces are
+  //   r = w + 4 (j & 1), s = j >> 1, so its lane reads row 4w + 16 (j&1) + (lane>>4): (j&1) adds 4 hidden units = 3,072 source
+  //   bytes, (j>>1) adds 256.
+  //   W2 image: LDS row R' = 16 ot + q' holds output channel (ot>>1)*32 + (q'>>2)*8 + (ot&1)*4 + (q'&3); chunk gch of the 64-byte
+  //   row sits at position gch ^ ((R'>>1) & 3).  Piece ot = wave + 4 j: two output-channel tiles = 4,096 source bytes per j.
+  auto src_w1 = [&]() -> unsigned {
+    unsigned l = (unsigned)lane;
+    asm volatile("" : "+v"(l));
+    const unsigned Rl = 4u * wave + (l >> 4), nl = 8u * wave + (l >> 4);
+    return (nl * E + (((l & 15u) ^ Rl) * 8u)) * 2u;
+  };
+  auto src_w2 = [&]() -> unsigned {
+    unsigned l = (unsigned)lane;
+    asm volatile("" : "+v"(l));
+    const unsigned q2 = l >> 2;                                  // R' & 15 (the wave's first piece is tile ot = wave)
+    const unsigned oc = (wave >> 1) * 32u + (q2 >> 2) * 8u + (wave & 1) * 4u + (q2 & 3u);
+    return (oc * CH + ((l & 3u) ^ ((q2 >> 1) & 3u)) * 8u) * 2u;
+  };
+  const __amdgpu_buffer_rsrc_t rsp = m_rsrc(PROJ ? (const void*)p.wpp : (const void*)p.w2p, (unsigned)((PROJ ? E * E : HID * E) * 2));
+  auto issue = [&](int Gi) {                                   // item Gi of the launch
+    int ii = Gi % ITEMS;
+    const int slot = Gi % NSLOT;
     unsigned char* sb = smem + slot * SLOT + wave * 1024;
+    if (PROJ && ii < NPJ) {                                     // k-step slab ii of Wp
+      const unsigned src2 = src_w2();
+#pragma unroll
+      for (int j = 0; j < 6; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsp, (lds_ptr)(sb + W1B + j * 4096), 16, src2, ii * W2B + j * 4096, 0, 0);
+      return;
+    }
+    ii -= NPJ;                                                  // MLP item: W1 chunk ii (ii < 48) and W2 chunk ii - 1 (ii >= 1)
     if (ii < NCH) {
       const int cb = ii * W1B;
+      const unsigned src1 = src_w1();
 #pragma unroll
-      for (int j = 0; j < 6; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr)(sb + j * 4096), 16, src1[j], cb, 0, 0);
+      for (int j = 0; j < 6; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr)(sb + (j >> 1) * 8192 + (j & 1) * 4096), 16, src1, cb + (j & 1) * 3072 + (j >> 1) * 256, 0, 0);
     }
     if (ii >= 1) {
       const int cb = (ii - 1) * W2B;
+      const unsigned src2 = src_w2();
 #pragma unroll
       for (int j = 0; j < 6; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_ptr)(sb + W1B + j * 4096), 16, src2, cb + j * 4096, 0, 0);
     }
   };
+  auto pieces = [&](int Gi) -> int {                            // pieces per wave of item Gi: 12, or 6 for the one-operand items
+    const int ii = Gi % ITEMS;
+    return (ii < NPJ || ii == NPJ || ii == ITEMS - 1) ? 6 : 12;
+  };
 
   // ---- fragment read addresses relative to a slot
-  unsigned w1a[4];
-#pragma unroll
-  for (int k3 = 0; k3 < 4; ++k3) w1a[k3] = (unsigned)(q * 768 + (((k3 * 4 + g) ^ q) << 4));
-  const unsigned w2a = (unsigned)(W1B + q * 64 + ((g ^ ((q >> 1) & 3)) << 4));
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smem;
   const unsigned lut_lds = lds0 + LUT_OFF;
   const unsigned b1_lds = lds0 + B1_OFF + (unsigned)(g * 8 * 4);
@@ -118,8 +138,96 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
     const int panel = (int)blockIdx.x + pi * (int)gridDim.x;
     const int row0 = panel * BM + wave * 32;
 
+    bf16x8 xf[2][12];                                           // LayerNorm_2 of this wave's 32 rows as MFMA B fragments
+    f32x4 acc2[2][24];                                          // the wave's [32 rows x 384] f32 output tile
+    int i = 0;
+#define MLP_STAMP(ph) do { if (p.dbg && blockIdx.x == 0 && tid == 0 && pi == 0 && i < NCH) p.dbg[i * 8 + (ph)] = __builtin_readcyclecounter(); } while (0)
+// Fragment groups of 4 (8 MFMAs each), three register buffers, reads two groups ahead.  GEMM1 group n = k-steps 2n, 2n+1 x the
+// two 16-row weight tiles; GEMM2 group n = output-channel tiles 4n .. 4n+3.
+#define MLP_G1(dst, n)                                                                                                   \
+  MLP_RD128(dst[0], a1v[(2 * (n)) & 3], ((2 * (n)) >> 2) * 8192);     MLP_RD128(dst[1], a1v[(2 * (n)) & 3], 4096 + ((2 * (n)) >> 2) * 8192); \
+  MLP_RD128(dst[2], a1v[(2 * (n) + 1) & 3], ((2 * (n) + 1) >> 2) * 8192); MLP_RD128(dst[3], a1v[(2 * (n) + 1) & 3], 4096 + ((2 * (n) + 1) >> 2) * 8192);
+#define MLP_G2(dst, n)                                                                                                   \
+  MLP_RD128(dst[0], a2, (4 * (n) + 0) * 1024); MLP_RD128(dst[1], a2, (4 * (n) + 1) * 1024);                              \
+  MLP_RD128(dst[2], a2, (4 * (n) + 2) * 1024); MLP_RD128(dst[3], a2, (4 * (n) + 3) * 1024);
+#define MLP_M1(src, n)                                                                                                   \
+  _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2)                                                                       \
+    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                                     \
+      _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                                                   \
+        accn[rt][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(src[k2 * 2 + jj], xf[rt][2 * (n) + k2], accn[rt][jj], 0, 0, 0);
+#define MLP_M2B(src, n, b0, b1)                                                                                          \
+  _Pragma("unroll") for (int o4 = 0; o4 < 4; ++o4) {                                                                     \
+    acc2[0][4 * (n) + o4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(src[o4], b0, acc2[0][4 * (n) + o4], 0, 0, 0);        \
+    acc2[1][4 * (n) + o4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(src[o4], b1, acc2[1][4 * (n) + o4], 0, 0, 0);        \
+  }
+#define MLP_M2(src, n) MLP_M2B(src, n, hf[0], hf[1])
+#define MLP_WAITF(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]))
+#define MLP_WAITFT(n, f, t) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]))
+    // GELU of one quarter (4 hidden units of one row tile) around its table read: A = index + read request, B = interpolate,
+    // multiply, round to bf16 into half of the row tile's B fragment
+    float u4[4];
+    float2 t4[4];
+    auto gelu_a = [&](const f32x4& acc) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        u4[e] = fmaf(__builtin_amdgcn_fmed3f(acc[e], -8.0f, 7.984375f), 64.0f, 512.0f);
+        const unsigned ad = lut_lds + ((unsigned)(int)u4[e] << 3);
+        asm volatile("ds_read_b64 %0, %1" : "=v"(t4[e]) : "v"(ad));
+      }
+    };
+    auto gelu_b = [&](const f32x4& acc, bf16x8& o, int half) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[half * 4 + e] = (bf16)(acc[e] * fmaf(__builtin_amdgcn_fractf(u4[e]), t4[e].y, t4[e].x));
+    };
+
+    // Software pipeline over the 48 hidden chunks: iteration i runs GEMM1 of chunk i with the GELU of chunk i-1 in the
+    // shadow of its MFMAs, then GEMM2 of chunk i-1.  Ring item G (49 per panel, G counts over the whole launch) =
+    // {W1 chunk i if i < 48, W2 chunk i-1 if i >= 1} in slot G % 3.
+    f32x4 accp[2][2];                                           // GEMM1 result of the previous iteration, before the activation
+    f32x4 accn[2][2];
+    bf16x8 f0[4], f1[4], f2[4];
+    bf16x8 hf[2];
+    unsigned a1v[4], a2;
+    // top of an iteration: item G has landed once at most the pieces of item G + 1 (12, or 6 at a panel edge) are still in
+    // flight — loads retire in order, and whatever the epilogue / prologue put on the queue since is younger still
+#define MLP_TOP()                                                                                          \
+  {                                                                                                        \
+    MLP_STAMP(0);                                                                                          \
+    if (G + 1 < total) {                                                                                   \
+      if (pieces(G + 1) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                             \
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                               \
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+    __builtin_amdgcn_s_barrier(); /* everyone's pieces landed; slot (G+2)%3 = (G-1)%3 is free again */     \
+    MLP_STAMP(1);                                                                                          \
+    const unsigned sbase = lds0 + (unsigned)((G % NSLOT) * SLOT);                                          \
+    /* fragment addresses are recomputed from the lane id every iteration (the empty asm stops the compiler from hoisting  \
+       them out of the loop into registers it then spills: a spill reload is a vector-memory load, and the wait for it drains  \
+       the LDS-DMA prefetch) */                                                                            \
+    unsigned ll = (unsigned)lane;                                                                          \
+    asm volatile("" : "+v"(ll));                                                                           \
+    const unsigned qq = ll & 15u, gq = ll >> 4;                                                            \
+    const unsigned rowb = sbase + qq * 256u;                                                               \
+    a1v[0] = rowb + (((0u + gq) ^ qq) << 4); a1v[1] = rowb + (((4u + gq) ^ qq) << 4);                      \
+    a1v[2] = rowb + (((8u + gq) ^ qq) << 4); a1v[3] = rowb + (((12u + gq) ^ qq) << 4);                     \
+    a2 = sbase + (unsigned)W1B + qq * 64u + ((gq ^ ((qq >> 1) & 3u)) << 4);                                \
+  }
+    // the first fragments are requested before the DMA issue, whose ~80 cycles per piece hide their latency.  (The CU's address
+    // unit takes 16-20 cycles per 1-KiB piece and the four waves queue behind one another; issuing a third of the item after
+    // every fourth MFMA group instead, one wave at a time, cost more in spills than it saved.)
+#define MLP_HEAD1()                                                                                        \
+  {                                                                                                        \
+    const unsigned ba = b1_lds + (unsigned)(i * CH * 4);                                                   \
+    MLP_RD128(accn[0][0], ba, 0);                                                                          \
+    MLP_RD128(accn[0][1], ba, 16);                                                                         \
+    MLP_G1(f0, 0)                                                                                          \
+    MLP_G1(f1, 1)                                                                                          \
+    if (G + 2 < total) issue(G + 2);                                                                       \
+    MLP_STAMP(2);                                                                                          \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(accn[0][0]), "+v"(accn[0][1]), "+v"(f0[0]), "+v"(f0[1]), "+v"(f0[2]), "+v"(f0[3]), "+v"(f1[0]), "+v"(f1[1]), "+v"(f1[2]), "+v"(f1[3])); \
+    accn[1][0] = accn[0][0]; accn[1][1] = accn[0][1];                                                      \
+  }
+    if (!PROJ) {
     // ---- LayerNorm of this wave's 32 rows -> B fragments.  Lane (q, g) holds, of row 16 rt + q, channels 32 ks + 8 g + e.
-    bf16x8 xf[2][12];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
       const int row = min(row0 + rt * 16 + q, p.M - 1);
@@ -156,89 +264,85 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
       }
     }
 
-    f32x4 acc2[2][24];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int ot = 0; ot < 24; ++ot) acc2[rt][ot] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#define MLP_STAMP(ph) do { if (p.dbg && blockIdx.x == 0 && tid == 0 && pi == 0 && i < NCH) p.dbg[i * 8 + (ph)] = __builtin_readcyclecounter(); } while (0)
-// Fragment groups of 4 (8 MFMAs each), three register buffers, reads two groups ahead.  GEMM1 group n = k-steps 2n, 2n+1 x the
-// two 16-row weight tiles; GEMM2 group n = output-channel tiles 4n .. 4n+3.
-#define MLP_G1(dst, n)                                                                                                   \
-  MLP_RD128(dst[0], a1v[(2 * (n)) & 3], ((2 * (n)) >> 2) * 256);     MLP_RD128(dst[1], a1v[(2 * (n)) & 3], 12288 + ((2 * (n)) >> 2) * 256); \
-  MLP_RD128(dst[2], a1v[(2 * (n) + 1) & 3], ((2 * (n) + 1) >> 2) * 256); MLP_RD128(dst[3], a1v[(2 * (n) + 1) & 3], 12288 + ((2 * (n) + 1) >> 2) * 256);
-#define MLP_G2(dst, n)                                                                                                   \
-  MLP_RD128(dst[0], a2, (4 * (n) + 0) * 1024); MLP_RD128(dst[1], a2, (4 * (n) + 1) * 1024);                              \
-  MLP_RD128(dst[2], a2, (4 * (n) + 2) * 1024); MLP_RD128(dst[3], a2, (4 * (n) + 3) * 1024);
-#define MLP_M1(src, n)                                                                                                   \
-  _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2)                                                                       \
-    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                                     \
-      _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                                                   \
-        accn[rt][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(src[k2 * 2 + jj], xf[rt][2 * (n) + k2], accn[rt][jj], 0, 0, 0);
-#define MLP_M2(src, n)                                                                                                   \
-  _Pragma("unroll") for (int o4 = 0; o4 < 4; ++o4)                                                                       \
-    _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                                                     \
-      acc2[rt][4 * (n) + o4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(src[o4], hf[rt], acc2[rt][4 * (n) + o4], 0, 0, 0);
-#define MLP_WAITF(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]))
-#define MLP_WAITFT(n, f, t) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]))
-    // GELU of one quarter (4 hidden units of one row tile) around its table read: A = index + read request, B = interpolate,
-    // multiply, round to bf16 into half of the row tile's B fragment
-    float u4[4];
-    float2 t4[4];
-    auto gelu_a = [&](const f32x4& acc) {
+    } else {
+      // ---- attention output projection: acc2 = att . Wp^T over 12 ring items (k-step slabs), then x' = acc2 + bp + x stays in
+      // acc2 as the MLP's starting value and LayerNorm_2(x') becomes the GEMM1 operand.  Lane (q, g) loads, of row 16 rt + q,
+      // channels 32 ks + 8 g + e of the attention output: the same fragment layout as xf.
+      bf16x8 af[2][12];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        u4[e] = fmaf(__builtin_amdgcn_fmed3f(acc[e], -8.0f, 7.984375f), 64.0f, 512.0f);
-        const unsigned ad = lut_lds + ((unsigned)(int)u4[e] << 3);
-        asm volatile("ds_read_b64 %0, %1" : "=v"(t4[e]) : "v"(ad));
+      for (int rt = 0; rt < 2; ++rt) {
+        const int row = min(row0 + rt * 16 + q, p.M - 1);
+        const bf16* ar = p.att + (size_t)row * E + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < 12; ++ks) af[rt][ks] = *reinterpret_cast<const bf16x8*>(ar + ks * 32);
       }
-    };
-    auto gelu_b = [&](const f32x4& acc, bf16x8& o, int half) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[half * 4 + e] = (bf16)(acc[e] * fmaf(__builtin_amdgcn_fractf(u4[e]), t4[e].y, t4[e].x));
-    };
-
-    // Software pipeline over the 48 hidden chunks: iteration i runs GEMM1 of chunk i with the GELU of chunk i-1 in the
-    // shadow of its MFMAs, then GEMM2 of chunk i-1.  Ring item G (49 per panel, G counts over the whole launch) =
-    // {W1 chunk i if i < 48, W2 chunk i-1 if i >= 1} in slot G % 3.
-    f32x4 accp[2][2];                                           // GEMM1 result of the previous iteration, before the activation
-    f32x4 accn[2][2];
-    bf16x8 f0[4], f1[4], f2[4];
-    bf16x8 hf[2];
-    unsigned a1v[4], a2;
-    // top of an iteration: item G has landed once at most the pieces of item G + 1 (12, or 6 at a panel edge) are still in
-    // flight — loads retire in order, and whatever the epilogue / prologue put on the queue since is younger still
-#define MLP_TOP()                                                                                          \
-  {                                                                                                        \
-    MLP_STAMP(0);                                                                                          \
-    if (G + 1 < total) {                                                                                   \
-      const int in = (G + 1) % (NCH + 1);                                                                  \
-      if (in == 0 || in == NCH) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                           \
-      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                               \
-    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
-    __builtin_amdgcn_s_barrier(); /* everyone's pieces landed; slot (G+2)%3 = (G-1)%3 is free again */     \
-    MLP_STAMP(1);                                                                                          \
-    const unsigned sbase = lds0 + (unsigned)((G % NSLOT) * SLOT);                                          \
-    a1v[0] = sbase + w1a[0]; a1v[1] = sbase + w1a[1]; a1v[2] = sbase + w1a[2]; a1v[3] = sbase + w1a[3];    \
-    a2 = sbase + w2a;                                                                                      \
-  }
-    // the first fragments are requested before the DMA issue, whose ~80 cycles per piece hide their latency.  (The CU's address
-    // unit takes 16-20 cycles per 1-KiB piece and the four waves queue behind one another; issuing a third of the item after
-    // every fourth MFMA group instead, one wave at a time, cost more in spills than it saved.)
-#define MLP_HEAD1()                                                                                        \
-  {                                                                                                        \
-    const unsigned ba = b1_lds + (unsigned)(i * CH * 4);                                                   \
-    MLP_RD128(accn[0][0], ba, 0);                                                                          \
-    MLP_RD128(accn[0][1], ba, 16);                                                                         \
-    MLP_G1(f0, 0)                                                                                          \
-    MLP_G1(f1, 1)                                                                                          \
-    if (G + 2 < total) issue(G + 2);                                                                       \
-    MLP_STAMP(2);                                                                                          \
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(accn[0][0]), "+v"(accn[0][1]), "+v"(f0[0]), "+v"(f0[1]), "+v"(f0[2]), "+v"(f0[3]), "+v"(f1[0]), "+v"(f1[1]), "+v"(f1[2]), "+v"(f1[3])); \
-    accn[1][0] = accn[0][0]; accn[1][1] = accn[0][1];                                                      \
-  }
-    int i = 0;
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ot = 0; ot < 24; ++ot) acc2[rt][ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+      i = NCH;                                                  // (no stamps in this phase)
+#pragma unroll
+      for (int ks = 0; ks < 12; ++ks) {
+        MLP_TOP()
+        MLP_G2(f0, 0)
+        MLP_G2(f1, 1)
+        if (ks < 10) {                                          // item G + 2 is another slab of Wp (known at compile time)
+          unsigned char* sb = smem + ((G + 2) % NSLOT) * SLOT + wave * 1024;
+          const unsigned src2 = src_w2();
+#pragma unroll
+          for (int j = 0; j < 6; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsp, (lds_ptr)(sb + W1B + j * 4096), 16, src2, (ks + 2) * W2B + j * 4096, 0, 0);
+        } else if (G + 2 < total) issue(G + 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f0[0]), "+v"(f0[1]), "+v"(f0[2]), "+v"(f0[3]), "+v"(f1[0]), "+v"(f1[1]), "+v"(f1[2]), "+v"(f1[3]));
+        MLP_G2(f2, 2)  MLP_M2B(f0, 0, af[0][ks], af[1][ks])
+        MLP_G2(f0, 3)  MLP_M2B(f1, 1, af[0][ks], af[1][ks])
+        MLP_G2(f1, 4)  MLP_WAITF(8, f2);  MLP_M2B(f2, 2, af[0][ks], af[1][ks])
+        MLP_G2(f2, 5)  MLP_WAITF(8, f0);  MLP_M2B(f0, 3, af[0][ks], af[1][ks])
+        MLP_WAITF(4, f1);  MLP_M2B(f1, 4, af[0][ks], af[1][ks])
+        MLP_WAITF(0, f2);  MLP_M2B(f2, 5, af[0][ks], af[1][ks])
+        __builtin_amdgcn_sched_barrier(0);
+        ++G;
+      }
+      i = 0;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const size_t ro = (size_t)min(row0 + rt * 16 + q, p.M - 1) * E + g * 8;
+        float s = 0.f;
+#pragma unroll
+        for (int pp = 0; pp < 12; ++pp) {
+          const float4 r0 = *reinterpret_cast<const float4*>(p.x + ro + pp * 32), r1 = *reinterpret_cast<const float4*>(p.x + ro + pp * 32 + 4);
+          const float4 c0 = *reinterpret_cast<const float4*>(p.bp + pp * 32 + g * 8), c1 = *reinterpret_cast<const float4*>(p.bp + pp * 32 + g * 8 + 4);
+          f32x4 lo = acc2[rt][2 * pp], hi = acc2[rt][2 * pp + 1];
+          lo[0] += c0.x + r0.x; lo[1] += c0.y + r0.y; lo[2] += c0.z + r0.z; lo[3] += c0.w + r0.w;
+          hi[0] += c1.x + r1.x; hi[1] += c1.y + r1.y; hi[2] += c1.z + r1.z; hi[3] += c1.w + r1.w;
+          acc2[rt][2 * pp] = lo; acc2[rt][2 * pp + 1] = hi;
+          s += (lo[0] + lo[1]) + (lo[2] + lo[3]) + (hi[0] + hi[1]) + (hi[2] + hi[3]);
+        }
+        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        const float mean = s * (1.f / E);
+        float s2 = 0.f;
+#pragma unroll
+        for (int ot = 0; ot < 24; ++ot)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float d = acc2[rt][ot][e] - mean; s2 += d * d; }
+        s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+        const float rstd = rsqrtf(s2 * (1.f / E) + p.ln_eps);
+#pragma unroll
+        for (int pp = 0; pp < 12; ++pp) {
+          const float4 g0 = *reinterpret_cast<const float4*>(p.ln_g + pp * 32 + g * 8), g1 = *reinterpret_cast<const float4*>(p.ln_g + pp * 32 + g * 8 + 4);
+          const float4 t0 = *reinterpret_cast<const float4*>(p.ln_b + pp * 32 + g * 8), t1 = *reinterpret_cast<const float4*>(p.ln_b + pp * 32 + g * 8 + 4);
+          const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16)(((e < 4 ? acc2[rt][2 * pp][e] : acc2[rt][2 * pp + 1][e - 4]) - mean) * rstd * gg[e] + bb[e]);
+          xf[rt][pp] = o;
+        }
+      }
+    }
     {                                                           // chunk 0: GEMM1 only
       MLP_TOP()
       MLP_HEAD1()
@@ -305,7 +409,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
       float v[12][8];
 #pragma unroll
       for (int pp = 0; pp < 12; ++pp) {
-        const float4 r0 = *reinterpret_cast<const float4*>(p.x + ro + pp * 32), r1 = *reinterpret_cast<const float4*>(p.x + ro + pp * 32 + 4);
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;   // PROJ: the residual is already inside acc2
+        if (!PROJ) { r0 = *reinterpret_cast<const float4*>(p.x + ro + pp * 32); r1 = *reinterpret_cast<const float4*>(p.x + ro + pp * 32 + 4); }
         const float4 c0 = *reinterpret_cast<const float4*>(p.b2 + pp * 32 + g * 8), c1 = *reinterpret_cast<const float4*>(p.b2 + pp * 32 + g * 8 + 4);
         v[pp][0] = acc2[rt][2 * pp][0] + c0.x + r0.x; v[pp][1] = acc2[rt][2 * pp][1] + c0.y + r0.y;
         v[pp][2] = acc2[rt][2 * pp][2] + c0.z + r0.z; v[pp][3] = acc2[rt][2 * pp][3] + c0.w + r0.w;
@@ -357,6 +462,7 @@ const char* mlp_fused_check(const MlpParams& p) {
   if (p.M <= 0) return "mlp_fused: bad row count";
   if (!p.x || !p.x_out || !p.ln_g || !p.ln_b || !p.w1 || !p.b1 || !p.w2p || !p.b2 || !p.gelu_lut) return "mlp_fused: null operand";
   if (p.nln_out && (!p.nln_g || !p.nln_b)) return "mlp_fused: next LayerNorm parameters";
+  if (p.att && (!p.wpp || !p.bp || (((uintptr_t)p.att | (uintptr_t)p.wpp | (uintptr_t)p.bp) & 15))) return "mlp_fused: projection operands";
   const uintptr_t a = (uintptr_t)p.x | (uintptr_t)p.x_out | (uintptr_t)p.ln_g | (uintptr_t)p.ln_b | (uintptr_t)p.w1 | (uintptr_t)p.b1 | (uintptr_t)p.w2p |
                       (uintptr_t)p.b2 | (uintptr_t)p.nln_out | (uintptr_t)p.nln_g | (uintptr_t)p.nln_b | (uintptr_t)p.gelu_lut;
   if (a & 15) return "mlp_fused: operands must be 16-byte aligned";
@@ -370,14 +476,16 @@ void launch_mlp_fused(const MlpParams& p_in, hipStream_t s) {
   if (const char* e = mlp_fused_check(p)) throw std::runtime_error(e);
   static bool once = false;
   if (!once) {
-    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
+    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
+    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
     once = true;
   }
   int dev = 0, cus = 256;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
   const int npanels = (p.M + BM - 1) / BM;
-  hipLaunchKernelGGL(mlp_fused_kernel, dim3(std::min(cus, npanels)), dim3(256), MLP_LDS, s, p);
+  if (p.att) hipLaunchKernelGGL(mlp_fused_kernel<true>, dim3(std::min(cus, npanels)), dim3(256), MLP_LDS, s, p);
+  else hipLaunchKernelGGL(mlp_fused_kernel<false>, dim3(std::min(cus, npanels)), dim3(256), MLP_LDS, s, p);
 }
 
 }  // namespace ttr

@@ -67,7 +67,7 @@ SYMBOLS = [
     ("ttr_set_decoder_mode", None, [_I]),
     ("ttr_set_tuning", _I, [C.c_char_p, _I]),
     ("ttr_last_host_us", None, [_VP, _PF]),
-    ("ttr_dbg_mlp", _I, [_VP, _PF, _I, _PF, _PF, C.c_float, _PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF]),
+    ("ttr_dbg_mlp", _I, [_VP, _PF, _I, _PF, _PF, C.c_float, _PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF]),
     ("ttr_dbg_dec_stamps", _I, [C.POINTER(C.c_ulonglong)]),
     ("ttr_bench_conv", _I, [_VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _PF]),
     ("ttr_get_profile", _I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
@@ -281,7 +281,7 @@ class Engine:
         self.lib.ttr_last_stage_ms(self.h, ms)
         return dict(craft=ms[0], post=ms[1], pack=ms[2], parseq=ms[3])
 
-    def dbg_mlp(self, x, ln_g, ln_b, w1, b1, w2, b2, nln_g=None, nln_b=None, eps=1e-6):
+    def dbg_mlp(self, x, ln_g, ln_b, w1, b1, w2, b2, nln_g=None, nln_b=None, eps=1e-6, att=None, wp=None, bp=None):
         """mlp_fused.hip on f32 rows x [M,384] -> (x_out f32 [M,384], LayerNorm_next(x_out) as f32 or None)."""
         f = lambda a: np.ascontiguousarray(a, np.float32)
         x, ln_g, ln_b, w1, b1, w2, b2 = map(f, (x, ln_g, ln_b, w1, b1, w2, b2))
@@ -291,7 +291,8 @@ class Engine:
         ng, nb = (f(nln_g), f(nln_b)) if nln_g is not None else (None, None)
         self._check(self.lib.ttr_dbg_mlp(self.h, _f(x), M, _f(ln_g), _f(ln_b), eps, _f(w1), _f(b1), _f(w2), _f(b2),
                                          _f(ng) if ng is not None else None, _f(nb) if nb is not None else None, _f(out),
-                                         _f(nout) if nout is not None else None))
+                                         _f(nout) if nout is not None else None,
+                                         _f(f(att)) if att is not None else None, _f(f(wp)) if att is not None else None, _f(f(bp)) if att is not None else None))
         return out, nout
 
     def last_host_us(self):
