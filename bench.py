@@ -207,12 +207,12 @@ def main():
                        "parallelism": f"dp{world}"},
             "p50_page_latency_ms": p50,
             "stage_ms_last_step": {k: round(v, 3) for k, v in stage.items()},
-            "roofline": {"kernel": "CRAFT convolutions: conv3p_kernel / gemm2_kernel / conv1_direct_kernel (+ igemm_kernel for the 32-channel head)", "bound": "mfma",
+            "roofline": {"kernel": "CRAFT convolutions: conv3p_first2_kernel / conv3p_kernel / conv3s_kernel / gemm2_kernel (24 launches per 16-page group)", "bound": "mfma",
                          "achieved": craft_tflops, "peak": peak, "unit": "TFLOP/s",
                          "frac": (craft_tflops / peak) if craft_tflops else None, "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes over 16-page CRAFT groups, profiles/r01_pmc_craft_b16.json)",
                          "launches_per_step": c["launches"] / max(1, args.steps * NC), "avg_launch_us": c["ms"] * 1e3 / max(1, c["launches"]),
                          "algorithmic_gflop_per_page": CRAFT_GFLOP_PER_PAGE},
-            "roofline_parseq_gemm": {"kernel": "gemm2_kernel: the ViT encoder GEMMs (+ cross-attention K/V projection and the refinement pass)", "bound": "mfma", "achieved": pq_tflops, "peak": peak,
+            "roofline_parseq_gemm": {"kernel": "PARSeq batched GEMM launches: gemm_ws_kernel (qkv, cross K/V), mlp_fused_kernel (proj + fc1 + fc2 of a block, LayerNorms and GELU included in its time), gemm2_kernel (patch embedding, refinement pass)", "bound": "mfma", "achieved": pq_tflops, "peak": peak,
                                      "unit": "TFLOP/s", "frac": (pq_tflops / peak) if pq_tflops else None,
                                      "launches_per_step": q["launches"] / SEC_STEPS, "measured": "2 extra steps after the timed region"},
             "roofline_parseq_ar_gemm": {"kernel": "gemm_sk_kernel: per-step autoregressive decoder linears (M = crops in flight; latency-bound)",
