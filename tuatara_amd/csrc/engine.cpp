@@ -1212,6 +1212,29 @@ int ttr_dbg_mlp(ttr_engine* e, const float* x, int M, const float* ln_g, const f
   TTR_GUARD_END(-1)
 }
 
+int ttr_dbg_attn_enc(ttr_engine* e, const float* qkv, int N, float* out) {
+  TTR_GUARD_BEGIN
+  Engine& E = *e->e;
+  std::lock_guard<std::mutex> lk(E.mu);
+  const size_t nin = (size_t)N * 128 * 1152, nout = (size_t)N * 128 * 384;
+  DevBuf din, dout;
+  din.ensure(nin * E.es); dout.ensure(nout * E.es);
+  if (E.prec == kBF16) {
+    std::vector<uint16_t> h(nin);
+    for (size_t i = 0; i < nin; ++i) h[i] = f32_to_bf16_rne(qkv[i]);
+    TTR_HIP_CHECK(hipMemcpy(din.p, h.data(), nin * 2, hipMemcpyHostToDevice));
+  } else TTR_HIP_CHECK(hipMemcpy(din.p, qkv, nin * 4, hipMemcpyHostToDevice));
+  launch_attn_enc(E.prec, din.p, dout.p, N, E.stream);
+  TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
+  if (E.prec == kBF16) {
+    std::vector<uint16_t> h(nout);
+    TTR_HIP_CHECK(hipMemcpy(h.data(), dout.p, nout * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < nout; ++i) { const uint32_t u = (uint32_t)h[i] << 16; memcpy(&out[i], &u, 4); }
+  } else TTR_HIP_CHECK(hipMemcpy(out, dout.p, nout * 4, hipMemcpyDeviceToHost));
+  return 0;
+  TTR_GUARD_END(-1)
+}
+
 int ttr_dbg_conv_pool(ttr_engine* e, const float* in0, int C0, int B, int H, int W, int ks, const float* wgt, const float* bias, int Cout, int act,
                       int pool_relu, float* out_full, float* out_pool) {
   TTR_GUARD_BEGIN
@@ -1259,6 +1282,7 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "mlp_fused") g_mlp_fused = value;   // 0 off, 1 from mlp_min_rows rows on, 2 always
   else if (k == "mlp_min_rows") g_mlp_min_rows = value;
   else if (k == "mlp_proj") g_mlp_proj = value;
+  else if (k == "attn_impl") set_attn_impl(value);
   else if (k == "ws_dbg_flags") set_gemm_ws_dbg_flags(value);
   else if (k == "ws_lean") set_gemm_ws_lean(value);
   else if (k == "store_policy") set_store_policy(value);

@@ -190,8 +190,12 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(const T* __restrict__ qkv
     }
 }
 
+static int g_attn_impl = 1;
+void set_attn_impl(int v) { g_attn_impl = v; }
+
 void launch_attn_enc(Precision prec, const void* qkv, void* out, int N, hipStream_t s) {
   if (N <= 0) return;
+  if (prec == kBF16 && g_attn_impl) return launch_attn_enc2((const bf16*)qkv, (bf16*)out, N, s);
   auto lds_bytes = [](size_t es) { return (2 * 128 * (64 + 8) + 64 * (128 + 8)) * es; };
   if (prec == kBF16) {
     hipLaunchKernelGGL(attn_enc_kernel<bf16>, dim3(N * 6), dim3(256), lds_bytes(2), s, (const bf16*)qkv, (bf16*)out);

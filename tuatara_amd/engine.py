@@ -67,6 +67,7 @@ SYMBOLS = [
     ("ttr_set_decoder_mode", None, [_I]),
     ("ttr_set_tuning", _I, [C.c_char_p, _I]),
     ("ttr_last_host_us", None, [_VP, _PF]),
+    ("ttr_dbg_attn_enc", _I, [_VP, _PF, _I, _PF]),
     ("ttr_dbg_mlp", _I, [_VP, _PF, _I, _PF, _PF, C.c_float, _PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF]),
     ("ttr_dbg_dec_stamps", _I, [C.POINTER(C.c_ulonglong)]),
     ("ttr_bench_conv", _I, [_VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _PF]),
@@ -280,6 +281,14 @@ class Engine:
         ms = (C.c_float * 4)()
         self.lib.ttr_last_stage_ms(self.h, ms)
         return dict(craft=ms[0], post=ms[1], pack=ms[2], parseq=ms[3])
+
+    def dbg_attn_enc(self, qkv):
+        """Encoder self-attention on qkv [N,128,1152] -> [N,128,384] (values rounded to the engine's type on the way in / out)."""
+        qkv = np.ascontiguousarray(qkv, np.float32)
+        N = qkv.shape[0]
+        out = np.zeros((N, 128, 384), np.float32)
+        self._check(self.lib.ttr_dbg_attn_enc(self.h, _f(qkv), N, _f(out)))
+        return out
 
     def dbg_mlp(self, x, ln_g, ln_b, w1, b1, w2, b2, nln_g=None, nln_b=None, eps=1e-6, att=None, wp=None, bp=None):
         """mlp_fused.hip on f32 rows x [M,384] -> (x_out f32 [M,384], LayerNorm_next(x_out) as f32 or None)."""
