@@ -124,6 +124,8 @@ int ttr_set_tuning(const char* key, int value);
 void ttr_last_host_us(ttr_engine* e, float out[8]);
 /* test hook for the ViT encoder self-attention kernels: qkv f32 [N][128][1152] (rounded to the engine's type) -> out [N][128][384] */
 int ttr_dbg_attn_enc(ttr_engine* e, const float* qkv, int N, float* out);
+/* test hook for qkv_attn.hip (bf16 engines): x f32 [N][128][384], w [1152][384], b [1152] -> self-attention output [N][128][384] */
+int ttr_dbg_qkv_attn(ttr_engine* e, const float* x, int N, const float* w, const float* b, float* out);
 /* test hook for mlp_fused.hip (bf16 engines): x_out = x + fc2(GELU(fc1(LayerNorm(x)))) over f32 rows [M][384] with weights
  * w1 [1536][384], w2 [384][1536] (rounded to bf16 inside); nln_out (may be NULL) = LayerNorm(x_out; nln_g, nln_b), bf16 values as f32.
  * With att != NULL the attention output projection runs first in the same launch: x is replaced by x + att . wp^T + bp

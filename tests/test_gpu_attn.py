@@ -54,3 +54,21 @@ def test_attn_enc_generations_agree(eng_bf16):
         eng_bf16.lib.ttr_set_tuning(b"attn_impl", 1)
     assert (np.abs(a - b) <= 2.0 ** -7 * np.abs(a) + 1e-6).all()          # at most one bf16 ulp (fp32 summation order)
     assert (a != b).mean() < 0.05
+
+
+@pytest.mark.parametrize("N", [3, 41, 95])
+def test_qkv_attn_fused_against_numpy(eng_bf16, N):
+    """qkv_attn.hip: projection + attention in one kernel; 3 crops = fewer than crop groups, 41 / 95 = ragged shares."""
+    rng = np.random.default_rng(N)
+    x = rng.standard_normal((N, 128, 384)).astype(np.float32)
+    w = (rng.standard_normal((1152, 384)) / np.sqrt(384)).astype(np.float32) * 1.5
+    b = (0.3 * rng.standard_normal(1152)).astype(np.float32)
+    out = eng_bf16.dbg_qkv_attn(x, w, b)
+    out2 = eng_bf16.dbg_qkv_attn(x, w, b)
+    assert np.array_equal(out, out2)
+    qkv = bf(x).astype(np.float64).reshape(-1, 384) @ bf(w).astype(np.float64).T + b
+    ref = ref_attn(qkv.reshape(N, 128, 1152).astype(np.float32))
+    err = np.abs(out - ref)
+    tol = 2.0 ** -7 * np.abs(ref) + 6e-3
+    assert (err <= tol).all(), float((err - tol).max())
+    assert err.mean() < 2e-3

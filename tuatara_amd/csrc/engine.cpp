@@ -44,6 +44,8 @@ void hip_fail(const char* what, hipError_t e, const char* file, int line) {
 static thread_local std::string g_last_error;
 static unsigned long long* g_dec_dbg = nullptr;   // device buffer for dec_ar phase stamps (diagnostics)
 static int g_dbg_bf16_out = 0;     // ttr_dbg_conv on a bf16 engine: take the kernel's bf16 output (the path the engine uses) instead of the f32 one
+static int g_qkv_attn = 1;           // bf16 encoder: qkv projection + self-attention as one kernel (qkv_attn.hip) from g_qkv_attn_min crops on
+static int g_qkv_attn_min = 160;
 static int g_mlp_proj = 1;           // ... with the attention output projection in front of it in the same launch
 static int g_mlp_min_rows = 49152;   // = 384 crops
 static int g_mlp_fused = 1;        // bf16 encoder: norm2 + fc1 + GELU + fc2 + residual (+ the next LayerNorm) as one kernel (mlp_fused.hip)
@@ -668,8 +670,13 @@ struct Engine {
       for (int l = 0; l < 12; ++l) {
         std::string p = "encoder.blocks." + std::to_string(l) + ".";
         if (!mlp_fused) ln(xc, p + "norm1", 1e-6f, t384, Mc);
-        gemm(pq.at(p + "qkv"), t384, Mc, tbig, 3 * E, kActNone);
-        launch_attn_enc(prec, tbig, att, nc, stream);
+        if (prec == kBF16 && gemm_config() >= 0 && (g_qkv_attn == 2 || (g_qkv_attn == 1 && nc >= g_qkv_attn_min))) {
+          const Linear& L = pq.at(p + "qkv");
+          timed(2.0 * Mc * E * 3 * E, [&] { launch_qkv_attn((const bf16*)t384, L.w.as<bf16>(), L.b.as<float>(), (bf16*)att, nc, stream); });
+        } else {
+          gemm(pq.at(p + "qkv"), t384, Mc, tbig, 3 * E, kActNone);
+          launch_attn_enc(prec, tbig, att, nc, stream);
+        }
         const bool proj_in = mlp_fused && g_mlp_proj;            // the projection runs inside the fused block kernel
         if (!proj_in) gemm(pq.at(p + "proj"), att, Mc, nullptr, 0, kActNone, xc, E, xc, E, 0);
         if (mlp_fused) {
@@ -1212,6 +1219,28 @@ int ttr_dbg_mlp(ttr_engine* e, const float* x, int M, const float* ln_g, const f
   TTR_GUARD_END(-1)
 }
 
+int ttr_dbg_qkv_attn(ttr_engine* e, const float* x, int N, const float* w, const float* b, float* out) {
+  TTR_GUARD_BEGIN
+  Engine& E = *e->e;
+  std::lock_guard<std::mutex> lk(E.mu);
+  if (E.prec != kBF16) throw std::runtime_error("ttr_dbg_qkv_attn: bf16 engines only");
+  const size_t nx = (size_t)N * 128 * 384, nw = (size_t)1152 * 384;
+  DevBuf dx, dw, db, dout;
+  std::vector<uint16_t> h(std::max(nx, nw));
+  for (size_t i = 0; i < nx; ++i) h[i] = f32_to_bf16_rne(x[i]);
+  dx.ensure(nx * 2); TTR_HIP_CHECK(hipMemcpy(dx.p, h.data(), nx * 2, hipMemcpyHostToDevice));
+  for (size_t i = 0; i < nw; ++i) h[i] = f32_to_bf16_rne(w[i]);
+  dw.ensure(nw * 2); TTR_HIP_CHECK(hipMemcpy(dw.p, h.data(), nw * 2, hipMemcpyHostToDevice));
+  db.ensure(1152 * 4); TTR_HIP_CHECK(hipMemcpy(db.p, b, 1152 * 4, hipMemcpyHostToDevice));
+  dout.ensure(nx * 2);
+  launch_qkv_attn(dx.as<bf16>(), dw.as<bf16>(), db.as<float>(), dout.as<bf16>(), N, E.stream);
+  TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
+  TTR_HIP_CHECK(hipMemcpy(h.data(), dout.p, nx * 2, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < nx; ++i) { const uint32_t u = (uint32_t)h[i] << 16; memcpy(&out[i], &u, 4); }
+  return 0;
+  TTR_GUARD_END(-1)
+}
+
 int ttr_dbg_attn_enc(ttr_engine* e, const float* qkv, int N, float* out) {
   TTR_GUARD_BEGIN
   Engine& E = *e->e;
@@ -1283,6 +1312,8 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "mlp_min_rows") g_mlp_min_rows = value;
   else if (k == "mlp_proj") g_mlp_proj = value;
   else if (k == "attn_impl") set_attn_impl(value);
+  else if (k == "qkv_attn") g_qkv_attn = value;        // 0 off, 1 from qkv_attn_min crops on, 2 always
+  else if (k == "qkv_attn_min") g_qkv_attn_min = value;
   else if (k == "ws_dbg_flags") set_gemm_ws_dbg_flags(value);
   else if (k == "ws_lean") set_gemm_ws_lean(value);
   else if (k == "store_policy") set_store_policy(value);

@@ -78,6 +78,8 @@ void launch_patchify(Precision prec, const uint8_t* crops, void* out, int N, hip
 void launch_layernorm(Precision prec, const float* in, int in_ld, const float* gamma, const float* beta, float eps, void* out, int out_ld, int M, int D, hipStream_t s);
 void launch_attn_enc(Precision prec, const void* qkv, void* out, int N, hipStream_t s);  // qkv T [N*128][1152] -> out T [N*128][384]
 void launch_attn_enc2(const bf16* qkv, bf16* out, int N, hipStream_t s);                  // bf16, second generation (attn_enc2.hip)
+// qkv projection + self-attention fused (qkv_attn.hip): x bf16 [N*128][384] (LayerNorm output), w [1152][384], bias [1152] -> out [N*128][384]
+void launch_qkv_attn(const bf16* x, const bf16* w, const float* bias, bf16* out, int N, hipStream_t s);
 void set_attn_impl(int v);                                                               // 0: bf16 also uses the first generation
 // content token embedding + norm_c.  rows (n, i) for i in [i0,i1): out row n*(i1-i0)+(i-i0)
 void launch_dec_embed_ln(Precision prec, const int* tokens, const float* emb, const float* pos_q, const float* gamma, const float* beta, float eps,

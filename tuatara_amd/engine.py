@@ -68,6 +68,7 @@ SYMBOLS = [
     ("ttr_set_tuning", _I, [C.c_char_p, _I]),
     ("ttr_last_host_us", None, [_VP, _PF]),
     ("ttr_dbg_attn_enc", _I, [_VP, _PF, _I, _PF]),
+    ("ttr_dbg_qkv_attn", _I, [_VP, _PF, _I, _PF, _PF, _PF]),
     ("ttr_dbg_mlp", _I, [_VP, _PF, _I, _PF, _PF, C.c_float, _PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF]),
     ("ttr_dbg_dec_stamps", _I, [C.POINTER(C.c_ulonglong)]),
     ("ttr_bench_conv", _I, [_VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _PF]),
@@ -288,6 +289,13 @@ class Engine:
         N = qkv.shape[0]
         out = np.zeros((N, 128, 384), np.float32)
         self._check(self.lib.ttr_dbg_attn_enc(self.h, _f(qkv), N, _f(out)))
+        return out
+
+    def dbg_qkv_attn(self, x, w, b):
+        """qkv_attn.hip: x [N,128,384] (LayerNorm output), w [1152,384], b [1152] -> attention output [N,128,384]."""
+        x = np.ascontiguousarray(x, np.float32); w = np.ascontiguousarray(w, np.float32); b = np.ascontiguousarray(b, np.float32)
+        out = np.zeros((x.shape[0], 128, 384), np.float32)
+        self._check(self.lib.ttr_dbg_qkv_attn(self.h, _f(x), x.shape[0], _f(w), _f(b), _f(out)))
         return out
 
     def dbg_mlp(self, x, ln_g, ln_b, w1, b1, w2, b2, nln_g=None, nln_b=None, eps=1e-6, att=None, wp=None, bp=None):
