@@ -1311,6 +1311,7 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "mlp_fused") g_mlp_fused = value;   // 0 off, 1 from mlp_min_rows rows on, 2 always
   else if (k == "mlp_min_rows") g_mlp_min_rows = value;
   else if (k == "mlp_proj") g_mlp_proj = value;
+  else if (k == "mlp_store_nt") set_mlp_store_nt(value);
   else if (k == "attn_impl") set_attn_impl(value);
   else if (k == "qkv_attn") g_qkv_attn = value;        // 0 off, 1 from qkv_attn_min crops on, 2 always
   else if (k == "qkv_attn_min") g_qkv_attn_min = value;

@@ -24,6 +24,7 @@ const void* gelu_lut_for_current_device();
 const char* gemm_sk_check(const ConvParams& p);
 void launch_gemm_sk(const ConvParams& p, hipStream_t s);
 void set_skinny_max_rows(int m);   // problems with M <= m rows go to gemm_sk (0 = never)
+void set_mlp_store_nt(int v);
 void set_mlp_stamps(unsigned long long* dev_buf);       // >= 48*8 u64 or null
 void set_gemm_ws_stamps(unsigned long long* dev_buf);   // >= 2*24*8 u64, or null: phase stamps of gemm_ws workgroup 0
 extern int g_store_policy;          // cache policy of the big streaming output stores: 0 default, 1 nt, 2 sc0 sc1 nt
@@ -103,6 +104,7 @@ struct MlpParams {
   const float *nln_g, *nln_b; float nln_eps; bf16* nln_out;   // optional: LayerNorm of x_out -> bf16 [M][384]
   const bf16* att; const bf16* wpp; const float* bp;  // optional: x' = x + att . Wp^T + bp first (att bf16 [M][384], Wp packed [12][384][32])
   const void* gelu_lut;    // set by the launcher
+  int store_nt;            // set by the launcher: streaming policy on the epilogue stores
   unsigned long long* dbg; // optional [48][8] shader-clock stamps of workgroup 0 / wave 0 over its first panel (diagnostics)
   int M;
 };

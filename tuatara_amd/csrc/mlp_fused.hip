@@ -52,7 +52,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t m_rsrc(const void* base, unsig
 // PROJ: the block's attention output projection runs in front, in the same launch: x' = x + att . Wp^T + bp is accumulated in the
 // registers that then hold the MLP's output tile, so the residual stream is read once and written once per block (12 more ring
 // items per panel: the [384 x 32] k-step slabs of a chunk-major copy of Wp, in the W2 half of a slot)
-template <bool PROJ>
+// STAMPS: a build with the phase stamps of tools/mlp_stamps.py (kept out of the production instantiations: the stamp address is one
+// more value for the register allocator to spill inside the chunk loop)
+template <bool PROJ, bool STAMPS>
 __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
   constexpr int NPJ = PROJ ? E / CH : 0, ITEMS = NPJ + NCH + 1;   // ring items per panel
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -137,11 +139,13 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
   for (int pi = 0; pi < my_n; ++pi) {
     const int panel = (int)blockIdx.x + pi * (int)gridDim.x;
     const int row0 = panel * BM + wave * 32;
+#define MLP_PSTAMP(k) do { if (STAMPS && p.dbg && blockIdx.x == 0 && tid == 0 && pi < 4) p.dbg[384 + pi * 4 + (k)] = __builtin_readcyclecounter(); } while (0)
+    MLP_PSTAMP(0);   // panel start | chunk loop start | chunk loop end | panel end
 
     bf16x8 xf[2][12];                                           // LayerNorm_2 of this wave's 32 rows as MFMA B fragments
     f32x4 acc2[2][24];                                          // the wave's [32 rows x 384] f32 output tile
     int i = 0;
-#define MLP_STAMP(ph) do { if (p.dbg && blockIdx.x == 0 && tid == 0 && pi == 0 && i < NCH) p.dbg[i * 8 + (ph)] = __builtin_readcyclecounter(); } while (0)
+#define MLP_STAMP(ph) do { if (STAMPS && p.dbg && blockIdx.x == 0 && tid == 0 && pi == 0 && i < NCH) p.dbg[i * 8 + (ph)] = __builtin_readcyclecounter(); } while (0)
 // Fragment groups of 4 (8 MFMAs each), three register buffers, reads two groups ahead.  GEMM1 group n = k-steps 2n, 2n+1 x the
 // two 16-row weight tiles; GEMM2 group n = output-channel tiles 4n .. 4n+3.
 #define MLP_G1(dst, n)                                                                                                   \
@@ -343,6 +347,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
         }
       }
     }
+    MLP_PSTAMP(1);
     {                                                           // chunk 0: GEMM1 only
       MLP_TOP()
       MLP_HEAD1()
@@ -400,6 +405,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
       ++G;
     }
 
+    MLP_PSTAMP(2);
     // ---- epilogue: + bias2 + residual -> f32; lane holds, of row 16 rt + q, channels 32 pp + 8 g + e (pp = 0..11)
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
@@ -421,8 +427,14 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
 #pragma unroll
         for (int pp = 0; pp < 12; ++pp) {
           float* op = p.x_out + ro + pp * 32;
-          *reinterpret_cast<float4*>(op) = make_float4(v[pp][0], v[pp][1], v[pp][2], v[pp][3]);
-          *reinterpret_cast<float4*>(op + 4) = make_float4(v[pp][4], v[pp][5], v[pp][6], v[pp][7]);
+          typedef __attribute__((ext_vector_type(4))) float f4;
+          if (p.store_nt) {
+            __builtin_nontemporal_store(f4{v[pp][0], v[pp][1], v[pp][2], v[pp][3]}, reinterpret_cast<f4*>(op));
+            __builtin_nontemporal_store(f4{v[pp][4], v[pp][5], v[pp][6], v[pp][7]}, reinterpret_cast<f4*>(op + 4));
+          } else {
+            *reinterpret_cast<float4*>(op) = make_float4(v[pp][0], v[pp][1], v[pp][2], v[pp][3]);
+            *reinterpret_cast<float4*>(op + 4) = make_float4(v[pp][4], v[pp][5], v[pp][6], v[pp][7]);
+          }
         }
       }
       if (p.nln_out) {                                          // uniform
@@ -448,14 +460,17 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
           bf16x8 o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (bf16)((v[pp][e] - mean) * rstd * gg[e] + bb[e]);
-          if (live) *reinterpret_cast<bf16x8*>(p.nln_out + ro + pp * 32) = o;
+          if (live) { if (p.store_nt) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(p.nln_out + ro + pp * 32)); else *reinterpret_cast<bf16x8*>(p.nln_out + ro + pp * 32) = o; }
         }
       }
     }
+    MLP_PSTAMP(3);
   }
 }
 
 static unsigned long long* g_mlp_dbg = nullptr;
+static int g_mlp_store_nt = 1;   // streaming policy on the epilogue's residual / LayerNorm stores: -0.25 ms per 32-page step
+void set_mlp_store_nt(int v) { g_mlp_store_nt = v; }
 void set_mlp_stamps(unsigned long long* d) { g_mlp_dbg = d; }
 
 const char* mlp_fused_check(const MlpParams& p) {
@@ -472,20 +487,26 @@ const char* mlp_fused_check(const MlpParams& p) {
 void launch_mlp_fused(const MlpParams& p_in, hipStream_t s) {
   MlpParams p = p_in;
   p.gelu_lut = gelu_lut_for_current_device();
-  p.dbg = g_mlp_dbg;
+  p.dbg = g_mlp_dbg; p.store_nt = g_mlp_store_nt;
   if (const char* e = mlp_fused_check(p)) throw std::runtime_error(e);
   static bool once = false;
   if (!once) {
-    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
-    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
+    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
+    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
+    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
+    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
     once = true;
   }
   int dev = 0, cus = 256;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
   const int npanels = (p.M + BM - 1) / BM;
-  if (p.att) hipLaunchKernelGGL(mlp_fused_kernel<true>, dim3(std::min(cus, npanels)), dim3(256), MLP_LDS, s, p);
-  else hipLaunchKernelGGL(mlp_fused_kernel<false>, dim3(std::min(cus, npanels)), dim3(256), MLP_LDS, s, p);
+  const dim3 grid(std::min(cus, npanels));
+  if (p.dbg) {
+    if (p.att) hipLaunchKernelGGL((mlp_fused_kernel<true, true>), grid, dim3(256), MLP_LDS, s, p);
+    else hipLaunchKernelGGL((mlp_fused_kernel<false, true>), grid, dim3(256), MLP_LDS, s, p);
+  } else if (p.att) hipLaunchKernelGGL((mlp_fused_kernel<true, false>), grid, dim3(256), MLP_LDS, s, p);
+  else hipLaunchKernelGGL((mlp_fused_kernel<false, false>), grid, dim3(256), MLP_LDS, s, p);
 }
 
 }  // namespace ttr
