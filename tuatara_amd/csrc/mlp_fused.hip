@@ -413,27 +413,49 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
       const bool live = row < p.M;
       const size_t ro = (size_t)min(row, p.M - 1) * E + g * 8;
       float v[12][8];
+      // loads in batches of 4 channel groups (a scheduling barrier keeps hipcc from sinking each load to its use, which made
+      // this 24 dependent L2 round trips; all 12 groups at once spill)
 #pragma unroll
-      for (int pp = 0; pp < 12; ++pp) {
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;   // PROJ: the residual is already inside acc2
-        if (!PROJ) { r0 = *reinterpret_cast<const float4*>(p.x + ro + pp * 32); r1 = *reinterpret_cast<const float4*>(p.x + ro + pp * 32 + 4); }
-        const float4 c0 = *reinterpret_cast<const float4*>(p.b2 + pp * 32 + g * 8), c1 = *reinterpret_cast<const float4*>(p.b2 + pp * 32 + g * 8 + 4);
-        v[pp][0] = acc2[rt][2 * pp][0] + c0.x + r0.x; v[pp][1] = acc2[rt][2 * pp][1] + c0.y + r0.y;
-        v[pp][2] = acc2[rt][2 * pp][2] + c0.z + r0.z; v[pp][3] = acc2[rt][2 * pp][3] + c0.w + r0.w;
-        v[pp][4] = acc2[rt][2 * pp + 1][0] + c1.x + r1.x; v[pp][5] = acc2[rt][2 * pp + 1][1] + c1.y + r1.y;
-        v[pp][6] = acc2[rt][2 * pp + 1][2] + c1.z + r1.z; v[pp][7] = acc2[rt][2 * pp + 1][3] + c1.w + r1.w;
+      for (int pb = 0; pb < 3; ++pb) {
+        float4 c0[4], c1[4], r0[4], r1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int pp = 4 * pb + k;
+          c0[k] = *reinterpret_cast<const float4*>(p.b2 + pp * 32 + g * 8); c1[k] = *reinterpret_cast<const float4*>(p.b2 + pp * 32 + g * 8 + 4);
+          r0[k] = make_float4(0.f, 0.f, 0.f, 0.f); r1[k] = r0[k];   // PROJ: the residual is already inside acc2
+          if (!PROJ) { r0[k] = *reinterpret_cast<const float4*>(p.x + ro + pp * 32); r1[k] = *reinterpret_cast<const float4*>(p.x + ro + pp * 32 + 4); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int pp = 4 * pb + k;
+          v[pp][0] = acc2[rt][2 * pp][0] + c0[k].x + r0[k].x; v[pp][1] = acc2[rt][2 * pp][1] + c0[k].y + r0[k].y;
+          v[pp][2] = acc2[rt][2 * pp][2] + c0[k].z + r0[k].z; v[pp][3] = acc2[rt][2 * pp][3] + c0[k].w + r0[k].w;
+          v[pp][4] = acc2[rt][2 * pp + 1][0] + c1[k].x + r1[k].x; v[pp][5] = acc2[rt][2 * pp + 1][1] + c1[k].y + r1[k].y;
+          v[pp][6] = acc2[rt][2 * pp + 1][2] + c1[k].z + r1[k].z; v[pp][7] = acc2[rt][2 * pp + 1][3] + c1[k].w + r1[k].w;
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if (live) {
+      // f32 stores: a lane holds 8 consecutive channels = 2 x 16 B, so storing them as they are writes four 16-byte pieces with
+      // 16-byte holes per row per instruction.  v_permlane32_swap (lanes i <-> i + 32, i.e. g <-> g + 2) of the lower half's second
+      // quad with the upper half's first quad makes each instruction write 64 contiguous bytes per row:
+      //   first instruction:  g = 0, 1, 2, 3 -> bytes 0-15, 32-47, 16-31, 48-63 of the row's 128;   second: the same + 64
+      {
+        float* const ob = p.x_out + ro - g * 8 + ((g & 1) * 8 + (g >> 1) * 4);     // row base + this lane's 16-byte slot of the first half
 #pragma unroll
         for (int pp = 0; pp < 12; ++pp) {
-          float* op = p.x_out + ro + pp * 32;
           typedef __attribute__((ext_vector_type(4))) float f4;
-          if (p.store_nt) {
-            __builtin_nontemporal_store(f4{v[pp][0], v[pp][1], v[pp][2], v[pp][3]}, reinterpret_cast<f4*>(op));
-            __builtin_nontemporal_store(f4{v[pp][4], v[pp][5], v[pp][6], v[pp][7]}, reinterpret_cast<f4*>(op + 4));
-          } else {
-            *reinterpret_cast<float4*>(op) = make_float4(v[pp][0], v[pp][1], v[pp][2], v[pp][3]);
-            *reinterpret_cast<float4*>(op + 4) = make_float4(v[pp][4], v[pp][5], v[pp][6], v[pp][7]);
+          f4 lo, hi;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float a_ = v[pp][e], b_ = v[pp][4 + e];          // (the pair-returning builtin gave hi == lo here)
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a_), "+v"(b_));
+            lo[e] = a_; hi[e] = b_;
+          }
+          if (live) {
+            float* op = ob + pp * 32;
+            if (p.store_nt) { __builtin_nontemporal_store(lo, reinterpret_cast<f4*>(op)); __builtin_nontemporal_store(hi, reinterpret_cast<f4*>(op + 16)); }
+            else { *reinterpret_cast<f4*>(op) = lo; *reinterpret_cast<f4*>(op + 16) = hi; }
           }
         }
       }
@@ -453,14 +475,25 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
         s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
         const float rstd = rsqrtf(s2 * (1.f / E) + p.nln_eps);
 #pragma unroll
-        for (int pp = 0; pp < 12; ++pp) {
-          const float4 g0 = *reinterpret_cast<const float4*>(p.nln_g + pp * 32 + g * 8), g1 = *reinterpret_cast<const float4*>(p.nln_g + pp * 32 + g * 8 + 4);
-          const float4 t0 = *reinterpret_cast<const float4*>(p.nln_b + pp * 32 + g * 8), t1 = *reinterpret_cast<const float4*>(p.nln_b + pp * 32 + g * 8 + 4);
-          const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-          bf16x8 o;
+        for (int pb = 0; pb < 3; ++pb) {
+          float4 g0[4], g1[4], t0[4], t1[4];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = (bf16)((v[pp][e] - mean) * rstd * gg[e] + bb[e]);
-          if (live) { if (p.store_nt) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(p.nln_out + ro + pp * 32)); else *reinterpret_cast<bf16x8*>(p.nln_out + ro + pp * 32) = o; }
+          for (int k = 0; k < 4; ++k) {
+            const int pp = 4 * pb + k;
+            g0[k] = *reinterpret_cast<const float4*>(p.nln_g + pp * 32 + g * 8); g1[k] = *reinterpret_cast<const float4*>(p.nln_g + pp * 32 + g * 8 + 4);
+            t0[k] = *reinterpret_cast<const float4*>(p.nln_b + pp * 32 + g * 8); t1[k] = *reinterpret_cast<const float4*>(p.nln_b + pp * 32 + g * 8 + 4);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int pp = 4 * pb + k;
+            const float gg[8] = {g0[k].x, g0[k].y, g0[k].z, g0[k].w, g1[k].x, g1[k].y, g1[k].z, g1[k].w}, bb[8] = {t0[k].x, t0[k].y, t0[k].z, t0[k].w, t1[k].x, t1[k].y, t1[k].z, t1[k].w};
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)((v[pp][e] - mean) * rstd * gg[e] + bb[e]);
+            if (live) { if (p.store_nt) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(p.nln_out + ro + pp * 32)); else *reinterpret_cast<bf16x8*>(p.nln_out + ro + pp * 32) = o; }
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
