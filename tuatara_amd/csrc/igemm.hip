@@ -261,8 +261,10 @@ int skinny_max_rows() { return g_gemm_cfg == 0 || g_gemm_cfg >= 7 ? g_sk_max_row
 void set_gemm_config(int cfg) { g_gemm_cfg = cfg; }
 int gemm_config() { return g_gemm_cfg; }
 
-void launch_igemm(Precision prec, const ConvParams& p, hipStream_t s) {
-  if (const char* e = igemm_check(p)) throw std::runtime_error(e);
+void launch_igemm(Precision prec, const ConvParams& p_in, hipStream_t s) {
+  if (const char* e = igemm_check(p_in)) throw std::runtime_error(e);
+  ConvParams p = p_in;
+  p.store_policy = g_store_policy;
   if (p.ln_in) {   // LayerNorm fused into the GEMM prologue: only the skinny kernel implements it
     if (prec != kBF16) throw std::runtime_error("igemm: fused LayerNorm input is bf16-only");
     return launch_gemm_sk(p, s);
