@@ -133,3 +133,26 @@ def test_fused_mlp_block_matches_separate_kernels(eng_bf16, n):
     same_path = (a0.argmax(-1) == a1.argmax(-1)).all(1)
     assert same_path.mean() >= 0.5
     assert np.abs(a1[same_path] - a0[same_path]).max() < 0.6
+
+
+@pytest.mark.parametrize("n", [200, 400])
+def test_fused_encoder_block_kernels_at_their_batch_sizes(eng_bf16, n):
+    """Default kernel selection at 200 crops (qkv_attn on, mlp_fused off) and 400 crops (both on) against the layer-per-kernel
+    encoder (both knobs off): same pipeline up to fp32 summation order (see the note on random-noise crops above)."""
+    rng = np.random.default_rng(n)
+    crops = rng.integers(0, 256, (n, 32, 128, 3), dtype=np.uint8)
+    try:
+        eng_bf16.lib.ttr_set_tuning(b"mlp_fused", 0); eng_bf16.lib.ttr_set_tuning(b"qkv_attn", 0)
+        l0, a0, i0 = eng_bf16.parseq_logits(crops, want_ar=True)
+        eng_bf16.lib.ttr_set_tuning(b"mlp_fused", 1); eng_bf16.lib.ttr_set_tuning(b"qkv_attn", 1)
+        l1, a1, i1 = eng_bf16.parseq_logits(crops, want_ar=True)
+        l2, a2, i2 = eng_bf16.parseq_logits(crops, want_ar=True)
+    finally:
+        eng_bf16.lib.ttr_set_tuning(b"mlp_fused", 1); eng_bf16.lib.ttr_set_tuning(b"qkv_attn", 1)
+    assert np.isfinite(a1).all() and np.isfinite(l1).all()
+    assert np.array_equal(a1, a2) and np.array_equal(l1, l2)
+    d0 = np.abs(a1[:, 0] - a0[:, 0]).max(1)
+    assert np.median(d0) < 0.2 and d0.max() < 0.8
+    same_path = (a0.argmax(-1) == a1.argmax(-1)).all(1)
+    assert same_path.mean() >= 0.5
+    assert np.abs(a1[same_path] - a0[same_path]).max() < 0.8
