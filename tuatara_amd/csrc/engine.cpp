@@ -253,6 +253,15 @@ struct Engine {
   hipStream_t stream = nullptr;
   std::unique_ptr<HostPool> host_pool;
   hipStream_t copy_stream = nullptr;              // device -> host copies of one page group's components while the next group's CRAFT runs
+  hipEvent_t copy_ev = nullptr, done_ev = nullptr;
+  // hand-over points of a batch are polled, not slept on: a blocking wait costs tens of microseconds of wake-up per sync
+  static void spin_event(hipEvent_t e) {
+    for (;;) {
+      const hipError_t r = hipEventQuery(e);
+      if (r == hipSuccess) return;
+      if (r != hipErrorNotReady) hip_fail("hipEventQuery", r, __FILE__, __LINE__);
+    }
+  }
   std::vector<hipEvent_t> group_ev;               // per page group: component counters are on the host
   std::mutex mu;
   Tokenizer tok;
@@ -469,6 +478,8 @@ struct Engine {
     TTR_HIP_CHECK(hipSetDevice(cfg.device));
     TTR_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     TTR_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    TTR_HIP_CHECK(hipEventCreateWithFlags(&copy_ev, hipEventDisableTiming));
+    TTR_HIP_CHECK(hipEventCreateWithFlags(&done_ev, hipEventDisableTiming));
     host_pool.reset(new HostPool(std::min(15, std::max(1, (int)std::thread::hardware_concurrency() - 1))));
     for (auto& x : ev) TTR_HIP_CHECK(hipEventCreate(&x));
     load_craft(dir);
@@ -478,6 +489,8 @@ struct Engine {
     for (auto& x : ev) if (x) (void)hipEventDestroy(x);
     for (auto& x : prof_pool) (void)hipEventDestroy(x);
     for (auto& x : group_ev) (void)hipEventDestroy(x);
+    if (copy_ev) (void)hipEventDestroy(copy_ev);
+    if (done_ev) (void)hipEventDestroy(done_ev);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -778,7 +791,7 @@ struct Engine {
   void ccl_collect(int p0, int pages, int g, int H2, int W2, std::vector<std::vector<RRect>>& det) {
     const int* counters = h_counters.as<int>() + 2 * p0;
     const double tc0 = now_us();
-    TTR_HIP_CHECK(hipEventSynchronize(group_ev[g]));
+    spin_event(group_ev[g]);
     const double tc1 = now_us();
     // two strided copies bring every page's candidates and row extremes over (width = the busiest page's share)
     int max_c = 0, max_r = 0;
@@ -796,7 +809,8 @@ struct Engine {
       const CclBuffers v = ccl.view(p0);
       TTR_HIP_CHECK(hipMemcpy2DAsync(cand, pitch_c, v.cand, (size_t)ccl.max_cand * 32, pitch_c, pages, hipMemcpyDeviceToHost, copy_stream));
       TTR_HIP_CHECK(hipMemcpy2DAsync(rw, pitch_r, v.rows_packed, (size_t)ccl.npx * 8, pitch_r, pages, hipMemcpyDeviceToHost, copy_stream));
-      TTR_HIP_CHECK(hipStreamSynchronize(copy_stream));
+      TTR_HIP_CHECK(hipEventRecord(copy_ev, copy_stream));
+      spin_event(copy_ev);
     }
     const double tc2 = now_us();
     // the calipers of a page depend on nothing but that page: a few host threads share the group
@@ -893,7 +907,8 @@ struct Engine {
       TTR_HIP_CHECK(hipEventRecord(ev[4], stream));
     }
     const double th2 = now_us();
-    TTR_HIP_CHECK(hipStreamSynchronize(stream));
+    TTR_HIP_CHECK(hipEventRecord(done_ev, stream));
+    spin_event(done_ev);
     const double th3 = now_us();
     for (int s = 0; s < 4; ++s) (void)hipEventElapsedTime(&stage_ms[s], ev[s], ev[s + 1]);
     if (profiling) prof_collect();
