@@ -138,6 +138,32 @@ struct WeightFile {
 };
 
 // A GEMM-shaped weight on the device: T [Cout_pad][K_pad] + f32 bias
+// mlp_fused.hip's weight operands are stored as the LDS images the kernel multiplies from (see the layout notes there)
+void pack_mlp_w1(const float* w1, uint16_t* out) {               // w1 [1536][384] -> [48 chunks][3 segments][32 rows][16 positions][8]
+  for (int c = 0; c < 48; ++c)
+    for (int s = 0; s < 3; ++s)
+      for (int R = 0; R < 32; ++R) {
+        const int n = ((R & 15) >> 2) * 8 + (R >> 4) * 4 + (R & 3);          // hidden unit of LDS row R
+        for (int cp = 0; cp < 16; ++cp) {
+          const int ch = s * 16 + (cp ^ (R & 15));                            // source 16-byte chunk at position cp
+          uint16_t* d = out + ((((size_t)c * 3 + s) * 32 + R) * 16 + cp) * 8;
+          for (int e = 0; e < 8; ++e) d[e] = f32_to_bf16_rne(w1[(size_t)(32 * c + n) * 384 + ch * 8 + e]);
+        }
+      }
+}
+void pack_mlp_w2(const float* w, int K, uint16_t* out) {          // w [384][K] -> [K/32 chunks][384 rows][4 positions][8]
+  for (int c = 0; c < K / 32; ++c)
+    for (int R = 0; R < 384; ++R) {
+      const int ot = R >> 4, q = R & 15;
+      const int oc = (ot >> 1) * 32 + (q >> 2) * 8 + (ot & 1) * 4 + (q & 3);   // output channel of LDS row R
+      for (int cp = 0; cp < 4; ++cp) {
+        const int g = cp ^ ((R >> 1) & 3);
+        uint16_t* d = out + (((size_t)c * 384 + R) * 4 + cp) * 8;
+        for (int e = 0; e < 8; ++e) d[e] = f32_to_bf16_rne(w[(size_t)oc * K + 32 * c + g * 8 + e]);
+      }
+    }
+}
+
 struct Linear {
   DevBuf w, b;
   int cout = 0, k = 0;  // padded sizes as the kernel sees them
@@ -271,6 +297,7 @@ struct Engine {
   // PARSeq
   std::map<std::string, Linear> pq;               // linears by upstream name
   std::map<std::string, DevBuf> pqf;              // f32 vectors (LayerNorm params, pos embed, ...)
+  DevBuf fc1_packed[12];                          // bf16 engines: encoder fc1 / fc2 / attn.proj weights as mlp_fused.hip's LDS images
   DevBuf proj_packed[12];                         // bf16 engines: encoder attn.proj weights k-step-major [12][384][32] (mlp_fused.hip, PROJ)
   DevBuf fc2_packed[12];                          // bf16 engines: encoder fc2 weights chunk-major [48][384][32] for mlp_fused.hip
   DevBuf qself;                                   // f32 [26][384]
@@ -411,19 +438,16 @@ struct Engine {
       lin(p + "proj", p + "attn.proj.weight", p + "attn.proj.bias", E, E);
       lin(p + "fc1", p + "mlp.fc1.weight", p + "mlp.fc1.bias", 4 * E, E);
       lin(p + "fc2", p + "mlp.fc2.weight", p + "mlp.fc2.bias", E, 4 * E);
-      if (prec == kBF16) {   // W2p[c][o][j] = W2[o][32 c + j]: the 32 hidden units of chunk c are one contiguous 24 KiB slab
-        const auto& w = wf.get(p + "mlp.fc2.weight", (size_t)E * 4 * E);
+      if (prec == kBF16) {   // mlp_fused.hip's operands as LDS images
         std::vector<uint16_t> h((size_t)E * 4 * E);
-        for (int c = 0; c < 48; ++c)
-          for (int o = 0; o < E; ++o)
-            for (int j = 0; j < 32; ++j) h[((size_t)c * E + o) * 32 + j] = f32_to_bf16_rne(w.data[(size_t)o * 4 * E + c * 32 + j]);
+        pack_mlp_w1(wf.get(p + "mlp.fc1.weight", (size_t)4 * E * E).data.data(), h.data());
+        fc1_packed[i].ensure(h.size() * 2);
+        TTR_HIP_CHECK(hipMemcpy(fc1_packed[i].p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        pack_mlp_w2(wf.get(p + "mlp.fc2.weight", (size_t)E * 4 * E).data.data(), 4 * E, h.data());
         fc2_packed[i].ensure(h.size() * 2);
         TTR_HIP_CHECK(hipMemcpy(fc2_packed[i].p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
-        const auto& wp = wf.get(p + "attn.proj.weight", (size_t)E * E);
         std::vector<uint16_t> hp((size_t)E * E);
-        for (int c = 0; c < 12; ++c)
-          for (int o = 0; o < E; ++o)
-            for (int j = 0; j < 32; ++j) hp[((size_t)c * E + o) * 32 + j] = f32_to_bf16_rne(wp.data[(size_t)o * E + c * 32 + j]);
+        pack_mlp_w2(wf.get(p + "attn.proj.weight", (size_t)E * E).data.data(), E, hp.data());
         proj_packed[i].ensure(hp.size() * 2);
         TTR_HIP_CHECK(hipMemcpy(proj_packed[i].p, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
       }
@@ -699,7 +723,7 @@ struct Engine {
           MlpParams q{};
           q.x = xc; q.x_out = xc; q.M = Mc;
           q.ln_g = pqf.at(p + "norm2.weight").as<float>(); q.ln_b = pqf.at(p + "norm2.bias").as<float>(); q.ln_eps = 1e-6f;
-          q.w1 = pq.at(p + "fc1").w.as<bf16>(); q.b1 = pq.at(p + "fc1").b.as<float>();
+          q.w1p = fc1_packed[l].as<bf16>(); q.b1 = pq.at(p + "fc1").b.as<float>();
           q.w2p = fc2_packed[l].as<bf16>(); q.b2 = pq.at(p + "fc2").b.as<float>();
           q.nln_g = pqf.at(nx + ".weight").as<float>(); q.nln_b = pqf.at(nx + ".bias").as<float>(); q.nln_eps = 1e-6f; q.nln_out = (bf16*)t384;
           if (proj_in) { q.att = (const bf16*)att; q.wpp = proj_packed[l].as<bf16>(); q.bp = pq.at(p + "proj").b.as<float>(); }
@@ -1199,24 +1223,20 @@ int ttr_dbg_mlp(ttr_engine* e, const float* x, int M, const float* ln_g, const f
   upf(dx, x, (size_t)M * D); upf(dg, ln_g, D); upf(db, ln_b, D); upf(db1, b1, H); upf(db2, b2, D);
   if (nln_out) { upf(dng, nln_g, D); upf(dnb, nln_b, D); dn.ensure((size_t)M * D * 2); }
   std::vector<uint16_t> h((size_t)H * D);
-  for (size_t i = 0; i < h.size(); ++i) h[i] = f32_to_bf16_rne(w1[i]);
+  pack_mlp_w1(w1, h.data());
   dw1.ensure(h.size() * 2); TTR_HIP_CHECK(hipMemcpy(dw1.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
-  for (int c = 0; c < 48; ++c)
-    for (int o = 0; o < D; ++o)
-      for (int j = 0; j < 32; ++j) h[((size_t)c * D + o) * 32 + j] = f32_to_bf16_rne(w2[(size_t)o * H + c * 32 + j]);
+  pack_mlp_w2(w2, H, h.data());
   dw2.ensure(h.size() * 2); TTR_HIP_CHECK(hipMemcpy(dw2.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
   dout.ensure((size_t)M * D * 4);
   MlpParams q{};
   q.x = dx.as<float>(); q.x_out = dout.as<float>(); q.M = M; q.ln_g = dg.as<float>(); q.ln_b = db.as<float>(); q.ln_eps = eps;
-  q.w1 = dw1.as<bf16>(); q.b1 = db1.as<float>(); q.w2p = dw2.as<bf16>(); q.b2 = db2.as<float>();
+  q.w1p = dw1.as<bf16>(); q.b1 = db1.as<float>(); q.w2p = dw2.as<bf16>(); q.b2 = db2.as<float>();
   if (nln_out) { q.nln_g = dng.as<float>(); q.nln_b = dnb.as<float>(); q.nln_eps = eps; q.nln_out = dn.as<bf16>(); }
   DevBuf datt, dwp, dbp;
   if (att) {
     std::vector<uint16_t> ha((size_t)M * D), hw((size_t)D * D);
     for (size_t i = 0; i < ha.size(); ++i) ha[i] = f32_to_bf16_rne(att[i]);
-    for (int c = 0; c < 12; ++c)
-      for (int o = 0; o < D; ++o)
-        for (int j = 0; j < 32; ++j) hw[((size_t)c * D + o) * 32 + j] = f32_to_bf16_rne(wp[(size_t)o * D + c * 32 + j]);
+    pack_mlp_w2(wp, D, hw.data());
     datt.ensure(ha.size() * 2); TTR_HIP_CHECK(hipMemcpy(datt.p, ha.data(), ha.size() * 2, hipMemcpyHostToDevice));
     dwp.ensure(hw.size() * 2); TTR_HIP_CHECK(hipMemcpy(dwp.p, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
     upf(dbp, bp, D);

@@ -99,16 +99,20 @@ struct MlpParams {
   const float* x;          // [M][384] f32 residual stream
   float* x_out;            // [M][384] f32; may be x (every row is read and written by one wave)
   const float *ln_g, *ln_b; float ln_eps;            // the block's norm2
-  const bf16* w1; const float* b1;                   // fc1 [1536][384], [1536]
-  const bf16* w2p; const float* b2;                  // fc2 packed [48][384][32] (pack_fc2_chunks), [384]
+  const bf16* w1p; const float* b1;                  // fc1 as 48 chunk images (pack_mlp_w1), bias [1536]
+  const bf16* w2p; const float* b2;                  // fc2 as 48 chunk images (pack_mlp_w2), bias [384]
   const float *nln_g, *nln_b; float nln_eps; bf16* nln_out;   // optional: LayerNorm of x_out -> bf16 [M][384]
-  const bf16* att; const bf16* wpp; const float* bp;  // optional: x' = x + att . Wp^T + bp first (att bf16 [M][384], Wp packed [12][384][32])
+  const bf16* att; const bf16* wpp; const float* bp;  // optional: x' = x + att . Wp^T + bp first (att bf16 [M][384], Wp as 12 k-step images, pack_mlp_w2)
   const void* gelu_lut;    // set by the launcher
   int store_nt;            // set by the launcher: streaming policy on the epilogue stores
   unsigned long long* dbg; // optional [48][8] shader-clock stamps of workgroup 0 / wave 0 over its first panel (diagnostics)
   int M;
 };
 void launch_mlp_fused(const MlpParams& p, hipStream_t s);
+// host-side packing of the weight operands into the kernel's LDS images (bf16 bits): w1 f32 [1536][384] -> 48 x 24 KiB;
+// w f32 [384][K] (fc2: K = 1536, attention projection: K = 384) -> K/32 x 24 KiB
+void pack_mlp_w1(const float* w1, uint16_t* out);
+void pack_mlp_w2(const float* w, int K, uint16_t* out);
 
 // ---- dec_fused.hip: the whole autoregressive decode (<= 26 steps) of PARSeq as one persistent kernel (bf16)
 struct DecArParams {

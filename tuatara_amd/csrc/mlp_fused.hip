@@ -15,8 +15,8 @@
 //     staging, as in gemm2.hip); bias is the MFMA's C operand, GELU and the bf16 rounding happen in registers and the
 //     result IS the B fragment (k = 8 (lane>>4) + e) of GEMM2 (A = 384 rows of W2 x 32 k, 48 MFMAs) — no LDS round trip.
 //     The [32 rows x 384] f32 output tile of the wave lives in 192 accumulator registers for the whole panel.
-//   * only the weights stream: chunk c = W1[32c..32c+31][:] (24 KiB, contiguous) + W2[:, 32c..32c+31] (24 KiB, from a
-//     chunk-major copy packed at load time) go global -> LDS by LDS-DMA into a 3-slot ring, two chunks ahead, ONE barrier
+//   * only the weights stream: chunk c = W1[32c..32c+31][:] + W2[:, 32c..32c+31] (24 KiB each, stored in memory as the LDS
+//     images themselves, packed at load time) go global -> LDS by LDS-DMA into a 3-slot ring, two chunks ahead, ONE barrier
 //     per chunk (= per 96 MFMAs of a wave).  Every workgroup streams the same 2.4 MB in the same order: L2 hits.
 //   * epilogue: + bias2 + residual (f32, re-read), f32 store (128 bytes per row per instruction), and the next
 //     LayerNorm (next block's norm1, or the encoder's final norm) on the rows still in registers.
@@ -70,55 +70,38 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
   for (int i = tid; i < HID / 4; i += 256) reinterpret_cast<float4*>(smem + B1_OFF)[i] = reinterpret_cast<const float4*>(p.b1)[i];
 
   // ---- weight stream: this wave's 6 + 6 one-KiB pieces of a chunk; source offsets are relative to the chunk's base
-  const __amdgpu_buffer_rsrc_t rs1 = m_rsrc(p.w1, (unsigned)(HID * E * 2));
+  const __amdgpu_buffer_rsrc_t rs1 = m_rsrc(p.w1p, (unsigned)(HID * E * 2));
   const __amdgpu_buffer_rsrc_t rs2 = m_rsrc(p.w2p, (unsigned)(HID * E * 2));
-  // Source offsets of the wave's pieces (a wave's six pieces of either operand differ by wave-uniform byte offsets only).  They are
-  // recomputed from the lane id at every issue — six integer instructions — because a register that lives across the whole
-  // chunk loop gets spilled here, and the wait for a spill reload (a vector-memory load) drains the LDS-DMA prefetch.
-  //   W1 image, segment-major: [3 k-segments of 256 B][32 rows][256 B]; LDS row R = 16 jj + q' holds hidden unit
+  // Both weight operands are stored in memory as the LDS images themselves (packed once at load time: pack_mlp_w1 / pack_mlp_w2
+  // in engine.cpp), so a piece is 1 KiB of contiguous memory — the address unit serves those ~1.5x faster than 8 x 128-byte
+  // gathers (tools/micro/dma_bench.hip) — and a lane's source offset is just 16 * lane.
+  //   W1 image of a chunk, segment-major: [3 k-segments of 256 B][32 rows][256 B]; LDS row R = 16 jj + q' holds hidden unit
   //   (q'>>2)*8 + jj*4 + (q'&3) of the chunk, and 16-byte chunk c (0..15) of a segment sits at position c ^ (R & 15) (every
-  //   row of a segment starts on bank 0).  Piece (segment s, row group r) = rows 4r .. 4r+3 of segment s; wave w's pieces are
-  //   r = w + 4 (j & 1), s = j >> 1, so its lane reads row 4w + 16 (j&1) + (lane>>4): (j&1) adds 4 hidden units = 3,072 source
-  //   bytes, (j>>1) adds 256.
-  //   W2 image: LDS row R' = 16 ot + q' holds output channel (ot>>1)*32 + (q'>>2)*8 + (ot&1)*4 + (q'&3); chunk gch of the 64-byte
-  //   row sits at position gch ^ ((R'>>1) & 3).  Piece ot = wave + 4 j: two output-channel tiles = 4,096 source bytes per j.
-  auto src_w1 = [&]() -> unsigned {
-    unsigned l = (unsigned)lane;
-    asm volatile("" : "+v"(l));
-    const unsigned Rl = 4u * wave + (l >> 4), nl = 8u * wave + (l >> 4);
-    return (nl * E + (((l & 15u) ^ Rl) * 8u)) * 2u;
-  };
-  auto src_w2 = [&]() -> unsigned {
-    unsigned l = (unsigned)lane;
-    asm volatile("" : "+v"(l));
-    const unsigned q2 = l >> 2;                                  // R' & 15 (the wave's first piece is tile ot = wave)
-    const unsigned oc = (wave >> 1) * 32u + (q2 >> 2) * 8u + (wave & 1) * 4u + (q2 & 3u);
-    return (oc * CH + ((l & 3u) ^ ((q2 >> 1) & 3u)) * 8u) * 2u;
-  };
+  //   row of a segment starts on bank 0).  Piece pp = 8 s + r = rows 4r .. 4r+3 of segment s.
+  //   W2 image of a chunk: LDS row R' = 16 ot + q' holds output channel (ot>>1)*32 + (q'>>2)*8 + (ot&1)*4 + (q'&3); chunk gch of
+  //   the 64-byte row sits at position gch ^ ((R'>>1) & 3).  Piece ot = rows 16 ot .. 16 ot + 15.
+  const unsigned src_lane = (unsigned)lane * 16u;
   const __amdgpu_buffer_rsrc_t rsp = m_rsrc(PROJ ? (const void*)p.wpp : (const void*)p.w2p, (unsigned)((PROJ ? E * E : HID * E) * 2));
   auto issue = [&](int Gi) {                                   // item Gi of the launch
     int ii = Gi % ITEMS;
     const int slot = Gi % NSLOT;
     unsigned char* sb = smem + slot * SLOT + wave * 1024;
     if (PROJ && ii < NPJ) {                                     // k-step slab ii of Wp
-      const unsigned src2 = src_w2();
 #pragma unroll
-      for (int j = 0; j < 6; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsp, (lds_ptr)(sb + W1B + j * 4096), 16, src2, ii * W2B + j * 4096, 0, 0);
+      for (int j = 0; j < 6; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsp, (lds_ptr)(sb + W1B + j * 4096), 16, src_lane, ii * W2B + (wave + 4 * j) * 1024, 0, 0);
       return;
     }
     ii -= NPJ;                                                  // MLP item: W1 chunk ii (ii < 48) and W2 chunk ii - 1 (ii >= 1)
     if (ii < NCH) {
       const int cb = ii * W1B;
-      const unsigned src1 = src_w1();
 #pragma unroll
-      for (int j = 0; j < 6; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr)(sb + (j >> 1) * 8192 + (j & 1) * 4096), 16, src1, cb + (j & 1) * 3072 + (j >> 1) * 256, 0, 0);
+      for (int j = 0; j < 6; ++j)   // piece 8 (j >> 1) + wave + 4 (j & 1)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr)(sb + (j >> 1) * 8192 + (j & 1) * 4096), 16, src_lane, cb + (j >> 1) * 8192 + (wave + 4 * (j & 1)) * 1024, 0, 0);
     }
     if (ii >= 1) {
       const int cb = (ii - 1) * W2B;
-      const unsigned src2 = src_w2();
 #pragma unroll
-      for (int j = 0; j < 6; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_ptr)(sb + W1B + j * 4096), 16, src2, cb + j * 4096, 0, 0);
+      for (int j = 0; j < 6; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_ptr)(sb + W1B + j * 4096), 16, src_lane, cb + (wave + 4 * j) * 1024, 0, 0);
     }
   };
   auto pieces = [&](int Gi) -> int {                            // pieces per wave of item Gi: 12, or 6 for the one-operand items
@@ -297,9 +280,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
         MLP_G2(f1, 1)
         if (ks < 10) {                                          // item G + 2 is another slab of Wp (known at compile time)
           unsigned char* sb = smem + ((G + 2) % NSLOT) * SLOT + wave * 1024;
-          const unsigned src2 = src_w2();
 #pragma unroll
-          for (int j = 0; j < 6; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsp, (lds_ptr)(sb + W1B + j * 4096), 16, src2, (ks + 2) * W2B + j * 4096, 0, 0);
+          for (int j = 0; j < 6; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsp, (lds_ptr)(sb + W1B + j * 4096), 16, src_lane, (ks + 2) * W2B + (wave + 4 * j) * 1024, 0, 0);
         } else if (G + 2 < total) issue(G + 2);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f0[0]), "+v"(f0[1]), "+v"(f0[2]), "+v"(f0[3]), "+v"(f1[0]), "+v"(f1[1]), "+v"(f1[2]), "+v"(f1[3]));
         MLP_G2(f2, 2)  MLP_M2B(f0, 0, af[0][ks], af[1][ks])
@@ -508,10 +490,10 @@ void set_mlp_stamps(unsigned long long* d) { g_mlp_dbg = d; }
 
 const char* mlp_fused_check(const MlpParams& p) {
   if (p.M <= 0) return "mlp_fused: bad row count";
-  if (!p.x || !p.x_out || !p.ln_g || !p.ln_b || !p.w1 || !p.b1 || !p.w2p || !p.b2 || !p.gelu_lut) return "mlp_fused: null operand";
+  if (!p.x || !p.x_out || !p.ln_g || !p.ln_b || !p.w1p || !p.b1 || !p.w2p || !p.b2 || !p.gelu_lut) return "mlp_fused: null operand";
   if (p.nln_out && (!p.nln_g || !p.nln_b)) return "mlp_fused: next LayerNorm parameters";
   if (p.att && (!p.wpp || !p.bp || (((uintptr_t)p.att | (uintptr_t)p.wpp | (uintptr_t)p.bp) & 15))) return "mlp_fused: projection operands";
-  const uintptr_t a = (uintptr_t)p.x | (uintptr_t)p.x_out | (uintptr_t)p.ln_g | (uintptr_t)p.ln_b | (uintptr_t)p.w1 | (uintptr_t)p.b1 | (uintptr_t)p.w2p |
+  const uintptr_t a = (uintptr_t)p.x | (uintptr_t)p.x_out | (uintptr_t)p.ln_g | (uintptr_t)p.ln_b | (uintptr_t)p.w1p | (uintptr_t)p.b1 | (uintptr_t)p.w2p |
                       (uintptr_t)p.b2 | (uintptr_t)p.nln_out | (uintptr_t)p.nln_g | (uintptr_t)p.nln_b | (uintptr_t)p.gelu_lut;
   if (a & 15) return "mlp_fused: operands must be 16-byte aligned";
   return nullptr;
