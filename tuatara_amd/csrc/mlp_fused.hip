@@ -46,6 +46,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t m_rsrc(const void* base, unsig
 // LDS reads as inline asm: hipcc puts s_waitcnt vmcnt(0) in front of every LDS read it can see once LDS-DMA loads are in
 // flight (it cannot prove they do not alias), which would serialise the weight stream.  Waits are placed by hand below.
 #define MLP_RD128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+// the lane id straight from the hardware (2 VALU): anything derived from threadIdx that lives across the chunk loop is a spill candidate
+#define MLP_LANE() __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))
 #define MLP_WAIT8(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]))
 }  // namespace
 
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
   //   row of a segment starts on bank 0).  Piece pp = 8 s + r = rows 4r .. 4r+3 of segment s.
   //   W2 image of a chunk: LDS row R' = 16 ot + q' holds output channel (ot>>1)*32 + (q'>>2)*8 + (ot&1)*4 + (q'&3); chunk gch of
   //   the 64-byte row sits at position gch ^ ((R'>>1) & 3).  Piece ot = rows 16 ot .. 16 ot + 15.
-  const unsigned src_lane = (unsigned)lane * 16u;
+#define src_lane (MLP_LANE() * 16u)
   const __amdgpu_buffer_rsrc_t rsp = m_rsrc(PROJ ? (const void*)p.wpp : (const void*)p.w2p, (unsigned)((PROJ ? E * E : HID * E) * 2));
   auto issue = [&](int Gi) {                                   // item Gi of the launch
     int ii = Gi % ITEMS;
@@ -190,8 +192,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
     /* fragment addresses are recomputed from the lane id every iteration (the empty asm stops the compiler from hoisting  \
        them out of the loop into registers it then spills: a spill reload is a vector-memory load, and the wait for it drains  \
        the LDS-DMA prefetch) */                                                                            \
-    unsigned ll = (unsigned)lane;                                                                          \
-    asm volatile("" : "+v"(ll));                                                                           \
+    const unsigned ll = MLP_LANE();   /* read from the hardware, not kept in a register across the loop */ \
     const unsigned qq = ll & 15u, gq = ll >> 4;                                                            \
     const unsigned rowb = sbase + qq * 256u;                                                               \
     a1v[0] = rowb + (((0u + gq) ^ qq) << 4); a1v[1] = rowb + (((4u + gq) ^ qq) << 4);                      \
@@ -345,14 +346,29 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
       MLP_STAMP(5);
       ++G;
     }
+    // In the steady loop wave w issues its 12 pieces of item G + 2 after MFMA group w - 1 (wave 0 right behind the barrier): four
+    // bursts hitting the address unit together behind the barrier cost 461 cycles per wave, free-running ones 233
+    // (tools/micro/issue_cost.hip).  All pieces are on the queue long before the next top-of-iteration wait.
+#define MLP_DMA_AT(t) if (more && wave == (t)) issue(G + 2);
     for (i = 1; i < NCH; ++i, ++G) {                             // GEMM1(i) with GELU(i-1) in its shadow, then GEMM2(i-1)
       MLP_TOP()
-      MLP_HEAD1()
+      const bool more = G + 2 < total;
+      {
+        const unsigned ba = b1_lds + (unsigned)(i * CH * 4);
+        MLP_RD128(accn[0][0], ba, 0);
+        MLP_RD128(accn[0][1], ba, 16);
+        MLP_G1(f0, 0)
+        MLP_G1(f1, 1)
+        MLP_DMA_AT(0)
+        MLP_STAMP(2);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(accn[0][0]), "+v"(accn[0][1]), "+v"(f0[0]), "+v"(f0[1]), "+v"(f0[2]), "+v"(f0[3]), "+v"(f1[0]), "+v"(f1[1]), "+v"(f1[2]), "+v"(f1[3]));
+        accn[1][0] = accn[0][0]; accn[1][1] = accn[0][1];
+      }
       // waits below: the group about to be multiplied and the table reads of the quarter about to be finished were issued
       // before the newest 4 fragment reads, and LDS returns in order
-      MLP_G1(f2, 2)  gelu_a(accp[0][0]);                                   MLP_M1(f0, 0)
-      MLP_G1(f0, 3)  MLP_WAITFT(4, f2, t4);  gelu_b(accp[0][0], hf[0], 0);  gelu_a(accp[0][1]);  MLP_M1(f1, 1)
-      MLP_G1(f1, 4)  MLP_WAITFT(4, f0, t4);  gelu_b(accp[0][1], hf[0], 1);  gelu_a(accp[1][0]);  MLP_M1(f2, 2)
+      MLP_G1(f2, 2)  gelu_a(accp[0][0]);                                   MLP_M1(f0, 0)  MLP_DMA_AT(1)
+      MLP_G1(f0, 3)  MLP_WAITFT(4, f2, t4);  gelu_b(accp[0][0], hf[0], 0);  gelu_a(accp[0][1]);  MLP_M1(f1, 1)  MLP_DMA_AT(2)
+      MLP_G1(f1, 4)  MLP_WAITFT(4, f0, t4);  gelu_b(accp[0][1], hf[0], 1);  gelu_a(accp[1][0]);  MLP_M1(f2, 2)  MLP_DMA_AT(3)
       MLP_G1(f2, 5)  MLP_WAITFT(4, f1, t4);  gelu_b(accp[1][0], hf[1], 0);  gelu_a(accp[1][1]);  MLP_M1(f0, 3)
       MLP_G2(f0, 0)  MLP_WAITFT(4, f2, t4);  gelu_b(accp[1][1], hf[1], 1);                       MLP_M1(f1, 4)
       MLP_G2(f1, 1)  MLP_WAITF(8, f2);  MLP_M1(f2, 5)
