@@ -96,7 +96,11 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_kernel(const bf16* __restrict
       if (hf == 0 && ci > 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                               // everyone's landed; the other slot and (hf == 0) the Q/K/V tiles are free
-      if (Hh + 1 < nhalves) issue_half(Hh + 1);
+      // wave w requests its 12 pieces of the next half after k-step 2w - 1 (wave 0 right here): four bursts arriving at the address
+      // unit together behind the barrier cost each wave twice what free-running ones do (tools/micro/issue_cost.hip)
+      const bool moreh = Hh + 1 < nhalves;
+#define QA_DMA_AT(wv) if (moreh && wave == (wv)) issue_half(Hh + 1);
+      QA_DMA_AT(0)
       // ---- [64 rows x 192 columns] = X_half . W_h^T: 12 k-steps of 32, 4 row tiles x 3 column tiles
       const unsigned xb = lds0 + (unsigned)(3 * TILE + (Hh & 1) * XHALF) + frag_lane;
       f32x4 acc[4][3];
@@ -113,17 +117,18 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_kernel(const bf16* __restrict
       acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ct][st], fx[buf][rt], (st) == 0 ? fb[ct] : acc[rt][ct], 0, 0, 0);
       QA_LOADX(0, 0)
       QA_LOADX(1, 1)   QA_WAITX(4, 0);  QA_MM(0, 0)
-      QA_LOADX(0, 2)   QA_WAITX(4, 1);  QA_MM(1, 1)
+      QA_LOADX(0, 2)   QA_WAITX(4, 1);  QA_MM(1, 1)  QA_DMA_AT(1)
       QA_LOADX(1, 3)   QA_WAITX(4, 0);  QA_MM(0, 2)
-      QA_LOADX(0, 4)   QA_WAITX(4, 1);  QA_MM(1, 3)
+      QA_LOADX(0, 4)   QA_WAITX(4, 1);  QA_MM(1, 3)  QA_DMA_AT(2)
       QA_LOADX(1, 5)   QA_WAITX(4, 0);  QA_MM(0, 4)
-      QA_LOADX(0, 6)   QA_WAITX(4, 1);  QA_MM(1, 5)
+      QA_LOADX(0, 6)   QA_WAITX(4, 1);  QA_MM(1, 5)  QA_DMA_AT(3)
       QA_LOADX(1, 7)   QA_WAITX(4, 0);  QA_MM(0, 6)
       QA_LOADX(0, 8)   QA_WAITX(4, 1);  QA_MM(1, 7)
       QA_LOADX(1, 9)   QA_WAITX(4, 0);  QA_MM(0, 8)
       QA_LOADX(0, 10)  QA_WAITX(4, 1);  QA_MM(1, 9)
       QA_LOADX(1, 11)  QA_WAITX(4, 0);  QA_MM(0, 10)
       QA_WAITX(0, 1);  QA_MM(1, 11)
+#undef QA_DMA_AT
 #undef QA_LOADX
 #undef QA_WAITX
 #undef QA_MM
