@@ -707,7 +707,7 @@ struct Engine {
       for (int l = 0; l < 12; ++l) {
         std::string p = "encoder.blocks." + std::to_string(l) + ".";
         if (!mlp_fused) ln(xc, p + "norm1", 1e-6f, t384, Mc);
-        if (prec == kBF16 && gemm_config() >= 0 && (g_qkv_attn == 2 || (g_qkv_attn == 1 && nc >= g_qkv_attn_min))) {
+        if (prec == kBF16 && gemm_config() >= 0 && (g_qkv_attn == 2 || (g_qkv_attn == 1 && nc >= g_qkv_attn_min)) && (size_t)Mc * E * 2 < ((size_t)1 << 31)) {   // (32-bit buffer offsets)
           const Linear& L = pq.at(p + "qkv");
           timed(2.0 * Mc * E * 3 * E, [&] { launch_qkv_attn((const bf16*)t384, L.w.as<bf16>(), L.b.as<float>(), (bf16*)att, nc, stream); });
         } else {
