@@ -110,6 +110,30 @@ def test_layernorm_fused_into_skinny_gemm_matches_separate_kernels(eng_bf16):
     assert np.array_equal(i0[same_path], i1[same_path])
 
 
+def test_token_prologue_in_self_kv_gemm_matches_separate_kernels(eng_bf16):
+    """gemm_sk's token prologue (argmax of the previous step's logits + text_embed + pos_queries + norm_c inside the self_kv GEMM)
+    vs argmax_kernel + dec_embed_ln_kernel + GEMM: the argmax is exact (first maximal index), the embedding sum is exact, only the
+    fp32 reduction order of the LayerNorm differs.  45 rows: ragged 32-row tile."""
+    rng = np.random.default_rng(14)
+    crops = rng.integers(0, 256, (45, 32, 128, 3), dtype=np.uint8)
+    try:
+        assert eng_bf16.lib.ttr_set_tuning(b"tok_fuse", 0) == 0
+        l0, a0, i0 = eng_bf16.parseq_logits(crops, want_ar=True)
+        assert eng_bf16.lib.ttr_set_tuning(b"tok_fuse", 1) == 0
+        l1, a1, i1 = eng_bf16.parseq_logits(crops, want_ar=True)
+        l2, i2 = eng_bf16.parseq_logits(crops, want_ar=False)       # 25 AR steps: the 26th token still comes from the prologue
+    finally:
+        eng_bf16.lib.ttr_set_tuning(b"tok_fuse", 1)
+    assert np.isfinite(a1).all()
+    assert np.abs(a1[:, 0] - a0[:, 0]).max() < 0.05                    # step 0: BOS for every crop; bf16 boundary flips only
+    same_path = (a0.argmax(-1) == a1.argmax(-1)).all(1)
+    assert same_path.mean() >= 0.9
+    assert np.abs(a1[same_path] - a0[same_path]).max() < 0.25
+    assert np.abs(l1[same_path] - l0[same_path]).max() < 0.25
+    assert np.array_equal(i0[same_path], i1[same_path])
+    assert np.array_equal(l1, l2) and np.array_equal(i1, i2)            # the AR-logit output buffer does not change the result
+
+
 @pytest.mark.parametrize("n", [45, 3])
 def test_fused_mlp_block_matches_separate_kernels(eng_bf16, n):
     """mlp_fused.hip (norm2 + fc1 + GELU + fc2 + residual + next LayerNorm in one kernel, hidden activation in registers) vs

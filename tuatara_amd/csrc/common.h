@@ -31,6 +31,10 @@ struct ConvParams {
   const void* pre_wgt; const float* pre_bias;   // conv3p only: fuse CRAFT's conv1_1 in front (in0 = u8 canvas [B][H][W][3], pre_wgt = T [64][32])
   // gemm_sk only: take the activation rows from LayerNorm(ln_in) instead of in0 (f32 [M][384] rows, stride ln_ld)
   const float* ln_in; int ln_ld; const float* ln_gamma; const float* ln_beta; float ln_eps;
+  // gemm_sk + LayerNorm prologue only, PARSeq AR step (tok != null): the row to normalise is emb[token] (+ tok_pos), token =
+  // tok[m * tok_ld + tok_col], or, when tok_logits is given, the first maximal index of the f32 row tok_logits[m * tok_logits_ld ..+ tok_C),
+  // which column-tile 0 also writes to tok[m * tok_ld + tok_col] (argmax + dec_embed_ln folded into the self_kv GEMM)
+  int* tok; int tok_ld, tok_col; const float* tok_logits; int tok_logits_ld, tok_C; const float* tok_emb; const float* tok_pos; int tok_max;
   unsigned long long* dbg;   // gemm_ws diagnostics: shader-clock stamps of workgroup 0 (null = off)
   int store_policy;          // set by the launchers: 0 default, 1 nt, 2 sc0 sc1 nt on the big streaming output stores
   int dbg_flags;             // gemm_ws diagnostics (timing experiments only, results are wrong): 1 = no output stores, 2 = no activation loads

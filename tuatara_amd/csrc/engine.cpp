@@ -49,6 +49,7 @@ static int g_qkv_attn_min = 160;
 static int g_mlp_proj = 1;           // ... with the attention output projection in front of it in the same launch
 static int g_mlp_min_rows = 49152;   // = 384 crops
 static int g_mlp_fused = 1;        // bf16 encoder: norm2 + fc1 + GELU + fc2 + residual (+ the next LayerNorm) as one kernel (mlp_fused.hip)
+static int g_tok_fuse = 1;         // bf16 AR steps: argmax of the previous step + token embedding + norm_c inside the self_kv skinny GEMM
 static int g_ln_fuse = 1;          // bf16 decoder steps: LayerNorm computed inside the skinny GEMM's loader (gemm_sk ln_in)
 static int g_fuse_first = 1;       // bf16: CRAFT conv1_1 fused into conv1_2's loader (conv3p FIRST)
 static int g_enc_chunk = 0;        // crops per encoder group (0 = all crops at once)
@@ -782,13 +783,27 @@ struct Engine {
       launch_dec_ar(q, G, stream);
     } else {
     prof_stage = 2;
+    const bool tok_fuse = g_tok_fuse && g_ln_fuse && prec == kBF16 && N <= skinny_max_rows();
     for (int i = 0; i < 26; ++i) {
-      launch_dec_embed_ln(prec, tk, emb, posq, gc, bc, 1e-5f, t384, N, i, i + 1, stream);
-      gemm(pq.at("self_kv"), t384, N, (char*)kvcache + (size_t)i * 768 * es, 26 * 768, kActNone);
+      if (tok_fuse) {   // token of step i = argmax of step i-1's logits, embedded and normalised in the GEMM's loader
+        const Linear& L = pq.at("self_kv");
+        ConvParams p{};
+        p.ln_in = emb; p.ln_ld = 384; p.ln_gamma = gc; p.ln_beta = bc; p.ln_eps = 1e-5f;
+        p.tok = tk; p.tok_ld = 26; p.tok_col = i; p.tok_emb = emb; p.tok_max = 96;
+        if (i > 0) { p.tok_logits = ar + (size_t)(i - 1) * 95; p.tok_logits_ld = 26 * 95; p.tok_C = 95; p.tok_pos = posq + (size_t)(i - 1) * E; }
+        p.C0 = L.k; p.B = 1; p.H = 1; p.W = N; p.ks = 1; p.dil = 1;
+        p.wgt = L.w.p; p.bias = L.b.as<float>();
+        p.out = (char*)kvcache + (size_t)i * 768 * es; p.out_ld = 26 * 768;
+        p.Cout = L.cout; p.M = N; p.act = kActNone;
+        igemm(p, 2.0 * N * L.cout * L.k);
+      } else {
+        launch_dec_embed_ln(prec, tk, emb, posq, gc, bc, 1e-5f, t384, N, i, i + 1, stream);
+        gemm(pq.at("self_kv"), t384, N, (char*)kvcache + (size_t)i * 768 * es, 26 * 768, kActNone);
+      }
       if (i >= nsteps) break;
       launch_dec_self_attn(prec, qself.as<float>(), kvcache, tk, att, N, 1, i, 0, stream);
       decoder_tail(att, N, 1, posq + (size_t)i * E, 1, tgt, t384, d384b, d1536, kvmem, ar + (size_t)i * 95, 26 * 95);
-      if (i + 1 < 26) launch_argmax(ar + (size_t)i * 95, 26 * 95, 95, tk, 26, i + 1, N, stream);
+      if (i + 1 < 26 && !tok_fuse) launch_argmax(ar + (size_t)i * 95, 26 * 95, 95, tk, 26, i + 1, N, stream);
     }
     prof_stage = 1;
     }
@@ -1343,6 +1358,7 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "enc_chunk") g_enc_chunk = value;
   else if (k == "fuse_first") g_fuse_first = value;
   else if (k == "ln_fuse") g_ln_fuse = value;
+  else if (k == "tok_fuse") g_tok_fuse = value;
   else if (k == "mlp_fused") g_mlp_fused = value;   // 0 off, 1 from mlp_min_rows rows on, 2 always
   else if (k == "mlp_min_rows") g_mlp_min_rows = value;
   else if (k == "mlp_proj") g_mlp_proj = value;

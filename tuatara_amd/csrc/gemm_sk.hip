@@ -58,13 +58,43 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(ConvParams p) {
       // reads expect
       const int row = wave * 8 + (lane >> 3), m = m0 + row, j = lane & 7;
       const bool live = m < p.M;
+      const float* lrow = p.ln_in + (int64_t)m * p.ln_ld;
+      if (p.tok) {   // PARSeq AR step: the row is the embedding of this crop's previous token (see ConvParams::tok)
+        int tokv = 0;
+        if (p.tok_logits) {
+          float best = -INFINITY; int bi = 0x7fffffff;
+          if (live) {
+            const float* lg = p.tok_logits + (int64_t)m * p.tok_logits_ld;
+            float x[16];                              // all loads in flight before the first compare (tok_C <= 128)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) x[u] = j + 8 * u < p.tok_C ? lg[j + 8 * u] : -INFINITY;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (x[u] > best) { best = x[u]; bi = j + 8 * u; }
+          }
+#pragma unroll
+          for (int o = 4; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+          }
+          if (live && tn == 0 && j == 0) p.tok[(int64_t)m * p.tok_ld + p.tok_col] = bi;
+          tokv = bi;
+        } else if (live) {
+          tokv = p.tok[(int64_t)m * p.tok_ld + p.tok_col];
+        }
+        tokv = tokv < 0 ? 0 : (tokv > p.tok_max ? p.tok_max : tokv);
+        lrow = p.tok_emb + (int64_t)tokv * 384;
+      }
       float v[6][8];
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
         if (live) {
-          const float* src = p.ln_in + (int64_t)m * p.ln_ld + (c * 8 + j) * 8;
+          const float* src = lrow + (c * 8 + j) * 8;
           a = *reinterpret_cast<const float4*>(src); b = *reinterpret_cast<const float4*>(src + 4);
+          if (p.tok && p.tok_pos) {
+            const float4 pa = *reinterpret_cast<const float4*>(p.tok_pos + (c * 8 + j) * 8), pb = *reinterpret_cast<const float4*>(p.tok_pos + (c * 8 + j) * 8 + 4);
+            a.x += pa.x; a.y += pa.y; a.z += pa.z; a.w += pa.w; b.x += pb.x; b.y += pb.y; b.z += pb.z; b.w += pb.w;
+          }
         }
         v[c][0] = a.x; v[c][1] = a.y; v[c][2] = a.z; v[c][3] = a.w; v[c][4] = b.x; v[c][5] = b.y; v[c][6] = b.z; v[c][7] = b.w;
       }
@@ -168,6 +198,8 @@ const char* gemm_sk_check(const ConvParams& p) {
   if ((!p.ln_in && ((uintptr_t)p.in0 & 15)) || ((uintptr_t)p.wgt & 15)) return "gemm_sk: operand alignment";
   if (p.ln_in && (p.C0 != 384 || p.ln_ld % 4 || ((uintptr_t)p.ln_in & 15) || !p.ln_gamma || !p.ln_beta || ((uintptr_t)p.ln_gamma & 15) || ((uintptr_t)p.ln_beta & 15)))
     return "gemm_sk: fused LayerNorm needs K == 384 and 16-byte aligned f32 rows / parameters";
+  if (p.tok && (!p.ln_in || !p.tok_emb || ((uintptr_t)p.tok_emb & 15) || ((uintptr_t)p.tok_pos & 15) || (p.tok_logits && (p.tok_C <= 0 || p.tok_C > 128)) || p.tok_max < 0))
+    return "gemm_sk: token prologue needs the LayerNorm prologue, a 16-byte aligned embedding table and position row";
   const size_t lim = (size_t)1 << 31;
   if ((!p.ln_in && (size_t)p.M * p.C0 * 2 >= lim) || (size_t)p.Cout * p.C0 * 2 >= lim) return "gemm_sk: tensor too large";
   if (p.M <= 0 || p.Cout <= 0) return "gemm_sk: bad shape";
