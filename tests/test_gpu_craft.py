@@ -73,3 +73,22 @@ def test_craft_bf16_kernel_generations_agree(engines_random, hw):
     rel = np.abs(new - old).max() / np.abs(old).max()
     print(f"bf16 CRAFT {hw}: second vs first generation kernels max|d|/max = {rel:.5f}")
     assert rel < 0.02
+
+
+@pytest.mark.parametrize("hw", [(256, 192), (64, 96), (1024, 768), (32, 32)])
+def test_first_pair_wave_specialised_kernel_is_bit_identical(engines_random, hw):
+    """conv3p_first2s_kernel (consumer waves multiply, producer waves run conv1_1 on the next patch's halo from their own canvas
+    strip; pooling before bias + ReLU) against conv3p_first2_kernel: same products in the same order, max-pool commuted with a
+    monotone map — the heat maps must be equal bit for bit.  Sizes: fewer patches than CUs, a single patch row, a persistent loop
+    of 12 patches per workgroup, four patches one above the other (image one patch wide)."""
+    _, ebf = engines_random
+    canvas = np.random.default_rng(hw[0] + hw[1]).integers(0, 256, (*hw, 3), dtype=np.uint8)
+    try:
+        assert ebf.lib.ttr_set_tuning(b"c3_first_persistent", 1) == 0
+        old = ebf.craft_heatmap(canvas)
+        assert ebf.lib.ttr_set_tuning(b"c3_first_persistent", 2) == 0
+        new = ebf.craft_heatmap(canvas)
+    finally:
+        ebf.lib.ttr_set_tuning(b"c3_first_persistent", 2)
+    assert np.isfinite(new).all()
+    assert np.array_equal(old, new)

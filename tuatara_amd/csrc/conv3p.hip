@@ -465,13 +465,16 @@ __global__ __launch_bounds__(512) void conv3p_first2_kernel(ConvParams p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the resident weights have landed
 
+#define F2_STAMP(ph) do { if (p.dbg && blockIdx.x == 0 && (tid & 255) == 0 && it < 24) p.dbg[((tid >> 8) * 24 + it) * 8 + (ph)] = __builtin_readcyclecounter(); } while (0)
   for (int it = 0; patch < npatch; patch += gridDim.x, ++it) {
     int b, y0, x0;
     patch_origin(patch, b, y0, x0);
     const int nextp = patch + gridDim.x;
     const unsigned char* xcur = xs + (it & 1) * XB;
     unsigned char* xnext = xs + ((it + 1) & 1) * XB;
+    F2_STAMP(0);
     __syncthreads();                                     // A: everyone finished the previous iteration (its cv and patch-buffer reads)
+    F2_STAMP(1);
     if (nextp < npatch) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) if (tid + 512 * k < 12 * 108) cv[tid + 512 * k] = cb[k];
@@ -480,7 +483,9 @@ __global__ __launch_bounds__(512) void conv3p_first2_kernel(ConvParams p) {
         for (int k = 0; k < 3; ++k) cb[k] = canvas_byte(nextp + gridDim.x, tid + 512 * k);   // in flight for a whole iteration
       }
     }
+    F2_STAMP(2);
     __syncthreads();                                     // B: cv (patch p+1) and the patch buffer of p are complete
+    F2_STAMP(3);
 
     f32x4 acc[2][MI];
     auto mfma_phase = [&]() {
@@ -510,11 +515,14 @@ __global__ __launch_bounds__(512) void conv3p_first2_kernel(ConvParams p) {
     };
     if (wave < 4) {
       mfma_phase();
+      F2_STAMP(4);
       if (nextp < npatch) prologue(nextp, xnext);
     } else {
       if (nextp < npatch) prologue(nextp, xnext);
+      F2_STAMP(4);
       mfma_phase();
     }
+    F2_STAMP(5);
     // ---- epilogue: lane holds channels n..n+7 of patch pixel (py, px) for every i; tile i + 2 is the pixel below
     const int n = wn * 32 + fg * 8;
     if (n < p.Cout) {
@@ -550,10 +558,263 @@ __global__ __launch_bounds__(512) void conv3p_first2_kernel(ConvParams p) {
         }
       }
     }
+    F2_STAMP(6);
   }
+#undef F2_STAMP
 }
 
-static void launch_first2(const ConvParams& p, hipStream_t s) {
+// ------------------------------------------------------------------------------------------------------------------
+// Wave-specialised form of the kernel above (stamps of that one, tools/first2_stamps.py: 12.9k cycles per patch of which the
+// matrix pipe needs 4.6k — every wave ran canvas addressing (1.3k), its share of conv1_1 (3-4k), 144 MFMAs at half rate
+// (4.3-5.7k) and the pooling epilogue (1.5-1.9k) one after the other).  Here the two waves of a SIMD have different jobs:
+//   waves 0-3 (consumers): conv1_2 on patch p, 64 pixels (two patch rows) x all 64 channels each: 288 MFMAs back to back with
+//     the fragments of the next K step already in registers, then the pooled epilogue (vertical max in registers, horizontal
+//     max by DPP, bias + ReLU after the max: x -> relu(x + b) is monotone, so the result is bit-identical);
+//   waves 4-7 (producers): conv1_1 on the halo of patch p+1 into the other patch buffer.  A producer owns 6 consecutive
+//     16-pixel halo tiles and the <= 6 canvas rows under them: it fetches those rows itself as dwords (one patch ahead, three
+//     per lane, out-of-image dwords zero by the buffer range rule) into a private LDS strip — no canvas hand-over between
+//     waves, ONE workgroup barrier per patch.
+__global__ __launch_bounds__(512) void conv3p_first2s_kernel(ConvParams p) {
+  using G = Geo<5>;
+  constexpr int PH = G::PH, PW = G::PW, HW2 = G::HW2, NHALO = G::NHALO;
+  constexpr int XB = NHALO * 128;                       // one patch buffer
+  constexpr int CVW = 6 * 112;                          // a producer's canvas strip: 6 rows x 28 dwords (byte 2 of a row = halo column 0, channel 0 of its left neighbour)
+  constexpr int MI = 4;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  unsigned char* const wsm = smem;                      // [9 taps][64 rows][128 B]   conv1_2 weights, gemm2 row/chunk permutation
+  unsigned char* const xs = smem + 9 * 8192;            // [2][340][128 B]            conv1_1 output on the halo patch
+  unsigned char* const cv = xs + 2 * XB;                // [4][6][112]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int ptx = p.W / PW, pty = p.H / PH, npatch = p.B * pty * ptx;
+  const bool producer = wave >= 4;
+
+  {   // resident conv1_2 weights: as conv3p_first2_kernel
+    const __amdgpu_buffer_rsrc_t rsw = mk_rsrc(p.wgt, (unsigned)((size_t)p.Cout * 576 * 2));
+    const int row = wave * 8 + (lane >> 3);
+    const int g = (lane & 7) ^ ((row >> 1) & 7);
+    const int q16 = row & 15;
+    const int n = (row & ~31) + (q16 >> 2) * 8 + ((row >> 4) & 1) * 4 + (q16 & 3);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const unsigned vo = n < p.Cout ? (unsigned)((n * 576 + t * 64 + g * 8) * 2) : 0x80000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(wsm + t * 8192 + wave * 1024), 16, vo, 0, 0, 0);
+    }
+  }
+  auto patch_origin = [&](int patch, int& b, int& y0, int& x0) {
+    b = patch / (pty * ptx);
+    const int trem = patch - b * pty * ptx, ty = trem / ptx;
+    y0 = ty * PH; x0 = (trem - ty * ptx) * PW;
+  };
+#define F2S_STAMP(ph) do { if (p.dbg && blockIdx.x == 0 && (tid & 255) == 0 && it < 24) p.dbg[((tid >> 8) * 24 + it) * 8 + (ph)] = __builtin_readcyclecounter(); } while (0)
+
+  if (producer) {
+    // ================================================================ producers
+    const int pw = wave & 3;
+    const int cvrow0 = (96 * pw) / HW2;                  // first canvas row (of the 12 around the halo) this wave's tiles touch: 0, 2, 5, 8
+    const int ntile = pw < 3 ? 6 : 4;                    // 22 halo tiles of 16 pixels
+    unsigned char* const cvw = cv + pw * CVW;
+    const __amdgpu_buffer_rsrc_t rsc = mk_rsrc(p.in0, (unsigned)((size_t)p.B * p.H * p.W * 3));
+    bf16x8 f1[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int n = 32 * (jj >> 1) + (fr >> 2) * 8 + (jj & 1) * 4 + (fr & 3);
+      f1[jj] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.pre_wgt) + n * 32 + fg * 8);
+    }
+    float b1[2][8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) b1[t][e] = p.pre_bias[32 * t + fg * 8 + e];
+    int koff[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = fg * 8 + e, tp = k / 3;
+      koff[e] = k < 27 ? (tp / 3) * 112 + (tp % 3) * 3 + (k - tp * 3) : 0;   // k >= 27 multiplies a zero weight column: any byte will do
+    }
+    int h_off[6], h_pr[6], h_pc[6];
+#pragma unroll
+    for (int t3 = 0; t3 < 6; ++t3) {
+      const int pi = (6 * pw + t3) * 16 + fr;
+      h_pr[t3] = pi / HW2; h_pc[t3] = pi - h_pr[t3] * HW2;
+      h_off[t3] = pi < NHALO ? (h_pr[t3] - cvrow0) * 112 + h_pc[t3] * 3 + 2 : 0;
+    }
+    // canvas strip: lane owns dwords q = lane + 64 k (k < 3, q < 168) = row q / 28, dword q % 28 of the strip; a row starts 8 bytes
+    // left of the patch's first pixel (dword aligned: 3 * x0 is a multiple of 96)
+    int c_row[3], c_col[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const int q = lane + 64 * k; c_row[k] = q / 28; c_col[k] = q - c_row[k] * 28; }
+    auto canvas_load = [&](int patch, unsigned (&cb)[3]) {
+      int b, y0, x0;
+      patch_origin(patch, b, y0, x0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int y = y0 - 2 + cvrow0 + c_row[k], xb = x0 * 3 - 8 + 4 * c_col[k];
+        const bool ok = lane + 64 * k < 168 && y >= 0 && y < p.H && xb >= 0 && xb + 4 <= p.W * 3;
+        cb[k] = __builtin_amdgcn_raw_buffer_load_b32(rsc, ok ? (unsigned)((b * p.H + y) * p.W * 3 + xb) : 0x80000000u, 0, 0);
+      }
+    };
+    auto canvas_put = [&](const unsigned (&cb)[3]) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) if (lane + 64 * k < 168) *reinterpret_cast<unsigned*>(cvw + (lane + 64 * k) * 4) = cb[k];
+    };
+    // conv1_1 (+ bias, ReLU; zero outside the image = conv1_2's padding) on this wave's halo tiles of `patch`, strip -> patch buffer xb
+    auto prologue = [&](int patch, unsigned char* xb) {
+      int b, y0, x0;
+      patch_origin(patch, b, y0, x0);
+#pragma unroll
+      for (int t3 = 0; t3 < 6; ++t3) {
+        if (t3 < ntile) {                                  // wave-uniform
+          const int pi = (6 * pw + t3) * 16 + fr;
+          const int y = y0 - 1 + h_pr[t3], x = x0 - 1 + h_pc[t3];
+          const bool inside = pi < NHALO && y >= 0 && y < p.H && x >= 0 && x < p.W;
+          const unsigned char* base = cvw + h_off[t3];
+          bf16x8 fx;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fx[e] = (bf16)((float)base[koff[e]] * 0.00392156862745098f);   // == bf16(v / 255.0f) for every byte value
+          f32x4 a1[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) a1[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1[jj], fx, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              o[e] = inside ? (bf16)fmaxf(a1[2 * t][e] + b1[t][e], 0.f) : (bf16)0.f;
+              o[4 + e] = inside ? (bf16)fmaxf(a1[2 * t + 1][e] + b1[t][4 + e], 0.f) : (bf16)0.f;
+            }
+            if (pi < NHALO) *reinterpret_cast<bf16x8*>(xb + pi * 128 + (((4 * t + fg) ^ (pi & 7)) << 4)) = o;
+          }
+        }
+      }
+    };
+
+    int patch = blockIdx.x;
+    unsigned cb[3];
+    canvas_load(patch, cb);
+    canvas_put(cb);
+    prologue(patch, xs);
+    if (patch + (int)gridDim.x < npatch) canvas_load(patch + gridDim.x, cb);
+    for (int it = 0; patch < npatch; patch += gridDim.x, ++it) {
+      const int nextp = patch + gridDim.x;
+      F2S_STAMP(0);
+      __syncthreads();                                   // patch buffer it & 1 complete; the other one no longer read
+      F2S_STAMP(1);
+      if (nextp < npatch) {
+        canvas_put(cb);
+        if (nextp + (int)gridDim.x < npatch) canvas_load(nextp + gridDim.x, cb);   // in flight for a whole patch
+        prologue(nextp, xs + ((it + 1) & 1) * XB);
+      }
+      F2S_STAMP(2);
+    }
+  } else {
+    // ================================================================ consumers
+    const int wm = wave;
+    float bv[2][8];                                        // conv1_2 bias: channels 32 h + 8 fg + e
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const int n = 32 * h + fg * 8 + e; bv[h][e] = (p.bias && n < p.Cout) ? p.bias[n] : 0.f; }
+    int pi0[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) { const int r = wm * 64 + i * 16 + fr; pi0[i] = (r >> 5) * HW2 + (r & 31); }
+    const int wfl = (lane & 15) * 128 + (((lane >> 4) ^ ((lane >> 1) & 7)) << 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of the resident weights has landed
+
+    int patch = blockIdx.x;
+    for (int it = 0; patch < npatch; patch += gridDim.x, ++it) {
+      int b, y0, x0;
+      patch_origin(patch, b, y0, x0);
+      const unsigned char* xcur = xs + (it & 1) * XB;
+      F2S_STAMP(0);
+      __syncthreads();
+      F2S_STAMP(1);
+      f32x4 acc[4][MI];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      bf16x8 fw[2][4], fx[2][MI];
+      auto ldfrag = [&](int s, bf16x8 (&w)[4], bf16x8 (&x)[MI]) {   // K step s = 2 * tap + half
+        const int t = s >> 1, kk = s & 1;
+        const int tapoff = (t / 3) * HW2 + (t % 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const bf16x8*>(wsm + t * 8192 + (wfl ^ (kk * 64)) + j * 2048);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int pi = pi0[i] + tapoff;
+          x[i] = *reinterpret_cast<const bf16x8*>(xcur + ((pi * 128 + ((fg ^ (pi & 7)) << 4)) ^ (kk * 64)));
+        }
+      };
+      ldfrag(0, fw[0], fx[0]);
+#pragma unroll
+      for (int s = 0; s < 18; ++s) {
+        if (s + 1 < 18) ldfrag(s + 1, fw[(s + 1) & 1], fx[(s + 1) & 1]);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[s & 1][j], fx[s & 1][i], acc[j][i], 0, 0, 0);
+        // issue order of the step: one fragment read of step s + 1 in front of every two MFMAs of step s (the compiler's own
+        // order puts the reads a few MFMAs ahead of their use and waits on them)
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      F2S_STAMP(2);
+      // ---- epilogue: lane holds, of patch pixel (2 wm + (i >> 1), 16 (i & 1) + fr), channels 32 h + 8 fg + {0..3} (j = 2 h) and + {4..7} (j = 2 h + 1)
+      if (p.out) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int r = wm * 64 + i * 16 + fr;
+          const int64_t m = ((int64_t)b * p.H + y0 + (r >> 5)) * p.W + x0 + (r & 31);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int n = 32 * h + fg * 8;
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] = (bf16)fmaxf(acc[2 * h][i][e] + bv[h][e], 0.f); o[4 + e] = (bf16)fmaxf(acc[2 * h + 1][i][e] + bv[h][4 + e], 0.f); }
+            if (n < p.Cout) st_out(reinterpret_cast<bf16*>(p.out) + m * p.out_ld + n, o, p.store_policy);
+          }
+        }
+      }
+      if (p.out_pool) {
+        const int yo = (y0 >> 1) + wm;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int xo2 = (x0 + i * 16 + fr) >> 1;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int n = 32 * h + fg * 8;
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int j = 2 * h + (e >> 2);
+              float v = fmaxf(acc[j][i][e & 3], acc[j][i + 2][e & 3]);                       // the pixel below
+              v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));   // px ^ 1 (quad_perm 1,0,3,2)
+              o[e] = (bf16)fmaxf(v + bv[h][e], 0.f);
+            }
+            if ((fr & 1) == 0 && n < p.Cout)
+              st_out(reinterpret_cast<bf16*>(p.out_pool) + (((int64_t)b * (p.H >> 1) + yo) * (p.W >> 1) + xo2) * p.out_ld + n, o, p.store_policy);
+          }
+        }
+      }
+      F2S_STAMP(3);
+    }
+  }
+#undef F2S_STAMP
+}
+
+static int g_first_persistent = 2;   // fused conv1_1 + conv1_2: 2 = wave-specialised persistent kernel, 1 = first persistent form, 0 = per-patch FIRST variant
+static unsigned long long* g_c3_dbg = nullptr;
+void set_conv3p_stamps(unsigned long long* d) { g_c3_dbg = d; }
+
+static void launch_first2(const ConvParams& p_in, hipStream_t s) {
+  ConvParams p = p_in;
+  p.dbg = g_c3_dbg;
   using G = Geo<5>;
   constexpr int lds = 9 * 8192 + 2 * G::NHALO * 128 + 1408;   // 162,176 B of the 163,840
   static bool once = false;
@@ -565,6 +826,16 @@ static void launch_first2(const ConvParams& p, hipStream_t s) {
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
   const int npatch = p.B * (p.H / G::PH) * (p.W / G::PW);
+  if (g_first_persistent == 2 && ((uintptr_t)p.in0 & 3) == 0 && (size_t)p.B * p.H * p.W * 3 < ((size_t)1 << 31)) {
+    constexpr int lds2 = 9 * 8192 + 2 * G::NHALO * 128 + 4 * 6 * 112;   // 163,456 B of the 163,840
+    static bool once2 = false;
+    if (!once2) {
+      TTR_HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_first2s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+      once2 = true;
+    }
+    hipLaunchKernelGGL(conv3p_first2s_kernel, dim3(std::min(npatch, cus)), dim3(512), lds2, s, p);
+    return;
+  }
   hipLaunchKernelGGL(conv3p_first2_kernel, dim3(std::min(npatch, cus)), dim3(512), lds, s, p);
 }
 
@@ -582,7 +853,6 @@ static void launch_c3(const ConvParams& p, hipStream_t s) {
   hipLaunchKernelGGL((conv3p_kernel<BN, WM, WN, FIRST, XS, LPW>), dim3(tilesM * tilesN), dim3(C::NT), lds, s, p);
 }
 
-static int g_first_persistent = 1;   // fused conv1_1 + conv1_2: persistent weight-resident kernel (0: per-patch FIRST variant)
 void set_conv3p_first_persistent(int v) { g_first_persistent = v; }
 static int g_c64_waves = 8;        // Cout <= 64 tiles: 8 waves (wave tile 64x32) or 4 waves (wave tile 64x64, fewer LDS fragment reads per MFMA)
 void set_conv3p_c64_waves(int w) { g_c64_waves = w; }

@@ -1381,6 +1381,7 @@ int ttr_set_tuning(const char* key, int value) {
     if (value && !g_dec_dbg) { void* d = nullptr; if (hipMalloc(&d, 26 * 16 * 8) != hipSuccess) return -1; (void)hipMemset(d, 0, 26 * 16 * 8); g_dec_dbg = (unsigned long long*)d; }
     if (!value) g_dec_dbg = nullptr;
     set_gemm_ws_stamps(value == 2 ? g_dec_dbg : nullptr);
+    set_conv3p_stamps(value == 4 ? g_dec_dbg : nullptr);    // 4: ... or conv3p_first2 stamps
     set_mlp_stamps(value == 3 ? g_dec_dbg : nullptr);       // 3: ... or mlp_fused stamps   // 2: the same buffer takes gemm_ws stamps instead
   }
   else return -1;
