@@ -18,7 +18,7 @@ assert eng.lib.ttr_dbg_dec_stamps(out) == 0
 t = np.array(out[:384], dtype=np.uint64).reshape(2, 24, 8).astype(np.float64)
 mode = int(os.environ.get("F2_MODE", "2"))
 if mode == 2:   # wave-specialised kernel: wave 0 = consumer, wave 4 = producer
-    for w, lab in ((0, ["barrier", "288 MFMAs", "pool epilogue"]), (1, ["barrier", "canvas + conv1_1 of the next patch"])):
+    for w, lab in ((0, ["barrier", "288 MFMAs", "pool epilogue"]), (1, ["barrier", "canvas strip", "tile 0 gather", "tile 0 rest", "tiles 1-2", "tiles 3-5"])):
         print(f"wave {4 * w}: per-patch period {np.diff(t[w, 4:20, 0]).mean():.0f} ticks")
         dt = np.diff(t[w, 4:20, :len(lab) + 1], axis=1).mean(0)
         print("   " + "  ".join(f"{l} {v:.0f}" for l, v in zip(lab, dt)))

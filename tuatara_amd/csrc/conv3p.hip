@@ -13,6 +13,7 @@
 // ReLU copy, optional fused 2x2 max-pool) as gemm2.hip; replaces LibTorch's conv2d inside the CRAFT
 // TorchScript module run at tuatara.cpp:376.
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -574,12 +575,25 @@ __global__ __launch_bounds__(512) void conv3p_first2_kernel(ConvParams p) {
 //     16-pixel halo tiles and the <= 6 canvas rows under them: it fetches those rows itself as dwords (one patch ahead, three
 //     per lane, out-of-image dwords zero by the buffer range rule) into a private LDS strip — no canvas hand-over between
 //     waves, ONE workgroup barrier per patch.
+// What the stamps of THIS kernel showed (8.1k cycles per patch, 1.6x the first form): while a wave streams independent MFMAs its
+// SIMD partner's vector-ALU instructions do not issue at all — the producer got through its scalar, LDS and memory instructions
+// and then sat in front of its first VALU instruction until the consumer's 288 MFMAs were done, with or without s_setprio (which
+// only decides who waits) and with or without MFMAs of its own.  MFMA time and VALU time of a SIMD simply add up, so the
+// kernel is written to need few VALU instructions: every LDS address is a lane constant plus a compile-time offset (eight
+// swizzle variants of one base address cover all 36 (tile, tap) fragment positions; the patch-buffer flip is an add on those
+// constants, not a second code copy), conversions and bias adds are packed (v_pk_mul/add_f32, one v_cvt_pk_bf16_f32 per pair),
+// ReLU is v_pk_max_i16 on the rounded pair, border tests run on border patches only, pooled stores are buffer stores with a
+// scalar row offset.  (d16 LDS loads cannot pack two bytes per register here: with SRAM ECC a d16 load clears the other half.)
 __global__ __launch_bounds__(512) void conv3p_first2s_kernel(ConvParams p) {
   using G = Geo<5>;
   constexpr int PH = G::PH, PW = G::PW, HW2 = G::HW2, NHALO = G::NHALO;
   constexpr int XB = NHALO * 128;                       // one patch buffer
   constexpr int CVW = 6 * 112;                          // a producer's canvas strip: 6 rows x 28 dwords (byte 2 of a row = halo column 0, channel 0 of its left neighbour)
   constexpr int MI = 4;
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  typedef __attribute__((ext_vector_type(2))) short i16x2;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4v;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* const wsm = smem;                      // [9 taps][64 rows][128 B]   conv1_2 weights, gemm2 row/chunk permutation
   unsigned char* const xs = smem + 9 * 8192;            // [2][340][128 B]            conv1_1 output on the halo patch
@@ -607,10 +621,15 @@ __global__ __launch_bounds__(512) void conv3p_first2s_kernel(ConvParams p) {
     const int trem = patch - b * pty * ptx, ty = trem / ptx;
     y0 = ty * PH; x0 = (trem - ty * ptx) * PW;
   };
+  auto on_border = [&](int y0, int x0) { return y0 == 0 || y0 + PH == p.H || x0 == 0 || x0 + PW == p.W; };
 #define F2S_STAMP(ph) do { if (p.dbg && blockIdx.x == 0 && (tid & 255) == 0 && it < 24) p.dbg[((tid >> 8) * 24 + it) * 8 + (ph)] = __builtin_readcyclecounter(); } while (0)
 
+  // Everything a lane needs per patch is a constant of the lane (LDS addresses of its fragments / canvas bytes / halo slots)
+  // plus a compile-time offset: the two waves of a SIMD share its issue port, so every VALU instruction of either role is
+  // matrix-pipe time (stamps: 288 MFMAs + ~1000 VALU instructions of the partner took 9.1k cycles per patch, not 4.6k).
   if (producer) {
     // ================================================================ producers
+    __builtin_amdgcn_s_setprio(3);                       // else their few MFMAs wait behind the partner's stream of 288 until it ends
     const int pw = wave & 3;
     const int cvrow0 = (96 * pw) / HW2;                  // first canvas row (of the 12 around the halo) this wave's tiles touch: 0, 2, 5, 8
     const int ntile = pw < 3 ? 6 : 4;                    // 22 halo tiles of 16 pixels
@@ -622,79 +641,131 @@ __global__ __launch_bounds__(512) void conv3p_first2s_kernel(ConvParams p) {
       const int n = 32 * (jj >> 1) + (fr >> 2) * 8 + (jj & 1) * 4 + (fr & 3);
       f1[jj] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.pre_wgt) + n * 32 + fg * 8);
     }
-    float b1[2][8];
+    f32x2 b1[2][4];                                      // conv1_1 bias of channels 32 t + 8 fg + 2 e2 (+1)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) b1[t][e] = p.pre_bias[32 * t + fg * 8 + e];
-    int koff[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int k = fg * 8 + e, tp = k / 3;
-      koff[e] = k < 27 ? (tp / 3) * 112 + (tp % 3) * 3 + (k - tp * 3) : 0;   // k >= 27 multiplies a zero weight column: any byte will do
-    }
-    int h_off[6], h_pr[6], h_pc[6];
+      for (int e2 = 0; e2 < 4; ++e2) b1[t][e2] = f32x2{p.pre_bias[32 * t + fg * 8 + 2 * e2], p.pre_bias[32 * t + fg * 8 + 2 * e2 + 1]};
+    // gather addresses: tile t3, k = 8 fg + e -> canvas byte (tap row, tap column, channel) of this lane's halo pixel
+    unsigned ga[6][8], wo[6][2];
+    int h_pr[6], h_pc[6];
 #pragma unroll
     for (int t3 = 0; t3 < 6; ++t3) {
       const int pi = (6 * pw + t3) * 16 + fr;
       h_pr[t3] = pi / HW2; h_pc[t3] = pi - h_pr[t3] * HW2;
-      h_off[t3] = pi < NHALO ? (h_pr[t3] - cvrow0) * 112 + h_pc[t3] * 3 + 2 : 0;
+      const int hoff = pi < NHALO ? (h_pr[t3] - cvrow0) * 112 + h_pc[t3] * 3 + 2 : 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = fg * 8 + e, tp = k / 3;
+        const int koff = k < 27 ? (tp / 3) * 112 + (tp % 3) * 3 + (k - tp * 3) : 0;   // k >= 27 multiplies a zero weight column: any byte will do
+        ga[t3][e] = (unsigned)(size_t)(lds_ptr)(cvw + hoff + koff);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) wo[t3][t] = (unsigned)(pi * 128 + (((4 * t + fg) ^ (pi & 7)) << 4));
     }
     // canvas strip: lane owns dwords q = lane + 64 k (k < 3, q < 168) = row q / 28, dword q % 28 of the strip; a row starts 8 bytes
     // left of the patch's first pixel (dword aligned: 3 * x0 is a multiple of 96)
-    int c_row[3], c_col[3];
+    int c_row[3], c_col[3], c_off[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { const int q = lane + 64 * k; c_row[k] = q / 28; c_col[k] = q - c_row[k] * 28; }
+    for (int k = 0; k < 3; ++k) {
+      const int q = lane + 64 * k < 168 ? lane + 64 * k : lane;   // lanes past the strip re-read a dword they own and do not store it
+      c_row[k] = q / 28; c_col[k] = q - c_row[k] * 28;
+      c_off[k] = (cvrow0 - 2 + c_row[k]) * p.W * 3 - 8 + 4 * c_col[k];
+    }
     auto canvas_load = [&](int patch, unsigned (&cb)[3]) {
       int b, y0, x0;
       patch_origin(patch, b, y0, x0);
+      if (!on_border(y0, x0)) {                            // every strip dword is inside the image
+        const int sbase = ((b * p.H + y0) * p.W + x0) * 3;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int y = y0 - 2 + cvrow0 + c_row[k], xb = x0 * 3 - 8 + 4 * c_col[k];
-        const bool ok = lane + 64 * k < 168 && y >= 0 && y < p.H && xb >= 0 && xb + 4 <= p.W * 3;
-        cb[k] = __builtin_amdgcn_raw_buffer_load_b32(rsc, ok ? (unsigned)((b * p.H + y) * p.W * 3 + xb) : 0x80000000u, 0, 0);
+        for (int k = 0; k < 3; ++k) cb[k] = __builtin_amdgcn_raw_buffer_load_b32(rsc, (unsigned)(sbase + c_off[k]), 0, 0);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int y = y0 - 2 + cvrow0 + c_row[k], xb = x0 * 3 - 8 + 4 * c_col[k];
+          const bool ok = y >= 0 && y < p.H && xb >= 0 && xb + 4 <= p.W * 3;
+          cb[k] = __builtin_amdgcn_raw_buffer_load_b32(rsc, ok ? (unsigned)((b * p.H + y) * p.W * 3 + xb) : 0x80000000u, 0, 0);
+        }
       }
     };
     auto canvas_put = [&](const unsigned (&cb)[3]) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) if (lane + 64 * k < 168) *reinterpret_cast<unsigned*>(cvw + (lane + 64 * k) * 4) = cb[k];
+      asm volatile("" ::: "memory");
     };
-    // conv1_1 (+ bias, ReLU; zero outside the image = conv1_2's padding) on this wave's halo tiles of `patch`, strip -> patch buffer xb
-    auto prologue = [&](int patch, unsigned char* xb) {
-      int b, y0, x0;
-      patch_origin(patch, b, y0, x0);
+    // conv1_1 (+ bias, ReLU; zero outside the image = conv1_2's padding) on this wave's halo tiles of `patch`, strip -> patch buffer
+    auto prologue_t = [&](int b, int y0, int x0, int it, auto brd) {   // writes the patch buffer wo[][] points into
+      constexpr bool border = decltype(brd)::value;
+      unsigned char* const xb = xs;
+      unsigned d[2][8];
+      // (no d16 pair loads: with SRAM ECC on, a d16 LDS load clears the other register half)
+#define F2S_GATHER(t3, dd)                                                                        \
+  _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                 \
+    const unsigned ad = ga[t3][e];                                                                \
+    asm volatile("ds_read_u8 %0, %1" : "=v"(dd[e]) : "v"(ad));                                    \
+  }
+      F2S_GATHER(0, d[0])
 #pragma unroll
       for (int t3 = 0; t3 < 6; ++t3) {
         if (t3 < ntile) {                                  // wave-uniform
-          const int pi = (6 * pw + t3) * 16 + fr;
-          const int y = y0 - 1 + h_pr[t3], x = x0 - 1 + h_pc[t3];
-          const bool inside = pi < NHALO && y >= 0 && y < p.H && x >= 0 && x < p.W;
-          const unsigned char* base = cvw + h_off[t3];
+          unsigned (&dc)[8] = d[t3 & 1];
+          if (t3 + 1 < 6 && t3 + 1 < ntile) {
+            F2S_GATHER(t3 + 1, d[(t3 + 1) & 1])
+            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(dc[0]), "+v"(dc[1]), "+v"(dc[2]), "+v"(dc[3]), "+v"(dc[4]), "+v"(dc[5]), "+v"(dc[6]), "+v"(dc[7]));
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dc[0]), "+v"(dc[1]), "+v"(dc[2]), "+v"(dc[3]), "+v"(dc[4]), "+v"(dc[5]), "+v"(dc[6]), "+v"(dc[7]));
+          }
+          if (t3 == 0) F2S_STAMP(3);
           bf16x8 fx;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) fx[e] = (bf16)((float)base[koff[e]] * 0.00392156862745098f);   // == bf16(v / 255.0f) for every byte value
+          for (int e2 = 0; e2 < 4; ++e2) {                 // == bf16(v / 255.0f) for every byte value
+            const f32x2 v = f32x2{(float)dc[2 * e2], (float)dc[2 * e2 + 1]} * f32x2{0.00392156862745098f, 0.00392156862745098f};
+            const bf16x2 r = __builtin_convertvector(v, bf16x2);
+            fx[2 * e2] = r[0]; fx[2 * e2 + 1] = r[1];
+          }
           f32x4 a1[4];
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) a1[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1[jj], fx, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          const int pi = (6 * pw + t3) * 16 + fr;
+          bool inside = true;
+          if (border) {
+            const int y = y0 - 1 + h_pr[t3], x = x0 - 1 + h_pc[t3];
+            inside = y >= 0 && y < p.H && x >= 0 && x < p.W;
+          }
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            bf16x8 o;
+            union { i16x2 h[4]; u32x4v u; } o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              o[e] = inside ? (bf16)fmaxf(a1[2 * t][e] + b1[t][e], 0.f) : (bf16)0.f;
-              o[4 + e] = inside ? (bf16)fmaxf(a1[2 * t + 1][e] + b1[t][4 + e], 0.f) : (bf16)0.f;
+            for (int e2 = 0; e2 < 4; ++e2) {               // + bias, round, ReLU on the rounded pair (sign test: bf16 >= 0 iff int16 >= 0)
+              const f32x4& av = a1[2 * t + (e2 >> 1)];
+              const f32x2 v = f32x2{av[2 * (e2 & 1)], av[2 * (e2 & 1) + 1]} + b1[t][e2];
+              const bf16x2 r = __builtin_convertvector(v, bf16x2);
+              o.h[e2] = __builtin_elementwise_max(__builtin_bit_cast(i16x2, r), i16x2{0, 0});
             }
-            if (pi < NHALO) *reinterpret_cast<bf16x8*>(xb + pi * 128 + (((4 * t + fg) ^ (pi & 7)) << 4)) = o;
+            if (border && !inside) o.u = u32x4v{0u, 0u, 0u, 0u};
+            if (pi < NHALO) *reinterpret_cast<u32x4v*>(xb + wo[t3][t]) = o.u;
           }
+          if (t3 == 0) F2S_STAMP(4);
+          if (t3 == 2) F2S_STAMP(5);
         }
       }
+    };
+    auto prologue = [&](int patch, int it) {
+      int b, y0, x0;
+      patch_origin(patch, b, y0, x0);
+      if (on_border(y0, x0)) prologue_t(b, y0, x0, it, std::true_type{});
+      else prologue_t(b, y0, x0, it, std::false_type{});
+    };
+    auto flip = [&](unsigned delta) {                      // the other patch buffer (one code copy for both: the kernel's hot code must stay in the 64 KB I-cache)
+#pragma unroll
+      for (int t3 = 0; t3 < 6; ++t3) { wo[t3][0] += delta; wo[t3][1] += delta; }
     };
 
     int patch = blockIdx.x;
     unsigned cb[3];
     canvas_load(patch, cb);
     canvas_put(cb);
-    prologue(patch, xs);
+    prologue(patch, 1 << 20);
     if (patch + (int)gridDim.x < npatch) canvas_load(patch + gridDim.x, cb);
     for (int it = 0; patch < npatch; patch += gridDim.x, ++it) {
       const int nextp = patch + gridDim.x;
@@ -704,29 +775,44 @@ __global__ __launch_bounds__(512) void conv3p_first2s_kernel(ConvParams p) {
       if (nextp < npatch) {
         canvas_put(cb);
         if (nextp + (int)gridDim.x < npatch) canvas_load(nextp + gridDim.x, cb);   // in flight for a whole patch
-        prologue(nextp, xs + ((it + 1) & 1) * XB);
+        F2S_STAMP(2);
+        flip((it & 1) ? (unsigned)-XB : (unsigned)XB);
+        prologue(nextp, it);
       }
-      F2S_STAMP(2);
+      F2S_STAMP(6);
     }
   } else {
     // ================================================================ consumers
     const int wm = wave;
-    float bv[2][8];                                        // conv1_2 bias: channels 32 h + 8 fg + e
+    f32x2 bv[2][4];                                        // conv1_2 bias: channels 32 h + 8 fg + 2 e2 (+1)
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { const int n = 32 * h + fg * 8 + e; bv[h][e] = (p.bias && n < p.Cout) ? p.bias[n] : 0.f; }
-    int pi0[MI];
+      for (int e2 = 0; e2 < 4; ++e2) {
+        const int n = 32 * h + fg * 8 + 2 * e2;
+        bv[h][e2] = f32x2{(p.bias && n < p.Cout) ? p.bias[n] : 0.f, (p.bias && n + 1 < p.Cout) ? p.bias[n + 1] : 0.f};
+      }
+    // pixel fragments: tile i = patch row 2 wm + (i >> 1), columns 16 (i & 1) + fr; tap (dy, dx) reads halo slot
+    // pi = base + 16 (i & 1) + 34 ((i >> 1) + dy) + dx, chunk (4 kk + fg) ^ (pi & 7), and pi & 7 = (base + 2 ((i >> 1) + dy) + dx) & 7:
+    // eight lane constants (one per value of that sum mod 8) + compile-time offsets address every fragment of the patch
+    const int pib = 2 * wm * HW2 + fr;
+    const unsigned char* xbase[2][8];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) { const int r = wm * 64 + i * 16 + fr; pi0[i] = (r >> 5) * HW2 + (r & 31); }
+    for (int sg = 0; sg < 8; ++sg)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) xbase[kk][sg] = xs + pib * 128 + ((((4 * kk + fg) ^ ((pib + sg) & 7))) << 4);
     const int wfl = (lane & 15) * 128 + (((lane >> 4) ^ ((lane >> 1) & 7)) << 4);
+    const unsigned char* wbase[2][2];                      // [kk][taps 0-4 | 5-8] (the offset field holds 16 bits)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) { wbase[kk][0] = wsm + (wfl ^ (kk * 64)); wbase[kk][1] = wsm + 5 * 8192 + (wfl ^ (kk * 64)); }
+    // pooled output: lane stores (even fr only) pixel column (16 i + fr) / 2 of pooled row y0 / 2 + wm, channels 32 h + 8 fg ..
+    const __amdgpu_buffer_rsrc_t rso = mk_rsrc(p.out_pool, p.out_pool ? (unsigned)((size_t)p.B * (p.H >> 1) * (p.W >> 1) * p.out_ld * 2) : 0u);
+    const unsigned so_lane = ((fr & 1) == 0 && fg * 8 < p.Cout) ? (unsigned)(((fr >> 1) * p.out_ld + fg * 8) * 2) : 0x80000000u;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of the resident weights has landed
 
-    int patch = blockIdx.x;
-    for (int it = 0; patch < npatch; patch += gridDim.x, ++it) {
+    auto body = [&](int patch, int it) {
       int b, y0, x0;
       patch_origin(patch, b, y0, x0);
-      const unsigned char* xcur = xs + (it & 1) * XB;
       F2S_STAMP(0);
       __syncthreads();
       F2S_STAMP(1);
@@ -736,21 +822,21 @@ __global__ __launch_bounds__(512) void conv3p_first2s_kernel(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
       bf16x8 fw[2][4], fx[2][MI];
-      auto ldfrag = [&](int s, bf16x8 (&w)[4], bf16x8 (&x)[MI]) {   // K step s = 2 * tap + half
-        const int t = s >> 1, kk = s & 1;
-        const int tapoff = (t / 3) * HW2 + (t % 3);
+      auto ldfrag = [&](auto sc, bf16x8 (&w)[4], bf16x8 (&x)[MI]) {   // K step s = 2 * tap + half
+        constexpr int s = decltype(sc)::value, t = s >> 1, kk = s & 1, dy = t / 3, dx = t % 3;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const bf16x8*>(wsm + t * 8192 + (wfl ^ (kk * 64)) + j * 2048);
+        for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const bf16x8*>(wbase[kk][t >= 5] + (t >= 5 ? t - 5 : t) * 8192 + j * 2048);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-          const int pi = pi0[i] + tapoff;
-          x[i] = *reinterpret_cast<const bf16x8*>(xcur + ((pi * 128 + ((fg ^ (pi & 7)) << 4)) ^ (kk * 64)));
+          constexpr int dummy = 0; (void)dummy;
+          const int rho = (i >> 1) + dy;
+          x[i] = *reinterpret_cast<const bf16x8*>(xbase[kk][(2 * rho + dx) & 7] + (16 * (i & 1) + HW2 * rho + dx) * 128);
         }
       };
-      ldfrag(0, fw[0], fx[0]);
-#pragma unroll
-      for (int s = 0; s < 18; ++s) {
-        if (s + 1 < 18) ldfrag(s + 1, fw[(s + 1) & 1], fx[(s + 1) & 1]);
+      ldfrag(std::integral_constant<int, 0>{}, fw[0], fx[0]);
+      auto kstep = [&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        if constexpr (s + 1 < 18) ldfrag(std::integral_constant<int, s + 1>{}, fw[(s + 1) & 1], fx[(s + 1) & 1]);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -763,7 +849,13 @@ __global__ __launch_bounds__(512) void conv3p_first2s_kernel(ConvParams p) {
           __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-      }
+      };
+      kstep(std::integral_constant<int, 0>{}); kstep(std::integral_constant<int, 1>{}); kstep(std::integral_constant<int, 2>{});
+      kstep(std::integral_constant<int, 3>{}); kstep(std::integral_constant<int, 4>{}); kstep(std::integral_constant<int, 5>{});
+      kstep(std::integral_constant<int, 6>{}); kstep(std::integral_constant<int, 7>{}); kstep(std::integral_constant<int, 8>{});
+      kstep(std::integral_constant<int, 9>{}); kstep(std::integral_constant<int, 10>{}); kstep(std::integral_constant<int, 11>{});
+      kstep(std::integral_constant<int, 12>{}); kstep(std::integral_constant<int, 13>{}); kstep(std::integral_constant<int, 14>{});
+      kstep(std::integral_constant<int, 15>{}); kstep(std::integral_constant<int, 16>{}); kstep(std::integral_constant<int, 17>{});
       F2S_STAMP(2);
       // ---- epilogue: lane holds, of patch pixel (2 wm + (i >> 1), 16 (i & 1) + fr), channels 32 h + 8 fg + {0..3} (j = 2 h) and + {4..7} (j = 2 h + 1)
       if (p.out) {
@@ -776,36 +868,52 @@ __global__ __launch_bounds__(512) void conv3p_first2s_kernel(ConvParams p) {
             const int n = 32 * h + fg * 8;
             bf16x8 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { o[e] = (bf16)fmaxf(acc[2 * h][i][e] + bv[h][e], 0.f); o[4 + e] = (bf16)fmaxf(acc[2 * h + 1][i][e] + bv[h][4 + e], 0.f); }
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)fmaxf(acc[2 * h + (e >> 2)][i][e & 3] + bv[h][e >> 1][e & 1], 0.f);
             if (n < p.Cout) st_out(reinterpret_cast<bf16*>(p.out) + m * p.out_ld + n, o, p.store_policy);
           }
         }
       }
       if (p.out_pool) {
-        const int yo = (y0 >> 1) + wm;
+        // max over the 2 x 2 window first (vertical partner = tile i + 2 in this lane, horizontal partner = lane ^ 1 by DPP), then
+        // + bias, round to bf16, ReLU on the rounded value: each step is monotone, so this equals pooling relu(x + b) bit for bit
+        const unsigned srow = (unsigned)((((b * (p.H >> 1) + (y0 >> 1) + wm) * (p.W >> 1) + (x0 >> 1)) * p.out_ld) * 2);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int xo2 = (x0 + i * 16 + fr) >> 1;
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            const int n = 32 * h + fg * 8;
-            bf16x8 o;
+            union { i16x2 hh[4]; u32x4v u; } o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const int j = 2 * h + (e >> 2);
-              float v = fmaxf(acc[j][i][e & 3], acc[j][i + 2][e & 3]);                       // the pixel below
-              v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));   // px ^ 1 (quad_perm 1,0,3,2)
-              o[e] = (bf16)fmaxf(v + bv[h][e], 0.f);
+            for (int e2 = 0; e2 < 4; ++e2) {
+              float m2[2];
+#pragma unroll
+              for (int c = 0; c < 2; ++c) {
+                const int e = 2 * e2 + c, j = 2 * h + (e >> 2);
+                const float v = fmaxf(acc[j][i][e & 3], acc[j][i + 2][e & 3]);
+                asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(m2[c]) : "v"(v));
+              }
+              const f32x2 s2 = f32x2{m2[0], m2[1]} + bv[h][e2];
+              const bf16x2 r = __builtin_convertvector(s2, bf16x2);
+              o.hh[e2] = __builtin_elementwise_max(__builtin_bit_cast(i16x2, r), i16x2{0, 0});
             }
-            if ((fr & 1) == 0 && n < p.Cout)
-              st_out(reinterpret_cast<bf16*>(p.out_pool) + (((int64_t)b * (p.H >> 1) + yo) * (p.W >> 1) + xo2) * p.out_ld + n, o, p.store_policy);
+            const unsigned soff = srow + (unsigned)((i * 8 * p.out_ld + 32 * h) * 2);
+            if (32 * h < p.Cout) {
+              if (p.store_policy == 1 || p.store_policy == 2) __builtin_amdgcn_raw_buffer_store_b128(o.u, rso, so_lane, soff, 2);
+              else __builtin_amdgcn_raw_buffer_store_b128(o.u, rso, so_lane, soff, 0);
+            }
           }
-        }
       }
       F2S_STAMP(3);
+    };
+    int patch = blockIdx.x;
+    for (int it = 0; patch < npatch; patch += gridDim.x, ++it) {
+      body(patch, it);
+      const int delta = (it & 1) ? -XB : XB;               // the other patch buffer next time
+#pragma unroll
+      for (int sg = 0; sg < 8; ++sg) { xbase[0][sg] += delta; xbase[1][sg] += delta; }
     }
   }
 #undef F2S_STAMP
+#undef F2S_GATHER
 }
 
 static int g_first_persistent = 2;   // fused conv1_1 + conv1_2: 2 = wave-specialised persistent kernel, 1 = first persistent form, 0 = per-patch FIRST variant
