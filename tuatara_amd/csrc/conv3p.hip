@@ -129,14 +129,15 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
       }
     }
   };
-  auto stage_w = [&](int step) {   // step = chunk*9 + tap; weights are [Cout][tap][Cin]
-    unsigned char* sb = ws + (step & 1) * C::WSTAGE;
-    const int chunk = step / 9, tap = step - chunk * 9;
+  // weights of K step (chunk, tap) -> W stage `parity`; [Cout][tap][Cin].  The K offset rides in the instruction's scalar offset (no
+  // per-lane arithmetic; the range check sees the lane offset only, so rows past Cout stay out of range)
+  auto stage_w = [&](int chunk, int tap, int parity) {
+    unsigned char* sb = ws + parity * C::WSTAGE;
     const unsigned ko = (unsigned)((tap * Cin + chunk * 64) * 2);
 #pragma unroll
     for (int j = 0; j < C::WPW; ++j) {
-      const unsigned vo = wb[j] == OOB ? OOB : wb[j] + ko;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sb + (j * C::NW + wave) * 1024), 16, vo, 0, 0, 0);
+      const unsigned vo = wb[j];   // (a local copy: with the array element as the builtin's argument hipcc's host pass drops the kernel's stub without a word)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sb + (j * C::NW + wave) * 1024), 16, vo, ko, 0, 0);
     }
   };
 
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
 #pragma unroll
     for (int i = 0; i < C::MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  stage_w(0);
+  stage_w(0, 0, 0);
   if constexpr (!FIRST) {
     stage_x(0);
   } else {
@@ -213,6 +214,65 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
     }
     __syncthreads();   // the patch is written with ds_write: the K loop's raw s_barrier would not wait for it
   }
+  // Production variants (one patch stage, 64-pixel wave tiles): the K loop with the nine taps unrolled and every fragment address a
+  // lane constant plus a compile-time offset.  Tile i, tap t reads halo slot pi = pib + off(i) + tapoff(t), chunk (4 kk + fg) ^ (pi & 7),
+  // and pi & 7 = (pib + sg) & 7 with sg = (off + tapoff) & 7: eight swizzle variants of ONE base address cover all 36 positions, the
+  // rest is an immediate.  (MFMA and VALU instructions of a SIMD do not overlap — conv3p_first2s_kernel's stamps — and the runtime-tap
+  // loop spends ~30 VALU instructions per K step on these addresses; this one ~8.)
+  // Measured per layer (16 pages): the 64-wide tiles gain 6-17 % (upconv2.3 98 -> 91, upconv3.3 136 -> 112, upconv4.3 258 -> 220 us); the
+  // 128-wide ones do not (3.27 -3.5 %, 1.7 +11 %: they sit at the 128-register limit and the extra live addresses spill), so those keep
+  // the runtime-tap loop below.
+  constexpr bool STATIC_ADDR = XS == 1 && BN <= 64 && C::TM == 64 && !FIRST;
+  if constexpr (STATIC_ADDR) {
+    const int pib = ((wm * C::TM) >> LPW) * HW2 + fr;
+    int xbase[8];                                          // byte offsets from smem (32-bit LDS arithmetic)
+#pragma unroll
+    for (int sg = 0; sg < 8; ++sg) xbase[sg] = pib * 128 + ((fg ^ ((pib + sg) & 7)) << 4);
+    const int wb0 = XS * XSTAGE + wfl;                     // stage 0; stage 1 = + WSTAGE
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int par = (chunk + tap) & 1;                 // (chunk * 9 + tap) & 1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tap == 0 && chunk > 0) {                       // single patch stage: the next chunk's patch can only be fetched now
+          stage_x(chunk);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+        const int wbuf = wb0 + par * C::WSTAGE;
+        const int tapoff = (tap / 3) * HW2 + (tap % 3);
+        int k64 = 64;                                      // opaque per step: the second K half's addresses (base ^ 64) are formed at their use,
+        asm volatile("" : "+v"(k64));                      // not kept in eight more registers across the loop (128-VGPR budget)
+        bf16x8 fx[C::MI], fw[C::NJ];
+#pragma unroll
+        for (int j = 0; j < C::NJ; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(smem + wbuf + j * 2048);
+#pragma unroll
+        for (int i = 0; i < C::MI; ++i) {
+          const int off = ((i * 16) >> LPW) * HW2 + ((i * 16) & (PW - 1)) + tapoff;
+          fx[i] = *reinterpret_cast<const bf16x8*>(smem + xbase[off & 7] + off * 128);
+        }
+        if (tap < 8) stage_w(chunk, tap + 1, par ^ 1);
+        else if (chunk + 1 < nchunks) stage_w(chunk + 1, 0, par ^ 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          if (kk) {
+#pragma unroll
+            for (int j = 0; j < C::NJ; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(smem + (wbuf ^ k64) + j * 2048);
+#pragma unroll
+            for (int i = 0; i < C::MI; ++i) {
+              const int off = ((i * 16) >> LPW) * HW2 + ((i * 16) & (PW - 1)) + tapoff;
+              fx[i] = *reinterpret_cast<const bf16x8*>(smem + (xbase[off & 7] ^ k64) + off * 128);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+            for (int j = 0; j < C::NJ; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fx[i], acc[j][i], 0, 0, 0);
+        }
+      }
+    }
+  } else {
   int chunk = 0, tap = 0;
   for (int s = 0; s < nsteps; ++s) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -236,7 +296,7 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
       xa[i] = pi * 128 + ((fg ^ (pi & 7)) << 4);
       fx[0][i] = *reinterpret_cast<const bf16x8*>(xb + xa[i]);
     }
-    if (s + 1 < nsteps) stage_w(s + 1);
+    if (s + 1 < nsteps) stage_w(tap == 8 ? chunk + 1 : chunk, tap == 8 ? 0 : tap + 1, (s + 1) & 1);
     if (XS == 2 && tap == 0 && chunk + 1 < nchunks) stage_x(chunk + 1);
     if constexpr (EARLY) {
 #pragma unroll
@@ -267,6 +327,7 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
       }
     }
     if (++tap == 9) { tap = 0; ++chunk; }
+  }
   }
 
   // ---- epilogue: lane holds channels n..n+7 of patch pixel (py, px) for every i; i^2 is the pixel below / above
