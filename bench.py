@@ -207,7 +207,7 @@ def main():
                        "parallelism": f"dp{world}"},
             "p50_page_latency_ms": p50,
             "stage_ms_last_step": {k: round(v, 3) for k, v in stage.items()},
-            "roofline": {"kernel": "CRAFT convolutions: conv3p_first2_kernel / conv3p_kernel / conv3s_kernel / gemm2_kernel (24 launches per 16-page group)", "bound": "mfma",
+            "roofline": {"kernel": "CRAFT convolutions: conv3p_first2s_kernel / conv3p_kernel / conv3s_kernel / gemm2_kernel (24 launches per 16-page group)", "bound": "mfma",
                          "achieved": craft_tflops, "peak": peak, "unit": "TFLOP/s",
                          "frac": (craft_tflops / peak) if craft_tflops else None, "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes over 16-page CRAFT groups, profiles/r01_pmc_craft_b16.json)",
                          "launches_per_step": c["launches"] / max(1, args.steps * NC), "avg_launch_us": c["ms"] * 1e3 / max(1, c["launches"]),
