@@ -91,6 +91,28 @@ def test_batch_of_pages_matches_single_pages(eng_f32, funsd):
     assert len(batch[0]) > 5 and len(batch[2]) >= 1
 
 
+def test_batch_of_pages_matches_single_pages_bf16(eng_bf16, funsd):
+    """Throughput mode: the detector runs the same kernels over more tiles in a batch (the persistent first-pair kernel walks
+    patches of several pages, CRAFT groups of up to 16 pages, batched CCL), so every page's boxes must equal its single-page
+    result exactly.  20 pages: two CRAFT groups.  (Strings are not compared: the recogniser picks its GEMM / fused-block kernels by
+    the crop count, which changes fp32 summation order, and greedy decoding of the fixture's random PARSeq weights forks at
+    near-ties; recogniser parity across kernel choices is pinned in test_gpu_parseq.py.)"""
+    from tuatara_amd.engine import DeviceBuffer
+    rng = np.random.default_rng(1)
+    base = [funsd[:512, :384].copy(), np.ascontiguousarray(funsd[300:812, 200:584]), np.ascontiguousarray(funsd[100:612, 300:684])]
+    pages = [base[i % 3].copy() for i in range(20)]
+    for i, pg in enumerate(pages):                                   # make the pages differ: a random black bar each
+        y, x = int(rng.integers(0, 480)), int(rng.integers(0, 200))
+        pg[y:y + 12, x:x + 150] = 0
+    buf = DeviceBuffer(len(pages) * 512 * 384 * 3)
+    buf.upload(np.stack(pages))
+    batch = eng_bf16.pages_to_data_dev(buf, len(pages), 512, 384)
+    for i in (0, 1, 7, 15, 16, 19):                                  # first / last pages of both groups
+        single = eng_bf16.image_to_data(pages[i])
+        assert [x["bbox"] for x in single] == [x["bbox"] for x in batch[i]], i
+    assert len(batch[0]) > 5
+
+
 def test_empty_and_blank_inputs(eng_f32):
     from tuatara_amd.engine import EngineError
     blank = np.full((64, 64, 3), 255, np.uint8)
