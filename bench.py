@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-iters", type=int, default=20)
+    ap.add_argument("--stream", type=int, default=1, help="1: feed the steps through ttr_stream_push (batch j's detector and batch j-1's recogniser are enqueued before batch j-2's results are awaited, "
+                    "host box extraction overlaps GPU work; one stream, kernels still run alone); 0: one synchronous ttr_pages_to_data_dev call per step")
     ap.add_argument("--tune", action="append", default=[], help="engine tuning knob key=value (ttr_set_tuning), repeatable")
     ap.add_argument("--decoder-mode", type=int, default=None, help="ttr_set_decoder_mode override (0 = kernel per op, 4/8/16 = fused)")
     args = ap.parse_args()
@@ -125,8 +127,33 @@ def main():
             D.all_gather_records(D.pack_records(res), device="cuda")
         return res
 
-    for _ in range(args.warmup):
-        res = step()
+    stream = bool(args.stream) and NC == 1
+
+    def run_steps(k_steps):
+        """k_steps whole steps; returns the last step's results.  Streamed: every step's results come back two pushes later, the last
+        two from the flushes — all inside the caller's timed region."""
+        if not stream:
+            out = None
+            for _ in range(k_steps):
+                out = step()
+            return out
+        out = None
+        for _ in range(k_steps):
+            prev = eng.stream_push(dbufs[0], P, H, Wd)
+            if prev:
+                if dist:
+                    D.all_gather_records(D.pack_records(prev), device="cuda")
+                out = prev
+        while True:                      # the (up to two) batches still in flight
+            last = eng.stream_flush()
+            if not last:
+                break
+            if dist:
+                D.all_gather_records(D.pack_records(last), device="cuda")
+            out = last
+        return out
+
+    res = run_steps(args.warmup) if args.warmup else None
     crops_per_page = float(np.mean([len(r) for r in res])) if args.warmup else 0.0
 
     def fence():
@@ -140,8 +167,7 @@ def main():
         e.set_profiling(1)     # timed region: HIP events around the dominant kernels only (the CRAFT convolutions)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
+    res = run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
     prof = {k: {"ms": 0.0, "flops": 0.0, "launches": 0} for k in ("craft", "parseq", "parseq_ar")}
@@ -157,8 +183,7 @@ def main():
     # region (1400 event records per step cost ~8 % of throughput, so they stay out of `value`)
     for e in engs:
         e.set_profiling(2)
-    for _ in range(2):
-        step()
+    run_steps(2)
     fence()
     for e in engs:
         pe = e.get_profile()
@@ -202,7 +227,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "configs[4]: synthetic stream of 1024x768 pages (~40 detected crops each), page-level DP, "
-                                   "RCCL all-gather of token ids", "pages_per_gpu_per_step": P, "engine_contexts_per_gpu": NC,
+                                   "RCCL all-gather of token ids", "pages_per_gpu_per_step": P, "engine_contexts_per_gpu": NC, "batches_in_flight": 3 if stream else 1,
                        "words_drawn_per_page": args.words, "crops_per_page": round(crops_per_page, 1), "weights": "seeded synthetic (structured CRAFT, random PARSeq)",
                        "parallelism": f"dp{world}"},
             "p50_page_latency_ms": p50,

@@ -57,6 +57,15 @@ int ttr_image_to_data(ttr_engine* e, const uint8_t* hwc_u8, int h, int w, int ro
 /* Batch of n same-sized pages already resident in device memory (contiguous [n][h][w][3] u8).
  * out[i] receives page i's result. */
 int ttr_pages_to_data_dev(ttr_engine* e, const uint8_t* d_pages, int n, int h, int w, ttr_result** out);
+/* Streamed form of ttr_pages_to_data_dev for a sequence of batches (same contract per batch, results two calls later):
+ * ttr_stream_push(j) enqueues the detector of batch j, then the recogniser of batch j-1, turns batch j's components into boxes on the
+ * host while the GPU works, and returns batch j-2's results in out_prev[0 .. *n_prev) (*n_prev = 0 on the first two pushes).  The
+ * GPU always has a whole detector or recogniser pass queued while the host decodes, returns and comes back with the next batch; one
+ * stream, kernels still run one at a time.  The pages of a batch must stay valid until its results have been returned.
+ * ttr_stream_flush returns the oldest batch still in flight (*n_prev = 0: none left; call it until then).  out_prev must hold as many
+ * entries as the largest batch.  The synchronous calls refuse to run while streamed batches are in flight. */
+int ttr_stream_push(ttr_engine* e, const uint8_t* d_pages, int n, int h, int w, ttr_result** out_prev, int* n_prev);
+int ttr_stream_flush(ttr_engine* e, ttr_result** out_prev, int* n_prev);
 
 int ttr_result_count(const ttr_result* r);
 const char* ttr_result_text(const ttr_result* r, int i);

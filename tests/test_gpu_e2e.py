@@ -113,6 +113,46 @@ def test_batch_of_pages_matches_single_pages_bf16(eng_bf16, funsd):
     assert len(batch[0]) > 5
 
 
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_streamed_batches_equal_synchronous_calls(eng_f32, eng_bf16, funsd, prec):
+    """ttr_stream_push / ttr_stream_flush: batch j's detector and batch j-1's recogniser are enqueued before batch j-2's results are
+    awaited, and results come back two calls later — same kernels over the same batches, so boxes and strings must equal the
+    synchronous call's exactly.  Five batches of different sizes (one of a single page, one of blank pages) and a refusal of synchronous
+    calls mid-stream."""
+    from tuatara_amd.engine import DeviceBuffer, EngineError
+    eng = eng_f32 if prec == "f32" else eng_bf16
+    crops3 = [funsd[:512, :384].copy(), np.ascontiguousarray(funsd[300:812, 200:584]), np.ascontiguousarray(funsd[100:612, 300:684])]
+    batches = [crops3, [crops3[1]], [np.full((512, 384, 3), 255, np.uint8)] * 2, crops3[::-1] + crops3, [crops3[2], crops3[0]]]
+    bufs = []
+    for b in batches:
+        buf = DeviceBuffer(len(b) * 512 * 384 * 3); buf.upload(np.stack(b)); bufs.append(buf)
+    sync = [eng.pages_to_data_dev(buf, len(b), 512, 384) for buf, b in zip(bufs, batches)]
+    got = []
+    for i, (buf, b) in enumerate(zip(bufs, batches)):
+        prev = eng.stream_push(buf, len(b), 512, 384)
+        assert len(prev) == (len(batches[i - 2]) if i >= 2 else 0)
+        if i >= 2:
+            got.append(prev)
+        if i == 1:
+            with pytest.raises(EngineError):
+                eng.pages_to_data_dev(bufs[0], len(batches[0]), 512, 384)      # streamed batches are in flight
+    got.append(eng.stream_flush())
+    got.append(eng.stream_flush())
+    assert eng.stream_flush() == []                                           # nothing left in flight
+    assert len(got) == len(sync)
+    for a, b in zip(sync, got):
+        assert len(a) == len(b)
+        for pa, pb in zip(a, b):
+            assert [x["bbox"] for x in pa] == [x["bbox"] for x in pb]
+            assert [x["text"] for x in pa] == [x["text"] for x in pb]
+    assert sum(len(p) for p in sync[0]) > 10
+    assert len(eng.pages_to_data_dev(bufs[1], 1, 512, 384)) == 1                # synchronous calls work again
+    # one push then flushes: a stream shorter than the pipeline
+    assert eng.stream_push(bufs[0], len(batches[0]), 512, 384) == []
+    only = eng.stream_flush()
+    assert [[x["text"] for x in pg] for pg in only] == [[x["text"] for x in pg] for pg in sync[0]] and eng.stream_flush() == []
+
+
 def test_empty_and_blank_inputs(eng_f32):
     from tuatara_amd.engine import EngineError
     blank = np.full((64, 64, 3), 255, np.uint8)

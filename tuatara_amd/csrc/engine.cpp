@@ -280,7 +280,8 @@ struct Engine {
   hipStream_t stream = nullptr;
   std::unique_ptr<HostPool> host_pool;
   hipStream_t copy_stream = nullptr;              // device -> host copies of one page group's components while the next group's CRAFT runs
-  hipEvent_t copy_ev = nullptr, done_ev = nullptr;
+  hipEvent_t copy_ev = nullptr, done_ev[2] = {nullptr, nullptr};   // done_ev[slot]: a batch's token ids have landed
+  hipEvent_t evr[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};   // per slot: before the packer, after it, after PARSeq
   // hand-over points of a batch are polled, not slept on: a blocking wait costs tens of microseconds of wake-up per sync
   static void spin_event(hipEvent_t e) {
     for (;;) {
@@ -308,7 +309,7 @@ struct Engine {
   DevBuf pq_ws[16];
   DevBuf canvas, heat, staging_img, crops, rects_dev, logits, ar_logits, ids_dev, tokens;
   CclBatch ccl;
-  PinnedBuf h_counters, h_cand, h_rows, h_rects, h_ids;   // pinned staging of the small host <-> device transfers
+  PinnedBuf h_counters, h_cand, h_rows, h_rects[2], h_ids[2];   // pinned staging of the small host <-> device transfers
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   float stage_ms[4] = {0, 0, 0, 0};
   float host_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // host wall-clock splits of the last run_pages (ttr_last_host_us)
@@ -504,7 +505,8 @@ struct Engine {
     TTR_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     TTR_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
     TTR_HIP_CHECK(hipEventCreateWithFlags(&copy_ev, hipEventDisableTiming));
-    TTR_HIP_CHECK(hipEventCreateWithFlags(&done_ev, hipEventDisableTiming));
+    for (auto& x : done_ev) TTR_HIP_CHECK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+    for (auto& sl : evr) for (auto& x : sl) TTR_HIP_CHECK(hipEventCreate(&x));
     host_pool.reset(new HostPool(std::min(15, std::max(1, (int)std::thread::hardware_concurrency() - 1))));
     for (auto& x : ev) TTR_HIP_CHECK(hipEventCreate(&x));
     load_craft(dir);
@@ -515,7 +517,8 @@ struct Engine {
     for (auto& x : prof_pool) (void)hipEventDestroy(x);
     for (auto& x : group_ev) (void)hipEventDestroy(x);
     if (copy_ev) (void)hipEventDestroy(copy_ev);
-    if (done_ev) (void)hipEventDestroy(done_ev);
+    for (auto& x : done_ev) if (x) (void)hipEventDestroy(x);
+    for (auto& sl : evr) for (auto& x : sl) if (x) (void)hipEventDestroy(x);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -871,20 +874,38 @@ struct Engine {
   // run f(page) for every page on the engine's host threads
   void parallel_pages(int pages, const std::function<void(int)>& f) { host_pool->run(pages, f); }
 
-  // ---- the hot path over a batch of same-sized device pages
-  void run_pages(const uint8_t* d_pages, int n, int h, int w, std::vector<Result>& results) {
-    results.assign(n, Result());
-    if (n <= 0) return;
-    const double th0 = now_us();
-    if (h <= 0 || w <= 0) throw std::runtime_error("Error reading image from file");  // image.empty(), tuatara.cpp:344
-    const CanvasGeom g = canvas_geometry(h, w, cfg.canvas_size, cfg.mag_ratio);
-    if (g.target_h <= 0 || g.target_w <= 0) throw std::runtime_error("image too thin to resize");
-    const int H = g.h32, W = g.w32, H2 = H / 2, W2 = W / 2;
-    const size_t page_bytes = (size_t)h * w * 3;
+  // ---- the hot path over a batch of same-sized device pages, in four phases so that several batches can be in flight:
+  //   detect_enqueue   resize + CRAFT + CCL kernels of a batch on the stream
+  //   detect_collect   host: wait for each CRAFT group's components, calipers -> boxes -> crop rectangles
+  //   recog_enqueue    crop rectangles -> packer -> PARSeq -> token ids back (stream)
+  //   finish           wait, decode the ids per page
+  // run_pages runs them in that order for one batch.  stream_push(j) runs detect_enqueue(j), recog_enqueue(j-1), detect_collect(j),
+  // finish(j-2): the stream holds C(j) P(j-1) behind whatever is running, so the GPU works through the previous batch's recogniser
+  // while the host turns batch j's components into boxes, and still has a whole recogniser queued while the host decodes batch j-2,
+  // returns to the caller and comes back with batch j+1 — no GPU idle at any hand-over; one stream, every kernel still runs alone.
+  // Host staging (crop rectangles, token ids) and the completion events exist twice (slot = batch parity).
+  struct PageBatch {
+    const uint8_t* d_pages = nullptr; int n = 0, h = 0, w = 0;
+    CanvasGeom g{}; int H = 0, W = 0, H2 = 0, W2 = 0; size_t page_bytes = 0;
+    std::vector<std::vector<RRect>> boxes;
+    std::vector<int> rects, page_of;
+    int N = 0, slot = 0;
+    bool live = false, enqueued = false;
+  };
+  PageBatch q1, q2;        // streamed batches: q1 = boxes known (recogniser enqueued or not), q2 = older, recogniser enqueued, results not yet returned
+  unsigned batch_seq = 0;
+
+  void detect_enqueue(PageBatch& B) {
+    if (B.h <= 0 || B.w <= 0) throw std::runtime_error("Error reading image from file");  // image.empty(), tuatara.cpp:344
+    B.g = canvas_geometry(B.h, B.w, cfg.canvas_size, cfg.mag_ratio);
+    if (B.g.target_h <= 0 || B.g.target_w <= 0) throw std::runtime_error("image too thin to resize");
+    B.H = B.g.h32; B.W = B.g.w32; B.H2 = B.H / 2; B.W2 = B.W / 2;
+    B.page_bytes = (size_t)B.h * B.w * 3;
+    const int n = B.n, H = B.H, W = B.W, H2 = B.H2, W2 = B.W2;
     canvas.ensure((size_t)n * H * W * 3);
     heat.ensure((size_t)n * H2 * W2 * 2 * 4);
     TTR_HIP_CHECK(hipEventRecord(ev[0], stream));
-    launch_resize_pad_u8(d_pages, h, w, w * 3, canvas.as<uint8_t>(), g.target_h, g.target_w, H, W, 1, stream, n, page_bytes);
+    launch_resize_pad_u8(B.d_pages, B.h, B.w, B.w * 3, canvas.as<uint8_t>(), B.g.target_h, B.g.target_w, H, W, 1, stream, n, B.page_bytes);
     // CRAFT in groups of <= 16 pages: bounds the activation workspace (~0.5 GB/page) and keeps every tensor
     // inside the 2 GiB window gemm2's 32-bit buffer offsets address.  Each group's CCL follows its CRAFT, so the host reads
     // group g's components back (and runs its calipers) while the GPU is busy with group g + 1.
@@ -896,18 +917,16 @@ struct Engine {
       ccl_launch(heat.as<float>() + (size_t)p0 * H2 * W2 * 2, p0, cnt, n, gi, H2, W2);
     }
     TTR_HIP_CHECK(hipEventRecord(ev[2], stream));
+  }
 
-    // host: boxes -> crop rectangles
-    const float ratio_w = 1.f / g.ratio, ratio_h = 1.f / g.ratio;   // tuatara.cpp:360-361
-    std::vector<int> rects;                 // x0,y0,x1,y1,page per crop
-    std::vector<int> page_of;               // page index per crop
-    std::vector<std::vector<RRect>> boxes(n);
-    std::vector<std::vector<RRect>> dets;
-    host_us[0] = (float)(now_us() - th0);
+  void detect_collect(PageBatch& B) {
+    const int n = B.n, groups = (n + 15) / 16;
+    const float ratio_w = 1.f / B.g.ratio, ratio_h = 1.f / B.g.ratio;   // tuatara.cpp:360-361
+    std::vector<std::vector<RRect>> dets(n);
+    B.boxes.assign(n, std::vector<RRect>());
+    B.rects.clear(); B.page_of.clear();        // x0,y0,x1,y1,page per crop; page index per crop
     host_us[1] = host_us[2] = host_us[3] = 0.f;
-    dets.assign(n, std::vector<RRect>());
-    for (int gi = 0; gi < groups; ++gi) ccl_collect(gi * 16, std::min(16, n - gi * 16), gi, H2, W2, dets);
-    const double th1 = now_us();
+    for (int gi = 0; gi < groups; ++gi) ccl_collect(gi * 16, std::min(16, n - gi * 16), gi, B.H2, B.W2, dets);
     for (int i = 0; i < n; ++i) {
       for (const RRect& r : dets[i]) {
         RRect b = adjust_coordinates(r, ratio_w, ratio_h);            // :406
@@ -915,46 +934,59 @@ struct Engine {
         bounding_rect(b, xywh);                                       // :416
         int x0 = xywh[0], y0 = xywh[1], x1 = xywh[0] + xywh[2], y1 = xywh[1] + xywh[3];
         if (cfg.strict_crops) {
-          if (x0 < 0 || y0 < 0 || x1 > w || y1 > h) throw std::runtime_error("text box leaves the image (cv::Exception in the reference, tuatara.cpp:416)");
+          if (x0 < 0 || y0 < 0 || x1 > B.w || y1 > B.h) throw std::runtime_error("text box leaves the image (cv::Exception in the reference, tuatara.cpp:416)");
         } else {
-          x0 = std::max(x0, 0); y0 = std::max(y0, 0); x1 = std::min(x1, w); y1 = std::min(y1, h);
+          x0 = std::max(x0, 0); y0 = std::max(y0, 0); x1 = std::min(x1, B.w); y1 = std::min(y1, B.h);
         }
         if (x1 <= x0 || y1 <= y0) continue;
-        boxes[i].push_back(b);
-        rects.insert(rects.end(), {x0, y0, x1, y1, i});
-        page_of.push_back(i);
+        B.boxes[i].push_back(b);
+        B.rects.insert(B.rects.end(), {x0, y0, x1, y1, i});
+        B.page_of.push_back(i);
       }
     }
-    const int N = (int)page_of.size();
-    h_ids.ensure((size_t)N * 26 * 4 + 4);
-    int32_t* ids = h_ids.as<int32_t>();
+    B.N = (int)B.page_of.size();
+  }
+
+  void recog_enqueue(PageBatch& B) {
+    const int N = B.N, sl = B.slot;
+    h_ids[sl].ensure((size_t)N * 26 * 4 + 4);
+    TTR_HIP_CHECK(hipEventRecord(evr[sl][0], stream));
     if (N > 0) {
-      rects_dev.ensure(rects.size() * 4);
-      h_rects.ensure(rects.size() * 4);
-      memcpy(h_rects.p, rects.data(), rects.size() * 4);
+      rects_dev.ensure(B.rects.size() * 4);
+      h_rects[sl].ensure(B.rects.size() * 4);
+      memcpy(h_rects[sl].p, B.rects.data(), B.rects.size() * 4);
       crops.ensure((size_t)N * 32 * 128 * 3);
       logits.ensure((size_t)N * 26 * 95 * 4);
       ids_dev.ensure((size_t)N * 26 * 4);
-      TTR_HIP_CHECK(hipMemcpyAsync(rects_dev.p, h_rects.p, rects.size() * 4, hipMemcpyHostToDevice, stream));
-      launch_pack_crops(d_pages, page_bytes, w * 3, rects_dev.as<int>(), crops.as<uint8_t>(), N, stream);
-      TTR_HIP_CHECK(hipEventRecord(ev[3], stream));
+      TTR_HIP_CHECK(hipMemcpyAsync(rects_dev.p, h_rects[sl].p, B.rects.size() * 4, hipMemcpyHostToDevice, stream));
+      launch_pack_crops(B.d_pages, B.page_bytes, B.w * 3, rects_dev.as<int>(), crops.as<uint8_t>(), N, stream);
+      TTR_HIP_CHECK(hipEventRecord(evr[sl][1], stream));
       parseq_forward(crops.as<uint8_t>(), N, logits.as<float>(), nullptr, ids_dev.as<int>());
-      TTR_HIP_CHECK(hipEventRecord(ev[4], stream));
-      TTR_HIP_CHECK(hipMemcpyAsync(ids, ids_dev.p, (size_t)N * 26 * 4, hipMemcpyDeviceToHost, stream));
+      TTR_HIP_CHECK(hipEventRecord(evr[sl][2], stream));
+      TTR_HIP_CHECK(hipMemcpyAsync(h_ids[sl].as<int32_t>(), ids_dev.p, (size_t)N * 26 * 4, hipMemcpyDeviceToHost, stream));
     } else {
-      TTR_HIP_CHECK(hipEventRecord(ev[3], stream));
-      TTR_HIP_CHECK(hipEventRecord(ev[4], stream));
+      TTR_HIP_CHECK(hipEventRecord(evr[sl][1], stream));
+      TTR_HIP_CHECK(hipEventRecord(evr[sl][2], stream));
     }
+    TTR_HIP_CHECK(hipEventRecord(done_ev[sl], stream));
+    B.enqueued = true;
+  }
+
+  void finish(PageBatch& B, std::vector<Result>& results) {
+    const int n = B.n, N = B.N;
+    results.assign(n, Result());
     const double th2 = now_us();
-    TTR_HIP_CHECK(hipEventRecord(done_ev, stream));
-    spin_event(done_ev);
+    spin_event(done_ev[B.slot]);
     const double th3 = now_us();
-    for (int s = 0; s < 4; ++s) (void)hipEventElapsedTime(&stage_ms[s], ev[s], ev[s + 1]);
+    // stage times: detector events belong to the latest batch enqueued (complete by now: its components were collected), recogniser events to this one
+    (void)hipEventElapsedTime(&stage_ms[0], ev[0], ev[1]); (void)hipEventElapsedTime(&stage_ms[1], ev[1], ev[2]);
+    (void)hipEventElapsedTime(&stage_ms[2], evr[B.slot][0], evr[B.slot][1]); (void)hipEventElapsedTime(&stage_ms[3], evr[B.slot][1], evr[B.slot][2]);
     if (profiling) prof_collect();
     const double th4 = now_us();
+    const int32_t* ids = h_ids[B.slot].as<int32_t>();
     // crops are ordered by page: page pg owns crops [first[pg], first[pg + 1]); pages decode independently
     std::vector<int> first(n + 1, 0);
-    for (int c = 0; c < N; ++c) first[page_of[c] + 1]++;
+    for (int c = 0; c < N; ++c) first[B.page_of[c] + 1]++;
     for (int pg = 0; pg < n; ++pg) first[pg + 1] += first[pg];
     auto decode_page = [&](int pg) {
       Result& r = results[pg];
@@ -964,13 +996,57 @@ struct Engine {
       for (int k = 0; k < cnt; ++k) {
         r.text.push_back(tok.decode(&ids[(size_t)(c0 + k) * 26], 26));   // :486-505
         float bb[4];
-        tesseract_bbox(boxes[pg][k], bb);                                 // :511
+        tesseract_bbox(B.boxes[pg][k], bb);                               // :511
         r.bbox.insert(r.bbox.end(), bb, bb + 4);
       }
     };
     if (N >= 256) parallel_pages(n, decode_page);
     else for (int pg = 0; pg < n; ++pg) decode_page(pg);
-    host_us[4] = (float)(th2 - th1); host_us[5] = (float)(th3 - th2); host_us[6] = (float)(th4 - th3); host_us[7] = (float)(now_us() - th4);
+    host_us[5] = (float)(th3 - th2); host_us[6] = (float)(th4 - th3); host_us[7] = (float)(now_us() - th4);
+    B.live = false; B.enqueued = false;
+  }
+
+  void run_pages(const uint8_t* d_pages, int n, int h, int w, std::vector<Result>& results) {
+    results.assign(n, Result());
+    if (n <= 0) return;
+    if (q1.live || q2.live) throw std::runtime_error("streamed batches are in flight: call ttr_stream_flush until it returns none");
+    const double th0 = now_us();
+    PageBatch B;
+    B.d_pages = d_pages; B.n = n; B.h = h; B.w = w; B.slot = 0;
+    detect_enqueue(B);
+    host_us[0] = (float)(now_us() - th0);
+    detect_collect(B);
+    const double th1 = now_us();
+    recog_enqueue(B);
+    host_us[4] = (float)(now_us() - th1);
+    finish(B, results);
+  }
+
+  // Streamed form: returns the results of the batch pushed TWO calls earlier (prev_n = its page count, 0 for the first two pushes).
+  // The pages of a batch must stay valid until its results have been returned (the crop packer reads them one push later).
+  void stream_push(const uint8_t* d_pages, int n, int h, int w, std::vector<Result>& prev_results, int& prev_n) {
+    prev_results.clear(); prev_n = 0;
+    if (n <= 0) throw std::runtime_error("stream_push: empty batch");
+    const double th0 = now_us();
+    PageBatch B;
+    B.d_pages = d_pages; B.n = n; B.h = h; B.w = w; B.slot = (int)(batch_seq++ & 1);
+    detect_enqueue(B);
+    host_us[0] = (float)(now_us() - th0);
+    const double th1 = now_us();
+    if (q1.live && !q1.enqueued) recog_enqueue(q1);
+    host_us[4] = (float)(now_us() - th1);
+    detect_collect(B);
+    if (q2.live) { prev_n = q2.n; finish(q2, prev_results); }
+    if (q1.live) q2 = std::move(q1);
+    q1 = std::move(B);
+    q1.live = true; q1.enqueued = false;
+  }
+  // results of the oldest batch in flight (prev_n = 0: none left)
+  void stream_flush(std::vector<Result>& prev_results, int& prev_n) {
+    prev_results.clear(); prev_n = 0;
+    if (q1.live && !q1.enqueued) recog_enqueue(q1);
+    if (q2.live) { prev_n = q2.n; finish(q2, prev_results); return; }
+    if (q1.live) { prev_n = q1.n; finish(q1, prev_results); }
   }
 };
 
@@ -1024,6 +1100,32 @@ int ttr_pages_to_data_dev(ttr_engine* e, const uint8_t* d_pages, int n, int h, i
   if (!e || !out) throw std::runtime_error("null argument");
   std::lock_guard<std::mutex> lk(e->e->mu);
   run_locked(e, d_pages, n, h, w, out);
+  return 0;
+  TTR_GUARD_END(-1)
+}
+
+int ttr_stream_push(ttr_engine* e, const uint8_t* d_pages, int n, int h, int w, ttr_result** out_prev, int* n_prev) {
+  TTR_GUARD_BEGIN
+  if (!e || !out_prev || !n_prev) throw std::runtime_error("null argument");
+  std::lock_guard<std::mutex> lk(e->e->mu);
+  std::vector<Result> res;
+  int np = 0;
+  e->e->stream_push(d_pages, n, h, w, res, np);
+  for (int i = 0; i < np; ++i) { out_prev[i] = new ttr_result(); out_prev[i]->r = std::move(res[i]); }
+  *n_prev = np;
+  return 0;
+  TTR_GUARD_END(-1)
+}
+
+int ttr_stream_flush(ttr_engine* e, ttr_result** out_prev, int* n_prev) {
+  TTR_GUARD_BEGIN
+  if (!e || !out_prev || !n_prev) throw std::runtime_error("null argument");
+  std::lock_guard<std::mutex> lk(e->e->mu);
+  std::vector<Result> res;
+  int np = 0;
+  e->e->stream_flush(res, np);
+  for (int i = 0; i < np; ++i) { out_prev[i] = new ttr_result(); out_prev[i]->r = std::move(res[i]); }
+  *n_prev = np;
   return 0;
   TTR_GUARD_END(-1)
 }

@@ -36,6 +36,8 @@ SYMBOLS = [
     ("ttr_version", C.c_char_p, []),
     ("ttr_image_to_data", _I, [_VP, _PU8, _I, _I, _I, C.POINTER(_VP)]),
     ("ttr_pages_to_data_dev", _I, [_VP, _VP, _I, _I, _I, C.POINTER(_VP)]),
+    ("ttr_stream_push", _I, [_VP, _VP, _I, _I, _I, C.POINTER(_VP), C.POINTER(C.c_int)]),
+    ("ttr_stream_flush", _I, [_VP, C.POINTER(_VP), C.POINTER(C.c_int)]),
     ("ttr_result_count", _I, [_VP]),
     ("ttr_result_text", C.c_char_p, [_VP, _I]),
     ("ttr_result_bbox", _PF, [_VP, _I]),
@@ -277,6 +279,30 @@ class Engine:
             counts.append(self.lib.ttr_result_count(arr[i]))
             self.lib.ttr_result_free(arr[i])
         return counts
+
+    def _stream_take(self, arr, n_prev: int, keep: bool):
+        if keep:
+            return self._take_many(arr, n_prev)
+        counts = []
+        for i in range(n_prev):
+            counts.append(self.lib.ttr_result_count(arr[i]))
+            self.lib.ttr_result_free(arr[i])
+        return counts
+
+    def stream_push(self, d_pages, n: int, h: int, w: int, keep: bool = True, max_batch: int = 0):
+        """Streamed batches (ttr_stream_push): enqueue batch k+1, get batch k's results (an empty list on the first push).  The
+        pages of a batch must stay alive until its results have come back."""
+        ptr = d_pages.ptr if isinstance(d_pages, DeviceBuffer) else d_pages
+        arr = (C.c_void_p * max(n, max_batch, 1024))()
+        n_prev = C.c_int(0)
+        self._check(self.lib.ttr_stream_push(self.h, ptr, n, h, w, arr, C.byref(n_prev)))
+        return self._stream_take(arr, n_prev.value, keep)
+
+    def stream_flush(self, keep: bool = True):
+        arr = (C.c_void_p * 1024)()
+        n_prev = C.c_int(0)
+        self._check(self.lib.ttr_stream_flush(self.h, arr, C.byref(n_prev)))
+        return self._stream_take(arr, n_prev.value, keep)
 
     def last_stage_ms(self):
         ms = (C.c_float * 4)()
