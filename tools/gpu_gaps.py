@@ -1,17 +1,15 @@
-"""Reads a rocprofv3 kernel trace CSV and prints, for the busiest 60 % of the run, the GPU busy fraction and the largest idle gaps.
-python tools/gpu_gaps.py <kernel_trace.csv>"""
+"""Reads a rocprofv3 kernel-trace CSV of a bench.py run and prints, per 32-page step (from one resize launch to the next), the wall
+time, the sum of kernel durations, the idle time and the largest gaps.   python tools/gpu_gaps.py <kernel_trace.csv>"""
 import csv, sys
-rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(sys.argv[1]))]
-rows.sort()
-t0, t1 = rows[0][0], rows[-1][1]
-lo, hi = t0 + (t1 - t0) * 0.45, t0 + (t1 - t0) * 0.75
-sel = [r for r in rows if r[0] >= lo and r[1] <= hi]
-busy = sum(e - s for s, e, _ in sel)
-gaps = []
-for a, b in zip(sel, sel[1:]):
-    g = b[0] - a[1]
-    if g > 0: gaps.append((g, a[2][:50], b[2][:50]))
-span = sel[-1][1] - sel[0][0]
-print(f"window {span/1e6:.1f} ms, kernels {len(sel)}, busy {busy/span:.4f}, idle {(span-busy)/1e6:.2f} ms; gaps > 20 us: {sum(g for g,_,_ in gaps if g > 20000)/1e6:.2f} ms")
-for g, a, b in sorted(gaps, reverse=True)[:12]:
-    print(f"  {g/1e3:8.1f} us  after {a}  before {b}")
+rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(sys.argv[1])))
+starts = [i for i, r in enumerate(rows) if "resize_pad" in r[2]]
+print(f"{len(rows)} kernels, {len(starts)} resize launches")
+for a, b in zip(starts, starts[1:]):
+    if b - a < 300:
+        continue                      # single-page latency runs
+    span = rows[b][0] - rows[a][0]
+    busy = sum(e - s for s, e, _ in rows[a:b])
+    gaps = sorted(((rows[i + 1][0] - rows[i][1], rows[i][2][:30], rows[i + 1][2][:30]) for i in range(a, b)), reverse=True)
+    idle = sum(g for g, _, _ in gaps if g > 0)
+    print(f"step {span / 1e6:6.2f} ms  kernels {busy / 1e6:6.2f} ms  idle {idle / 1e6:5.2f} ms   largest gaps (us): " +
+          "; ".join(f"{g / 1e3:.0f} {x} -> {y}" for g, x, y in gaps[:2]))
