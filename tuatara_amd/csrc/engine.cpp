@@ -347,14 +347,21 @@ struct Engine {
     seg_open = false;
   }
   void igemm(const ConvParams& p, double true_flops) { timed(true_flops, [&] { launch_igemm(prec, p, stream); }); }
-  void prof_collect() {  // after a stream sync
-    for (size_t i = 0; i < prof_recs.size(); ++i) {
+  // Folds the records whose events have completed (one stream: they complete in order).  With streamed batches the newest records
+  // belong to a pass that is still running: they stay, with their events, for the next call.
+  void prof_collect() {
+    if (seg_open) return;                        // (never between the two events of a run)
+    size_t done = 0;
+    for (; done < prof_recs.size(); ++done) {
+      if (hipEventQuery(prof_pool[2 * done + 1]) != hipSuccess) { (void)hipGetLastError(); break; }
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, prof_pool[2 * i], prof_pool[2 * i + 1]) == hipSuccess) {
-        prof_ms[prof_recs[i].stage] += ms; prof_flops[prof_recs[i].stage] += prof_recs[i].flops; prof_launches[prof_recs[i].stage] += prof_recs[i].launches;
+      if (hipEventElapsedTime(&ms, prof_pool[2 * done], prof_pool[2 * done + 1]) == hipSuccess) {
+        prof_ms[prof_recs[done].stage] += ms; prof_flops[prof_recs[done].stage] += prof_recs[done].flops; prof_launches[prof_recs[done].stage] += prof_recs[done].launches;
       }
     }
-    prof_recs.clear();
+    if (done == 0) return;
+    std::rotate(prof_pool.begin(), prof_pool.begin() + 2 * done, prof_pool.begin() + 2 * prof_recs.size());
+    prof_recs.erase(prof_recs.begin(), prof_recs.begin() + done);
   }
 
   // ---- construction
@@ -1575,6 +1582,7 @@ int ttr_set_profiling(ttr_engine* e, int on) {
 int ttr_get_profile(ttr_engine* e, double ms[3], double flops[3], long long launches[3]) {
   Engine& E = *e->e;
   std::lock_guard<std::mutex> lk(E.mu);
+  E.prof_collect();          // records whose events completed since the last batch was finished
   for (int i = 0; i < 3; ++i) { ms[i] = E.prof_ms[i]; flops[i] = E.prof_flops[i]; launches[i] = E.prof_launches[i]; }
   return 0;
 }
