@@ -110,6 +110,23 @@ def test_layernorm_fused_into_skinny_gemm_matches_separate_kernels(eng_bf16):
     assert np.array_equal(i0[same_path], i1[same_path])
 
 
+def test_refinement_self_attention_per_crop_kernel_is_bit_identical(eng_bf16):
+    """dec_self_attn_refine_kernel (one workgroup per crop, K/V cache in LDS, all 26 query rows) against dec_self_attn_kernel (one
+    workgroup per row): same operations in the same order — logits and ids must be equal bit for bit.  The crops' random tokens
+    include early EOS for some (key padding) and none for others."""
+    rng = np.random.default_rng(15)
+    crops = rng.integers(0, 256, (45, 32, 128, 3), dtype=np.uint8)
+    try:
+        assert eng_bf16.lib.ttr_set_tuning(b"self_refine", 0) == 0
+        l0, i0 = eng_bf16.parseq_logits(crops)
+        assert eng_bf16.lib.ttr_set_tuning(b"self_refine", 1) == 0
+        l1, i1 = eng_bf16.parseq_logits(crops)
+    finally:
+        eng_bf16.lib.ttr_set_tuning(b"self_refine", 1)
+    assert np.isfinite(l1).all()
+    assert np.array_equal(l0, l1) and np.array_equal(i0, i1)
+
+
 def test_token_prologue_in_self_kv_gemm_matches_separate_kernels(eng_bf16):
     """gemm_sk's token prologue (argmax of the previous step's logits + text_embed + pos_queries + norm_c inside the self_kv GEMM)
     vs argmax_kernel + dec_embed_ln_kernel + GEMM: the argmax is exact (first maximal index), the embedding sum is exact, only the

@@ -300,8 +300,95 @@ __global__ __launch_bounds__(384) void dec_self_attn_kernel(const float* __restr
   }
 }
 
+// Refinement pass (mode 1, R = 26 query rows per crop), bf16: ONE workgroup per crop does all 26 rows — the crop's K/V cache
+// (26 x 768, 40 KB) goes to LDS once instead of being pulled through L2 by 26 workgroups (1.3 GB of L2 traffic at 1220 crops,
+// 190 us).  Same operations in the same order as dec_self_attn_kernel, so the result is bit-identical.
+namespace {
+constexpr int SR_KS = 776;                                   // padded K/V row (elements): 1552 B, 4 banks apart from row to row
+constexpr int SR_LDS = 26 * SR_KS * 2 + 26 * 12 * 26 * 4 + 256;   // K/V rows, probabilities, pad flags [32] + tokens [32]
+}
+__global__ __launch_bounds__(384) void dec_self_attn_refine_kernel(const float* __restrict__ q, const bf16* __restrict__ kv, const int* __restrict__ tokens,
+                                                                   bf16* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sr_smem[];
+  bf16* const skv = reinterpret_cast<bf16*>(sr_smem);                                   // [26][SR_KS]
+  float* const sp = reinterpret_cast<float*>(sr_smem + 26 * SR_KS * 2);                 // [26 qi][12 h][26 j]
+  int* const pad = reinterpret_cast<int*>(sr_smem + 26 * SR_KS * 2 + 26 * 12 * 26 * 4); // key j hidden by an EOS at or before it
+  const int n = blockIdx.x, t = threadIdx.x;
+  const bf16* kvn = kv + (int64_t)n * 26 * 768;
+  for (int v = t; v < 26 * 96; v += 384) {
+    const int r = v / 96, c = v - r * 96;
+    *reinterpret_cast<bf16x8*>(skv + r * SR_KS + c * 8) = *reinterpret_cast<const bf16x8*>(kvn + r * 768 + c * 8);
+  }
+  if (t < 26) pad[32 + t] = tokens[n * 26 + t];              // one load per thread (a serial loop of dependent global loads costs ~20 us)
+  __syncthreads();
+  if (t < 26) {
+    int hid = 0;
+    for (int j = 0; j <= t; ++j) if (pad[32 + j] == 0) hid = 1;
+    pad[t] = hid;
+  }
+  __syncthreads();
+  if (t < 312) {                                             // thread = one (query row, head): its 26 scores stay in registers
+    const int qi = t / 12, h = t - qi * 12;
+    float4 qv[8];
+    const float4* q4 = reinterpret_cast<const float4*>(q + qi * 384 + h * 32);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) qv[c] = q4[c];
+    float sc[26], mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 26; ++j) {
+      float s = -INFINITY;
+      if (!pad[j] && j != qi + 1) {                          // cloze mask + key padding (PARSeq.forward)
+        s = 0.f;
+        const bf16x8* k8 = reinterpret_cast<const bf16x8*>(skv + j * SR_KS + h * 32);   // 16-byte aligned: rows are 1552 B apart
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                        // d = 0 .. 31 in order, as the per-row kernel
+          const bf16x8 kk = k8[c];
+          const float4 qa = qv[2 * c], qb = qv[2 * c + 1];
+          s += qa.x * (float)kk[0]; s += qa.y * (float)kk[1]; s += qa.z * (float)kk[2]; s += qa.w * (float)kk[3];
+          s += qb.x * (float)kk[4]; s += qb.y * (float)kk[5]; s += qb.z * (float)kk[6]; s += qb.w * (float)kk[7];
+        }
+        s *= 0.17677669529663687f;  // 1/sqrt(32)
+      }
+      sc[j] = s;
+      mx = fmaxf(mx, s);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 26; ++j) { const float e = sc[j] == -INFINITY ? 0.f : __expf(sc[j] - mx); sc[j] = e; sum += e; }
+    const float inv = 1.0f / sum;
+    float* row = sp + t * 26;                                // (qi, h) = (t / 12, t % 12)
+#pragma unroll
+    for (int j = 0; j < 26; ++j) row[j] = sc[j] * inv;
+  }
+  __syncthreads();
+  {
+    const int h = t >> 5;
+    float vj[26];                                            // this thread's V column, once
+#pragma unroll
+    for (int j = 0; j < 26; ++j) vj[j] = (float)skv[j * SR_KS + 384 + t];
+    for (int qi = 0; qi < 26; ++qi) {
+      const float2* row = reinterpret_cast<const float2*>(sp + (qi * 12 + h) * 26);   // 104-byte rows: 8-byte aligned
+      float acc = 0.f;
+#pragma unroll
+      for (int j2 = 0; j2 < 13; ++j2) { const float2 p2 = row[j2]; acc += p2.x * vj[2 * j2]; acc += p2.y * vj[2 * j2 + 1]; }
+      out[((int64_t)n * 26 + qi) * 384 + t] = (bf16)acc;
+    }
+  }
+}
+static int g_self_refine = 1;
+void set_dec_self_refine(int v) { g_self_refine = v; }
+
 void launch_dec_self_attn(Precision prec, const float* q, const void* kvcache, const int* tokens, void* out, int N, int R, int qi0, int mode, hipStream_t s) {
   if (N <= 0) return;
+  if (prec == kBF16 && mode == 1 && R == 26 && g_self_refine) {
+    static bool once = false;
+    if (!once) {
+      TTR_HIP_CHECK(hipFuncSetAttribute((const void*)dec_self_attn_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS));
+      once = true;
+    }
+    hipLaunchKernelGGL(dec_self_attn_refine_kernel, dim3(N), dim3(384), SR_LDS, s, q, (const bf16*)kvcache, tokens, (bf16*)out);
+    return;
+  }
   dim3 grid(N * R);
   if (prec == kBF16) hipLaunchKernelGGL(dec_self_attn_kernel<bf16>, grid, dim3(384), 0, s, q, (const bf16*)kvcache, tokens, (bf16*)out, R, qi0, mode);
   else hipLaunchKernelGGL(dec_self_attn_kernel<float>, grid, dim3(384), 0, s, q, (const float*)kvcache, tokens, (float*)out, R, qi0, mode);
