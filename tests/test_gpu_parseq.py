@@ -127,6 +127,31 @@ def test_refinement_self_attention_per_crop_kernel_is_bit_identical(eng_bf16):
     assert np.array_equal(l0, l1) and np.array_equal(i0, i1)
 
 
+@pytest.mark.parametrize("n", [45, 700])
+def test_refinement_block_through_fused_kernel_matches_separate_kernels(eng_bf16, n):
+    """Refinement pass: cross_out + residual + norm2 + linear1 + GELU + linear2 + residual + final norm through mlp_fused.hip (the
+    encoder block kernel with the decoder's weights; 26 n rows, a ragged last panel) against the separate GEMM / LayerNorm
+    kernels.  The AR pass is untouched, so both runs refine the same token sequences: same rounding points, fp32 summation order
+    differs.  700 crops = above the row count from which the engine picks the fused kernel by itself."""
+    rng = np.random.default_rng(16)
+    crops = rng.integers(0, 256, (n, 32, 128, 3), dtype=np.uint8)
+    try:
+        assert eng_bf16.lib.ttr_set_tuning(b"dec_mlp_fused", 0) == 0
+        l0, a0, i0 = eng_bf16.parseq_logits(crops, want_ar=True)
+        assert eng_bf16.lib.ttr_set_tuning(b"dec_mlp_fused", 1) == 0
+        assert eng_bf16.lib.ttr_set_tuning(b"dec_mlp_min_rows", 1) == 0
+        l1, a1, i1 = eng_bf16.parseq_logits(crops, want_ar=True)
+    finally:
+        eng_bf16.lib.ttr_set_tuning(b"dec_mlp_fused", 1)
+        eng_bf16.lib.ttr_set_tuning(b"dec_mlp_min_rows", 16384)
+    assert np.isfinite(l1).all()
+    assert np.array_equal(a0, a1)                                      # the AR pass does not use the fused block
+    d = np.abs(l1 - l0)
+    print(f"refinement block fused vs separate ({n} crops): median |dlogit| {np.median(d):.4f}, max {d.max():.3f}, logit sigma {l0.std():.2f}")
+    assert np.median(d) < 0.01 and d.max() < 0.1                       # measured: median 0, max 0.02 at logit sigma 6.5
+    assert (i0 == i1).mean() > 0.97
+
+
 def test_token_prologue_in_self_kv_gemm_matches_separate_kernels(eng_bf16):
     """gemm_sk's token prologue (argmax of the previous step's logits + text_embed + pos_queries + norm_c inside the self_kv GEMM)
     vs argmax_kernel + dec_embed_ln_kernel + GEMM: the argmax is exact (first maximal index), the embedding sum is exact, only the

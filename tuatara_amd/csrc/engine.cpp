@@ -48,6 +48,8 @@ static int g_qkv_attn = 1;           // bf16 encoder: qkv projection + self-atte
 static int g_qkv_attn_min = 160;
 static int g_mlp_proj = 1;           // ... with the attention output projection in front of it in the same launch
 static int g_mlp_min_rows = 49152;   // = 384 crops
+static int g_dec_mlp_fused = 1;    // bf16 refinement pass: cross_out + norm2 + linear1 + GELU + linear2 + final norm through mlp_fused.hip
+static int g_dec_mlp_min_rows = 16384;
 static int g_mlp_fused = 1;        // bf16 encoder: norm2 + fc1 + GELU + fc2 + residual (+ the next LayerNorm) as one kernel (mlp_fused.hip)
 static int g_tok_fuse = 1;         // bf16 AR steps: argmax of the previous step + token embedding + norm_c inside the self_kv skinny GEMM
 static int g_ln_fuse = 1;          // bf16 decoder steps: LayerNorm computed inside the skinny GEMM's loader (gemm_sk ln_in)
@@ -301,6 +303,7 @@ struct Engine {
   std::map<std::string, DevBuf> pqf;              // f32 vectors (LayerNorm params, pos embed, ...)
   DevBuf fc1_packed[12];                          // bf16 engines: encoder fc1 / fc2 / attn.proj weights as mlp_fused.hip's LDS images
   DevBuf proj_packed[12];                         // bf16 engines: encoder attn.proj weights k-step-major [12][384][32] (mlp_fused.hip, PROJ)
+  DevBuf dec_ffn1_packed, dec_ffn2_packed, dec_co_packed;   // bf16 engines: decoder linear1 / linear2 / cross_attn.out_proj as mlp_fused images (refinement pass)
   DevBuf fc2_packed[12];                          // bf16 engines: encoder fc2 weights chunk-major [48][384][32] for mlp_fused.hip
   DevBuf qself;                                   // f32 [26][384]
 
@@ -470,6 +473,15 @@ struct Engine {
     lin("cross_out", d + "cross_attn.out_proj.weight", d + "cross_attn.out_proj.bias", E, E);
     lin("ffn1", d + "linear1.weight", d + "linear1.bias", 4 * E, E);
     lin("ffn2", d + "linear2.weight", d + "linear2.bias", E, 4 * E);
+    if (prec == kBF16) {   // the refinement pass runs cross_out + norm2 + FFN + final norm through mlp_fused.hip
+      std::vector<uint16_t> h((size_t)E * 4 * E), hp((size_t)E * E);
+      pack_mlp_w1(wf.get(d + "linear1.weight", (size_t)4 * E * E).data.data(), h.data());
+      dec_ffn1_packed.ensure(h.size() * 2); TTR_HIP_CHECK(hipMemcpy(dec_ffn1_packed.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+      pack_mlp_w2(wf.get(d + "linear2.weight", (size_t)E * 4 * E).data.data(), 4 * E, h.data());
+      dec_ffn2_packed.ensure(h.size() * 2); TTR_HIP_CHECK(hipMemcpy(dec_ffn2_packed.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+      pack_mlp_w2(wf.get(d + "cross_attn.out_proj.weight", (size_t)E * E).data.data(), E, hp.data());
+      dec_co_packed.ensure(hp.size() * 2); TTR_HIP_CHECK(hipMemcpy(dec_co_packed.p, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
+    }
     for (const char* n : {"norm1", "norm2", "norm_q", "norm_c"}) { vec(d + n + ".weight", E); vec(d + n + ".bias", E); }
     vec("decoder.norm.weight", E); vec("decoder.norm.bias", E);
     lin("head", "head.weight", "head.bias", 95, E);
@@ -688,6 +700,20 @@ struct Engine {
     gemm(pq.at("self_out"), sa, rows, nullptr, 0, kActNone, tgt, 384, resid_pos, 384, resid_mod);      // tgt = query + self_attn
     ln_gemm(tgt, d + "norm1", 1e-5f, t384, pq.at("cross_q"), rows, t384b, 384, kActNone);
     launch_dec_cross_attn(prec, t384b, kvmem, t384, N, R, stream);
+    if (R > 1 && prec == kBF16 && gemm_config() >= 0 && g_dec_mlp_fused && rows >= g_dec_mlp_min_rows) {
+      // refinement pass (26 rows per crop): the block behind the cross-attention is an encoder block's second half with other weights —
+      // out projection + residual, norm2, linear1, GELU, linear2, residual, and the final norm as the "next LayerNorm" — one launch
+      MlpParams q{};
+      q.x = tgt; q.x_out = tgt; q.M = rows;
+      q.ln_g = pqf.at(d + "norm2.weight").as<float>(); q.ln_b = pqf.at(d + "norm2.bias").as<float>(); q.ln_eps = 1e-5f;
+      q.w1p = dec_ffn1_packed.as<bf16>(); q.b1 = pq.at("ffn1").b.as<float>();
+      q.w2p = dec_ffn2_packed.as<bf16>(); q.b2 = pq.at("ffn2").b.as<float>();
+      q.nln_g = pqf.at("decoder.norm.weight").as<float>(); q.nln_b = pqf.at("decoder.norm.bias").as<float>(); q.nln_eps = 1e-5f; q.nln_out = (bf16*)t384b;
+      q.att = (const bf16*)t384; q.wpp = dec_co_packed.as<bf16>(); q.bp = pq.at("cross_out").b.as<float>();
+      timed(2.0 * rows * 384 * 1536 * 2 + 2.0 * rows * 384 * 384, [&] { launch_mlp_fused(q, stream); });
+      gemm(pq.at("head"), t384b, rows, nullptr, 0, kActNone, logits_out, logits_ld);
+      return;
+    }
     gemm(pq.at("cross_out"), t384, rows, nullptr, 0, kActNone, tgt, 384, tgt, 384, 0);                 // tgt += cross_attn
     ln_gemm(tgt, d + "norm2", 1e-5f, t384, pq.at("ffn1"), rows, t1536, 1536, kActGelu);
     gemm(pq.at("ffn2"), t1536, rows, nullptr, 0, kActNone, tgt, 384, tgt, 384, 0);                     // tgt += ffn
@@ -1471,6 +1497,8 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "tok_fuse") g_tok_fuse = value;
   else if (k == "mlp_fused") g_mlp_fused = value;   // 0 off, 1 from mlp_min_rows rows on, 2 always
   else if (k == "mlp_min_rows") g_mlp_min_rows = value;
+  else if (k == "dec_mlp_fused") g_dec_mlp_fused = value;
+  else if (k == "dec_mlp_min_rows") g_dec_mlp_min_rows = value;
   else if (k == "mlp_proj") g_mlp_proj = value;
   else if (k == "mlp_store_nt") set_mlp_store_nt(value);
   else if (k == "attn_impl") set_attn_impl(value);
