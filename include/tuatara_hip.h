@@ -123,7 +123,7 @@ void ttr_set_decoder_mode(int mode);
  * encoder group, 0 = all at once), "sk_max_rows" / "ws_min_rows" (row counts up to / from which linears use the skinny / the
  * weight-stationary GEMM), "mlp_fused" (0 off, 1 = from "mlp_min_rows" rows on (default), 2 = always), "ln_fuse" (decoder
  * LayerNorms inside the skinny GEMM), "tok_fuse" (AR steps: argmax + token embedding + norm_c inside the self_kv skinny GEMM), "self_refine" (refinement-pass
- * self-attention as one workgroup per crop), "dec_mlp_fused" / "dec_mlp_min_rows" (refinement pass: cross_out + norm2 + FFN + final norm through the
+ * self-attention as one workgroup per crop), "cross_mfma" (refinement-pass cross-attention on the matrix cores), "dec_mlp_fused" / "dec_mlp_min_rows" (refinement pass: cross_out + norm2 + FFN + final norm through the
  * fused block kernel from that many rows on), "fuse_first", "ws_lean", "store_policy" (0 default, 1 streaming, 2 system-scope streaming
  * output stores), "g2_x_ring3", "c3_*" (conv3p variants).  Diagnostics: "dec_stamps" (1 fused decoder, 2 gemm_ws, 3 mlp_fused
  * phase stamps, read back with ttr_dbg_dec_stamps), "dbg_bf16_out", "ws_dbg_flags".

@@ -152,6 +152,28 @@ def test_refinement_block_through_fused_kernel_matches_separate_kernels(eng_bf16
     assert (i0 == i1).mean() > 0.97
 
 
+@pytest.mark.parametrize("n", [45, 3])
+def test_refinement_cross_attention_on_matrix_cores_matches_per_row_kernel(eng_bf16, n):
+    """dec_cross_attn_mfma_kernel (attn_dec2.hip: one wave per crop and head pair, S^T = K Q^T on the matrix cores, P rounded to bf16
+    as in the encoder attention) against dec_cross_attn_rows_kernel (one workgroup per query row, P in fp32).  The AR pass is
+    untouched, so both runs refine the same token sequences."""
+    rng = np.random.default_rng(17)
+    crops = rng.integers(0, 256, (n, 32, 128, 3), dtype=np.uint8)
+    try:
+        assert eng_bf16.lib.ttr_set_tuning(b"cross_mfma", 0) == 0
+        l0, a0, i0 = eng_bf16.parseq_logits(crops, want_ar=True)
+        assert eng_bf16.lib.ttr_set_tuning(b"cross_mfma", 1) == 0
+        l1, a1, i1 = eng_bf16.parseq_logits(crops, want_ar=True)
+    finally:
+        eng_bf16.lib.ttr_set_tuning(b"cross_mfma", 1)
+    assert np.isfinite(l1).all()
+    assert np.array_equal(a0, a1)
+    d = np.abs(l1 - l0)
+    print(f"refinement cross-attention MFMA vs per-row ({n} crops): median |dlogit| {np.median(d):.4f}, max {d.max():.3f}, logit sigma {l0.std():.2f}")
+    assert np.median(d) < 0.03 and d.max() < 0.4
+    assert (i0 == i1).mean() > 0.97
+
+
 def test_token_prologue_in_self_kv_gemm_matches_separate_kernels(eng_bf16):
     """gemm_sk's token prologue (argmax of the previous step's logits + text_embed + pos_queries + norm_c inside the self_kv GEMM)
     vs argmax_kernel + dec_embed_ln_kernel + GEMM: the argmax is exact (first maximal index), the embedding sum is exact, only the

@@ -1494,6 +1494,7 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "fuse_first") g_fuse_first = value;
   else if (k == "ln_fuse") g_ln_fuse = value;
   else if (k == "self_refine") set_dec_self_refine(value);
+  else if (k == "cross_mfma") set_dec_cross_mfma(value);
   else if (k == "tok_fuse") g_tok_fuse = value;
   else if (k == "mlp_fused") g_mlp_fused = value;   // 0 off, 1 from mlp_min_rows rows on, 2 always
   else if (k == "mlp_min_rows") g_mlp_min_rows = value;

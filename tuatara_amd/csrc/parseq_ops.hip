@@ -517,8 +517,12 @@ __global__ __launch_bounds__(256) void dec_cross_attn_rows_kernel(const bf16* __
   }
 }
 
+static int g_cross_mfma = 1;
+void set_dec_cross_mfma(int v) { g_cross_mfma = v; }
+
 void launch_dec_cross_attn(Precision prec, const void* q, const void* kvmem, void* out, int N, int R, hipStream_t s) {
   if (N <= 0) return;
+  if (prec == kBF16 && R == 26 && g_cross_mfma) return launch_dec_cross_attn_mfma((const bf16*)q, (const bf16*)kvmem, (bf16*)out, N, s);   // refinement pass (attn_dec2.hip)
   dim3 grid(N * R);
   if (prec == kBF16) hipLaunchKernelGGL(dec_cross_attn_rows_kernel, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)kvmem, (bf16*)out, R);
   else hipLaunchKernelGGL(dec_cross_attn_kernel<float>, grid, dim3(384), 0, s, (const float*)q, (const float*)kvmem, (float*)out, R);
