@@ -19,11 +19,11 @@ namespace ttr {
 namespace {
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-constexpr int S = 128, EQ = 384, EKV = 768, RQ = 26;
+constexpr int S = 128, EQ = 384, EKV = 768;
 constexpr int QT = 32 * 128, KT = S * 128;   // Q tile 4 KiB (32 rows), K / V tiles 16 KiB
 }  // namespace
 
-__global__ __launch_bounds__(64) void dec_cross_attn_mfma_kernel(const bf16* __restrict__ qin, const bf16* __restrict__ kvmem, bf16* __restrict__ out, int N) {
+__global__ __launch_bounds__(64) void dec_cross_attn_mfma_kernel(const bf16* __restrict__ qin, const bf16* __restrict__ kvmem, bf16* __restrict__ out, int N, int RQ) {   // RQ <= 32 query rows per crop
   __shared__ __attribute__((aligned(1024))) unsigned char smem[QT + 2 * KT];
   unsigned char* const sQ = smem;
   unsigned char* const sK = smem + QT;
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(64) void dec_cross_attn_mfma_kernel(const bf16* __r
     const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(qb), 0, (int)((RQ - 1) * EQ * 2 + 128), 0x00020000);
     const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(kb), 0, (int)((S - 1) * EKV * 2 + (EQ + 64) * 2), 0x00020000);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {                               // query rows 26..31: past the descriptor's end -> zeros
+    for (int p = 0; p < 4; ++p) {                               // query rows RQ..31: out of range -> zeros
       const int R = p * 8 + (lane >> 3), c = lane & 7, cs = c ^ ((R >> 1) & 7);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_ptr)(sQ + p * 1024), 16, R < RQ ? (unsigned)((R * EQ + cs * 8) * 2) : 0x80000000u, 0, 0, 0);
     }
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64) void dec_cross_attn_mfma_kernel(const bf16* __r
 #undef ATT_TR
 
   // ---- out: lane holds d = 16 dt + 4 g + r of query 16 qt + q; staged through the Q rows in LDS (its fragments are consumed),
-  // then whole 128-byte rows (the pair's 64 columns), 16 bytes per lane, rows < 26 only
+  // then whole 128-byte rows (the pair's 64 columns), 16 bytes per lane, rows < RQ only
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt)
@@ -151,10 +151,11 @@ __global__ __launch_bounds__(64) void dec_cross_attn_mfma_kernel(const bf16* __r
   }
 }
 
-void launch_dec_cross_attn_mfma(const bf16* q, const bf16* kvmem, bf16* out, int N, hipStream_t s) {
+void launch_dec_cross_attn_mfma(const bf16* q, const bf16* kvmem, bf16* out, int N, int R, hipStream_t s) {
   if (N <= 0) return;
+  if (R < 1 || R > 32) throw std::runtime_error("dec_cross_attn_mfma: 1..32 query rows per crop");
   if (((uintptr_t)q | (uintptr_t)kvmem | (uintptr_t)out) & 15) throw std::runtime_error("dec_cross_attn_mfma: operands must be 16-byte aligned");
-  hipLaunchKernelGGL(dec_cross_attn_mfma_kernel, dim3(N * 6), dim3(64), 0, s, q, kvmem, out, N);
+  hipLaunchKernelGGL(dec_cross_attn_mfma_kernel, dim3(N * 6), dim3(64), 0, s, q, kvmem, out, N, R);
 }
 
 }  // namespace ttr
