@@ -34,31 +34,46 @@ def test_funsd_f32_identical_to_oracle(eng_f32, oracle_models, funsd):
     assert sum(g["text"] == r["text"] for g, r in zip(got, G["funsd"])) >= len(got) - 2
 
 
-def test_funsd_bf16_boxes_iou_and_strings(eng_bf16, oracle_models, funsd):
-    """bf16 throughput mode on synthetic weights: bf16 rounding moves the heat map by ~1e-2, which can
-    push a borderline component across a threshold or shift a blob outline by a pixel.  Required:
-    at least 85 % of the oracle boxes have a bf16 box with IoU >= 0.99 and at most 3 boxes change
-    substantially (a borderline component merged, split or dropped)."""
-    from oracle import pipeline
+def test_funsd_bf16_margin_aware_equivalence(eng_bf16, oracle_models, funsd):
+    """Config 4 in the bf16 throughput mode.  bf16 rounding moves the heat map by ~1e-2 at a few pixels, so a pixel whose fp32
+    value sits on a threshold (tuatara.cpp:131-132) can flip and move a blob outline by one pixel.  Required:
+      * the heat map stays within a bounded error of the oracle's and the flipped pixels are a small share of the set ones;
+      * the engine's boxes are exactly the reference post-processing (oracle/post.c) of the engine's own heat map;
+      * >= 80 % of the oracle's boxes are reproduced with IoU >= 0.99, at most 3 change substantially;
+      * strings: the margin rule of tests/parity_rules.py on every crop of the oracle, and the end-to-end text of every box
+        with the oracle's coordinates equals the engine's decode of that crop."""
+    import torch
+    from oracle import pipeline, post
+    from tests import parity_rules as R
+    from tuatara_amd.engine import decode_ids
     got = eng_bf16.image_to_data(funsd)
     d = pipeline.image_to_data(oracle_models[0], oracle_models[1], funsd, debug=True)
     ref = d["result"]
+    heat = eng_bf16.craft_heatmap(d["canvas"])
+    flips, err, nset = R.heatmap_flips(d["heat"], heat)
+    print(f"bf16 FUNSD heat map: max |d| {np.abs(heat - d['heat']).max():.4f}, normalised {err:.4f}; {int(flips.sum())} threshold flips of {nset} set pixels")
+    assert np.abs(heat - d["heat"]).max() < 0.08 and flips.sum() < 0.02 * nset
+    det, _, _ = post.get_detected_boxes(heat[..., 0], heat[..., 1])
+    boxes = post.adjust_result_coordinates(det, 1.0 / d["ratio"], 1.0 / d["ratio"])
+    assert [g["bbox"] for g in got] == [post.tesseract_bbox(b) for b in boxes]       # reference post-processing of the bf16 heat map
     assert abs(len(got) - len(ref)) <= 3
-    best = [max(_iou(r["bbox"], g["bbox"]) for g in got) for r in ref]
+    best = [max(R.box_iou(r["bbox"], g["bbox"]) for g in got) for r in ref]
     exact = np.array(best) >= 0.99
     print(f"bf16 FUNSD: {len(got)} boxes vs {len(ref)}; {exact.sum()} oracle boxes matched at IoU>=0.99, min best IoU {min(best):.3f}")
-    assert exact.mean() >= 0.85
-    # boxes that moved: a threshold crossing merged/split/dropped a borderline component
-    moved = [(k, round(v, 3)) for k, v in enumerate(best) if v < 0.99]
-    print("bf16 FUNSD: oracle boxes without an IoU>=0.99 partner:", moved)
-    assert sum(v < 0.5 for v in best) <= 3
-    srt = np.sort(d["logits"], -1)
-    margin = (srt[..., -1] - srt[..., -2]).min(1)
+    assert exact.mean() >= 0.8 and sum(v < 0.5 for v in best) <= 3
+    with torch.no_grad():
+        x = torch.from_numpy(d["crops"]).permute(0, 3, 1, 2).float().div(255.0)
+        lo, ao = oracle_models[1](x, return_ar=True)
+    lb, ab, idb = eng_bf16.parseq_logits(d["crops"], want_ar=True)
+    st = R.parseq_margin_rule(lo.numpy(), ao.numpy(), lb, ab, min_same=0.9, label="bf16 FUNSD crops vs oracle")
     texts = {tuple(g["bbox"]): g["text"] for g in got}
-    pairs = [(texts[tuple(r["bbox"])], r["text"], m) for r, m in zip(ref, margin) if tuple(r["bbox"]) in texts]
-    same = np.array([a == b for a, b, _ in pairs])
-    print(f"bf16 FUNSD: {same.sum()}/{len(same)} strings identical on boxes with identical coordinates")
-    assert same.mean() > 0.5
+    n_eq = n_pair = 0
+    for k, r in enumerate(ref):
+        if tuple(r["bbox"]) in texts and st["same_mask"][k]:
+            n_pair += 1
+            n_eq += texts[tuple(r["bbox"])] == r["text"] == decode_ids(idb[k])
+    print(f"bf16 FUNSD: {n_eq}/{n_pair} strings identical on boxes with the oracle's coordinates whose crop follows the oracle's path")
+    assert n_pair >= 0.6 * len(ref) and n_eq == n_pair
 
 
 def test_pytuatara_run_ocr_counterpart(weights, eng_f32, funsd, monkeypatch):

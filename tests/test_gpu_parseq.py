@@ -35,12 +35,11 @@ def test_parseq_f32_batch_invariance(eng_f32):
     assert np.abs(a - b).max() < 1e-4
 
 
-def test_parseq_bf16_close_and_margin_exact(eng_bf16, oracle_models):
-    """bf16 throughput mode.  Greedy AR decoding is chaotic under near-ties (random weights have many),
-    so: (1) on crops whose AR token path equals the oracle's, the refined logits must be close;
-    (2) a crop may only diverge at a position where the oracle's own top-2 margin is small."""
+def test_parseq_bf16_margin_rule_small_batch(eng_bf16, oracle_models):
+    """bf16 throughput mode, small-batch kernels (48 crops): the margin rule of tests/parity_rules.py against the CPU oracle.
+    (The benchmark's batch sizes: tests/test_gpu_bf16_parity.py.)"""
     import torch
-    from oracle import post
+    from tests import parity_rules as R
     _, parseq = oracle_models
     crops = _crops(48, seed=1)
     with torch.no_grad():
@@ -48,23 +47,8 @@ def test_parseq_bf16_close_and_margin_exact(eng_bf16, oracle_models):
         ref, ref_ar = parseq(x, return_ar=True)
     ref, ref_ar = ref.numpy(), ref_ar.numpy()
     got, got_ar, ids = eng_bf16.parseq_logits(crops, want_ar=True)
-    ar_ids, ar_ref = got_ar.argmax(-1)[:, :25], ref_ar.argmax(-1)[:, :25]
-    same_path = (ar_ids == ar_ref).all(1)
-    err = np.abs(got - ref)
-    print(f"bf16 parseq: {same_path.sum()}/{len(crops)} crops follow the oracle's AR path; on those max|dlogit|="
-          f"{err[same_path].max():.4f} mean={err[same_path].mean():.5f} (logit std {ref.std():.2f})")
-    assert same_path.mean() >= 0.25
-    assert err[same_path].max() < 1.0 and err[same_path].mean() < 0.15
-    srt = np.sort(ref_ar, -1)
-    ar_margin = srt[..., -1] - srt[..., -2]
-    for n in np.nonzero(~same_path)[0]:
-        first = int(np.nonzero(ar_ids[n] != ar_ref[n])[0][0])
-        assert ar_margin[n, first] < 1.0, (n, first, ar_margin[n, first])   # only near-ties may flip
-    _, ids_ref = post.decode_logits(ref)
-    srt = np.sort(ref, -1)
-    margin = srt[..., -1] - srt[..., -2]
-    confident = same_path[:, None] & (margin > 1.0)
-    assert (ids == ids_ref)[confident].all()
+    st = R.parseq_margin_rule(ref, ref_ar, got, got_ar, min_same=0.85, label="bf16 PARSeq, 48 crops vs oracle")
+    assert st["mean_dlogit"] < 0.5
 
 
 @pytest.mark.parametrize("G", [4, 8, 16])

@@ -1,0 +1,123 @@
+"""Probe the designed PARSeq read-out (tuatara_amd/weights.py: _wire_parseq_dfa) on the CPU oracle: LayerNorm sigmas of the
+streams the designed rows read (-> weights.NOM), the reserved channels stage by stage, and how often bf16 noise
+(oracle/bf16sim.py) changes a decoded string.  Development tool (uses the oracle): python tools/calibrate_parseq.py [n_crops]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import bf16sim, pipeline, post  # noqa: E402
+from tuatara_amd import weights as W  # noqa: E402
+
+
+def probe(parseq, x):
+    """Returns a dict of reserved-channel tensors captured by forward hooks."""
+    cap = {}
+    hooks = []
+
+    def grab(name, mod, inp=False):
+        def fn(m, i, o):
+            t = i[0] if inp else o
+            if isinstance(t, tuple):
+                t = t[0]
+            cap.setdefault(name, []).append(t.detach().clone())
+        hooks.append(mod.register_forward_hook(fn))
+
+    enc = parseq.encoder
+    grab("patch", enc.patch_embed)
+    for i in range(4):
+        grab(f"blk{i}", enc.blocks[i])
+        grab(f"blk{i}.norm1", enc.blocks[i].norm1)
+        grab(f"blk{i}.norm2", enc.blocks[i].norm2)
+    grab("memory", enc.norm)
+    L = parseq.decoder.layers[0]
+    for n in ("norm_q", "norm_c", "norm1", "norm2"):
+        grab("dec." + n, getattr(L, n))
+        grab("dec." + n + ".in", getattr(L, n), inp=True)
+    grab("dec.final.in", parseq.decoder.norm, inp=True)
+    grab("dec.final", parseq.decoder.norm)
+    with torch.no_grad():
+        out = parseq(x, return_ar=True)
+    for h in hooks:
+        h.remove()
+    return cap, out
+
+
+def expected_strings(parseq, x):
+    """The DFA's prediction from the content bits read off the encoder's memory."""
+    first, nxt = W.dfa_tables(0)
+    with torch.no_grad():
+        mem = parseq.encode(x)
+    bits = (mem[:, :, W._B3:W._B3 + 8].mean(1) > mem[:, :, W._ZERO:W._ZERO + 1].mean(1)).numpy()
+    ids = []
+    for b in bits:
+        v = sum(int(b[j]) << j for j in range(6))
+        tab = int(b[6]) + 2 * int(b[7])
+        seq = [int(first[v])]
+        while len(seq) < 26 and seq[-1] != 0:
+            seq.append(int(nxt[tab, seq[-1]]))
+        seq += [0] * (26 - len(seq))
+        ids.append(seq)
+    return np.array(ids), bits
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    st = W.synth_parseq(0)
+    _, parseq = pipeline.load_models(W.synth_craft(0, True), st)
+    crops = np.random.default_rng(1).integers(0, 256, (n, 32, 128, 3), dtype=np.uint8)
+    x = torch.from_numpy(crops).permute(0, 3, 1, 2).float().div(255.0)
+    cap, (ref, ref_ar) = probe(parseq, x)
+
+    def sig(t):
+        return t.float().std(-1, unbiased=False)
+    print("sigma patch+pos (blk0.norm1 in):", float(sig(cap["patch"][0] + parseq.encoder.pos_embed).mean()))
+    for i in range(4):
+        print(f"sigma after block {i}:", float(sig(cap[f"blk{i}"][0]).mean()))
+    for nme in ("norm_q", "norm_c", "norm1", "norm2"):
+        s = torch.cat([sig(t).flatten() for t in cap["dec." + nme + ".in"]])
+        print(f"sigma dec.{nme} input: mean {float(s.mean()):.3f} min {float(s.min()):.3f} max {float(s.max()):.3f}")
+    s = torch.cat([sig(t).flatten() for t in cap["dec.final.in"]])
+    print(f"sigma dec.final input: mean {float(s.mean()):.3f} min {float(s.min()):.3f} max {float(s.max()):.3f}")
+    b0 = cap["blk0"][0]
+    print("C1 std", float(b0[..., W._C1].std()), "D_0 (tokens of region 0) std", float(b0[:, 0:2, W._D].std()))
+    b1 = cap["blk1"][0]
+    print("S std over crops", b1[:, 0, W._S:W._S + 8].std(0).numpy().round(4))
+    for i, c in ((1, W._B1), (2, W._B2), (3, W._B3)):
+        t = cap[f"blk{i}"][0][:, 0, c:c + 9]
+        print(f"B{i} token 0, crop 0:", t[0].numpy().round(3))
+    m = cap["memory"][0]
+    print("memory bits crop0 tok0:", (m[0, 0, W._B3:W._B3 + 9] - m[0, 0, W._ZERO]).numpy().round(3))
+    fin = cap["dec.final.in"]
+    print("step-0 query stream: PREV", fin[0][0, 0, W._PREV:W._PREV + 7].numpy().round(3), "PBOS/PREF", fin[0][0, 0, W._PBOS:W._PREF + 1].numpy().round(3))
+    print("   CONT", fin[0][0, 0, W._CONT:W._CONT + 9].numpy().round(3))
+    print("   OUT", fin[0][0, 0, W._OUT:W._OUT + 7].numpy().round(3))
+    print("step-1: PREV", fin[1][0, 0, W._PREV:W._PREV + 7].numpy().round(3), "PBOS/PREF", fin[1][0, 0, W._PBOS:W._PREF + 1].numpy().round(3), "OUT", fin[1][0, 0, W._OUT:W._OUT + 7].numpy().round(3))
+    ref, ref_ar = ref.numpy(), ref_ar.numpy()
+    exp, bits = expected_strings(parseq, x)
+    ids = ref.argmax(-1)
+    upto = np.array([np.argmax(r == 0) + 1 if (r == 0).any() else 26 for r in exp])
+    ok = np.array([np.array_equal(ids[i, :upto[i]], exp[i, :upto[i]]) for i in range(n)])
+    print("oracle ids == DFA prediction (up to EOS):", ok.mean(), " AR ids too:", np.mean([np.array_equal(ref_ar.argmax(-1)[i, :upto[i]], exp[i, :upto[i]]) for i in range(n)]))
+    srt = np.sort(ref, -1)
+    marg = srt[..., -1] - srt[..., -2]
+    mm = np.array([marg[i, :upto[i]].min() for i in range(n)])
+    print("min margin up to EOS per crop: median %.2f  min %.2f; logit std %.2f" % (np.median(mm), mm.min(), ref.std()))
+    strs, _ = post.decode_logits(ref)
+    print("strings:", strs[:12], "distinct:", len(set(strs)), "of", n, " mean len %.1f" % np.mean([len(s) for s in strs]))
+    with torch.no_grad(), bf16sim.bf16_noise():
+        got, got_ar = parseq(x, return_ar=True)
+    got, got_ar = got.numpy(), got_ar.numpy()
+    same = (ref_ar.argmax(-1)[:, :25] == got_ar.argmax(-1)[:, :25]).all(1)
+    s2, _ = post.decode_logits(got)
+    print("bf16 noise model: same AR path %.3f, same strings %.3f, |dlogit| mean %.4f max %.3f" % (
+        same.mean(), np.mean([a == b for a, b in zip(strs, s2)]), np.abs(got - ref).mean(), np.abs(got - ref).max()))
+    bad = [i for i in range(n) if strs[i] != s2[i]]
+    for i in bad[:8]:
+        print("  diff crop", i, repr(strs[i]), repr(s2[i]), "min margin", mm[i])
+
+
+if __name__ == "__main__":
+    main()

@@ -199,12 +199,18 @@ def _wire_ink_pathway(st: State, gain: float = 6.0) -> None:
     st["conv_cls.8.bias"][:] = 1.0
 
 
-def synth_parseq(seed: int = 0, eos_shift: float = 1.7, head_gain: float = 6.0, sharp: float = 3.0) -> State:
+def synth_parseq(seed: int = 0, eos_shift: float = 1.7, head_gain: float = 6.0, sharp: float = 3.0, structured: bool = True) -> State:
     """Seeded PARSeq weights.  1/sqrt(fan_in) linears (O(1) residual updates),
     LayerNorm near identity, q/k projections scaled by ``sharp`` so attention is
-    peaked and the output depends on the image (with diffuse attention a random
-    model decodes the same string for every crop), a head gain so logits have
-    std ~``head_gain`` and an EOS shift so decoded strings have realistic lengths."""
+    peaked, a head gain so logits have std ~``head_gain`` and an EOS shift.
+
+    A purely random model decides every character by the top of 95 Gaussian
+    scores: the top-2 margin is below twice the bf16 error of the whole network
+    at ~7 % of the positions, so greedy decoding forks on more than half of the
+    crops and string equality says little.  ``structured`` (the default) therefore
+    wires a confident, "trained-like" read-out on 64 reserved channels on top of
+    the random model (``_wire_parseq_dfa``) and turns the random head down to a
+    texture of std ~1."""
     rng = np.random.default_rng(seed + 1000)
     st: State = {}
     E = EMBED
@@ -229,9 +235,264 @@ def synth_parseq(seed: int = 0, eos_shift: float = 1.7, head_gain: float = 6.0, 
         if name.endswith("cross_attn.out_proj.weight"):
             v *= np.float32(sharp)
         st[name] = v
-    st["head.weight"] *= np.float32(head_gain)
-    st["head.bias"][0] += np.float32(eos_shift * head_gain)
+    if structured:
+        st["head.weight"] *= np.float32(1.0)          # texture: logit std ~1 under the designed read-out
+        _wire_parseq_dfa(st)
+    else:
+        st["head.weight"] *= np.float32(head_gain)
+        st["head.bias"][0] += np.float32(eos_shift * head_gain)
     return st
+
+
+# ---- the designed PARSeq read-out ---------------------------------------------------------------
+# Reserved model channels (the last 64 of 384).  Random weights neither read nor write them; every
+# LayerNorm is the identity on them (gamma 1, beta 0), so a reserved value v leaves a LayerNorm as
+# (v - mu) / sigma with the token's mu and sigma.  Every designed row reads differences against the
+# ZERO channel (weights sum to zero: mu cancels) and states its thresholds as multiples of a reference
+# channel that went through the same LayerNorms (sigma cancels): the logic is ratio-metric.
+RES0 = 320
+_ZERO, _ONE = 320, 321
+# encoder stream
+_RG, _C1, _D, _S, _B1, _B2, _B3 = 322, 330, 331, 339, 347, 356, 365       # RG/D/S: 8 channels, B*: 8 bits + reference
+# decoder streams: context stream (token + position embeddings) ...
+_POS, _BOSF, _TREF, _TOK = 322, 348, 349, 350                                # POS: 26, TOK: 7
+# ... and query stream
+_PREV, _PBOS, _PREF, _CONT, _CREF, _OUT = 357, 364, 365, 366, 374, 375       # PREV: 7, CONT: 8, OUT: 7
+N_BITS, N_CODE = 8, 7
+A_ONE, A_POS, A_TOK = 2.0, 3.0, 1.0
+DFA_FIRST_BITS = 6                     # content bits 0..5 choose the first character, bits 6..7 the transition table
+
+
+def dfa_tables(seed: int = 0):
+    """The string a crop decodes to under the designed read-out: first[v] (v = content bits 0..5 as an integer) is
+    the first class id, nxt[u][t] the class that follows class t under transition table u (content bits 6..7);
+    class 0 is EOS.  Ids cover the whole 1..94 range, including the reference tokenizer's shifted ids 69..94
+    and its eos_id 88 (tuatara.cpp:31-48)."""
+    rng = np.random.default_rng(seed + 4242)
+    first = rng.permutation(np.arange(1, 95))[:64].astype(np.int64)
+    nxt = np.zeros((4, 95), np.int64)
+    for u in range(4):
+        perm = rng.permutation(np.arange(1, 95))
+        for t in range(1, 95):
+            nxt[u, t] = 0 if (t + 2 * u) % 6 == 0 else perm[t - 1]
+    return first, nxt
+
+
+def _code(c: int) -> np.ndarray:
+    return np.array([1.0 if (c >> k) & 1 else -1.0 for k in range(N_CODE)], np.float32)
+
+
+def _wire_parseq_dfa(st: State, seed: int = 0) -> None:
+    """Hand-wired confident read-out (the PARSeq counterpart of ``_wire_ink_pathway``), every stage through the
+    same kernels as the random part:
+
+    encoder  patch-embed: C1 = left-minus-right contrast of the patch.  block 0 MLP: D_j = C1 gated by the patch's
+             region j (8 regions of 2 patch columns) - GELU(z) - GELU(-z) = z exactly.  block 1 attention,
+             head 5: q = k = 0, uniform pooling over the 128 tokens -> S_j = region sums, at every token.  blocks 1..3
+             MLP: three soft sign stages B = sat(g S) (four GELU units per bit; the reference bit BREF goes through
+             the same units so that later stages know the amplitude).  memory carries 8 bits +-BREF.
+    decoder  self-attention head 11: query i matches context slot i by a one-hot position code and copies the
+             previous token's 7-bit code (PREV), a was-BOS flag and a reference.  cross-attention head 11: uniform
+             pooling of the memory's bits (CONT) and reference.  FFN: exact-match detectors - 64 for the first
+             character (BOS and content bits 0..5), 94 x 4 for the transitions (previous class and bits 6..7) - write
+             the next class's code to OUT; no detector firing means EOS.  head: logit_c = G <code_c, OUT> + texture.
+
+    Near a content-bit tie (|S_j| within a few bf16 errors of 0) the bit is soft, the detectors fire partly and the
+    logit margin shrinks continuously, so a decision that bf16 noise can flip shows a small fp32 margin."""
+    E = EMBED
+    R = slice(RES0, E)
+    first, nxt = dfa_tables(seed)
+
+    def put(w: np.ndarray, row: int, cols: Dict[int, float]) -> None:
+        """w[row, c] = v for the reserved input channels c, and minus their sum on ZERO (mean-free row)."""
+        tot = 0.0
+        for c, v in cols.items():
+            w[row, c] = v
+            tot += v
+        w[row, _ZERO] -= tot
+
+    # ---------------- isolate the reserved channels from the random model
+    st["encoder.patch_embed.proj.weight"][R] = 0.0
+    st["encoder.patch_embed.proj.bias"][R] = 0.0
+    st["encoder.pos_embed"][:, :, R] = 0.0
+    for i in range(ENC_DEPTH):
+        p = f"encoder.blocks.{i}."
+        st[p + "attn.qkv.weight"][:, R] = 0.0
+        st[p + "attn.proj.weight"][R, :] = 0.0
+        st[p + "attn.proj.bias"][R] = 0.0
+        st[p + "mlp.fc1.weight"][:, R] = 0.0
+        st[p + "mlp.fc2.weight"][R, :] = 0.0
+        st[p + "mlp.fc2.bias"][R] = 0.0
+        for n in ("norm1", "norm2"):
+            st[p + n + ".weight"][R] = 1.0
+            st[p + n + ".bias"][R] = 0.0
+    st["encoder.norm.weight"][R] = 1.0
+    st["encoder.norm.bias"][R] = 0.0
+    d = "decoder.layers.0."
+    for a in ("self_attn", "cross_attn"):
+        st[d + a + ".in_proj_weight"][:, R] = 0.0
+        st[d + a + ".out_proj.weight"][R, :] = 0.0
+        st[d + a + ".out_proj.bias"][R] = 0.0
+    st[d + "linear1.weight"][:, R] = 0.0
+    st[d + "linear2.weight"][R, :] = 0.0
+    st[d + "linear2.bias"][R] = 0.0
+    for n in (d + "norm1", d + "norm2", d + "norm_q", d + "norm_c", "decoder.norm"):
+        st[n + ".weight"][R] = 1.0
+        st[n + ".bias"][R] = 0.0
+    st["head.weight"][:, R] = 0.0
+    st["text_embed.embedding.weight"][:, R] = 0.0
+    st["pos_queries"][:, :, R] = 0.0
+
+    # ---------------- encoder
+    w = st["encoder.patch_embed.proj.weight"]                 # [E, 3, 4, 8]
+    w[_C1, :, :, 0:4] = 1.0 / 16.0
+    w[_C1, :, :, 4:8] = -1.0 / 16.0
+    pe = st["encoder.pos_embed"]                               # [1, 128, E], token = py * 16 + px
+    pe[0, :, _ONE] = A_ONE
+    for tok in range(N_PATCH):
+        j = (tok & 15) >> 1
+        pe[0, tok, _RG + j] = A_ONE
+
+    def mlp_units(block: int, n: int):
+        p = f"encoder.blocks.{block}.mlp."
+        st[p + "fc1.weight"][0:n] = 0.0
+        st[p + "fc1.bias"][0:n] = 0.0
+        st[p + "fc2.weight"][:, 0:n] = 0.0
+        return st[p + "fc1.weight"], st[p + "fc1.bias"], st[p + "fc2.weight"]
+
+    # block 0 MLP: D_j = g1 * C1 / sigma where the patch lies in region j (gate: M (RG_j - ONE) = 0 or -M A_ONE / sigma)
+    g1, M = 4.0, 8.0
+    w1, b1, w2 = mlp_units(0, 2 * N_BITS)
+    for j in range(N_BITS):
+        for s, sign in enumerate((1.0, -1.0)):
+            u = 2 * j + s
+            put(w1, u, {_C1: sign * g1, _RG + j: M, _ONE: -M})
+            w2[_D + j, u] = sign
+    # block 1 attention head 5: uniform pooling of D_j over all tokens, S_j written to every token
+    p = "encoder.blocks.1.attn."
+    qkv, qb = st[p + "qkv.weight"], st[p + "qkv.bias"]
+    for part in range(3):
+        qkv[part * E + 320: part * E + 384] = 0.0
+        qb[part * E + 320: part * E + 384] = 0.0
+    pw = st[p + "proj.weight"]
+    pw[:, 320:384] = 0.0
+    for j in range(N_BITS):
+        put(qkv, 2 * E + 320 + j, {_D + j: 1.0})
+        pw[_S + j, 320 + j] = 8.0                              # 16 of the 128 tokens carry region j
+
+    def sat_stage(block: int, src: int, dst: int, gain: float, K: float, first_stage: bool) -> None:
+        """dst_j = w [ (h(z+k) - h(z-k)) - (h(-z+k) - h(-z-k)) ], z = gain * src_j / sigma, k = K * ONE / (A_ONE sigma): a soft sign of
+        amplitude 2 K w / sigma whose knee sits at |src_j| = K / gain whatever the LayerNorm's sigma; bit 8 = the reference."""
+        w1, b1, w2 = mlp_units(block, 4 * (N_BITS + 1))
+        wout = 0.25
+        for j in range(N_BITS + 1):
+            if j < N_BITS:
+                cin, g = src + j, gain
+            else:                                               # reference bit: always saturated to +
+                cin, g = (_ONE, 4.0 * K / A_ONE) if first_stage else (src + N_BITS, gain)
+            for s, (sz, sk, so) in enumerate(((1, 1, 1), (1, -1, -1), (-1, 1, -1), (-1, -1, 1))):
+                u = 4 * j + s
+                cols = {cin: sz * g}
+                cols[_ONE] = cols.get(_ONE, 0.0) + sk * K / A_ONE
+                put(w1, u, cols)
+                w2[dst + j, u] = so * wout
+
+    sat_stage(1, _S, _B1, 32.0, 4.0, True)
+    sat_stage(2, _B1, _B2, 12.0, 4.0, False)
+    sat_stage(3, _B2, _B3, 12.0, 4.0, False)
+
+    # ---------------- decoder: embeddings
+    pq = st["pos_queries"]                                      # [1, 26, E]
+    pq[0, :, _ONE] = A_ONE
+    for i in range(MAX_LEN + 1):
+        pq[0, i, _POS + i] = A_POS
+    te = st["text_embed.embedding.weight"]                      # [97, E], scaled by sqrt(E) at lookup
+    rs = 1.0 / math.sqrt(E)
+    for t in range(N_CLASSES):
+        te[t, _TOK:_TOK + N_CODE] = _code(t) * A_TOK * rs
+        te[t, _TREF] = A_TOK * rs
+    te[95, _BOSF] = A_TOK * rs                                  # [B]
+    te[95, _TREF] = A_TOK * rs
+
+    # self-attention head 11: one-hot position match -> previous token's code
+    H0 = 352
+    w, b = st[d + "self_attn.in_proj_weight"], st[d + "self_attn.in_proj_bias"]
+    for part in range(3):
+        w[part * E + H0: part * E + H0 + 32] = 0.0
+        b[part * E + H0: part * E + H0 + 32] = 0.0
+    s_q, s_k = NOM["self_sq"], NOM["self_sk"]
+    for m in range(MAX_LEN):                                    # query i (>= 1) lights dim i - 1; context slot j (>= 1) carries POS_{j-1}
+        put(w, H0 + m, {_POS + m + 1: s_q})
+        put(w, E + H0 + m, {_POS + m: s_k})
+    put(w, H0 + 26, {_POS + 0: s_q})                            # query 0 <-> the BOS slot
+    put(w, E + H0 + 26, {_BOSF: s_k * A_POS / A_TOK})
+    for k in range(N_CODE):
+        put(w, 2 * E + H0 + k, {_TOK + k: 1.0})
+    put(w, 2 * E + H0 + 7, {_BOSF: 1.0})
+    put(w, 2 * E + H0 + 8, {_TREF: 1.0})
+    ow = st[d + "self_attn.out_proj.weight"]
+    ow[:, H0:H0 + 32] = 0.0
+    for k in range(N_CODE):
+        ow[_PREV + k, H0 + k] = 1.0
+    ow[_PBOS, H0 + 7] = 1.0
+    ow[_PREF, H0 + 8] = 1.0
+
+    # cross-attention head 11: uniform pooling of the memory's bits
+    w, b = st[d + "cross_attn.in_proj_weight"], st[d + "cross_attn.in_proj_bias"]
+    for part in range(3):
+        w[part * E + H0: part * E + H0 + 32] = 0.0
+        b[part * E + H0: part * E + H0 + 32] = 0.0
+    for j in range(N_BITS + 1):
+        put(w, 2 * E + H0 + j, {_B3 + j: 1.0})
+    ow = st[d + "cross_attn.out_proj.weight"]
+    ow[:, H0:H0 + 32] = 0.0
+    for j in range(N_BITS):
+        ow[_CONT + j, H0 + j] = 1.0
+    ow[_CREF, H0 + N_BITS] = 1.0
+
+    # FFN detectors
+    n_units = 64 + 4 * 94
+    l1, lb, l2 = st[d + "linear1.weight"], st[d + "linear1.bias"], st[d + "linear2.weight"]
+    l1[0:n_units] = 0.0
+    lb[0:n_units] = 0.0
+    l2[:, 0:n_units] = 0.0
+    a_c, a_p, Mg, w_o, o = NOM["ffn_ac"], NOM["ffn_ap"], NOM["ffn_gate"], NOM["ffn_wo"], NOM["out_amp"]
+    eos = _code(0)
+    st[d + "linear2.bias"][_OUT:_OUT + N_CODE] = o * eos
+    u = 0
+    for v in range(64):                                         # first character: BOS and content bits 0..5 = v
+        cols = {_CREF: -5.0 * a_c, _PBOS: Mg, _PREF: -Mg}
+        for j in range(DFA_FIRST_BITS):
+            cols[_CONT + j] = a_c if (v >> j) & 1 else -a_c
+        put(l1, u, cols)
+        l2[_OUT:_OUT + N_CODE, u] = w_o * (_code(int(first[v])) - eos)
+        u += 1
+    for tab in range(4):                                        # transitions: previous class t and content bits 6..7 = tab
+        for t in range(1, 95):
+            cols = {_PREF: -6.0 * a_p, _CREF: -2.0 * a_c}
+            for k, ck in enumerate(_code(t)):
+                cols[_PREV + k] = a_p * float(ck)
+            for jj in range(2):
+                cols[_CONT + DFA_FIRST_BITS + jj] = a_c if (tab >> jj) & 1 else -a_c
+            put(l1, u, cols)
+            l2[_OUT:_OUT + N_CODE, u] = w_o * (_code(int(nxt[tab, t])) - eos)
+            u += 1
+    # head: logit_c = G <code_c, OUT> (ZERO column keeps the rows mean-free)
+    hw = st["head.weight"]
+    G = NOM["head_gain"]
+    for c in range(N_CLASSES):
+        put(hw, c, {_OUT + k: G * float(ck) for k, ck in enumerate(_code(c))})
+
+
+# Nominal gains of the designed decoder rows.  They only set how sharp the detectors are (the thresholds are
+# ratio-metric); measured with tools/calibrate_parseq.py on the seed-0 random model (LayerNorm sigmas of the
+# query / context streams) and rounded.
+NOM = {
+    "self_sq": 1.5, "self_sk": 1.5,          # match score (1.5 * 3 / 0.26) (1.5 * 3 / 0.95) / sqrt(32) ~ 14.5
+    "ffn_ac": 56.0, "ffn_ap": 12.0,          # content bit 0.23 / 2.47 and token bit 1.03 / 2.47 -> detector step ~5
+    "ffn_gate": 36.0, "ffn_wo": 0.5, "out_amp": 2.5,
+    "head_gain": 4.0,                        # OUT 2.5 / 2.55 -> +-3.9 per code bit: top-2 margin ~7.8, top logit ~27
+}
 
 
 # ----------------------------------------------------------------------------- export (engine layout)
@@ -334,7 +595,7 @@ def export_parseq(st: State, weights_dir: str) -> str:
 
 def make_synthetic_weights(weights_dir: str, seed: int = 0, structured: bool = True) -> Tuple[State, State]:
     """Write ``craft.ttrw`` + ``parseq.ttrw`` for ``seed`` (idempotent) and return the raw state dicts."""
-    c, p = synth_craft(seed, structured), synth_parseq(seed)
+    c, p = synth_craft(seed, structured), synth_parseq(seed, structured=structured)
     export_craft(c, weights_dir)
     export_parseq(p, weights_dir)
     return c, p
