@@ -254,6 +254,7 @@ RES0 = 320
 _ZERO, _ONE = 320, 321
 # encoder stream
 _RG, _C1, _D, _S, _B1, _B2, _B3 = 322, 330, 331, 339, 347, 356, 365       # RG/D/S: 8 channels, B*: 8 bits + reference
+_DA, _SA = 374, 375                                                          # |contrast| per patch, and its mean over the crop
 # decoder streams: context stream (token + position embeddings) ...
 _POS, _BOSF, _TREF, _TOK = 322, 348, 349, 350                                # POS: 26, TOK: 7
 # ... and query stream
@@ -266,15 +267,18 @@ DFA_FIRST_BITS = 6                     # content bits 0..5 choose the first char
 def dfa_tables(seed: int = 0):
     """The string a crop decodes to under the designed read-out: first[v] (v = content bits 0..5 as an integer) is
     the first class id, nxt[u][t] the class that follows class t under transition table u (content bits 6..7);
-    class 0 is EOS.  Ids cover the whole 1..94 range, including the reference tokenizer's shifted ids 69..94
-    and its eos_id 88 (tuatara.cpp:31-48)."""
+    class 0 is EOS.  Both tables are Gray-like in the content bits - flipping one content bit flips exactly one bit
+    of the 7-bit class code (first[v] = v; nxt[u][t] = base[t] ^ u with base[t] a multiple of 4, or EOS) - so that near a
+    content-bit tie the logits move between two neighbouring classes only, with a gentle slope.  The transition
+    tables reach ids up to 91: the reference tokenizer's shifted ids 69..94 and its eos_id 88 (tuatara.cpp:31-48)
+    all occur in decoded strings."""
     rng = np.random.default_rng(seed + 4242)
-    first = rng.permutation(np.arange(1, 95))[:64].astype(np.int64)
-    nxt = np.zeros((4, 95), np.int64)
-    for u in range(4):
-        perm = rng.permutation(np.arange(1, 95))
-        for t in range(1, 95):
-            nxt[u, t] = 0 if (t + 2 * u) % 6 == 0 else perm[t - 1]
+    first = np.arange(64, dtype=np.int64)
+    base = np.zeros(95, np.int64)
+    for t in range(1, 95):
+        base[t] = 0 if rng.random() < 0.2 else 4 * int(rng.integers(1, 23))        # 4 .. 88
+    nxt = np.stack([np.where(base > 0, base ^ u, 0) for u in range(4)])                # a fifth of the classes end the string
+    nxt[:, 0] = 0                                                                    # EOS stays EOS (no detector: the default)
     return first, nxt
 
 
@@ -289,8 +293,9 @@ def _wire_parseq_dfa(st: State, seed: int = 0) -> None:
     encoder  patch-embed: C1 = left-minus-right contrast of the patch.  block 0 MLP: D_j = C1 gated by the patch's
              region j (8 regions of 2 patch columns) - GELU(z) - GELU(-z) = z exactly.  block 1 attention,
              head 5: q = k = 0, uniform pooling over the 128 tokens -> S_j = region sums, at every token.  blocks 1..3
-             MLP: three soft sign stages B = sat(g S) (four GELU units per bit; the reference bit BREF goes through
-             the same units so that later stages know the amplitude).  memory carries 8 bits +-BREF.
+             MLP: three soft sign stages B = sat(g S) (four GELU units per bit); every knee is a fraction of a reference
+             that scales with the crop's contrast (SA = pooled |C1|, then the previous stage's reference bit), so the
+             soft zone tracks the bf16 noise of the pooled sums whatever the crop.  memory carries 8 bits +-BREF.
     decoder  self-attention head 11: query i matches context slot i by a one-hot position code and copies the
              previous token's 7-bit code (PREV), a was-BOS flag and a reference.  cross-attention head 11: uniform
              pooling of the memory's bits (CONT) and reference.  FFN: exact-match detectors - 64 for the first
@@ -360,15 +365,20 @@ def _wire_parseq_dfa(st: State, seed: int = 0) -> None:
         st[p + "fc2.weight"][:, 0:n] = 0.0
         return st[p + "fc1.weight"], st[p + "fc1.bias"], st[p + "fc2.weight"]
 
-    # block 0 MLP: D_j = g1 * C1 / sigma where the patch lies in region j (gate: M (RG_j - ONE) = 0 or -M A_ONE / sigma)
-    g1, M = 4.0, 8.0
-    w1, b1, w2 = mlp_units(0, 2 * N_BITS)
+    # block 0 MLP: D_j = clip(g1 C1, +-kc) / sigma where the patch lies in region j (gate: M (RG_j - ONE) = 0 or -M A_ONE / sigma),
+    # DA = |D_j|.  clip(z) = (h(z) - h(z-k)) - (h(-z) - h(-z-k)), |clip(z)| = the same four units with a + : exact for GELU's h up to
+    # its rounding at 0.  The clip (at |C1| = 1; a random-noise crop has sigma 0.18, a black/white edge up to 3) bounds how much a
+    # high-contrast crop can scale the bits - the decoder's detectors see content amplitudes within a factor ~3 - and a clipped patch
+    # carries at most 3x the bf16 rounding error of an unclipped one (h(z) - h(z - k) cancels).
+    g1, M, kc = 32.0, 64.0, 1.0 * 32.0 / A_ONE                # GELU arguments of several units: the relu-like regime
+    w1, b1, w2 = mlp_units(0, 4 * N_BITS)
     for j in range(N_BITS):
-        for s, sign in enumerate((1.0, -1.0)):
-            u = 2 * j + s
-            put(w1, u, {_C1: sign * g1, _RG + j: M, _ONE: -M})
-            w2[_D + j, u] = sign
-    # block 1 attention head 5: uniform pooling of D_j over all tokens, S_j written to every token
+        for s, (sz, sk, so) in enumerate(((1, 0, 1), (1, -1, -1), (-1, 0, -1), (-1, -1, 1))):
+            u = 4 * j + s
+            put(w1, u, {_C1: sz * g1, _RG + j: M, _ONE: -M + sk * kc})
+            w2[_D + j, u] = so / 8.0
+            w2[_DA, u] = so * sz / 8.0
+    # block 1 attention head 5: uniform pooling over all tokens: S_j = region sums of D_j, SA = mean of DA, written to every token
     p = "encoder.blocks.1.attn."
     qkv, qb = st[p + "qkv.weight"], st[p + "qkv.bias"]
     for part in range(3):
@@ -379,27 +389,28 @@ def _wire_parseq_dfa(st: State, seed: int = 0) -> None:
     for j in range(N_BITS):
         put(qkv, 2 * E + 320 + j, {_D + j: 1.0})
         pw[_S + j, 320 + j] = 8.0                              # 16 of the 128 tokens carry region j
+    put(qkv, 2 * E + 320 + N_BITS, {_DA: 1.0})
+    pw[_SA, 320 + N_BITS] = 1.0
 
-    def sat_stage(block: int, src: int, dst: int, gain: float, K: float, first_stage: bool) -> None:
-        """dst_j = w [ (h(z+k) - h(z-k)) - (h(-z+k) - h(-z-k)) ], z = gain * src_j / sigma, k = K * ONE / (A_ONE sigma): a soft sign of
-        amplitude 2 K w / sigma whose knee sits at |src_j| = K / gain whatever the LayerNorm's sigma; bit 8 = the reference."""
+    def sat_stage(block: int, src: int, ref: int, dst: int, gain: float, kappa: float, ref_gain: float) -> None:
+        """dst_j = w [ (h(z+k) - h(z-k)) - (h(-z+k) - h(-z-k)) ], z = gain * src_j / sigma, k = kappa * ref / sigma: a soft sign of
+        amplitude 2 kappa w ref / sigma whose knee sits at |src_j| = (kappa / gain) ref - a fraction of the reference, which went
+        through the same LayerNorms and scales with the crop's contrast like the bits (and like their bf16 noise): the knee is
+        scale-free.  Bit 8 = the next stage's reference: the same units driven by ref itself (always saturated to +)."""
         w1, b1, w2 = mlp_units(block, 4 * (N_BITS + 1))
         wout = 0.25
         for j in range(N_BITS + 1):
-            if j < N_BITS:
-                cin, g = src + j, gain
-            else:                                               # reference bit: always saturated to +
-                cin, g = (_ONE, 4.0 * K / A_ONE) if first_stage else (src + N_BITS, gain)
+            cin, g = (src + j, gain) if j < N_BITS else (ref, ref_gain)
             for s, (sz, sk, so) in enumerate(((1, 1, 1), (1, -1, -1), (-1, 1, -1), (-1, -1, 1))):
                 u = 4 * j + s
                 cols = {cin: sz * g}
-                cols[_ONE] = cols.get(_ONE, 0.0) + sk * K / A_ONE
+                cols[ref] = cols.get(ref, 0.0) + sk * kappa
                 put(w1, u, cols)
                 w2[dst + j, u] = so * wout
 
-    sat_stage(1, _S, _B1, 32.0, 4.0, True)
-    sat_stage(2, _B1, _B2, 12.0, 4.0, False)
-    sat_stage(3, _B2, _B3, 12.0, 4.0, False)
+    sat_stage(1, _S, _SA, _B1, 40.0, 16.0, 64.0)               # knee |S_j| = 0.4 SA ~ 1.5 sigma(S_j): mostly linear
+    sat_stage(2, _B1, _B1 + N_BITS, _B2, 16.0, 4.0, 16.0)      # knee at 1/4 of the reference amplitude
+    sat_stage(3, _B2, _B2 + N_BITS, _B3, 16.0, 4.0, 16.0)      # -> bits saturate beyond |S_j| ~ SA / 40
 
     # ---------------- decoder: embeddings
     pq = st["pos_queries"]                                      # [1, 26, E]
@@ -461,7 +472,8 @@ def _wire_parseq_dfa(st: State, seed: int = 0) -> None:
     st[d + "linear2.bias"][_OUT:_OUT + N_CODE] = o * eos
     u = 0
     for v in range(64):                                         # first character: BOS and content bits 0..5 = v
-        cols = {_CREF: -5.0 * a_c, _PBOS: Mg, _PREF: -Mg}
+        # a_c (<u, CONT> - 4 CREF): 2 b on a match, b when one bit sits at 0 (two detectors at half strength: a linear hand-over), 0 one bit off
+        cols = {_CREF: -4.0 * a_c, _PBOS: Mg, _PREF: -Mg}
         for j in range(DFA_FIRST_BITS):
             cols[_CONT + j] = a_c if (v >> j) & 1 else -a_c
         put(l1, u, cols)
@@ -469,7 +481,8 @@ def _wire_parseq_dfa(st: State, seed: int = 0) -> None:
         u += 1
     for tab in range(4):                                        # transitions: previous class t and content bits 6..7 = tab
         for t in range(1, 95):
-            cols = {_PREF: -6.0 * a_p, _CREF: -2.0 * a_c}
+            # a_p (<code_t, PREV> - 7 PREF) + a_c <u, CONT_6..7>: 2 b on a match, b / 0 as above, < 0 for any other previous class (a_p >> a_c)
+            cols = {_PREF: -7.0 * a_p}
             for k, ck in enumerate(_code(t)):
                 cols[_PREV + k] = a_p * float(ck)
             for jj in range(2):
@@ -489,8 +502,8 @@ def _wire_parseq_dfa(st: State, seed: int = 0) -> None:
 # query / context streams) and rounded.
 NOM = {
     "self_sq": 1.5, "self_sk": 1.5,          # match score (1.5 * 3 / 0.26) (1.5 * 3 / 0.95) / sqrt(32) ~ 14.5
-    "ffn_ac": 56.0, "ffn_ap": 12.0,          # content bit 0.23 / 2.47 and token bit 1.03 / 2.47 -> detector step ~5
-    "ffn_gate": 36.0, "ffn_wo": 0.5, "out_amp": 2.5,
+    "ffn_ac": 48.0, "ffn_ap": 40.0,         # content bit ~0.25 / 2.47 (random-noise crops; it scales with the crop's contrast) and token bit 1.03 / 2.47 -> detector steps b ~5 (up to ~15) and a ~17
+    "ffn_gate": 1024.0, "ffn_wo": 0.25, "out_amp": 2.5,   # gate: -1024 x 0.42 when the previous token is not BOS (content amplitude x a_c never gets there)
     "head_gain": 4.0,                        # OUT 2.5 / 2.55 -> +-3.9 per code bit: top-2 margin ~7.8, top logit ~27
 }
 
