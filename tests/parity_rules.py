@@ -5,8 +5,8 @@ the bf16 error can come out either way.  The rule used by every bf16 test:
 
   * PARSeq: a crop's greedy path (autoregressive tokens, then the refined ids, both up to and including the first EOS - the
     reference cuts the string there, tuatara.cpp:497-502) must equal the oracle's, except that the FIRST position where it
-    differs must have an oracle top-2 margin below tau = 2 x E, E = the 99th percentile of the measured change of the top-2 gap
-    over all positions of the crops that do follow the oracle's path.  Any divergence at a larger margin fails the test.  tau must
+    differs must have an oracle top-2 margin below tau = 2 x E, E = the 99.9th percentile of the measured change of the top-2 gap
+    over all positions of the crops that do follow the oracle's path (a flip is a tail event of that distribution).  Any divergence at a larger margin fails the test.  tau must
     itself stay well below the typical margin, and at least `min_same` of the crops must follow the oracle's path outright.
   * CRAFT: see tests/test_gpu_bf16_parity.py (heat-map error bound, boxes = the reference post-processing of the engine's own
     heat map, flipped-pixel accounting).
@@ -47,14 +47,14 @@ def parseq_margin_rule(ref, ref_ar, got, got_ar, min_same: float = 0.9, label: s
     sel_ar, sel_rf = same[:, None] & mask_ar, same[:, None] & mask_rf
     gap_err = np.concatenate([e_ar[sel_ar], e_rf[sel_rf]])
     margins = np.concatenate([m_ar[sel_ar], m_rf[sel_rf]])
-    E = float(np.percentile(gap_err, 99)) if len(gap_err) else 0.0
+    E = float(np.percentile(gap_err, 99.9)) if len(gap_err) else 0.0
     tau = 2.0 * E
     dl = np.abs(got - ref)[sel_rf]
     stats = dict(n=n, same=float(same.mean()), E=E, tau=tau, median_margin=float(np.median(margins)) if len(margins) else 0.0,
                  mean_dlogit=float(dl.mean()) if dl.size else 0.0, max_dlogit=float(dl.max()) if dl.size else 0.0,
                  frac_below_tau=float((margins < tau).mean()) if len(margins) else 0.0)
     print(f"{label}: {int(same.sum())}/{n} crops follow the oracle's greedy path (AR + refined, up to EOS); on those mean |dlogit| "
-          f"{stats['mean_dlogit']:.4f} max {stats['max_dlogit']:.3f}; top-2 gap error p99 {E:.3f} -> tau {tau:.3f}; median margin "
+          f"{stats['mean_dlogit']:.4f} max {stats['max_dlogit']:.3f}; top-2 gap error p99.9 {E:.3f} -> tau {tau:.3f}; median margin "
           f"{stats['median_margin']:.2f}; {100 * stats['frac_below_tau']:.1f} % of positions have margin < tau")
     assert same.mean() >= min_same, (label, same.mean())
     assert tau < tau_cap_frac * stats["median_margin"], (label, tau, stats["median_margin"])   # the rule must stay meaningful

@@ -14,14 +14,13 @@ def _dfa_prediction(parseq, x):
         mem = parseq.encode(x)
     val = (mem[:, :, W._B3:W._B3 + 8] - mem[:, :, W._ZERO:W._ZERO + 1]).mean(1).numpy()
     ref = (mem[:, :, W._B3 + 8] - mem[:, :, W._ZERO]).mean(1).numpy()
-    hard = (np.abs(val) > 0.95 * ref[:, None]).all(1)              # every content bit saturated
+    hard = (np.abs(val[:, :6]) > 0.95 * ref[:, None]).all(1)       # every content bit the decoder reads is saturated
     ids = []
     for b in val > 0:
         v = sum(int(b[j]) << j for j in range(6))
-        tab = int(b[6]) + 2 * int(b[7])
         seq = [int(first[v])]
         while len(seq) < 26 and seq[-1] != 0:
-            seq.append(int(nxt[tab, seq[-1]]))
+            seq.append(int(nxt[seq[-1]]))
         ids.append(seq + [0] * (26 - len(seq)))
     return np.array(ids), hard
 
@@ -41,10 +40,10 @@ def test_designed_readout_decodes_its_tables_with_large_margins(oracle_models):
     for i in np.nonzero(hard)[0]:
         assert np.array_equal(ref.argmax(-1)[i, :up[i]], exp[i, :up[i]]), i          # refined ids = the tables' string
         assert np.array_equal(ref_ar.argmax(-1)[i, :up[i]], exp[i, :up[i]]), i
-        assert margin[i, :up[i]].min() > 4.0, (i, margin[i, :up[i]].min())            # bf16 |dlogit| is ~0.1
+        assert margin[i, :up[i]].min() > 3.0, (i, margin[i, :up[i]].min())            # bf16 |dlogit| is ~0.1
     from oracle import post
     strs, _ = post.decode_logits(ref)
-    assert len(set(strs)) > 32                                                         # the string depends on the crop
+    assert len(set(strs)) > 24                                                         # the string depends on the crop
 
 
 def test_bf16_noise_model_keeps_nine_paths_in_ten(oracle_models):

@@ -54,10 +54,9 @@ def expected_strings(parseq, x):
     ids = []
     for b in bits:
         v = sum(int(b[j]) << j for j in range(6))
-        tab = int(b[6]) + 2 * int(b[7])
         seq = [int(first[v])]
         while len(seq) < 26 and seq[-1] != 0:
-            seq.append(int(nxt[tab, seq[-1]]))
+            seq.append(int(nxt[seq[-1]]))
         seq += [0] * (26 - len(seq))
         ids.append(seq)
     return np.array(ids), bits

@@ -261,24 +261,20 @@ _POS, _BOSF, _TREF, _TOK = 322, 348, 349, 350                                # P
 _PREV, _PBOS, _PREF, _CONT, _CREF, _OUT = 357, 364, 365, 366, 374, 375       # PREV: 7, CONT: 8, OUT: 7
 N_BITS, N_CODE = 8, 7
 A_ONE, A_POS, A_TOK = 2.0, 3.0, 1.0
-DFA_FIRST_BITS = 6                     # content bits 0..5 choose the first character, bits 6..7 the transition table
+DFA_FIRST_BITS = 6                     # content bits 0..5 choose the first character (bits 6..7 are computed and not read)
 
 
 def dfa_tables(seed: int = 0):
     """The string a crop decodes to under the designed read-out: first[v] (v = content bits 0..5 as an integer) is
-    the first class id, nxt[u][t] the class that follows class t under transition table u (content bits 6..7);
-    class 0 is EOS.  Both tables are Gray-like in the content bits - flipping one content bit flips exactly one bit
-    of the 7-bit class code (first[v] = v; nxt[u][t] = base[t] ^ u with base[t] a multiple of 4, or EOS) - so that near a
-    content-bit tie the logits move between two neighbouring classes only, with a gentle slope.  The transition
-    tables reach ids up to 91: the reference tokenizer's shifted ids 69..94 and its eos_id 88 (tuatara.cpp:31-48)
-    all occur in decoded strings."""
+    the first class id, nxt[t] the class that follows class t; class 0 is EOS.  first is Gray-like in the content bits -
+    flipping one content bit flips exactly one bit of the 7-bit class code (first[v] = v) - so that near a content-bit
+    tie the logits move between two neighbouring classes only, with a gentle slope.  nxt reaches ids up to 94: the
+    reference tokenizer's shifted ids 69..94 and its eos_id 88 (tuatara.cpp:31-48) all occur in decoded strings."""
     rng = np.random.default_rng(seed + 4242)
     first = np.arange(64, dtype=np.int64)
-    base = np.zeros(95, np.int64)
+    nxt = np.zeros(95, np.int64)
     for t in range(1, 95):
-        base[t] = 0 if rng.random() < 0.2 else 4 * int(rng.integers(1, 23))        # 4 .. 88
-    nxt = np.stack([np.where(base > 0, base ^ u, 0) for u in range(4)])                # a fifth of the classes end the string
-    nxt[:, 0] = 0                                                                    # EOS stays EOS (no detector: the default)
+        nxt[t] = 0 if rng.random() < 0.2 else int(rng.integers(1, 95))               # a fifth of the classes end the string
     return first, nxt
 
 
@@ -299,8 +295,8 @@ def _wire_parseq_dfa(st: State, seed: int = 0) -> None:
     decoder  self-attention head 11: query i matches context slot i by a one-hot position code and copies the
              previous token's 7-bit code (PREV), a was-BOS flag and a reference.  cross-attention head 11: uniform
              pooling of the memory's bits (CONT) and reference.  FFN: exact-match detectors - 64 for the first
-             character (BOS and content bits 0..5), 94 x 4 for the transitions (previous class and bits 6..7) - write
-             the next class's code to OUT; no detector firing means EOS.  head: logit_c = G <code_c, OUT> + texture.
+             character (BOS and content bits 0..5), 94 for the transitions (previous class) - write the next class's
+             code to OUT; no detector firing means EOS.  head: logit_c = G <code_c, OUT> + texture.
 
     Near a content-bit tie (|S_j| within a few bf16 errors of 0) the bit is soft, the detectors fire partly and the
     logit margin shrinks continuously, so a decision that bf16 noise can flip shows a small fp32 margin."""
@@ -408,9 +404,9 @@ def _wire_parseq_dfa(st: State, seed: int = 0) -> None:
                 put(w1, u, cols)
                 w2[dst + j, u] = so * wout
 
-    sat_stage(1, _S, _SA, _B1, 40.0, 16.0, 64.0)               # knee |S_j| = 0.4 SA ~ 1.5 sigma(S_j): mostly linear
+    sat_stage(1, _S, _SA, _B1, 20.0, 16.0, 64.0)               # knee |S_j| = 0.8 SA ~ 3 sigma(S_j): linear
     sat_stage(2, _B1, _B1 + N_BITS, _B2, 16.0, 4.0, 16.0)      # knee at 1/4 of the reference amplitude
-    sat_stage(3, _B2, _B2 + N_BITS, _B3, 16.0, 4.0, 16.0)      # -> bits saturate beyond |S_j| ~ SA / 40
+    sat_stage(3, _B2, _B2 + N_BITS, _B3, 16.0, 4.0, 16.0)      # -> bits saturate beyond |S_j| ~ SA / 20
 
     # ---------------- decoder: embeddings
     pq = st["pos_queries"]                                      # [1, 26, E]
@@ -461,35 +457,40 @@ def _wire_parseq_dfa(st: State, seed: int = 0) -> None:
         ow[_CONT + j, H0 + j] = 1.0
     ow[_CREF, H0 + N_BITS] = 1.0
 
-    # FFN detectors
-    n_units = 64 + 4 * 94
+    # FFN detectors, each a clipped pair h(pre) - h(pre - cap): the output is w_o cap whenever pre > cap + 3 - it does not pass on
+    # the rounding noise of pre, nor the crop's contrast
+    n_det = 64 + 94
     l1, lb, l2 = st[d + "linear1.weight"], st[d + "linear1.bias"], st[d + "linear2.weight"]
-    l1[0:n_units] = 0.0
-    lb[0:n_units] = 0.0
-    l2[:, 0:n_units] = 0.0
-    a_c, a_p, Mg, w_o, o = NOM["ffn_ac"], NOM["ffn_ap"], NOM["ffn_gate"], NOM["ffn_wo"], NOM["out_amp"]
+    l1[0:2 * n_det] = 0.0
+    lb[0:2 * n_det] = 0.0
+    l2[:, 0:2 * n_det] = 0.0
+    a_c, a_p, Mg, cap, o = NOM["ffn_ac"], NOM["ffn_ap"], NOM["ffn_gate"], NOM["ffn_cap"], NOM["out_amp"]
+    w_o = o / cap
     eos = _code(0)
     st[d + "linear2.bias"][_OUT:_OUT + N_CODE] = o * eos
+
+    def detector(u: int, cols: Dict[int, float], nxt_class: int) -> None:
+        for s in range(2):
+            put(l1, 2 * u + s, cols)
+            lb[2 * u + s] = -cap * s
+            l2[_OUT:_OUT + N_CODE, 2 * u + s] = (1.0 - 2.0 * s) * w_o * (_code(nxt_class) - eos)
+
     u = 0
     for v in range(64):                                         # first character: BOS and content bits 0..5 = v
-        # a_c (<u, CONT> - 4 CREF): 2 b on a match, b when one bit sits at 0 (two detectors at half strength: a linear hand-over), 0 one bit off
+        # a_c (<u, CONT> - 4 CREF): 2 b on a match, b when one bit sits at 0, 0 one bit off, < 0 beyond
         cols = {_CREF: -4.0 * a_c, _PBOS: Mg, _PREF: -Mg}
         for j in range(DFA_FIRST_BITS):
             cols[_CONT + j] = a_c if (v >> j) & 1 else -a_c
-        put(l1, u, cols)
-        l2[_OUT:_OUT + N_CODE, u] = w_o * (_code(int(first[v])) - eos)
+        detector(u, cols, int(first[v]))
         u += 1
-    for tab in range(4):                                        # transitions: previous class t and content bits 6..7 = tab
-        for t in range(1, 95):
-            # a_p (<code_t, PREV> - 7 PREF) + a_c <u, CONT_6..7>: 2 b on a match, b / 0 as above, < 0 for any other previous class (a_p >> a_c)
-            cols = {_PREF: -7.0 * a_p}
-            for k, ck in enumerate(_code(t)):
-                cols[_PREV + k] = a_p * float(ck)
-            for jj in range(2):
-                cols[_CONT + DFA_FIRST_BITS + jj] = a_c if (tab >> jj) & 1 else -a_c
-            put(l1, u, cols)
-            l2[_OUT:_OUT + N_CODE, u] = w_o * (_code(int(nxt[tab, t])) - eos)
-            u += 1
+    for t in range(1, 95):                                      # transitions: previous class t
+        # a_p (<code_t, PREV> - 6 PREF): a on a match, <= -a otherwise.  (Content bits are not read here: PREV's and PREF's bf16
+        # roundings differ coherently over the 7 code bits, and a threshold that has to cancel them exactly passes that on.)
+        cols = {_PREF: -6.0 * a_p}
+        for k, ck in enumerate(_code(t)):
+            cols[_PREV + k] = a_p * float(ck)
+        detector(u, cols, int(nxt[t]))
+        u += 1
     # head: logit_c = G <code_c, OUT> (ZERO column keeps the rows mean-free)
     hw = st["head.weight"]
     G = NOM["head_gain"]
@@ -502,8 +503,8 @@ def _wire_parseq_dfa(st: State, seed: int = 0) -> None:
 # query / context streams) and rounded.
 NOM = {
     "self_sq": 1.5, "self_sk": 1.5,          # match score (1.5 * 3 / 0.26) (1.5 * 3 / 0.95) / sqrt(32) ~ 14.5
-    "ffn_ac": 48.0, "ffn_ap": 40.0,         # content bit ~0.25 / 2.47 (random-noise crops; it scales with the crop's contrast) and token bit 1.03 / 2.47 -> detector steps b ~5 (up to ~15) and a ~17
-    "ffn_gate": 1024.0, "ffn_wo": 0.25, "out_amp": 2.5,   # gate: -1024 x 0.42 when the previous token is not BOS (content amplitude x a_c never gets there)
+    "ffn_ac": 48.0, "ffn_ap": 28.0,         # content bit ~0.25 / 2.47 (random-noise crops; it scales with the crop's contrast) and token bit 1.03 / 2.47 -> detector steps b ~5 (up to ~15) and a ~11.5
+    "ffn_gate": 1024.0, "ffn_cap": 5.0, "out_amp": 2.5,   # gate: -1024 x 0.42 when the previous token is not BOS (content amplitude x a_c never gets there)
     "head_gain": 4.0,                        # OUT 2.5 / 2.55 -> +-3.9 per code bit: top-2 margin ~7.8, top logit ~27
 }
 
