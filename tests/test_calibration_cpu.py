@@ -40,7 +40,7 @@ def test_designed_readout_decodes_its_tables_with_large_margins(oracle_models):
     for i in np.nonzero(hard)[0]:
         assert np.array_equal(ref.argmax(-1)[i, :up[i]], exp[i, :up[i]]), i          # refined ids = the tables' string
         assert np.array_equal(ref_ar.argmax(-1)[i, :up[i]], exp[i, :up[i]]), i
-        assert margin[i, :up[i]].min() > 3.0, (i, margin[i, :up[i]].min())            # bf16 |dlogit| is ~0.1
+        assert margin[i, :up[i]].min() > 1.5, (i, margin[i, :up[i]].min())            # bf16 |dlogit| is ~0.05
     from oracle import post
     strs, _ = post.decode_logits(ref)
     assert len(set(strs)) > 24                                                         # the string depends on the crop
