@@ -204,3 +204,11 @@ def test_cpp_cli_and_pytuatara_callers(weights, funsd, tmp_path):
     ref_rgb = eng.image_to_data(funsd)
     assert int(out.stdout.splitlines()[0]) == len(ref_rgb)
     assert ref_rgb[0]["text"] in out.stdout.splitlines()[1]
+
+
+def test_decode_ids_matches_the_reference_tokenizer_on_the_gpu_box():
+    """ttr_decode_ids against the vectors the reference's own Tokenizer class produced (oracle/build_ref_tokenizer.py)."""
+    from tuatara_amd.engine import decode_ids
+    g = json.load(open(os.path.join(GOLDEN, "g1_ref_tokenizer.json")))
+    for c in g["cases"]:
+        assert [ord(ch) for ch in decode_ids(c["ids"])] == c["text"], c["ids"]
