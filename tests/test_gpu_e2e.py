@@ -212,3 +212,83 @@ def test_decode_ids_matches_the_reference_tokenizer_on_the_gpu_box():
     g = json.load(open(os.path.join(GOLDEN, "g1_ref_tokenizer.json")))
     for c in g["cases"]:
         assert [ord(ch) for ch in decode_ids(c["ids"])] == c["text"], c["ids"]
+
+
+def test_stream_survives_a_failed_push(eng_bf16, funsd):
+    """A push that throws (here: a page too thin to resize, tuatara.cpp:206-234 would produce an empty canvas) must leave the
+    two batches in flight, and the staging-slot parity, as they were: the following results belong to the right batches."""
+    from tuatara_amd.engine import DeviceBuffer, EngineError
+    pages = [np.ascontiguousarray(funsd[:512, :384]), np.ascontiguousarray(funsd[300:812, 200:584]), np.ascontiguousarray(funsd[100:612, 100:484])]
+    bufs = []
+    for p in pages:
+        b = DeviceBuffer(p.nbytes)
+        b.upload(p)
+        bufs.append(b)
+    want = [eng_bf16.image_to_data(p) for p in pages]
+    thin = DeviceBuffer(4000 * 3)
+    thin.upload(np.zeros((1, 4000, 3), np.uint8))
+    assert eng_bf16.stream_push(bufs[0], 1, 512, 384) == []
+    with pytest.raises(EngineError):
+        eng_bf16.stream_push(thin, 1, 1, 4000)
+    assert eng_bf16.stream_push(bufs[1], 1, 512, 384) == []
+    with pytest.raises(EngineError):
+        eng_bf16.stream_push(thin, 1, 1, 4000)
+    got = [eng_bf16.stream_push(bufs[2], 1, 512, 384)]
+    got.append(eng_bf16.stream_flush())
+    got.append(eng_bf16.stream_flush())
+    assert eng_bf16.stream_flush() == []
+    for g, w in zip(got, want):
+        assert len(g) == 1
+        assert [x["bbox"] for x in g[0]] == [x["bbox"] for x in w] and [x["text"] for x in g[0]] == [x["text"] for x in w]
+
+
+def test_engine_called_from_another_thread(weights, funsd):
+    """HIP's current device is per thread: every C ABI entry point makes the engine's device current itself, so an engine may be
+    created in one thread and driven from others."""
+    import threading
+    from tuatara_amd.engine import Engine
+    page = np.ascontiguousarray(funsd[:512, :384])
+    box = {}
+
+    def make():
+        box["eng"] = Engine(weights["dir"], precision="bf16")
+        box["a"] = box["eng"].image_to_data(page)
+
+    def use():
+        box["b"] = box["eng"].image_to_data(page)
+        box["c"], _ = box["eng"].parseq_logits(np.zeros((3, 32, 128, 3), np.uint8))
+
+    for fn in (make, use):
+        t = threading.Thread(target=fn)
+        t.start()
+        t.join()
+    assert len(box["a"]) > 3 and box["a"] == box["b"] and np.isfinite(box["c"]).all()
+    box["eng"].close()
+
+
+def test_malformed_inputs_are_rejected_loudly(weights, eng_f32, tmp_path):
+    """A corrupt .ttrw entry (byte count that disagrees with the dims, or a range that wraps) fails ttr_create instead of corrupting
+    the heap; the ctypes wrapper refuses arrays that are not [H, W, 3]."""
+    import shutil
+    import struct
+    from tuatara_amd.engine import Engine, EngineError
+    with pytest.raises(RuntimeError):
+        eng_f32.image_to_data(np.zeros((64, 64, 1), np.uint8))
+    with pytest.raises(RuntimeError):
+        eng_f32.image_to_data(np.zeros((64, 64, 4), np.uint8))
+    d = tmp_path / "bad"
+    shutil.copytree(weights["dir"], d)
+    raw = bytearray((d / "parseq.ttrw").read_bytes())
+    (n,) = struct.unpack_from("<I", raw, 8)
+    p = 12
+    (ln,) = struct.unpack_from("<H", raw, p)
+    p += 2 + ln
+    nd = raw[p + 1]
+    p += 2 + 4 * nd
+    for off, nb in ((None, 6), (2 ** 64 - 8, None)):          # nb not a multiple of 4 / offset that wraps in uint64
+        bad = bytearray(raw)
+        o, b = struct.unpack_from("<QQ", bad, p)
+        struct.pack_into("<QQ", bad, p, o if off is None else off, b if nb is None else nb)
+        (d / "parseq.ttrw").write_bytes(bytes(bad))
+        with pytest.raises(EngineError):
+            Engine(str(d), precision="f32")

@@ -1,6 +1,9 @@
 // Shared device/host definitions for the tuatara MI355X (gfx950) engine.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <mutex>
 #include <stdint.h>
 
 namespace ttr {
@@ -92,4 +95,21 @@ template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T
 
 namespace ttr {
 void hip_fail(const char* what, hipError_t e, const char* file, int line);  // throws std::runtime_error
+
+// hipFuncSetAttribute acts on the CURRENT device: the launchers set a kernel's dynamic-LDS limit once per (kernel, device),
+// from whatever thread gets there first (an engine per GPU in one process, engines driven from several threads).
+struct PerDeviceOnce {
+  std::atomic<unsigned long long> done{0};
+  std::mutex m;
+  template <typename F> void run(F&& f) {
+    int dev = 0;
+    TTR_HIP_CHECK(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    std::lock_guard<std::mutex> lk(m);
+    if (done.load(std::memory_order_relaxed) & bit) return;
+    f();
+    done.fetch_or(bit, std::memory_order_release);
+  }
+};
 }

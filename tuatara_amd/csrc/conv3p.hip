@@ -986,22 +986,16 @@ static void launch_first2(const ConvParams& p_in, hipStream_t s) {
   p.dbg = g_c3_dbg;
   using G = Geo<5>;
   constexpr int lds = 9 * 8192 + 2 * G::NHALO * 128 + 1408;   // 162,176 B of the 163,840
-  static bool once = false;
-  if (!once) {
-    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_first2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    once = true;
-  }
+  static PerDeviceOnce once;
+  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_first2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); });
   int dev = 0, cus = 256;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
   const int npatch = p.B * (p.H / G::PH) * (p.W / G::PW);
   if (g_first_persistent == 2 && ((uintptr_t)p.in0 & 3) == 0 && (size_t)p.B * p.H * p.W * 3 < ((size_t)1 << 31)) {
     constexpr int lds2 = 9 * 8192 + 2 * G::NHALO * 128 + 4 * 6 * 112;   // 163,456 B of the 163,840
-    static bool once2 = false;
-    if (!once2) {
-      TTR_HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_first2s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
-      once2 = true;
-    }
+    static PerDeviceOnce once2;
+  once2.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_first2s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds2)); });
     hipLaunchKernelGGL(conv3p_first2s_kernel, dim3(std::min(npatch, cus)), dim3(512), lds2, s, p);
     return;
   }
@@ -1014,11 +1008,8 @@ static void launch_c3(const ConvParams& p, hipStream_t s) {
   using G = Geo<LPW>;
   const int tilesM = p.B * (p.H / G::PH) * (p.W / G::PW), tilesN = (p.Cout + BN - 1) / BN;
   constexpr int lds = XS * G::XSTAGE + 2 * C::WSTAGE + (FIRST ? 2048 : 0);
-  static bool once = false;
-  if (!once) {
-    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_kernel<BN, WM, WN, FIRST, XS, LPW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    once = true;
-  }
+  static PerDeviceOnce once;
+  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_kernel<BN, WM, WN, FIRST, XS, LPW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); });
   hipLaunchKernelGGL((conv3p_kernel<BN, WM, WN, FIRST, XS, LPW>), dim3(tilesM * tilesN), dim3(C::NT), lds, s, p);
 }
 

@@ -382,11 +382,8 @@ __global__ __launch_bounds__(NTHREADS) void dec_ar_kernel(DecArParams p, int G) 
 void launch_dec_ar(const DecArParams& p, int G, hipStream_t s) {
   if (p.N <= 0) return;
   if (G != 4 && G != 8 && G != 16) throw std::runtime_error("dec_ar: crops per workgroup must be 4, 8 or 16");
-  static bool once = false;
-  if (!once) {
-    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)dec_ar_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)));
-    once = true;
-  }
+  static PerDeviceOnce once;
+  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)dec_ar_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem))); });
   hipLaunchKernelGGL(dec_ar_kernel, dim3((p.N + G - 1) / G), dim3(NTHREADS), sizeof(Smem), s, p, G);
 }
 

@@ -63,8 +63,9 @@ struct DevBuf {
   size_t cap = 0;
   void ensure(size_t bytes) {
     if (bytes <= cap) return;
-    if (p) TTR_HIP_CHECK(hipFree(p));
-    p = nullptr; cap = 0;
+    void* old = p;
+    p = nullptr; cap = 0;                       // a throwing hipFree must not leave a dangling pointer for the destructor
+    if (old) TTR_HIP_CHECK(hipFree(old));
     size_t want = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
     TTR_HIP_CHECK(hipMalloc(&p, want));
     cap = want;
@@ -89,8 +90,9 @@ struct PinnedBuf {
   size_t cap = 0;
   void ensure(size_t bytes) {
     if (bytes <= cap) return;
-    if (p) TTR_HIP_CHECK(hipHostFree(p));
+    void* old = p;
     p = nullptr; cap = 0;
+    if (old) TTR_HIP_CHECK(hipHostFree(old));
     size_t want = (bytes + 65535) & ~(size_t)65535;
     TTR_HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
     cap = want;
@@ -125,8 +127,13 @@ struct WeightFile {
       rd(&e.off, 8); rd(&e.nb, 8);
     }
     uint64_t data0; rd(&data0, 8);
+    if (data0 > buf.size()) throw std::runtime_error("corrupt .ttrw (data offset): " + path);
+    const uint64_t room = buf.size() - data0;
     for (auto& e : ents) {
-      if (data0 + e.off + e.nb > buf.size()) throw std::runtime_error("tensor out of range in " + path);
+      uint64_t numel = 1;
+      for (uint32_t d : e.dims) { if (d && numel > (uint64_t)1 << 40) throw std::runtime_error("corrupt .ttrw (dims): " + path); numel *= d; }
+      if (e.nb % 4 != 0 || e.nb != 4 * numel) throw std::runtime_error("corrupt .ttrw (byte count of " + e.name + "): " + path);
+      if (e.off > room || e.nb > room - e.off) throw std::runtime_error("tensor out of range in " + path);   // overflow-safe
       HostTensor ht; ht.dims = e.dims; ht.data.resize(e.nb / 4);
       memcpy(ht.data.data(), buf.data() + data0 + e.off, e.nb);
       t[e.name] = std::move(ht);
@@ -532,6 +539,7 @@ struct Engine {
     load_parseq(dir);
   }
   ~Engine() {
+    (void)hipSetDevice(cfg.device);
     for (auto& x : ev) if (x) (void)hipEventDestroy(x);
     for (auto& x : prof_pool) (void)hipEventDestroy(x);
     for (auto& x : group_ev) (void)hipEventDestroy(x);
@@ -926,7 +934,6 @@ struct Engine {
     bool live = false, enqueued = false;
   };
   PageBatch q1, q2;        // streamed batches: q1 = boxes known (recogniser enqueued or not), q2 = older, recogniser enqueued, results not yet returned
-  unsigned batch_seq = 0;
 
   void detect_enqueue(PageBatch& B) {
     if (B.h <= 0 || B.w <= 0) throw std::runtime_error("Error reading image from file");  // image.empty(), tuatara.cpp:344
@@ -1062,7 +1069,8 @@ struct Engine {
     if (n <= 0) throw std::runtime_error("stream_push: empty batch");
     const double th0 = now_us();
     PageBatch B;
-    B.d_pages = d_pages; B.n = n; B.h = h; B.w = w; B.slot = (int)(batch_seq++ & 1);
+    B.d_pages = d_pages; B.n = n; B.h = h; B.w = w;
+    B.slot = q1.live ? (q1.slot ^ 1) : 0;     // from the pipeline's state, not a counter: a push that throws leaves q1 / q2 and the slot parity as they were
     detect_enqueue(B);
     host_us[0] = (float)(now_us() - th0);
     const double th1 = now_us();
@@ -1090,6 +1098,13 @@ using namespace ttr;
 
 struct ttr_engine { std::unique_ptr<Engine> e; };
 struct ttr_result { Result r; };
+
+// Every entry point: the engine's lock, and the engine's device made current for the calling thread (HIP's current device is per
+// thread: allocations, hipFuncSetAttribute and device queries inside the call must hit the device the stream belongs to).
+struct EngineScope {
+  std::lock_guard<std::mutex> lk;
+  explicit EngineScope(Engine& E) : lk(E.mu) { TTR_HIP_CHECK(hipSetDevice(E.cfg.device)); }
+};
 
 #define TTR_GUARD_BEGIN try {
 #define TTR_GUARD_END(rc)                                   \
@@ -1131,7 +1146,7 @@ static void run_locked(ttr_engine* e, const uint8_t* d_pages, int n, int h, int 
 int ttr_pages_to_data_dev(ttr_engine* e, const uint8_t* d_pages, int n, int h, int w, ttr_result** out) {
   TTR_GUARD_BEGIN
   if (!e || !out) throw std::runtime_error("null argument");
-  std::lock_guard<std::mutex> lk(e->e->mu);
+  EngineScope lk(*e->e);
   run_locked(e, d_pages, n, h, w, out);
   return 0;
   TTR_GUARD_END(-1)
@@ -1140,7 +1155,7 @@ int ttr_pages_to_data_dev(ttr_engine* e, const uint8_t* d_pages, int n, int h, i
 int ttr_stream_push(ttr_engine* e, const uint8_t* d_pages, int n, int h, int w, ttr_result** out_prev, int* n_prev) {
   TTR_GUARD_BEGIN
   if (!e || !out_prev || !n_prev) throw std::runtime_error("null argument");
-  std::lock_guard<std::mutex> lk(e->e->mu);
+  EngineScope lk(*e->e);
   std::vector<Result> res;
   int np = 0;
   e->e->stream_push(d_pages, n, h, w, res, np);
@@ -1153,7 +1168,7 @@ int ttr_stream_push(ttr_engine* e, const uint8_t* d_pages, int n, int h, int w, 
 int ttr_stream_flush(ttr_engine* e, ttr_result** out_prev, int* n_prev) {
   TTR_GUARD_BEGIN
   if (!e || !out_prev || !n_prev) throw std::runtime_error("null argument");
-  std::lock_guard<std::mutex> lk(e->e->mu);
+  EngineScope lk(*e->e);
   std::vector<Result> res;
   int np = 0;
   e->e->stream_flush(res, np);
@@ -1168,7 +1183,7 @@ int ttr_image_to_data(ttr_engine* e, const uint8_t* img, int h, int w, int row_s
   if (!e || !out) throw std::runtime_error("null argument");
   if (!img || h <= 0 || w <= 0) throw std::runtime_error("Error reading image from file");  // tuatara.cpp:344-347
   Engine& E = *e->e;
-  std::lock_guard<std::mutex> lk(E.mu);
+  EngineScope lk(E);
   E.staging_img.ensure((size_t)h * w * 3);
   TTR_HIP_CHECK(hipMemcpy2DAsync(E.staging_img.p, (size_t)w * 3, img, row_stride, (size_t)w * 3, h, hipMemcpyHostToDevice, E.stream));
   run_locked(e, E.staging_img.as<uint8_t>(), 1, h, w, out);
@@ -1216,7 +1231,7 @@ int ttr_result_texts(const ttr_result* r, char* buf, size_t cap) {
 int ttr_craft_heatmap(ttr_engine* e, const uint8_t* canvas, int H, int W, float* heat_out) {
   TTR_GUARD_BEGIN
   Engine& E = *e->e;
-  std::lock_guard<std::mutex> lk(E.mu);
+  EngineScope lk(E);
   E.canvas.ensure((size_t)H * W * 3);
   E.heat.ensure((size_t)H * W / 4 * 2 * 4);
   TTR_HIP_CHECK(hipMemcpyAsync(E.canvas.p, canvas, (size_t)H * W * 3, hipMemcpyHostToDevice, E.stream));
@@ -1230,7 +1245,7 @@ int ttr_craft_heatmap(ttr_engine* e, const uint8_t* canvas, int H, int W, float*
 int ttr_ccl_boxes(ttr_engine* e, const float* heat, int H2, int W2, float* rects5, int max_rects, int* n) {
   TTR_GUARD_BEGIN
   Engine& E = *e->e;
-  std::lock_guard<std::mutex> lk(E.mu);
+  EngineScope lk(E);
   E.heat.ensure((size_t)H2 * W2 * 2 * 4);
   TTR_HIP_CHECK(hipMemcpyAsync(E.heat.p, heat, (size_t)H2 * W2 * 2 * 4, hipMemcpyHostToDevice, E.stream));
   E.ccl_launch(E.heat.as<float>(), 0, 1, 1, 0, H2, W2);
@@ -1249,7 +1264,7 @@ int ttr_ccl_boxes(ttr_engine* e, const float* heat, int H2, int W2, float* rects
 int ttr_resize_canvas(ttr_engine* e, const uint8_t* img, int h, int w, int row_stride, uint8_t* canvas, size_t cap, int* H, int* W, float* ratio) {
   TTR_GUARD_BEGIN
   Engine& E = *e->e;
-  std::lock_guard<std::mutex> lk(E.mu);
+  EngineScope lk(E);
   const CanvasGeom g = canvas_geometry(h, w, E.cfg.canvas_size, E.cfg.mag_ratio);
   *H = g.h32; *W = g.w32; *ratio = g.ratio;
   const size_t need = (size_t)g.h32 * g.w32 * 3;
@@ -1268,7 +1283,7 @@ int ttr_pack_crops(ttr_engine* e, const uint8_t* img, int h, int w, int row_stri
                    float* boxes_out) {
   TTR_GUARD_BEGIN
   Engine& E = *e->e;
-  std::lock_guard<std::mutex> lk(E.mu);
+  EngineScope lk(E);
   if (n <= 0) return 0;
   std::vector<int> rects((size_t)n * 5, 0);
   for (int i = 0; i < n; ++i) {
@@ -1295,7 +1310,7 @@ int ttr_pack_crops(ttr_engine* e, const uint8_t* img, int h, int w, int row_stri
 int ttr_parseq_logits(ttr_engine* e, const uint8_t* crops, int n, float* logits, float* ar_logits, int32_t* ids) {
   TTR_GUARD_BEGIN
   Engine& E = *e->e;
-  std::lock_guard<std::mutex> lk(E.mu);
+  EngineScope lk(E);
   if (n <= 0) return 0;
   E.crops.ensure((size_t)n * 32 * 128 * 3);
   E.logits.ensure((size_t)n * 26 * 95 * 4);
@@ -1324,7 +1339,7 @@ int ttr_dbg_conv(ttr_engine* e, const float* in0, int C0, const float* in1, int 
                  const float* wgt, const float* bias, int Cout, int act, float* out) {
   TTR_GUARD_BEGIN
   Engine& E = *e->e;
-  std::lock_guard<std::mutex> lk(E.mu);
+  EngineScope lk(E);
   const size_t M = (size_t)B * H * W;
   const int K = ks * ks * (C0 + C1);
   DevBuf d0, d1, dout;
@@ -1365,7 +1380,7 @@ int ttr_dbg_mlp(ttr_engine* e, const float* x, int M, const float* ln_g, const f
                 const float* b2, const float* nln_g, const float* nln_b, float* x_out, float* nln_out, const float* att, const float* wp, const float* bp) {
   TTR_GUARD_BEGIN
   Engine& E = *e->e;
-  std::lock_guard<std::mutex> lk(E.mu);
+  EngineScope lk(E);
   if (E.prec != kBF16) throw std::runtime_error("ttr_dbg_mlp: bf16 engines only");
   const int D = 384, H = 1536;
   DevBuf dx, dout, dg, db, dw1, db1, dw2, db2, dng, dnb, dn;
@@ -1407,7 +1422,7 @@ int ttr_dbg_mlp(ttr_engine* e, const float* x, int M, const float* ln_g, const f
 int ttr_dbg_qkv_attn(ttr_engine* e, const float* x, int N, const float* w, const float* b, float* out) {
   TTR_GUARD_BEGIN
   Engine& E = *e->e;
-  std::lock_guard<std::mutex> lk(E.mu);
+  EngineScope lk(E);
   if (E.prec != kBF16) throw std::runtime_error("ttr_dbg_qkv_attn: bf16 engines only");
   const size_t nx = (size_t)N * 128 * 384, nw = (size_t)1152 * 384;
   DevBuf dx, dw, db, dout;
@@ -1429,7 +1444,7 @@ int ttr_dbg_qkv_attn(ttr_engine* e, const float* x, int N, const float* w, const
 int ttr_dbg_attn_enc(ttr_engine* e, const float* qkv, int N, float* out) {
   TTR_GUARD_BEGIN
   Engine& E = *e->e;
-  std::lock_guard<std::mutex> lk(E.mu);
+  EngineScope lk(E);
   const size_t nin = (size_t)N * 128 * 1152, nout = (size_t)N * 128 * 384;
   DevBuf din, dout;
   din.ensure(nin * E.es); dout.ensure(nout * E.es);
@@ -1453,7 +1468,7 @@ int ttr_dbg_conv_pool(ttr_engine* e, const float* in0, int C0, int B, int H, int
                       int pool_relu, float* out_full, float* out_pool) {
   TTR_GUARD_BEGIN
   Engine& E = *e->e;
-  std::lock_guard<std::mutex> lk(E.mu);
+  EngineScope lk(E);
   if (E.prec != kBF16) throw std::runtime_error("ttr_dbg_conv_pool: bf16 engines only (the fused pool lives in gemm2)");
   const size_t M = (size_t)B * H * W, Mp = M / 4;
   const int K = ks * ks * C0;
@@ -1530,7 +1545,7 @@ int ttr_set_tuning(const char* key, int value) {
 int ttr_bench_conv(ttr_engine* e, int B, int H, int W, int C0, int C1, int ks, int dil, int Cout, int act, int f32_resid, int iters, float* avg_us) {
   TTR_GUARD_BEGIN
   Engine& E = *e->e;
-  std::lock_guard<std::mutex> lk(E.mu);
+  EngineScope lk(E);
   const size_t M = (size_t)B * H * W;
   const int K = ks * ks * (C0 + C1);
   DevBuf d0, d1, dw, db, dout, dres;
@@ -1603,7 +1618,7 @@ int ttr_dev_download(void* dst, const void* src, size_t bytes) { return hipMemcp
 int ttr_dev_sync(ttr_engine* e) { return hipStreamSynchronize(e->e->stream) == hipSuccess ? 0 : -1; }
 int ttr_set_profiling(ttr_engine* e, int on) {
   Engine& E = *e->e;
-  std::lock_guard<std::mutex> lk(E.mu);
+  EngineScope lk(E);
   E.profiling = on < 0 ? 0 : (on > 2 ? 2 : on);
   E.prof_recs.clear();
   for (int i = 0; i < 3; ++i) { E.prof_ms[i] = 0; E.prof_flops[i] = 0; E.prof_launches[i] = 0; }
@@ -1611,7 +1626,7 @@ int ttr_set_profiling(ttr_engine* e, int on) {
 }
 int ttr_get_profile(ttr_engine* e, double ms[3], double flops[3], long long launches[3]) {
   Engine& E = *e->e;
-  std::lock_guard<std::mutex> lk(E.mu);
+  EngineScope lk(E);
   E.prof_collect();          // records whose events completed since the last batch was finished
   for (int i = 0; i < 3; ++i) { ms[i] = E.prof_ms[i]; flops[i] = E.prof_flops[i]; launches[i] = E.prof_launches[i]; }
   return 0;

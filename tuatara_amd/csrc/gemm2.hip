@@ -328,11 +328,8 @@ template <int BM, int BN, int WM, int WN, int MINB, int XST>
 static void launch_g2(const ConvParams& p, hipStream_t s) {
   using C = G2Cfg<BM, BN, WM, WN, XST>;
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
-  static bool once = false;
-  if (!once) {
-    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WM, WN, MINB, XST>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + (XST == 2 ? 8192 : 0)));
-    once = true;
-  }
+  static PerDeviceOnce once;
+  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WM, WN, MINB, XST>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + (XST == 2 ? 8192 : 0))); });
   const size_t lds = C::LDS + (p.act == kActGelu ? 8192 : 0);
   // persistent grid: as many workgroups as fit the chip at once (a multiple of 8: one share per XCD), never more than tiles
   const int per_cu = std::max(1, std::min((int)(160 * 1024 / lds), 2048 / C::NT));

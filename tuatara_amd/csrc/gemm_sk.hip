@@ -212,11 +212,8 @@ void launch_gemm_sk(const ConvParams& p_in, hipStream_t s) {
   p.gelu_lut = p.act == kActGelu ? gelu_lut_for_current_device() : nullptr;
   const int KC = p.C0 < SK_KC ? p.C0 : SK_KC;
   const size_t lds = (size_t)(SK_BM + SK_BN) * KC * 2;
-  static bool once = false;
-  if (!once) {
-    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_sk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (SK_BM + SK_BN) * SK_KC * 2));
-    once = true;
-  }
+  static PerDeviceOnce once;
+  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_sk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (SK_BM + SK_BN) * SK_KC * 2)); });
   const int tilesM = (p.M + SK_BM - 1) / SK_BM, tilesN = (p.Cout + SK_BN - 1) / SK_BN;
   hipLaunchKernelGGL(gemm_sk_kernel, dim3(tilesM * tilesN), dim3(256), lds, s, p);
 }

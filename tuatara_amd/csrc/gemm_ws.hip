@@ -236,11 +236,8 @@ const char* gemm_ws_check(const ConvParams& p) {
 
 template <int NK, int ACT = -1>
 static void launch_ws(const ConvParams& p, int nslices, int mgroups, int grid, size_t lds, hipStream_t s) {
-  static bool once = false;
-  if (!once) {
-    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_ws_kernel<NK, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SLOTS * WS_BM * NK * 128 + 8192));
-    once = true;
-  }
+  static PerDeviceOnce once;
+  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_ws_kernel<NK, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SLOTS * WS_BM * NK * 128 + 8192)); });
   hipLaunchKernelGGL((gemm_ws_kernel<NK, ACT>), dim3(grid), dim3(512), lds, s, p, nslices, mgroups);
 }
 

@@ -223,8 +223,8 @@ static void launch_cfg(const ConvParams& p, hipStream_t s) {
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
   const size_t lds = 2 * (size_t)(BM + BN) * CPR * 16;
   if (lds > 48 * 1024) {
-    static bool once = false;
-    if (!once) { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)igemm_kernel<T, WMT, WNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
+    static PerDeviceOnce once;
+  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)igemm_kernel<T, WMT, WNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); });
   }
   hipLaunchKernelGGL((igemm_kernel<T, WMT, WNT>), dim3(tilesM * tilesN), dim3(256), lds, s, p);
 }

@@ -520,14 +520,11 @@ void launch_mlp_fused(const MlpParams& p_in, hipStream_t s) {
   p.gelu_lut = gelu_lut_for_current_device();
   p.dbg = g_mlp_dbg; p.store_nt = g_mlp_store_nt;
   if (const char* e = mlp_fused_check(p)) throw std::runtime_error(e);
-  static bool once = false;
-  if (!once) {
-    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
+  static PerDeviceOnce once;
+  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
     TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
     TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
-    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
-    once = true;
-  }
+    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS)); });
   int dev = 0, cus = 256;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;

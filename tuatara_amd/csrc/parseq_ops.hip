@@ -200,8 +200,8 @@ void launch_attn_enc(Precision prec, const void* qkv, void* out, int N, hipStrea
   if (prec == kBF16) {
     hipLaunchKernelGGL(attn_enc_kernel<bf16>, dim3(N * 6), dim3(256), lds_bytes(2), s, (const bf16*)qkv, (bf16*)out);
   } else {
-    static bool once = false;
-    if (!once) { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)attn_enc_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(4))); once = true; }
+    static PerDeviceOnce once;
+  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)attn_enc_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(4))); });
     hipLaunchKernelGGL(attn_enc_kernel<float>, dim3(N * 6), dim3(256), lds_bytes(4), s, (const float*)qkv, (float*)out);
   }
 }
@@ -381,11 +381,8 @@ void set_dec_self_refine(int v) { g_self_refine = v; }
 void launch_dec_self_attn(Precision prec, const float* q, const void* kvcache, const int* tokens, void* out, int N, int R, int qi0, int mode, hipStream_t s) {
   if (N <= 0) return;
   if (prec == kBF16 && mode == 1 && R == 26 && g_self_refine) {
-    static bool once = false;
-    if (!once) {
-      TTR_HIP_CHECK(hipFuncSetAttribute((const void*)dec_self_attn_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS));
-      once = true;
-    }
+    static PerDeviceOnce once;
+  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)dec_self_attn_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS)); });
     hipLaunchKernelGGL(dec_self_attn_refine_kernel, dim3(N), dim3(384), SR_LDS, s, q, (const bf16*)kvcache, tokens, (bf16*)out);
     return;
   }

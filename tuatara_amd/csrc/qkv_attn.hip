@@ -255,8 +255,8 @@ void launch_qkv_attn(const bf16* x, const bf16* w, const float* bias, bf16* out,
   if (N <= 0) return;
   if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)out) & 15) throw std::runtime_error("qkv_attn: operands must be 16-byte aligned");
   if ((size_t)N * S * E * 2 >= ((size_t)1 << 31)) throw std::runtime_error("qkv_attn: too many crops for 32-bit buffer offsets");
-  static bool once = false;
-  if (!once) { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)qkv_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, QA_LDS)); once = true; }
+  static PerDeviceOnce once;
+  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)qkv_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, QA_LDS)); });
   hipLaunchKernelGGL(qkv_attn_kernel, dim3(8 * 32), dim3(256), QA_LDS, s, x, w, bias, out, N);
 }
 

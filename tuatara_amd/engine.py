@@ -261,7 +261,9 @@ class Engine:
     # ---- hot path
     def image_to_data(self, image: np.ndarray) -> List[dict]:
         if image.ndim != 3:
-            raise RuntimeError("Input array should have 3 dimensions")
+            raise RuntimeError("Input array should have 3 dimensions")          # bindings/python.cpp:15-17 of the reference
+        if image.shape[2] != 3:
+            raise RuntimeError("Input array should have 3 channels")            # the C ABI reads rows of 3 * w bytes
         image = np.ascontiguousarray(image, dtype=np.uint8)
         r = C.c_void_p()
         self._check(self.lib.ttr_image_to_data(self.h, _u8(image), image.shape[0], image.shape[1], image.shape[1] * 3, C.byref(r)))
@@ -293,13 +295,14 @@ class Engine:
         """Streamed batches (ttr_stream_push): enqueue batch k+1, get batch k's results (an empty list on the first push).  The
         pages of a batch must stay alive until its results have come back."""
         ptr = d_pages.ptr if isinstance(d_pages, DeviceBuffer) else d_pages
-        arr = (C.c_void_p * max(n, max_batch, 1024))()
+        self._max_pushed = max(getattr(self, "_max_pushed", 1), n, max_batch)   # a returned batch is never larger than the largest pushed
+        arr = (C.c_void_p * self._max_pushed)()
         n_prev = C.c_int(0)
         self._check(self.lib.ttr_stream_push(self.h, ptr, n, h, w, arr, C.byref(n_prev)))
         return self._stream_take(arr, n_prev.value, keep)
 
     def stream_flush(self, keep: bool = True):
-        arr = (C.c_void_p * 1024)()
+        arr = (C.c_void_p * getattr(self, "_max_pushed", 1))()
         n_prev = C.c_int(0)
         self._check(self.lib.ttr_stream_flush(self.h, arr, C.byref(n_prev)))
         return self._stream_take(arr, n_prev.value, keep)
