@@ -39,6 +39,8 @@ typedef struct ttr_config {
   int strict_crops;      /* 0: clamp crops to the image; 1: fail like the reference's cv::Exception at :416 */
   int max_components;    /* capacity for CCL candidates per page (default 4096) */
   int verbose;
+  int bench_grid_boxes;  /* 0.  Benchmark only (--boxes=grid40): the detector runs in full, then every page's boxes are
+                            replaced by a fixed 5 x 8 grid of 150 x 40 px boxes so that the recogniser sees exactly 40 crops per page */
 } ttr_config;
 
 void ttr_config_default(ttr_config* cfg);

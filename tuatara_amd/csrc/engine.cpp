@@ -967,6 +967,17 @@ struct Engine {
     B.rects.clear(); B.page_of.clear();        // x0,y0,x1,y1,page per crop; page index per crop
     host_us[1] = host_us[2] = host_us[3] = 0.f;
     for (int gi = 0; gi < groups; ++gi) ccl_collect(gi * 16, std::min(16, n - gi * 16), gi, B.H2, B.W2, dets);
+    if (cfg.bench_grid_boxes) {   // benchmark workload control: the detector's work is done (and timed); 40 fixed boxes per page go on
+      for (int i = 0; i < n; ++i) {
+        dets[i].clear();
+        for (int r = 0; r < 8; ++r)
+          for (int c = 0; c < 5; ++c) {
+            RRect g;
+            g.cx = (c + 0.5f) * (float)B.W2 / 5.f; g.cy = (r + 0.5f) * (float)B.H2 / 8.f; g.w = 75.f * B.g.ratio; g.h = 20.f * B.g.ratio; g.angle = 0.f;
+            dets[i].push_back(g);
+          }
+      }
+    }
     for (int i = 0; i < n; ++i) {
       for (const RRect& r : dets[i]) {
         RRect b = adjust_coordinates(r, ratio_w, ratio_h);            // :406
@@ -1117,7 +1128,7 @@ extern "C" {
 void ttr_config_default(ttr_config* c) {
   c->precision = TTR_PREC_BF16; c->device = 0; c->canvas_size = 1024; c->mag_ratio = 1.0f;
   c->text_threshold = 0.7f; c->link_threshold = 0.4f; c->low_text = 0.4f; c->min_area = 10;
-  c->strict_crops = 0; c->max_components = 4096; c->verbose = 0;
+  c->strict_crops = 0; c->max_components = 4096; c->verbose = 0; c->bench_grid_boxes = 0;
 }
 
 const char* ttr_last_error(void) { return g_last_error.c_str(); }

@@ -22,7 +22,7 @@ PREC_BF16, PREC_F32 = 0, 1
 class Config(C.Structure):
     _fields_ = [("precision", C.c_int), ("device", C.c_int), ("canvas_size", C.c_int), ("mag_ratio", C.c_float),
                 ("text_threshold", C.c_float), ("link_threshold", C.c_float), ("low_text", C.c_float), ("min_area", C.c_int),
-                ("strict_crops", C.c_int), ("max_components", C.c_int), ("verbose", C.c_int)]
+                ("strict_crops", C.c_int), ("max_components", C.c_int), ("verbose", C.c_int), ("bench_grid_boxes", C.c_int)]
 
 
 # every symbol include/tuatara_hip.h declares: (name, restype, argtypes)
