@@ -229,3 +229,30 @@ def test_fused_encoder_block_kernels_at_their_batch_sizes(eng_bf16, n):
     same_path = (a0.argmax(-1) == a1.argmax(-1)).all(1)
     assert same_path.mean() >= 0.9
     assert np.percentile(np.abs(a1[same_path] - a0[same_path]), 99.9) < 0.8
+
+
+@pytest.mark.parametrize("n", [45, 700])
+def test_ar_early_exit_is_invisible_in_the_refined_logits(eng_bf16, n):
+    """Upstream PARSeq leaves its AR loop once every crop of the batch has emitted EOS (system.py; SURVEY 2.2: the refined logits do
+    not depend on it).  The engine does the same on the device - the per-step kernels return at once when the batch's done counter
+    has reached N - so the steps behind the exit cost a launch boundary each instead of a decode step.  Keys behind a crop's EOS are
+    masked in the refinement pass, so the refined logits must be BIT-IDENTICAL with and without the exit; the AR logits agree on
+    every step that ran and read zero behind the exit."""
+    crops = np.random.default_rng(21).integers(0, 256, (n, 32, 128, 3), dtype=np.uint8)
+    try:
+        assert eng_bf16.lib.ttr_set_tuning(b"ar_early_exit", 0) == 0
+        l0, a0, i0 = eng_bf16.parseq_logits(crops, want_ar=True)
+        assert eng_bf16.lib.ttr_set_tuning(b"ar_early_exit", 1) == 0
+        l1, a1, i1 = eng_bf16.parseq_logits(crops, want_ar=True)
+        l2, i2 = eng_bf16.parseq_logits(crops)
+    finally:
+        eng_bf16.lib.ttr_set_tuning(b"ar_early_exit", 1)
+    assert np.array_equal(l0, l1) and np.array_equal(i0, i1) and np.array_equal(l1, l2)
+    ran = np.abs(a1).max((0, 2)) > 0                       # steps that ran for the batch
+    steps = int(ran.sum())
+    assert ran[:steps].all() and not ran[steps:].any()
+    assert np.array_equal(a0[:, :steps], a1[:, :steps])
+    from tests.parity_rules import upto_eos
+    longest = int(upto_eos(a0.argmax(-1)).max())
+    print(f"AR early exit, {n} crops: {steps} of 26 steps ran; the longest string of the batch ends at step {longest}")
+    assert steps <= longest + 1 < 26                       # the designed weights decode strings of at most 10 characters

@@ -41,6 +41,10 @@ struct ConvParams {
   unsigned long long* dbg;   // gemm_ws diagnostics: shader-clock stamps of workgroup 0 (null = off)
   int store_policy;          // set by the launchers: 0 default, 1 nt, 2 sc0 sc1 nt on the big streaming output stores
   int dbg_flags;             // gemm_ws diagnostics (timing experiments only, results are wrong): 1 = no output stores, 2 = no activation loads
+  // PARSeq AR early exit (upstream system.py: the loop breaks once every crop of the batch has emitted EOS): a kernel returns at
+  // once when *skip >= skip_n; the token prologue counts crops whose FIRST EOS (id tok_eos) is the token it has just formed
+  const int* skip; int skip_n;
+  int* done_count; int tok_eos;
   const void* gelu_lut;      // set by launch_gemm2: float2 [1024] = {Phi(x_i), Phi(x_i+1) - Phi(x_i)}, x_i = -8 + i/64
 };
 

@@ -55,6 +55,7 @@ static int g_tok_fuse = 1;         // bf16 AR steps: argmax of the previous step
 static int g_ln_fuse = 1;          // bf16 decoder steps: LayerNorm computed inside the skinny GEMM's loader (gemm_sk ln_in)
 static int g_fuse_first = 1;       // bf16: CRAFT conv1_1 fused into conv1_2's loader (conv3p FIRST)
 static int g_enc_chunk = 0;        // crops per encoder group (0 = all crops at once)
+static int g_ar_early_exit = 1;    // bf16 kernel-per-op AR loop: the steps' kernels return at once when every crop of the batch has emitted EOS (upstream's break)
 static int g_decoder_mode = 1;   // 0 = kernel-per-op AR loop, 4/8/16 = fused kernel with that many crops per workgroup, else automatic
 
 // ------------------------------------------------------------------ small utilities
@@ -679,6 +680,7 @@ struct Engine {
       p.wgt = L.w.p; p.bias = L.b.as<float>();
       p.out = out; p.out_ld = out_ld; p.out_f32 = out_f32; p.out_f32_ld = out_f32_ld;
       p.Cout = L.cout; p.M = M; p.act = act;
+      p.skip = cur_skip; p.skip_n = cur_skip_n;
       igemm(p, 2.0 * M * L.cout * L.k);
       return;
     }
@@ -693,8 +695,14 @@ struct Engine {
     p.out = out; p.out_ld = out_ld; p.out_f32 = out_f32; p.out_f32_ld = out_f32_ld;
     p.resid = resid; p.resid_ld = resid_ld; p.resid_mod = resid_mod;
     p.Cout = L.cout; p.M = M; p.act = act;
+    p.skip = cur_skip; p.skip_n = cur_skip_n;
     igemm(p, 2.0 * M * L.cout * L.k);
   }
+  // AR early exit: while set, the decoder's per-step launches carry the batch's done counter (ConvParams::skip); only the skinny
+  // GEMM and the per-row attention kernels honour it, which are the ones the bf16 AR steps use
+  const int* cur_skip = nullptr; int cur_skip_n = 0;
+  DevBuf ar_done;
+  size_t kvcache_zeroed = 0;
   void ln(const float* x, const std::string& name, float eps, void* out, int M) {
     launch_layernorm(prec, x, 384, pqf.at(name + ".weight").as<float>(), pqf.at(name + ".bias").as<float>(), eps, out, 384, M, 384, stream);
   }
@@ -707,7 +715,7 @@ struct Engine {
     const std::string d = "decoder.layers.0.";
     gemm(pq.at("self_out"), sa, rows, nullptr, 0, kActNone, tgt, 384, resid_pos, 384, resid_mod);      // tgt = query + self_attn
     ln_gemm(tgt, d + "norm1", 1e-5f, t384, pq.at("cross_q"), rows, t384b, 384, kActNone);
-    launch_dec_cross_attn(prec, t384b, kvmem, t384, N, R, stream);
+    launch_dec_cross_attn(prec, t384b, kvmem, t384, N, R, stream, cur_skip, cur_skip_n);
     if (R > 1 && prec == kBF16 && gemm_config() >= 0 && g_dec_mlp_fused && rows >= g_dec_mlp_min_rows) {
       // refinement pass (26 rows per crop): the block behind the cross-attention is an encoder block's second half with other weights —
       // out projection + residual, norm2, linear1, GELU, linear2, residual, and the final norm as the "next LayerNorm" — one launch
@@ -786,6 +794,10 @@ struct Engine {
 
     // ---- decoder
     void* kvcache = (pq_ws[6].ensure((size_t)N * 26 * 768 * es), pq_ws[6].p);
+    if (kvcache_zeroed != pq_ws[6].cap) {   // slots behind an early exit keep older (finite) rows; they are masked, but 0 x NaN is not 0
+      TTR_HIP_CHECK(hipMemsetAsync(kvcache, 0, pq_ws[6].cap, stream));
+      kvcache_zeroed = pq_ws[6].cap;
+    }
     float* tgt = (float*)(pq_ws[7].ensure((size_t)N * 26 * E * 4), pq_ws[7].p);
     void* d384b = (pq_ws[8].ensure((size_t)N * 26 * E * es), pq_ws[8].p);
     void* d1536 = (pq_ws[9].ensure((size_t)N * 26 * 1536 * es), pq_ws[9].p);
@@ -828,6 +840,13 @@ struct Engine {
     } else {
     prof_stage = 2;
     const bool tok_fuse = g_tok_fuse && g_ln_fuse && prec == kBF16 && N <= skinny_max_rows();
+    const bool early = tok_fuse && g_ar_early_exit;
+    if (early) {
+      ar_done.ensure(64);
+      TTR_HIP_CHECK(hipMemsetAsync(ar_done.p, 0, 4, stream));
+      if (d_ar) TTR_HIP_CHECK(hipMemsetAsync(d_ar, 0, (size_t)N * 26 * 95 * 4, stream));   // steps behind the exit stay zero
+      cur_skip = ar_done.as<int>(); cur_skip_n = N;
+    }
     for (int i = 0; i < 26; ++i) {
       if (tok_fuse) {   // token of step i = argmax of step i-1's logits, embedded and normalised in the GEMM's loader
         const Linear& L = pq.at("self_kv");
@@ -835,6 +854,7 @@ struct Engine {
         p.ln_in = emb; p.ln_ld = 384; p.ln_gamma = gc; p.ln_beta = bc; p.ln_eps = 1e-5f;
         p.tok = tk; p.tok_ld = 26; p.tok_col = i; p.tok_emb = emb; p.tok_max = 96;
         if (i > 0) { p.tok_logits = ar + (size_t)(i - 1) * 95; p.tok_logits_ld = 26 * 95; p.tok_C = 95; p.tok_pos = posq + (size_t)(i - 1) * E; }
+        if (early) { p.skip = cur_skip; p.skip_n = cur_skip_n; p.done_count = ar_done.as<int>(); p.tok_eos = 0; }
         p.C0 = L.k; p.B = 1; p.H = 1; p.W = N; p.ks = 1; p.dil = 1;
         p.wgt = L.w.p; p.bias = L.b.as<float>();
         p.out = (char*)kvcache + (size_t)i * 768 * es; p.out_ld = 26 * 768;
@@ -845,10 +865,11 @@ struct Engine {
         gemm(pq.at("self_kv"), t384, N, (char*)kvcache + (size_t)i * 768 * es, 26 * 768, kActNone);
       }
       if (i >= nsteps) break;
-      launch_dec_self_attn(prec, qself.as<float>(), kvcache, tk, att, N, 1, i, 0, stream);
+      launch_dec_self_attn(prec, qself.as<float>(), kvcache, tk, att, N, 1, i, 0, stream, cur_skip, cur_skip_n);
       decoder_tail(att, N, 1, posq + (size_t)i * E, 1, tgt, t384, d384b, d1536, kvmem, ar + (size_t)i * 95, 26 * 95);
       if (i + 1 < 26 && !tok_fuse) launch_argmax(ar + (size_t)i * 95, 26 * 95, 95, tk, 26, i + 1, N, stream);
     }
+    cur_skip = nullptr; cur_skip_n = 0;
     prof_stage = 1;
     }
     // ---- refinement pass (cloze mask + EOS key padding), R = 26 query rows per crop
@@ -1522,6 +1543,7 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "self_refine") set_dec_self_refine(value);
   else if (k == "cross_mfma") set_dec_cross_mfma(value);
   else if (k == "tok_fuse") g_tok_fuse = value;
+  else if (k == "ar_early_exit") g_ar_early_exit = value;
   else if (k == "mlp_fused") g_mlp_fused = value;   // 0 off, 1 from mlp_min_rows rows on, 2 always
   else if (k == "mlp_min_rows") g_mlp_min_rows = value;
   else if (k == "dec_mlp_fused") g_dec_mlp_fused = value;

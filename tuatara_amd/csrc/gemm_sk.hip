@@ -21,6 +21,7 @@ constexpr int SK_BM = 32, SK_BN = 32, SK_KC = 768;
 
 __global__ __launch_bounds__(256) void gemm_sk_kernel(ConvParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  if (p.skip && __builtin_nontemporal_load(p.skip) >= p.skip_n) return;   // every crop has emitted EOS: nothing left to decode
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
@@ -76,7 +77,15 @@ __global__ __launch_bounds__(256) void gemm_sk_kernel(ConvParams p) {
             const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
             if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
           }
-          if (live && tn == 0 && j == 0) p.tok[(int64_t)m * p.tok_ld + p.tok_col] = bi;
+          if (live && tn == 0 && j == 0) {
+            int* trow = p.tok + (int64_t)m * p.tok_ld;
+            trow[p.tok_col] = bi;
+            if (p.done_count && bi == p.tok_eos) {       // this crop's first EOS?  (column 0 is BOS)
+              bool first = true;
+              for (int c = 1; c < p.tok_col; ++c) first = first && trow[c] != p.tok_eos;
+              if (first) atomicAdd(p.done_count, 1);
+            }
+          }
           tokv = bi;
         } else if (live) {
           tokv = p.tok[(int64_t)m * p.tok_ld + p.tok_col];

@@ -91,9 +91,11 @@ void launch_dec_embed_ln(Precision prec, const int* tokens, const float* emb, co
                          void* out, int N, int i0, int i1, hipStream_t s);
 // self attention of R query rows per crop against the K/V cache [N][26][768].
 // mode 0 (AR): R == 1, query index qi0, keys 0..qi0.  mode 1 (refine): R == 26, cloze mask + EOS key padding.
-void launch_dec_self_attn(Precision prec, const float* q /*[26][384] f32*/, const void* kvcache, const int* tokens, void* out, int N, int R, int qi0, int mode, hipStream_t s);
+// skip / skip_n: the kernel returns at once when *skip >= skip_n (AR early exit, ConvParams::skip); bf16 per-row kernels only
+void launch_dec_self_attn(Precision prec, const float* q /*[26][384] f32*/, const void* kvcache, const int* tokens, void* out, int N, int R, int qi0, int mode, hipStream_t s,
+                          const int* skip = nullptr, int skip_n = 0);
 // cross attention of rows [N*R] (Q: T [N*R][384]) against kvmem T [N*128][768]
-void launch_dec_cross_attn(Precision prec, const void* q, const void* kvmem, void* out, int N, int R, hipStream_t s);
+void launch_dec_cross_attn(Precision prec, const void* q, const void* kvmem, void* out, int N, int R, hipStream_t s, const int* skip = nullptr, int skip_n = 0);
 // tokens[n*tok_ld + col] = argmax over C of logits[n*ld ..]
 void launch_argmax(const float* logits, int ld, int C, int* tokens, int tok_ld, int col, int N, hipStream_t s);
 void launch_fill_i32(int* p, int value, int n, int stride, hipStream_t s);

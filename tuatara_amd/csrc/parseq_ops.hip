@@ -252,7 +252,8 @@ void launch_dec_embed_ln(Precision prec, const int* tokens, const float* emb, co
 //   mode 1 (refine): key j hidden iff j == qi+1 (cloze) or tokens[n][0..j] contains EOS (key padding).
 template <typename T>
 __global__ __launch_bounds__(384) void dec_self_attn_kernel(const float* __restrict__ q, const T* __restrict__ kv, const int* __restrict__ tokens,
-                                                            T* __restrict__ out, int R, int qi0, int mode) {
+                                                            T* __restrict__ out, int R, int qi0, int mode, const int* skip, int skip_n) {
+  if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;   // AR early exit (see ConvParams::skip)
   __shared__ float sq[384];
   __shared__ float sp[12][28];
   __shared__ int visible[26];
@@ -378,7 +379,8 @@ __global__ __launch_bounds__(384) void dec_self_attn_refine_kernel(const float* 
 static int g_self_refine = 1;
 void set_dec_self_refine(int v) { g_self_refine = v; }
 
-void launch_dec_self_attn(Precision prec, const float* q, const void* kvcache, const int* tokens, void* out, int N, int R, int qi0, int mode, hipStream_t s) {
+void launch_dec_self_attn(Precision prec, const float* q, const void* kvcache, const int* tokens, void* out, int N, int R, int qi0, int mode, hipStream_t s,
+                          const int* skip, int skip_n) {
   if (N <= 0) return;
   if (prec == kBF16 && mode == 1 && R == 26 && g_self_refine) {
     static PerDeviceOnce once;
@@ -387,8 +389,8 @@ void launch_dec_self_attn(Precision prec, const float* q, const void* kvcache, c
     return;
   }
   dim3 grid(N * R);
-  if (prec == kBF16) hipLaunchKernelGGL(dec_self_attn_kernel<bf16>, grid, dim3(384), 0, s, q, (const bf16*)kvcache, tokens, (bf16*)out, R, qi0, mode);
-  else hipLaunchKernelGGL(dec_self_attn_kernel<float>, grid, dim3(384), 0, s, q, (const float*)kvcache, tokens, (float*)out, R, qi0, mode);
+  if (prec == kBF16) hipLaunchKernelGGL(dec_self_attn_kernel<bf16>, grid, dim3(384), 0, s, q, (const bf16*)kvcache, tokens, (bf16*)out, R, qi0, mode, skip, skip_n);
+  else hipLaunchKernelGGL(dec_self_attn_kernel<float>, grid, dim3(384), 0, s, q, (const float*)kvcache, tokens, (float*)out, R, qi0, mode, skip, skip_n);
 }
 
 // ------------------------------------------------------------------ decoder cross attention
@@ -438,7 +440,9 @@ __global__ __launch_bounds__(384) void dec_cross_attn_kernel(const T* __restrict
 // bf16 fast path: a K (or V) row of the crop's memory is 768 bytes = 48 lanes x 16 bytes, so one wave instruction fetches one
 // whole row (the kernel above reads 2 bytes per lane at a 1.5 KB stride).  4 waves x 32 keys each, online softmax per wave,
 // partial (max, sum, out) merged through LDS.  Lane c < 48 holds dims 8c..8c+7, head = c / 4.
-__global__ __launch_bounds__(256) void dec_cross_attn_rows_kernel(const bf16* __restrict__ q, const bf16* __restrict__ kvmem, bf16* __restrict__ out, int R) {
+__global__ __launch_bounds__(256) void dec_cross_attn_rows_kernel(const bf16* __restrict__ q, const bf16* __restrict__ kvmem, bf16* __restrict__ out, int R,
+                                                                  const int* skip, int skip_n) {
+  if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;   // AR early exit (see ConvParams::skip)
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
   __shared__ float sm[4][48], sl[4][48], so[4][48][8];
   const int row = blockIdx.x, n = row / R, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -517,11 +521,11 @@ __global__ __launch_bounds__(256) void dec_cross_attn_rows_kernel(const bf16* __
 static int g_cross_mfma = 1;
 void set_dec_cross_mfma(int v) { g_cross_mfma = v; }
 
-void launch_dec_cross_attn(Precision prec, const void* q, const void* kvmem, void* out, int N, int R, hipStream_t s) {
+void launch_dec_cross_attn(Precision prec, const void* q, const void* kvmem, void* out, int N, int R, hipStream_t s, const int* skip, int skip_n) {
   if (N <= 0) return;
   if (prec == kBF16 && g_cross_mfma && (R == 26 || g_cross_mfma == 2)) return launch_dec_cross_attn_mfma((const bf16*)q, (const bf16*)kvmem, (bf16*)out, N, R, s);   // refinement pass (attn_dec2.hip); 2: the AR steps' single row too
   dim3 grid(N * R);
-  if (prec == kBF16) hipLaunchKernelGGL(dec_cross_attn_rows_kernel, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)kvmem, (bf16*)out, R);
+  if (prec == kBF16) hipLaunchKernelGGL(dec_cross_attn_rows_kernel, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)kvmem, (bf16*)out, R, skip, skip_n);
   else hipLaunchKernelGGL(dec_cross_attn_kernel<float>, grid, dim3(384), 0, s, (const float*)q, (const float*)kvmem, (float*)out, R);
 }
 

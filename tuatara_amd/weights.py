@@ -272,9 +272,15 @@ def dfa_tables(seed: int = 0):
     reference tokenizer's shifted ids 69..94 and its eos_id 88 (tuatara.cpp:31-48) all occur in decoded strings."""
     rng = np.random.default_rng(seed + 4242)
     first = np.arange(64, dtype=np.int64)
+    # every class has a level 1..10 = the length of the string that starts with it (config 5 draws words of 3-10 characters);
+    # nxt[t] is a random class one level down, level-1 classes end the string: every chain reaches EOS within 10 steps, so a
+    # batch's autoregressive loop can stop early the way upstream PARSeq's does
+    level = np.zeros(95, np.int64)
+    level[1:] = 1 + rng.permutation(94) % 10
     nxt = np.zeros(95, np.int64)
     for t in range(1, 95):
-        nxt[t] = 0 if rng.random() < 0.2 else int(rng.integers(1, 95))               # a fifth of the classes end the string
+        if level[t] > 1:
+            nxt[t] = int(rng.choice(np.nonzero(level == level[t] - 1)[0]))
     return first, nxt
 
 
