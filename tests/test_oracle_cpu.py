@@ -229,7 +229,7 @@ def test_parseq_early_exit_invariance(oracle_models):
     from tests.parity_rules import upto_eos
     mask = np.arange(26)[None, :] < upto_eos(b.argmax(-1))[:, None]       # what the reference's string cut keeps (tuatara.cpp:497-502)
     assert np.array_equal(a.argmax(-1)[mask], b.argmax(-1)[mask])
-    assert np.abs(a - b)[mask].max() < 2e-4 and np.abs(a - b).max() < 2e-3  # fp32 summation order of the shorter batch shapes
+    assert np.abs(a - b)[mask].max() < 1e-3 and np.abs(a - b).max() < 5e-3  # fp32 summation order of the shorter batch shapes (logits reach ~30)
 
 
 def test_craft_oracle_golden(weights_random):
