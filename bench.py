@@ -166,10 +166,10 @@ def main():
     engs = [Engine(wdir, precision=args.precision, device=local_rank, bench_grid_boxes=grid) for _ in range(NC)]
     eng = engs[0]
     if args.decoder_mode is not None:
-        eng.lib.ttr_set_decoder_mode(args.decoder_mode)
+        eng.set_tuning(b"decoder_mode", args.decoder_mode)
     for kv in args.tune:
         k, v = kv.split("=")
-        assert eng.lib.ttr_set_tuning(k.encode(), int(v)) == 0, kv
+        assert eng.set_tuning(k.encode(), int(v)) == 0, kv
     # the 512-seed stream of SURVEY.md section 8d: step k of rank r works on pages (r * NB + k % NB) * P .. + P - 1 (mod 512), NB distinct
     # device-resident buffers rotated so that consecutive steps never see the same pages
     NB = max(3, args.buffers)

@@ -28,11 +28,11 @@ def test_attn_enc_bf16_against_numpy(eng_bf16, impl):
     qkv = rng.standard_normal((5, 128, 1152)).astype(np.float32) * 1.5
     qkv[1] *= 4.0                                                        # peaky softmax rows
     try:
-        assert eng_bf16.lib.ttr_set_tuning(b"attn_impl", impl) == 0
+        assert eng_bf16.set_tuning(b"attn_impl", impl) == 0
         out = eng_bf16.dbg_attn_enc(qkv)
         out2 = eng_bf16.dbg_attn_enc(qkv)
     finally:
-        eng_bf16.lib.ttr_set_tuning(b"attn_impl", 1)
+        eng_bf16.set_tuning(b"attn_impl", 1)
     ref = ref_attn(qkv)
     assert np.array_equal(out, out2)
     assert np.isfinite(out).all()
@@ -46,12 +46,12 @@ def test_attn_enc_generations_agree(eng_bf16):
     rng = np.random.default_rng(4)
     qkv = rng.standard_normal((7, 128, 1152)).astype(np.float32) * 2.0
     try:
-        eng_bf16.lib.ttr_set_tuning(b"attn_impl", 0)
+        eng_bf16.set_tuning(b"attn_impl", 0)
         a = eng_bf16.dbg_attn_enc(qkv)
-        eng_bf16.lib.ttr_set_tuning(b"attn_impl", 1)
+        eng_bf16.set_tuning(b"attn_impl", 1)
         b = eng_bf16.dbg_attn_enc(qkv)
     finally:
-        eng_bf16.lib.ttr_set_tuning(b"attn_impl", 1)
+        eng_bf16.set_tuning(b"attn_impl", 1)
     assert (np.abs(a - b) <= 2.0 ** -7 * np.abs(a) + 1e-6).all()          # at most one bf16 ulp (fp32 summation order)
     assert (a != b).mean() < 0.05
 

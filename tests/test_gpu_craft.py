@@ -84,11 +84,11 @@ def test_first_pair_wave_specialised_kernel_is_bit_identical(engines_random, hw)
     _, ebf = engines_random
     canvas = np.random.default_rng(hw[0] + hw[1]).integers(0, 256, (*hw, 3), dtype=np.uint8)
     try:
-        assert ebf.lib.ttr_set_tuning(b"c3_first_persistent", 1) == 0
+        assert ebf.set_tuning(b"c3_first_persistent", 1) == 0
         old = ebf.craft_heatmap(canvas)
-        assert ebf.lib.ttr_set_tuning(b"c3_first_persistent", 2) == 0
+        assert ebf.set_tuning(b"c3_first_persistent", 2) == 0
         new = ebf.craft_heatmap(canvas)
     finally:
-        ebf.lib.ttr_set_tuning(b"c3_first_persistent", 2)
+        ebf.set_tuning(b"c3_first_persistent", 2)
     assert np.isfinite(new).all()
     assert np.array_equal(old, new)

@@ -170,12 +170,12 @@ def test_gemm_skinny(eng_bf16, case):
     b = rng.standard_normal(Cout).astype(np.float32)
     ref = _ref_conv(x, w, b, 1, 1, act)
     try:
-        assert eng_bf16.lib.ttr_set_tuning(b"sk_max_rows", 2048) == 0
+        assert eng_bf16.set_tuning(b"sk_max_rows", 2048) == 0
         got = eng_bf16.dbg_conv(x, w, b, 1, 1, act)
-        eng_bf16.lib.ttr_set_tuning(b"sk_max_rows", 0)
+        eng_bf16.set_tuning(b"sk_max_rows", 0)
         other = eng_bf16.dbg_conv(x, w, b, 1, 1, act)
     finally:
-        eng_bf16.lib.ttr_set_tuning(b"sk_max_rows", 2048)
+        eng_bf16.set_tuning(b"sk_max_rows", 2048)
     assert np.abs(got - ref).max() < 2e-4
     assert np.abs(got - other).max() < 1e-4
 
@@ -197,14 +197,14 @@ def test_gemm_weight_stationary(eng_bf16, case):
     b = rng.standard_normal(Cout).astype(np.float32)
     ref = _ref_conv(x, w, b, 1, 1, act)
     try:
-        eng_bf16.lib.ttr_set_tuning(b"sk_max_rows", 0)
-        eng_bf16.lib.ttr_set_tuning(b"ws_min_rows", 1)
+        eng_bf16.set_tuning(b"sk_max_rows", 0)
+        eng_bf16.set_tuning(b"ws_min_rows", 1)
         got = eng_bf16.dbg_conv(x, w, b, 1, 1, act)
-        eng_bf16.lib.ttr_set_tuning(b"ws_min_rows", 0)
+        eng_bf16.set_tuning(b"ws_min_rows", 0)
         other = eng_bf16.dbg_conv(x, w, b, 1, 1, act)
     finally:
-        eng_bf16.lib.ttr_set_tuning(b"sk_max_rows", 2048)
-        eng_bf16.lib.ttr_set_tuning(b"ws_min_rows", 8192)
+        eng_bf16.set_tuning(b"sk_max_rows", 2048)
+        eng_bf16.set_tuning(b"ws_min_rows", 8192)
     assert np.abs(got - ref).max() < 2e-4
     assert np.abs(got - other).max() < 1e-4
 
@@ -221,15 +221,15 @@ def test_gemm_weight_stationary_bf16_output_long_streams(eng_bf16, case):
     w = bf((rng.standard_normal((Cout, 1, 1, K)) / np.sqrt(K)).astype(np.float32))
     b = rng.standard_normal(Cout).astype(np.float32)
     try:
-        eng_bf16.lib.ttr_set_tuning(b"dbg_bf16_out", 1)
-        eng_bf16.lib.ttr_set_tuning(b"ws_min_rows", 1)
+        eng_bf16.set_tuning(b"dbg_bf16_out", 1)
+        eng_bf16.set_tuning(b"ws_min_rows", 1)
         got = eng_bf16.dbg_conv(x, w, b, 1, 1, act)
         again = eng_bf16.dbg_conv(x, w, b, 1, 1, act)
-        eng_bf16.lib.ttr_set_tuning(b"ws_min_rows", 0)
+        eng_bf16.set_tuning(b"ws_min_rows", 0)
         other = eng_bf16.dbg_conv(x, w, b, 1, 1, act)
     finally:
-        eng_bf16.lib.ttr_set_tuning(b"dbg_bf16_out", 0)
-        eng_bf16.lib.ttr_set_tuning(b"ws_min_rows", 8192)
+        eng_bf16.set_tuning(b"dbg_bf16_out", 0)
+        eng_bf16.set_tuning(b"ws_min_rows", 8192)
     assert np.array_equal(got, again)                                   # no race: run to run identical
     scale = np.maximum(np.abs(other), 1.0)
     assert (np.abs(got - other) / scale).max() < 2 ** -6                # one bf16 ulp

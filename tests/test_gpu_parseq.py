@@ -5,6 +5,21 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def _same_path(a0, a1):
+    """Per crop: the AR token paths of two runs agree up to and including the first run's EOS (steps behind a batch's early exit
+    read zero in both, and a fork can move the exit step)."""
+    from tests.parity_rules import upto_eos
+    t0, t1 = a0.argmax(-1), a1.argmax(-1)
+    mask = np.arange(t0.shape[1])[None, :] < upto_eos(t0)[:, None]
+    return ((t0 == t1) | ~mask).all(1)
+
+
+def _ar_diff(a0, a1, same):
+    """|a1 - a0| of the crops in `same` over the AR steps that ran in both runs."""
+    ran = (np.abs(a0).max((0, 2)) > 0) & (np.abs(a1).max((0, 2)) > 0)
+    return np.abs(a1[same][:, ran] - a0[same][:, ran])
+
+
 def _crops(n, seed=0):
     return np.random.default_rng(seed).integers(0, 256, (n, 32, 128, 3), dtype=np.uint8)
 
@@ -58,12 +73,14 @@ def test_fused_ar_decoder_matches_kernel_per_op_loop(eng_bf16, G):
     rng = np.random.default_rng(11)
     crops = rng.integers(0, 256, (37, 32, 128, 3), dtype=np.uint8)     # 37: ragged last workgroup for every G
     try:
-        eng_bf16.lib.ttr_set_decoder_mode(0)
+        eng_bf16.set_tuning(b"ar_early_exit", 0)            # the fused kernel always runs the 26 steps: compare like with like
+        eng_bf16.set_tuning(b"decoder_mode", 0)
         l0, a0, i0 = eng_bf16.parseq_logits(crops, want_ar=True)
-        eng_bf16.lib.ttr_set_decoder_mode(G)
+        eng_bf16.set_tuning(b"decoder_mode", G)
         l1, a1, i1 = eng_bf16.parseq_logits(crops, want_ar=True)
     finally:
-        eng_bf16.lib.ttr_set_decoder_mode(1)
+        eng_bf16.set_tuning(b"decoder_mode", 1)
+        eng_bf16.set_tuning(b"ar_early_exit", 1)
     assert np.isfinite(l1).all() and np.isfinite(a1).all()
     d0 = np.abs(a1[:, 0] - a0[:, 0]).max(1)                            # step 0: no token feedback yet
     assert np.median(d0) < 1e-3 and d0.max() < 0.05                    # fp32 summation order; a crop may catch one bf16 boundary flip
@@ -80,17 +97,17 @@ def test_layernorm_fused_into_skinny_gemm_matches_separate_kernels(eng_bf16):
     rng = np.random.default_rng(12)
     crops = rng.integers(0, 256, (45, 32, 128, 3), dtype=np.uint8)     # 45 rows: ragged 32-row tile
     try:
-        assert eng_bf16.lib.ttr_set_tuning(b"ln_fuse", 0) == 0
+        assert eng_bf16.set_tuning(b"ln_fuse", 0) == 0
         l0, a0, i0 = eng_bf16.parseq_logits(crops, want_ar=True)
-        assert eng_bf16.lib.ttr_set_tuning(b"ln_fuse", 1) == 0
+        assert eng_bf16.set_tuning(b"ln_fuse", 1) == 0
         l1, a1, i1 = eng_bf16.parseq_logits(crops, want_ar=True)
     finally:
-        eng_bf16.lib.ttr_set_tuning(b"ln_fuse", 1)
+        eng_bf16.set_tuning(b"ln_fuse", 1)
     assert np.isfinite(a1).all()
     assert np.abs(a1[:, 0] - a0[:, 0]).max() < 0.05                    # step 0: no token feedback yet; bf16 boundary flips only
-    same_path = (a0.argmax(-1) == a1.argmax(-1)).all(1)
+    same_path = _same_path(a0, a1)
     assert same_path.mean() >= 0.9
-    assert np.abs(a1[same_path] - a0[same_path]).max() < 0.25
+    assert _ar_diff(a0, a1, same_path).max() < 0.25
     assert np.array_equal(i0[same_path], i1[same_path])
 
 
@@ -101,12 +118,12 @@ def test_refinement_self_attention_per_crop_kernel_is_bit_identical(eng_bf16):
     rng = np.random.default_rng(15)
     crops = rng.integers(0, 256, (45, 32, 128, 3), dtype=np.uint8)
     try:
-        assert eng_bf16.lib.ttr_set_tuning(b"self_refine", 0) == 0
+        assert eng_bf16.set_tuning(b"self_refine", 0) == 0
         l0, i0 = eng_bf16.parseq_logits(crops)
-        assert eng_bf16.lib.ttr_set_tuning(b"self_refine", 1) == 0
+        assert eng_bf16.set_tuning(b"self_refine", 1) == 0
         l1, i1 = eng_bf16.parseq_logits(crops)
     finally:
-        eng_bf16.lib.ttr_set_tuning(b"self_refine", 1)
+        eng_bf16.set_tuning(b"self_refine", 1)
     assert np.isfinite(l1).all()
     assert np.array_equal(l0, l1) and np.array_equal(i0, i1)
 
@@ -120,14 +137,14 @@ def test_refinement_block_through_fused_kernel_matches_separate_kernels(eng_bf16
     rng = np.random.default_rng(16)
     crops = rng.integers(0, 256, (n, 32, 128, 3), dtype=np.uint8)
     try:
-        assert eng_bf16.lib.ttr_set_tuning(b"dec_mlp_fused", 0) == 0
+        assert eng_bf16.set_tuning(b"dec_mlp_fused", 0) == 0
         l0, a0, i0 = eng_bf16.parseq_logits(crops, want_ar=True)
-        assert eng_bf16.lib.ttr_set_tuning(b"dec_mlp_fused", 1) == 0
-        assert eng_bf16.lib.ttr_set_tuning(b"dec_mlp_min_rows", 1) == 0
+        assert eng_bf16.set_tuning(b"dec_mlp_fused", 1) == 0
+        assert eng_bf16.set_tuning(b"dec_mlp_min_rows", 1) == 0
         l1, a1, i1 = eng_bf16.parseq_logits(crops, want_ar=True)
     finally:
-        eng_bf16.lib.ttr_set_tuning(b"dec_mlp_fused", 1)
-        eng_bf16.lib.ttr_set_tuning(b"dec_mlp_min_rows", 16384)
+        eng_bf16.set_tuning(b"dec_mlp_fused", 1)
+        eng_bf16.set_tuning(b"dec_mlp_min_rows", 16384)
     assert np.isfinite(l1).all()
     assert np.array_equal(a0, a1)                                      # the AR pass does not use the fused block
     d = np.abs(l1 - l0)
@@ -144,12 +161,12 @@ def test_refinement_cross_attention_on_matrix_cores_matches_per_row_kernel(eng_b
     rng = np.random.default_rng(17)
     crops = rng.integers(0, 256, (n, 32, 128, 3), dtype=np.uint8)
     try:
-        assert eng_bf16.lib.ttr_set_tuning(b"cross_mfma", 0) == 0
+        assert eng_bf16.set_tuning(b"cross_mfma", 0) == 0
         l0, a0, i0 = eng_bf16.parseq_logits(crops, want_ar=True)
-        assert eng_bf16.lib.ttr_set_tuning(b"cross_mfma", 1) == 0
+        assert eng_bf16.set_tuning(b"cross_mfma", 1) == 0
         l1, a1, i1 = eng_bf16.parseq_logits(crops, want_ar=True)
     finally:
-        eng_bf16.lib.ttr_set_tuning(b"cross_mfma", 1)
+        eng_bf16.set_tuning(b"cross_mfma", 1)
     assert np.isfinite(l1).all()
     assert np.array_equal(a0, a1)
     d = np.abs(l1 - l0)
@@ -165,18 +182,18 @@ def test_token_prologue_in_self_kv_gemm_matches_separate_kernels(eng_bf16):
     rng = np.random.default_rng(14)
     crops = rng.integers(0, 256, (45, 32, 128, 3), dtype=np.uint8)
     try:
-        assert eng_bf16.lib.ttr_set_tuning(b"tok_fuse", 0) == 0
+        assert eng_bf16.set_tuning(b"tok_fuse", 0) == 0
         l0, a0, i0 = eng_bf16.parseq_logits(crops, want_ar=True)
-        assert eng_bf16.lib.ttr_set_tuning(b"tok_fuse", 1) == 0
+        assert eng_bf16.set_tuning(b"tok_fuse", 1) == 0
         l1, a1, i1 = eng_bf16.parseq_logits(crops, want_ar=True)
         l2, i2 = eng_bf16.parseq_logits(crops, want_ar=False)       # 25 AR steps: the 26th token still comes from the prologue
     finally:
-        eng_bf16.lib.ttr_set_tuning(b"tok_fuse", 1)
+        eng_bf16.set_tuning(b"tok_fuse", 1)
     assert np.isfinite(a1).all()
     assert np.abs(a1[:, 0] - a0[:, 0]).max() < 0.05                    # step 0: BOS for every crop; bf16 boundary flips only
-    same_path = (a0.argmax(-1) == a1.argmax(-1)).all(1)
+    same_path = _same_path(a0, a1)
     assert same_path.mean() >= 0.9
-    assert np.abs(a1[same_path] - a0[same_path]).max() < 0.25
+    assert _ar_diff(a0, a1, same_path).max() < 0.25
     assert np.abs(l1[same_path] - l0[same_path]).max() < 0.25
     assert np.array_equal(i0[same_path], i1[same_path])
     assert np.array_equal(l1, l2) and np.array_equal(i1, i2)            # the AR-logit output buffer does not change the result
@@ -190,22 +207,22 @@ def test_fused_mlp_block_matches_separate_kernels(eng_bf16, n):
     rng = np.random.default_rng(13)
     crops = rng.integers(0, 256, (n, 32, 128, 3), dtype=np.uint8)
     try:
-        assert eng_bf16.lib.ttr_set_tuning(b"mlp_fused", 0) == 0
+        assert eng_bf16.set_tuning(b"mlp_fused", 0) == 0
         l0, a0, i0 = eng_bf16.parseq_logits(crops, want_ar=True)
-        assert eng_bf16.lib.ttr_set_tuning(b"mlp_fused", 2) == 0          # 2: also below the row count where it pays
+        assert eng_bf16.set_tuning(b"mlp_fused", 2) == 0          # 2: also below the row count where it pays
         l1, a1, i1 = eng_bf16.parseq_logits(crops, want_ar=True)
         l2, a2, i2 = eng_bf16.parseq_logits(crops, want_ar=True)
     finally:
-        eng_bf16.lib.ttr_set_tuning(b"mlp_fused", 1)
+        eng_bf16.set_tuning(b"mlp_fused", 1)
     assert np.isfinite(a1).all() and np.isfinite(l1).all()
     assert np.array_equal(a1, a2) and np.array_equal(l1, l2)              # run to run identical (no race in the weight ring)
     # A changed fp32 summation order anywhere in the 12-block encoder moves these random-noise crops' logits by ~0.25 (the same
     # spread as between the two GEMM kernel generations); the kernel's own accuracy is pinned in test_gpu_mlp.py.
     d0 = np.abs(a1[:, 0] - a0[:, 0])                                      # step 0: no token feedback yet
     assert np.median(d0) < 0.1 and np.percentile(d0, 99) < 0.8            # the tail: crops with a content bit inside its soft knee
-    same_path = (a0.argmax(-1) == a1.argmax(-1)).all(1)
+    same_path = _same_path(a0, a1)
     assert same_path.mean() >= 0.9
-    assert np.percentile(np.abs(a1[same_path] - a0[same_path]), 99.9) < 0.8
+    assert np.percentile(_ar_diff(a0, a1, same_path), 99.9) < 0.8
 
 
 @pytest.mark.parametrize("n", [200, 400])
@@ -215,20 +232,20 @@ def test_fused_encoder_block_kernels_at_their_batch_sizes(eng_bf16, n):
     rng = np.random.default_rng(n)
     crops = rng.integers(0, 256, (n, 32, 128, 3), dtype=np.uint8)
     try:
-        eng_bf16.lib.ttr_set_tuning(b"mlp_fused", 0); eng_bf16.lib.ttr_set_tuning(b"qkv_attn", 0)
+        eng_bf16.set_tuning(b"mlp_fused", 0); eng_bf16.set_tuning(b"qkv_attn", 0)
         l0, a0, i0 = eng_bf16.parseq_logits(crops, want_ar=True)
-        eng_bf16.lib.ttr_set_tuning(b"mlp_fused", 1); eng_bf16.lib.ttr_set_tuning(b"qkv_attn", 1)
+        eng_bf16.set_tuning(b"mlp_fused", 1); eng_bf16.set_tuning(b"qkv_attn", 1)
         l1, a1, i1 = eng_bf16.parseq_logits(crops, want_ar=True)
         l2, a2, i2 = eng_bf16.parseq_logits(crops, want_ar=True)
     finally:
-        eng_bf16.lib.ttr_set_tuning(b"mlp_fused", 1); eng_bf16.lib.ttr_set_tuning(b"qkv_attn", 1)
+        eng_bf16.set_tuning(b"mlp_fused", 1); eng_bf16.set_tuning(b"qkv_attn", 1)
     assert np.isfinite(a1).all() and np.isfinite(l1).all()
     assert np.array_equal(a1, a2) and np.array_equal(l1, l2)
     d0 = np.abs(a1[:, 0] - a0[:, 0]).max(1)
     assert np.median(d0) < 0.2 and np.percentile(d0, 95) < 0.8
-    same_path = (a0.argmax(-1) == a1.argmax(-1)).all(1)
+    same_path = _same_path(a0, a1)
     assert same_path.mean() >= 0.9
-    assert np.percentile(np.abs(a1[same_path] - a0[same_path]), 99.9) < 0.8
+    assert np.percentile(_ar_diff(a0, a1, same_path), 99.9) < 0.8
 
 
 @pytest.mark.parametrize("n", [45, 700])
@@ -240,13 +257,13 @@ def test_ar_early_exit_is_invisible_in_the_refined_logits(eng_bf16, n):
     every step that ran and read zero behind the exit."""
     crops = np.random.default_rng(21).integers(0, 256, (n, 32, 128, 3), dtype=np.uint8)
     try:
-        assert eng_bf16.lib.ttr_set_tuning(b"ar_early_exit", 0) == 0
+        assert eng_bf16.set_tuning(b"ar_early_exit", 0) == 0
         l0, a0, i0 = eng_bf16.parseq_logits(crops, want_ar=True)
-        assert eng_bf16.lib.ttr_set_tuning(b"ar_early_exit", 1) == 0
+        assert eng_bf16.set_tuning(b"ar_early_exit", 1) == 0
         l1, a1, i1 = eng_bf16.parseq_logits(crops, want_ar=True)
         l2, i2 = eng_bf16.parseq_logits(crops)
     finally:
-        eng_bf16.lib.ttr_set_tuning(b"ar_early_exit", 1)
+        eng_bf16.set_tuning(b"ar_early_exit", 1)
     assert np.array_equal(l0, l1) and np.array_equal(i0, i1) and np.array_equal(l1, l2)
     ran = np.abs(a1).max((0, 2)) > 0                       # steps that ran for the batch
     steps = int(ran.sum())

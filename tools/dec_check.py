@@ -12,10 +12,10 @@ eng = Engine(d, precision="bf16")
 rng = np.random.default_rng(0)
 for n in (70, 37):
     crops = rng.integers(0, 256, (n, 32, 128, 3), dtype=np.uint8)
-    eng.lib.ttr_set_decoder_mode(0)
+    eng.set_tuning(b"decoder_mode", 0)
     l0, a0, i0 = eng.parseq_logits(crops, want_ar=True)
     for mode in (4, 8, 16):
-        eng.lib.ttr_set_decoder_mode(mode)
+        eng.set_tuning(b"decoder_mode", mode)
         l1, a1, i1 = eng.parseq_logits(crops, want_ar=True)
         same_rows = (i0 == i1).all(1)
         # AR step 0 has no token feedback: a pure numerics comparison
@@ -31,10 +31,10 @@ for n in (70, 37):
 crops = rng.integers(0, 256, (320, 32, 128, 3), dtype=np.uint8)
 for n in (40, 320):
     for mode in (0, 4, 8, 16):
-        eng.lib.ttr_set_decoder_mode(mode)
+        eng.set_tuning(b"decoder_mode", mode)
         eng.parseq_logits(crops[:n])
         t0 = time.perf_counter()
         for _ in range(5):
             eng.parseq_logits(crops[:n])
         print(f"parseq n={n} mode={mode}: {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms (incl. H2D/D2H)", flush=True)
-eng.lib.ttr_set_decoder_mode(1)
+eng.set_tuning(b"decoder_mode", 1)

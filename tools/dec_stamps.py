@@ -8,9 +8,9 @@ d = tempfile.mkdtemp(); W.make_synthetic_weights(d, seed=0, structured=True)
 eng = Engine(d, precision="bf16")
 names = ["embed+LNc", "self_kv gemm", "self attn", "self_out gemm + LN1", "cross_q gemm", "cross attn", "cross_out gemm + LN2", "ffn1", "ffn2 + LNf", "head", "argmax"]
 crops = np.random.default_rng(0).integers(0, 256, (int(sys.argv[1]) if len(sys.argv) > 1 else 614, 32, 128, 3), dtype=np.uint8)
-eng.lib.ttr_set_tuning(b"dec_stamps", 1)
+eng.set_tuning(b"dec_stamps", 1)
 for G in (4, 8, 16):
-    eng.lib.ttr_set_decoder_mode(G)
+    eng.set_tuning(b"decoder_mode", G)
     eng.parseq_logits(crops); eng.parseq_logits(crops)
     buf = (C.c_ulonglong * (26 * 16))()
     assert eng.lib.ttr_dbg_dec_stamps(buf) == 0

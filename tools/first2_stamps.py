@@ -8,8 +8,8 @@ from tuatara_amd.engine import DeviceBuffer, Engine
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 d = tempfile.mkdtemp(); W.make_synthetic_weights(d, seed=0, structured=True)
 eng = Engine(d, precision="bf16")
-assert eng.lib.ttr_set_tuning(b"dec_stamps", 4) == 0
-assert eng.lib.ttr_set_tuning(b"c3_first_persistent", int(os.environ.get("F2_MODE", "2"))) == 0
+assert eng.set_tuning(b"dec_stamps", 4) == 0
+assert eng.set_tuning(b"c3_first_persistent", int(os.environ.get("F2_MODE", "2"))) == 0
 pages = np.full((P, 1024, 768, 3), 255, np.uint8)
 buf = DeviceBuffer(pages.nbytes); buf.upload(pages)
 for s in range(2): eng.pages_to_data_dev(buf, P, 1024, 768)

@@ -102,7 +102,7 @@ def main():
     rng = np.random.default_rng(0)
     for kv in args.tune:
         k, v = kv.split("=")
-        assert eng.lib.ttr_set_tuning(k.encode(), int(v)) == 0, kv
+        assert eng.set_tuning(k.encode(), int(v)) == 0, kv
 
     if not args.skip_check:
         print("== correctness (max |err| / max |ref|) ==")

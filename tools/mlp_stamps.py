@@ -6,7 +6,7 @@ from tuatara_amd import weights as W
 from tuatara_amd.engine import Engine
 d = tempfile.mkdtemp(); W.make_synthetic_weights(d, seed=0, structured=False)
 eng = Engine(d, precision="bf16")
-assert eng.lib.ttr_set_tuning(b"dec_stamps", 3) == 0
+assert eng.set_tuning(b"dec_stamps", 3) == 0
 M = (int(sys.argv[1]) if len(sys.argv) > 1 else 1280) * 128
 rng = np.random.default_rng(0)
 x = rng.standard_normal((M, 384)).astype(np.float32)

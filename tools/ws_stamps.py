@@ -6,11 +6,11 @@ from tuatara_amd import weights as W
 from tuatara_amd.engine import Engine
 d = tempfile.mkdtemp(); W.make_synthetic_weights(d, seed=0, structured=False)
 eng = Engine(d, precision="bf16")
-assert eng.lib.ttr_set_tuning(b"dec_stamps", 2) == 0
+assert eng.set_tuning(b"dec_stamps", 2) == 0
 us = C.c_float()
 M = int(sys.argv[1]) * 128 if len(sys.argv) > 1 else 1280 * 128
 for flags in [int(x) for x in os.environ.get('WS_FLAGS', '0,1,2,3').split(',')]:
-  eng.lib.ttr_set_tuning(b"ws_dbg_flags", flags)
+  eng.set_tuning(b"ws_dbg_flags", flags)
   print("== dbg flags", flags, "(1 = no stores, 2 = no loads)")
   for name, cout, act in (("qkv", 1152, 0), ("fc1", 1536, 2)):
       rc = eng.lib.ttr_bench_conv(eng.h, 1, 1, M, 384, 0, 1, 1, cout, act, 0, 3, C.byref(us))

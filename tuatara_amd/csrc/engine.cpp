@@ -28,7 +28,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/tuatara_hip.h"
+#include "../../include/tuatara_hip_debug.h"
 #include "common.h"
 #include "geometry.h"
 #include "kernels.h"
@@ -43,20 +43,42 @@ void hip_fail(const char* what, hipError_t e, const char* file, int line) {
 
 static thread_local std::string g_last_error;
 static unsigned long long* g_dec_dbg = nullptr;   // device buffer for dec_ar phase stamps (diagnostics)
-static int g_dbg_bf16_out = 0;     // ttr_dbg_conv on a bf16 engine: take the kernel's bf16 output (the path the engine uses) instead of the f32 one
-static int g_qkv_attn = 1;           // bf16 encoder: qkv projection + self-attention as one kernel (qkv_attn.hip) from g_qkv_attn_min crops on
-static int g_qkv_attn_min = 160;
-static int g_mlp_proj = 1;           // ... with the attention output projection in front of it in the same launch
-static int g_mlp_min_rows = 49152;   // = 384 crops
-static int g_dec_mlp_fused = 1;    // bf16 refinement pass: cross_out + norm2 + linear1 + GELU + linear2 + final norm through mlp_fused.hip
-static int g_dec_mlp_min_rows = 16384;
-static int g_mlp_fused = 1;        // bf16 encoder: norm2 + fc1 + GELU + fc2 + residual (+ the next LayerNorm) as one kernel (mlp_fused.hip)
-static int g_tok_fuse = 1;         // bf16 AR steps: argmax of the previous step + token embedding + norm_c inside the self_kv skinny GEMM
-static int g_ln_fuse = 1;          // bf16 decoder steps: LayerNorm computed inside the skinny GEMM's loader (gemm_sk ln_in)
-static int g_fuse_first = 1;       // bf16: CRAFT conv1_1 fused into conv1_2's loader (conv3p FIRST)
-static int g_enc_chunk = 0;        // crops per encoder group (0 = all crops at once)
-static int g_ar_early_exit = 1;    // bf16 kernel-per-op AR loop: the steps' kernels return at once when every crop of the batch has emitted EOS (upstream's break)
-static int g_decoder_mode = 1;   // 0 = kernel-per-op AR loop, 4/8/16 = fused kernel with that many crops per workgroup, else automatic
+// Kernel-selection knobs, per engine (ttr_engine_set_tuning); g_tuning_default seeds engines created afterwards (ttr_set_tuning)
+struct Tuning {
+  int dbg_bf16_out = 0;       // ttr_dbg_conv on a bf16 engine: take the kernel's bf16 output (the path the engine uses) instead of the f32 one
+  int qkv_attn = 1;           // bf16 encoder: qkv projection + self-attention as one kernel (qkv_attn.hip) from qkv_attn_min crops on
+  int qkv_attn_min = 160;
+  int mlp_proj = 1;           // ... with the attention output projection in front of it in the same launch
+  int mlp_min_rows = 49152;   // = 384 crops
+  int dec_mlp_fused = 1;      // bf16 refinement pass: cross_out + norm2 + linear1 + GELU + linear2 + final norm through mlp_fused.hip
+  int dec_mlp_min_rows = 16384;
+  int mlp_fused = 1;          // bf16 encoder: norm2 + fc1 + GELU + fc2 + residual (+ the next LayerNorm) as one kernel (mlp_fused.hip)
+  int tok_fuse = 1;           // bf16 AR steps: argmax of the previous step + token embedding + norm_c inside the self_kv skinny GEMM
+  int ln_fuse = 1;            // bf16 decoder steps: LayerNorm computed inside the skinny GEMM's loader (gemm_sk ln_in)
+  int fuse_first = 1;         // bf16: CRAFT conv1_1 fused into conv1_2's loader (conv3p FIRST)
+  int enc_chunk = 0;          // crops per encoder group (0 = all crops at once)
+  int ar_early_exit = 1;      // bf16 kernel-per-op AR loop: the steps' kernels return at once when every crop of the batch has emitted EOS (upstream's break)
+  int decoder_mode = 1;       // 0 = kernel-per-op AR loop, 4/8/16 = fused kernel with that many crops per workgroup, else automatic
+  bool set(const std::string& k, int value) {
+    if (k == "decoder_mode") decoder_mode = value;
+    else if (k == "enc_chunk") enc_chunk = value;
+    else if (k == "fuse_first") fuse_first = value;
+    else if (k == "ln_fuse") ln_fuse = value;
+    else if (k == "tok_fuse") tok_fuse = value;
+    else if (k == "ar_early_exit") ar_early_exit = value;
+    else if (k == "mlp_fused") mlp_fused = value;     // 0 off, 1 from mlp_min_rows rows on, 2 always
+    else if (k == "mlp_min_rows") mlp_min_rows = value;
+    else if (k == "dec_mlp_fused") dec_mlp_fused = value;
+    else if (k == "dec_mlp_min_rows") dec_mlp_min_rows = value;
+    else if (k == "mlp_proj") mlp_proj = value;
+    else if (k == "qkv_attn") qkv_attn = value;        // 0 off, 1 from qkv_attn_min crops on, 2 always
+    else if (k == "qkv_attn_min") qkv_attn_min = value;
+    else if (k == "dbg_bf16_out") dbg_bf16_out = value;
+    else return false;
+    return true;
+  }
+};
+static Tuning g_tuning_default;
 
 // ------------------------------------------------------------------ small utilities
 struct DevBuf {
@@ -285,6 +307,7 @@ class HostPool {
 
 struct Engine {
   ttr_config cfg;
+  Tuning tn = g_tuning_default;
   Precision prec;
   size_t es;  // element size of T
   hipStream_t stream = nullptr;
@@ -534,7 +557,14 @@ struct Engine {
     TTR_HIP_CHECK(hipEventCreateWithFlags(&copy_ev, hipEventDisableTiming));
     for (auto& x : done_ev) TTR_HIP_CHECK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
     for (auto& sl : evr) for (auto& x : sl) TTR_HIP_CHECK(hipEventCreate(&x));
-    host_pool.reset(new HostPool(std::min(15, std::max(1, (int)std::thread::hardware_concurrency() - 1))));
+    {   // host threads for the per-page calipers / decode: at most 15, and a fair share of the box when several ranks run on it
+      // (torch.distributed.run exports LOCAL_WORLD_SIZE); TUATARA_HOST_THREADS overrides
+      int hw = std::max(1, (int)std::thread::hardware_concurrency());
+      if (const char* lw = getenv("LOCAL_WORLD_SIZE")) { const int n = atoi(lw); if (n > 1) hw = std::max(1, hw / n); }
+      int workers = std::min(15, std::max(1, hw - 1));
+      if (const char* ht = getenv("TUATARA_HOST_THREADS")) { const int n = atoi(ht); if (n >= 1) workers = std::min(64, n); }
+      host_pool.reset(new HostPool(workers));
+    }
     for (auto& x : ev) TTR_HIP_CHECK(hipEventCreate(&x));
     load_craft(dir);
     load_parseq(dir);
@@ -586,7 +616,7 @@ struct Engine {
     auto buf = [&](size_t rows, int C) -> void* { return ws(k++, rows * C * es).p; };
     // 2x2 max-pools: fused into the producing conv's epilogue in bf16 mode (gemm2 / conv3p), a separate kernel in f32 mode
     const bool fp = prec == kBF16 && gemm_config() >= 0;
-    const bool first_fused = fp && g_fuse_first && H % 8 == 0 && W % 32 == 0;   // conv1_1 computed inside conv1_2's loader (conv3p FIRST)
+    const bool first_fused = fp && tn.fuse_first && H % 8 == 0 && W % 32 == 0;   // conv1_1 computed inside conv1_2's loader (conv3p FIRST)
     void* a0 = buf(prec == kBF16 ? 0 : M0, 32);
     void* c11 = buf(first_fused ? 0 : M0, 64);
     void* c12 = buf(fp ? 0 : M0, 64); void* p1 = buf(M1, 64);
@@ -673,7 +703,7 @@ struct Engine {
   // otherwise the LayerNorm kernel writes `scratch` and the plain GEMM follows
   void ln_gemm(const float* x, const std::string& ln_name, float eps, void* scratch, const Linear& L, int M, void* out, int out_ld, int act,
                float* out_f32 = nullptr, int out_f32_ld = 0) {
-    if (g_ln_fuse && prec == kBF16 && L.k == 384 && M <= skinny_max_rows()) {
+    if (tn.ln_fuse && prec == kBF16 && L.k == 384 && M <= skinny_max_rows()) {
       ConvParams p{};
       p.ln_in = x; p.ln_ld = 384; p.ln_gamma = pqf.at(ln_name + ".weight").as<float>(); p.ln_beta = pqf.at(ln_name + ".bias").as<float>(); p.ln_eps = eps;
       p.C0 = L.k; p.B = 1; p.H = 1; p.W = M; p.ks = 1; p.dil = 1;
@@ -716,7 +746,7 @@ struct Engine {
     gemm(pq.at("self_out"), sa, rows, nullptr, 0, kActNone, tgt, 384, resid_pos, 384, resid_mod);      // tgt = query + self_attn
     ln_gemm(tgt, d + "norm1", 1e-5f, t384, pq.at("cross_q"), rows, t384b, 384, kActNone);
     launch_dec_cross_attn(prec, t384b, kvmem, t384, N, R, stream, cur_skip, cur_skip_n);
-    if (R > 1 && prec == kBF16 && gemm_config() >= 0 && g_dec_mlp_fused && rows >= g_dec_mlp_min_rows) {
+    if (R > 1 && prec == kBF16 && gemm_config() >= 0 && tn.dec_mlp_fused && rows >= tn.dec_mlp_min_rows) {
       // refinement pass (26 rows per crop): the block behind the cross-attention is an encoder block's second half with other weights —
       // out projection + residual, norm2, linear1, GELU, linear2, residual, and the final norm as the "next LayerNorm" — one launch
       MlpParams q{};
@@ -749,10 +779,10 @@ struct Engine {
     launch_patchify(prec, d_crops, patches, N, stream);
     gemm(pq.at("patch"), patches, M, nullptr, 0, kActNone, x, E, pqf.at("encoder.pos_embed").as<float>(), E, 128);
     // The 12 encoder blocks run over groups of crops so that a group's widest intermediates (qkv, the MLP hidden) are
-    // re-read from the 256 MiB Infinity Cache rather than from HBM (g_enc_chunk crops per group; 0 = one group).
+    // re-read from the 256 MiB Infinity Cache rather than from HBM (tn.enc_chunk crops per group; 0 = one group).
     // the fused MLP block needs a panel of 128 rows per CU to fill the chip: below ~2 panels per CU the separate GEMMs win
-    const bool mlp_fused = prec == kBF16 && gemm_config() >= 0 && (g_mlp_fused == 2 || (g_mlp_fused == 1 && M >= g_mlp_min_rows));
-    const int CH = (g_enc_chunk > 0 && !mlp_fused) ? g_enc_chunk : N;
+    const bool mlp_fused = prec == kBF16 && gemm_config() >= 0 && (tn.mlp_fused == 2 || (tn.mlp_fused == 1 && M >= tn.mlp_min_rows));
+    const int CH = (tn.enc_chunk > 0 && !mlp_fused) ? tn.enc_chunk : N;
     for (int c0 = 0; c0 < N; c0 += CH) {
       const int nc = std::min(CH, N - c0), Mc = nc * 128;
       float* xc = x + (size_t)c0 * 128 * E;
@@ -760,14 +790,14 @@ struct Engine {
       for (int l = 0; l < 12; ++l) {
         std::string p = "encoder.blocks." + std::to_string(l) + ".";
         if (!mlp_fused) ln(xc, p + "norm1", 1e-6f, t384, Mc);
-        if (prec == kBF16 && gemm_config() >= 0 && (g_qkv_attn == 2 || (g_qkv_attn == 1 && nc >= g_qkv_attn_min)) && (size_t)Mc * E * 2 < ((size_t)1 << 31)) {   // (32-bit buffer offsets)
+        if (prec == kBF16 && gemm_config() >= 0 && (tn.qkv_attn == 2 || (tn.qkv_attn == 1 && nc >= tn.qkv_attn_min)) && (size_t)Mc * E * 2 < ((size_t)1 << 31)) {   // (32-bit buffer offsets)
           const Linear& L = pq.at(p + "qkv");
           timed(2.0 * Mc * E * 3 * E, [&] { launch_qkv_attn((const bf16*)t384, L.w.as<bf16>(), L.b.as<float>(), (bf16*)att, nc, stream); });
         } else {
           gemm(pq.at(p + "qkv"), t384, Mc, tbig, 3 * E, kActNone);
           launch_attn_enc(prec, tbig, att, nc, stream);
         }
-        const bool proj_in = mlp_fused && g_mlp_proj;            // the projection runs inside the fused block kernel
+        const bool proj_in = mlp_fused && tn.mlp_proj;            // the projection runs inside the fused block kernel
         if (!proj_in) gemm(pq.at(p + "proj"), att, Mc, nullptr, 0, kActNone, xc, E, xc, E, 0);
         if (mlp_fused) {
           // norm2 + fc1 + GELU + fc2 + residual in one kernel; it also leaves the next LayerNorm (the next block's norm1, or
@@ -816,7 +846,7 @@ struct Engine {
     // Fused persistent AR kernel (dec_fused.hip): ~150 us per step whatever N is (every workgroup is bound by its own
     // ~12 B/clk fetch rate on the weight and K/V streams).  With the skinny per-step GEMMs (gemm_sk.hip) the kernel-per-op
     // loop is faster up to ~1200 crops (measured at 40 / 320 / 614 crops), so the fused kernel is only picked beyond that.
-    const bool fused_ar = prec == kBF16 && g_decoder_mode != 0 && (g_decoder_mode == 4 || g_decoder_mode == 8 || g_decoder_mode == 16 || N > 2048);
+    const bool fused_ar = prec == kBF16 && tn.decoder_mode != 0 && (tn.decoder_mode == 4 || tn.decoder_mode == 8 || tn.decoder_mode == 16 || N > 2048);
     if (fused_ar) {
       DecArParams q{};
       auto W = [&](const char* k) { return pq.at(k).w.as<bf16>(); };
@@ -834,13 +864,13 @@ struct Engine {
       q.gelu_lut = gelu_lut_for_current_device();
       q.dbg = g_dec_dbg;
       q.N = N; q.nsteps = nsteps;
-      int G = g_decoder_mode;
+      int G = tn.decoder_mode;
       if (G != 4 && G != 8 && G != 16) G = N <= 1024 ? 4 : 8;
       launch_dec_ar(q, G, stream);
     } else {
     prof_stage = 2;
-    const bool tok_fuse = g_tok_fuse && g_ln_fuse && prec == kBF16 && N <= skinny_max_rows();
-    const bool early = tok_fuse && g_ar_early_exit;
+    const bool tok_fuse = tn.tok_fuse && tn.ln_fuse && prec == kBF16 && N <= skinny_max_rows();
+    const bool early = tok_fuse && tn.ar_early_exit;
     if (early) {
       ar_done.ensure(64);
       TTR_HIP_CHECK(hipMemsetAsync(ar_done.p, 0, 4, stream));
@@ -1392,7 +1422,7 @@ int ttr_dbg_conv(ttr_engine* e, const float* in0, int C0, const float* in1, int 
   p.in0 = d0.p; p.C0 = C0; p.in1 = C1 ? d1.p : nullptr; p.C1 = C1; p.relu0 = relu0; p.relu1 = relu1;
   p.B = B; p.H = H; p.W = W; p.ks = ks; p.dil = dil; p.wgt = L.w.p; p.bias = bias ? L.b.as<float>() : nullptr;
   p.out = nullptr; p.out_f32 = dout.as<float>(); p.out_f32_ld = Cout; p.Cout = Cout; p.M = (int)M; p.act = act;
-  const bool bf16_out = g_dbg_bf16_out && E.prec == kBF16;
+  const bool bf16_out = E.tn.dbg_bf16_out && E.prec == kBF16;
   if (bf16_out) { p.out = dout.p; p.out_ld = Cout; p.out_f32 = nullptr; p.out_f32_ld = 0; }
   launch_igemm(E.prec, p, E.stream);
   if (bf16_out) {
@@ -1530,33 +1560,21 @@ int ttr_dbg_conv_pool(ttr_engine* e, const float* in0, int C0, int B, int H, int
 }
 
 void ttr_set_gemm_config(int cfg) { set_gemm_config(cfg); }
-void ttr_set_decoder_mode(int mode) { g_decoder_mode = mode; }
+void ttr_set_decoder_mode(int mode) { g_tuning_default.decoder_mode = mode; }
 void ttr_last_host_us(ttr_engine* e, float out[8]) { for (int i = 0; i < 8; ++i) out[i] = e ? e->e->host_us[i] : 0.f; }
 int ttr_dbg_dec_stamps(unsigned long long* out) { return g_dec_dbg && hipMemcpy(out, g_dec_dbg, 26 * 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
+// process-wide: the kernel files' variant switches and diagnostics; engine-level keys set the default of engines created afterwards
 int ttr_set_tuning(const char* key, int value) {
   const std::string k = key ? key : "";
+  if (g_tuning_default.set(k, value)) return 0;
   if (k == "gemm_config") set_gemm_config(value);
-  else if (k == "decoder_mode") g_decoder_mode = value;
-  else if (k == "enc_chunk") g_enc_chunk = value;
-  else if (k == "fuse_first") g_fuse_first = value;
-  else if (k == "ln_fuse") g_ln_fuse = value;
   else if (k == "self_refine") set_dec_self_refine(value);
   else if (k == "cross_mfma") set_dec_cross_mfma(value);
-  else if (k == "tok_fuse") g_tok_fuse = value;
-  else if (k == "ar_early_exit") g_ar_early_exit = value;
-  else if (k == "mlp_fused") g_mlp_fused = value;   // 0 off, 1 from mlp_min_rows rows on, 2 always
-  else if (k == "mlp_min_rows") g_mlp_min_rows = value;
-  else if (k == "dec_mlp_fused") g_dec_mlp_fused = value;
-  else if (k == "dec_mlp_min_rows") g_dec_mlp_min_rows = value;
-  else if (k == "mlp_proj") g_mlp_proj = value;
   else if (k == "mlp_store_nt") set_mlp_store_nt(value);
   else if (k == "attn_impl") set_attn_impl(value);
-  else if (k == "qkv_attn") g_qkv_attn = value;        // 0 off, 1 from qkv_attn_min crops on, 2 always
-  else if (k == "qkv_attn_min") g_qkv_attn_min = value;
   else if (k == "ws_dbg_flags") set_gemm_ws_dbg_flags(value);
   else if (k == "ws_lean") set_gemm_ws_lean(value);
   else if (k == "store_policy") set_store_policy(value);
-  else if (k == "dbg_bf16_out") g_dbg_bf16_out = value;
   else if (k == "g2_x_ring3") set_gemm2_x_ring3(value);
   else if (k == "c3_xs1_max_cin") set_conv3p_single_stage_max_cin(value);
   else if (k == "c3_force_bn128") set_conv3p_force_bn128(value);
@@ -1573,6 +1591,16 @@ int ttr_set_tuning(const char* key, int value) {
   }
   else return -1;
   return 0;
+}
+// per engine (under the engine's lock: a batch in flight on another thread keeps the selection it started with)
+int ttr_engine_set_tuning(ttr_engine* e, const char* key, int value) {
+  if (!e) return -1;
+  const std::string k = key ? key : "";
+  {
+    std::lock_guard<std::mutex> lk(e->e->mu);
+    if (e->e->tn.set(k, value)) return 0;
+  }
+  return ttr_set_tuning(key, value);
 }
 
 int ttr_bench_conv(ttr_engine* e, int B, int H, int W, int C0, int C1, int ks, int dil, int Cout, int act, int f32_resid, int iters, float* avg_us) {

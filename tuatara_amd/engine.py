@@ -53,6 +53,7 @@ SYMBOLS = [
     ("ttr_pack_crops", _I, [_VP, _PU8, _I, _I, _I, _PF, _I, _F, _PU8, _PF]),
     ("ttr_parseq_logits", _I, [_VP, _PU8, _I, _PF, _PF, _PI]),
     ("ttr_decode_ids", _I, [_PI, _I, C.c_char_p]),
+    ("ttr_engine_set_tuning", _I, [_VP, C.c_char_p, _I]),
     ("ttr_dbg_conv", _I, [_VP, _PF, _I, _PF, _I, _I, _I, _I, _I, _I, _I, _I, _PF, _PF, _I, _I, _PF]),
     ("ttr_dbg_min_area_rect", _I, [_PF, _I, _PF]),
     ("ttr_dbg_component_rect", _I, [_I, _I, _I, _I, _I, _PI, _I, _I, _PF]),
@@ -209,6 +210,10 @@ class Engine:
         self.h = self.lib.ttr_create(weights_dir.encode(), C.byref(cfg))
         if not self.h:
             raise EngineError(self.lib.ttr_last_error().decode())
+
+    def set_tuning(self, key, value: int) -> int:
+        """Per-engine kernel-selection knob (ttr_engine_set_tuning); keys it does not know go to the process-wide diagnostics setter."""
+        return self.lib.ttr_engine_set_tuning(self.h, key if isinstance(key, bytes) else key.encode(), int(value))
 
     def close(self):
         if getattr(self, "h", None):
