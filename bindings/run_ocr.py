@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Counterpart of the reference's demo harness (bindings/run_ocr.py:85-107): open an image with PIL,
 .convert("RGB"), hand the numpy array to pytuatara.image_to_data(image, weights_dir, outputs_dir), print the
-result, and save an annotated copy (boxes on the page beside the recognised text).  Drawing uses PIL only
+result, and save an annotated copy (the reference's three panels: boxes on the page, text at the boxes, running text).  Drawing uses PIL only
 (the reference draws with cv2 and opens a window; neither is needed for the results).
 
   python bindings/run_ocr.py [image] [weights_dir] [outputs_dir]
@@ -19,19 +19,31 @@ sys.path.append(os.path.join(HERE, "..", "build", "bindings"))   # where the bui
 
 
 def annotate(image: np.ndarray, result) -> Image.Image:
-    """Page with boxes | white panel with each text drawn at its box position, reading order (y1, x1)."""
+    """The reference's three panels side by side (run_ocr.py:10-82), drawn with PIL: the page with its boxes | each text at its
+    box position | the texts as running text in reading order - sorted by (y1, x1) (:12), starting at (10, 30), wrapped at the
+    page width, 10 px between words and lines (:20-25, :62-75)."""
     page = Image.fromarray(image).convert("RGB")
+    w, h = page.size
     boxes = page.copy()
-    panel = Image.new("RGB", page.size, "white")
-    db, dp = ImageDraw.Draw(boxes), ImageDraw.Draw(panel)
+    panel = Image.new("RGB", page.size, "black")
+    running = Image.new("RGB", page.size, "black")
+    db, dp, dr = ImageDraw.Draw(boxes), ImageDraw.Draw(panel), ImageDraw.Draw(running)
+    tx, ty, gap = 10, 30, 10
     for item in sorted(result, key=lambda it: (it["bbox"][1], it["bbox"][0])):
-        x1, y1, x2, y2 = item["bbox"]
-        db.rectangle([x1, y1, x2, y2], outline=(0, 160, 0), width=2)
-        dp.rectangle([x1, y1, x2, y2], outline=(200, 200, 200), width=1)
-        dp.text((x1 + 2, y1 + 1), item["text"], fill=(0, 0, 0))
-    out = Image.new("RGB", (page.size[0] * 2, page.size[1]), "white")
-    out.paste(boxes, (0, 0))
-    out.paste(panel, (page.size[0], 0))
+        x1, y1, x2, y2 = (int(v) for v in item["bbox"])
+        text = item["text"]
+        db.rectangle([x1, y1, x2, y2], outline=(0, 255, 0), width=2)
+        dp.text((x1, y1), text, fill=(255, 0, 0))
+        l, t, r, btm = dr.textbbox((0, 0), text or " ")
+        tw, th = r - l, btm - t
+        if tx + tw > w:
+            tx = 10
+            ty += th + gap
+        dr.text((tx, ty - th), text, fill=(255, 0, 0))
+        tx += tw + gap
+    out = Image.new("RGB", (3 * w, h), "black")
+    for k, im in enumerate((boxes, panel, running)):
+        out.paste(im, (k * w, 0))
     return out
 
 

@@ -65,12 +65,19 @@ def test_cli_rejects_garbage(cli, tmp_path):
     assert out.returncode == 1 and "not a PNG" in out.stderr
 
 
-def test_run_ocr_annotate_draws_every_box():
+def test_run_ocr_annotate_draws_the_three_panels():
+    """The reference's draw_boxes_and_text (run_ocr.py:10-82): page with boxes | texts at their boxes | running text sorted by (y1, x1)."""
     sys.path.insert(0, os.path.join(ROOT, "bindings"))
     import run_ocr
     img = np.full((60, 100, 3), 255, np.uint8)
-    res = [{"text": "ab", "bbox": [10.0, 10.0, 40.0, 22.0]}, {"text": "cd", "bbox": [50.0, 30.0, 90.0, 44.0]}]
+    res = [{"text": "cd", "bbox": [50.0, 30.0, 90.0, 44.0]}, {"text": "ab", "bbox": [10.0, 10.0, 40.0, 22.0]}]
     out = np.array(run_ocr.annotate(img, res))
-    assert out.shape == (60, 200, 3)
-    assert (out[10, 10:40] != 255).any() and (out[30, 50:90] != 255).any()          # boxes on the page copy
-    assert (out[12:22, 112:140] != 255).any()                                        # text in the side panel
+    assert out.shape == (60, 300, 3)
+    assert (out[10, 10:40] != 255).any() and (out[30, 50:90] != 255).any()          # green boxes on the page copy
+    assert tuple(out[10, 20]) == (0, 255, 0)
+    assert (out[10:22, 110:140] != 0).any() and (out[30:44, 150:190] != 0).any()      # each text at its box, second panel
+    third = out[:, 200:]
+    ys, xs = np.nonzero(third.any(-1))
+    assert len(xs) and xs.min() >= 10 and ys.max() <= 32                              # running text starts at (10, 30), third panel
+    first_word = third[:, :10 + (xs.max() - 10) // 2]
+    assert first_word.any()                                                           # "ab" (smaller y1) comes first on the line

@@ -292,3 +292,38 @@ def test_malformed_inputs_are_rejected_loudly(weights, eng_f32, tmp_path):
         (d / "parseq.ttrw").write_bytes(bytes(bad))
         with pytest.raises(EngineError):
             Engine(str(d), precision="f32")
+
+
+def test_converted_torchscript_archives_end_to_end(tmp_path, oracle_models, funsd):
+    """SURVEY 8f-1 end to end: the reference loads two TorchScript archives (tuatara.cpp:333-336, :423-428).  Archives of that
+    layout are traced from the oracle models, saved under the reference's file names, converted by tools/convert_weights.py, and
+    the engine on the converted directory must give what the ARCHIVES give when run the reference's way (torch.jit.load ->
+    forward) through the oracle's post-processing: identical boxes and strings (f32 parity mode)."""
+    import subprocess
+    import torch
+    from oracle import pipeline, post
+    from tuatara_amd.engine import Engine
+    craft, parseq = oracle_models
+    d = pipeline.image_to_data(craft, parseq, funsd, debug=True)
+    n = len(d["crops"])
+    wd = str(tmp_path)
+    cpath, ppath = os.path.join(wd, "craft_traced_torchscript_model.pt"), os.path.join(wd, "parseq_torchscript.bin")
+    with torch.no_grad():
+        torch.jit.trace(craft, torch.zeros(1, 3, d["canvas"].shape[0], d["canvas"].shape[1]), check_trace=False).save(cpath)
+        torch.jit.trace(parseq, torch.zeros(n, 3, 32, 128), check_trace=False).save(ppath)   # the trace fixes the batch size
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "convert_weights.py"), wd], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    # the reference's way: load the archives, forward
+    tc, tp = torch.jit.load(cpath), torch.jit.load(ppath)
+    da = pipeline.detect(tc, funsd)
+    crops = np.stack([post.crop_resize(da["swapped"], b, True) for b in da["boxes"]])
+    assert len(crops) == n
+    with torch.no_grad():
+        logits = tp(torch.from_numpy(crops).permute(0, 3, 1, 2).float().div(255.0)).numpy()
+    texts, _ = post.decode_logits(logits)
+    ref = [{"text": t, "bbox": post.tesseract_bbox(b)} for t, b in zip(texts, da["boxes"])]
+    eng = Engine(wd, precision="f32")
+    got = eng.image_to_data(funsd)
+    eng.close()
+    assert [g["bbox"] for g in got] == [r["bbox"] for r in ref] and len(got) >= 40
+    assert [g["text"] for g in got] == [r["text"] for r in ref]

@@ -94,3 +94,15 @@ def test_pack_crops_colour_and_ragged_sizes(eng_f32):
     for i, b in enumerate(post.adjust_result_coordinates(rects, 1.0, 1.0)):
         ref = post.crop_resize(swapped, b, clamp=True)
         assert ref is not None and np.array_equal(crops[i], ref), i
+
+
+@pytest.mark.parametrize("hw", [(96, 112), (384, 304), (128, 64), (64, 448)])
+def test_ccl_statistics_paths(eng_f32, hw):
+    """Component statistics are folded per wave where a wave's 64 pixels share a row (W a multiple of 64) and accumulated per pixel
+    otherwise; both must give the oracle's boxes (area / bbox / text maximum feed the candidate filter and the calipers)."""
+    from oracle import post
+    from tests.golden.make_golden import synthetic_heatmap
+    heat = synthetic_heatmap(11 + hw[1], hw[0], hw[1])
+    got = eng_f32.ccl_boxes(heat)
+    ref, _, _ = post.get_detected_boxes(heat[..., 0], heat[..., 1])
+    assert len(ref) >= 3 and np.array_equal(got, ref)

@@ -87,8 +87,10 @@ __global__ void binarize_kernel(CclBuffers b, const float* __restrict__ heat_all
   c.tnorm[i] = tn;
   c.flags[i] = (uint8_t)(ts | (ls << 1) | (comb << 2));
   c.parent[i] = comb ? i : -1;
-  c.area[i] = 0; c.maxt[i] = 0u; c.cand_slot[i] = -1;
-  c.bbox[4 * i] = 0x7fffffff; c.bbox[4 * i + 1] = 0x7fffffff; c.bbox[4 * i + 2] = -1; c.bbox[4 * i + 3] = -1;
+  if (comb) {   // per-component statistics live at the component's root, and only a set pixel can become one: 28 B for ~5 % of the pixels
+    c.area[i] = 0; c.maxt[i] = 0u; c.cand_slot[i] = -1;
+    c.bbox[4 * i] = 0x7fffffff; c.bbox[4 * i + 1] = 0x7fffffff; c.bbox[4 * i + 2] = -1; c.bbox[4 * i + 3] = -1;
+  }
 }
 
 // Lock-free union-find (ECL-CC style).  Hooking is a CAS on a *true* root (parent[a]==a),
@@ -134,17 +136,48 @@ __global__ void ccl_merge_kernel(CclBuffers b, int H, int W) {
   if (y > 0 && parent[i - W] >= 0) uf_union(parent, i, i - W);
 }
 
-__global__ void ccl_flatten_stats_kernel(CclBuffers b, int H, int W) {
+// A wave covers 64 consecutive pixels of one row (W is a multiple of 64 on every canvas the engine pads to; otherwise the
+// per-pixel form below runs) and those mostly share a root: the lanes of one root are folded in the wave - count by popcount, x
+// extremes from the first / last lane of the group (lanes are in x order), the text maximum by a masked wave maximum - and ONE lane
+// issues the six atomics for the group.  Sums of ones, minima and maxima: the statistics are exactly those of the per-pixel form.
+__global__ __launch_bounds__(256) void ccl_flatten_stats_kernel(CclBuffers b, int H, int W) {
   const CclPage c = ccl_page(b, nullptr, H * W);
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= H * W || c.parent[i] < 0) return;
-  int r = uf_find_ro(c.parent, i);
-  __hip_atomic_store(&c.parent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // readers see the old ancestor or the root: both lead to r
-  int x = i % W, y = i / W;
-  atomicAdd(&c.area[r], 1);
-  atomicMin(&c.bbox[4 * r], x); atomicMin(&c.bbox[4 * r + 1], y);
-  atomicMax(&c.bbox[4 * r + 2], x); atomicMax(&c.bbox[4 * r + 3], y);
-  atomicMax(&c.maxt[r], __float_as_uint(fmaxf(c.tnorm[i], 0.f)));
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool set = i < H * W && c.parent[i] >= 0;
+  int r = -1;
+  if (set) {
+    r = uf_find_ro(c.parent, i);
+    __hip_atomic_store(&c.parent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // readers see the old ancestor or the root: both lead to r
+  }
+  const int x = i % W, y = i / W;
+  const unsigned tbits = set ? __float_as_uint(fmaxf(c.tnorm[i], 0.f)) : 0u;
+  if ((W & 63) != 0) {   // a wave may straddle two rows: per-pixel atomics
+    if (set) {
+      atomicAdd(&c.area[r], 1);
+      atomicMin(&c.bbox[4 * r], x); atomicMin(&c.bbox[4 * r + 1], y);
+      atomicMax(&c.bbox[4 * r + 2], x); atomicMax(&c.bbox[4 * r + 3], y);
+      atomicMax(&c.maxt[r], tbits);
+    }
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(set);
+  while (todo) {
+    const int lead = __ffsll((long long)todo) - 1;
+    const int rr = __shfl(r, lead);
+    const unsigned long long grp = __ballot(set && r == rr);
+    unsigned m = (set && r == rr) ? tbits : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if (lane == lead) {
+      const int x1 = x - lane + (63 - __clzll((long long)grp));          // x of the group's last lane
+      atomicAdd(&c.area[rr], __popcll(grp));
+      atomicMin(&c.bbox[4 * rr], x); atomicMin(&c.bbox[4 * rr + 1], y);
+      atomicMax(&c.bbox[4 * rr + 2], x1); atomicMax(&c.bbox[4 * rr + 3], y);
+      atomicMax(&c.maxt[rr], m);
+    }
+    todo &= ~grp;
+  }
 }
 
 __global__ void candidates_kernel(CclBuffers b, int npx, float text_threshold, int min_area) {
