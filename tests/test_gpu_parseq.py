@@ -278,3 +278,31 @@ def test_ar_early_exit_is_invisible_in_the_refined_logits(eng_bf16, n):
     longest = int(upto_eos(a0.argmax(-1)).max())
     print(f"AR early exit, {n} crops: {steps} of 26 steps ran; the longest string of the batch ends at step {longest}")
     assert steps <= longest + 1 < 26                       # the designed weights decode strings of at most 10 characters
+
+
+@pytest.mark.parametrize("n", [37, 700])
+def test_ar_tail_in_the_fused_kernel_matches_the_per_op_steps(eng_bf16, n):
+    """With the early exit, AR steps from `ar_tail_step` on run as one launch of dec_fused.hip in its tail form (it picks up the
+    tokens and the K/V cache of the kernel-per-op steps, and returns at once when the batch is done).  Forced to start at step 3,
+    where most crops are still decoding, it must continue the same greedy paths as the kernel-per-op loop (fp32 summation order
+    differs: engine-vs-engine bounds as for the full fused kernel)."""
+    crops = np.random.default_rng(23).integers(0, 256, (n, 32, 128, 3), dtype=np.uint8)
+    try:
+        assert eng_bf16.set_tuning(b"ar_tail_step", 0) == 0         # kernel-per-op all the way
+        l0, a0, i0 = eng_bf16.parseq_logits(crops, want_ar=True)
+        assert eng_bf16.set_tuning(b"ar_tail_step", 3) == 0
+        l1, a1, i1 = eng_bf16.parseq_logits(crops, want_ar=True)
+        l2, i2 = eng_bf16.parseq_logits(crops)
+    finally:
+        eng_bf16.set_tuning(b"ar_tail_step", 12)
+    assert np.isfinite(l1).all() and np.isfinite(a1).all()
+    assert np.array_equal(a0[:, :3], a1[:, :3])                     # the steps before the hand-over are the same launches
+    same_path = _same_path(a0, a1)
+    assert same_path.mean() >= 0.9
+    from tests.parity_rules import upto_eos
+    keep = np.arange(26)[None, :] < upto_eos(a0.argmax(-1))[:, None]
+    d = np.abs(a1 - a0)[same_path[:, None] & keep]
+    assert np.percentile(d, 99.9) < 0.25 and d.max() < 1.5
+    keep_r = np.arange(26)[None, :] < upto_eos(i0)[:, None]
+    assert np.array_equal(i0[same_path][keep_r[same_path]], i1[same_path][keep_r[same_path]])
+    assert np.array_equal(l1, l2) and np.array_equal(i1, i2)

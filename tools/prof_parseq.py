@@ -1,5 +1,5 @@
 """GPU box tool for rocprofv3 passes over the recogniser alone: PARSeq on one batch of random crops (default 1280 = the benchmark's
-32 pages x 40 crops), a few forwards, nothing else.   python3 tools/prof_parseq.py [crops] [iterations]"""
+32 pages x 40 crops), a few forwards, nothing else.   python3 tools/prof_parseq.py [crops] [iterations] [key=value ...]"""
 import os, sys, tempfile
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,6 +11,9 @@ it = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 d = tempfile.mkdtemp()
 W.make_synthetic_weights(d, seed=0, structured=True)
 eng = Engine(d, precision="bf16")
+for kv in sys.argv[3:]:                      # key=value tuning knobs (Engine.set_tuning)
+    k, v = kv.split("=")
+    assert eng.set_tuning(k, int(v)) == 0, kv
 crops = np.random.default_rng(0).integers(0, 256, (N, 32, 128, 3), dtype=np.uint8)
 for _ in range(it):
     lg, ids = eng.parseq_logits(crops)

@@ -110,6 +110,7 @@ __device__ __forceinline__ void unpack8(const u32x4& u, float* f) {
 
 __global__ __launch_bounds__(NTHREADS) void dec_ar_kernel(DecArParams p, int G) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (p.skip && __builtin_nontemporal_load(p.skip) >= p.skip_n) return;   // tail form: every crop of the batch has emitted EOS
   Smem& S = *reinterpret_cast<Smem*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * G;
@@ -123,13 +124,39 @@ __global__ __launch_bounds__(NTHREADS) void dec_ar_kernel(DecArParams p, int G) 
   for (int i = tid; i < 16 * 26; i += NTHREADS) S.tok[i] = (i % 26 == 0) ? 95 : 96;   // BOS, then PAD
   for (int i = tid; i < 512; i += NTHREADS) reinterpret_cast<uint4*>(S.glut)[i] = reinterpret_cast<const uint4*>(p.gelu_lut)[i];
   __syncthreads();
-  for (int i = tid; i < rows * 26; i += NTHREADS) p.tokens[(size_t)n0 * 26 + i] = S.tok[i];
+  if (p.first_step == 0) {
+    for (int i = tid; i < rows * 26; i += NTHREADS) p.tokens[(size_t)n0 * 26 + i] = S.tok[i];
+  } else {
+    // tail form: take over the tokens the kernel-per-op steps produced, form token first_step (first maximal index of the
+    // previous step's logits, as argmax_kernel / the skinny GEMM's prologue do), and leave if this workgroup's crops are all done
+    for (int i = tid; i < rows * 26; i += NTHREADS) if (i % 26 < p.first_step) S.tok[i] = p.tokens[(size_t)n0 * 26 + i];
+    __syncthreads();
+    for (int r = wave; r < rows; r += NWAVES) {
+      const float* x = p.prev_logits + (size_t)(n0 + r) * p.prev_ld;
+      float best = -INFINITY; int bi = 0x7fffffff;
+      for (int c = lane; c < 95; c += 64) { const float v = x[c]; if (v > best) { best = v; bi = c; } }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      }
+      if (lane == 0) { S.tok[r * 26 + p.first_step] = bi; p.tokens[(size_t)(n0 + r) * 26 + p.first_step] = bi; }
+    }
+    __syncthreads();
+    int open_rows = 0;
+    for (int r = 0; r < rows; ++r) {
+      bool eos = false;
+      for (int c = 1; c <= p.first_step; ++c) eos = eos || S.tok[r * 26 + c] == 0;
+      open_rows += eos ? 0 : 1;
+    }
+    if (open_rows == 0) return;                   // (uniform: every thread read the same LDS words)
+  }
 
   const float kScale = 0.17677669529663687f;   // 1/sqrt(32)
   // optional phase stamps (diagnostic builds of the caller only): dbg[step*16 + phase] = shader clock, workgroup 0, thread 0
 #define DEC_STAMP(ph) do { if (p.dbg && blockIdx.x == 0 && tid == 0) p.dbg[i * 16 + (ph)] = __builtin_readcyclecounter(); } while (0)
 
-  for (int i = 0; i < 26; ++i) {
+  for (int i = p.first_step; i < 26; ++i) {
     DEC_STAMP(0);
     // ---- content row i: emb[tok] (+ pos_q[i-1]) -> norm_c -> xa
     for (int r = wave; r < rows; r += NWAVES) {

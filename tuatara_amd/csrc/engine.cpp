@@ -57,6 +57,7 @@ struct Tuning {
   int ln_fuse = 1;            // bf16 decoder steps: LayerNorm computed inside the skinny GEMM's loader (gemm_sk ln_in)
   int fuse_first = 1;         // bf16: CRAFT conv1_1 fused into conv1_2's loader (conv3p FIRST)
   int enc_chunk = 0;          // crops per encoder group (0 = all crops at once)
+  int ar_tail_step = 12;      // with ar_early_exit: AR steps from this one on run as ONE launch of the fused kernel (which returns at once when the batch is done)
   int ar_early_exit = 1;      // bf16 kernel-per-op AR loop: the steps' kernels return at once when every crop of the batch has emitted EOS (upstream's break)
   int decoder_mode = 1;       // 0 = kernel-per-op AR loop, 4/8/16 = fused kernel with that many crops per workgroup, else automatic
   bool set(const std::string& k, int value) {
@@ -66,6 +67,7 @@ struct Tuning {
     else if (k == "ln_fuse") ln_fuse = value;
     else if (k == "tok_fuse") tok_fuse = value;
     else if (k == "ar_early_exit") ar_early_exit = value;
+    else if (k == "ar_tail_step") ar_tail_step = value;
     else if (k == "mlp_fused") mlp_fused = value;     // 0 off, 1 from mlp_min_rows rows on, 2 always
     else if (k == "mlp_min_rows") mlp_min_rows = value;
     else if (k == "dec_mlp_fused") dec_mlp_fused = value;
@@ -847,7 +849,7 @@ struct Engine {
     // ~12 B/clk fetch rate on the weight and K/V streams).  With the skinny per-step GEMMs (gemm_sk.hip) the kernel-per-op
     // loop is faster up to ~1200 crops (measured at 40 / 320 / 614 crops), so the fused kernel is only picked beyond that.
     const bool fused_ar = prec == kBF16 && tn.decoder_mode != 0 && (tn.decoder_mode == 4 || tn.decoder_mode == 8 || tn.decoder_mode == 16 || N > 2048);
-    if (fused_ar) {
+    auto dec_params = [&]() {
       DecArParams q{};
       auto W = [&](const char* k) { return pq.at(k).w.as<bf16>(); };
       auto Bv = [&](const char* k) { return pq.at(k).b.as<float>(); };
@@ -864,6 +866,10 @@ struct Engine {
       q.gelu_lut = gelu_lut_for_current_device();
       q.dbg = g_dec_dbg;
       q.N = N; q.nsteps = nsteps;
+      return q;
+    };
+    if (fused_ar) {
+      DecArParams q = dec_params();
       int G = tn.decoder_mode;
       if (G != 4 && G != 8 && G != 16) G = N <= 1024 ? 4 : 8;
       launch_dec_ar(q, G, stream);
@@ -877,7 +883,17 @@ struct Engine {
       if (d_ar) TTR_HIP_CHECK(hipMemsetAsync(d_ar, 0, (size_t)N * 26 * 95 * 4, stream));   // steps behind the exit stay zero
       cur_skip = ar_done.as<int>(); cur_skip_n = N;
     }
+    // with the early exit, the steps from ar_tail_step on are ONE launch of the fused kernel in its tail form: when every crop
+    // has emitted EOS by then (the usual case: words are short) it returns at once, instead of ~9 returning launches per step
+    const int tail_at = (early && tn.ar_tail_step > 0 && tn.ar_tail_step < nsteps) ? tn.ar_tail_step : 26;
     for (int i = 0; i < 26; ++i) {
+      if (i == tail_at) {
+        DecArParams q = dec_params();
+        q.first_step = i; q.prev_logits = ar + (size_t)(i - 1) * 95; q.prev_ld = 26 * 95; q.skip = cur_skip; q.skip_n = cur_skip_n;
+        if (!d_ar) q.ar_logits = nullptr;
+        launch_dec_ar(q, N <= 1024 ? 4 : 8, stream);
+        break;
+      }
       if (tok_fuse) {   // token of step i = argmax of step i-1's logits, embedded and normalised in the GEMM's loader
         const Linear& L = pq.at("self_kv");
         ConvParams p{};

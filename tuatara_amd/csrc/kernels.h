@@ -133,6 +133,10 @@ struct DecArParams {
   const void* gelu_lut;  // gelu_lut_for_current_device()
   unsigned long long* dbg;   // optional [26][16] phase stamps of workgroup 0 (diagnostics), else null
   int N, nsteps;         // nsteps: 25 (logits of the 26th step are never used) or 26
+  // Tail form (the kernel-per-op loop ran steps 0 .. first_step-1): the tokens of positions <= first_step-1 are read from `tokens`,
+  // token first_step is the argmax of prev_logits (step first_step-1's logits, row stride prev_ld), and the launch returns at once
+  // when *skip >= skip_n (every crop of the batch has emitted EOS); a workgroup whose own crops all have is done as well.
+  int first_step; const float* prev_logits; int prev_ld; const int* skip; int skip_n;
 };
 void launch_dec_ar(const DecArParams& p, int crops_per_workgroup, hipStream_t s);
 
