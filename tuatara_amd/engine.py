@@ -9,6 +9,7 @@ from __future__ import annotations
 import collections.abc
 import ctypes as C
 import os
+import sys
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -199,6 +200,17 @@ class DeviceBuffer:
 class Engine:
     def __init__(self, weights_dir: str, precision: str = "bf16", device: int = 0, strict_crops: bool = False, **overrides):
         self.lib = load()
+        # A process that also uses torch's GPU runtime (bench.py, tuatara_amd/dist.py over RCCL) must let torch initialise FIRST:
+        # the torch wheel bundles its own ROCm 7.0 HIP / HSA libraries, and they do not come up once the system ROCm 7.2 runtime the
+        # engine links has claimed the device ("No HIP GPUs are available"); the other order works.  So if torch is already
+        # imported, bring its runtime up before the engine's.
+        _t = sys.modules.get("torch")
+        if _t is not None and hasattr(_t, "cuda"):
+            try:
+                if _t.cuda.is_available():
+                    _t.cuda.init()
+            except Exception:
+                pass
         cfg = Config()
         self.lib.ttr_config_default(C.byref(cfg))
         cfg.precision = PREC_F32 if precision in ("f32", "fp32", PREC_F32) else PREC_BF16
