@@ -348,7 +348,7 @@ def main():
         q = prof["parseq"]
         pq_tflops = (q["flops"] / (q["ms"] * 1e-3) / 1e12) if q["ms"] else None
         out = {
-            "metric": "pages/sec whole-node (1024x768, ~40 words/page)", "value": total_pages / dt, "unit": "pages/s",
+            "metric": "pages/sec whole-node (1024x768, ~40 crops/page)", "value": total_pages / dt, "unit": "pages/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "configs[4]: synthetic stream of 1024x768 pages (~40 detected crops each), page-level DP, "
