@@ -52,6 +52,7 @@ struct Tuning {
   int mlp_min_rows = 49152;   // = 384 crops
   int dec_mlp_fused = 1;      // bf16 refinement pass: cross_out + norm2 + linear1 + GELU + linear2 + final norm through mlp_fused.hip
   int dec_mlp_min_rows = 16384;
+  int mlp_pair = 0;           // the fused MLP block as the pair-split kernel (mlp_pair.hip: two waves per SIMD; the projection stays a separate GEMM)
   int mlp_fused = 1;          // bf16 encoder: norm2 + fc1 + GELU + fc2 + residual (+ the next LayerNorm) as one kernel (mlp_fused.hip)
   int tok_fuse = 1;           // bf16 AR steps: argmax of the previous step + token embedding + norm_c inside the self_kv skinny GEMM
   int ln_fuse = 1;            // bf16 decoder steps: LayerNorm computed inside the skinny GEMM's loader (gemm_sk ln_in)
@@ -73,6 +74,7 @@ struct Tuning {
     else if (k == "dec_mlp_fused") dec_mlp_fused = value;
     else if (k == "dec_mlp_min_rows") dec_mlp_min_rows = value;
     else if (k == "mlp_proj") mlp_proj = value;
+    else if (k == "mlp_pair") mlp_pair = value;
     else if (k == "qkv_attn") qkv_attn = value;        // 0 off, 1 from qkv_attn_min crops on, 2 always
     else if (k == "qkv_attn_min") qkv_attn_min = value;
     else if (k == "dbg_bf16_out") dbg_bf16_out = value;
@@ -799,7 +801,7 @@ struct Engine {
           gemm(pq.at(p + "qkv"), t384, Mc, tbig, 3 * E, kActNone);
           launch_attn_enc(prec, tbig, att, nc, stream);
         }
-        const bool proj_in = mlp_fused && tn.mlp_proj;            // the projection runs inside the fused block kernel
+        const bool proj_in = mlp_fused && tn.mlp_proj && !tn.mlp_pair;   // the projection runs inside the fused block kernel
         if (!proj_in) gemm(pq.at(p + "proj"), att, Mc, nullptr, 0, kActNone, xc, E, xc, E, 0);
         if (mlp_fused) {
           // norm2 + fc1 + GELU + fc2 + residual in one kernel; it also leaves the next LayerNorm (the next block's norm1, or
@@ -812,7 +814,7 @@ struct Engine {
           q.w2p = fc2_packed[l].as<bf16>(); q.b2 = pq.at(p + "fc2").b.as<float>();
           q.nln_g = pqf.at(nx + ".weight").as<float>(); q.nln_b = pqf.at(nx + ".bias").as<float>(); q.nln_eps = 1e-6f; q.nln_out = (bf16*)t384;
           if (proj_in) { q.att = (const bf16*)att; q.wpp = proj_packed[l].as<bf16>(); q.bp = pq.at(p + "proj").b.as<float>(); }
-          timed(2.0 * Mc * E * 4 * E * 2 + (proj_in ? 2.0 * Mc * E * E : 0.0), [&] { launch_mlp_fused(q, stream); });
+          timed(2.0 * Mc * E * 4 * E * 2 + (proj_in ? 2.0 * Mc * E * E : 0.0), [&] { if (tn.mlp_pair) launch_mlp_pair(q, stream); else launch_mlp_fused(q, stream); });
           continue;
         }
         ln(xc, p + "norm2", 1e-6f, t384, Mc);
@@ -1485,7 +1487,7 @@ int ttr_dbg_mlp(ttr_engine* e, const float* x, int M, const float* ln_g, const f
     upf(dbp, bp, D);
     q.att = datt.as<bf16>(); q.wpp = dwp.as<bf16>(); q.bp = dbp.as<float>();
   }
-  launch_mlp_fused(q, E.stream);
+  if (E.tn.mlp_pair && !att) launch_mlp_pair(q, E.stream); else launch_mlp_fused(q, E.stream);
   TTR_HIP_CHECK(hipMemcpyAsync(x_out, dout.p, (size_t)M * D * 4, hipMemcpyDeviceToHost, E.stream));
   TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
   if (nln_out) {

@@ -115,6 +115,8 @@ struct MlpParams {
   int M;
 };
 void launch_mlp_fused(const MlpParams& p, hipStream_t s);
+// ---- mlp_pair.hip: the same block with two waves per SIMD (a pair of waves shares 32 rows and splits hidden units / output channels); no projection
+void launch_mlp_pair(const MlpParams& p, hipStream_t s);
 // host-side packing of the weight operands into the kernel's LDS images (bf16 bits): w1 f32 [1536][384] -> 48 x 24 KiB;
 // w f32 [384][K] (fc2: K = 1536, attention projection: K = 384) -> K/32 x 24 KiB
 void pack_mlp_w1(const float* w1, uint16_t* out);
