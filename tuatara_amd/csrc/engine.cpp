@@ -1589,6 +1589,7 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "self_refine") set_dec_self_refine(value);
   else if (k == "cross_mfma") set_dec_cross_mfma(value);
   else if (k == "mlp_store_nt") set_mlp_store_nt(value);
+  else if (k == "pair_ablate") set_mlp_pair_ablate(value);
   else if (k == "attn_impl") set_attn_impl(value);
   else if (k == "ws_dbg_flags") set_gemm_ws_dbg_flags(value);
   else if (k == "ws_lean") set_gemm_ws_lean(value);
@@ -1605,7 +1606,8 @@ int ttr_set_tuning(const char* key, int value) {
     if (!value) g_dec_dbg = nullptr;
     set_gemm_ws_stamps(value == 2 ? g_dec_dbg : nullptr);
     set_conv3p_stamps(value == 4 ? g_dec_dbg : nullptr);    // 4: ... or conv3p_first2 stamps
-    set_mlp_stamps(value == 3 ? g_dec_dbg : nullptr);       // 3: ... or mlp_fused stamps   // 2: the same buffer takes gemm_ws stamps instead
+    set_mlp_stamps(value == 3 ? g_dec_dbg : nullptr);
+    set_mlp_pair_stamps(value == 5 ? g_dec_dbg : nullptr);  // 5: mlp_pair panel stamps       // 3: ... or mlp_fused stamps   // 2: the same buffer takes gemm_ws stamps instead
   }
   else return -1;
   return 0;

@@ -113,10 +113,13 @@ struct MlpParams {
   int store_nt;            // set by the launcher: streaming policy on the epilogue stores
   unsigned long long* dbg; // optional [48][8] shader-clock stamps of workgroup 0 / wave 0 over its first panel (diagnostics)
   int M;
+  int ablate;              // mlp_pair timing experiments (results are wrong): 1 no weight DMA after the first items, 2 no GELU, 4 no GEMM2, 8 no GEMM1, 16 no epilogue stores
 };
 void launch_mlp_fused(const MlpParams& p, hipStream_t s);
 // ---- mlp_pair.hip: the same block with two waves per SIMD (a pair of waves shares 32 rows and splits hidden units / output channels); no projection
 void launch_mlp_pair(const MlpParams& p, hipStream_t s);
+void set_mlp_pair_stamps(unsigned long long* dev_buf);   // >= 400 u64 or null: panel stamps of workgroup 0
+void set_mlp_pair_ablate(int v);   // timing experiments (MlpParams::ablate)
 // host-side packing of the weight operands into the kernel's LDS images (bf16 bits): w1 f32 [1536][384] -> 48 x 24 KiB;
 // w f32 [384][K] (fc2: K = 1536, attention projection: K = 384) -> K/32 x 24 KiB
 void pack_mlp_w1(const float* w1, uint16_t* out);

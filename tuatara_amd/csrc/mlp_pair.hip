@@ -47,16 +47,27 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t p_rsrc(const void* base, unsig
 }
 // LDS accesses next to the LDS-DMA stream are inline asm (hipcc drains the vector-memory queue before any it can see)
 #define PR_RD128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-#define PR_LANE() __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))
+// the lane id, re-read from the hardware wherever it is needed: volatile, so that neither it nor anything derived from it is
+// hoisted out of the chunk loop and kept (= spilled: a spill reload is a vector-memory load whose wait stalls the weight DMA)
+__device__ __forceinline__ unsigned pr_lane() {
+  unsigned l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+#define PR_LANE() pr_lane()
 #define PR_WAITF(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]))
 }  // namespace
 
-__global__ __launch_bounds__(512, 2) void mlp_pair_kernel(MlpParams p) {
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
+// HH = the wave's half, a compile-time constant per code path: half 0 runs an iteration as [GEMM2 of the previous chunk, GEMM1 + GELU
+// of this one], half 1 the other way round, so the SIMD's two waves are half an iteration apart from barrier to barrier (one's
+// fragment waits and GELU beside the other's MFMAs) - a run-time `if` around the two orders made hipcc spill inside the loop
+template <int HH>
+__device__ __forceinline__ void mlp_pair_body(const MlpParams& p, unsigned char* smem) {
+  const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int pr = wave & 3, hh = wave >> 2;                     // pair (rows 32 pr ..) and half: waves w and w + 4 share a SIMD
-  const int q = lane & 15, g = lane >> 4;
+  constexpr int hh = HH;
+  const int pr = wave & 3;                     // pair (rows 32 pr ..) and half: waves w and w + 4 share a SIMD
+  int q, g;                                                    // lane & 15, lane >> 4: re-derived per phase (see pr_lane)
   const int npanels = (p.M + BM - 1) / BM;
   if ((int)blockIdx.x >= npanels) return;
   const int my_n = (npanels - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -94,8 +105,11 @@ __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(MlpParams p) {
   for (int pi = 0; pi < my_n; ++pi) {
     const int panel = (int)blockIdx.x + pi * (int)gridDim.x;
     const int row0 = panel * BM + pr * 32;
+#define PR_PSTAMP(k) do { if (p.dbg && blockIdx.x == 0 && tid == 0 && pi < 4) p.dbg[384 + pi * 4 + (k)] = __builtin_readcyclecounter(); } while (0)
+    PR_PSTAMP(0);
 
     bf16x8 xf[2][12];                                           // LayerNorm_2 of the pair's 32 rows as MFMA B fragments
+    { const unsigned lf = PR_LANE(); q = (int)(lf & 15u); g = (int)(lf >> 4); }
     f32x4 acc2[2][12];                                          // this half's [32 rows x 192 channels] of the output tile
     // ---- LayerNorm of the 32 rows (both waves of the pair, redundantly).  Lane (q, g): row 16 rt + q, channels 32 ks + 8 g + e.
 #pragma unroll
@@ -138,16 +152,28 @@ __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(MlpParams p) {
 #pragma unroll
       for (int t = 0; t < 12; ++t) acc2[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    PR_PSTAMP(1);
     // ---- 49 iterations: iteration it = GEMM1 + GELU of chunk it (it < 48) and GEMM2 of chunk it - 1 (it >= 1)
     u32x4 hprev = u32x4{0u, 0u, 0u, 0u};                         // this half's GELU output of the previous chunk: {rt 0: 4 bf16, rt 1: 4 bf16}
+    u32x4 hnew = hprev;                                          // (half 1 only: its phase 1 runs before the phase 2 that still needs the previous half)
     for (int it = 0; it <= NCH; ++it, ++G) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // this wave's pieces of item G have landed, its hidden half is in LDS
       __builtin_amdgcn_s_barrier();                              // everyone's have; iteration it - 1 is over: slot (G + 1) & 1 and the older exchange buffer are free
-      if (G + 1 < total) issue(G + 1);
-      const unsigned sbase = lds0 + (unsigned)((G & 1) * SLOT);
       const unsigned ll = PR_LANE();
+      const bool more = G + 1 < total && !((p.ablate & 1) && G >= 2);
+      const int nii = (G + 1) % ITEMS;                           // the next item: W1 chunk nii (nii < 48), W2 chunk nii - 1 (nii >= 1)
+      // its 3 + 3 pieces are issued one behind each MFMA group of this iteration: the address unit takes ~20 cycles per 1-KiB piece
+      // and holds the issuing wave meanwhile - time the SIMD's other wave spends in its MFMAs (a burst of all 48 pieces behind the
+      // barrier stopped all eight waves for ~900 cycles)
+      auto piece = [&](int k) {
+        if (!more) return;
+        unsigned char* sb = smem + ((G + 1) & 1) * SLOT + wave * 1024;
+        const unsigned sl = ll * 16u;
+        if (k < 3) { if (nii < NCH) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr)(sb + k * 8192), 16, sl, nii * W1B + (wave + 8 * k) * 1024, 0, 0); }
+        else if (nii >= 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_ptr)(sb + W1B + (k - 3) * 8192), 16, sl, (nii - 1) * W2B + (wave + 8 * (k - 3)) * 1024, 0, 0);
+      };
+      const unsigned sbase = lds0 + (unsigned)((G & 1) * SLOT);
       const unsigned qq = ll & 15u, gq = ll >> 4;
-      u32x4 hnew = hprev;
 
       // phase 1: GEMM1 (hidden units 8 g + 4 hh + e of the chunk, rows q of both row tiles), GELU, hand the half to the partner
       auto phase1 = [&]() {
@@ -172,10 +198,13 @@ __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(MlpParams p) {
         accn[1] = accn[0];
         PR_M1(fa, 0)
         PR_G1(fa, 2)
+        piece(0);
         PR_WAITF(4, fb);
         PR_M1(fb, 1)
+        piece(1);
         PR_WAITF(0, fa);
         PR_M1(fa, 2)
+        piece(2);
         // GELU(x) = x Phi(x), Phi by the interpolated table (common.h: gelu_lut); 8 values per lane, one row tile at a time
         // (four table reads in flight: the temporaries of all eight at once push the loop over the 256-register budget)
         bf16x8 o;
@@ -193,9 +222,9 @@ __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(MlpParams p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[rt * 4 + e] = (bf16)(accn[rt][e] * fmaf(__builtin_amdgcn_fractf(u4[e]), t4[e].y, t4[e].x));
         }
-        hnew = *reinterpret_cast<u32x4*>(&o);
+        if (HH == 0) hprev = *reinterpret_cast<u32x4*>(&o); else hnew = *reinterpret_cast<u32x4*>(&o);
         const unsigned ex = lds0 + EX_OFF + (unsigned)((it & 1) * 8192 + wave * 1024) + ll * 16u;
-        asm volatile("ds_write_b128 %0, %1" :: "v"(ex), "v"(hnew) : "memory");
+        if (HH == 0) asm volatile("ds_write_b128 %0, %1" :: "v"(ex), "v"(hprev) : "memory"); else asm volatile("ds_write_b128 %0, %1" :: "v"(ex), "v"(hnew) : "memory");
       };
       // phase 2: GEMM2 of the previous chunk: output channels 192 hh .. 192 hh + 191 (weight tiles 12 hh .. 12 hh + 11)
       auto phase2 = [&]() {
@@ -222,30 +251,27 @@ __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(MlpParams p) {
         const bf16x8 h0 = *reinterpret_cast<bf16x8*>(&w0), h1 = *reinterpret_cast<bf16x8*>(&w1);
         PR_M2(fa, 0)
         PR_G2(fa, 2)
+        piece(3);
         PR_WAITF(4, fb);
         PR_M2(fb, 1)
+        piece(4);
         PR_WAITF(0, fa);
         PR_M2(fa, 2)
+        piece(5);
       };
-#ifndef PAIR_STAGGER
-#define PAIR_STAGGER 0
-#endif
-#if PAIR_STAGGER
-      if (hh == 0) {
-        if (it < NCH) phase1();
-        if (it >= 1) phase2();
+      if (HH == 0) {
+        if (it >= 1 && !(p.ablate & 4)) phase2(); else { piece(3); piece(4); piece(5); }
+        if (it < NCH && !(p.ablate & 8)) phase1(); else { piece(0); piece(1); piece(2); }
       } else {
-        if (it >= 1) phase2();
-        if (it < NCH) phase1();
+        if (it < NCH && !(p.ablate & 8)) phase1(); else { piece(0); piece(1); piece(2); }
+        if (it >= 1 && !(p.ablate & 4)) phase2(); else { piece(3); piece(4); piece(5); }
+        hprev = hnew;
       }
-#else
-      if (it < NCH) phase1();
-      if (it >= 1) phase2();
-#endif
       __builtin_amdgcn_sched_barrier(0);
-      hprev = hnew;
     }
 
+    PR_PSTAMP(2);
+    { const unsigned lf = PR_LANE(); q = (int)(lf & 15u); g = (int)(lf >> 4); }
     // ---- epilogue: + bias2 + residual -> f32; this half holds channels 192 hh + 32 pl + 8 g + e (pl = 0..5) of row 16 rt + q
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
@@ -283,7 +309,7 @@ __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(MlpParams p) {
             asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a_), "+v"(b_));
             lo[e] = a_; hi[e] = b_;
           }
-          if (live) {
+          if (live && !(p.ablate & 16)) {
             float* op = ob + pl * 32;
             if (p.store_nt) { __builtin_nontemporal_store(lo, reinterpret_cast<f4*>(op)); __builtin_nontemporal_store(hi, reinterpret_cast<f4*>(op + 16)); }
             else { *reinterpret_cast<f4*>(op) = lo; *reinterpret_cast<f4*>(op + 16) = hi; }
@@ -323,10 +349,20 @@ __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(MlpParams p) {
         }
       }
     }
+    PR_PSTAMP(3);
   }
 }
 
+__global__ __launch_bounds__(512, 2) void mlp_pair_kernel(MlpParams p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0) mlp_pair_body<0>(p, smem); else mlp_pair_body<1>(p, smem);   // waves 0..3 / 4..7
+}
+
 static int g_pair_store_nt = 1;
+static int g_pair_ablate = 0;
+static unsigned long long* g_pair_dbg = nullptr;
+void set_mlp_pair_stamps(unsigned long long* d) { g_pair_dbg = d; }
+void set_mlp_pair_ablate(int v) { g_pair_ablate = v; }
 
 const char* mlp_pair_check(const MlpParams& p) {
   if (p.M <= 0) return "mlp_pair: bad row count";
@@ -343,6 +379,8 @@ void launch_mlp_pair(const MlpParams& p_in, hipStream_t s) {
   MlpParams p = p_in;
   p.gelu_lut = gelu_lut_for_current_device();
   p.store_nt = g_pair_store_nt;
+  p.ablate = g_pair_ablate;
+  p.dbg = g_pair_dbg;
   if (const char* e = mlp_pair_check(p)) throw std::runtime_error(e);
   static PerDeviceOnce once;
   once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS)); });
