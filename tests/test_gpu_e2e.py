@@ -327,3 +327,27 @@ def test_converted_torchscript_archives_end_to_end(tmp_path, oracle_models, funs
     eng.close()
     assert [g["bbox"] for g in got] == [r["bbox"] for r in ref] and len(got) >= 40
     assert [g["text"] for g in got] == [r["text"] for r in ref]
+
+
+def test_craft_group_size_does_not_change_results(eng_bf16):
+    """The detector walks a batch in launch groups of `craft_group` pages (default 16; engine.cpp detect_enqueue).  Group size
+    is scheduling only: 40 pages of 1024x768 give the same boxes and strings in groups of 16, 20 and 32 (32 pages put the
+    widest activation at 1.6 GB - the 32-bit buffer-offset window is 2 GiB - and the fused first pair past 2^31 virtual input
+    bytes, the case conv3p_check sizes by the u8 canvas instead)."""
+    from tuatara_amd import synth
+    from tuatara_amd.engine import DeviceBuffer
+    P = 40
+    pages = np.stack([synth.synthetic_page(100 + i, 1024, 768, n_words=24) for i in range(P)])
+    buf = DeviceBuffer(pages.nbytes)
+    buf.upload(pages)
+    res = {}
+    try:
+        for g in (16, 20, 32):
+            eng_bf16.set_tuning("craft_group", g)
+            r = eng_bf16.pages_to_data_dev(buf, P, 1024, 768)
+            res[g] = [[(tuple(x["bbox"]), x["text"]) for x in pg] for pg in r]
+    finally:
+        eng_bf16.set_tuning("craft_group", 16)
+    assert sum(len(p) for p in res[16]) > 20 * P
+    assert res[20] == res[16]
+    assert res[32] == res[16]

@@ -1035,7 +1035,10 @@ const char* conv3p_check(const ConvParams& p) {
   if (p.bias && ((uintptr_t)p.bias & 15)) return "conv3p: bias alignment";
   if ((!p.pre_wgt && ((uintptr_t)p.in0 & 15)) || ((uintptr_t)p.wgt & 15) || ((uintptr_t)p.pre_wgt & 15)) return "conv3p: operand alignment";
   const size_t lim = (size_t)1 << 31;
-  if ((size_t)p.M * p.C0 * 2 >= lim || (size_t)p.Cout * 9 * p.C0 * 2 >= lim) return "conv3p: tensor too large for 32-bit buffer offsets";
+  // (the fused first pair reads the u8 canvas - 3 bytes per pixel - and never forms its 64-channel input)
+  const size_t in_bytes = p.pre_wgt ? (size_t)p.M * 3 : (size_t)p.M * p.C0 * 2;
+  const size_t out_bytes = (size_t)p.M * p.Cout * 2 / (p.out ? 1 : 4);
+  if (in_bytes >= lim || out_bytes >= lim || (size_t)p.Cout * 9 * p.C0 * 2 >= lim) return "conv3p: tensor too large for 32-bit buffer offsets";
   if (p.M != p.B * p.H * p.W || p.M <= 0) return "conv3p: bad shape";
   return nullptr;
 }

@@ -58,6 +58,7 @@ struct Tuning {
   int ln_fuse = 1;            // bf16 decoder steps: LayerNorm computed inside the skinny GEMM's loader (gemm_sk ln_in)
   int fuse_first = 1;         // bf16: CRAFT conv1_1 fused into conv1_2's loader (conv3p FIRST)
   int enc_chunk = 0;          // crops per encoder group (0 = all crops at once)
+  int craft_group = 16;       // pages per CRAFT launch group (activation workspace ~0.5 GB/page; every tensor must stay inside the 2 GiB window of 32-bit buffer offsets)
   int ar_tail_step = 12;      // with ar_early_exit: AR steps from this one on run as ONE launch of the fused kernel (which returns at once when the batch is done)
   int ar_early_exit = 1;      // bf16 kernel-per-op AR loop: the steps' kernels return at once when every crop of the batch has emitted EOS (upstream's break)
   int decoder_mode = 1;       // 0 = kernel-per-op AR loop, 4/8/16 = fused kernel with that many crops per workgroup, else automatic
@@ -69,6 +70,7 @@ struct Tuning {
     else if (k == "tok_fuse") tok_fuse = value;
     else if (k == "ar_early_exit") ar_early_exit = value;
     else if (k == "ar_tail_step") ar_tail_step = value;
+    else if (k == "craft_group") craft_group = value < 1 ? 1 : (value > 32 ? 32 : value);
     else if (k == "mlp_fused") mlp_fused = value;     // 0 off, 1 from mlp_min_rows rows on, 2 always
     else if (k == "mlp_min_rows") mlp_min_rows = value;
     else if (k == "dec_mlp_fused") dec_mlp_fused = value;
@@ -999,7 +1001,7 @@ struct Engine {
     CanvasGeom g{}; int H = 0, W = 0, H2 = 0, W2 = 0; size_t page_bytes = 0;
     std::vector<std::vector<RRect>> boxes;
     std::vector<int> rects, page_of;
-    int N = 0, slot = 0;
+    int N = 0, slot = 0, group = 16;
     bool live = false, enqueued = false;
   };
   PageBatch q1, q2;        // streamed batches: q1 = boxes known (recogniser enqueued or not), q2 = older, recogniser enqueued, results not yet returned
@@ -1018,9 +1020,11 @@ struct Engine {
     // CRAFT in groups of <= 16 pages: bounds the activation workspace (~0.5 GB/page) and keeps every tensor
     // inside the 2 GiB window gemm2's 32-bit buffer offsets address.  Each group's CCL follows its CRAFT, so the host reads
     // group g's components back (and runs its calipers) while the GPU is busy with group g + 1.
-    const int groups = (n + 15) / 16;
+    const int GP = tn.craft_group;
+    B.group = GP;
+    const int groups = (n + GP - 1) / GP;
     for (int gi = 0; gi < groups; ++gi) {
-      const int p0 = gi * 16, cnt = std::min(16, n - p0);
+      const int p0 = gi * GP, cnt = std::min(GP, n - p0);
       craft_forward(canvas.as<uint8_t>() + (size_t)p0 * H * W * 3, cnt, H, W, heat.as<float>() + (size_t)p0 * H2 * W2 * 2);
       if (gi == groups - 1) TTR_HIP_CHECK(hipEventRecord(ev[1], stream));
       ccl_launch(heat.as<float>() + (size_t)p0 * H2 * W2 * 2, p0, cnt, n, gi, H2, W2);
@@ -1029,13 +1033,13 @@ struct Engine {
   }
 
   void detect_collect(PageBatch& B) {
-    const int n = B.n, groups = (n + 15) / 16;
+    const int n = B.n, GP = B.group, groups = (n + GP - 1) / GP;
     const float ratio_w = 1.f / B.g.ratio, ratio_h = 1.f / B.g.ratio;   // tuatara.cpp:360-361
     std::vector<std::vector<RRect>> dets(n);
     B.boxes.assign(n, std::vector<RRect>());
     B.rects.clear(); B.page_of.clear();        // x0,y0,x1,y1,page per crop; page index per crop
     host_us[1] = host_us[2] = host_us[3] = 0.f;
-    for (int gi = 0; gi < groups; ++gi) ccl_collect(gi * 16, std::min(16, n - gi * 16), gi, B.H2, B.W2, dets);
+    for (int gi = 0; gi < groups; ++gi) ccl_collect(gi * GP, std::min(GP, n - gi * GP), gi, B.H2, B.W2, dets);
     if (cfg.bench_grid_boxes) {   // benchmark workload control: the detector's work is done (and timed); 40 fixed boxes per page go on
       for (int i = 0; i < n; ++i) {
         dets[i].clear();
