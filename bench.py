@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--words", type=int, default=40, help="words drawn per synthetic page (SURVEY.md section 8d: ~40 random words)")
     ap.add_argument("--boxes", default="grid40", choices=["grid40", "detected"], help="grid40 (SURVEY.md section 8d): CRAFT + CCL + box extraction run in full (timed), then every page's "
                     "boxes are replaced by a fixed 5 x 8 grid of 150 x 40 px boxes so that PARSeq sees exactly 40 crops per page; detected: the synthetic detector's own boxes")
-    ap.add_argument("--buffers", type=int, default=4, help="distinct device page buffers rotated over the steps (each holds --pages distinct pages of the 512-seed stream)")
+    ap.add_argument("--buffers", type=int, default=16, help="distinct device page buffers rotated over the steps (each holds --pages distinct pages of the 512-seed stream; 16 x 32 = all 512 seeds)")
     ap.add_argument("--parity-pages", type=int, default=8, help="pages per step of the f32 parity-mode measurement after the timed region (0 = skip)")
     ap.add_argument("--contexts", type=int, default=1, help="engine contexts (HIP streams + host threads) per GPU; a step's pages are split between them")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])

@@ -11,10 +11,15 @@ it = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 d = tempfile.mkdtemp()
 W.make_synthetic_weights(d, seed=0, structured=True)
 eng = Engine(d, precision="bf16")
+const = "const" in sys.argv[3:]                # all crops one flat grey: near-constant MFMA operands (the DVFS / power comparison)
 for kv in sys.argv[3:]:                      # key=value tuning knobs (Engine.set_tuning)
+    if kv == "const":
+        continue
     k, v = kv.split("=")
     assert eng.set_tuning(k, int(v)) == 0, kv
 crops = np.random.default_rng(0).integers(0, 256, (N, 32, 128, 3), dtype=np.uint8)
+if const:
+    crops[:] = 128
 for _ in range(it):
     lg, ids = eng.parseq_logits(crops)
 print("crops", N, "iterations", it, "finite", bool(np.isfinite(lg).all()))

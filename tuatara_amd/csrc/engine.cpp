@@ -1594,6 +1594,8 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "cross_mfma") set_dec_cross_mfma(value);
   else if (k == "mlp_store_nt") set_mlp_store_nt(value);
   else if (k == "pair_ablate") set_mlp_pair_ablate(value);
+  else if (k == "mlp_stagger") set_mlp_stagger(value);
+  else if (k == "mlp_ablate") set_mlp_ablate(value);
   else if (k == "attn_impl") set_attn_impl(value);
   else if (k == "ws_dbg_flags") set_gemm_ws_dbg_flags(value);
   else if (k == "ws_lean") set_gemm_ws_lean(value);

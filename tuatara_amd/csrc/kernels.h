@@ -113,9 +113,13 @@ struct MlpParams {
   int store_nt;            // set by the launcher: streaming policy on the epilogue stores
   unsigned long long* dbg; // optional [48][8] shader-clock stamps of workgroup 0 / wave 0 over its first panel (diagnostics)
   int M;
+  int stagger;             // set by the launcher: (groups << 16) | microseconds - workgroup (blockIdx / 8) % groups starts that many steps late, to take the
+                           // panels' HBM phases (front loads, epilogue stores) of the groups out of lock-step; 0 = all start together
   int ablate;              // mlp_pair timing experiments (results are wrong): 1 no weight DMA after the first items, 2 no GELU, 4 no GEMM2, 8 no GEMM1, 16 no epilogue stores
 };
 void launch_mlp_fused(const MlpParams& p, hipStream_t s);
+void set_mlp_ablate(int v);    // MlpParams::ablate of the stamps build (tools/mlp_stamps.py)
+void set_mlp_stagger(int v);   // MlpParams::stagger for the following launches
 // ---- mlp_pair.hip: the same block with two waves per SIMD (a pair of waves shares 32 rows and splits hidden units / output channels); no projection
 void launch_mlp_pair(const MlpParams& p, hipStream_t s);
 void set_mlp_pair_stamps(unsigned long long* dev_buf);   // >= 400 u64 or null: panel stamps of workgroup 0

@@ -45,10 +45,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t m_rsrc(const void* base, unsig
 }
 // LDS reads as inline asm: hipcc puts s_waitcnt vmcnt(0) in front of every LDS read it can see once LDS-DMA loads are in
 // flight (it cannot prove they do not alias), which would serialise the weight stream.  Waits are placed by hand below.
+#define MLP_RDV(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
 #define MLP_RD128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 // the lane id straight from the hardware (2 VALU): anything derived from threadIdx that lives across the chunk loop is a spill candidate
 #define MLP_LANE() __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))
 #define MLP_WAIT8(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]))
+// timing experiments of the STAMPS build (MlpParams::ablate; results are wrong): 1 = per-channel vectors (biases, LayerNorm gains)
+// not loaded, 2 = no epilogue stores, 4 = attention output / residual rows of the front not loaded
+#define MLP_VEC4(ptr) (((STAMPS >> 1) & 1) ? make_float4(1.f, 1.f, 1.f, 1.f) : *reinterpret_cast<const float4*>(ptr))
+__device__ __forceinline__ float4 mlp_fake4(unsigned k) {   // pseudo-random values in [-2, 2): the no-load experiment must keep the MFMA operands toggling
+  const unsigned h = k * 2654435761u + 12345u;
+  return make_float4((float)((int)(h & 1023u) - 512) * (1.f / 256), (float)((int)((h >> 10) & 1023u) - 512) * (1.f / 256),
+                     (float)((int)((h >> 20) & 1023u) - 512) * (1.f / 256), (float)((int)((h >> 5) & 1023u) - 512) * (1.f / 256));
+}
+#define MLP_ROW4(ptr) (((STAMPS >> 1) & 4) ? (((STAMPS >> 1) & 8) ? mlp_fake4((unsigned)(size_t)(ptr)) : make_float4(.5f, .25f, 1.f, 2.f)) : *reinterpret_cast<const float4*>(ptr))
 }  // namespace
 
 // PROJ: the block's attention output projection runs in front, in the same launch: x' = x + att . Wp^T + bp is accumulated in the
@@ -56,7 +66,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t m_rsrc(const void* base, unsig
 // items per panel: the [384 x 32] k-step slabs of a chunk-major copy of Wp, in the W2 half of a slot)
 // STAMPS: a build with the phase stamps of tools/mlp_stamps.py (kept out of the production instantiations: the stamp address is one
 // more value for the register allocator to spill inside the chunk loop)
-template <bool PROJ, bool STAMPS>
+template <bool PROJ, int STAMPS>
 __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
   constexpr int NPJ = PROJ ? E / CH : 0, ITEMS = NPJ + NCH + 1;   // ring items per panel
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -68,6 +78,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
   const int my_n = (npanels - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int total = my_n * ITEMS;                              // ring items this workgroup walks (see the chunk loop)
 
+  if (p.stagger) {                                             // start late by group (see MlpParams::stagger)
+    const int gi = ((int)blockIdx.x >> 3) % (p.stagger >> 16);
+    const long long wait = (long long)gi * (p.stagger & 0xffff) * 100;   // wall clock: 100 MHz
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(64);
+  }
   for (int i = tid; i < 512; i += 256) reinterpret_cast<uint4*>(smem + LUT_OFF)[i] = reinterpret_cast<const uint4*>(p.gelu_lut)[i];
   for (int i = tid; i < HID / 4; i += 256) reinterpret_cast<float4*>(smem + B1_OFF)[i] = reinterpret_cast<const float4*>(p.b1)[i];
 
@@ -84,6 +100,19 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
   //   the 64-byte row sits at position gch ^ ((R'>>1) & 3).  Piece ot = rows 16 ot .. 16 ot + 15.
 #define src_lane (MLP_LANE() * 16u)
   const __amdgpu_buffer_rsrc_t rsp = m_rsrc(PROJ ? (const void*)p.wpp : (const void*)p.w2p, (unsigned)((PROJ ? E * E : HID * E) * 2));
+  // Per-channel vectors (biases, LayerNorm gains and offsets: 1536 B each) ride in the W1 half of the two ring items that do not use
+  // it — the last slab of Wp (bp | ln_g | ln_b for the front) and the panel's last item (b2 | nln_g | nln_b for the epilogue) —
+  // 2 KiB apart.  Read per lane from global memory they cost 288 wave-wide 16-byte loads per wave and panel, 17 % of the launch
+  // (tools/mlp_ablate_sweep.sh); from LDS they are broadcast reads.  Wave w fetches both 1-KiB halves of vector w % 3 (wave 3
+  // repeats wave 0's: every wave issues the same number of pieces); lanes behind byte 1536 are out of range and write zeros.
+  auto issue_vec = [&](int slot, const float* v0, const float* v1, const float* v2) {
+    const int v = wave == 3 ? 0 : wave;
+    const float* src = v == 0 ? v0 : (v == 1 ? v1 : v2);
+    const __amdgpu_buffer_rsrc_t rv = m_rsrc(src, (unsigned)(E * 4));
+    unsigned char* d = smem + slot * SLOT + v * 2048;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr)d, 16, src_lane, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr)(d + 1024), 16, src_lane + 1024u, 0, 0, 0);   // (in the vector offset: that is what the range check sees)
+  };
   auto issue = [&](int Gi) {                                   // item Gi of the launch
     int ii = Gi % ITEMS;
     const int slot = Gi % NSLOT;
@@ -91,6 +120,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
     if (PROJ && ii < NPJ) {                                     // k-step slab ii of Wp
 #pragma unroll
       for (int j = 0; j < 6; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsp, (lds_ptr)(sb + W1B + j * 4096), 16, src_lane, ii * W2B + (wave + 4 * j) * 1024, 0, 0);
+      if (ii == NPJ - 1) issue_vec(slot, p.bp, p.ln_g, p.ln_b);
       return;
     }
     ii -= NPJ;                                                  // MLP item: W1 chunk ii (ii < 48) and W2 chunk ii - 1 (ii >= 1)
@@ -105,10 +135,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
 #pragma unroll
       for (int j = 0; j < 6; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_ptr)(sb + W1B + j * 4096), 16, src_lane, cb + (wave + 4 * j) * 1024, 0, 0);
     }
+    if (ii == NCH) issue_vec(slot, p.b2, p.nln_out ? p.nln_g : p.b2, p.nln_out ? p.nln_b : p.b2);
   };
-  auto pieces = [&](int Gi) -> int {                            // pieces per wave of item Gi: 12, or 6 for the one-operand items
+  auto pieces = [&](int Gi) -> int {                            // pieces per wave of item Gi: 12; 6 for the one-operand items, 8 for those that carry vectors
     const int ii = Gi % ITEMS;
-    return (ii < NPJ || ii == NPJ || ii == ITEMS - 1) ? 6 : 12;
+    return (ii == NPJ - 1 || ii == ITEMS - 1) ? 8 : ((ii < NPJ || ii == NPJ) ? 6 : 12);
   };
 
   // ---- fragment read addresses relative to a slot
@@ -124,13 +155,13 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
   for (int pi = 0; pi < my_n; ++pi) {
     const int panel = (int)blockIdx.x + pi * (int)gridDim.x;
     const int row0 = panel * BM + wave * 32;
-#define MLP_PSTAMP(k) do { if (STAMPS && p.dbg && blockIdx.x == 0 && tid == 0 && pi < 4) p.dbg[384 + pi * 4 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define MLP_PSTAMP(k) do { if ((STAMPS & 1) && p.dbg && blockIdx.x == 0 && tid == 0 && pi < 4) { p.dbg[384 + pi * 4 + (k)] = __builtin_readcyclecounter(); p.dbg[400 + pi * 4 + (k)] = wall_clock64(); } } while (0)   // shader clock | 100 MHz wall clock
     MLP_PSTAMP(0);   // panel start | chunk loop start | chunk loop end | panel end
 
     bf16x8 xf[2][12];                                           // LayerNorm_2 of this wave's 32 rows as MFMA B fragments
     f32x4 acc2[2][24];                                          // the wave's [32 rows x 384] f32 output tile
     int i = 0;
-#define MLP_STAMP(ph) do { if (STAMPS && p.dbg && blockIdx.x == 0 && tid == 0 && pi == 0 && i < NCH) p.dbg[i * 8 + (ph)] = __builtin_readcyclecounter(); } while (0)
+#define MLP_STAMP(ph) do { if ((STAMPS & 1) && p.dbg && blockIdx.x == 0 && tid == 0 && pi == 0 && i < NCH) p.dbg[i * 8 + (ph)] = __builtin_readcyclecounter(); } while (0)
 // Fragment groups of 4 (8 MFMAs each), three register buffers, reads two groups ahead.  GEMM1 group n = k-steps 2n, 2n+1 x the
 // two 16-row weight tiles; GEMM2 group n = output-channel tiles 4n .. 4n+3.
 #define MLP_G1(dst, n)                                                                                                   \
@@ -160,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         u4[e] = fmaf(__builtin_amdgcn_fmed3f(acc[e], -8.0f, 7.984375f), 64.0f, 512.0f);
-        const unsigned ad = lut_lds + ((unsigned)(int)u4[e] << 3);
+        const unsigned ad = ((STAMPS >> 1) & 16) ? lut_lds + (((unsigned)(int)u4[e] << 3) & 8u) : lut_lds + ((unsigned)(int)u4[e] << 3);   // (16: timing experiment, two table entries only)
         asm volatile("ds_read_b64 %0, %1" : "=v"(t4[e]) : "v"(ad));
       }
     };
@@ -183,7 +214,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
   {                                                                                                        \
     MLP_STAMP(0);                                                                                          \
     if (G + 1 < total) {                                                                                   \
-      if (pieces(G + 1) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                             \
+      const int pc_ = pieces(G + 1);                                                                       \
+      if (pc_ == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                       \
+      else if (pc_ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                  \
       else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                               \
     } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
     __builtin_amdgcn_s_barrier(); /* everyone's pieces landed; slot (G+2)%3 = (G-1)%3 is free again */     \
@@ -242,8 +275,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
       const float rstd = rsqrtf(s2 * (1.f / E) + p.ln_eps);
 #pragma unroll
       for (int ks = 0; ks < 12; ++ks) {
-        const float4 g0 = *reinterpret_cast<const float4*>(p.ln_g + ks * 32 + g * 8), g1 = *reinterpret_cast<const float4*>(p.ln_g + ks * 32 + g * 8 + 4);
-        const float4 t0 = *reinterpret_cast<const float4*>(p.ln_b + ks * 32 + g * 8), t1 = *reinterpret_cast<const float4*>(p.ln_b + ks * 32 + g * 8 + 4);
+        const float4 g0 = MLP_VEC4(p.ln_g + ks * 32 + g * 8), g1 = MLP_VEC4(p.ln_g + ks * 32 + g * 8 + 4);
+        const float4 t0 = MLP_VEC4(p.ln_b + ks * 32 + g * 8), t1 = MLP_VEC4(p.ln_b + ks * 32 + g * 8 + 4);
         const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
         bf16x8 o;
 #pragma unroll
@@ -267,7 +300,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
         const int row = min(row0 + rt * 16 + q, p.M - 1);
         const bf16* ar = p.att + (size_t)row * E + g * 8;
 #pragma unroll
-        for (int ks = 0; ks < 12; ++ks) af[rt][ks] = *reinterpret_cast<const bf16x8*>(ar + ks * 32);
+        for (int ks = 0; ks < 12; ++ks) {
+          if ((STAMPS >> 1) & 8) { const float4 a = mlp_fake4((unsigned)(size_t)(ar + ks * 32)), b = mlp_fake4((unsigned)(size_t)(ar + ks * 32) + 7u);
+            af[rt][ks] = bf16x8{(bf16)a.x, (bf16)a.y, (bf16)a.z, (bf16)a.w, (bf16)b.x, (bf16)b.y, (bf16)b.z, (bf16)b.w}; }
+          else af[rt][ks] = ((STAMPS >> 1) & 4) ? bf16x8{(bf16)1.f, (bf16).5f, (bf16)1.f, (bf16).5f, (bf16)1.f, (bf16).5f, (bf16)1.f, (bf16).5f} : *reinterpret_cast<const bf16x8*>(ar + ks * 32);
+        }
       }
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
@@ -283,6 +320,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
           unsigned char* sb = smem + ((G + 2) % NSLOT) * SLOT + wave * 1024;
 #pragma unroll
           for (int j = 0; j < 6; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsp, (lds_ptr)(sb + W1B + j * 4096), 16, src_lane, (ks + 2) * W2B + (wave + 4 * j) * 1024, 0, 0);
+          if (ks + 2 == NPJ - 1) issue_vec((G + 2) % NSLOT, p.bp, p.ln_g, p.ln_b);
         } else if (G + 2 < total) issue(G + 2);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f0[0]), "+v"(f0[1]), "+v"(f0[2]), "+v"(f0[3]), "+v"(f1[0]), "+v"(f1[1]), "+v"(f1[2]), "+v"(f1[3]));
         MLP_G2(f2, 2)  MLP_M2B(f0, 0, af[0][ks], af[1][ks])
@@ -295,39 +333,81 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
         ++G;
       }
       i = 0;
+      // bp | ln_g | ln_b came in with the last slab (item G - 1); lane (q, g) reads channels 32 pp + 8 g .. + 7 of each.
+      // Pass 1 (both row tiles): x' = acc + bp + x back into the accumulators, with the row statistics gathered on the way as
+      // sums shifted by the lane's first value (then merged over the row's four lanes as mean / M2 pairs) — a separate
+      // variance pass would keep the 96 values of a row tile in vector registers next to xf, which hipcc answers with spills
+      // (and a spill reload in front of the chunk loop waits for the weight prefetch).  Pass 2 reads x' back from the
+      // accumulators, both row tiles per gain / offset read.
+      const unsigned vfb = lds0 + (unsigned)(((G - 1) % NSLOT) * SLOT) + (MLP_LANE() >> 4) * 32u;
+      float rstd2[2], nmr2[2];
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         const size_t ro = (size_t)min(row0 + rt * 16 + q, p.M - 1) * E + g * 8;
-        float s = 0.f;
+        float K = 0.f, S1 = 0.f, S2 = 0.f;
 #pragma unroll
-        for (int pp = 0; pp < 12; ++pp) {
-          const float4 r0 = *reinterpret_cast<const float4*>(p.x + ro + pp * 32), r1 = *reinterpret_cast<const float4*>(p.x + ro + pp * 32 + 4);
-          const float4 c0 = *reinterpret_cast<const float4*>(p.bp + pp * 32 + g * 8), c1 = *reinterpret_cast<const float4*>(p.bp + pp * 32 + g * 8 + 4);
-          f32x4 lo = acc2[rt][2 * pp], hi = acc2[rt][2 * pp + 1];
-          lo[0] += c0.x + r0.x; lo[1] += c0.y + r0.y; lo[2] += c0.z + r0.z; lo[3] += c0.w + r0.w;
-          hi[0] += c1.x + r1.x; hi[1] += c1.y + r1.y; hi[2] += c1.z + r1.z; hi[3] += c1.w + r1.w;
-          acc2[rt][2 * pp] = lo; acc2[rt][2 * pp + 1] = hi;
-          s += (lo[0] + lo[1]) + (lo[2] + lo[3]) + (hi[0] + hi[1]) + (hi[2] + hi[3]);
+        for (int pb = 0; pb < 6; ++pb) {                        // batches of 2 channel groups
+          f32x4 c[4];
+          float4 r0[2], r1[2];
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const unsigned a = vfb + (unsigned)((2 * pb + k) * 128);
+            MLP_RDV(c[2 * k], a);  MLP_RDV(c[2 * k + 1], a + 16u);
+            r0[k] = MLP_ROW4(p.x + ro + (2 * pb + k) * 32); r1[k] = MLP_ROW4(p.x + ro + (2 * pb + k) * 32 + 4);
+          }
+          MLP_WAITF(0, c);
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int pp = 2 * pb + k;
+            f32x4 lo = acc2[rt][2 * pp], hi = acc2[rt][2 * pp + 1];
+            lo[0] += c[2 * k][0] + r0[k].x; lo[1] += c[2 * k][1] + r0[k].y; lo[2] += c[2 * k][2] + r0[k].z; lo[3] += c[2 * k][3] + r0[k].w;
+            hi[0] += c[2 * k + 1][0] + r1[k].x; hi[1] += c[2 * k + 1][1] + r1[k].y; hi[2] += c[2 * k + 1][2] + r1[k].z; hi[3] += c[2 * k + 1][3] + r1[k].w;
+            acc2[rt][2 * pp] = lo; acc2[rt][2 * pp + 1] = hi;
+            if (pp == 0) K = lo[0];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d0 = lo[e] - K, d1 = hi[e] - K; S1 += d0 + d1; S2 = fmaf(d0, d0, S2); S2 = fmaf(d1, d1, S2); }
+          }
+          __builtin_amdgcn_sched_barrier(0);                    // (a batch's values are used up before the next batch is read)
         }
-        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
-        const float mean = s * (1.f / E);
-        float s2 = 0.f;
+        // the lane's 96 values: mean_l = K + S1 / 96, M2_l = S2 - S1^2 / 96; the row: mean = average of the four mean_l,
+        // M2 = sum of M2_l + 96 (mean_l - mean)^2
+        const float ml = S1 * (1.f / 96), mean_l = K + ml;
+        float ms = mean_l;
+        ms += __shfl_xor(ms, 16); ms += __shfl_xor(ms, 32);
+        const float mean = ms * 0.25f, dm = mean_l - mean;
+        float m2 = fmaf(96.f * dm, dm, S2 - S1 * ml);
+        m2 += __shfl_xor(m2, 16); m2 += __shfl_xor(m2, 32);
+        rstd2[rt] = rsqrtf(m2 * (1.f / E) + p.ln_eps);
+        nmr2[rt] = -mean * rstd2[rt];
+      }
+      // y = x' * (rstd * gain) + (offset - mean * rstd * gain); the empty asm ties the batch reads to the statistics, or they move
+      // above pass 1 and their values get spilled
+      unsigned vg = vfb + 2048u;
+      asm volatile("" : "+v"(vg) : "v"(rstd2[1]));
 #pragma unroll
-        for (int ot = 0; ot < 24; ++ot)
+      for (int pb = 0; pb < 6; ++pb) {                          // batches of 2 channel groups: gain lo | hi, offset lo | hi
+        f32x4 gb[8];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { const float d = acc2[rt][ot][e] - mean; s2 += d * d; }
-        s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
-        const float rstd = rsqrtf(s2 * (1.f / E) + p.ln_eps);
-#pragma unroll
-        for (int pp = 0; pp < 12; ++pp) {
-          const float4 g0 = *reinterpret_cast<const float4*>(p.ln_g + pp * 32 + g * 8), g1 = *reinterpret_cast<const float4*>(p.ln_g + pp * 32 + g * 8 + 4);
-          const float4 t0 = *reinterpret_cast<const float4*>(p.ln_b + pp * 32 + g * 8), t1 = *reinterpret_cast<const float4*>(p.ln_b + pp * 32 + g * 8 + 4);
-          const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-          bf16x8 o;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = (bf16)(((e < 4 ? acc2[rt][2 * pp][e] : acc2[rt][2 * pp + 1][e - 4]) - mean) * rstd * gg[e] + bb[e]);
-          xf[rt][pp] = o;
+        for (int k = 0; k < 2; ++k) {
+          const unsigned a = vg + (unsigned)((2 * pb + k) * 128);
+          MLP_RDV(gb[4 * k], a);  MLP_RDV(gb[4 * k + 1], a + 16u);  MLP_RDV(gb[4 * k + 2], a + 2048u);  MLP_RDV(gb[4 * k + 3], a + 2064u);
         }
+        MLP_WAIT8(0, gb);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int pp = 2 * pb + k;
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float gn = e < 4 ? gb[4 * k][e] : gb[4 * k + 1][e - 4], of = e < 4 ? gb[4 * k + 2][e] : gb[4 * k + 3][e - 4];
+              o[e] = (bf16)fmaf(e < 4 ? acc2[rt][2 * pp][e] : acc2[rt][2 * pp + 1][e - 4], rstd2[rt] * gn, fmaf(nmr2[rt], gn, of));
+            }
+            xf[rt][pp] = o;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     MLP_PSTAMP(1);
@@ -404,95 +484,101 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
     }
 
     MLP_PSTAMP(2);
-    // ---- epilogue: + bias2 + residual -> f32; lane holds, of row 16 rt + q, channels 32 pp + 8 g + e (pp = 0..11)
+    // ---- epilogue: + bias2 (+ residual) -> f32 store, then the next LayerNorm on the values still in registers.  Lane (q, g)
+    // holds, of row 16 rt + q, channels 32 pp + 8 g + e (pp = 0..11).  b2 | nln_g | nln_b came in with the panel's last item
+    // (G - 1), in the W1 half of its slot.  Pass 1 per row tile, in batches of 2 channel groups: the sum goes back into the
+    // accumulators and out to x_out, the row statistics are gathered on the way (shifted sums, as in the front).
+    const unsigned veb = lds0 + (unsigned)(((G - 1) % NSLOT) * SLOT) + (MLP_LANE() >> 4) * 32u;
+    float rstd2[2], nmr2[2];
+    size_t ro2[2];
+    bool live2[2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
       const int row = row0 + rt * 16 + q;
       const bool live = row < p.M;
       const size_t ro = (size_t)min(row, p.M - 1) * E + g * 8;
-      float v[12][8];
-      // loads in batches of 4 channel groups (a scheduling barrier keeps hipcc from sinking each load to its use, which made
-      // this 24 dependent L2 round trips; all 12 groups at once spill)
-#pragma unroll
-      for (int pb = 0; pb < 3; ++pb) {
-        float4 c0[4], c1[4], r0[4], r1[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int pp = 4 * pb + k;
-          c0[k] = *reinterpret_cast<const float4*>(p.b2 + pp * 32 + g * 8); c1[k] = *reinterpret_cast<const float4*>(p.b2 + pp * 32 + g * 8 + 4);
-          r0[k] = make_float4(0.f, 0.f, 0.f, 0.f); r1[k] = r0[k];   // PROJ: the residual is already inside acc2
-          if (!PROJ) { r0[k] = *reinterpret_cast<const float4*>(p.x + ro + pp * 32); r1[k] = *reinterpret_cast<const float4*>(p.x + ro + pp * 32 + 4); }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int pp = 4 * pb + k;
-          v[pp][0] = acc2[rt][2 * pp][0] + c0[k].x + r0[k].x; v[pp][1] = acc2[rt][2 * pp][1] + c0[k].y + r0[k].y;
-          v[pp][2] = acc2[rt][2 * pp][2] + c0[k].z + r0[k].z; v[pp][3] = acc2[rt][2 * pp][3] + c0[k].w + r0[k].w;
-          v[pp][4] = acc2[rt][2 * pp + 1][0] + c1[k].x + r1[k].x; v[pp][5] = acc2[rt][2 * pp + 1][1] + c1[k].y + r1[k].y;
-          v[pp][6] = acc2[rt][2 * pp + 1][2] + c1[k].z + r1[k].z; v[pp][7] = acc2[rt][2 * pp + 1][3] + c1[k].w + r1[k].w;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      ro2[rt] = ro; live2[rt] = live;
       // f32 stores: a lane holds 8 consecutive channels = 2 x 16 B, so storing them as they are writes four 16-byte pieces with
       // 16-byte holes per row per instruction.  v_permlane32_swap (lanes i <-> i + 32, i.e. g <-> g + 2) of the lower half's second
       // quad with the upper half's first quad makes each instruction write 64 contiguous bytes per row:
       //   first instruction:  g = 0, 1, 2, 3 -> bytes 0-15, 32-47, 16-31, 48-63 of the row's 128;   second: the same + 64
-      {
-        float* const ob = p.x_out + ro - g * 8 + ((g & 1) * 8 + (g >> 1) * 4);     // row base + this lane's 16-byte slot of the first half
+      float* const ob = p.x_out + ro - g * 8 + ((g & 1) * 8 + (g >> 1) * 4);     // row base + this lane's 16-byte slot of the first half
+      float K = 0.f, S1 = 0.f, S2 = 0.f;
 #pragma unroll
-        for (int pp = 0; pp < 12; ++pp) {
+      for (int pb = 0; pb < 6; ++pb) {
+        f32x4 c[4];
+        float4 r0[2], r1[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int pp = 2 * pb + k;
+          const unsigned a = veb + (unsigned)(pp * 128);
+          MLP_RDV(c[2 * k], a);  MLP_RDV(c[2 * k + 1], a + 16u);
+          if (!PROJ) { r0[k] = MLP_ROW4(p.x + ro + pp * 32); r1[k] = MLP_ROW4(p.x + ro + pp * 32 + 4); }   // PROJ: the residual is already inside acc2
+        }
+        MLP_WAITF(0, c);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int pp = 2 * pb + k;
+          f32x4 lo = acc2[rt][2 * pp], hi = acc2[rt][2 * pp + 1];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { lo[e] += c[2 * k][e]; hi[e] += c[2 * k + 1][e]; }
+          if (!PROJ) { lo[0] += r0[k].x; lo[1] += r0[k].y; lo[2] += r0[k].z; lo[3] += r0[k].w; hi[0] += r1[k].x; hi[1] += r1[k].y; hi[2] += r1[k].z; hi[3] += r1[k].w; }
+          acc2[rt][2 * pp] = lo; acc2[rt][2 * pp + 1] = hi;
+          if (pp == 0) K = lo[0];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float d0 = lo[e] - K, d1 = hi[e] - K; S1 += d0 + d1; S2 = fmaf(d0, d0, S2); S2 = fmaf(d1, d1, S2); }
           typedef __attribute__((ext_vector_type(4))) float f4;
-          f4 lo, hi;
+          f4 slo, shi;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float a_ = v[pp][e], b_ = v[pp][4 + e];          // (the pair-returning builtin gave hi == lo here)
+            float a_ = lo[e], b_ = hi[e];                    // (the pair-returning builtin gave hi == lo here)
             asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a_), "+v"(b_));
-            lo[e] = a_; hi[e] = b_;
+            slo[e] = a_; shi[e] = b_;
           }
-          if (live) {
+          if (live && !((STAMPS >> 1) & 2)) {
             float* op = ob + pp * 32;
-            if (p.store_nt) { __builtin_nontemporal_store(lo, reinterpret_cast<f4*>(op)); __builtin_nontemporal_store(hi, reinterpret_cast<f4*>(op + 16)); }
-            else { *reinterpret_cast<f4*>(op) = lo; *reinterpret_cast<f4*>(op + 16) = hi; }
+            if (p.store_nt) { __builtin_nontemporal_store(slo, reinterpret_cast<f4*>(op)); __builtin_nontemporal_store(shi, reinterpret_cast<f4*>(op + 16)); }
+            else { *reinterpret_cast<f4*>(op) = slo; *reinterpret_cast<f4*>(op + 16) = shi; }
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if (p.nln_out) {                                          // uniform
-        float s = 0.f;
+      const float ml = S1 * (1.f / 96), mean_l = K + ml;
+      float ms = mean_l;
+      ms += __shfl_xor(ms, 16); ms += __shfl_xor(ms, 32);
+      const float mean = ms * 0.25f, dm = mean_l - mean;
+      float m2 = fmaf(96.f * dm, dm, S2 - S1 * ml);
+      m2 += __shfl_xor(m2, 16); m2 += __shfl_xor(m2, 32);
+      rstd2[rt] = rsqrtf(m2 * (1.f / E) + p.nln_eps);
+      nmr2[rt] = -mean * rstd2[rt];
+    }
+    if (p.nln_out) {                                            // uniform
+      unsigned vg = veb + 2048u;
+      asm volatile("" : "+v"(vg) : "v"(rstd2[1]));
 #pragma unroll
-        for (int pp = 0; pp < 12; ++pp)
+      for (int pb = 0; pb < 6; ++pb) {                          // batches of 2 channel groups: gain lo | hi, offset lo | hi
+        f32x4 gb[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) s += v[pp][e];
-        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
-        const float mean = s * (1.f / E);
-        float s2 = 0.f;
+        for (int k = 0; k < 2; ++k) {
+          const unsigned a = vg + (unsigned)((2 * pb + k) * 128);
+          MLP_RDV(gb[4 * k], a);  MLP_RDV(gb[4 * k + 1], a + 16u);  MLP_RDV(gb[4 * k + 2], a + 2048u);  MLP_RDV(gb[4 * k + 3], a + 2064u);
+        }
+        MLP_WAIT8(0, gb);
 #pragma unroll
-        for (int pp = 0; pp < 12; ++pp)
+        for (int k = 0; k < 2; ++k) {
+          const int pp = 2 * pb + k;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { const float d = v[pp][e] - mean; s2 += d * d; }
-        s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
-        const float rstd = rsqrtf(s2 * (1.f / E) + p.nln_eps);
-#pragma unroll
-        for (int pb = 0; pb < 3; ++pb) {
-          float4 g0[4], g1[4], t0[4], t1[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int pp = 4 * pb + k;
-            g0[k] = *reinterpret_cast<const float4*>(p.nln_g + pp * 32 + g * 8); g1[k] = *reinterpret_cast<const float4*>(p.nln_g + pp * 32 + g * 8 + 4);
-            t0[k] = *reinterpret_cast<const float4*>(p.nln_b + pp * 32 + g * 8); t1[k] = *reinterpret_cast<const float4*>(p.nln_b + pp * 32 + g * 8 + 4);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int pp = 4 * pb + k;
-            const float gg[8] = {g0[k].x, g0[k].y, g0[k].z, g0[k].w, g1[k].x, g1[k].y, g1[k].z, g1[k].w}, bb[8] = {t0[k].x, t0[k].y, t0[k].z, t0[k].w, t1[k].x, t1[k].y, t1[k].z, t1[k].w};
+          for (int rt = 0; rt < 2; ++rt) {
             bf16x8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (bf16)((v[pp][e] - mean) * rstd * gg[e] + bb[e]);
-            if (live) { if (p.store_nt) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(p.nln_out + ro + pp * 32)); else *reinterpret_cast<bf16x8*>(p.nln_out + ro + pp * 32) = o; }
+            for (int e = 0; e < 8; ++e) {
+              const float gn = e < 4 ? gb[4 * k][e] : gb[4 * k + 1][e - 4], of = e < 4 ? gb[4 * k + 2][e] : gb[4 * k + 3][e - 4];
+              o[e] = (bf16)fmaf(e < 4 ? acc2[rt][2 * pp][e] : acc2[rt][2 * pp + 1][e - 4], rstd2[rt] * gn, fmaf(nmr2[rt], gn, of));
+            }
+            if (live2[rt] && !((STAMPS >> 1) & 2)) { if (p.store_nt) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(p.nln_out + ro2[rt] + pp * 32)); else *reinterpret_cast<bf16x8*>(p.nln_out + ro2[rt] + pp * 32) = o; }
           }
-          __builtin_amdgcn_sched_barrier(0);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     MLP_PSTAMP(3);
@@ -503,6 +589,9 @@ static unsigned long long* g_mlp_dbg = nullptr;
 static int g_mlp_store_nt = 1;   // streaming policy on the epilogue's residual / LayerNorm stores: -0.25 ms per 32-page step
 void set_mlp_store_nt(int v) { g_mlp_store_nt = v; }
 void set_mlp_stamps(unsigned long long* d) { g_mlp_dbg = d; }
+static int g_mlp_stagger = 0, g_mlp_ablate = 0;
+void set_mlp_ablate(int v) { g_mlp_ablate = v; }
+void set_mlp_stagger(int v) { g_mlp_stagger = (v >> 16) > 1 ? v : 0; }
 
 const char* mlp_fused_check(const MlpParams& p) {
   if (p.M <= 0) return "mlp_fused: bad row count";
@@ -518,23 +607,29 @@ const char* mlp_fused_check(const MlpParams& p) {
 void launch_mlp_fused(const MlpParams& p_in, hipStream_t s) {
   MlpParams p = p_in;
   p.gelu_lut = gelu_lut_for_current_device();
-  p.dbg = g_mlp_dbg; p.store_nt = g_mlp_store_nt;
+  p.dbg = g_mlp_dbg; p.store_nt = g_mlp_store_nt; p.stagger = g_mlp_stagger; p.ablate = g_mlp_ablate;
   if (const char* e = mlp_fused_check(p)) throw std::runtime_error(e);
   static PerDeviceOnce once;
-  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
-    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
-    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
-    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS)); });
+  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
+    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
+    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
+    TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS)); });
   int dev = 0, cus = 256;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
   const int npanels = (p.M + BM - 1) / BM;
   const dim3 grid(std::min(cus, npanels));
+#ifdef MLP_ABLATE_BUILDS
+  if (p.att && p.ablate && !p.dbg) {   // production code + one ablation, timed from outside (rocprofv3)
+#define ABL(a) if (p.ablate == a) { static PerDeviceOnce o; o.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<true, 2 * a>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS)); }); hipLaunchKernelGGL((mlp_fused_kernel<true, 2 * a>), grid, dim3(256), MLP_LDS, s, p); return; }
+    ABL(2) ABL(12) ABL(14)
+  }
+#endif
   if (p.dbg) {
-    if (p.att) hipLaunchKernelGGL((mlp_fused_kernel<true, true>), grid, dim3(256), MLP_LDS, s, p);
-    else hipLaunchKernelGGL((mlp_fused_kernel<false, true>), grid, dim3(256), MLP_LDS, s, p);
-  } else if (p.att) hipLaunchKernelGGL((mlp_fused_kernel<true, false>), grid, dim3(256), MLP_LDS, s, p);
-  else hipLaunchKernelGGL((mlp_fused_kernel<false, false>), grid, dim3(256), MLP_LDS, s, p);
+    if (p.att) hipLaunchKernelGGL((mlp_fused_kernel<true, 1>), grid, dim3(256), MLP_LDS, s, p);
+    else hipLaunchKernelGGL((mlp_fused_kernel<false, 1>), grid, dim3(256), MLP_LDS, s, p);
+  } else if (p.att) hipLaunchKernelGGL((mlp_fused_kernel<true, 0>), grid, dim3(256), MLP_LDS, s, p);
+  else hipLaunchKernelGGL((mlp_fused_kernel<false, 0>), grid, dim3(256), MLP_LDS, s, p);
 }
 
 }  // namespace ttr
