@@ -48,7 +48,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t m_rsrc(const void* base, unsig
 #define MLP_RDV(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
 #define MLP_RD128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 // the lane id straight from the hardware (2 VALU): anything derived from threadIdx that lives across the chunk loop is a spill candidate
-#define MLP_LANE() __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))
+__device__ __forceinline__ unsigned mlp_lane_v() {   // volatile: hipcc cannot hoist what is derived from it out of the chunk loop (and then spill it:
+  unsigned l;                                          // a spill reload inside the loop waits with vmcnt(0), i.e. for the whole weight prefetch)
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+#define MLP_LANE() mlp_lane_v()
 #define MLP_WAIT8(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]))
 // timing experiments of the STAMPS build (MlpParams::ablate; results are wrong): 1 = per-channel vectors (biases, LayerNorm gains)
 // not loaded, 2 = no epilogue stores, 4 = attention output / residual rows of the front not loaded
@@ -98,7 +103,6 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
   //   row of a segment starts on bank 0).  Piece pp = 8 s + r = rows 4r .. 4r+3 of segment s.
   //   W2 image of a chunk: LDS row R' = 16 ot + q' holds output channel (ot>>1)*32 + (q'>>2)*8 + (ot&1)*4 + (q'&3); chunk gch of
   //   the 64-byte row sits at position gch ^ ((R'>>1) & 3).  Piece ot = rows 16 ot .. 16 ot + 15.
-#define src_lane (MLP_LANE() * 16u)
   const __amdgpu_buffer_rsrc_t rsp = m_rsrc(PROJ ? (const void*)p.wpp : (const void*)p.w2p, (unsigned)((PROJ ? E * E : HID * E) * 2));
   // Per-channel vectors (biases, LayerNorm gains and offsets: 1536 B each) ride in the W1 half of the two ring items that do not use
   // it — the last slab of Wp (bp | ln_g | ln_b for the front) and the panel's last item (b2 | nln_g | nln_b for the epilogue) —
@@ -109,6 +113,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
     const int v = wave == 3 ? 0 : wave;
     const float* src = v == 0 ? v0 : (v == 1 ? v1 : v2);
     const __amdgpu_buffer_rsrc_t rv = m_rsrc(src, (unsigned)(E * 4));
+    const unsigned src_lane = MLP_LANE() * 16u;
     unsigned char* d = smem + slot * SLOT + v * 2048;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr)d, 16, src_lane, 0, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr)(d + 1024), 16, src_lane + 1024u, 0, 0, 0);   // (in the vector offset: that is what the range check sees)
@@ -116,6 +121,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
   auto issue = [&](int Gi) {                                   // item Gi of the launch
     int ii = Gi % ITEMS;
     const int slot = Gi % NSLOT;
+    const unsigned src_lane = MLP_LANE() * 16u;                 // (re-read per call: see mlp_lane_v)
     unsigned char* sb = smem + slot * SLOT + wave * 1024;
     if (PROJ && ii < NPJ) {                                     // k-step slab ii of Wp
 #pragma unroll
@@ -318,6 +324,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
         MLP_G2(f1, 1)
         if (ks < 10) {                                          // item G + 2 is another slab of Wp (known at compile time)
           unsigned char* sb = smem + ((G + 2) % NSLOT) * SLOT + wave * 1024;
+          const unsigned src_lane = MLP_LANE() * 16u;
 #pragma unroll
           for (int j = 0; j < 6; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsp, (lds_ptr)(sb + W1B + j * 4096), 16, src_lane, (ks + 2) * W2B + (wave + 4 * j) * 1024, 0, 0);
           if (ks + 2 == NPJ - 1) issue_vec((G + 2) % NSLOT, p.bp, p.ln_g, p.ln_b);
