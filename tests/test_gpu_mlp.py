@@ -92,3 +92,24 @@ def test_mlp_pair_against_numpy(eng_bf16, M):
     assert np.abs(nout[rows] - rn).max() < 0.04
     assert np.array_equal(out, out2) and np.array_equal(nout, nout2)           # no race in the ring or the hidden exchange
     assert np.abs(out - out0).max() < 0.02
+
+
+def test_mlp_fused_layernorm_statistics_with_a_large_row_offset(eng_bf16):
+    """The front and the epilogue gather a row's LayerNorm statistics in one pass (sums shifted by the lane's first value, merged
+    over the row's four lanes as mean / M2 pairs).  Rows whose mean is 200 standard deviations away from zero - where a plain
+    sum-of-squares formula loses every digit in fp32 - must still normalise like the two-pass reference."""
+    M = 256
+    rng = np.random.default_rng(7)
+    x = (rng.standard_normal((M, 384)) * 0.5 + rng.uniform(-100.0, 100.0, (M, 1))).astype(np.float32)
+    att = rng.standard_normal((M, 384)).astype(np.float32)
+    wp = (rng.standard_normal((384, 384)) / np.sqrt(384)).astype(np.float32); bp = (0.2 * rng.standard_normal(384)).astype(np.float32)
+    ln_g = (1 + 0.2 * rng.standard_normal(384)).astype(np.float32); ln_b = (0.1 * rng.standard_normal(384)).astype(np.float32)
+    w1 = (rng.standard_normal((1536, 384)) / np.sqrt(384)).astype(np.float32); b1 = (0.2 * rng.standard_normal(1536)).astype(np.float32)
+    w2 = (rng.standard_normal((384, 1536)) / np.sqrt(1536)).astype(np.float32); b2 = (0.2 * rng.standard_normal(384)).astype(np.float32)
+    ng = (1 + 0.2 * rng.standard_normal(384)).astype(np.float32); nb = (0.1 * rng.standard_normal(384)).astype(np.float32)
+    out, nout = eng_bf16.dbg_mlp(x, ln_g, ln_b, w1, b1, w2, b2, ng, nb, att=att, wp=wp, bp=bp)
+    x1 = (x.astype(np.float64) + bf(att).astype(np.float64) @ bf(wp).astype(np.float64).T + bp).astype(np.float32)
+    ro, rn = ref_mlp(x1, ln_g, ln_b, w1, b1, w2, b2, ng, nb)
+    # the residual stream is ~100: one fp32 ulp of it is 8e-6, the bf16 operands' flips stay as above; the next LayerNorm divides by a std ~1
+    assert np.abs(out - ro).max() < 0.03, np.abs(out - ro).max()
+    assert np.abs(nout - rn).max() < 0.06, np.abs(nout - rn).max()
