@@ -12,6 +12,9 @@ words = int(sys.argv[3]) if len(sys.argv) > 3 else 28   # 0: blank pages, no cro
 d = tempfile.mkdtemp()
 W.make_synthetic_weights(d, seed=0, structured=True)
 eng = Engine(d, precision="bf16")
+for kv in sys.argv[4:]:                      # key=value tuning knobs (Engine.set_tuning)
+    k, v = kv.split("=")
+    assert eng.set_tuning(k, int(v)) == 0, kv
 pages = np.stack([synth.synthetic_page(i, 1024, 768, n_words=words) for i in range(P)]) if words else np.full((P, 1024, 768, 3), 255, np.uint8)
 buf = DeviceBuffer(pages.nbytes)
 buf.upload(pages)

@@ -53,6 +53,7 @@ struct Conv3sParams {
 };
 const char* conv3s_check(const Conv3sParams& p);
 void launch_conv3s(const Conv3sParams& p, hipStream_t s);
+void set_conv3s_wgs_per_cu(int v);   // persistent grid: workgroups per CU (default 4)
 // ---- conv3p.hip (bf16 3x3 conv with a patch-stationary input tile)
 const char* conv3p_check(const ConvParams& p);   // nullptr when conv3p can run the layer
 void launch_conv3p(const ConvParams& p, hipStream_t s);
