@@ -92,3 +92,19 @@ def test_first_pair_wave_specialised_kernel_is_bit_identical(engines_random, hw)
         ebf.set_tuning(b"c3_first_persistent", 2)
     assert np.isfinite(new).all()
     assert np.array_equal(old, new)
+
+
+@pytest.mark.parametrize("hw", [(256, 192), (32, 64), (96, 160)])
+def test_upsample_block_kernel_is_bit_identical(engines_random, hw):
+    """upsample2x_block_kernel (a thread forms a 2 x 4 output block from one clamped 3 x 4 input window) evaluates the expression of
+    the one-output-per-thread kernel on the same source pixels: the heat maps are equal bit for bit, in both precisions, down to the
+    smallest map the detector upsamples (2 x 4 at a 32 x 64 canvas: every pixel is a border pixel)."""
+    canvas = np.random.default_rng(sum(hw)).integers(0, 256, (*hw, 3), dtype=np.uint8)
+    for eng in engines_random:
+        try:
+            assert eng.set_tuning("upsample_block", 0) == 0
+            a = eng.craft_heatmap(canvas)
+        finally:
+            eng.set_tuning("upsample_block", 1)
+        b = eng.craft_heatmap(canvas)
+        assert np.isfinite(a).all() and np.array_equal(a, b)

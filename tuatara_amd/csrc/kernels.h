@@ -75,7 +75,8 @@ void launch_im2col_l1(Precision prec, const uint8_t* canvas, void* out, int B, i
 void launch_conv1_direct(const uint8_t* canvas, const void* wgt /*bf16 [64][32]*/, const float* bias, void* out /*bf16 [M][64]*/, int B, int H, int W, hipStream_t s);
 void launch_maxpool2x2(Precision prec, const void* in, void* out, int B, int H, int W, int C, int relu, hipStream_t s);
 void launch_maxpool3x3s1(Precision prec, const void* in, void* out, int B, int H, int W, int C, hipStream_t s);
-void launch_upsample2x(Precision prec, const void* in, void* out, int B, int H, int W, int C, hipStream_t s);  // in [B,H,W,C] -> out [B,2H,2W,C]
+void launch_upsample2x(Precision prec, const void* in, void* out, int B, int H, int W, int C, hipStream_t s);
+void set_upsample_block(int v);   // 1 (default): a thread forms a 2 x 4 output block from one 3 x 4 input window  // in [B,H,W,C] -> out [B,2H,2W,C]
 // T [M][ld] -> f32 [M][2] (the two heat-map channels)
 void launch_extract_heat(Precision prec, const void* in, int ld, float* out, int M, hipStream_t s);
 
