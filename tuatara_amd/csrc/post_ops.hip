@@ -203,21 +203,39 @@ __global__ void rowext_init_kernel(CclBuffers b, int npx) {
   c.rows_packed[2 * i] = 0x7fffffff; c.rows_packed[2 * i + 1] = -1;
 }
 
+// Per (candidate, row): the extent [min x, max x] of its pixels, for the host's rotating calipers.  A wave covers 64 consecutive pixels;
+// when W % 64 == 0 they lie in one image row, x grows with the lane, and the pixels of one (candidate, row) entry are folded inside the
+// wave - first lane = min, last lane = max, ONE lane issues the two atomics - instead of 64 lanes queueing on the same two addresses.
 __global__ void rowext_kernel(CclBuffers b, int H, int W) {
   const CclPage c = ccl_page(b, nullptr, H * W);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= H * W) return;
-  int r = c.parent[i];
-  if (r < 0) return;
-  int slot = c.cand_slot[r];
-  if (slot < 0) return;
-  uint8_t f = c.flags[i];
-  if ((f & 2) && !(f & 1)) return;  // segmap.setTo(0, link_score==1 & text_score==0)  (:160)
-  const int* cd = c.cand + 8 * slot;
-  int x = i % W, y = i / W;
-  int idx = cd[6] + (y - cd[3]);
-  atomicMin(&c.rows_packed[2 * idx], x);
-  atomicMax(&c.rows_packed[2 * idx + 1], x);
+  int idx = -1, x = 0;
+  if (i < H * W) {
+    int r = c.parent[i];
+    int slot = r >= 0 ? c.cand_slot[r] : -1;
+    if (slot >= 0) {
+      uint8_t f = c.flags[i];
+      if (!((f & 2) && !(f & 1))) {   // segmap.setTo(0, link_score==1 & text_score==0)  (:160)
+        const int* cd = c.cand + 8 * slot;
+        x = i % W;
+        idx = cd[6] + (i / W - cd[3]);
+      }
+    }
+  }
+  if (W % 64) {                       // a wave may straddle two rows: per-pixel atomics
+    if (idx >= 0) { atomicMin(&c.rows_packed[2 * idx], x); atomicMax(&c.rows_packed[2 * idx + 1], x); }
+    return;
+  }
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  unsigned long long todo = __ballot(idx >= 0);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int lidx = __shfl(idx, leader);
+    const unsigned long long same = __ballot(idx == lidx) & todo;
+    const int first = __ffsll((long long)same) - 1, last = 63 - __clzll((long long)same);
+    if (lane == first) { atomicMin(&c.rows_packed[2 * idx], x); atomicMax(&c.rows_packed[2 * idx + 1], x + (last - first)); }
+    todo &= ~same;
+  }
 }
 
 void launch_ccl(const float* heat, int pages, int H, int W, float text_threshold, float link_threshold, float low_text, int min_area, const CclBuffers& b, hipStream_t s) {
