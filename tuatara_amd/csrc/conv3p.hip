@@ -1014,6 +1014,8 @@ static void launch_c3(const ConvParams& p, hipStream_t s) {
 }
 
 void set_conv3p_first_persistent(int v) { g_first_persistent = v; }
+static int g_c32_tile = 1;          // Cout <= 32: 32-wide tiles, 4 waves of 64 pixels x 32 channels (0: the 64-wide tile)
+void set_conv3p_c32_tile(int v) { g_c32_tile = v; }
 static int g_c64_waves = 8;        // Cout <= 64 tiles: 8 waves (wave tile 64x32) or 4 waves (wave tile 64x64, fewer LDS fragment reads per MFMA)
 void set_conv3p_c64_waves(int w) { g_c64_waves = w; }
 static int g_force_bn128 = 1;     // BN = 128 single-stage tiles, two workgroups per CU, for every Cout > 64 (0: BN = 256, one per CU, for Cout % 256 == 0):
@@ -1053,6 +1055,7 @@ void launch_conv3p(const ConvParams& p, hipStream_t s) {
   const bool wide = p.H % 8 == 0 && p.W % 32 == 0;   // 8 x 32 patches; else 16 x 16 (checked above)
   if (p.Cout <= 64) {
     if (!wide) return launch_c3<64, 4, 2, false, 1, 4>(p, s);
+    if (p.Cout <= 32 && g_c32_tile && p.C0 <= g_xs1_max_cin) return launch_c3<32, 4, 1, false, 1>(p, s);   // upconv4.3: a 64-wide tile multiplies 32 rows of zero weights
     if (g_c64_waves == 4) return launch_c3<64, 4, 1, false, 1>(p, s);
     return p.C0 <= g_xs1_max_cin ? launch_c3<64, 4, 2, false, 1>(p, s) : launch_c3<64, 4, 2>(p, s);
   }
