@@ -90,6 +90,16 @@ def load():
     if _lib is None:
         if not os.path.exists(_LIBPATH):
             raise RuntimeError(f"{_LIBPATH} is missing: run `python -m tuatara_amd.build` (or __graft_entry__.build()) first")
+        # PyTorch's ROCm wheel carries its own HIP runtime.  If torch is imported AFTER this library (which links the system
+        # runtime) has been loaded, the process ends up with two runtimes and the one that initialises second sees no device
+        # ("no HIP device available").  Imported first, torch's copy is the one both use.  A Python process that loads the
+        # engine may import torch later (the oracle, torch.distributed), so: torch first, where it is installed
+        # (TUATARA_PRELOAD_TORCH=0 turns this off; the C++ callers - pytuatara, ocr_cli - never see torch).
+        if "torch" not in sys.modules and os.environ.get("TUATARA_PRELOAD_TORCH", "1") != "0":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         lib = C.CDLL(_LIBPATH)
         for name, res, args in SYMBOLS:
             fn = getattr(lib, name)
