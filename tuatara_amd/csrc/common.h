@@ -102,6 +102,21 @@ void hip_fail(const char* what, hipError_t e, const char* file, int line);  // t
 
 // hipFuncSetAttribute acts on the CURRENT device: the launchers set a kernel's dynamic-LDS limit once per (kernel, device),
 // from whatever thread gets there first (an engine per GPU in one process, engines driven from several threads).
+// Compute units of the current device, asked of the runtime once per device (hipGetDeviceProperties fills a ~1.5 KB struct and takes
+// tens of microseconds: too slow for a launch path that runs 60 times per batch)
+inline int device_cu_count(int fallback = 256) {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fallback;
+  std::atomic<int>& c = cache[dev & 63];
+  int n = c.load(std::memory_order_relaxed);
+  if (n > 0) return n;
+  hipDeviceProp_t prop;
+  n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : fallback;
+  c.store(n, std::memory_order_relaxed);
+  return n;
+}
+
 struct PerDeviceOnce {
   std::atomic<unsigned long long> done{0};
   std::mutex m;

@@ -988,9 +988,7 @@ static void launch_first2(const ConvParams& p_in, hipStream_t s) {
   constexpr int lds = 9 * 8192 + 2 * G::NHALO * 128 + 1408;   // 162,176 B of the 163,840
   static PerDeviceOnce once;
   once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_first2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); });
-  int dev = 0, cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  const int cus = device_cu_count(256);
   const int npatch = p.B * (p.H / G::PH) * (p.W / G::PW);
   if (g_first_persistent == 2 && ((uintptr_t)p.in0 & 3) == 0 && (size_t)p.B * p.H * p.W * 3 < ((size_t)1 << 31)) {
     constexpr int lds2 = 9 * 8192 + 2 * G::NHALO * 128 + 4 * 6 * 112;   // 163,456 B of the 163,840

@@ -155,9 +155,7 @@ void set_conv3s_wgs_per_cu(int v) { g_c3s_wgs_per_cu = v < 1 ? 1 : (v > 8 ? 8 : 
 void launch_conv3s(const Conv3sParams& p, hipStream_t s) {
   if (const char* e = conv3s_check(p)) throw std::runtime_error(e);
   const int tiles = p.B * (p.H / PH) * (p.W / PW);
-  int dev = 0, cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  const int cus = device_cu_count(256);
   const int grid = std::max(8, std::min((tiles + 7) & ~7, cus * g_c3s_wgs_per_cu));   // a multiple of 8: an equal number of workgroups per XCD
   if (p.heat) hipLaunchKernelGGL(conv3s_kernel<true>, dim3(grid), dim3(256), 0, s, p);
   else hipLaunchKernelGGL(conv3s_kernel<false>, dim3(grid), dim3(256), 0, s, p);

@@ -313,16 +313,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
   }
 }
 
-static int num_cus() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
-    else n = 256;
-  }
-  return n;
-}
+static int num_cus() { return device_cu_count(256); }   // (per device: a process may drive several)
 
 template <int BM, int BN, int WM, int WN, int MINB, int XST>
 static void launch_g2(const ConvParams& p, hipStream_t s) {

@@ -246,9 +246,7 @@ void launch_gemm_ws(const ConvParams& p_in, hipStream_t s) {
   ConvParams p = p_in;
   p.gelu_lut = p.act == kActGelu ? gelu_lut_for_current_device() : nullptr;
   p.dbg = g_ws_dbg; p.dbg_flags = g_ws_dbg_flags; p.store_policy = g_store_policy;
-  int dev = 0, cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8) cus = prop.multiProcessorCount;
+  const int cus = device_cu_count(256);
   const int nslices = (p.Cout + WS_BN - 1) / WS_BN;
   const int per_xcd = std::max(nslices, cus / 8);                 // one workgroup per CU; at least one slice set per XCD
   const int mg_per_xcd = per_xcd / nslices;

@@ -621,9 +621,7 @@ void launch_mlp_fused(const MlpParams& p_in, hipStream_t s) {
     TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
     TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
     TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS)); });
-  int dev = 0, cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  const int cus = device_cu_count(256);
   const int npanels = (p.M + BM - 1) / BM;
   const dim3 grid(std::min(cus, npanels));
 #ifdef MLP_ABLATE_BUILDS

@@ -384,9 +384,7 @@ void launch_mlp_pair(const MlpParams& p_in, hipStream_t s) {
   if (const char* e = mlp_pair_check(p)) throw std::runtime_error(e);
   static PerDeviceOnce once;
   once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS)); });
-  int dev = 0, cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  const int cus = device_cu_count(256);
   const int npanels = (p.M + BM - 1) / BM;
   hipLaunchKernelGGL(mlp_pair_kernel, dim3(std::min(cus, npanels)), dim3(512), PAIR_LDS, s, p);
 }
