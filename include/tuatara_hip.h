@@ -100,7 +100,9 @@ int ttr_resize_canvas(ttr_engine* e, const uint8_t* hwc_u8, int h, int w, int ro
 int ttr_pack_crops(ttr_engine* e, const uint8_t* hwc_u8, int h, int w, int row_stride, const float* rects5, int n,
                    float ratio, uint8_t* crops, float* boxes_out);
 /* PARSeq forward (tuatara.cpp:443-446 + :307): crops u8 [n][32][128][3] -> logits f32 [n][26][95];
- * ar_logits (optional) receives the autoregressive pass's logits, ids (optional) the argmax ids [n][26]. */
+ * ar_logits (optional) receives the autoregressive pass's logits - per crop defined up to and including its EOS step (upstream leaves
+ * its loop when every crop has emitted EOS; behind a crop's own EOS the bf16 engine skips it, and zero-fills the steps behind the batch's
+ * exit) -, ids (optional) the argmax ids [n][26]. */
 int ttr_parseq_logits(ttr_engine* e, const uint8_t* crops, int n, float* logits, float* ar_logits, int32_t* ids);
 /* Tokenizer::decode + EOS cut (tuatara.cpp:61-78, :497-502) on 26 ids; buf needs >= 27 bytes. */
 int ttr_decode_ids(const int32_t* ids, int n, char* buf);

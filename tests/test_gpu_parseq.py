@@ -15,9 +15,13 @@ def _same_path(a0, a1):
 
 
 def _ar_diff(a0, a1, same):
-    """|a1 - a0| of the crops in `same` over the AR steps that ran in both runs."""
+    """|a1 - a0| of the crops in `same` over the AR steps that ran in both runs, per crop up to and including its EOS: behind a crop's
+    EOS the step's attention kernels skip it (its rows hold whatever the previous step left), and nothing reads those logits."""
+    from tests.parity_rules import upto_eos
     ran = (np.abs(a0).max((0, 2)) > 0) & (np.abs(a1).max((0, 2)) > 0)
-    return np.abs(a1[same][:, ran] - a0[same][:, ran])
+    live = np.arange(a0.shape[1])[None, :] < upto_eos(a0.argmax(-1))[:, None]
+    d = np.abs(a1 - a0) * live[:, :, None]
+    return d[same][:, ran]
 
 
 def _crops(n, seed=0):
@@ -259,7 +263,7 @@ def test_ar_early_exit_is_invisible_in_the_refined_logits(eng_bf16, n):
     not depend on it).  The engine does the same on the device - the per-step kernels return at once when the batch's done counter
     has reached N - so the steps behind the exit cost a launch boundary each instead of a decode step.  Keys behind a crop's EOS are
     masked in the refinement pass, so the refined logits must be BIT-IDENTICAL with and without the exit; the AR logits agree on
-    every step that ran and read zero behind the exit."""
+    every step that ran - per crop up to its EOS - and read zero behind the exit."""
     crops = np.random.default_rng(21).integers(0, 256, (n, 32, 128, 3), dtype=np.uint8)
     try:
         assert eng_bf16.set_tuning(b"ar_early_exit", 0) == 0
@@ -273,8 +277,11 @@ def test_ar_early_exit_is_invisible_in_the_refined_logits(eng_bf16, n):
     ran = np.abs(a1).max((0, 2)) > 0                       # steps that ran for the batch
     steps = int(ran.sum())
     assert ran[:steps].all() and not ran[steps:].any()
-    assert np.array_equal(a0[:, :steps], a1[:, :steps])
     from tests.parity_rules import upto_eos
+    # per crop too: behind a crop's own EOS the step's two attention kernels skip it (ar_crop_exit), so its AR logits agree up to
+    # and including the EOS step and are undefined (never read) behind it
+    live = np.arange(26)[None, :] < upto_eos(a0.argmax(-1))[:, None]
+    assert np.array_equal(a0[live], a1[live])
     longest = int(upto_eos(a0.argmax(-1)).max())
     print(f"AR early exit, {n} crops: {steps} of 26 steps ran; the longest string of the batch ends at step {longest}")
     assert steps <= longest + 1 < 26                       # the designed weights decode strings of at most 10 characters

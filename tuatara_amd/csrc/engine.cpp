@@ -60,6 +60,7 @@ struct Tuning {
   int enc_chunk = 0;          // crops per encoder group (0 = all crops at once)
   int craft_group = 16;       // pages per CRAFT launch group (activation workspace ~0.5 GB/page; every tensor must stay inside the 2 GiB window of 32-bit buffer offsets)
   int ar_tail_step = 12;      // with ar_early_exit: AR steps from this one on run as ONE launch of the fused kernel (which returns at once when the batch is done)
+  int ar_crop_exit = 1;       // ... and, per crop, the two attention kernels of a step return for crops that have emitted EOS
   int ar_early_exit = 1;      // bf16 kernel-per-op AR loop: the steps' kernels return at once when every crop of the batch has emitted EOS (upstream's break)
   int decoder_mode = 1;       // 0 = kernel-per-op AR loop, 4/8/16 = fused kernel with that many crops per workgroup, else automatic
   bool set(const std::string& k, int value) {
@@ -69,6 +70,7 @@ struct Tuning {
     else if (k == "ln_fuse") ln_fuse = value;
     else if (k == "tok_fuse") tok_fuse = value;
     else if (k == "ar_early_exit") ar_early_exit = value;
+    else if (k == "ar_crop_exit") ar_crop_exit = value;
     else if (k == "ar_tail_step") ar_tail_step = value;
     else if (k == "craft_group") craft_group = value < 1 ? 1 : (value > 32 ? 32 : value);
     else if (k == "mlp_fused") mlp_fused = value;     // 0 off, 1 from mlp_min_rows rows on, 2 always
@@ -746,12 +748,12 @@ struct Engine {
   // decoder tail shared by the AR steps (R = 1) and the refinement pass (R = 26):
   // sa T [rows][384] -> logits f32 (row stride logits_ld)
   void decoder_tail(const void* sa, int N, int R, const float* resid_pos, int resid_mod, float* tgt, void* t384, void* t384b, void* t1536,
-                    const void* kvmem, float* logits_out, int logits_ld) {
+                    const void* kvmem, float* logits_out, int logits_ld, const int* done_tok = nullptr, int done_col = 0) {
     const int rows = N * R;
     const std::string d = "decoder.layers.0.";
     gemm(pq.at("self_out"), sa, rows, nullptr, 0, kActNone, tgt, 384, resid_pos, 384, resid_mod);      // tgt = query + self_attn
     ln_gemm(tgt, d + "norm1", 1e-5f, t384, pq.at("cross_q"), rows, t384b, 384, kActNone);
-    launch_dec_cross_attn(prec, t384b, kvmem, t384, N, R, stream, cur_skip, cur_skip_n);
+    launch_dec_cross_attn(prec, t384b, kvmem, t384, N, R, stream, cur_skip, cur_skip_n, done_tok, done_col);
     if (R > 1 && prec == kBF16 && gemm_config() >= 0 && tn.dec_mlp_fused && rows >= tn.dec_mlp_min_rows) {
       // refinement pass (26 rows per crop): the block behind the cross-attention is an encoder block's second half with other weights —
       // out projection + residual, norm2, linear1, GELU, linear2, residual, and the final norm as the "next LayerNorm" — one launch
@@ -916,7 +918,7 @@ struct Engine {
       }
       if (i >= nsteps) break;
       launch_dec_self_attn(prec, qself.as<float>(), kvcache, tk, att, N, 1, i, 0, stream, cur_skip, cur_skip_n);
-      decoder_tail(att, N, 1, posq + (size_t)i * E, 1, tgt, t384, d384b, d1536, kvmem, ar + (size_t)i * 95, 26 * 95);
+      decoder_tail(att, N, 1, posq + (size_t)i * E, 1, tgt, t384, d384b, d1536, kvmem, ar + (size_t)i * 95, 26 * 95, early && tn.ar_early_exit >= 1 && tn.ar_crop_exit ? tk : nullptr, i);
       if (i + 1 < 26 && !tok_fuse) launch_argmax(ar + (size_t)i * 95, 26 * 95, 95, tk, 26, i + 1, N, stream);
     }
     cur_skip = nullptr; cur_skip_n = 0;

@@ -98,7 +98,8 @@ void launch_dec_embed_ln(Precision prec, const int* tokens, const float* emb, co
 void launch_dec_self_attn(Precision prec, const float* q /*[26][384] f32*/, const void* kvcache, const int* tokens, void* out, int N, int R, int qi0, int mode, hipStream_t s,
                           const int* skip = nullptr, int skip_n = 0);
 // cross attention of rows [N*R] (Q: T [N*R][384]) against kvmem T [N*128][768]
-void launch_dec_cross_attn(Precision prec, const void* q, const void* kvmem, void* out, int N, int R, hipStream_t s, const int* skip = nullptr, int skip_n = 0);
+void launch_dec_cross_attn(Precision prec, const void* q, const void* kvmem, void* out, int N, int R, hipStream_t s, const int* skip = nullptr, int skip_n = 0,
+                           const int* done_tok = nullptr, int done_col = 0);   // done_tok [N][26]: AR steps skip crops with EOS (0) in columns 1 .. done_col
 // tokens[n*tok_ld + col] = argmax over C of logits[n*ld ..]
 void launch_argmax(const float* logits, int ld, int C, int* tokens, int tok_ld, int col, int N, hipStream_t s);
 void launch_fill_i32(int* p, int value, int n, int stride, hipStream_t s);

@@ -258,6 +258,9 @@ __global__ __launch_bounds__(384) void dec_self_attn_kernel(const float* __restr
   __shared__ float sp[12][28];
   __shared__ int visible[26];
   const int row = blockIdx.x, n = row / R, qi = (mode == 0) ? qi0 : row % R;
+  if (skip && mode == 0) {   // ... and per crop: this crop has emitted EOS (token columns 1 .. qi0), nothing behind it is ever read
+    for (int c = 1; c <= qi0; ++c) if (tokens[n * 26 + c] == 0) return;
+  }
   const int nkeys = (mode == 0) ? qi + 1 : 26;
   const int t = threadIdx.x;
   sq[t] = q[qi * 384 + t];
@@ -441,8 +444,12 @@ __global__ __launch_bounds__(384) void dec_cross_attn_kernel(const T* __restrict
 // whole row (the kernel above reads 2 bytes per lane at a 1.5 KB stride).  4 waves x 32 keys each, online softmax per wave,
 // partial (max, sum, out) merged through LDS.  Lane c < 48 holds dims 8c..8c+7, head = c / 4.
 __global__ __launch_bounds__(256) void dec_cross_attn_rows_kernel(const bf16* __restrict__ q, const bf16* __restrict__ kvmem, bf16* __restrict__ out, int R,
-                                                                  const int* skip, int skip_n) {
+                                                                  const int* skip, int skip_n, const int* done_tok, int done_col) {
   if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;   // AR early exit (see ConvParams::skip)
+  if (done_tok) {   // per crop (AR steps, R = 1): a crop that has emitted EOS in token columns 1 .. done_col reads no more of its 196 KB of K / V -
+    const int* tr = done_tok + (int64_t)(blockIdx.x / R) * 26;   // what the rest of the step computes for its row is never read (refinement masks it)
+    for (int c = 1; c <= done_col; ++c) if (tr[c] == 0) return;
+  }
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
   __shared__ float sm[4][48], sl[4][48], so[4][48][8];
   const int row = blockIdx.x, n = row / R, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -521,11 +528,12 @@ __global__ __launch_bounds__(256) void dec_cross_attn_rows_kernel(const bf16* __
 static int g_cross_mfma = 1;
 void set_dec_cross_mfma(int v) { g_cross_mfma = v; }
 
-void launch_dec_cross_attn(Precision prec, const void* q, const void* kvmem, void* out, int N, int R, hipStream_t s, const int* skip, int skip_n) {
+void launch_dec_cross_attn(Precision prec, const void* q, const void* kvmem, void* out, int N, int R, hipStream_t s, const int* skip, int skip_n,
+                           const int* done_tok, int done_col) {
   if (N <= 0) return;
   if (prec == kBF16 && g_cross_mfma && (R == 26 || g_cross_mfma == 2)) return launch_dec_cross_attn_mfma((const bf16*)q, (const bf16*)kvmem, (bf16*)out, N, R, s);   // refinement pass (attn_dec2.hip); 2: the AR steps' single row too
   dim3 grid(N * R);
-  if (prec == kBF16) hipLaunchKernelGGL(dec_cross_attn_rows_kernel, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)kvmem, (bf16*)out, R, skip, skip_n);
+  if (prec == kBF16) hipLaunchKernelGGL(dec_cross_attn_rows_kernel, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)kvmem, (bf16*)out, R, skip, skip_n, R == 1 ? done_tok : nullptr, done_col);
   else hipLaunchKernelGGL(dec_cross_attn_kernel<float>, grid, dim3(384), 0, s, (const float*)q, (const float*)kvmem, (float*)out, R);
 }
 
