@@ -1014,6 +1014,8 @@ static void launch_c3(const ConvParams& p, hipStream_t s) {
 void set_conv3p_first_persistent(int v) { g_first_persistent = v; }
 static int g_c32_tile = 1;          // Cout <= 32: 32-wide tiles, 4 waves of 64 pixels x 32 channels (0: the 64-wide tile)
 void set_conv3p_c32_tile(int v) { g_c32_tile = v; }
+static int g_narrow_bn64 = 2;       // 16 x 16-patch maps with Cout > 64 on 64-wide tiles: 0 never, 1 always, 2 when the 128-wide tiles do not fill the chip once
+void set_conv3p_narrow_bn64(int v) { g_narrow_bn64 = v; }
 static int g_c64_waves = 8;        // Cout <= 64 tiles: 8 waves (wave tile 64x32) or 4 waves (wave tile 64x64, fewer LDS fragment reads per MFMA)
 void set_conv3p_c64_waves(int w) { g_c64_waves = w; }
 static int g_force_bn128 = 1;     // BN = 128 single-stage tiles, two workgroups per CU, for every Cout > 64 (0: BN = 256, one per CU, for Cout % 256 == 0):
@@ -1057,7 +1059,13 @@ void launch_conv3p(const ConvParams& p, hipStream_t s) {
     if (g_c64_waves == 4) return launch_c3<64, 4, 1, false, 1>(p, s);
     return p.C0 <= g_xs1_max_cin ? launch_c3<64, 4, 2, false, 1>(p, s) : launch_c3<64, 4, 2>(p, s);
   }
-  if (!wide) return launch_c3<128, 4, 2, false, 1, 4>(p, s);
+  if (!wide) {
+    // fewer 128-wide tiles than the chip holds at once (two workgroups per CU): 64-wide tiles fill it better (upconv1.3 at 16 pages:
+    // 384 tiles -> 768, 112 -> 98 us; the layers with a full round of 128-wide tiles lose 0-2 % on the narrower tile)
+    const int tiles128 = p.B * (p.H / 16) * (p.W / 16) * ((p.Cout + 127) / 128);
+    const bool narrow = g_narrow_bn64 == 1 || (g_narrow_bn64 == 2 && tiles128 < 2 * device_cu_count(256));
+    return narrow ? launch_c3<64, 4, 2, false, 1, 4>(p, s) : launch_c3<128, 4, 2, false, 1, 4>(p, s);
+  }
   if (p.Cout <= 128 || p.Cout % 256 || g_force_bn128) return p.C0 <= g_xs1_max_cin ? launch_c3<128, 4, 2, false, 1>(p, s) : launch_c3<128, 4, 2>(p, s);
   return launch_c3<256, 2, 4>(p, s);
 }

@@ -1599,6 +1599,7 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "mlp_stagger") set_mlp_stagger(value);
   else if (k == "c3s_wgs") set_conv3s_wgs_per_cu(value);
   else if (k == "c3_c32") set_conv3p_c32_tile(value);
+  else if (k == "c3_narrow64") set_conv3p_narrow_bn64(value);
   else if (k == "upsample_block") set_upsample_block(value);
   else if (k == "mlp_ablate") set_mlp_ablate(value);
   else if (k == "attn_impl") set_attn_impl(value);

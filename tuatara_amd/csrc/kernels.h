@@ -61,6 +61,7 @@ void set_conv3p_single_stage_max_cin(int c);
 void set_conv3p_force_bn128(int v);
 void set_conv3p_c64_waves(int w);
 void set_conv3p_first_persistent(int v);
+void set_conv3p_narrow_bn64(int v);
 void set_conv3p_c32_tile(int v);   // Cout <= 32 on 32-wide tiles (default 1)
 // n pseudo-random values, uniform in [-scale, scale) (benchmark inputs)
 void launch_fill_random(Precision prec, void* p, size_t n, unsigned seed, float scale, hipStream_t s);
