@@ -189,10 +189,35 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
 #define MLP_M2(src, n) MLP_M2B(src, n, hf[0], hf[1])
 #define MLP_WAITF(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]))
 #define MLP_WAITFT(n, f, t) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]))
-    // GELU of one quarter (4 hidden units of one row tile) around its table read: A = index + read request, B = interpolate,
-    // multiply, round to bf16 into half of the row tile's B fragment
+    // GELU of one quarter (4 hidden units of one row tile), rounded to bf16 into half of the row tile's B fragment.
+    // Table form (default): A = index + read request, B = interpolate (1024 knots of Phi on [-8, 8), |dPhi| < 7e-6), multiply.
+    // MLP_GELU_POLY 1 (measured, slower: 618 vs 555 us per launch): gelu(x) = 0.5 x + |x| S(min(|x|, 5)), S(u) = Phi(u) - 0.5 as a
+    // degree-12 polynomial in t = 0.4 u - 1 (Chebyshev fit on [0, 5], fp32 Horner: |gelu - exact| < 2.1e-6 over [-10, 10]) - no LDS
+    // read, but 96 packed FMAs + ~50 more vector-ALU instructions per chunk than the table form's ~110, and every one of them is
+    // issue time of the wave's serial stream here (the isolated loop of tools/micro/mlp_loop.hip hides such work; this kernel does not).
+#ifndef MLP_GELU_POLY
+#define MLP_GELU_POLY 0
+#endif
     float u4[4];
     float2 t4[4];
+#if MLP_GELU_POLY
+    for (int e = 0; e < 4; ++e) { u4[e] = 0.f; t4[e] = make_float2(0.f, 0.f); }   // (only named by the waits' register lists)
+    auto gelu_a = [&](const f32x4&) {};
+    auto gelu_b = [&](const f32x4& acc, bf16x8& o, int half) {
+      constexpr float kC[13] = {0.49378976225852966f, 0.043821267783641815f, -0.13688436150550842f, 0.23961056768894196f, -0.23270182311534882f,
+                                0.06559479981660843f, 0.13090801239013672f, -0.16348905861377716f, 0.025033878162503242f, 0.07832171767950058f,
+                                -0.04101016744971275f, -0.013859635218977928f, 0.01086505502462387f};
+      float t[4], s[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { t[e] = fmaf(fminf(fabsf(acc[e]), 5.0f), 0.4f, -1.0f); s[e] = kC[12]; }
+#pragma unroll
+      for (int k = 11; k >= 0; --k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] = fmaf(s[e], t[e], kC[k]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[half * 4 + e] = (bf16)fmaf(fabsf(acc[e]), s[e], 0.5f * acc[e]);
+    };
+#else
     auto gelu_a = [&](const f32x4& acc) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -205,6 +230,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[half * 4 + e] = (bf16)(acc[e] * fmaf(__builtin_amdgcn_fractf(u4[e]), t4[e].y, t4[e].x));
     };
+#endif
 
     // Software pipeline over the 48 hidden chunks: iteration i runs GEMM1 of chunk i with the GELU of chunk i-1 in the
     // shadow of its MFMAs, then GEMM2 of chunk i-1.  Ring item G (49 per panel, G counts over the whole launch) =
