@@ -818,6 +818,7 @@ struct Engine {
           q.w2p = fc2_packed[l].as<bf16>(); q.b2 = pq.at(p + "fc2").b.as<float>();
           q.nln_g = pqf.at(nx + ".weight").as<float>(); q.nln_b = pqf.at(nx + ".bias").as<float>(); q.nln_eps = 1e-6f; q.nln_out = (bf16*)t384;
           if (proj_in) { q.att = (const bf16*)att; q.wpp = proj_packed[l].as<bf16>(); q.bp = pq.at(p + "proj").b.as<float>(); }
+          q.no_x_store = l == 11 && !tn.mlp_pair;   // behind the last block only the final norm (the decoder's memory) is read
           timed(2.0 * Mc * E * 4 * E * 2 + (proj_in ? 2.0 * Mc * E * E : 0.0), [&] { if (tn.mlp_pair) launch_mlp_pair(q, stream); else launch_mlp_fused(q, stream); });
           continue;
         }

@@ -115,6 +115,7 @@ struct MlpParams {
   const float *nln_g, *nln_b; float nln_eps; bf16* nln_out;   // optional: LayerNorm of x_out -> bf16 [M][384]
   const bf16* att; const bf16* wpp; const float* bp;  // optional: x' = x + att . Wp^T + bp first (att bf16 [M][384], Wp as 12 k-step images, pack_mlp_w2)
   const void* gelu_lut;    // set by the launcher
+  int no_x_store;          // 1: x_out is not written (the caller only wants nln_out: the last encoder block - nothing reads its residual stream)
   int store_nt;            // set by the launcher: streaming policy on the epilogue stores
   unsigned long long* dbg; // optional [48][8] shader-clock stamps of workgroup 0 / wave 0 over its first panel (diagnostics)
   int M;

@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpParams p) {
             asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a_), "+v"(b_));
             slo[e] = a_; shi[e] = b_;
           }
-          if (live && !((STAMPS >> 1) & 2)) {
+          if (live && !p.no_x_store && !((STAMPS >> 1) & 2)) {
             float* op = ob + pp * 32;
             if (p.store_nt) { __builtin_nontemporal_store(slo, reinterpret_cast<f4*>(op)); __builtin_nontemporal_store(shi, reinterpret_cast<f4*>(op + 16)); }
             else { *reinterpret_cast<f4*>(op) = slo; *reinterpret_cast<f4*>(op + 16) = shi; }
@@ -630,6 +630,7 @@ const char* mlp_fused_check(const MlpParams& p) {
   if (p.M <= 0) return "mlp_fused: bad row count";
   if (!p.x || !p.x_out || !p.ln_g || !p.ln_b || !p.w1p || !p.b1 || !p.w2p || !p.b2 || !p.gelu_lut) return "mlp_fused: null operand";
   if (p.nln_out && (!p.nln_g || !p.nln_b)) return "mlp_fused: next LayerNorm parameters";
+  if (p.no_x_store && !p.nln_out) return "mlp_fused: no output";
   if (p.att && (!p.wpp || !p.bp || (((uintptr_t)p.att | (uintptr_t)p.wpp | (uintptr_t)p.bp) & 15))) return "mlp_fused: projection operands";
   const uintptr_t a = (uintptr_t)p.x | (uintptr_t)p.x_out | (uintptr_t)p.ln_g | (uintptr_t)p.ln_b | (uintptr_t)p.w1p | (uintptr_t)p.b1 | (uintptr_t)p.w2p |
                       (uintptr_t)p.b2 | (uintptr_t)p.nln_out | (uintptr_t)p.nln_g | (uintptr_t)p.nln_b | (uintptr_t)p.gelu_lut;
