@@ -14,7 +14,8 @@
 //     K rows permuted so a lane of the score MFMA ends up with 8 consecutive keys);
 //   * the attention itself is attn_enc2.hip's: S^T = K Q^T, in-register softmax -> P fragments, V^T by transposed LDS reads,
 //     128-byte output rows.  The next crop's first half is already streaming in meanwhile.
-// The six head workgroups of a crop group sit on one XCD (blockIdx % 8) and read the same activation rows: one HBM fetch.
+// The six head workgroups of a crop group sit on one XCD (blockIdx % 8) and read the same activation rows: one HBM fetch
+// (40 groups on 30 of an XCD's 32 CUs; two more groups on the left-over CUs).
 // Rounding points are those of the separate kernels (q, k, v rounded to bf16; P rounded to bf16; output bf16).
 #include "common.h"
 #include "kernels.h"
@@ -45,11 +46,18 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_kernel(const bf16* __restrict
 
   // workgroups b and b + 8 share an XCD (speed only): XCD x runs crop groups 5x .. 5x+4, six head workgroups each
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  if (slot >= GROUPS_PER_XCD * NH) return;
-  const int h = slot % NH, group = xcd * GROUPS_PER_XCD + slot / NH;
-  constexpr int NGROUPS = 8 * GROUPS_PER_XCD;
+  // ... and the two left-over CUs of every XCD (16 workgroups) run the twelve head workgroups of crop groups 40 and 41, spread over
+  // the XCDs (their activations are fetched once per head instead of once per group): 42 groups, 31 crops each at 1280 instead of 32
+  constexpr int NGROUPS = 8 * GROUPS_PER_XCD + 2;
+  int h, group;
+  if (slot < GROUPS_PER_XCD * NH) { h = slot % NH; group = xcd * GROUPS_PER_XCD + slot / NH; }
+  else {
+    const int sp = xcd * 2 + (slot - GROUPS_PER_XCD * NH);
+    if (sp >= 2 * NH) return;
+    h = sp % NH; group = 8 * GROUPS_PER_XCD + sp / NH;
+  }
   if (group >= N) return;
-  const int ncrops = (N - group + NGROUPS - 1) / NGROUPS;     // crops group, group + 40, ...
+  const int ncrops = (N - group + NGROUPS - 1) / NGROUPS;     // crops group, group + 42, ...
 
   // ---- resident weights: output column c = 48 wave + 16 ct + row of the head's [Q | K | V] block (64 each)
   bf16x8 fw[3][12];
