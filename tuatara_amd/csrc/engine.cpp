@@ -754,7 +754,11 @@ struct Engine {
     gemm(pq.at("self_out"), sa, rows, nullptr, 0, kActNone, tgt, 384, resid_pos, 384, resid_mod);      // tgt = query + self_attn
     ln_gemm(tgt, d + "norm1", 1e-5f, t384, pq.at("cross_q"), rows, t384b, 384, kActNone);
     launch_dec_cross_attn(prec, t384b, kvmem, t384, N, R, stream, cur_skip, cur_skip_n, done_tok, done_col);
-    if (R > 1 && prec == kBF16 && gemm_config() >= 0 && tn.dec_mlp_fused && rows >= tn.dec_mlp_min_rows) {
+    // (the fused block kernel is one persistent workgroup per CU over 128-row panels: when the panels fill the last round of CUs badly -
+    // 1280 crops x 26 rows = 260 panels on 256 CUs: two rounds for 1.02 - the separate GEMMs are faster: 12.17 vs 12.27 ms per forward)
+    const int dec_panels = (rows + 127) / 128, dec_cus = device_cu_count(256), dec_rounds = (dec_panels + dec_cus - 1) / dec_cus;
+    const bool dec_fill = tn.dec_mlp_fused == 2 || dec_panels * 100 >= 65 * dec_rounds * dec_cus;
+    if (R > 1 && prec == kBF16 && gemm_config() >= 0 && tn.dec_mlp_fused && rows >= tn.dec_mlp_min_rows && dec_fill) {
       // refinement pass (26 rows per crop): the block behind the cross-attention is an encoder block's second half with other weights —
       // out projection + residual, norm2, linear1, GELU, linear2, residual, and the final norm as the "next LayerNorm" — one launch
       MlpParams q{};
