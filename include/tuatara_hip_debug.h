@@ -32,7 +32,7 @@ void ttr_set_decoder_mode(int mode);
  * weight-stationary GEMM), "mlp_fused" (0 off, 1 = from "mlp_min_rows" rows on (default), 2 = always), "ln_fuse" (decoder
  * LayerNorms inside the skinny GEMM), "tok_fuse" (AR steps: argmax + token embedding + norm_c inside the self_kv skinny GEMM), "self_refine" (refinement-pass
  * self-attention as one workgroup per crop), "cross_mfma" (refinement-pass cross-attention on the matrix cores), "dec_mlp_fused" / "dec_mlp_min_rows" (refinement pass: cross_out + norm2 + FFN + final norm through the
- * fused block kernel from that many rows on), "fuse_first", "ws_lean", "store_policy" (0 default, 1 streaming, 2 system-scope streaming
+ * fused block kernel from that many rows on; 1 = when its 128-row panels fill the CUs' last round to 65 %, 2 = always), "fuse_first", "ws_lean", "store_policy" (0 default, 1 streaming, 2 system-scope streaming
  * output stores), "g2_x_ring3", "c3_*" (conv3p variants: "c3_c32" 32-wide tiles for Cout <= 32, "c3_narrow64" 64-wide tiles on the
  * 16x16-patch maps: 0 never / 1 always / 2 when the chip would be under-filled), "c3s_wgs" (persistent conv3s workgroups per CU),
  * "upsample_block" (2x4-block bilinear kernel), "craft_group" (pages per CRAFT launch group), "ar_early_exit" / "ar_crop_exit" /
