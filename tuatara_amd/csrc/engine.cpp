@@ -480,7 +480,12 @@ struct Engine {
     };
     auto vec = [&](const std::string& name, size_t n) { upload_f32(pqf[name], wf.get(name, n).data.data(), n); };
     const int E = 384;
-    lin("patch", "encoder.patch_embed.proj.weight", "encoder.patch_embed.proj.bias", E, 96);
+    {   // patch embedding: K = 96 (4 x 8 x 3); the bf16 engine pads it to 128 so that the linear runs on gemm2 (K % 64) instead of the
+      // first-generation igemm (104 -> ~60 us at 1280 crops); the pad columns are zero in the patches and in the weights
+      const auto& w = wf.get("encoder.patch_embed.proj.weight", (size_t)E * 96);
+      const auto& b = wf.get("encoder.patch_embed.proj.bias", (size_t)E);
+      upload_linear(pq["patch"], w.data.data(), E, 96, b.data.data(), E, prec == kBF16 ? 128 : 96);
+    }
     vec("encoder.pos_embed", 128 * E);
     for (int i = 0; i < 12; ++i) {
       std::string p = "encoder.blocks." + std::to_string(i) + ".";
@@ -783,12 +788,13 @@ struct Engine {
     if (N <= 0) return;
     prof_stage = 1;
     const int M = N * 128, E = 384;
-    void* patches = (pq_ws[0].ensure((size_t)M * 96 * es), pq_ws[0].p);
+    const int patch_ld = pq.at("patch").k;   // 96, or 128 in bf16 mode (zero-padded)
+    void* patches = (pq_ws[0].ensure((size_t)M * patch_ld * es), pq_ws[0].p);
     float* x = (float*)(pq_ws[1].ensure((size_t)M * E * 4), pq_ws[1].p);
     void* t384 = (pq_ws[2].ensure((size_t)std::max(M, N * 26) * E * es), pq_ws[2].p);
     void* tbig = (pq_ws[3].ensure((size_t)M * 1536 * es), pq_ws[3].p);
     void* att = (pq_ws[4].ensure((size_t)std::max(M, N * 26) * E * es), pq_ws[4].p);
-    launch_patchify(prec, d_crops, patches, N, stream);
+    launch_patchify(prec, d_crops, patches, N, patch_ld, stream);
     gemm(pq.at("patch"), patches, M, nullptr, 0, kActNone, x, E, pqf.at("encoder.pos_embed").as<float>(), E, 128);
     // The 12 encoder blocks run over groups of crops so that a group's widest intermediates (qkv, the MLP hidden) are
     // re-read from the 256 MiB Infinity Cache rather than from HBM (tn.enc_chunk crops per group; 0 = one group).

@@ -83,7 +83,7 @@ void set_upsample_block(int v);   // 1 (default): a thread forms a 2 x 4 output 
 void launch_extract_heat(Precision prec, const void* in, int ld, float* out, int M, hipStream_t s);
 
 // ---- parseq_ops.hip
-void launch_patchify(Precision prec, const uint8_t* crops, void* out, int N, hipStream_t s);
+void launch_patchify(Precision prec, const uint8_t* crops, void* out, int N, int ld, hipStream_t s);   // out [N*128][ld], ld >= 96: columns 96 .. ld-1 are zeroed
 void launch_layernorm(Precision prec, const float* in, int in_ld, const float* gamma, const float* beta, float eps, void* out, int out_ld, int M, int D, hipStream_t s);
 void launch_attn_enc(Precision prec, const void* qkv, void* out, int N, hipStream_t s);  // qkv T [N*128][1152] -> out T [N*128][384]
 void launch_attn_enc2(const bf16* qkv, bf16* out, int N, hipStream_t s);                  // bf16, second generation (attn_enc2.hip)

@@ -11,23 +11,25 @@ namespace ttr {
 // ------------------------------------------------------------------ patchify
 // crops u8 [N][32][128][3] -> A [N*128][96], token = py*16+px (4x8 patches), k = (dy*8+dx)*3+c
 template <typename T>
-__global__ void patchify_kernel(const uint8_t* __restrict__ crops, T* __restrict__ out, int N) {
+__global__ void patchify_kernel(const uint8_t* __restrict__ crops, T* __restrict__ out, int N, int ld) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (token row, dy): 24 contiguous bytes
   int total = N * 128 * 4;
   if (idx >= total) return;
   int dy = idx & 3, row = idx >> 2;
   int n = row >> 7, tok = row & 127, py = tok >> 4, px = tok & 15;
   const uint8_t* src = crops + (((size_t)n * 32 + py * 4 + dy) * 128 + px * 8) * 3;
-  T* dst = out + (size_t)row * 96 + dy * 24;
+  T* dst = out + (size_t)row * ld + dy * 24;
 #pragma unroll
   for (int i = 0; i < 24; ++i) dst[i] = (T)((float)src[i] / 255.0f);
+  for (int i = 96 + dy; i < ld; i += 4) out[(size_t)row * ld + i] = (T)0.f;   // K padded for the GEMM kernel (ld = 128)
 }
 
-void launch_patchify(Precision prec, const uint8_t* crops, void* out, int N, hipStream_t s) {
+void launch_patchify(Precision prec, const uint8_t* crops, void* out, int N, int ld, hipStream_t s) {
   if (N <= 0) return;
+  if (ld < 96) throw std::runtime_error("patchify: row stride < 96");
   dim3 grid((N * 128 * 4 + 255) / 256);
-  if (prec == kBF16) hipLaunchKernelGGL(patchify_kernel<bf16>, grid, dim3(256), 0, s, crops, (bf16*)out, N);
-  else hipLaunchKernelGGL(patchify_kernel<float>, grid, dim3(256), 0, s, crops, (float*)out, N);
+  if (prec == kBF16) hipLaunchKernelGGL(patchify_kernel<bf16>, grid, dim3(256), 0, s, crops, (bf16*)out, N, ld);
+  else hipLaunchKernelGGL(patchify_kernel<float>, grid, dim3(256), 0, s, crops, (float*)out, N, ld);
 }
 
 // ------------------------------------------------------------------ LayerNorm: one wave64 per row
