@@ -9,6 +9,6 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print(f"kernel time per 16-page pass {tot/4e6:.2f} ms")
-for r in rows[:16]:
+for r in rows[:40]:
     print(f"{float(r['TotalDurationNs'])/4e6:8.3f} ms/pass {int(r['Calls'])/4:5.1f} x {float(r['AverageNs'])/1e3:8.1f} us  {r['Name'][:80]}")
 PY

@@ -169,6 +169,39 @@ __global__ void maxpool2x2_kernel(const T* __restrict__ in, T* __restrict__ out,
   st_chunk(out + (((int64_t)b * Ho + yo) * Wo + xo) * C + cc * N, o);
 }
 
+// The same for W % 4 == 0, half the load instructions per output: a thread owns four consecutive outputs of a row and reads the
+// 3 x 6 window above them once, coordinates clamped at the borders (a duplicated border pixel does not change a maximum): column maxima
+// first, then three adjacent ones per output.  max is exact and order-free: bit-identical to the kernel below.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3x3s1_strip_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C) {
+  constexpr int N = Chunk<T>::N;
+  const int Cc = C / N, Wq = W / 4;
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)B * H * Wq * Cc;
+  if (idx >= total) return;
+  const int cc = (int)(idx % Cc); int64_t t = idx / Cc;
+  const int xq = (int)(t % Wq); t /= Wq;
+  const int y = (int)(t % H); const int b = (int)(t / H);
+  const int x0 = 4 * xq;
+  const T* base = in + (int64_t)b * H * W * C + cc * N;
+  const int ry[3] = {max(y - 1, 0), y, min(y + 1, H - 1)};
+  float col[6][N];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const int x = min(max(x0 - 1 + c, 0), W - 1);
+    const Chunk<T> v0 = ld_chunk(base + ((int64_t)ry[0] * W + x) * C), v1 = ld_chunk(base + ((int64_t)ry[1] * W + x) * C), v2 = ld_chunk(base + ((int64_t)ry[2] * W + x) * C);
+#pragma unroll
+    for (int i = 0; i < N; ++i) col[c][i] = fmaxf(fmaxf((float)v0.v[i], (float)v1.v[i]), (float)v2.v[i]);
+  }
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    Chunk<T> o;
+#pragma unroll
+    for (int i = 0; i < N; ++i) o.v[i] = (T)fmaxf(fmaxf(col[d][i], col[d + 1][i]), col[d + 2][i]);
+    st_chunk(out + (((int64_t)b * H + y) * W + x0 + d) * C + cc * N, o);
+  }
+}
+
 template <typename T>
 __global__ void maxpool3x3s1_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C) {
   constexpr int N = Chunk<T>::N;
@@ -288,6 +321,9 @@ __global__ void extract_heat_kernel(const T* __restrict__ in, int ld, float* __r
 
 static inline int chunk_elems(Precision p) { return p == kBF16 ? 8 : 4; }
 
+static int g_upsample_block = 1;   // upsample2x: 2 x 4 output blocks per thread, maxpool3x3s1: 1 x 4 strips (0: one output chunk per thread)
+void set_upsample_block(int v) { g_upsample_block = v; }
+
 void launch_maxpool2x2(Precision prec, const void* in, void* out, int B, int H, int W, int C, int relu, hipStream_t s) {
   if (C % chunk_elems(prec) || (H | W) & 1) throw std::runtime_error("maxpool2x2: bad shape");
   int64_t total = (int64_t)B * (H / 2) * (W / 2) * (C / chunk_elems(prec));
@@ -297,13 +333,18 @@ void launch_maxpool2x2(Precision prec, const void* in, void* out, int B, int H, 
 }
 void launch_maxpool3x3s1(Precision prec, const void* in, void* out, int B, int H, int W, int C, hipStream_t s) {
   if (C % chunk_elems(prec)) throw std::runtime_error("maxpool3x3: bad shape");
+  if (W % 4 == 0 && g_upsample_block) {   // (the knob of the block-wise elementwise kernels)
+    const int64_t ns = (int64_t)B * H * (W / 4) * (C / chunk_elems(prec));
+    dim3 gs((unsigned)((ns + 255) / 256));
+    if (prec == kBF16) hipLaunchKernelGGL(maxpool3x3s1_strip_kernel<bf16>, gs, dim3(256), 0, s, (const bf16*)in, (bf16*)out, B, H, W, C);
+    else hipLaunchKernelGGL(maxpool3x3s1_strip_kernel<float>, gs, dim3(256), 0, s, (const float*)in, (float*)out, B, H, W, C);
+    return;
+  }
   int64_t total = (int64_t)B * H * W * (C / chunk_elems(prec));
   dim3 grid((unsigned)((total + 255) / 256));
   if (prec == kBF16) hipLaunchKernelGGL(maxpool3x3s1_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)in, (bf16*)out, B, H, W, C);
   else hipLaunchKernelGGL(maxpool3x3s1_kernel<float>, grid, dim3(256), 0, s, (const float*)in, (float*)out, B, H, W, C);
 }
-static int g_upsample_block = 1;   // 2 x 4 output blocks per thread (0: one output chunk per thread)
-void set_upsample_block(int v) { g_upsample_block = v; }
 void launch_upsample2x(Precision prec, const void* in, void* out, int B, int H, int W, int C, hipStream_t s) {
   if (C % chunk_elems(prec)) throw std::runtime_error("upsample2x: bad shape");
   if (W % 2 == 0 && W >= 4 && g_upsample_block) {
