@@ -332,7 +332,7 @@ def main():
         # HBM bytes of the CRAFT conv kernels per launch, from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE,
         # gfx950 corrections applied; the json names the build it was taken on) -- counters cannot be read from inside this process
         traffic = traffic_src = None
-        for name in ("r02_pmc_craft_b16.json", "r01_pmc_craft_b16.json"):
+        for name in ("r02_pmc_craft_b16_v2.json", "r02_pmc_craft_b16.json", "r01_pmc_craft_b16.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:   # measured on 16-page CRAFT groups
                     tj = json.load(f)
