@@ -22,13 +22,17 @@ extern "C" {
 typedef struct ttr_engine ttr_engine;
 typedef struct ttr_result ttr_result;
 
-enum { TTR_PREC_BF16 = 0, TTR_PREC_F32 = 1 };
+/* TTR_PREC_F16X4: fp32-equivalent results on the f16 matrix cores - every fp32 activation as three f16 planes, every weight as an
+   f16 pair, four MFMAs per product into one fp32 accumulator (tuatara_amd/csrc/split.h).  The reference computes in fp32
+   (tuatara.cpp:363-376, :443-446, :307); this mode meets its outputs at the level of fp32 rounding noise and is the default.
+   TTR_PREC_BF16: operands rounded to bf16 (fastest; logits differ by up to ~1e-1).  TTR_PREC_F32: fp32 MFMA throughout. */
+enum { TTR_PREC_BF16 = 0, TTR_PREC_F32 = 1, TTR_PREC_F16X4 = 2 };
 enum { TTR_ORDER_AS_IS = 0 };  /* channel order: the engine reproduces "swap, detect; swap back, recognise"
                                   (tuatara.cpp:349, :441) relative to whatever the caller passes */
 
 /* The constants the reference hard-codes (tuatara.cpp:352-353, :397-399, :148). */
 typedef struct ttr_config {
-  int precision;         /* TTR_PREC_BF16 (throughput) or TTR_PREC_F32 (parity mode: fp32 MFMA) */
+  int precision;         /* TTR_PREC_F16X4 (default), TTR_PREC_BF16 or TTR_PREC_F32 */
   int device;            /* HIP device ordinal */
   int canvas_size;       /* 1024   tuatara.cpp:352 */
   float mag_ratio;       /* 1.0    tuatara.cpp:353 */

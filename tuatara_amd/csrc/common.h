@@ -12,7 +12,7 @@ typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-enum Precision { kBF16 = 0, kF32 = 1 };
+enum Precision { kBF16 = 0, kF32 = 1, kSplit = 2 };   // kSplit: fp32 tensors, matrix products as four f16 MFMAs (split.h)
 enum Act { kActNone = 0, kActRelu = 1, kActGelu = 2 };
 
 // Implicit-GEMM convolution / linear layer.  Activations are NHWC, weights are
@@ -46,6 +46,9 @@ struct ConvParams {
   const int* skip; int skip_n;
   int* done_count; int tok_eos;
   const void* gelu_lut;      // set by launch_gemm2: float2 [1024] = {Phi(x_i), Phi(x_i+1) - Phi(x_i)}, x_i = -8 + i/64
+  // split-operand mode (split.h; gemm2 / conv3p): in0 / in1 are f16 planes [M][3 C], wgt f16 [Cout][4 K]; out_scale = 1 / S of
+  // the weight tensor; out / out_relu / out_pool are fp32 [M][out_ld] or, with out_planes, f16 planes [M][3 out_ld]
+  int split; float out_scale; int out_planes;
 };
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

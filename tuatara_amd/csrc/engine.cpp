@@ -58,6 +58,7 @@ struct Tuning {
   int ln_fuse = 1;            // bf16 decoder steps: LayerNorm computed inside the skinny GEMM's loader (gemm_sk ln_in)
   int fuse_first = 1;         // bf16: CRAFT conv1_1 fused into conv1_2's loader (conv3p FIRST)
   int enc_chunk = 0;          // crops per encoder group (0 = all crops at once)
+  int split_gemm = 1;         // split-operand engines: 0 = every layer on the fp32 MFMA kernel (A/B and tests)
   int craft_group = 16;       // pages per CRAFT launch group (activation workspace ~0.5 GB/page; every tensor must stay inside the 2 GiB window of 32-bit buffer offsets)
   int ar_tail_step = 12;      // with ar_early_exit: AR steps from this one on run as ONE launch of the fused kernel (which returns at once when the batch is done)
   int ar_crop_exit = 1;       // ... and, per crop, the two attention kernels of a step return for crops that have emitted EOS
@@ -72,6 +73,7 @@ struct Tuning {
     else if (k == "ar_early_exit") ar_early_exit = value;
     else if (k == "ar_crop_exit") ar_crop_exit = value;
     else if (k == "ar_tail_step") ar_tail_step = value;
+    else if (k == "split_gemm") split_gemm = value;
     else if (k == "craft_group") craft_group = value < 1 ? 1 : (value > 32 ? 32 : value);
     else if (k == "mlp_fused") mlp_fused = value;     // 0 off, 1 from mlp_min_rows rows on, 2 always
     else if (k == "mlp_min_rows") mlp_min_rows = value;
@@ -208,6 +210,8 @@ void pack_mlp_w2(const float* w, int K, uint16_t* out) {          // w [384][K] 
 struct Linear {
   DevBuf w, b;
   int cout = 0, k = 0;  // padded sizes as the kernel sees them
+  DevBuf ws;            // split-operand engines (split.h): f16 [cout][4][k] = w0 | w0/2^11 | w0/2^22 | w1 of w S
+  float inv_scale = 0;  // 1 / S
 };
 
 // ------------------------------------------------------------------ the engine
@@ -388,7 +392,31 @@ struct Engine {
     prof_recs.push_back(ProfRec{0, seg_flops, seg_launches});
     seg_open = false;
   }
-  void igemm(const ConvParams& p, double true_flops) { timed(true_flops, [&] { launch_igemm(prec, p, stream); }); }
+  void igemm(const ConvParams& p, double true_flops) {
+    if (prec == kSplit && split_gemm(p, true_flops)) return;
+    timed(true_flops, [&] { launch_igemm(prec, p, stream); });
+  }
+  // split-operand engines: the layer as four f16 MFMAs per product (gemm2.hip, SP) when its shape allows; the fp32 inputs
+  // are written as planes first (split_ops.hip)
+  std::map<const void*, const Linear*> split_by_w;   // fp32 weight pointer -> its Linear (the one with the planes)
+  DevBuf split_in[2];
+  bool split_gemm(const ConvParams& p, double true_flops) {
+    auto it = split_by_w.find(p.wgt);
+    if (it == split_by_w.end() || !tn.split_gemm || p.relu0 || p.relu1 || p.ln_in || p.pre_wgt) return false;
+    const Linear& L = *it->second;
+    ConvParams q = p;
+    q.split = 1; q.wgt = L.ws.p; q.out_scale = L.inv_scale; q.out_planes = 0; q.store_policy = 0;
+    split_in[0].ensure((size_t)p.M * p.C0 * 6);
+    q.in0 = split_in[0].p;
+    if (p.C1) { split_in[1].ensure((size_t)p.M * p.C1 * 6); q.in1 = split_in[1].p; }
+    if (gemm2_check(q) != nullptr) return false;
+    prof_break_if_craft();
+    launch_split_planes((const float*)p.in0, p.C0, split_in[0].p, p.M, p.C0, 0, stream);
+    if (p.C1) launch_split_planes((const float*)p.in1, p.C1, split_in[1].p, p.M, p.C1, 0, stream);
+    timed(true_flops, [&] { launch_gemm2(q, 0, stream); });
+    return true;
+  }
+  void prof_break_if_craft() { if (prof_stage == 0) prof_break(); }
   // Folds the records whose events have completed (one stream: they complete in order).  With streamed batches the newest records
   // belong to a pass that is still running: they stay, with their events, for the next call.
   void prof_collect() {
@@ -424,6 +452,30 @@ struct Engine {
       TTR_HIP_CHECK(hipMemcpy(L.w.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
     } else {
       TTR_HIP_CHECK(hipMemcpy(L.w.p, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (prec == kSplit && k_pad % 64 == 0 && cout_pad % 8 == 0) {   // the f16x4 GEMM's weight planes (the fp32 copy stays for the layers it cannot run)
+      float mx = 0.f;
+      for (float v : wp) mx = std::max(mx, std::fabs(v));
+      int e = 0;
+      if (mx > 0.f) { (void)std::frexp(mx, &e); e = 14 - e; }            // max |w| 2^e in [2^13, 2^14)
+      e = std::max(-24, std::min(40, e));
+      const float S = std::ldexp(1.f, e);
+      std::vector<_Float16> h((size_t)cout_pad * 4 * k_pad);
+      for (int o = 0; o < cout_pad; ++o)
+        for (int kk = 0; kk < k_pad; ++kk) {
+          const float v = wp[(size_t)o * k_pad + kk] * S;               // exact
+          const _Float16 w0 = (_Float16)v;
+          const _Float16 w1 = (_Float16)(v - (float)w0);                 // exact difference, then rounded: 22+ bits in the pair
+          _Float16* row = h.data() + (size_t)o * 4 * k_pad;
+          row[kk] = w0;
+          row[k_pad + kk] = (_Float16)((float)w0 * (1.f / 2048.f));
+          row[2 * k_pad + kk] = (_Float16)((float)w0 * (1.f / 2048.f / 2048.f));
+          row[3 * k_pad + kk] = w1;
+        }
+      L.ws.ensure(h.size() * 2);
+      TTR_HIP_CHECK(hipMemcpy(L.ws.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+      L.inv_scale = std::ldexp(1.f, -e);
+      split_by_w[L.w.p] = &L;
     }
     std::vector<float> bp(cout_pad, 0.f);
     if (bias) memcpy(bp.data(), bias, sizeof(float) * cout);
@@ -484,7 +536,7 @@ struct Engine {
       // first-generation igemm (104 -> ~60 us at 1280 crops); the pad columns are zero in the patches and in the weights
       const auto& w = wf.get("encoder.patch_embed.proj.weight", (size_t)E * 96);
       const auto& b = wf.get("encoder.patch_embed.proj.bias", (size_t)E);
-      upload_linear(pq["patch"], w.data.data(), E, 96, b.data.data(), E, prec == kBF16 ? 128 : 96);
+      upload_linear(pq["patch"], w.data.data(), E, 96, b.data.data(), E, prec != kF32 ? 128 : 96);
     }
     vec("encoder.pos_embed", 128 * E);
     for (int i = 0; i < 12; ++i) {
@@ -559,7 +611,7 @@ struct Engine {
   }
 
   Engine(const std::string& dir, const ttr_config& c) : cfg(c) {
-    prec = cfg.precision == TTR_PREC_F32 ? kF32 : kBF16;
+    prec = cfg.precision == TTR_PREC_F32 ? kF32 : cfg.precision == TTR_PREC_F16X4 ? kSplit : kBF16;
     es = prec == kBF16 ? 2 : 4;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -1033,7 +1085,11 @@ struct Engine {
     // CRAFT in groups of <= 16 pages: bounds the activation workspace (~0.5 GB/page) and keeps every tensor
     // inside the 2 GiB window gemm2's 32-bit buffer offsets address.  Each group's CCL follows its CRAFT, so the host reads
     // group g's components back (and runs its calipers) while the GPU is busy with group g + 1.
-    const int GP = tn.craft_group;
+    int GP = tn.craft_group;
+    if (prec == kSplit) {   // three f16 planes per value: the widest tensor (64 channels at full resolution) must stay inside the 2 GiB window
+      const size_t per_page = (size_t)H * W * 64 * 6;
+      GP = (int)std::max<size_t>(1, std::min<size_t>(GP, (((size_t)1 << 31) - 1) / per_page));
+    }
     B.group = GP;
     const int groups = (n + GP - 1) / GP;
     for (int gi = 0; gi < groups; ++gi) {

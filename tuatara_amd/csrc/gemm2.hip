@@ -21,10 +21,12 @@
 #include <algorithm>
 #include <cmath>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
 #include "kernels.h"
+#include "split.h"
 
 namespace ttr {
 
@@ -38,6 +40,20 @@ __device__ __forceinline__ void st_out(bf16* dst, bf16x8 v, int policy) {
 #endif
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
+
+// split-operand mode: 8 consecutive channels of pixel m -> fp32 [m][ld] or the three f16 planes [m][3 ld]
+__device__ __forceinline__ void st_split(void* out, int64_t m, int ld, int n, const float (&v)[8], int planes) {
+  if (planes) {
+    f16x8 a, b, c;
+    split3_x8(v, a, b, c);
+    f16* o = reinterpret_cast<f16*>(out) + m * (3 * (int64_t)ld) + n;
+    *reinterpret_cast<f16x8*>(o) = a; *reinterpret_cast<f16x8*>(o + ld) = b; *reinterpret_cast<f16x8*>(o + 2 * ld) = c;
+  } else {
+    float* o = reinterpret_cast<float*>(out) + m * ld + n;
+    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
@@ -59,7 +75,12 @@ struct G2Cfg {
 // XST = 3: the activation tiles run TWO K steps ahead of the MFMAs (the weight tiles one).  Activations are streamed once, so
 // every X tile is a first-touch HBM miss (~2 us); one K step of MFMA work is shorter than that and the one-step-ahead form
 // spent 37-51 % of its wave cycles parked on vmcnt (SQ_WAIT_ANY).  Weights stay L2 resident and need only one step.
-template <int BM, int BN, int WM, int WN, int MINB, int XST>
+//
+// SP (split-operand mode, split.h): the operands are f16 planes - activation rows [x0 | x1 | x2] of 3 C halves per pixel, weight
+// rows [w0 | w0/2^11 | w0/2^22 | w1] of 4 K - and the K loop runs over K' = 4 K (plane 3 re-reads activation plane 0); the
+// accumulator times p.out_scale is the fp32 product.  Every output (out, out_relu, out_pool, out_f32) is fp32 then, or, with
+// p.out_planes, out / out_relu / out_pool are written as the three planes of the value (row stride 3 out_ld halves).
+template <int BM, int BN, int WM, int WN, int MINB, int XST, bool SP>
 __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p) {
   using C = G2Cfg<BM, BN, WM, WN, XST>;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -93,12 +114,14 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
 
   const int Ctot = p.C0 + p.C1;
   const int K = p.ks * p.ks * Ctot;
-  const int nk = K >> 6;
+  constexpr int PL = SP ? 3 : 1;                 // activation planes per pixel
+  const int KP = SP ? 4 * K : K;                 // K as the loop sees it
+  const int nk = KP >> 6;
   const int HW = p.H * p.W;
 
-  const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(p.in0, (unsigned)((size_t)p.M * p.C0 * 2));
-  const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(p.C1 ? p.in1 : p.in0, (unsigned)((size_t)p.M * (p.C1 ? p.C1 : p.C0) * 2));
-  const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.wgt, (unsigned)((size_t)p.Cout * K * 2));
+  const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(p.in0, (unsigned)((size_t)p.M * p.C0 * 2 * PL));
+  const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(p.C1 ? p.in1 : p.in0, (unsigned)((size_t)p.M * (p.C1 ? p.C1 : p.C0) * 2 * PL));
+  const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.wgt, (unsigned)((size_t)p.Cout * KP * 2));
   constexpr unsigned OOB = 0x80000000u;
 
   // Tile row -> pixel.  Normally the identity (tile rows are consecutive pixels).  With a fused 2x2 max-pool the
@@ -141,8 +164,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
         } else mask = 1u;
       }
       xmask[i] = mask;
-      xb0[i] = ((unsigned)m * (unsigned)p.C0 + g * 8) * 2u;
-      xb1[i] = ((unsigned)m * (unsigned)p.C1 + g * 8) * 2u;
+      xb0[i] = ((unsigned)m * (unsigned)(p.C0 * PL) + g * 8) * 2u;
+      xb1[i] = ((unsigned)m * (unsigned)(p.C1 * PL) + g * 8) * 2u;
     }
   };
   auto setup_w = [&](int li) {
@@ -154,17 +177,19 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
       const int q16 = row & 15;
       const int nl = (row & ~31) + (q16 >> 2) * 8 + ((row >> 4) & 1) * 4 + (q16 & 3);   // channel held by that LDS row
       const int n = n0 + nl;
-      wb[j] = (n < p.Cout) ? ((unsigned)n * (unsigned)K + g * 8) * 2u : OOB;
+      wb[j] = (n < p.Cout) ? ((unsigned)n * (unsigned)KP + g * 8) * 2u : OOB;
     }
   };
   auto issue_x = [&]() {               // loads of (x_idx, x_k) into ring slot x_slot, then advance the stream
     unsigned char* sb = xring + x_slot * C::XBYTES;
-    const int k0 = x_k << 6, tap = k0 / Ctot, cc = k0 - tap * Ctot;
+    int k0 = x_k << 6, plane = 0;
+    if (SP) { plane = k0 / K; k0 -= plane * K; plane = plane == 3 ? 0 : plane; }   // K chunk -> (activation plane, k inside it)
+    const int tap = k0 / Ctot, cc = k0 - tap * Ctot;
     const bool s1 = cc >= p.C0;
     int dpix = 0;
     if (p.ks == 3) { const int ky = tap / 3, kx = tap - ky * 3; dpix = ((ky - 1) * p.W + (kx - 1)) * p.dil; }
     const int Cs = s1 ? p.C1 : p.C0;
-    const unsigned soff = (unsigned)((dpix * Cs + (s1 ? cc - p.C0 : cc)) * 2);
+    const unsigned soff = (unsigned)((dpix * Cs * PL + plane * Cs + (s1 ? cc - p.C0 : cc)) * 2);
     const unsigned bit = 1u << tap;
 #pragma unroll
     for (int i = 0; i < C::XPW; ++i) {
@@ -220,25 +245,29 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
       __builtin_amdgcn_s_barrier();                      // everyone's have; everyone is done reading the slots refilled below
       // all fragment reads of this K step are issued up front (their latency hides behind the
       // loader's address arithmetic), then the MFMAs run back to back
-      bf16x8 fx[2][C::MI], fw[2][C::NJ];
+      using frag_t = typename std::conditional<SP, f16x8, bf16x8>::type;
+      frag_t fx[2][C::MI], fw[2][C::NJ];
 #pragma unroll
-      for (int j = 0; j < C::NJ; ++j) fw[0][j] = *reinterpret_cast<const bf16x8*>(wfrag[0] + wo + j * 2048);
+      for (int j = 0; j < C::NJ; ++j) fw[0][j] = *reinterpret_cast<const frag_t*>(wfrag[0] + wo + j * 2048);
 #pragma unroll
-      for (int i = 0; i < C::MI; ++i) fx[0][i] = *reinterpret_cast<const bf16x8*>(xfrag[0] + xo + i * 2048);
+      for (int i = 0; i < C::MI; ++i) fx[0][i] = *reinterpret_cast<const frag_t*>(xfrag[0] + xo + i * 2048);
       if (w_ok) issue_w();                               // W one step ahead, issued BEFORE the younger X stage
       x_ahead = x_ok;
       if (x_ok) issue_x();                               // X two steps ahead (one when XST == 2)
 #pragma unroll
-      for (int j = 0; j < C::NJ; ++j) fw[1][j] = *reinterpret_cast<const bf16x8*>(wfrag[1] + wo + j * 2048);
+      for (int j = 0; j < C::NJ; ++j) fw[1][j] = *reinterpret_cast<const frag_t*>(wfrag[1] + wo + j * 2048);
 #pragma unroll
-      for (int i = 0; i < C::MI; ++i) fx[1][i] = *reinterpret_cast<const bf16x8*>(xfrag[1] + xo + i * 2048);
+      for (int i = 0; i < C::MI; ++i) fx[1][i] = *reinterpret_cast<const frag_t*>(xfrag[1] + xo + i * 2048);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int i = 0; i < C::MI; ++i)
 #pragma unroll
-          for (int j = 0; j < C::NJ; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[kk][j], fx[kk][i], acc[j][i], 0, 0, 0);
+          for (int j = 0; j < C::NJ; ++j) {
+            if constexpr (SP) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[kk][j], fx[kk][i], acc[j][i], 0, 0, 0);
+            else acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[kk][j], fx[kk][i], acc[j][i], 0, 0, 0);
+          }
       __builtin_amdgcn_sched_barrier(0);
       xr = xr + 1 == XST ? 0 : xr + 1;
       wr ^= 1;
@@ -266,7 +295,10 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
         const int m = row_to_pixel(valid ? grow : 0);
         float v[8];
   #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = acc[2 * t][i][e] + bv[e]; v[4 + e] = acc[2 * t + 1][i][e] + bv[4 + e]; }
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (SP) { v[e] = fmaf(acc[2 * t][i][e], p.out_scale, bv[e]); v[4 + e] = fmaf(acc[2 * t + 1][i][e], p.out_scale, bv[4 + e]); }
+          else { v[e] = acc[2 * t][i][e] + bv[e]; v[4 + e] = acc[2 * t + 1][i][e] + bv[4 + e]; }
+        }
         if (p.resid && valid) {
           const float* rp = p.resid + (int64_t)(p.resid_mod ? m % p.resid_mod : m) * p.resid_ld + n;
           const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
@@ -277,8 +309,17 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
           for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         } else if (p.act == kActGelu) {
   #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_lut(v[e], glut);
+          for (int e = 0; e < 8; ++e) v[e] = SP ? gelu_exact(v[e]) : gelu_lut(v[e], glut);   // (fp32-equivalent mode: erf, as the f32 kernels)
         }
+        if constexpr (SP) {
+          if (p.out && valid) st_split(p.out, (int64_t)m, p.out_ld, n, v, p.out_planes);
+          if (p.out_relu && valid) {
+            float w[8];
+  #pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = fmaxf(v[e], 0.f);
+            st_split(p.out_relu, (int64_t)m, p.out_ld, n, w, p.out_planes);
+          }
+        } else {
         if (p.out && valid) {
           bf16x8 o;
   #pragma unroll
@@ -291,21 +332,29 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
           for (int e = 0; e < 8; ++e) o[e] = (bf16)fmaxf(v[e], 0.f);
           st_out(reinterpret_cast<bf16*>(p.out_relu) + (int64_t)m * p.out_ld + n, o, p.store_policy);
         }
+        }
         if (p.out_f32 && valid) {
           float* op = p.out_f32 + (int64_t)m * p.out_f32_ld + n;
           *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
           *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
         }
         if (p.out_pool) {   // 2x2 max over lanes fr, fr^1, fr^2, fr^3; rounding to bf16 commutes with max
-          bf16x8 o;
+          float w[8];
   #pragma unroll
           for (int e = 0; e < 8; ++e) {
             float x = p.pool_relu ? fmaxf(v[e], 0.f) : v[e];
             x = fmaxf(x, __shfl_xor(x, 1));
             x = fmaxf(x, __shfl_xor(x, 2));
-            o[e] = (bf16)x;
+            w[e] = x;
           }
-          if (valid && (fr & 3) == 0) st_out(reinterpret_cast<bf16*>(p.out_pool) + (int64_t)(grow >> 2) * p.out_ld + n, o, p.store_policy);
+          if constexpr (SP) {
+            if (valid && (fr & 3) == 0) st_split(p.out_pool, (int64_t)(grow >> 2), p.out_ld, n, w, p.out_planes);
+          } else {
+            bf16x8 o;
+  #pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)w[e];
+            if (valid && (fr & 3) == 0) st_out(reinterpret_cast<bf16*>(p.out_pool) + (int64_t)(grow >> 2) * p.out_ld + n, o, p.store_policy);
+          }
         }
       }
     }
@@ -315,18 +364,18 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
 
 static int num_cus() { return device_cu_count(256); }   // (per device: a process may drive several)
 
-template <int BM, int BN, int WM, int WN, int MINB, int XST>
+template <int BM, int BN, int WM, int WN, int MINB, int XST, bool SP = false>
 static void launch_g2(const ConvParams& p, hipStream_t s) {
   using C = G2Cfg<BM, BN, WM, WN, XST>;
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
   static PerDeviceOnce once;
-  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WM, WN, MINB, XST>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + (XST == 2 ? 8192 : 0))); });
+  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WM, WN, MINB, XST, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + (XST == 2 ? 8192 : 0))); });
   const size_t lds = C::LDS + (p.act == kActGelu ? 8192 : 0);
   // persistent grid: as many workgroups as fit the chip at once (a multiple of 8: one share per XCD), never more than tiles
   const int per_cu = std::max(1, std::min((int)(160 * 1024 / lds), 2048 / C::NT));
   const int cap = num_cus() * per_cu / 8 * 8;
   const int grid = std::min((tilesM * tilesN + 7) / 8 * 8, std::max(cap, 8));
-  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM, WN, MINB, XST>), dim3(grid), dim3(C::NT), lds, s, p);
+  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM, WN, MINB, XST, SP>), dim3(grid), dim3(C::NT), lds, s, p);
 }
 
 // Phi table of the GELU epilogue, one per device, built on first use (host erf in double)
@@ -357,21 +406,25 @@ void set_gemm2_x_ring3(int v) { g_x_ring3 = v; }
 
 const char* gemm2_check(const ConvParams& p) {
   const int Ctot = p.C0 + p.C1;
+  const int es_in = p.split ? 6 : 2;                                  // bytes per activation element (three f16 planes when split)
+  const int es_out = p.split ? (p.out_planes ? 2 : 4) : 2;            // bytes per element of out / out_relu / out_pool (per plane)
+  const int ovec = 16 / es_out;                                        // elements per 16-byte store
   if (p.ks != 1 && p.ks != 3) return "gemm2: ks must be 1 or 3";
   if (Ctot % 64 || p.C0 % 64) return "gemm2: channel counts must be multiples of 64";
   if (p.Cout % 8) return "gemm2: Cout must be a multiple of 8";
   if (p.relu0 || p.relu1) return "gemm2: ReLU-on-load is not supported";
-  if (p.out && (p.out_ld % 8 || ((uintptr_t)p.out & 15))) return "gemm2: bf16 output must be 16-byte aligned";
+  if (p.out && (p.out_ld % ovec || ((uintptr_t)p.out & 15))) return "gemm2: output must be 16-byte aligned";
   if (p.out_relu && (!p.out || ((uintptr_t)p.out_relu & 15))) return "gemm2: out_relu needs out and 16-byte alignment";
-  if (p.out_pool && ((p.H | p.W) & 1 || p.out_ld % 8 || ((uintptr_t)p.out_pool & 15))) return "gemm2: fused max-pool needs even H, W and a 16-byte aligned output";
+  if (p.out_pool && ((p.H | p.W) & 1 || p.out_ld % ovec || ((uintptr_t)p.out_pool & 15))) return "gemm2: fused max-pool needs even H, W and a 16-byte aligned output";
   if (p.out_f32 && (p.out_f32_ld % 4 || ((uintptr_t)p.out_f32 & 15))) return "gemm2: f32 output must be 16-byte aligned";
   if (p.resid && (p.resid_ld % 4 || ((uintptr_t)p.resid & 15))) return "gemm2: residual must be 16-byte aligned";
   if (p.bias && ((uintptr_t)p.bias & 15)) return "gemm2: bias must be 16-byte aligned";
   if (((uintptr_t)p.in0 & 15) || ((uintptr_t)p.wgt & 15) || (p.C1 && ((uintptr_t)p.in1 & 15))) return "gemm2: operands must be 16-byte aligned";
   const size_t lim = (size_t)1 << 31;   // buffer offsets: valid lanes < 2^31, 0x80000000 is the out-of-range marker
-  const int K = p.ks * p.ks * Ctot;
-  if ((size_t)p.M * p.C0 * 2 >= lim || (size_t)p.M * p.C1 * 2 >= lim || (size_t)p.Cout * K * 2 >= lim) return "gemm2: tensor too large for 32-bit buffer offsets";
+  const int K = p.ks * p.ks * Ctot * (p.split ? 4 : 1);
+  if ((size_t)p.M * p.C0 * es_in >= lim || (size_t)p.M * p.C1 * es_in >= lim || (size_t)p.Cout * K * 2 >= lim) return "gemm2: tensor too large for 32-bit buffer offsets";
   if (p.M != p.B * p.H * p.W || p.M <= 0 || p.Cout <= 0) return "gemm2: bad shape";
+  if (p.split && !(p.out_scale > 0.f)) return "gemm2: split mode needs out_scale";
   return nullptr;
 }
 
@@ -396,6 +449,17 @@ void launch_gemm2(const ConvParams& p_in, int cfg, hipStream_t s) {
   // X ring depth: 3 (activation tiles two K steps ahead) wherever the LDS budget keeps the configuration's workgroups-per-CU;
   // the GELU table (8 KiB) pushes the 256x256 and 128x128 tiles back to 2
   const bool deep = g_x_ring3 && p.act != kActGelu;
+  if (p.split) {
+    switch (cfg) {
+      case 1: return deep ? launch_g2<256, 256, 2, 4, 1, 3, true>(p, s) : launch_g2<256, 256, 2, 4, 1, 2, true>(p, s);
+      case 2: return deep ? launch_g2<256, 128, 4, 2, 1, 3, true>(p, s) : launch_g2<256, 128, 4, 2, 1, 2, true>(p, s);
+      case 3: return deep ? launch_g2<128, 128, 2, 2, 2, 3, true>(p, s) : launch_g2<128, 128, 2, 2, 2, 2, true>(p, s);
+      case 4: return launch_g2<256, 64, 4, 1, 2, 2, true>(p, s);
+      case 5: return launch_g2<128, 64, 2, 2, 2, 2, true>(p, s);
+      case 6: return deep ? launch_g2<128, 256, 2, 4, 1, 3, true>(p, s) : launch_g2<128, 256, 2, 4, 1, 2, true>(p, s);
+      default: throw std::runtime_error("gemm2: unknown configuration");
+    }
+  }
   switch (cfg) {
     case 1: return deep ? launch_g2<256, 256, 2, 4, 1, 3>(p, s) : launch_g2<256, 256, 2, 4, 1, 2>(p, s);
     case 2: return deep ? launch_g2<256, 128, 4, 2, 1, 3>(p, s) : launch_g2<256, 128, 4, 2, 1, 2>(p, s);

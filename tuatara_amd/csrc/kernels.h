@@ -66,6 +66,10 @@ void set_conv3p_c32_tile(int v);   // Cout <= 32 on 32-wide tiles (default 1)
 // n pseudo-random values, uniform in [-scale, scale) (benchmark inputs)
 void launch_fill_random(Precision prec, void* p, size_t n, unsigned seed, float scale, hipStream_t s);
 
+// ---- split_ops.hip (split-operand mode, split.h)
+// fp32 [M][C] (row stride ld) -> f16 planes [M][3 C], optional ReLU first
+void launch_split_planes(const float* in, int ld, void* out, int64_t M, int C, int relu, hipStream_t s);
+
 // ---- craft_ops.hip
 // OpenCV-style 8-bit INTER_LINEAR resize of src[sh,sw,3] to [th,tw], zero pad to [H,W], optional channel swap.
 // `pages` equally sized pages in one launch: sources src_page bytes apart, canvases H*W*3 bytes apart

@@ -17,7 +17,7 @@ import numpy as np
 _LIBPATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtuatara_hip.so")
 _lib = None
 
-PREC_BF16, PREC_F32 = 0, 1
+PREC_BF16, PREC_F32, PREC_F16X4 = 0, 1, 2
 
 
 class Config(C.Structure):
@@ -223,7 +223,8 @@ class Engine:
                 pass
         cfg = Config()
         self.lib.ttr_config_default(C.byref(cfg))
-        cfg.precision = PREC_F32 if precision in ("f32", "fp32", PREC_F32) else PREC_BF16
+        cfg.precision = (PREC_F32 if precision in ("f32", "fp32", PREC_F32) else
+                         PREC_F16X4 if precision in ("f16x4", "split", PREC_F16X4) else PREC_BF16)
         cfg.device = device
         cfg.strict_crops = int(strict_crops)
         for k, v in overrides.items():
