@@ -120,7 +120,7 @@ def main():
     ap.add_argument("--buffers", type=int, default=16, help="distinct device page buffers rotated over the steps (each holds --pages distinct pages of the 512-seed stream; 16 x 32 = all 512 seeds)")
     ap.add_argument("--parity-pages", type=int, default=8, help="pages per step of the f32 parity-mode measurement after the timed region (0 = skip)")
     ap.add_argument("--contexts", type=int, default=1, help="engine contexts (HIP streams + host threads) per GPU; a step's pages are split between them")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32", "f16x4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-iters", type=int, default=20)
     ap.add_argument("--stream", type=int, default=1, help="1: feed the steps through ttr_stream_push (batch j's detector and batch j-1's recogniser are enqueued before batch j-2's results are awaited, "

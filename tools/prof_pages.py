@@ -11,7 +11,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 words = int(sys.argv[3]) if len(sys.argv) > 3 else 28   # 0: blank pages, no crops -> the detector only
 d = tempfile.mkdtemp()
 W.make_synthetic_weights(d, seed=0, structured=True)
-eng = Engine(d, precision="bf16")
+eng = Engine(d, precision=os.environ.get("TTR_PREC", "bf16"))
 for kv in sys.argv[4:]:                      # key=value tuning knobs (Engine.set_tuning)
     k, v = kv.split("=")
     assert eng.set_tuning(k, int(v)) == 0, kv

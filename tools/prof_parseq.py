@@ -10,7 +10,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 1280
 it = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 d = tempfile.mkdtemp()
 W.make_synthetic_weights(d, seed=0, structured=True)
-eng = Engine(d, precision="bf16")
+eng = Engine(d, precision=os.environ.get("TTR_PREC", "bf16"))
 const = "const" in sys.argv[3:]                # all crops one flat grey: near-constant MFMA operands (the DVFS / power comparison)
 for kv in sys.argv[3:]:                      # key=value tuning knobs (Engine.set_tuning)
     if kv == "const":

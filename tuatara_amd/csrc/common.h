@@ -46,7 +46,7 @@ struct ConvParams {
   const int* skip; int skip_n;
   int* done_count; int tok_eos;
   const void* gelu_lut;      // set by launch_gemm2: float2 [1024] = {Phi(x_i), Phi(x_i+1) - Phi(x_i)}, x_i = -8 + i/64
-  // split-operand mode (split.h; gemm2 / conv3p): in0 / in1 are f16 planes [M][3 C], wgt f16 [Cout][4 K]; out_scale = 1 / S of
+  // split-operand mode (split.h; gemm2 / conv3p): in0 / in1 are f16 planes [M][3 C], wgt f16 [Cout][3 K] = w0 | w0/2^11 | w1; out_scale = 1 / S of
   // the weight tensor; out / out_relu / out_pool are fp32 [M][out_ld] or, with out_planes, f16 planes [M][3 out_ld]
   int split; float out_scale; int out_planes;
 };

@@ -17,6 +17,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "split.h"
 
 namespace ttr {
 
@@ -30,6 +31,20 @@ __device__ __forceinline__ void st_out(bf16* dst, bf16x8 v, int policy) {
 #endif
 
 namespace {
+
+// split-operand mode: 8 consecutive channels of pixel m -> fp32 [m][ld] or the three f16 planes [m][3 ld]
+__device__ __forceinline__ void st_split3(void* out, int64_t m, int ld, int n, const float (&v)[8], int planes) {
+  if (planes) {
+    f16x8 a, b, c;
+    split3_x8(v, a, b, c);
+    f16* o = reinterpret_cast<f16*>(out) + m * (3 * (int64_t)ld) + n;
+    *reinterpret_cast<f16x8*>(o) = a; *reinterpret_cast<f16x8*>(o + ld) = b; *reinterpret_cast<f16x8*>(o + 2 * ld) = c;
+  } else {
+    float* o = reinterpret_cast<float*>(out) + m * ld + n;
+    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 // Patch geometry: 256 output pixels as 8 x 32 (LPW = 5) or, for maps whose width is not a multiple of 32 (CRAFT's 64 x 48
@@ -62,10 +77,17 @@ struct C3 {
 // halo patch is computed in the prologue: conv1_1 (3 -> 64, 3x3, ReLU; weights p.pre_wgt [64][32] with k = (ky*3+kx)*3+c as
 // in conv1_direct_kernel, bias p.pre_bias) evaluated on the 10 x 34 halo pixels and written straight into the LDS patch.
 // That removes CRAFT's largest tensor (100 MB per page written and read back) and the conv1_1 launch.
-template <int BN, int WM, int WN, bool FIRST, int XS, int LPW>   // XS: patch stages (1 when Cin = 64: a single chunk, and two workgroups fit a CU)
+//
+// SP (split-operand mode, split.h): f16 planes.  The input holds [x0 | x1 | x2] per pixel (3 Cin halves), the weight rows
+// [w0 | w0/2^11 | w1] (3 x 9 Cin).  A 64-channel chunk becomes four virtual chunks: x0 with w0, x0 again with w1
+// (the patch stays), x1 with w0/2^11, x2 with w0/2^11 - 36 tap steps into the one accumulator, three patch loads instead of one.
+template <int BN, int WM, int WN, bool FIRST, int XS, int LPW, bool SP = false>   // XS: patch stages (1 when Cin = 64: a single chunk, and two workgroups fit a CU)
 __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM * WN == 4 ? 1 : 1)) void conv3p_kernel(ConvParams p) {
   using C = C3<BN, WM, WN, LPW>;
   using G = Geo<LPW>;
+  static_assert(!SP || (XS == 1 && !FIRST), "split mode: single patch stage, no fused first layer");
+  using frag_t = typename std::conditional<SP, f16x8, bf16x8>::type;
+  constexpr int PL = SP ? 3 : 1;
   constexpr int PH = G::PH, PW = G::PW, HW2 = G::HW2, XSLOTS = G::XSLOTS, XPIECES = G::XPIECES, XSTAGE = G::XSTAGE, NHALO = G::NHALO;
   static_assert(!FIRST || LPW == 5, "the fused first layer uses 8 x 32 patches");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -92,9 +114,10 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
   const int b = tm / (pty * ptx), trem = tm - b * pty * ptx, ty = trem / ptx, tx = trem - ty * ptx;
   const int y0 = ty * PH, x0 = tx * PW;
 
-  const int Cin = p.C0, K = 9 * Cin, nchunks = Cin >> 6, nsteps = nchunks * 9;
-  const __amdgpu_buffer_rsrc_t rsx = mk_rsrc(p.in0, FIRST ? 16u : (unsigned)((size_t)p.M * Cin * 2));
-  const __amdgpu_buffer_rsrc_t rsw = mk_rsrc(p.wgt, (unsigned)((size_t)p.Cout * K * 2));
+  const int Cin = p.C0, K = 9 * Cin, KP = SP ? 3 * K : K;   // KP: weight row length
+  const int nchunks = SP ? 4 * (Cin >> 6) : (Cin >> 6), nsteps = nchunks * 9;   // (virtual chunks when SP)
+  const __amdgpu_buffer_rsrc_t rsx = mk_rsrc(p.in0, FIRST ? 16u : (unsigned)((size_t)p.M * Cin * 2 * PL));
+  const __amdgpu_buffer_rsrc_t rsw = mk_rsrc(p.wgt, (unsigned)((size_t)p.Cout * KP * 2));
   constexpr unsigned OOB = 0x80000000u;
 
   // ---- loader state: X piece q = i*8 + wave covers halo slots 8q..8q+7; this lane owns slot 8q + (lane>>3), LDS chunk lane&7
@@ -106,7 +129,7 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
     const int y = y0 - 1 + pr, x = x0 - 1 + pc;
     const int g = (lane & 7) ^ (pi & 7);
     const bool ok = pi < NHALO && y >= 0 && y < p.H && x >= 0 && x < p.W;
-    xo[i] = ok ? (unsigned)((((b * p.H + y) * p.W + x) * Cin + g * 8) * 2) : OOB;
+    xo[i] = ok ? (unsigned)((((b * p.H + y) * p.W + x) * (Cin * PL) + g * 8) * 2) : OOB;
   }
   unsigned wb[C::WPW];
 #pragma unroll
@@ -115,11 +138,12 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
     const int g = (lane & 7) ^ ((row >> 1) & 7);
     const int q16 = row & 15;
     const int n = n0 + (row & ~31) + (q16 >> 2) * 8 + ((row >> 4) & 1) * 4 + (q16 & 3);
-    wb[j] = n < p.Cout ? (unsigned)((n * K + g * 8) * 2) : OOB;
+    wb[j] = n < p.Cout ? (unsigned)((n * KP + g * 8) * 2) : OOB;
   }
   auto stage_x = [&](int chunk) {
     unsigned char* sb = xs + (chunk & (XS - 1)) * XSTAGE;
-    const unsigned co = (unsigned)(chunk * 64 * 2);
+    unsigned co = (unsigned)(chunk * 64 * 2);
+    if constexpr (SP) { const int q = chunk & 3, pl = q < 2 ? 0 : q - 1; co = (unsigned)((pl * Cin + (chunk >> 2) * 64) * 2); }
 #pragma unroll
     for (int i = 0; i < C::XPW; ++i) {
       const int piece = i * C::NW + wave;
@@ -133,7 +157,8 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
   // per-lane arithmetic; the range check sees the lane offset only, so rows past Cout stay out of range)
   auto stage_w = [&](int chunk, int tap, int parity) {
     unsigned char* sb = ws + parity * C::WSTAGE;
-    const unsigned ko = (unsigned)((tap * Cin + chunk * 64) * 2);
+    unsigned ko = (unsigned)((tap * Cin + chunk * 64) * 2);
+    if constexpr (SP) { const int q = chunk & 3, pl = q == 0 ? 0 : q == 1 ? 2 : 1; ko = (unsigned)((pl * K + tap * Cin + (chunk >> 2) * 64) * 2); }
 #pragma unroll
     for (int j = 0; j < C::WPW; ++j) {
       const unsigned vo = wb[j];   // (a local copy: with the array element as the builtin's argument hipcc's host pass drops the kernel's stub without a word)
@@ -235,7 +260,7 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
         const int par = (chunk + tap) & 1;                 // (chunk * 9 + tap) & 1
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (tap == 0 && chunk > 0) {                       // single patch stage: the next chunk's patch can only be fetched now
+        if (tap == 0 && chunk > 0 && (!SP || (chunk & 3) != 1)) {   // single patch stage: the next chunk's patch can only be fetched now
           stage_x(chunk);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
@@ -244,13 +269,13 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
         const int tapoff = (tap / 3) * HW2 + (tap % 3);
         int k64 = 64;                                      // opaque per step: the second K half's addresses (base ^ 64) are formed at their use,
         asm volatile("" : "+v"(k64));                      // not kept in eight more registers across the loop (128-VGPR budget)
-        bf16x8 fx[C::MI], fw[C::NJ];
+        frag_t fx[C::MI], fw[C::NJ];
 #pragma unroll
-        for (int j = 0; j < C::NJ; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(smem + wbuf + j * 2048);
+        for (int j = 0; j < C::NJ; ++j) fw[j] = *reinterpret_cast<const frag_t*>(smem + wbuf + j * 2048);
 #pragma unroll
         for (int i = 0; i < C::MI; ++i) {
           const int off = ((i * 16) >> LPW) * HW2 + ((i * 16) & (PW - 1)) + tapoff;
-          fx[i] = *reinterpret_cast<const bf16x8*>(smem + xbase[off & 7] + off * 128);
+          fx[i] = *reinterpret_cast<const frag_t*>(smem + xbase[off & 7] + off * 128);
         }
         if (tap < 8) stage_w(chunk, tap + 1, par ^ 1);
         else if (chunk + 1 < nchunks) stage_w(chunk + 1, 0, par ^ 1);
@@ -258,17 +283,20 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
         for (int kk = 0; kk < 2; ++kk) {
           if (kk) {
 #pragma unroll
-            for (int j = 0; j < C::NJ; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(smem + (wbuf ^ k64) + j * 2048);
+            for (int j = 0; j < C::NJ; ++j) fw[j] = *reinterpret_cast<const frag_t*>(smem + (wbuf ^ k64) + j * 2048);
 #pragma unroll
             for (int i = 0; i < C::MI; ++i) {
               const int off = ((i * 16) >> LPW) * HW2 + ((i * 16) & (PW - 1)) + tapoff;
-              fx[i] = *reinterpret_cast<const bf16x8*>(smem + (xbase[off & 7] ^ k64) + off * 128);
+              fx[i] = *reinterpret_cast<const frag_t*>(smem + (xbase[off & 7] ^ k64) + off * 128);
             }
           }
 #pragma unroll
           for (int i = 0; i < C::MI; ++i)
 #pragma unroll
-            for (int j = 0; j < C::NJ; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fx[i], acc[j][i], 0, 0, 0);
+            for (int j = 0; j < C::NJ; ++j) {
+              if constexpr (SP) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[j], fx[i], acc[j][i], 0, 0, 0);
+              else acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fx[i], acc[j][i], 0, 0, 0);
+            }
         }
       }
     }
@@ -277,7 +305,7 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
   for (int s = 0; s < nsteps; ++s) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (XS == 1 && tap == 0 && chunk > 0) {   // single patch stage: the next chunk's patch can only be fetched now (its latency is
+    if (XS == 1 && tap == 0 && chunk > 0 && (!SP || (chunk & 3) != 1)) {   // single patch stage: the next chunk's patch can only be fetched now (its latency is
       stage_x(chunk);                         // covered by the CU's other workgroup, which is what the single stage buys)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -286,44 +314,50 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
     const unsigned char* wbuf = ws + (s & 1) * C::WSTAGE;
     const int tapoff = (tap / 3) * HW2 + (tap % 3);
     constexpr bool EARLY = !(XS == 1 && BN <= 128);   // the two-workgroups-per-CU variants have 128 VGPRs: one fragment set at a time
-    bf16x8 fx[EARLY ? 2 : 1][C::MI], fw[EARLY ? 2 : 1][C::NJ];
+    frag_t fx[EARLY ? 2 : 1][C::MI], fw[EARLY ? 2 : 1][C::NJ];
 #pragma unroll
-    for (int j = 0; j < C::NJ; ++j) fw[0][j] = *reinterpret_cast<const bf16x8*>(wbuf + wfl + j * 2048);
+    for (int j = 0; j < C::NJ; ++j) fw[0][j] = *reinterpret_cast<const frag_t*>(wbuf + wfl + j * 2048);
     int xa[C::MI];
 #pragma unroll
     for (int i = 0; i < C::MI; ++i) {
       const int pi = pi0[i] + tapoff;
       xa[i] = pi * 128 + ((fg ^ (pi & 7)) << 4);
-      fx[0][i] = *reinterpret_cast<const bf16x8*>(xb + xa[i]);
+      fx[0][i] = *reinterpret_cast<const frag_t*>(xb + xa[i]);
     }
     if (s + 1 < nsteps) stage_w(tap == 8 ? chunk + 1 : chunk, tap == 8 ? 0 : tap + 1, (s + 1) & 1);
     if (XS == 2 && tap == 0 && chunk + 1 < nchunks) stage_x(chunk + 1);
     if constexpr (EARLY) {
 #pragma unroll
-      for (int j = 0; j < C::NJ; ++j) fw[1][j] = *reinterpret_cast<const bf16x8*>(wbuf + (wfl ^ 64) + j * 2048);
+      for (int j = 0; j < C::NJ; ++j) fw[1][j] = *reinterpret_cast<const frag_t*>(wbuf + (wfl ^ 64) + j * 2048);
 #pragma unroll
-      for (int i = 0; i < C::MI; ++i) fx[1][i] = *reinterpret_cast<const bf16x8*>(xb + (xa[i] ^ 64));
+      for (int i = 0; i < C::MI; ++i) fx[1][i] = *reinterpret_cast<const frag_t*>(xb + (xa[i] ^ 64));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int i = 0; i < C::MI; ++i)
 #pragma unroll
-          for (int j = 0; j < C::NJ; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[kk][j], fx[kk][i], acc[j][i], 0, 0, 0);
+          for (int j = 0; j < C::NJ; ++j) {
+            if constexpr (SP) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[kk][j], fx[kk][i], acc[j][i], 0, 0, 0);
+            else acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[kk][j], fx[kk][i], acc[j][i], 0, 0, 0);
+          }
       __builtin_amdgcn_sched_barrier(0);
     } else {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         if (kk) {
 #pragma unroll
-          for (int j = 0; j < C::NJ; ++j) fw[0][j] = *reinterpret_cast<const bf16x8*>(wbuf + (wfl ^ 64) + j * 2048);
+          for (int j = 0; j < C::NJ; ++j) fw[0][j] = *reinterpret_cast<const frag_t*>(wbuf + (wfl ^ 64) + j * 2048);
 #pragma unroll
-          for (int i = 0; i < C::MI; ++i) fx[0][i] = *reinterpret_cast<const bf16x8*>(xb + (xa[i] ^ 64));
+          for (int i = 0; i < C::MI; ++i) fx[0][i] = *reinterpret_cast<const frag_t*>(xb + (xa[i] ^ 64));
         }
 #pragma unroll
         for (int i = 0; i < C::MI; ++i)
 #pragma unroll
-          for (int j = 0; j < C::NJ; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0][j], fx[0][i], acc[j][i], 0, 0, 0);
+          for (int j = 0; j < C::NJ; ++j) {
+            if constexpr (SP) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[0][j], fx[0][i], acc[j][i], 0, 0, 0);
+            else acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0][j], fx[0][i], acc[j][i], 0, 0, 0);
+          }
       }
     }
     if (++tap == 9) { tap = 0; ++chunk; }
@@ -351,11 +385,23 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
       const int64_t m = ((int64_t)b * p.H + y) * p.W + x;
       float v[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] = acc[2 * t][i][e] + bv[e]; v[4 + e] = acc[2 * t + 1][i][e] + bv[4 + e]; }
+      for (int e = 0; e < 4; ++e) {
+        if constexpr (SP) { v[e] = fmaf(acc[2 * t][i][e], p.out_scale, bv[e]); v[4 + e] = fmaf(acc[2 * t + 1][i][e], p.out_scale, bv[4 + e]); }
+        else { v[e] = acc[2 * t][i][e] + bv[e]; v[4 + e] = acc[2 * t + 1][i][e] + bv[4 + e]; }
+      }
       if (p.act == kActRelu) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
       }
+      if constexpr (SP) {
+        if (p.out) st_split3(p.out, m, p.out_ld, n, v, p.out_planes);
+        if (p.out_relu) {
+          float w[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = fmaxf(v[e], 0.f);
+          st_split3(p.out_relu, m, p.out_ld, n, w, p.out_planes);
+        }
+      } else {
       if (p.out) {
         bf16x8 o;
 #pragma unroll
@@ -367,6 +413,7 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (bf16)fmaxf(v[e], 0.f);
         st_out(reinterpret_cast<bf16*>(p.out_relu) + m * p.out_ld + n, o, p.store_policy);
+      }
       }
       if (p.out_pool) {
 #pragma unroll
@@ -384,11 +431,18 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
         if ((i & PD) == 0) {                           // even patch row: partner row is tile i + PD
           const int r = wm * C::TM + i * 16 + fr;
           const int yo = (y0 + (r >> LPW)) >> 1, xo2 = (x0 + (r & (PW - 1))) >> 1;
+          if constexpr (SP) {
+            float w[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = fmaxf(pooled[i][e], pooled[i + PD][e]);
+            if ((fr & 1) == 0) st_split3(p.out_pool, ((int64_t)b * (p.H >> 1) + yo) * (p.W >> 1) + xo2, p.out_ld, n, w, p.out_planes);
+          } else {
           bf16x8 o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (bf16)fmaxf(pooled[i][e], pooled[i + PD][e]);
           if ((fr & 1) == 0)
             st_out(reinterpret_cast<bf16*>(p.out_pool) + (((int64_t)b * (p.H >> 1) + yo) * (p.W >> 1) + xo2) * p.out_ld + n, o, p.store_policy);
+          }
         }
       }
     }
@@ -1000,15 +1054,15 @@ static void launch_first2(const ConvParams& p_in, hipStream_t s) {
   hipLaunchKernelGGL(conv3p_first2_kernel, dim3(std::min(npatch, cus)), dim3(512), lds, s, p);
 }
 
-template <int BN, int WM, int WN, bool FIRST = false, int XS = 2, int LPW = 5>
+template <int BN, int WM, int WN, bool FIRST = false, int XS = 2, int LPW = 5, bool SP = false>
 static void launch_c3(const ConvParams& p, hipStream_t s) {
   using C = C3<BN, WM, WN, LPW>;
   using G = Geo<LPW>;
   const int tilesM = p.B * (p.H / G::PH) * (p.W / G::PW), tilesN = (p.Cout + BN - 1) / BN;
   constexpr int lds = XS * G::XSTAGE + 2 * C::WSTAGE + (FIRST ? 2048 : 0);
   static PerDeviceOnce once;
-  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_kernel<BN, WM, WN, FIRST, XS, LPW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); });
-  hipLaunchKernelGGL((conv3p_kernel<BN, WM, WN, FIRST, XS, LPW>), dim3(tilesM * tilesN), dim3(C::NT), lds, s, p);
+  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_kernel<BN, WM, WN, FIRST, XS, LPW, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); });
+  hipLaunchKernelGGL((conv3p_kernel<BN, WM, WN, FIRST, XS, LPW, SP>), dim3(tilesM * tilesN), dim3(C::NT), lds, s, p);
 }
 
 void set_conv3p_first_persistent(int v) { g_first_persistent = v; }
@@ -1025,6 +1079,22 @@ static int g_xs1_max_cin = 1 << 20;   // layers with Cout <= 128 and Cin up to t
 void set_conv3p_single_stage_max_cin(int c) { g_xs1_max_cin = c; }
 
 const char* conv3p_check(const ConvParams& p) {
+  if (p.split) {   // f16 planes in; fp32 or planes out
+    if (p.ks != 3 || p.dil != 1 || p.C1 || p.relu0 || p.relu1 || p.pre_wgt) return "conv3p: 3x3, dilation 1, single source";
+    if (p.C0 % 64 || p.Cout % 8) return "conv3p: Cin % 64, Cout % 8";
+    if (!((p.H % 8 == 0 && p.W % 32 == 0) || (p.H % 16 == 0 && p.W % 16 == 0))) return "conv3p: the map must tile into 8x32 or 16x16 patches";
+    if (p.resid || p.out_f32 || p.act == kActGelu) return "conv3p: conv epilogues only";
+    const int ov = p.out_planes ? 8 : 4;
+    if (p.out && (p.out_ld % ov || ((uintptr_t)p.out & 15))) return "conv3p: output alignment";
+    if (p.out_relu && (!p.out || ((uintptr_t)p.out_relu & 15))) return "conv3p: out_relu alignment";
+    if (p.out_pool && (p.out_ld % ov || ((uintptr_t)p.out_pool & 15) || (p.H | p.W) & 1)) return "conv3p: out_pool alignment";
+    if (!p.out && !p.out_pool) return "conv3p: no output";
+    if ((p.bias && ((uintptr_t)p.bias & 15)) || ((uintptr_t)p.in0 & 15) || ((uintptr_t)p.wgt & 15)) return "conv3p: operand alignment";
+    const size_t lim = (size_t)1 << 31;
+    if ((size_t)p.M * p.C0 * 6 >= lim || (size_t)p.Cout * 27 * p.C0 * 2 >= lim) return "conv3p: tensor too large for 32-bit buffer offsets";
+    if (p.M != p.B * p.H * p.W || p.M <= 0 || !(p.out_scale > 0.f)) return "conv3p: bad shape";
+    return nullptr;
+  }
   if (p.ks != 3 || p.dil != 1) return "conv3p: 3x3, dilation 1 only";
   if (p.C1 || p.relu0 || p.relu1) return "conv3p: single source, no ReLU on load";
   if (p.C0 % 64 || p.Cout % 8) return "conv3p: Cin % 64, Cout % 8";
@@ -1047,6 +1117,19 @@ const char* conv3p_check(const ConvParams& p) {
 
 void launch_conv3p(const ConvParams& p, hipStream_t s) {
   if (const char* e = conv3p_check(p)) throw std::runtime_error(e);
+  if (p.split) {   // the one-patch-stage tiles (two workgroups per CU)
+    const bool wide = p.H % 8 == 0 && p.W % 32 == 0;
+    if (p.Cout <= 64) {
+      if (!wide) return launch_c3<64, 4, 2, false, 1, 4, true>(p, s);
+      if (p.Cout <= 32) return launch_c3<32, 4, 1, false, 1, 5, true>(p, s);
+      return launch_c3<64, 4, 2, false, 1, 5, true>(p, s);
+    }
+    if (!wide) {
+      const int tiles128 = p.B * (p.H / 16) * (p.W / 16) * ((p.Cout + 127) / 128);
+      return tiles128 < 2 * device_cu_count(256) ? launch_c3<64, 4, 2, false, 1, 4, true>(p, s) : launch_c3<128, 4, 2, false, 1, 4, true>(p, s);
+    }
+    return launch_c3<128, 4, 2, false, 1, 5, true>(p, s);
+  }
   if (p.pre_wgt) {
     if (p.C0 != 64 || p.Cout > 64 || !p.pre_bias) throw std::runtime_error("conv3p: the fused first layer needs Cin = 64, Cout <= 64");
     if (g_first_persistent && p.act == kActRelu && !p.out_relu && p.H % 8 == 0 && p.W % 32 == 0) return launch_first2(p, s);

@@ -58,6 +58,8 @@ struct Tuning {
   int ln_fuse = 1;            // bf16 decoder steps: LayerNorm computed inside the skinny GEMM's loader (gemm_sk ln_in)
   int fuse_first = 1;         // bf16: CRAFT conv1_1 fused into conv1_2's loader (conv3p FIRST)
   int enc_chunk = 0;          // crops per encoder group (0 = all crops at once)
+  int split_planes = 1;       // split-operand engines: activations stay in planes between the layers (0: fp32 tensors + a split pass in front of every GEMM)
+  int split_conv3p = 1;       // split-operand engines: 3x3 layers on the patch-stationary kernel (0: gemm2)
   int split_gemm = 1;         // split-operand engines: 0 = every layer on the fp32 MFMA kernel (A/B and tests)
   int craft_group = 16;       // pages per CRAFT launch group (activation workspace ~0.5 GB/page; every tensor must stay inside the 2 GiB window of 32-bit buffer offsets)
   int ar_tail_step = 12;      // with ar_early_exit: AR steps from this one on run as ONE launch of the fused kernel (which returns at once when the batch is done)
@@ -74,6 +76,8 @@ struct Tuning {
     else if (k == "ar_crop_exit") ar_crop_exit = value;
     else if (k == "ar_tail_step") ar_tail_step = value;
     else if (k == "split_gemm") split_gemm = value;
+    else if (k == "split_conv3p") split_conv3p = value;
+    else if (k == "split_planes") split_planes = value;
     else if (k == "craft_group") craft_group = value < 1 ? 1 : (value > 32 ? 32 : value);
     else if (k == "mlp_fused") mlp_fused = value;     // 0 off, 1 from mlp_min_rows rows on, 2 always
     else if (k == "mlp_min_rows") mlp_min_rows = value;
@@ -210,7 +214,7 @@ void pack_mlp_w2(const float* w, int K, uint16_t* out) {          // w [384][K] 
 struct Linear {
   DevBuf w, b;
   int cout = 0, k = 0;  // padded sizes as the kernel sees them
-  DevBuf ws;            // split-operand engines (split.h): f16 [cout][4][k] = w0 | w0/2^11 | w0/2^22 | w1 of w S
+  DevBuf ws;            // split-operand engines (split.h): f16 [cout][3][k] = w0 | w0/2^11 | w1 of w S
   float inv_scale = 0;  // 1 / S
 };
 
@@ -409,11 +413,12 @@ struct Engine {
     split_in[0].ensure((size_t)p.M * p.C0 * 6);
     q.in0 = split_in[0].p;
     if (p.C1) { split_in[1].ensure((size_t)p.M * p.C1 * 6); q.in1 = split_in[1].p; }
-    if (gemm2_check(q) != nullptr) return false;
+    const bool c3 = tn.split_conv3p && p.Cout >= 32 && conv3p_check(q) == nullptr;
+    if (!c3 && gemm2_check(q) != nullptr) return false;
     prof_break_if_craft();
     launch_split_planes((const float*)p.in0, p.C0, split_in[0].p, p.M, p.C0, 0, stream);
     if (p.C1) launch_split_planes((const float*)p.in1, p.C1, split_in[1].p, p.M, p.C1, 0, stream);
-    timed(true_flops, [&] { launch_gemm2(q, 0, stream); });
+    timed(true_flops, [&] { if (c3) launch_conv3p(q, stream); else launch_gemm2(q, 0, stream); });
     return true;
   }
   void prof_break_if_craft() { if (prof_stage == 0) prof_break(); }
@@ -453,24 +458,23 @@ struct Engine {
     } else {
       TTR_HIP_CHECK(hipMemcpy(L.w.p, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
     }
-    if (prec == kSplit && k_pad % 64 == 0 && cout_pad % 8 == 0) {   // the f16x4 GEMM's weight planes (the fp32 copy stays for the layers it cannot run)
+    if (prec == kSplit && k_pad % 32 == 0 && cout_pad % 8 == 0) {   // the f16x4 GEMM's weight planes (the fp32 copy stays for the layers it cannot run)
       float mx = 0.f;
       for (float v : wp) mx = std::max(mx, std::fabs(v));
       int e = 0;
       if (mx > 0.f) { (void)std::frexp(mx, &e); e = 14 - e; }            // max |w| 2^e in [2^13, 2^14)
       e = std::max(-24, std::min(40, e));
       const float S = std::ldexp(1.f, e);
-      std::vector<_Float16> h((size_t)cout_pad * 4 * k_pad);
+      std::vector<_Float16> h((size_t)cout_pad * 3 * k_pad);
       for (int o = 0; o < cout_pad; ++o)
         for (int kk = 0; kk < k_pad; ++kk) {
           const float v = wp[(size_t)o * k_pad + kk] * S;               // exact
           const _Float16 w0 = (_Float16)v;
           const _Float16 w1 = (_Float16)(v - (float)w0);                 // exact difference, then rounded: 22+ bits in the pair
-          _Float16* row = h.data() + (size_t)o * 4 * k_pad;
+          _Float16* row = h.data() + (size_t)o * 3 * k_pad;
           row[kk] = w0;
           row[k_pad + kk] = (_Float16)((float)w0 * (1.f / 2048.f));
-          row[2 * k_pad + kk] = (_Float16)((float)w0 * (1.f / 2048.f / 2048.f));
-          row[3 * k_pad + kk] = w1;
+          row[2 * k_pad + kk] = w1;
         }
       L.ws.ensure(h.size() * 2);
       TTR_HIP_CHECK(hipMemcpy(L.ws.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
@@ -674,6 +678,7 @@ struct Engine {
   // canvas u8 [B][H][W][3] (device) -> heat f32 [B][H/2][W/2][2] (device)
   void craft_forward(const uint8_t* d_canvas, int B, int H, int W, float* d_heat) {
     if (H % 32 || W % 32) throw std::runtime_error("CRAFT canvas must be a multiple of 32");
+    if (prec == kSplit && tn.split_gemm && tn.split_planes) return craft_forward_split(d_canvas, B, H, W, d_heat);
     prof_stage = 0;
     const size_t M0 = (size_t)B * H * W, M1 = M0 / 4, M2 = M1 / 4, M3 = M2 / 4, M4 = M3 / 4;
     const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8, H4 = H / 16, W4 = W / 16;
@@ -763,7 +768,93 @@ struct Engine {
     prof_break();
   }
 
+
+  // ---- CRAFT, split-operand engines: every tensor between the convolutions lives as f16 planes ([pixel][x0 | x1 | x2], 6 bytes per
+  // value); the convolutions' epilogues write them (bias, ReLU, ReLU copy, 2x2 max-pool fused), so no fp32 tensor and no separate
+  // split pass exists up to the 32-channel head, which stays on the fp32 MFMA kernel (thin layers: 3 % of the FLOPs).
+  void sconv(const char* name, const void* in0, int C0, const void* in1, int C1, int B, int H, int W, void* out, int act,
+             void* out_relu = nullptr, void* out_pool = nullptr, int pool_relu = 0, int out_planes = 1) {
+    const Linear& L = craft.at(name);
+    ConvParams p{};
+    p.in0 = in0; p.C0 = C0; p.in1 = in1; p.C1 = C1; p.B = B; p.H = H; p.W = W;
+    const int Ct = C0 + C1;
+    p.ks = (L.k == Ct) ? 1 : 3;
+    if (L.k != p.ks * p.ks * Ct || !L.ws.p) throw std::runtime_error(std::string("split conv shape mismatch at ") + name);
+    p.dil = std::string(name) == "slice5.1" ? 6 : 1;
+    p.wgt = L.ws.p; p.bias = L.b.as<float>(); p.split = 1; p.out_scale = L.inv_scale; p.out_planes = out_planes;
+    p.out = out; p.out_ld = L.cout; p.out_relu = out_relu; p.out_pool = out_pool; p.pool_relu = pool_relu;
+    p.Cout = L.cout; p.M = B * H * W; p.act = act;
+    double flops = 0;
+    for (const auto& c : craft_convs()) if (std::string(c.name) == name) flops = 2.0 * p.M * c.cout * c.ks * c.ks * c.cin;
+    const bool c3 = tn.split_conv3p && p.Cout >= 32 && conv3p_check(p) == nullptr;
+    if (!c3) { if (const char* e = gemm2_check(p)) throw std::runtime_error(std::string(name) + ": " + e); }
+    timed(flops, [&] { if (c3) launch_conv3p(p, stream); else launch_gemm2(p, 0, stream); });
+  }
+  void craft_forward_split(const uint8_t* d_canvas, int B, int H, int W, float* d_heat) {
+    prof_stage = 0;
+    const size_t M0 = (size_t)B * H * W, M1 = M0 / 4, M2 = M1 / 4, M3 = M2 / 4, M4 = M3 / 4;
+    const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8, H4 = H / 16, W4 = W / 16;
+    size_t k = 0;
+    auto pbuf = [&](size_t rows, int C) -> void* { return ws(k++, rows * C * 6).p; };   // planes
+    auto fbuf = [&](size_t rows, int C) -> void* { return ws(k++, rows * C * 4).p; };   // fp32
+    void* c11 = pbuf(M0, 64);
+    {
+      const Linear& L0 = craft.at("slice1.0");
+      timed(2.0 * M0 * 64 * 27, [&] { launch_conv1_split(d_canvas, L0.ws.p, L0.b.as<float>(), L0.inv_scale, c11, B, H, W, stream); });
+    }
+    void* p1 = pbuf(M1, 64);   sconv("slice1.3", c11, 64, nullptr, 0, B, H, W, nullptr, kActRelu, nullptr, p1, 0);
+    void* c21 = pbuf(M1, 128); sconv("slice1.7", p1, 64, nullptr, 0, B, H1, W1, c21, kActRelu);
+    void* c22 = pbuf(M1, 128); void* p2 = pbuf(M2, 128);
+    sconv("slice1.10", c21, 128, nullptr, 0, B, H1, W1, c22, kActNone, nullptr, p2, 1);                    // relu2_2 skip (pre-ReLU) + pooled ReLU
+    void* c31 = pbuf(M2, 256); sconv("slice2.14", p2, 128, nullptr, 0, B, H2, W2, c31, kActRelu);
+    void* c32 = pbuf(M2, 256); void* c32r = pbuf(M2, 256);
+    sconv("slice2.17", c31, 256, nullptr, 0, B, H2, W2, c32, kActNone, c32r);                               // relu3_2 skip + its ReLU
+    void* p3 = pbuf(M3, 256);  sconv("slice3.20", c32r, 256, nullptr, 0, B, H2, W2, nullptr, kActRelu, nullptr, p3, 0);
+    void* c41 = pbuf(M3, 512); sconv("slice3.24", p3, 256, nullptr, 0, B, H3, W3, c41, kActRelu);
+    void* c42 = pbuf(M3, 512); void* c42r = pbuf(M3, 512);
+    sconv("slice3.27", c41, 512, nullptr, 0, B, H3, W3, c42, kActNone, c42r);                               // relu4_3 skip + its ReLU
+    void* p4 = pbuf(M4, 512);  sconv("slice4.30", c42r, 512, nullptr, 0, B, H3, W3, nullptr, kActRelu, nullptr, p4, 0);
+    void* c51 = pbuf(M4, 512); sconv("slice4.34", p4, 512, nullptr, 0, B, H4, W4, c51, kActRelu);
+    void* c52 = pbuf(M4, 512); sconv("slice4.37", c51, 512, nullptr, 0, B, H4, W4, c52, kActNone);          // relu5_3 skip
+    void* mp = pbuf(M4, 512);  prof_break(), launch_maxpool3x3s1_planes(c52, mp, B, H4, W4, 512, stream);
+    void* c6 = pbuf(M4, 1024); sconv("slice5.1", mp, 512, nullptr, 0, B, H4, W4, c6, kActNone);
+    void* fc7 = pbuf(M4, 1024); sconv("slice5.2", c6, 1024, nullptr, 0, B, H4, W4, fc7, kActNone);
+    void* u1a = pbuf(M4, 512); sconv("upconv1.0", fc7, 1024, c52, 512, B, H4, W4, u1a, kActRelu);
+    void* u1b = pbuf(M4, 256); sconv("upconv1.3", u1a, 512, nullptr, 0, B, H4, W4, u1b, kActRelu);
+    void* up1 = pbuf(M3, 256); prof_break(), launch_upsample2x_planes(u1b, up1, B, H4, W4, 256, stream);
+    void* u2a = pbuf(M3, 256); sconv("upconv2.0", up1, 256, c42, 512, B, H3, W3, u2a, kActRelu);
+    void* u2b = pbuf(M3, 128); sconv("upconv2.3", u2a, 256, nullptr, 0, B, H3, W3, u2b, kActRelu);
+    void* up2 = pbuf(M2, 128); prof_break(), launch_upsample2x_planes(u2b, up2, B, H3, W3, 128, stream);
+    void* u3a = pbuf(M2, 128); sconv("upconv3.0", up2, 128, c32, 256, B, H2, W2, u3a, kActRelu);
+    void* u3b = pbuf(M2, 64);  sconv("upconv3.3", u3a, 128, nullptr, 0, B, H2, W2, u3b, kActRelu);
+    void* up3 = pbuf(M1, 64);  prof_break(), launch_upsample2x_planes(u3b, up3, B, H2, W2, 64, stream);
+    void* u4a = pbuf(M1, 64);  sconv("upconv4.0", up3, 64, c22, 128, B, H1, W1, u4a, kActRelu);
+    void* u4b = fbuf(M1, 32);  sconv("upconv4.3", u4a, 64, nullptr, 0, B, H1, W1, u4b, kActRelu, nullptr, nullptr, 0, /*out_planes=*/0);
+    // 32-channel head on the fp32 MFMA kernel
+    const int sg = tn.split_gemm; tn.split_gemm = 0;
+    void* h0 = fbuf(M1, 32); void* h2 = fbuf(M1, 32); void* h4 = fbuf(M1, 32); void* h6 = fbuf(M1, 32);
+    conv("conv_cls.0", u4b, 32, nullptr, 0, 0, B, H1, W1, h0, kActRelu);
+    conv("conv_cls.2", h0, 32, nullptr, 0, 0, B, H1, W1, h2, kActRelu);
+    conv("conv_cls.4", h2, 32, nullptr, 0, 0, B, H1, W1, h4, kActRelu);
+    conv("conv_cls.6", h4, 32, nullptr, 0, 0, B, H1, W1, h6, kActRelu);
+    conv("conv_cls.8", h6, 32, nullptr, 0, 0, B, H1, W1, nullptr, kActNone, d_heat);
+    tn.split_gemm = sg;
+    prof_break();
+  }
+
   // ---- PARSeq
+  // split-operand linear on planes: in [M][3 K] -> out (planes [M][3 out_ld] or fp32 [M][out_ld]) and / or out_f32 (+ fp32 residual)
+  void sgemm(const Linear& L, const void* in_planes, int M, void* out, int out_ld, int act, int out_planes,
+             float* out_f32 = nullptr, int out_f32_ld = 0, const float* resid = nullptr, int resid_ld = 0) {
+    if (!L.ws.p) throw std::runtime_error("split GEMM: the layer has no weight planes");
+    ConvParams p{};
+    p.in0 = in_planes; p.C0 = L.k; p.B = 1; p.H = 1; p.W = M; p.ks = 1; p.dil = 1;
+    p.wgt = L.ws.p; p.bias = L.b.as<float>(); p.split = 1; p.out_scale = L.inv_scale; p.out_planes = out_planes;
+    p.out = out; p.out_ld = out_ld; p.out_f32 = out_f32; p.out_f32_ld = out_f32_ld; p.resid = resid; p.resid_ld = resid_ld;
+    p.Cout = L.cout; p.M = M; p.act = act;
+    if (const char* e = gemm2_check(p)) throw std::runtime_error(e);
+    timed(2.0 * M * L.cout * L.k, [&] { launch_gemm2(p, 0, stream); });
+  }
   // out = L(LayerNorm(x)) for the decoder's per-step rows: the skinny GEMM normalises its own activation rows (bf16, few rows);
   // otherwise the LayerNorm kernel writes `scratch` and the plain GEMM follows
   void ln_gemm(const float* x, const std::string& ln_name, float eps, void* scratch, const Linear& L, int M, void* out, int out_ld, int act,
@@ -848,12 +939,37 @@ struct Engine {
     void* att = (pq_ws[4].ensure((size_t)std::max(M, N * 26) * E * es), pq_ws[4].p);
     launch_patchify(prec, d_crops, patches, N, patch_ld, stream);
     gemm(pq.at("patch"), patches, M, nullptr, 0, kActNone, x, E, pqf.at("encoder.pos_embed").as<float>(), E, 128);
+    const bool enc_split = prec == kSplit && tn.split_gemm && tn.split_planes;
+    if (enc_split) {
+      // split-operand engines: LayerNorm, GEMM epilogues and the attention kernel hand each other planes (split.h); only the residual
+      // stream x is fp32.  Crop groups keep the widest planes tensor (the MLP hidden: 1536 x 6 bytes per row) inside the 2 GiB window.
+      const int CHS = std::max(1, std::min(N, (int)((((size_t)1 << 31) - 1) / ((size_t)128 * 1536 * 6))));
+      void* lnp = (pq_ws[11].ensure((size_t)M * E * 6), pq_ws[11].p);                       // LayerNorm output planes (whole batch: the memory at the end)
+      void* bigp = (pq_ws[12].ensure((size_t)std::min(N, CHS) * 128 * 1536 * 6), pq_ws[12].p);   // qkv / MLP hidden planes
+      void* attp = (pq_ws[13].ensure((size_t)std::min(N, CHS) * 128 * E * 6), pq_ws[13].p);      // attention output planes
+      auto lnp_at = [&](int c0) { return (char*)lnp + (size_t)c0 * 128 * E * 6; };
+      for (int c0 = 0; c0 < N; c0 += CHS) {
+        const int nc = std::min(CHS, N - c0), Mc = nc * 128;
+        float* xc = x + (size_t)c0 * 128 * E;
+        for (int l = 0; l < 12; ++l) {
+          const std::string p = "encoder.blocks." + std::to_string(l) + ".";
+          launch_layernorm_planes(xc, E, pqf.at(p + "norm1.weight").as<float>(), pqf.at(p + "norm1.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream);
+          sgemm(pq.at(p + "qkv"), lnp_at(c0), Mc, bigp, 3 * E, kActNone, 1);
+          launch_attn_enc_split(bigp, attp, nc, stream);
+          sgemm(pq.at(p + "proj"), attp, Mc, nullptr, 0, kActNone, 0, xc, E, xc, E);
+          launch_layernorm_planes(xc, E, pqf.at(p + "norm2.weight").as<float>(), pqf.at(p + "norm2.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream);
+          sgemm(pq.at(p + "fc1"), lnp_at(c0), Mc, bigp, 4 * E, kActGelu, 1);
+          sgemm(pq.at(p + "fc2"), bigp, Mc, nullptr, 0, kActNone, 0, xc, E, xc, E);
+        }
+        launch_layernorm_planes(xc, E, pqf.at("encoder.norm.weight").as<float>(), pqf.at("encoder.norm.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream);
+      }
+    }
     // The 12 encoder blocks run over groups of crops so that a group's widest intermediates (qkv, the MLP hidden) are
     // re-read from the 256 MiB Infinity Cache rather than from HBM (tn.enc_chunk crops per group; 0 = one group).
     // the fused MLP block needs a panel of 128 rows per CU to fill the chip: below ~2 panels per CU the separate GEMMs win
     const bool mlp_fused = prec == kBF16 && gemm_config() >= 0 && (tn.mlp_fused == 2 || (tn.mlp_fused == 1 && M >= tn.mlp_min_rows));
     const int CH = (tn.enc_chunk > 0 && !mlp_fused) ? tn.enc_chunk : N;
-    for (int c0 = 0; c0 < N; c0 += CH) {
+    for (int c0 = 0; c0 < N && !enc_split; c0 += CH) {
       const int nc = std::min(CH, N - c0), Mc = nc * 128;
       float* xc = x + (size_t)c0 * 128 * E;
       if (mlp_fused) ln(xc, "encoder.blocks.0.norm1", 1e-6f, t384, Mc);
@@ -889,8 +1005,15 @@ struct Engine {
         gemm(pq.at(p + "fc2"), tbig, Mc, nullptr, 0, kActNone, xc, E, xc, E, 0);
       }
     }
-    if (!mlp_fused) ln(x, "encoder.norm", 1e-6f, t384, M);       // memory
+    if (!mlp_fused && !enc_split) ln(x, "encoder.norm", 1e-6f, t384, M);       // memory
     void* kvmem = (pq_ws[5].ensure((size_t)M * 768 * es), pq_ws[5].p);
+    if (enc_split) {
+      const int rows_max = (int)((((size_t)1 << 31) - 1) / ((size_t)E * 6));
+      for (int r0 = 0; r0 < M; r0 += rows_max) {
+        const int rr = std::min(rows_max, M - r0);
+        sgemm(pq.at("cross_kv"), (char*)pq_ws[11].p + (size_t)r0 * E * 6, rr, (char*)kvmem + (size_t)r0 * 768 * 4, 768, kActNone, 0);
+      }
+    } else
     gemm(pq.at("cross_kv"), t384, M, kvmem, 768, kActNone);
 
     // ---- decoder

@@ -77,7 +77,7 @@ struct G2Cfg {
 // spent 37-51 % of its wave cycles parked on vmcnt (SQ_WAIT_ANY).  Weights stay L2 resident and need only one step.
 //
 // SP (split-operand mode, split.h): the operands are f16 planes - activation rows [x0 | x1 | x2] of 3 C halves per pixel, weight
-// rows [w0 | w0/2^11 | w0/2^22 | w1] of 4 K - and the K loop runs over K' = 4 K (plane 3 re-reads activation plane 0); the
+// rows [w0 | w0/2^11 | w1] of 3 K - and the K loop runs over K' = 4 K (quarter q: activation plane {0,1,2,0}, weight plane {0,1,1,2}); the
 // accumulator times p.out_scale is the fp32 product.  Every output (out, out_relu, out_pool, out_f32) is fp32 then, or, with
 // p.out_planes, out / out_relu / out_pool are written as the three planes of the value (row stride 3 out_ld halves).
 template <int BM, int BN, int WM, int WN, int MINB, int XST, bool SP>
@@ -121,7 +121,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
 
   const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(p.in0, (unsigned)((size_t)p.M * p.C0 * 2 * PL));
   const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(p.C1 ? p.in1 : p.in0, (unsigned)((size_t)p.M * (p.C1 ? p.C1 : p.C0) * 2 * PL));
-  const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.wgt, (unsigned)((size_t)p.Cout * KP * 2));
+  const int KW = SP ? 3 * K : K;                 // weight row length
+  const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.wgt, (unsigned)((size_t)p.Cout * KW * 2));
   constexpr unsigned OOB = 0x80000000u;
 
   // Tile row -> pixel.  Normally the identity (tile rows are consecutive pixels).  With a fused 2x2 max-pool the
@@ -177,13 +178,13 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
       const int q16 = row & 15;
       const int nl = (row & ~31) + (q16 >> 2) * 8 + ((row >> 4) & 1) * 4 + (q16 & 3);   // channel held by that LDS row
       const int n = n0 + nl;
-      wb[j] = (n < p.Cout) ? ((unsigned)n * (unsigned)KP + g * 8) * 2u : OOB;
+      wb[j] = (n < p.Cout) ? ((unsigned)n * (unsigned)KW + g * 8) * 2u : OOB;
     }
   };
   auto issue_x = [&]() {               // loads of (x_idx, x_k) into ring slot x_slot, then advance the stream
     unsigned char* sb = xring + x_slot * C::XBYTES;
     int k0 = x_k << 6, plane = 0;
-    if (SP) { plane = k0 / K; k0 -= plane * K; plane = plane == 3 ? 0 : plane; }   // K chunk -> (activation plane, k inside it)
+    if (SP) { plane = k0 / K; k0 -= plane * K; plane = split_xplane(plane); }   // K chunk -> (activation plane, k inside it)
     const int tap = k0 / Ctot, cc = k0 - tap * Ctot;
     const bool s1 = cc >= p.C0;
     int dpix = 0;
@@ -203,7 +204,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
   };
   auto issue_w = [&]() {
     unsigned char* sb = wring + w_slot * C::WBYTES;
-    const unsigned koff = (unsigned)(w_k << 7);          // k0 * 2 bytes: weights are [Cout][taps][Cin] = K contiguous
+    unsigned koff = (unsigned)(w_k << 7);                // k0 * 2 bytes: weights are [Cout][taps][Cin] = K contiguous
+    if (SP) { const int k0 = w_k << 6, q = k0 / K; koff = (unsigned)((split_wplane(q) * K + (k0 - q * K)) * 2); }
 #pragma unroll
     for (int j = 0; j < C::WPW; ++j) {
       const unsigned vo = wb[j] == OOB ? OOB : wb[j] + koff;
@@ -421,7 +423,7 @@ const char* gemm2_check(const ConvParams& p) {
   if (p.bias && ((uintptr_t)p.bias & 15)) return "gemm2: bias must be 16-byte aligned";
   if (((uintptr_t)p.in0 & 15) || ((uintptr_t)p.wgt & 15) || (p.C1 && ((uintptr_t)p.in1 & 15))) return "gemm2: operands must be 16-byte aligned";
   const size_t lim = (size_t)1 << 31;   // buffer offsets: valid lanes < 2^31, 0x80000000 is the out-of-range marker
-  const int K = p.ks * p.ks * Ctot * (p.split ? 4 : 1);
+  const int K = p.ks * p.ks * Ctot * (p.split ? 3 : 1);
   if ((size_t)p.M * p.C0 * es_in >= lim || (size_t)p.M * p.C1 * es_in >= lim || (size_t)p.Cout * K * 2 >= lim) return "gemm2: tensor too large for 32-bit buffer offsets";
   if (p.M != p.B * p.H * p.W || p.M <= 0 || p.Cout <= 0) return "gemm2: bad shape";
   if (p.split && !(p.out_scale > 0.f)) return "gemm2: split mode needs out_scale";

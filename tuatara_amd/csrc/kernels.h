@@ -69,6 +69,15 @@ void launch_fill_random(Precision prec, void* p, size_t n, unsigned seed, float 
 // ---- split_ops.hip (split-operand mode, split.h)
 // fp32 [M][C] (row stride ld) -> f16 planes [M][3 C], optional ReLU first
 void launch_split_planes(const float* in, int ld, void* out, int64_t M, int C, int relu, hipStream_t s);
+// planes [B][H][W][3 C] in and out: CRAFT's 3x3 / stride-1 max-pool and its bilinear x2 upsampling (bit-identical to the fp32 kernels)
+void launch_maxpool3x3s1_planes(const void* in, void* out, int B, int H, int W, int C, hipStream_t s);
+void launch_upsample2x_planes(const void* in, void* out, int B, int H, int W, int C, hipStream_t s);
+// LayerNorm over 384 columns of fp32 rows (stride in_ld) -> planes [M][3 * 384]
+void launch_layernorm_planes(const float* in, int in_ld, const float* gamma, const float* beta, float eps, void* out, int M, hipStream_t s);
+// attn_split.hip: ViT encoder self-attention, qkv planes [N*128][3][1152] -> planes [N*128][3][384]
+void launch_attn_enc_split(const void* qkv_planes, void* out_planes, int N, hipStream_t s);
+// CRAFT's conv1_1 + bias + ReLU from the u8 canvas into planes [M][3 * 64]; wgt_planes f16 [64][3][32] (k = (ky*3+kx)*3+c, 27 used)
+void launch_conv1_split(const uint8_t* canvas, const void* wgt_planes, const float* bias, float out_scale, void* out, int B, int H, int W, hipStream_t s);
 
 // ---- craft_ops.hip
 // OpenCV-style 8-bit INTER_LINEAR resize of src[sh,sw,3] to [th,tw], zero pad to [H,W], optional channel swap.

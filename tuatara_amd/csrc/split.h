@@ -3,17 +3,18 @@
 // The reference computes both models in fp32 (tuatara.cpp:363-376, :443-446, :307).  The bf16 MFMA rounds its operands to 8
 // bits; the f32 MFMA runs at 1/16 of the 16-bit rate.  This mode writes every fp32 ACTIVATION x exactly as three f16 planes
 //
-//     x = x0 + x1 / 2^11 + x2 / 2^22,     x0 = rtz_f16(x),  x1 = rtz_f16((x - x0) 2^11),  x2 = f16(((x - x0) 2^11 - x1) 2^11)
+//     x = x0 + (x1 + x2) / 2^11,     x0 = rtz_f16(x),  x1 = rtz_f16((x - x0) 2^11),  x2 = f16((x - x0) 2^11 - x1)
 //
-// (11 + 11 + 2 significand bits; the lower planes are stored pre-scaled so that they never reach the f16 subnormal range, and
-// the round-toward-zero conversions never produce an infinity: |x| < 65504 is the only range condition) and every WEIGHT as
-// a pair w S = w0 + w1 (S a power of two per tensor that puts max |w| S in [2^13, 2^14): 22+ bits, static).  A product is
+// (11 + 11 + 2 significand bits; the lower planes are stored scaled by 2^11 so that x1 never reaches the f16 subnormal range and
+// x2's subnormal spacing is 2^-35 in units of x; the round-toward-zero conversions never produce an infinity: |x| < 65504 is the
+// only range condition) and every WEIGHT as a pair w S = w0 + w1 (S a power of two per tensor that puts max |w| S in
+// [2^13, 2^14): 22+ bits, static), plus the copy w0b = w0 / 2^11.  A product is
 //
-//     x w S  =  x0 w0  +  x1 (w0 / 2^11)  +  x2 (w0 / 2^22)  +  x0 w1          (dropped: x1 w1 ~ 2^-22, x2 w1 ~ 2^-33)
+//     x w S  =  x0 w0  +  x1 w0b  +  x2 w0b  +  x0 w1          (dropped: x1 w1 ~ 2^-22, x2 w1 ~ 2^-33)
 //
 // i.e. FOUR f16 MFMAs into ONE fp32 accumulator.  Laid out along K this is a plain GEMM with K' = 4 K:
-//     activation row [x0 | x1 | x2]            (3 C halves per pixel; K chunk of plane 3 re-reads plane 0)
-//     weight row     [w0 | w0/2^11 | w0/2^22 | w1]   (each plane [taps][Cin])
+//     activation row [x0 | x1 | x2]       (3 C halves per pixel; the fourth K quarter re-reads plane 0)
+//     weight row     [w0 | w0b | w1]      (each plane [taps][Cin]; K quarters 1 and 2 both read w0b)
 // so the LDS-DMA kernels keep their loops; the epilogue multiplies by 1 / S (exact).  Measured against the fp32 oracle this is
 // at the level of fp32's own rounding noise ("f16x4"); pairs (x0, x1) alone lose the last bit of half the
 // activations and miss north_star's 1e-3 on the logits by 2x, bf16 pairs by 10x (oracle/splitsim.py).
@@ -31,7 +32,7 @@ __device__ __forceinline__ void split3_pair(float a, float b, f16x2& p0, f16x2& 
   p0 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
   const float ra = fmaf((float)p0[0], -2048.f, a * 2048.f), rb = fmaf((float)p0[1], -2048.f, b * 2048.f);   // exact
   p1 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(ra, rb));
-  const float sa = (ra - (float)p1[0]) * 2048.f, sb = (rb - (float)p1[1]) * 2048.f;                          // exact
+  const float sa = ra - (float)p1[0], sb = rb - (float)p1[1];                                                // exact: the last <= 2 bits
   p2 = f16x2{(f16)sa, (f16)sb};
 }
 
@@ -45,6 +46,10 @@ __device__ __forceinline__ void split3_x8(const float (&v)[8], f16x8& o0, f16x8&
   }
 }
 
-__device__ __forceinline__ float join3(f16 a, f16 b, f16 c) { return (float)a + ((float)b + (float)c * (1.f / 2048.f)) * (1.f / 2048.f); }
+__device__ __forceinline__ float join3(f16 a, f16 b, f16 c) { return (float)a + ((float)b + (float)c) * (1.f / 2048.f); }   // (every step exact)
+
+// K quarter q of the four products -> activation plane / weight plane
+__host__ __device__ __forceinline__ constexpr int split_xplane(int q) { return q == 3 ? 0 : q; }
+__host__ __device__ __forceinline__ constexpr int split_wplane(int q) { return q == 0 ? 0 : q == 3 ? 2 : 1; }
 
 }  // namespace ttr

@@ -39,3 +39,217 @@ void launch_split_planes(const float* in, int ld, void* out, int64_t M, int C, i
 }
 
 }  // namespace ttr
+
+// ------------------------------------------------------------------------------------------------------------------
+// Planes in, planes out: the elementwise layers between CRAFT's convolutions.  A value is joined from its three planes
+// (exact), the fp32 kernels' arithmetic is applied unchanged (craft_ops.hip: max is order-free, the bilinear weights use
+// the same spelled-out expression), and the result is split again (exact): bit-identical to the fp32 engine's tensors.
+namespace ttr {
+namespace {
+
+struct V8 { float v[8]; };
+__device__ __forceinline__ V8 ld_planes(const f16* p, int C) {   // p -> plane 0 of 8 channels of a pixel
+  const f16x8 a = *reinterpret_cast<const f16x8*>(p), b = *reinterpret_cast<const f16x8*>(p + C), c = *reinterpret_cast<const f16x8*>(p + 2 * C);
+  V8 r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r.v[e] = join3(a[e], b[e], c[e]);
+  return r;
+}
+__device__ __forceinline__ void st_planes(f16* p, int C, const V8& r) {
+  f16x8 a, b, c;
+  split3_x8(r.v, a, b, c);
+  *reinterpret_cast<f16x8*>(p) = a; *reinterpret_cast<f16x8*>(p + C) = b; *reinterpret_cast<f16x8*>(p + 2 * C) = c;
+}
+
+__global__ __launch_bounds__(256) void maxpool3x3s1_planes_kernel(const f16* __restrict__ in, f16* __restrict__ out, int B, int H, int W, int C) {
+  const int Cc = C >> 3;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, total = (int64_t)B * H * W * Cc;
+  if (idx >= total) return;
+  const int cc = (int)(idx % Cc); int64_t t = idx / Cc;
+  const int x = (int)(t % W); t /= W;
+  const int y = (int)(t % H); const int b = (int)(t / H);
+  V8 m;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) m.v[e] = -INFINITY;
+  for (int dy = -1; dy <= 1; ++dy)
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int yy = y + dy, xx = x + dx;
+      if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+      const V8 v = ld_planes(in + (((int64_t)b * H + yy) * W + xx) * (3 * (int64_t)C) + cc * 8, C);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) m.v[e] = fmaxf(m.v[e], v.v[e]);
+    }
+  st_planes(out + (((int64_t)b * H + y) * W + x) * (3 * (int64_t)C) + cc * 8, C, m);
+}
+
+// F.interpolate(mode='bilinear', align_corners=False), exact x2: the expression of craft_ops.hip's bilerp()
+__device__ __forceinline__ float bilerp_s(float v00, float v01, float v10, float v11, float lx0, float lx1, float ly0, float ly1) {
+  const float top = fmaf(lx1, v01, lx0 * v00), bot = fmaf(lx1, v11, lx0 * v10);
+  return fmaf(ly1, bot, ly0 * top);
+}
+__global__ __launch_bounds__(256) void upsample2x_planes_kernel(const f16* __restrict__ in, f16* __restrict__ out, int B, int H, int W, int C) {
+  const int Ho = 2 * H, Wo = 2 * W, Cc = C >> 3;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, total = (int64_t)B * Ho * Wo * Cc;
+  if (idx >= total) return;
+  const int cc = (int)(idx % Cc); int64_t t = idx / Cc;
+  const int xo = (int)(t % Wo); t /= Wo;
+  const int yo = (int)(t % Ho); const int b = (int)(t / Ho);
+  const float sy = fmaxf(0.5f * ((float)yo + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * ((float)xo + 0.5f) - 0.5f, 0.f);
+  const int y0 = (int)sy, x0 = (int)sx;
+  const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+  const float ly1 = sy - (float)y0, ly0 = 1.f - ly1, lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+  const f16* base = in + (int64_t)b * H * W * (3 * (int64_t)C) + cc * 8;
+  const int64_t ps = 3 * (int64_t)C;
+  const V8 v00 = ld_planes(base + ((int64_t)y0 * W + x0) * ps, C), v01 = ld_planes(base + ((int64_t)y0 * W + x1) * ps, C);
+  const V8 v10 = ld_planes(base + ((int64_t)y1 * W + x0) * ps, C), v11 = ld_planes(base + ((int64_t)y1 * W + x1) * ps, C);
+  V8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o.v[e] = bilerp_s(v00.v[e], v01.v[e], v10.v[e], v11.v[e], lx0, lx1, ly0, ly1);
+  st_planes(out + (((int64_t)b * Ho + yo) * Wo + xo) * ps + cc * 8, C, o);
+}
+
+// CRAFT's conv1_1 (3 -> 64, 3x3, ReLU) from the u8 canvas straight into planes: conv1_direct_kernel's structure (craft_ops.hip)
+// with split operands.  A pixel's 27 inputs are u8 / 255 in fp32 (the reference's division, tuatara.cpp:367-370): their three planes
+// come from three 256-entry tables built once per workgroup; the weights are the layer's three planes [64][3][32].
+__global__ __launch_bounds__(256) void conv1_split_kernel(const uint8_t* __restrict__ canvas, const f16* __restrict__ wgt /*[64][3][32]*/, const float* __restrict__ bias,
+                                                         float out_scale, f16* __restrict__ out /*[M][3*64]*/, int B, int H, int W) {
+  __shared__ f16 lut[3][256];
+  {
+    f16x2 a, b, c;
+    split3_pair((float)threadIdx.x / 255.0f, 0.f, a, b, c);
+    lut[0][threadIdx.x] = a[0]; lut[1][threadIdx.x] = b[0]; lut[2][threadIdx.x] = c[0];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, fr = lane & 15, fg = lane >> 4;
+  const int64_t M = (int64_t)B * H * W;
+  const int HW = H * W;
+  f16x8 fw[3][4];   // [weight plane w0 | w0b | w1][jj]
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int n = 32 * (jj >> 1) + (fr >> 2) * 8 + (jj & 1) * 4 + (fr & 3);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) fw[pl][jj] = *reinterpret_cast<const f16x8*>(wgt + n * 96 + pl * 32 + fg * 8);
+  }
+  float bv[2][8];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[t][e] = bias[32 * t + fg * 8 + e];
+  int off[8], dy[8], dx[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = fg * 8 + e, tap = k / 3;
+    dy[e] = tap / 3 - 1; dx[e] = tap % 3 - 1;
+    off[e] = (dy[e] * W + dx[e]) * 3 + (k - tap * 3);
+  }
+  const int64_t nwaves = (int64_t)gridDim.x * 4, wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  for (int64_t g = wave0; g * 64 < M; g += nwaves) {
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = g * 64 + i * 16 + fr;
+      f16x8 fx[3];
+      const bool mv = m < M;
+      const int r = (int)((mv ? m : 0) % HW), y = r / W, x = r - y * W;
+      const uint8_t* px = canvas + (mv ? m : 0) * 3;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int yy = y + dy[e], xx = x + dx[e];
+        const bool ok = mv && (fg * 8 + e < 27) && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const int byte = ok ? px[off[e]] : 0;            // table entry 0 = (0, 0, 0)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) fx[pl][e] = lut[pl][byte];
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[0][jj], fx[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[1][jj], fx[1], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[1][jj], fx[2], a, 0, 0, 0);
+        acc[jj][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[2][jj], fx[0], a, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = g * 64 + i * 16 + fr;
+      if (m >= M) continue;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        V8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o.v[e] = fmaxf(fmaf(acc[2 * t][i][e], out_scale, bv[t][e]), 0.f);
+          o.v[4 + e] = fmaxf(fmaf(acc[2 * t + 1][i][e], out_scale, bv[t][4 + e]), 0.f);
+        }
+        st_planes(out + m * 192 + 32 * t + fg * 8, 64, o);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+void launch_maxpool3x3s1_planes(const void* in, void* out, int B, int H, int W, int C, hipStream_t s) {
+  if (C % 8) throw std::runtime_error("maxpool3x3 (planes): C % 8");
+  const int64_t total = (int64_t)B * H * W * (C >> 3);
+  hipLaunchKernelGGL(maxpool3x3s1_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f16*)in, (f16*)out, B, H, W, C);
+}
+void launch_upsample2x_planes(const void* in, void* out, int B, int H, int W, int C, hipStream_t s) {
+  if (C % 8) throw std::runtime_error("upsample2x (planes): C % 8");
+  const int64_t total = (int64_t)B * 4 * H * W * (C >> 3);
+  hipLaunchKernelGGL(upsample2x_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f16*)in, (f16*)out, B, H, W, C);
+}
+void launch_conv1_split(const uint8_t* canvas, const void* wgt_planes, const float* bias, float out_scale, void* out, int B, int H, int W, hipStream_t s) {
+  const int64_t M = (int64_t)B * H * W;
+  const int grid = (int)std::min<int64_t>((M + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(conv1_split_kernel, dim3(grid), dim3(256), 0, s, canvas, (const f16*)wgt_planes, bias, out_scale, (f16*)out, B, H, W);
+}
+
+}  // namespace ttr
+
+// ------------------------------------------------------------------------------------------------------------------
+// LayerNorm (D = 384) of fp32 rows into planes: one wave per row, 48 lanes x 8 consecutive columns (two 16-byte loads, three
+// 16-byte plane stores per lane); statistics as layernorm_kernel (parseq_ops.hip): mean, then the centred sum of squares.
+namespace ttr {
+namespace {
+__global__ __launch_bounds__(256) void layernorm_planes_kernel(const float* __restrict__ in, int in_ld, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float eps, f16* __restrict__ out, int M) {
+  constexpr int D = 384;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const bool act = lane < 48;
+  const int c = (act ? lane : 0) * 8;
+  const float* x = in + (int64_t)row * in_ld + c;
+  float v[8];
+  {
+    const float4 a = *reinterpret_cast<const float4*>(x), b = *reinterpret_cast<const float4*>(x + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s += act ? v[e] : 0.f;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s * (1.0f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; q += act ? d * d : 0.f; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = rsqrtf(q * (1.0f / D) + eps);
+  if (!act) return;
+  const float4 g0 = *reinterpret_cast<const float4*>(gamma + c), g1 = *reinterpret_cast<const float4*>(gamma + c + 4);
+  const float4 b0 = *reinterpret_cast<const float4*>(beta + c), b1 = *reinterpret_cast<const float4*>(beta + c + 4);
+  const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+  V8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o.v[e] = (v[e] - mean) * rstd * gg[e] + bb[e];
+  st_planes(out + (int64_t)row * (3 * D) + c, D, o);
+}
+}  // namespace
+
+void launch_layernorm_planes(const float* in, int in_ld, const float* gamma, const float* beta, float eps, void* out, int M, hipStream_t s) {
+  if (M <= 0) return;
+  if (in_ld % 4 || (((uintptr_t)in | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15)) throw std::runtime_error("layernorm (planes): 16-byte alignment");
+  hipLaunchKernelGGL(layernorm_planes_kernel, dim3((M + 3) / 4), dim3(256), 0, s, in, in_ld, gamma, beta, eps, (f16*)out, M);
+}
+}  // namespace ttr
