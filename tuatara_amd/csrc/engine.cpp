@@ -1391,7 +1391,7 @@ struct EngineScope {
 extern "C" {
 
 void ttr_config_default(ttr_config* c) {
-  c->precision = TTR_PREC_BF16; c->device = 0; c->canvas_size = 1024; c->mag_ratio = 1.0f;
+  c->precision = TTR_PREC_F16X4; c->device = 0; c->canvas_size = 1024; c->mag_ratio = 1.0f;
   c->text_threshold = 0.7f; c->link_threshold = 0.4f; c->low_text = 0.4f; c->min_area = 10;
   c->strict_crops = 0; c->max_components = 4096; c->verbose = 0; c->bench_grid_boxes = 0;
 }

@@ -16,7 +16,10 @@ ttr_engine* engine_for(const std::string& weights_dir) {
   std::lock_guard<std::mutex> lk(g_mu);
   ttr_config cfg;
   ttr_config_default(&cfg);
-  if (const char* p = std::getenv("TUATARA_PRECISION")) cfg.precision = (std::string(p) == "f32") ? TTR_PREC_F32 : TTR_PREC_BF16;
+  if (const char* p = std::getenv("TUATARA_PRECISION")) {   // default: TTR_PREC_F16X4 (fp32-equivalent, the reference computes in fp32)
+    const std::string v(p);
+    cfg.precision = v == "f32" ? TTR_PREC_F32 : v == "bf16" ? TTR_PREC_BF16 : TTR_PREC_F16X4;
+  }
   if (const char* p = std::getenv("TUATARA_STRICT_CROPS")) cfg.strict_crops = std::atoi(p);
   if (const char* p = std::getenv("TUATARA_DEVICE")) cfg.device = std::atoi(p);
   std::string key = weights_dir + "#" + std::to_string(cfg.precision) + "#" + std::to_string(cfg.device);

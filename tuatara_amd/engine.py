@@ -208,7 +208,7 @@ class DeviceBuffer:
 
 
 class Engine:
-    def __init__(self, weights_dir: str, precision: str = "bf16", device: int = 0, strict_crops: bool = False, **overrides):
+    def __init__(self, weights_dir: str, precision: str = "f16x4", device: int = 0, strict_crops: bool = False, **overrides):
         self.lib = load()
         # A process that also uses torch's GPU runtime (bench.py, tuatara_amd/dist.py over RCCL) must let torch initialise FIRST:
         # the torch wheel bundles its own ROCm 7.0 HIP / HSA libraries, and they do not come up once the system ROCm 7.2 runtime the
