@@ -42,9 +42,7 @@ typedef struct ttr_config {
   int min_area;          /* 10     tuatara.cpp:148 */
   int strict_crops;      /* 0: clamp crops to the image; 1: fail like the reference's cv::Exception at :416 */
   int max_components;    /* capacity for CCL candidates per page (default 4096) */
-  int verbose;
-  int bench_grid_boxes;  /* 0.  Benchmark only (--boxes=grid40): the detector runs in full, then every page's boxes are
-                            replaced by a fixed 5 x 8 grid of 150 x 40 px boxes so that the recogniser sees exactly 40 crops per page */
+  int verbose;           /* 1: the reference's progress lines on stdout (tuatara.cpp:328-329, :342, :386, :421, :434, :488, :509); TUATARA_VERBOSE=1 does the same */
 } ttr_config;
 
 void ttr_config_default(ttr_config* cfg);
@@ -87,6 +85,39 @@ int ttr_result_texts(const ttr_result* r, char* buf, size_t cap);
  * above ('\n' after each item, copied when texts_cap >= *texts_need).  Returns the total item count. */
 int ttr_results_gather(ttr_result* const* rs, int n, int32_t* counts, float* bboxes, int32_t* ids, char* texts, size_t texts_cap,
                        size_t* texts_need);
+
+/* ---- multi-GPU: RCCL in the C++ host -----------------------------------------------------------------
+ * One process per GPU, one engine per process.  The OCR path has no data-path collective: pages are independent.  The one exchange is
+ * the gather of the decoded token ids, and it runs device buffer to device buffer with ncclAllGather (/opt/rocm/include/rccl/rccl.h:678)
+ * on the engine's stream: attach a communicator and every batch's ids are gathered behind its recogniser pass.  Records are variable
+ * length - every rank's crops-per-page counts travel first, then the payload (the largest rank total rows of 26 ids per rank); nothing
+ * is truncated.  There is no torch in this path. */
+typedef struct ttr_comm ttr_comm;
+#define TTR_COMM_ID_BYTES 256
+/* ncclGetUniqueId (x2: a data and a control communicator): call on ONE rank and hand the bytes to the others by any means ... */
+int ttr_comm_unique_id(void* id256);
+ttr_comm* ttr_comm_create(ttr_engine* e, int rank, int world, const void* id256);
+/* ... or let rank 0 listen on addr:port (TCP) and hand them over itself (single node: addr = 127.0.0.1) */
+ttr_comm* ttr_comm_create_tcp(ttr_engine* e, int rank, int world, const char* addr, int port);
+void ttr_comm_destroy(ttr_comm* c);
+int ttr_comm_rank(const ttr_comm* c);
+int ttr_comm_world(const ttr_comm* c);
+/* c != NULL: from now on ttr_pages_to_data_dev / ttr_stream_push / ttr_stream_flush all-gather the token ids of every batch (every rank
+ * must then make the same sequence of calls with the same page counts); c == NULL: detach. */
+int ttr_engine_attach_comm(ttr_engine* e, ttr_comm* c);
+/* The gathered ids of the batch whose results the last such call returned: counts[world][pages] crops per page, ids[sum][26] in
+ * (rank, page, crop) order.  Returns the number of id rows (and the sizes through world / pages / ids_need); buffers that are too
+ * small or NULL are not written. */
+int ttr_last_gathered(ttr_engine* e, int* world, int* pages, int32_t* counts, size_t counts_cap, int32_t* ids, size_t ids_cap, size_t* ids_need);
+/* bytes of every rank concatenated by rank into all[world * bytes] (small host buffers; also the barrier of the benchmark) */
+int ttr_comm_allgather_host(ttr_comm* c, const void* mine, size_t bytes, void* all);
+/* the framing of a gathered batch, host logic only (no GPU): counts[world][pages] -> cap (payload rows per rank), total[world],
+ * first[world * pages + 1] (row of each page's first crop in the compacted array) */
+int ttr_gather_layout(const int32_t* counts, int world, int pages, int* cap, int32_t* total, int64_t* first);
+/* Latency mode (the reference's 6-thread fan-out over the crop batch, tuatara.cpp:450-485, across GPUs): rank 0 passes the pages, detects
+ * and packs the crop batch; it is broadcast, rank r recognises shard r of ceil(N / world) crops, the ids are all-gathered and rank 0
+ * receives the pages' results (the other ranks pass d_pages = NULL and get n empty results).  Collective.  Returns the result count. */
+int ttr_pages_to_data_dev_sharded(ttr_comm* c, const uint8_t* d_pages, int n, int h, int w, ttr_result** out);
 
 /* ---- stage-level entry points (BASELINE.json configs 2-3; used by the parity tests) -------- */
 /* CRAFT forward (tuatara.cpp:363-394): canvas u8 [H][W][3] (H,W multiples of 32, already resized,

@@ -1,9 +1,10 @@
-"""CPU suite: the N>1 plumbing with world_size 2 over gloo (the same code runs over RCCL in bench.py)."""
+"""CPU suite: the N > 1 schedules with world_size 2 over gloo - the record framing (counts first, then the payload; a page with more
+than 128 crops; an empty page; ragged totals) and latency mode with the REAL fp32 oracle recogniser per rank on FUNSD crops - and the
+C++ host's framing logic (ttr_gather_layout, no GPU needed) against the same numpy restatement."""
 import os
 import socket
 
 import numpy as np
-import pytest
 import torch.multiprocessing as mp
 
 from tuatara_amd import dist as D
@@ -17,38 +18,44 @@ def _free_port():
     return p
 
 
-def _fake_recognise(crops):
-    # deterministic stand-in for PARSeq: ids derived from the crop bytes
-    s = crops.reshape(len(crops), 32 * 128 * 3).astype(np.int64).sum(1)
-    return ((s[:, None] + np.arange(26)[None, :]) % 95).astype(np.int32)
+def _ids_of(rank, page, crop):
+    return [(rank * 31 + page * 7 + crop + k) % 95 for k in range(26)]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, crops_path):
+    import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(3)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        # throughput mode: each rank "processes" its pages, records are all-gathered
-        n_pages = 5
-        mine = D.pages_of_rank(n_pages, rank, world)
-        results = [[{"ids": [(p * 7 + c + k) % 95 for k in range(26)]} for c in range(p + 1)] for p in mine]
-        while len(results) < -(-n_pages // world):
-            results.append([])                       # ragged: pad with an empty page
-        rec = D.pack_records(results, max_crops=8)
-        allrec = D.all_gather_records(rec)
-        assert allrec.shape == (world, -(-n_pages // world), 8, 26)
+        # throughput mode: variable-length records; rank 0 has a 150-crop page (nothing is cut at 128) and an empty one
+        per_page = [[150, 0, 3], [2, 5, 1]][rank]
+        results = [[{"ids": _ids_of(rank, p, c)} for c in range(n)] for p, n in enumerate(per_page)]
+        counts, ids = D.frame_records(results)
+        counts_all, ids_all = D.all_gather_var(counts, ids)
+        assert counts_all.tolist() == [[150, 0, 3], [2, 5, 1]]
+        cap, total, first = D.gather_layout(counts_all)
+        assert cap == 153 and total.tolist() == [153, 8] and len(ids_all) == 161
         for r in range(world):
-            for i, p in enumerate(D.pages_of_rank(n_pages, r, world)):
-                for c in range(p + 1):
-                    assert allrec[r, i, c].tolist() == [(p * 7 + c + k) % 95 for k in range(26)]
-                assert (allrec[r, i, p + 1:] == -1).all()
-        # latency mode: crop batch sharded over ranks, ids gathered; ragged (N not divisible) and empty
-        for n in (7, 2, 1, 0):
-            crops = np.random.default_rng(n).integers(0, 256, (n, 32, 128, 3), dtype=np.uint8)
-            ids = D.recognise_sharded(crops if rank == 0 else None, _fake_recognise)
+            for p in range(3):
+                for c in range(counts_all[r, p]):
+                    assert ids_all[first[r * 3 + p] + c].tolist() == _ids_of(r, p, c)
+        # latency mode: the fp32 oracle PARSeq recognises this rank's shard of real crops; every rank ends with the whole batch's ids
+        from oracle import pipeline
+        from tuatara_amd import weights as W
+        _, parseq = pipeline.load_models(W.synth_craft(0, True), W.synth_parseq(0))
+        crops = np.load(crops_path)["crops"]
+
+        def recognise(c):
+            return pipeline.parseq_logits(parseq, c).argmax(-1).astype(np.int32)
+
+        for n in (len(crops), 1, 0):
+            ids = D.recognise_sharded(crops[:n] if rank == 0 else None, recognise)
             assert ids.shape == (n, 26)
-            assert np.array_equal(ids, _fake_recognise(crops).reshape(n, 26))
+            if rank == 1 and n:
+                q.put(("ids", n, ids.tolist()))
         q.put((rank, "ok"))
     except Exception as ex:  # pragma: no cover
         q.put((rank, repr(ex)))
@@ -56,17 +63,31 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_world2_gloo_gather_and_sharding():
+def test_world2_gloo_framing_and_latency_mode_with_the_oracle_recogniser(tmp_path, oracle_models, funsd):
+    from oracle import pipeline, post
+    craft, parseq = oracle_models
+    d = pipeline.image_to_data(craft, parseq, funsd[:420], debug=True)       # the top of the FUNSD page: a few seconds of CPU
+    crops = d["crops"][:7]                                                   # 7 crops: ragged shards (4 + 3)
+    assert len(crops) == 7
+    single = pipeline.parseq_logits(parseq, crops).argmax(-1)
+    path = str(tmp_path / "crops.npz")
+    np.savez(path, crops=crops)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, path)) for r in range(2)]
     for p in procs:
         p.start()
-    out = sorted(q.get(timeout=180) for _ in procs)
+    got = [q.get(timeout=600) for _ in range(4)]
     for p in procs:
         p.join(timeout=60)
-    assert out == [(0, "ok"), (1, "ok")], out
+    assert sorted(g for g in got if g[0] in (0, 1)) == [(0, "ok"), (1, "ok")], got
+    for g in got:
+        if g[0] == "ids":
+            n, ids = g[1], np.array(g[2])
+            assert np.array_equal(ids, single[:n])                              # gathered == single process
+            strs = [post.decode_ids(r) for r in ids]
+            assert strs == post.decode_logits(pipeline.parseq_logits(parseq, crops[:n]))[0]
 
 
 def test_shard_helpers():
@@ -74,6 +95,20 @@ def test_shard_helpers():
     assert [D.crop_shard(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
     assert [D.crop_shard(2, r, 4) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
     assert D.crop_shard(0, 0, 2) == (0, 0)
-    rec = D.pack_records([[{"ids": list(range(26))}], []], max_crops=3)
-    assert rec.shape == (2, 3, 26) and (rec[1] == -1).all()
-    assert D.unpack_records(rec) == [[list(range(26))], []]
+    counts, ids = D.frame_records([[{"ids": list(range(26))}], []])
+    assert counts.tolist() == [1, 0] and ids.shape == (1, 26)
+
+
+def test_cpp_gather_layout_matches_the_restatement():
+    """ttr_gather_layout is the framing the C++ host uses for the RCCL gather (GatherLayout, engine.cpp): host logic, runs without a GPU."""
+    from tuatara_amd.build import build_lib
+    from tuatara_amd.engine import gather_layout
+    build_lib()
+    rng = np.random.default_rng(0)
+    for world, pages in ((1, 1), (2, 3), (8, 32), (4, 0)):
+        counts = rng.integers(0, 200, (world, pages)).astype(np.int32)
+        if pages:
+            counts[0, 0] = 300                                                 # far beyond the old 128-crop record
+        cap, total, first = gather_layout(counts)
+        cap2, total2, first2 = D.gather_layout(counts)
+        assert cap == cap2 and total.tolist() == total2.tolist() and first.tolist() == first2.tolist()

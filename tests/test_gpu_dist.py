@@ -1,13 +1,13 @@
-"""-m gpu: the RCCL path of tuatara_amd/dist.py in ONE process with an engine: torch's "nccl" backend is the RCCL bundled with the
-torch ROCm-7.0 wheel, the engine links the system ROCm-7.2 runtime (check that the two coexist).  They do when
-torch's runtime comes up first (bench.py's order; Engine() sees to it when torch is already imported).  A GPU box has one MI355X,
-so world_size = 1; world_size 2 runs over gloo in tests/test_dist_cpu.py and N = 2, 4, 8 in the driver's scaling bench
-(python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...).
-Each case runs in a fresh interpreter so that the initialisation order is the one written here."""
+"""-m gpu: the multi-GPU entry points of the C ABI (include/tuatara_hip.h, "multi-GPU") on the one MI355X of a GPU box: world_size 1
+through the real RCCL calls (ncclCommInitRank, ncclAllGather on the engine's stream, ncclBroadcast) - a page with more than 128 crops
+goes through the gather untruncated, latency mode returns what the plain call returns - once inside the test process (where torch
+is imported: the engine then shares torch's bundled ROCm runtime and RCCL) and once in a fresh torch-free interpreter (the system
+runtime, the way bench.py runs).  world_size 2 runs over gloo in tests/test_dist_cpu.py; N = 2, 4, 8 in the driver's scaling bench."""
 import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 from tests.conftest import ROOT
@@ -15,39 +15,75 @@ from tests.conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 BODY = r'''
-import os, socket, sys
+import os, sys
 import numpy as np
 sys.path.insert(0, {root!r})
-{first}
-from tuatara_amd import dist as D
-from tuatara_amd.engine import DeviceBuffer, Engine
-import torch, torch.distributed as dist
-s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-eng = Engine({wdir!r}, precision="bf16")
-from PIL import Image
-page = np.ascontiguousarray(np.array(Image.open({png!r}).convert("RGB"))[:512, :384])
-before = eng.image_to_data(page)
-torch.cuda.set_device(0)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from tuatara_amd import synth
+from tuatara_amd.engine import Comm, DeviceBuffer, Engine
+assert "torch" not in sys.modules
+eng = Engine({wdir!r}, canvas_size=2048)
+page = synth.synthetic_page(7, 2048, 1536, n_words=160)                    # 40 rows of 4 words on a 2048 canvas: > 128 boxes
+small = [synth.synthetic_page(8 + i, 1024, 768, n_words=12) for i in range(3)]
+comm = Comm(eng, 0, 1, unique_id=Comm.unique_id())
+ref = eng.image_to_data(page)
+assert len(ref) > 128, len(ref)
+comm.attach(True)
 buf = DeviceBuffer(page.nbytes); buf.upload(page)
-res = eng.pages_to_data_dev(buf, 1, 512, 384)
-rec = D.pack_records(res)
-allrec = D.all_gather_records(rec, device="cuda")            # one RCCL collective, as in bench.py's step
-assert allrec.shape == (1,) + rec.shape and np.array_equal(allrec[0], rec)
-ids = D.recognise_sharded(np.zeros((5, 32, 128, 3), np.uint8), lambda c: eng.parseq_logits(c)[1], device="cuda")
-assert ids.shape == (5, 26)
-after = eng.image_to_data(page)                               # the engine still works beside the process group
-assert [x["bbox"] for x in after] == [x["bbox"] for x in before] and [x["text"] for x in after] == [x["text"] for x in before]
-assert D.unpack_records(allrec[0])[0] == [x["ids"] for x in res[0]][:D.MAX_CROPS] and len(before) > 3
-dist.destroy_process_group()
-print("OK", len(before))
+res = eng.pages_to_data_dev(buf, 1, 2048, 1536)
+counts, ids = comm.last_gathered()
+assert counts.tolist() == [[len(ref)]] and ids.shape == (len(ref), 26)
+assert np.array_equal(ids, np.array([r["ids"] for r in ref])) and [r["text"] for r in res[0]] == [r["text"] for r in ref]
+b3 = DeviceBuffer(3 * 1024 * 768 * 3); b3.upload(np.stack(small))
+got = []
+for k in range(3):                                                           # streamed batches: the gather rides every pass
+    prev = eng.stream_push(b3, 3, 1024, 768)
+    if prev:
+        c, i = comm.last_gathered(); got.append((prev, c, i))
+while True:
+    last = eng.stream_flush()
+    if not last:
+        break
+    c, i = comm.last_gathered(); got.append((last, c, i))
+assert len(got) == 3
+for r, c, i in got:
+    assert c.tolist() == [[len(p) for p in r]] and np.array_equal(i, np.concatenate([p.ids for p in r]))
+comm.attach(False)
+one = DeviceBuffer(small[0].nbytes); one.upload(small[0])
+lat = comm.pages_to_data_sharded(one, 1, 1024, 768)                           # latency mode, world 1: detect, broadcast, recognise, gather
+plain = eng.image_to_data(small[0])
+assert len(plain) > 5 and [x["text"] for x in lat[0]] == [x["text"] for x in plain] and [x["bbox"] for x in lat[0]] == [x["bbox"] for x in plain]
+assert comm.allgather_host(np.arange(5, dtype=np.int32)).tolist() == [[0, 1, 2, 3, 4]]
+comm.close()
+after = eng.image_to_data(small[0])
+assert [x["text"] for x in after] == [x["text"] for x in plain]
+print("OK", len(ref))
 '''
 
 
-@pytest.mark.parametrize("first", ["import torch; torch.cuda.set_device(0)      # bench.py's order: torch's runtime first",
-                                   "import torch                                  # imported only: Engine() initialises torch's runtime before its own"])
-def test_nccl_all_gather_beside_an_engine(weights, first):
-    code = BODY.format(root=ROOT, wdir=weights["dir"], png=os.path.join(ROOT, "tests", "data", "funsd_0001129658.png"), first=first)
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-3000:]
+def test_rccl_gather_and_latency_mode_in_a_torch_free_process(weights):
+    code = BODY.format(root=ROOT, wdir=weights["dir"])
+    env = dict(os.environ, TUATARA_PRELOAD_TORCH="0")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0 and "OK" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+
+
+def test_rccl_gather_beside_torch(weights):
+    """The same calls inside this process (torch imported by the oracle fixtures)."""
+    from tuatara_amd import synth
+    from tuatara_amd.engine import Comm, DeviceBuffer
+    from tests.conftest import _engine
+    eng = _engine(weights["dir"], "f16x4")
+    comm = Comm(eng, 0, 1, unique_id=Comm.unique_id())
+    pages = np.stack([synth.synthetic_page(20 + i, 1024, 768, n_words=10 + 5 * i) for i in range(2)])
+    buf = DeviceBuffer(pages.nbytes)
+    buf.upload(pages)
+    comm.attach(True)
+    res = eng.pages_to_data_dev(buf, 2, 1024, 768)
+    counts, ids = comm.last_gathered()
+    assert counts.tolist() == [[len(res[0]), len(res[1])]] and len(res[0]) != len(res[1])
+    assert np.array_equal(ids, np.concatenate([res[0].ids, res[1].ids]))
+    comm.attach(False)
+    lat = comm.pages_to_data_sharded(buf, 2, 1024, 768)
+    assert [[x["text"] for x in p] for p in lat] == [[x["text"] for x in p] for p in res]
+    comm.close()
+    buf.free()

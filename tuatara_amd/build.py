@@ -57,7 +57,7 @@ def build_lib(verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(_compile, SOURCES))
     if _stale(LIB, objs):
-        subprocess.check_call([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs)
+        subprocess.check_call([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-ldl", "-L/opt/rocm/lib", "-lrccl"])
     return LIB
 
 

@@ -15,11 +15,21 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <iostream>
 #include <iterator>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <chrono>
+#include <dlfcn.h>
+#include <arpa/inet.h>
+#include <netdb.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/socket.h>
+#include <unistd.h>
+#include <rccl/rccl.h>
+
 #include <atomic>
 #include <functional>
 #include <condition_variable>
@@ -58,6 +68,7 @@ struct Tuning {
   int ln_fuse = 1;            // bf16 decoder steps: LayerNorm computed inside the skinny GEMM's loader (gemm_sk ln_in)
   int fuse_first = 1;         // bf16: CRAFT conv1_1 fused into conv1_2's loader (conv3p FIRST)
   int enc_chunk = 0;          // crops per encoder group (0 = all crops at once)
+  int bench_grid_boxes = 0;   // benchmark workload control (bench.py --boxes=grid40): the detector runs in full, then every page's boxes are replaced by a fixed 5 x 8 grid
   int split_planes = 1;       // split-operand engines: activations stay in planes between the layers (0: fp32 tensors + a split pass in front of every GEMM)
   int split_conv3p = 1;       // split-operand engines: 3x3 layers on the patch-stationary kernel (0: gemm2)
   int split_gemm = 1;         // split-operand engines: 0 = every layer on the fp32 MFMA kernel (A/B and tests)
@@ -76,6 +87,7 @@ struct Tuning {
     else if (k == "ar_crop_exit") ar_crop_exit = value;
     else if (k == "ar_tail_step") ar_tail_step = value;
     else if (k == "split_gemm") split_gemm = value;
+    else if (k == "bench_grid_boxes") bench_grid_boxes = value;
     else if (k == "split_conv3p") split_conv3p = value;
     else if (k == "split_planes") split_planes = value;
     else if (k == "craft_group") craft_group = value < 1 ? 1 : (value > 32 ? 32 : value);
@@ -95,6 +107,27 @@ struct Tuning {
 static Tuning g_tuning_default;
 
 // ------------------------------------------------------------------ small utilities
+// roctx ranges around the host phases of a batch (rocprofv3 --marker-trace shows them next to the kernels).
+// The marker library is looked up at run time: without it the ranges are no-ops.
+struct Roctx {
+  int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
+  Roctx() {
+    for (const char* n : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+      if (void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) {
+        push = (int (*)(const char*))dlsym(h, "roctxRangePushA"); pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (push && pop) return;
+        push = nullptr; pop = nullptr;
+      }
+    }
+  }
+};
+static Roctx& roctx() { static Roctx r; return r; }
+struct RangeScope {
+  bool on;
+  explicit RangeScope(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+  ~RangeScope() { if (on) roctx().pop(); }
+};
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
@@ -319,6 +352,53 @@ class HostPool {
   unsigned long long gen_ = 0;
   bool stop_ = false;
   std::exception_ptr err_;
+};
+
+
+#define TTR_NCCL_CHECK(expr)                                                                                          \
+  do {                                                                                                                \
+    ncclResult_t _r = (expr);                                                                                         \
+    if (_r != ncclSuccess) throw std::runtime_error(std::string("RCCL: ") + ncclGetErrorString(_r) + " at " #expr);   \
+  } while (0)
+
+// Multi-GPU exchange in the C++ host (RCCL = the NCCL API of /opt/rocm/include/rccl/rccl.h): one process per GPU,
+// two communicators per process - `data` carries the per-batch token-id all-gather (and the latency mode's crop broadcast) on the
+// engine's main stream, `ctl` the small host-side exchanges (crop counts, barriers) on the engine's copy stream: collectives of one
+// communicator must be issued in one order on every rank, and the two kinds interleave differently from batch to batch.
+struct Comm {
+  ncclComm_t data = nullptr, ctl = nullptr;
+  int rank = 0, world = 1;
+  struct Engine* E = nullptr;
+  DevBuf d_in, d_out;
+  PinnedBuf h_in, h_out;
+  ~Comm() {
+    if (data) (void)ncclCommDestroy(data);
+    if (ctl) (void)ncclCommDestroy(ctl);
+  }
+};
+
+// The layout of a gathered batch (pure host logic, tests/test_comm_cpu.py drives it through ttr_gather_layout): every rank
+// contributes its crops-per-page counts first; the payload then travels as `cap` = the largest rank total rows of 26 ids per rank.
+// Nothing is truncated: a page may hold any number of crops.
+struct GatherLayout {
+  int world = 0, pages = 0, cap = 0;
+  std::vector<int> total;      // crops of rank r
+  std::vector<int64_t> first;  // row of (rank r, page p)'s first crop in the compacted [sum(total)][26] array
+  static GatherLayout from_counts(const int32_t* counts, int world, int pages) {
+    GatherLayout L;
+    L.world = world; L.pages = pages; L.total.assign(world, 0); L.first.assign((size_t)world * pages + 1, 0);
+    int64_t run = 0;
+    for (int r = 0; r < world; ++r)
+      for (int p = 0; p < pages; ++p) {
+        const int c = counts[(size_t)r * pages + p];
+        if (c < 0) throw std::runtime_error("gather: negative crop count");
+        L.first[(size_t)r * pages + p] = run;
+        run += c; L.total[r] += c;
+      }
+    L.first[(size_t)world * pages] = run;
+    for (int r = 0; r < world; ++r) L.cap = std::max(L.cap, L.total[r]);
+    return L;
+  }
 };
 
 struct Engine {
@@ -614,7 +694,26 @@ struct Engine {
     }
   }
 
+  bool verbose = false;
+  // ---- multi-GPU (ttr_engine_attach_comm): every batch's token ids are all-gathered on the stream, device buffer to device buffer
+  Comm* comm = nullptr;
+  DevBuf gath_dev[2];
+  PinnedBuf h_gath[2];
+  struct Gathered { int world = 0, pages = 0; std::vector<int32_t> counts, ids; } last_gathered;
+  // small host buffers of every rank, concatenated by rank (also the barrier): staged through device memory on the copy stream
+  void allgather_host(const void* mine, size_t bytes, void* all) {
+    Comm& c = *comm;
+    const size_t b = std::max<size_t>(bytes, 1);
+    c.h_in.ensure(b); c.h_out.ensure(b * c.world); c.d_in.ensure(b); c.d_out.ensure(b * c.world);
+    if (bytes) memcpy(c.h_in.p, mine, bytes);
+    TTR_HIP_CHECK(hipMemcpyAsync(c.d_in.p, c.h_in.p, b, hipMemcpyHostToDevice, copy_stream));
+    TTR_NCCL_CHECK(ncclAllGather(c.d_in.p, c.d_out.p, b, ncclChar, c.ctl, copy_stream));
+    TTR_HIP_CHECK(hipMemcpyAsync(c.h_out.p, c.d_out.p, b * c.world, hipMemcpyDeviceToHost, copy_stream));
+    TTR_HIP_CHECK(hipStreamSynchronize(copy_stream));
+    if (bytes && all) memcpy(all, c.h_out.p, bytes * c.world);
+  }
   Engine(const std::string& dir, const ttr_config& c) : cfg(c) {
+    { const char* v = getenv("TUATARA_VERBOSE"); verbose = cfg.verbose != 0 || (v && *v && std::string(v) != "0"); }
     prec = cfg.precision == TTR_PREC_F32 ? kF32 : cfg.precision == TTR_PREC_F16X4 ? kSplit : kBF16;
     es = prec == kBF16 ? 2 : 4;
     int ndev = 0;
@@ -1191,6 +1290,8 @@ struct Engine {
     std::vector<int> rects, page_of;
     int N = 0, slot = 0, group = 16;
     bool live = false, enqueued = false;
+    std::vector<int32_t> all_counts;   // with a communicator: crops per page of every rank [world][n]
+    int cap = 0;                       // ... and the largest rank total (rows of the gathered payload per rank)
   };
   PageBatch q1, q2;        // streamed batches: q1 = boxes known (recogniser enqueued or not), q2 = older, recogniser enqueued, results not yet returned
 
@@ -1232,7 +1333,7 @@ struct Engine {
     B.rects.clear(); B.page_of.clear();        // x0,y0,x1,y1,page per crop; page index per crop
     host_us[1] = host_us[2] = host_us[3] = 0.f;
     for (int gi = 0; gi < groups; ++gi) ccl_collect(gi * GP, std::min(GP, n - gi * GP), gi, B.H2, B.W2, dets);
-    if (cfg.bench_grid_boxes) {   // benchmark workload control: the detector's work is done (and timed); 40 fixed boxes per page go on
+    if (tn.bench_grid_boxes) {   // benchmark workload control (tuning key "bench_grid_boxes", tuatara_hip_debug.h): the detector's work is done (and timed); 40 fixed boxes per page go on
       for (int i = 0; i < n; ++i) {
         dets[i].clear();
         for (int r = 0; r < 8; ++r)
@@ -1261,6 +1362,13 @@ struct Engine {
       }
     }
     B.N = (int)B.page_of.size();
+    if (comm) {   // counts first (host-side exchange on the control communicator), so that every rank knows the payload's size
+      std::vector<int32_t> mine(n, 0);
+      for (int pg : B.page_of) mine[pg]++;
+      B.all_counts.assign((size_t)comm->world * n, 0);
+      allgather_host(mine.data(), (size_t)n * 4, B.all_counts.data());
+      B.cap = GatherLayout::from_counts(B.all_counts.data(), comm->world, n).cap;
+    }
   }
 
   void recog_enqueue(PageBatch& B) {
@@ -1273,7 +1381,7 @@ struct Engine {
       memcpy(h_rects[sl].p, B.rects.data(), B.rects.size() * 4);
       crops.ensure((size_t)N * 32 * 128 * 3);
       logits.ensure((size_t)N * 26 * 95 * 4);
-      ids_dev.ensure((size_t)N * 26 * 4);
+      ids_dev.ensure((size_t)std::max(N, B.cap) * 26 * 4);
       TTR_HIP_CHECK(hipMemcpyAsync(rects_dev.p, h_rects[sl].p, B.rects.size() * 4, hipMemcpyHostToDevice, stream));
       launch_pack_crops(B.d_pages, B.page_bytes, B.w * 3, rects_dev.as<int>(), crops.as<uint8_t>(), N, stream);
       TTR_HIP_CHECK(hipEventRecord(evr[sl][1], stream));
@@ -1283,6 +1391,14 @@ struct Engine {
     } else {
       TTR_HIP_CHECK(hipEventRecord(evr[sl][1], stream));
       TTR_HIP_CHECK(hipEventRecord(evr[sl][2], stream));
+    }
+    if (comm && B.cap > 0) {   // the payload: cap rows of 26 ids per rank, straight from the recogniser's device buffer
+      const size_t per = (size_t)B.cap * 26;
+      ids_dev.ensure(per * 4);
+      gath_dev[sl].ensure(per * 4 * comm->world);
+      h_gath[sl].ensure(per * 4 * comm->world);
+      TTR_NCCL_CHECK(ncclAllGather(ids_dev.p, gath_dev[sl].p, per, ncclInt32, comm->data, stream));
+      TTR_HIP_CHECK(hipMemcpyAsync(h_gath[sl].p, gath_dev[sl].p, per * 4 * comm->world, hipMemcpyDeviceToHost, stream));
     }
     TTR_HIP_CHECK(hipEventRecord(done_ev[sl], stream));
     B.enqueued = true;
@@ -1299,6 +1415,14 @@ struct Engine {
     (void)hipEventElapsedTime(&stage_ms[2], evr[B.slot][0], evr[B.slot][1]); (void)hipEventElapsedTime(&stage_ms[3], evr[B.slot][1], evr[B.slot][2]);
     if (profiling) prof_collect();
     const double th4 = now_us();
+    if (comm) {   // compact the gathered payload: (rank, page, crop) order, no padding
+      const GatherLayout L = GatherLayout::from_counts(B.all_counts.data(), comm->world, n);
+      last_gathered.world = L.world; last_gathered.pages = n; last_gathered.counts = B.all_counts;
+      last_gathered.ids.resize((size_t)L.first.back() * 26);
+      const int32_t* g = h_gath[B.slot].as<int32_t>();
+      for (int r = 0; r < L.world; ++r)
+        if (L.total[r]) memcpy(&last_gathered.ids[(size_t)L.first[(size_t)r * n] * 26], g + (size_t)r * B.cap * 26, (size_t)L.total[r] * 26 * 4);
+    }
     const int32_t* ids = h_ids[B.slot].as<int32_t>();
     // crops are ordered by page: page pg owns crops [first[pg], first[pg + 1]); pages decode independently
     std::vector<int> first(n + 1, 0);
@@ -1327,15 +1451,88 @@ struct Engine {
     if (n <= 0) return;
     if (q1.live || q2.live) throw std::runtime_error("streamed batches are in flight: call ttr_stream_flush until it returns none");
     const double th0 = now_us();
+    // the reference's progress lines (tuatara.cpp:328-329, :342, :421, :434: the models are loaded once per engine here, so those
+    // lines report a fact; :386, :488, :509), on request only: callers do not parse stdout
+    if (verbose) std::cout << ttr_version() << " (HIP " << HIP_VERSION_MAJOR << "." << HIP_VERSION_MINOR << ")\ncraft model loaded" << std::endl;
     PageBatch B;
     B.d_pages = d_pages; B.n = n; B.h = h; B.w = w; B.slot = 0;
-    detect_enqueue(B);
+    { RangeScope r("ttr:detect_enqueue"); detect_enqueue(B); }
     host_us[0] = (float)(now_us() - th0);
-    detect_collect(B);
+    if (verbose) std::cout << "post processing craft predictions..." << std::endl;
+    { RangeScope r("ttr:detect_collect"); detect_collect(B); }
     const double th1 = now_us();
-    recog_enqueue(B);
+    if (verbose) std::cout << "loading parseq model...\nparseq model loaded" << std::endl;
+    { RangeScope r("ttr:recog_enqueue"); recog_enqueue(B); }
     host_us[4] = (float)(now_us() - th1);
-    finish(B, results);
+    if (verbose) std::cout << "Running tokenizer..." << std::endl;
+    { RangeScope r("ttr:finish"); finish(B, results); }
+    if (verbose) std::cout << "Elapsed time: " << (now_us() - th0) * 1e-6 << " seconds " << std::endl;
+  }
+
+  // Latency mode (the reference's 6-thread fan-out over chunks of the crop batch, tuatara.cpp:450-485, across
+  // GPUs): rank 0 detects and packs the crop batch, the batch is broadcast, rank r recognises the contiguous shard r of
+  // ceil(N / world) crops, the ids are all-gathered, rank 0 decodes and returns the pages' results (the other ranks pass no pages and
+  // return n empty results).  Collective over the engine's communicator.
+  void run_pages_sharded(const uint8_t* d_pages, int n, int h, int w, std::vector<Result>& results) {
+    if (!comm) throw std::runtime_error("latency mode needs a communicator (ttr_engine_attach_comm)");
+    if (q1.live || q2.live) throw std::runtime_error("streamed batches are in flight: call ttr_stream_flush until it returns none");
+    Comm* const c = comm;
+    const int world = c->world, rank = c->rank;
+    PageBatch B;
+    int32_t hdr[2] = {0, 0};                                     // {pages, crops} of rank 0
+    comm = nullptr;                                              // (the detector below is not the throughput mode's: no per-batch gather)
+    try {
+      if (rank == 0) {
+        if (!d_pages || n <= 0) throw std::runtime_error("latency mode: rank 0 passes the pages");
+        B.d_pages = d_pages; B.n = n; B.h = h; B.w = w; B.slot = 0;
+        detect_enqueue(B);
+        detect_collect(B);
+        hdr[0] = n; hdr[1] = B.N;
+      }
+    } catch (...) { comm = c; hdr[0] = -1; std::vector<int32_t> all(2 * world); allgather_host(hdr, 8, all.data()); throw; }
+    comm = c;
+    std::vector<int32_t> all(2 * (size_t)world);
+    allgather_host(hdr, 8, all.data());
+    if (all[0] < 0) throw std::runtime_error("latency mode: rank 0 failed in the detector");
+    const int pages = all[0], N = all[1];
+    results.assign(rank == 0 ? pages : std::max(n, 0), Result());
+    if (N == 0) return;
+    const int per = (N + world - 1) / world;
+    const int lo = std::min(N, rank * per), hi = std::min(N, lo + per);
+    crops.ensure((size_t)world * per * 32 * 128 * 3);           // (the last shard may be ragged: the buffer holds world * per crops)
+    if (rank == 0) {
+      rects_dev.ensure(B.rects.size() * 4);
+      h_rects[0].ensure(B.rects.size() * 4);
+      memcpy(h_rects[0].p, B.rects.data(), B.rects.size() * 4);
+      TTR_HIP_CHECK(hipMemcpyAsync(rects_dev.p, h_rects[0].p, B.rects.size() * 4, hipMemcpyHostToDevice, stream));
+      launch_pack_crops(B.d_pages, B.page_bytes, B.w * 3, rects_dev.as<int>(), crops.as<uint8_t>(), N, stream);
+    }
+    TTR_NCCL_CHECK(ncclBroadcast(crops.p, crops.p, (size_t)N * 32 * 128 * 3, ncclUint8, 0, c->data, stream));
+    logits.ensure((size_t)per * 26 * 95 * 4);
+    ids_dev.ensure((size_t)per * 26 * 4);
+    if (hi > lo) parseq_forward(crops.as<uint8_t>() + (size_t)lo * 32 * 128 * 3, hi - lo, logits.as<float>(), nullptr, ids_dev.as<int>());
+    gath_dev[0].ensure((size_t)world * per * 26 * 4);
+    h_gath[0].ensure((size_t)world * per * 26 * 4);
+    TTR_NCCL_CHECK(ncclAllGather(ids_dev.p, gath_dev[0].p, (size_t)per * 26, ncclInt32, c->data, stream));
+    TTR_HIP_CHECK(hipMemcpyAsync(h_gath[0].p, gath_dev[0].p, (size_t)world * per * 26 * 4, hipMemcpyDeviceToHost, stream));
+    TTR_HIP_CHECK(hipEventRecord(done_ev[0], stream));
+    spin_event(done_ev[0]);
+    if (rank != 0) return;
+    const int32_t* ids = h_gath[0].as<int32_t>();                // shard r occupies rows [r * per, r * per + its size): crop k = row k
+    std::vector<int> first(pages + 1, 0);
+    for (int k = 0; k < N; ++k) first[B.page_of[k] + 1]++;
+    for (int pg = 0; pg < pages; ++pg) first[pg + 1] += first[pg];
+    for (int pg = 0; pg < pages; ++pg) {
+      Result& r = results[pg];
+      const int c0 = first[pg], cnt = first[pg + 1] - c0;
+      r.ids.assign(&ids[(size_t)c0 * 26], &ids[(size_t)(c0 + cnt) * 26]);
+      for (int k = 0; k < cnt; ++k) {
+        r.text.push_back(tok.decode(&ids[(size_t)(c0 + k) * 26], 26));
+        float bb[4];
+        tesseract_bbox(B.boxes[pg][k], bb);
+        r.bbox.insert(r.bbox.end(), bb, bb + 4);
+      }
+    }
   }
 
   // Streamed form: returns the results of the batch pushed TWO calls earlier (prev_n = its page count, 0 for the first two pushes).
@@ -1347,13 +1544,13 @@ struct Engine {
     PageBatch B;
     B.d_pages = d_pages; B.n = n; B.h = h; B.w = w;
     B.slot = q1.live ? (q1.slot ^ 1) : 0;     // from the pipeline's state, not a counter: a push that throws leaves q1 / q2 and the slot parity as they were
-    detect_enqueue(B);
+    { RangeScope r("ttr:detect_enqueue"); detect_enqueue(B); }
     host_us[0] = (float)(now_us() - th0);
     const double th1 = now_us();
-    if (q1.live && !q1.enqueued) recog_enqueue(q1);
+    if (q1.live && !q1.enqueued) { RangeScope r("ttr:recog_enqueue"); recog_enqueue(q1); }
     host_us[4] = (float)(now_us() - th1);
-    detect_collect(B);
-    if (q2.live) { prev_n = q2.n; finish(q2, prev_results); }
+    { RangeScope r("ttr:detect_collect"); detect_collect(B); }
+    if (q2.live) { RangeScope r("ttr:finish"); prev_n = q2.n; finish(q2, prev_results); }
     if (q1.live) q2 = std::move(q1);
     q1 = std::move(B);
     q1.live = true; q1.enqueued = false;
@@ -1393,7 +1590,7 @@ extern "C" {
 void ttr_config_default(ttr_config* c) {
   c->precision = TTR_PREC_F16X4; c->device = 0; c->canvas_size = 1024; c->mag_ratio = 1.0f;
   c->text_threshold = 0.7f; c->link_threshold = 0.4f; c->low_text = 0.4f; c->min_area = 10;
-  c->strict_crops = 0; c->max_components = 4096; c->verbose = 0; c->bench_grid_boxes = 0;
+  c->strict_crops = 0; c->max_components = 4096; c->verbose = 0;
 }
 
 const char* ttr_last_error(void) { return g_last_error.c_str(); }
@@ -1425,6 +1622,180 @@ int ttr_pages_to_data_dev(ttr_engine* e, const uint8_t* d_pages, int n, int h, i
   EngineScope lk(*e->e);
   run_locked(e, d_pages, n, h, w, out);
   return 0;
+  TTR_GUARD_END(-1)
+}
+
+struct ttr_comm { std::unique_ptr<Comm> c; };
+
+// rank 0 listens on addr:port and hands its bytes to the world - 1 peers that connect (each sends its rank first)
+static void tcp_share(int rank, int world, const char* addr, int port, void* buf, size_t bytes) {
+  if (world <= 1) return;
+  auto fail = [](const std::string& m) { throw std::runtime_error("comm rendezvous: " + m + ": " + strerror(errno)); };
+  if (rank == 0) {
+    int ls = socket(AF_INET, SOCK_STREAM, 0);
+    if (ls < 0) fail("socket");
+    int one = 1;
+    setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+    sockaddr_in sa{};
+    sa.sin_family = AF_INET; sa.sin_port = htons((uint16_t)port); sa.sin_addr.s_addr = htonl(INADDR_ANY);
+    if (bind(ls, (sockaddr*)&sa, sizeof(sa)) < 0) { close(ls); fail("bind port " + std::to_string(port)); }
+    if (listen(ls, world) < 0) { close(ls); fail("listen"); }
+    for (int k = 1; k < world; ++k) {
+      int cs = accept(ls, nullptr, nullptr);
+      if (cs < 0) { close(ls); fail("accept"); }
+      int32_t peer = -1;
+      if (recv(cs, &peer, 4, MSG_WAITALL) != 4) { close(cs); close(ls); fail("recv"); }
+      size_t off = 0;
+      while (off < bytes) { ssize_t w = send(cs, (const char*)buf + off, bytes - off, 0); if (w <= 0) { close(cs); close(ls); fail("send"); } off += (size_t)w; }
+      close(cs);
+    }
+    close(ls);
+  } else {
+    sockaddr_in sa{};
+    sa.sin_family = AF_INET; sa.sin_port = htons((uint16_t)port);
+    if (inet_pton(AF_INET, (addr && *addr) ? addr : "127.0.0.1", &sa.sin_addr) != 1) {
+      hostent* he = gethostbyname(addr);
+      if (!he) fail(std::string("cannot resolve ") + addr);
+      memcpy(&sa.sin_addr, he->h_addr_list[0], sizeof(sa.sin_addr));
+    }
+    for (int attempt = 0;; ++attempt) {          // rank 0 may not be listening yet
+      int cs = socket(AF_INET, SOCK_STREAM, 0);
+      if (cs < 0) fail("socket");
+      if (connect(cs, (sockaddr*)&sa, sizeof(sa)) == 0) {
+        int32_t me = rank;
+        if (send(cs, &me, 4, 0) != 4) { close(cs); fail("send"); }
+        size_t off = 0;
+        while (off < bytes) { ssize_t r = recv(cs, (char*)buf + off, bytes - off, 0); if (r <= 0) { close(cs); fail("recv"); } off += (size_t)r; }
+        close(cs);
+        return;
+      }
+      close(cs);
+      if (attempt > 3000) fail("connect to " + std::string(addr ? addr : "") + ":" + std::to_string(port));
+      usleep(20000);
+    }
+  }
+}
+
+static ttr_comm* comm_create(ttr_engine* e, int rank, int world, const ncclUniqueId ids[2]) {
+  if (!e || world < 1 || rank < 0 || rank >= world) throw std::runtime_error("ttr_comm_create: bad arguments");
+  Engine& E = *e->e;
+  EngineScope lk(E);
+  std::unique_ptr<ttr_comm> h(new ttr_comm());
+  h->c.reset(new Comm());
+  h->c->rank = rank; h->c->world = world; h->c->E = &E;
+  TTR_NCCL_CHECK(ncclCommInitRank(&h->c->data, world, ids[0], rank));
+  TTR_NCCL_CHECK(ncclCommInitRank(&h->c->ctl, world, ids[1], rank));
+  return h.release();
+}
+
+int ttr_comm_unique_id(void* id256) {
+  TTR_GUARD_BEGIN
+  if (!id256) throw std::runtime_error("null argument");
+  static_assert(sizeof(ncclUniqueId) == 128, "TTR_COMM_ID_BYTES");
+  ncclUniqueId ids[2];
+  TTR_NCCL_CHECK(ncclGetUniqueId(&ids[0]));
+  TTR_NCCL_CHECK(ncclGetUniqueId(&ids[1]));
+  memcpy(id256, ids, sizeof(ids));
+  return 0;
+  TTR_GUARD_END(-1)
+}
+
+ttr_comm* ttr_comm_create(ttr_engine* e, int rank, int world, const void* id256) {
+  TTR_GUARD_BEGIN
+  if (!id256) throw std::runtime_error("null argument");
+  ncclUniqueId ids[2];
+  memcpy(ids, id256, sizeof(ids));
+  return comm_create(e, rank, world, ids);
+  TTR_GUARD_END(nullptr)
+}
+
+ttr_comm* ttr_comm_create_tcp(ttr_engine* e, int rank, int world, const char* addr, int port) {
+  TTR_GUARD_BEGIN
+  ncclUniqueId ids[2];
+  if (rank == 0) { TTR_NCCL_CHECK(ncclGetUniqueId(&ids[0])); TTR_NCCL_CHECK(ncclGetUniqueId(&ids[1])); }
+  tcp_share(rank, world, addr, port, ids, sizeof(ids));
+  return comm_create(e, rank, world, ids);
+  TTR_GUARD_END(nullptr)
+}
+
+void ttr_comm_destroy(ttr_comm* c) {
+  if (!c) return;
+  try {
+    if (c->c && c->c->E) {
+      Engine& E = *c->c->E;
+      EngineScope lk(E);
+      if (E.comm == c->c.get()) E.comm = nullptr;
+      (void)hipStreamSynchronize(E.stream); (void)hipStreamSynchronize(E.copy_stream);
+      c->c.reset();
+    }
+  } catch (...) {}
+  delete c;
+}
+
+int ttr_comm_rank(const ttr_comm* c) { return c && c->c ? c->c->rank : -1; }
+int ttr_comm_world(const ttr_comm* c) { return c && c->c ? c->c->world : -1; }
+
+int ttr_engine_attach_comm(ttr_engine* e, ttr_comm* c) {
+  TTR_GUARD_BEGIN
+  if (!e) throw std::runtime_error("null argument");
+  EngineScope lk(*e->e);
+  if (e->e->q1.live || e->e->q2.live) throw std::runtime_error("streamed batches are in flight");
+  if (c && c->c->E != e->e.get()) throw std::runtime_error("the communicator belongs to another engine");
+  e->e->comm = c ? c->c.get() : nullptr;
+  return 0;
+  TTR_GUARD_END(-1)
+}
+
+int ttr_comm_allgather_host(ttr_comm* c, const void* mine, size_t bytes, void* all) {
+  TTR_GUARD_BEGIN
+  if (!c || !c->c) throw std::runtime_error("null argument");
+  Engine& E = *c->c->E;
+  EngineScope lk(E);
+  Comm* keep = E.comm;
+  E.comm = c->c.get();
+  try { E.allgather_host(mine, bytes, all); } catch (...) { E.comm = keep; throw; }
+  E.comm = keep;
+  return 0;
+  TTR_GUARD_END(-1)
+}
+
+int ttr_last_gathered(ttr_engine* e, int* world, int* pages, int32_t* counts, size_t counts_cap, int32_t* ids, size_t ids_cap, size_t* ids_need) {
+  TTR_GUARD_BEGIN
+  if (!e) throw std::runtime_error("null argument");
+  EngineScope lk(*e->e);
+  const auto& g = e->e->last_gathered;
+  if (world) *world = g.world;
+  if (pages) *pages = g.pages;
+  if (ids_need) *ids_need = g.ids.size();
+  if (counts && counts_cap >= g.counts.size() && !g.counts.empty()) memcpy(counts, g.counts.data(), g.counts.size() * 4);
+  if (ids && ids_cap >= g.ids.size() && !g.ids.empty()) memcpy(ids, g.ids.data(), g.ids.size() * 4);
+  return (int)(g.ids.size() / 26);
+  TTR_GUARD_END(-1)
+}
+
+int ttr_gather_layout(const int32_t* counts, int world, int pages, int* cap, int32_t* total, int64_t* first) {
+  TTR_GUARD_BEGIN
+  if (!counts || world < 1 || pages < 0) throw std::runtime_error("bad arguments");
+  const GatherLayout L = GatherLayout::from_counts(counts, world, pages);
+  if (cap) *cap = L.cap;
+  if (total) memcpy(total, L.total.data(), (size_t)world * 4);
+  if (first) memcpy(first, L.first.data(), L.first.size() * 8);
+  return 0;
+  TTR_GUARD_END(-1)
+}
+
+int ttr_pages_to_data_dev_sharded(ttr_comm* c, const uint8_t* d_pages, int n, int h, int w, ttr_result** out) {
+  TTR_GUARD_BEGIN
+  if (!c || !c->c || !out) throw std::runtime_error("null argument");
+  Engine& E = *c->c->E;
+  EngineScope lk(E);
+  Comm* keep = E.comm;
+  E.comm = c->c.get();
+  std::vector<Result> res;
+  try { E.run_pages_sharded(d_pages, n, h, w, res); } catch (...) { E.comm = keep; throw; }
+  E.comm = keep;
+  for (size_t i = 0; i < res.size(); ++i) { out[i] = new ttr_result(); out[i]->r = std::move(res[i]); }
+  return (int)res.size();
   TTR_GUARD_END(-1)
 }
 

@@ -1,11 +1,11 @@
-"""Multi-GPU plumbing (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm,
-"gloo" in the CPU tests).  The OCR path has no data-path collective: pages are independent and,
-inside a page, crops are independent.  The only exchange is gathering the decoded
-token ids — fixed-size records, a few KB, latency-bound on xGMI — so one all_gather per step.
+"""Multi-GPU launcher glue (one process per GPU).  The exchange itself lives in the C++ host behind the C ABI - RCCL
+all-gather of the token ids on the engine's stream, latency mode's crop broadcast (include/tuatara_hip.h, "multi-GPU";
+tuatara_amd.engine.Comm) - and needs no torch.  What is left here:
 
-  throughput mode : page p -> rank p % G; every rank runs the whole pipeline on its pages.
-  latency mode    : rank 0 detects and packs crops, broadcasts them, rank r recognises the
-                    contiguous shard r of the crop batch, ids are all-gathered.
+  * how work is dealt out: page p -> rank p % G (throughput mode), contiguous crop shards (latency mode);
+  * the same record framing and the same latency-mode schedule over torch.distributed, for the CPU tests (backend "gloo",
+    world_size 2: tests/test_dist_cpu.py) - counts first, then the payload, nothing truncated - mirroring
+    GatherLayout / Engine::run_pages_sharded of tuatara_amd/csrc/engine.cpp.
 """
 from __future__ import annotations
 
@@ -13,7 +13,6 @@ from typing import Callable, List, Sequence, Tuple
 
 import numpy as np
 
-MAX_CROPS = 128      # record capacity per page
 L = 26               # token ids per crop
 
 
@@ -28,42 +27,48 @@ def crop_shard(n_crops: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, min(n_crops, lo + per)
 
 
-def pack_records(results: Sequence[Sequence[dict]], max_crops: int = MAX_CROPS) -> np.ndarray:
-    """results[page][crop]["ids"] -> int32 [pages, max_crops, 26], -1 padded."""
-    rec = np.full((len(results), max_crops, L), -1, np.int32)
-    for i, r in enumerate(results):
+def frame_records(results: Sequence[Sequence[dict]]) -> Tuple[np.ndarray, np.ndarray]:
+    """One rank's batch -> (counts int32 [pages], ids int32 [sum(counts), 26]): any number of crops per page."""
+    counts = np.array([len(r) for r in results], np.int32)
+    rows = []
+    for r in results:
         ids = getattr(r, "ids", None)
-        if isinstance(ids, np.ndarray):            # engine.PageResult: the id array the C ABI filled
-            k = min(len(ids), max_crops)
-            rec[i, :k] = ids[:k]
-            continue
-        for j, item in enumerate(r[:max_crops]):
-            rec[i, j] = item["ids"]
-    return rec
+        rows.append(np.asarray(ids, np.int32).reshape(-1, L) if isinstance(ids, np.ndarray) else np.array([it["ids"] for it in r], np.int32).reshape(-1, L))
+    return counts, (np.concatenate(rows) if rows else np.zeros((0, L), np.int32))
 
 
-def unpack_records(rec: np.ndarray) -> List[List[List[int]]]:
-    out = []
-    for page in rec:
-        out.append([row.tolist() for row in page if row[0] != -1 or (row != -1).any()])
-    return out
+def gather_layout(counts_all: np.ndarray):
+    """counts [world, pages] -> (cap, total[world], first[world * pages + 1]): GatherLayout::from_counts restated."""
+    counts_all = np.asarray(counts_all, np.int64)
+    total = counts_all.sum(1)
+    first = np.concatenate([[0], np.cumsum(counts_all.reshape(-1))])
+    return int(total.max()) if total.size else 0, total.astype(np.int32), first
 
 
-def all_gather_records(rec: np.ndarray, device: str = "cpu") -> np.ndarray:
-    """[pages, C, 26] on every rank -> [world, pages, C, 26] on every rank (one collective)."""
+def all_gather_var(counts: np.ndarray, ids: np.ndarray, device: str = "cpu"):
+    """Every rank's (counts, ids) -> (counts_all [world, pages], ids_all [sum, 26] in (rank, page, crop) order): two collectives,
+    the counts, then the payload padded to the largest rank total."""
     import torch
     import torch.distributed as dist
 
-    mine = torch.from_numpy(np.ascontiguousarray(rec)).to(device)
     world = dist.get_world_size()
-    out = torch.empty((world * mine.shape[0],) + tuple(mine.shape[1:]), dtype=mine.dtype, device=device)
-    dist.all_gather_into_tensor(out, mine)   # concatenation along dim 0 (the form gloo and RCCL both accept)
-    return out.reshape((world,) + tuple(mine.shape)).cpu().numpy()
+    c = torch.from_numpy(np.ascontiguousarray(counts, np.int32)).to(device)
+    call = torch.empty((world * c.shape[0],), dtype=c.dtype, device=device)
+    dist.all_gather_into_tensor(call, c)
+    counts_all = call.cpu().numpy().reshape(world, -1)
+    cap, total, _ = gather_layout(counts_all)
+    pay = torch.full((max(cap, 1), L), -1, dtype=torch.int32, device=device)
+    if len(ids):
+        pay[: len(ids)] = torch.from_numpy(np.ascontiguousarray(ids, np.int32)).to(device)
+    out = torch.empty((world * pay.shape[0], L), dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(out, pay)
+    out = out.cpu().numpy().reshape(world, -1, L)
+    return counts_all, np.concatenate([out[r, : total[r]] for r in range(world)]) if total.sum() else np.zeros((0, L), np.int32)
 
 
 def recognise_sharded(crops: np.ndarray | None, recognise: Callable[[np.ndarray], np.ndarray], device: str = "cpu") -> np.ndarray:
-    """Latency mode.  rank 0 passes the packed crop batch u8 [N,32,128,3] (others pass None);
-    every rank returns the ids int32 [N,26] of the whole batch."""
+    """Latency mode over torch.distributed (the CPU twin of ttr_pages_to_data_dev_sharded).  rank 0 passes the packed crop batch
+    u8 [N,32,128,3] (others pass None); every rank returns the ids int32 [N,26] of the whole batch."""
     import torch
     import torch.distributed as dist
 
@@ -74,12 +79,12 @@ def recognise_sharded(crops: np.ndarray | None, recognise: Callable[[np.ndarray]
     if n == 0:
         return np.zeros((0, L), np.int32)
     buf = torch.from_numpy(np.ascontiguousarray(crops)).to(device) if rank == 0 else torch.empty((n, 32, 128, 3), dtype=torch.uint8, device=device)
-    if n:
-        dist.broadcast(buf, 0)
-    per = -(-n // world) if n else 0
+    dist.broadcast(buf, 0)
+    per = -(-n // world)
     lo, hi = crop_shard(n, rank, world)
-    ids = np.full((per, L), -1, np.int32)
+    ids = torch.full((per, L), -1, dtype=torch.int32, device=device)
     if hi > lo:
-        ids[: hi - lo] = recognise(buf[lo:hi].cpu().numpy())
-    gathered = all_gather_records(ids[None], device)[:, 0]          # [world, per, 26]
-    return gathered.reshape(world * per, L)[:n]
+        ids[: hi - lo] = torch.from_numpy(np.ascontiguousarray(recognise(buf[lo:hi].cpu().numpy()), np.int32)).to(device)
+    out = torch.empty((world * per, L), dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(out, ids)
+    return out.cpu().numpy()[:n]

@@ -23,7 +23,7 @@ PREC_BF16, PREC_F32, PREC_F16X4 = 0, 1, 2
 class Config(C.Structure):
     _fields_ = [("precision", C.c_int), ("device", C.c_int), ("canvas_size", C.c_int), ("mag_ratio", C.c_float),
                 ("text_threshold", C.c_float), ("link_threshold", C.c_float), ("low_text", C.c_float), ("min_area", C.c_int),
-                ("strict_crops", C.c_int), ("max_components", C.c_int), ("verbose", C.c_int), ("bench_grid_boxes", C.c_int)]
+                ("strict_crops", C.c_int), ("max_components", C.c_int), ("verbose", C.c_int)]
 
 
 # every symbol include/tuatara_hip.h declares: (name, restype, argtypes)
@@ -77,6 +77,17 @@ SYMBOLS = [
     ("ttr_dbg_dec_stamps", _I, [C.POINTER(C.c_ulonglong)]),
     ("ttr_bench_conv", _I, [_VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _PF]),
     ("ttr_get_profile", _I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    ("ttr_comm_unique_id", _I, [_VP]),
+    ("ttr_comm_create", _VP, [_VP, _I, _I, _VP]),
+    ("ttr_comm_create_tcp", _VP, [_VP, _I, _I, C.c_char_p, _I]),
+    ("ttr_comm_destroy", None, [_VP]),
+    ("ttr_comm_rank", _I, [_VP]),
+    ("ttr_comm_world", _I, [_VP]),
+    ("ttr_engine_attach_comm", _I, [_VP, _VP]),
+    ("ttr_last_gathered", _I, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int), _PI, C.c_size_t, _PI, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("ttr_comm_allgather_host", _I, [_VP, _VP, C.c_size_t, _VP]),
+    ("ttr_gather_layout", _I, [_PI, _I, _I, C.POINTER(C.c_int), _PI, C.POINTER(C.c_int64)]),
+    ("ttr_pages_to_data_dev_sharded", _I, [_VP, _VP, _I, _I, _I, C.POINTER(_VP)]),
 ]
 
 
@@ -227,12 +238,16 @@ class Engine:
                          PREC_F16X4 if precision in ("f16x4", "split", PREC_F16X4) else PREC_BF16)
         cfg.device = device
         cfg.strict_crops = int(strict_crops)
+        tuning = {k: overrides.pop(k) for k in list(overrides) if not hasattr(cfg, k)}     # not a config field: a tuning key (below)
         for k, v in overrides.items():
             setattr(cfg, k, v)
         self.cfg = cfg
         self.h = self.lib.ttr_create(weights_dir.encode(), C.byref(cfg))
         if not self.h:
             raise EngineError(self.lib.ttr_last_error().decode())
+        for k, v in tuning.items():
+            if self.set_tuning(k, int(v)) != 0:
+                raise EngineError(f"unknown engine option {k!r}")
 
     def set_tuning(self, key, value: int) -> int:
         """Per-engine kernel-selection knob (ttr_engine_set_tuning); keys it does not know go to the process-wide diagnostics setter."""
@@ -458,3 +473,78 @@ class Engine:
         self._check(self.lib.ttr_dbg_conv(self.h, _f(x0), C0, _f(x1) if x1 is not None else None, C1, int(relu0), int(relu1), B, H, W_, ks, dil,
                                           _f(w), _f(b) if b is not None else None, Cout, act, _f(out)))
         return out
+
+
+def gather_layout(counts: np.ndarray):
+    """The framing of a gathered batch (ttr_gather_layout, host logic only): counts int32 [world, pages] -> (cap, total[world],
+    first[world * pages + 1])."""
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    world, pages = counts.shape
+    cap = C.c_int()
+    total = np.zeros(world, np.int32)
+    first = np.zeros(world * pages + 1, np.int64)
+    if load().ttr_gather_layout(_i(counts), world, pages, C.byref(cap), _i(total), first.ctypes.data_as(C.POINTER(C.c_int64))) != 0:
+        raise EngineError(load().ttr_last_error().decode())
+    return cap.value, total, first
+
+
+class Comm:
+    """RCCL communicator pair of an engine (include/tuatara_hip.h, "multi-GPU"): one process per GPU.  `Comm(engine, rank, world,
+    addr, port)`: rank 0 listens on addr:port and hands the NCCL ids to the others; `attach()` makes every batch of the engine
+    all-gather its token ids on the engine's stream."""
+
+    def __init__(self, engine: "Engine", rank: int, world: int, addr: str = "127.0.0.1", port: int = 29617, unique_id: Optional[bytes] = None):
+        self.eng, self.lib = engine, engine.lib
+        if unique_id is not None:
+            buf = C.create_string_buffer(unique_id, 256)
+            self.h = self.lib.ttr_comm_create(engine.h, rank, world, buf)
+        else:
+            self.h = self.lib.ttr_comm_create_tcp(engine.h, rank, world, addr.encode(), port)
+        if not self.h:
+            raise EngineError(self.lib.ttr_last_error().decode())
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(256)
+        if load().ttr_comm_unique_id(buf) != 0:
+            raise EngineError(load().ttr_last_error().decode())
+        return buf.raw
+
+    def attach(self, on: bool = True):
+        if self.lib.ttr_engine_attach_comm(self.eng.h, self.h if on else None) != 0:
+            raise EngineError(self.lib.ttr_last_error().decode())
+
+    def allgather_host(self, mine: np.ndarray) -> np.ndarray:
+        """Small host array of every rank, stacked by rank (collective; with an empty array: a barrier)."""
+        mine = np.ascontiguousarray(mine)
+        out = np.zeros((self.world,) + mine.shape, mine.dtype)
+        if self.lib.ttr_comm_allgather_host(self.h, mine.ctypes.data_as(C.c_void_p), mine.nbytes, out.ctypes.data_as(C.c_void_p)) != 0:
+            raise EngineError(self.lib.ttr_last_error().decode())
+        return out
+
+    def barrier(self):
+        self.allgather_host(np.zeros(1, np.int32))
+
+    def last_gathered(self):
+        """(counts int32 [world, pages], ids int32 [rows, 26]) of the batch whose results the engine returned last."""
+        world, pages, need = C.c_int(), C.c_int(), C.c_size_t()
+        self.lib.ttr_last_gathered(self.eng.h, C.byref(world), C.byref(pages), None, 0, None, 0, C.byref(need))
+        counts = np.zeros((max(world.value, 0), max(pages.value, 0)), np.int32)
+        ids = np.zeros((need.value // 26, 26), np.int32)
+        self.lib.ttr_last_gathered(self.eng.h, None, None, _i(counts), counts.size, _i(ids), ids.size, None)
+        return counts, ids
+
+    def pages_to_data_sharded(self, d_pages, n: int, h: int, w: int):
+        """Latency mode (ttr_pages_to_data_dev_sharded): rank 0 passes the device pages, the others None."""
+        ptr = d_pages.ptr if isinstance(d_pages, DeviceBuffer) else d_pages
+        arr = (C.c_void_p * max(n, 1))()
+        k = self.lib.ttr_pages_to_data_dev_sharded(self.h, ptr, n, h, w, arr)
+        if k < 0:
+            raise EngineError(self.lib.ttr_last_error().decode())
+        return self.eng._take_many(arr, k) if k else []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ttr_comm_destroy(self.h)
+            self.h = None
