@@ -33,7 +33,8 @@ CRAFT_GFLOP_PER_PAGE = 559.5      # 27 convs, 2*MACs, BN
 PARSEQ_GFLOP_PER_CROP = 6.129     # encoder 5.747 + KV-cached AR 0.190 + refine 0.191
 MFMA_16BIT_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 / f16
 MFMA_F32_PEAK_TFLOPS = 157.3
-MFMA_PER_PRODUCT = {"f16x4": 4, "bf16": 1, "f32": 1}   # matrix-pipe flops per algorithmic flop (tuatara_amd/csrc/split.h)
+MFMA_PER_PRODUCT = {"f16x4": 4, "bf16": 1, "f32": 1}   # matrix-pipe flops per algorithmic flop (tuatara_amd/csrc/split.h): PARSeq
+CRAFT_MFMA_PER_PRODUCT = {"f16x4": 3, "bf16": 1, "f32": 1}   # ... CRAFT runs on activation pairs: three MFMAs per product
 
 
 # --------------------------------------------------------------------------------------------------------------- CPU baseline
@@ -321,7 +322,7 @@ def main():
     out = None
     n_pass = args.steps * R
     if rank == 0:
-        mpp = MFMA_PER_PRODUCT[args.precision]
+        mpp = CRAFT_MFMA_PER_PRODUCT[args.precision]
         peak = MFMA_F32_PEAK_TFLOPS if args.precision == "f32" else MFMA_16BIT_PEAK_TFLOPS
         c = prof["craft"]
         craft_alg = (CRAFT_GFLOP_PER_PAGE * 1e9 * P * n_pass) / (c["ms"] * 1e-3) / 1e12 if c["ms"] else None
@@ -347,8 +348,9 @@ def main():
                        "ar_steps": "26 (no early exit in this precision)" if args.precision != "bf16" else "early exit when every crop of the batch has emitted EOS (upstream PARSeq's break)",
                        "decoded_string_length_histogram": lens.tolist(),
                        "distinct_pages": NB * P, "page_buffers_rotated": NB, "weights": "seeded synthetic (designed read-outs on random CRAFT / PARSeq, tuatara_amd/weights.py)",
-                       "precision": {"f16x4": "fp32-equivalent: every product as four f16 MFMAs on exact activation triples and weight pairs (tuatara_amd/csrc/split.h); "
-                                              "logits within 1e-3 of the CPU fp32 reference, boxes and strings identical (tests/test_gpu_x4_parity.py)",
+                       "precision": {"f16x4": "fp32-equivalent split-operand f16 MFMA (tuatara_amd/csrc/split.h): PARSeq on exact activation triples x weight pairs (four MFMAs per product), "
+                                              "CRAFT on activation pairs (three; its heat map stays at fp32 noise level); logits within 1e-3 of the CPU fp32 reference, boxes and "
+                                              "strings identical (tests/test_gpu_x4_parity.py)",
                                      "bf16": "operands rounded to bf16: NOT output-equivalent (|dlogit| up to ~1e-1..1)", "f32": "fp32 MFMA"}[args.precision],
                        "parallelism": f"dp{world}"},
             "gathered_id_rows_last_pass": gathered_rows,

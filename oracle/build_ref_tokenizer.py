@@ -91,7 +91,7 @@ def build() -> str | None:
             f.write(DRIVER)
         cmd = ["g++", "-O1", "-std=c++17", drv, "-o", BIN, "-I", os.path.join(tdir, "include"),
                "-I", os.path.join(tdir, "include", "torch", "csrc", "api", "include"), "-L", os.path.join(tdir, "lib"),
-               "-ltorch", "-ltorch_cpu", "-lc10", f"-Wl,-rpath,{os.path.join(tdir, 'lib')}", "-D_GLIBCXX_USE_CXX11_ABI=1"]
+               "-ltorch", "-ltorch_cpu", "-lc10", f"-Wl,-rpath,{os.path.join(tdir, 'lib')}", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch.compiled_with_cxx11_abi())}"]
         subprocess.check_call(cmd)
     finally:
         for p in (inc, drv):                      # the extract is reference text: it does not stay on disk

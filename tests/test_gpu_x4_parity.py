@@ -93,6 +93,25 @@ def test_x4_craft_full_page_structured_and_random_weights(eng_x4, eng_x4_random,
     assert np.abs(got_r - ref_r).max() < TOL * scale
 
 
+def test_x4_craft_exact_triples_option(eng_x4_random, weights_random):
+    """CRAFT on exact activation triples (four MFMAs per product, tuning key "craft_products" = 4) instead of the default pairs:
+    the same bar, and both forms agree with each other far inside it."""
+    from oracle import pipeline
+    craft_r, _ = pipeline.load_models(weights_random["craft"], weights_random["parseq"])
+    canvas = np.random.default_rng(4).integers(0, 256, (512, 384, 3), dtype=np.uint8)
+    ref = pipeline.craft_heatmap(craft_r, canvas)
+    pairs = eng_x4_random.craft_heatmap(canvas)
+    assert eng_x4_random.set_tuning(b"craft_products", 4) == 0
+    try:
+        triples = eng_x4_random.craft_heatmap(canvas)
+    finally:
+        eng_x4_random.set_tuning(b"craft_products", 3)
+    scale = max(1.0, float(np.abs(ref).max()))
+    print(f"CRAFT 512x384 random weights: pairs {np.abs(pairs - ref).max():.2e}, triples {np.abs(triples - ref).max():.2e} (max |heat| {scale:.2f})")
+    assert np.abs(pairs - ref).max() < TOL * scale and np.abs(triples - ref).max() < TOL * scale
+    assert np.abs(pairs - triples).max() < 1e-4 * scale
+
+
 @pytest.mark.parametrize("hw", [(256, 192), (96, 160), (64, 96)])
 def test_x4_craft_small_canvases_random_weights(eng_x4_random, weights_random, hw):
     """Canvases that do not tile into conv3p patches at every level (gemm2's split variant serves those layers)."""

@@ -32,20 +32,6 @@ __device__ __forceinline__ void st_out(bf16* dst, bf16x8 v, int policy) {
 
 namespace {
 
-// split-operand mode: 8 consecutive channels of pixel m -> fp32 [m][ld] or the three f16 planes [m][3 ld]
-__device__ __forceinline__ void st_split3(void* out, int64_t m, int ld, int n, const float (&v)[8], int planes) {
-  if (planes) {
-    f16x8 a, b, c;
-    split3_x8(v, a, b, c);
-    f16* o = reinterpret_cast<f16*>(out) + m * (3 * (int64_t)ld) + n;
-    *reinterpret_cast<f16x8*>(o) = a; *reinterpret_cast<f16x8*>(o + ld) = b; *reinterpret_cast<f16x8*>(o + 2 * ld) = c;
-  } else {
-    float* o = reinterpret_cast<float*>(out) + m * ld + n;
-    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-    *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-  }
-}
-
 typedef __attribute__((address_space(3))) void* lds_ptr;
 // Patch geometry: 256 output pixels as 8 x 32 (LPW = 5) or, for maps whose width is not a multiple of 32 (CRAFT's 64 x 48
 // level), 16 x 16 (LPW = 4).  Halo patch (PH+2) x (PW+2) pixel slots of 128 B, padded to whole 1-KiB pieces of 8 slots.
@@ -81,13 +67,15 @@ struct C3 {
 // SP (split-operand mode, split.h): f16 planes.  The input holds [x0 | x1 | x2] per pixel (3 Cin halves), the weight rows
 // [w0 | w0/2^11 | w1] (3 x 9 Cin).  A 64-channel chunk becomes four virtual chunks: x0 with w0, x0 again with w1
 // (the patch stays), x1 with w0/2^11, x2 with w0/2^11 - 36 tap steps into the one accumulator, three patch loads instead of one.
-template <int BN, int WM, int WN, bool FIRST, int XS, int LPW, bool SP = false>   // XS: patch stages (1 when Cin = 64: a single chunk, and two workgroups fit a CU)
+template <int BN, int WM, int WN, bool FIRST, int XS, int LPW, int NP = 0>   // NP: 0 = bf16, 4 = triples, 3 = pairs (split.h).  XS: patch stages (1 when Cin = 64: a single chunk, and two workgroups fit a CU)
 __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM * WN == 4 ? 1 : 1)) void conv3p_kernel(ConvParams p) {
   using C = C3<BN, WM, WN, LPW>;
   using G = Geo<LPW>;
+  constexpr bool SP = NP != 0;
   static_assert(!SP || (XS == 1 && !FIRST), "split mode: single patch stage, no fused first layer");
   using frag_t = typename std::conditional<SP, f16x8, bf16x8>::type;
-  constexpr int PL = SP ? 3 : 1;
+  constexpr int PL = NP == 4 ? 3 : NP == 3 ? 2 : 1;      // activation planes per pixel
+  constexpr int VC = SP ? NP : 1;                         // virtual chunks per 64-channel chunk: (x0, w0) (x0, w1) (x1, w0b) [(x2, w0b)]
   constexpr int PH = G::PH, PW = G::PW, HW2 = G::HW2, XSLOTS = G::XSLOTS, XPIECES = G::XPIECES, XSTAGE = G::XSTAGE, NHALO = G::NHALO;
   static_assert(!FIRST || LPW == 5, "the fused first layer uses 8 x 32 patches");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -115,7 +103,7 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
   const int y0 = ty * PH, x0 = tx * PW;
 
   const int Cin = p.C0, K = 9 * Cin, KP = SP ? 3 * K : K;   // KP: weight row length
-  const int nchunks = SP ? 4 * (Cin >> 6) : (Cin >> 6), nsteps = nchunks * 9;   // (virtual chunks when SP)
+  const int nchunks = VC * (Cin >> 6), nsteps = nchunks * 9;   // (virtual chunks when SP)
   const __amdgpu_buffer_rsrc_t rsx = mk_rsrc(p.in0, FIRST ? 16u : (unsigned)((size_t)p.M * Cin * 2 * PL));
   const __amdgpu_buffer_rsrc_t rsw = mk_rsrc(p.wgt, (unsigned)((size_t)p.Cout * KP * 2));
   constexpr unsigned OOB = 0x80000000u;
@@ -143,7 +131,7 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
   auto stage_x = [&](int chunk) {
     unsigned char* sb = xs + (chunk & (XS - 1)) * XSTAGE;
     unsigned co = (unsigned)(chunk * 64 * 2);
-    if constexpr (SP) { const int q = chunk & 3, pl = q < 2 ? 0 : q - 1; co = (unsigned)((pl * Cin + (chunk >> 2) * 64) * 2); }
+    if constexpr (SP) { const int q = chunk % VC, pl = q < 2 ? 0 : q - 1; co = (unsigned)((pl * Cin + (chunk / VC) * 64) * 2); }
 #pragma unroll
     for (int i = 0; i < C::XPW; ++i) {
       const int piece = i * C::NW + wave;
@@ -158,7 +146,7 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
   auto stage_w = [&](int chunk, int tap, int parity) {
     unsigned char* sb = ws + parity * C::WSTAGE;
     unsigned ko = (unsigned)((tap * Cin + chunk * 64) * 2);
-    if constexpr (SP) { const int q = chunk & 3, pl = q == 0 ? 0 : q == 1 ? 2 : 1; ko = (unsigned)((pl * K + tap * Cin + (chunk >> 2) * 64) * 2); }
+    if constexpr (SP) { const int q = chunk % VC, pl = q == 0 ? 0 : q == 1 ? 2 : 1; ko = (unsigned)((pl * K + tap * Cin + (chunk / VC) * 64) * 2); }
 #pragma unroll
     for (int j = 0; j < C::WPW; ++j) {
       const unsigned vo = wb[j];   // (a local copy: with the array element as the builtin's argument hipcc's host pass drops the kernel's stub without a word)
@@ -260,7 +248,7 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
         const int par = (chunk + tap) & 1;                 // (chunk * 9 + tap) & 1
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (tap == 0 && chunk > 0 && (!SP || (chunk & 3) != 1)) {   // single patch stage: the next chunk's patch can only be fetched now
+        if (tap == 0 && chunk > 0 && (!SP || chunk % VC != 1)) {   // single patch stage: the next chunk's patch can only be fetched now
           stage_x(chunk);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
@@ -305,7 +293,7 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
   for (int s = 0; s < nsteps; ++s) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (XS == 1 && tap == 0 && chunk > 0 && (!SP || (chunk & 3) != 1)) {   // single patch stage: the next chunk's patch can only be fetched now (its latency is
+    if (XS == 1 && tap == 0 && chunk > 0 && (!SP || chunk % VC != 1)) {   // single patch stage: the next chunk's patch can only be fetched now (its latency is
       stage_x(chunk);                         // covered by the CU's other workgroup, which is what the single stage buys)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -394,12 +382,12 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
       }
       if constexpr (SP) {
-        if (p.out) st_split3(p.out, m, p.out_ld, n, v, p.out_planes);
+        if (p.out) st_split_n(p.out, m, p.out_ld, n, v, p.out_planes);
         if (p.out_relu) {
           float w[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) w[e] = fmaxf(v[e], 0.f);
-          st_split3(p.out_relu, m, p.out_ld, n, w, p.out_planes);
+          st_split_n(p.out_relu, m, p.out_ld, n, w, p.out_planes);
         }
       } else {
       if (p.out) {
@@ -435,7 +423,7 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
             float w[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) w[e] = fmaxf(pooled[i][e], pooled[i + PD][e]);
-            if ((fr & 1) == 0) st_split3(p.out_pool, ((int64_t)b * (p.H >> 1) + yo) * (p.W >> 1) + xo2, p.out_ld, n, w, p.out_planes);
+            if ((fr & 1) == 0) st_split_n(p.out_pool, ((int64_t)b * (p.H >> 1) + yo) * (p.W >> 1) + xo2, p.out_ld, n, w, p.out_planes);
           } else {
           bf16x8 o;
 #pragma unroll
@@ -1054,15 +1042,15 @@ static void launch_first2(const ConvParams& p_in, hipStream_t s) {
   hipLaunchKernelGGL(conv3p_first2_kernel, dim3(std::min(npatch, cus)), dim3(512), lds, s, p);
 }
 
-template <int BN, int WM, int WN, bool FIRST = false, int XS = 2, int LPW = 5, bool SP = false>
+template <int BN, int WM, int WN, bool FIRST = false, int XS = 2, int LPW = 5, int NP = 0>
 static void launch_c3(const ConvParams& p, hipStream_t s) {
   using C = C3<BN, WM, WN, LPW>;
   using G = Geo<LPW>;
   const int tilesM = p.B * (p.H / G::PH) * (p.W / G::PW), tilesN = (p.Cout + BN - 1) / BN;
   constexpr int lds = XS * G::XSTAGE + 2 * C::WSTAGE + (FIRST ? 2048 : 0);
   static PerDeviceOnce once;
-  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_kernel<BN, WM, WN, FIRST, XS, LPW, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); });
-  hipLaunchKernelGGL((conv3p_kernel<BN, WM, WN, FIRST, XS, LPW, SP>), dim3(tilesM * tilesN), dim3(C::NT), lds, s, p);
+  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_kernel<BN, WM, WN, FIRST, XS, LPW, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); });
+  hipLaunchKernelGGL((conv3p_kernel<BN, WM, WN, FIRST, XS, LPW, NP>), dim3(tilesM * tilesN), dim3(C::NT), lds, s, p);
 }
 
 void set_conv3p_first_persistent(int v) { g_first_persistent = v; }
@@ -1091,7 +1079,9 @@ const char* conv3p_check(const ConvParams& p) {
     if (!p.out && !p.out_pool) return "conv3p: no output";
     if ((p.bias && ((uintptr_t)p.bias & 15)) || ((uintptr_t)p.in0 & 15) || ((uintptr_t)p.wgt & 15)) return "conv3p: operand alignment";
     const size_t lim = (size_t)1 << 31;
-    if ((size_t)p.M * p.C0 * 6 >= lim || (size_t)p.Cout * 27 * p.C0 * 2 >= lim) return "conv3p: tensor too large for 32-bit buffer offsets";
+    if (p.split != 3 && p.split != 4) return "conv3p: split must be 3 or 4";
+    if (p.out_planes != 0 && p.out_planes != 2 && p.out_planes != 3) return "conv3p: out_planes must be 0, 2 or 3";
+    if ((size_t)p.M * p.C0 * (p.split == 4 ? 6 : 4) >= lim || (size_t)p.Cout * 27 * p.C0 * 2 >= lim) return "conv3p: tensor too large for 32-bit buffer offsets";
     if (p.M != p.B * p.H * p.W || p.M <= 0 || !(p.out_scale > 0.f)) return "conv3p: bad shape";
     return nullptr;
   }
@@ -1119,16 +1109,19 @@ void launch_conv3p(const ConvParams& p, hipStream_t s) {
   if (const char* e = conv3p_check(p)) throw std::runtime_error(e);
   if (p.split) {   // the one-patch-stage tiles (two workgroups per CU)
     const bool wide = p.H % 8 == 0 && p.W % 32 == 0;
-    if (p.Cout <= 64) {
-      if (!wide) return launch_c3<64, 4, 2, false, 1, 4, true>(p, s);
-      if (p.Cout <= 32) return launch_c3<32, 4, 1, false, 1, 5, true>(p, s);
-      return launch_c3<64, 4, 2, false, 1, 5, true>(p, s);
-    }
-    if (!wide) {
-      const int tiles128 = p.B * (p.H / 16) * (p.W / 16) * ((p.Cout + 127) / 128);
-      return tiles128 < 2 * device_cu_count(256) ? launch_c3<64, 4, 2, false, 1, 4, true>(p, s) : launch_c3<128, 4, 2, false, 1, 4, true>(p, s);
-    }
-    return launch_c3<128, 4, 2, false, 1, 5, true>(p, s);
+    const int tiles128 = wide ? 0 : p.B * (p.H / 16) * (p.W / 16) * ((p.Cout + 127) / 128);
+    const bool narrow = !wide && tiles128 < 2 * device_cu_count(256);
+#define TTR_C3_SPLIT(NPV)                                                                               \
+    if (p.Cout <= 64) {                                                                                 \
+      if (!wide) return launch_c3<64, 4, 2, false, 1, 4, NPV>(p, s);                                    \
+      if (p.Cout <= 32) return launch_c3<32, 4, 1, false, 1, 5, NPV>(p, s);                             \
+      return launch_c3<64, 4, 2, false, 1, 5, NPV>(p, s);                                               \
+    }                                                                                                   \
+    if (!wide) return narrow ? launch_c3<64, 4, 2, false, 1, 4, NPV>(p, s) : launch_c3<128, 4, 2, false, 1, 4, NPV>(p, s);   \
+    return launch_c3<128, 4, 2, false, 1, 5, NPV>(p, s);
+    if (p.split == 3) { TTR_C3_SPLIT(3) }
+    TTR_C3_SPLIT(4)
+#undef TTR_C3_SPLIT
   }
   if (p.pre_wgt) {
     if (p.C0 != 64 || p.Cout > 64 || !p.pre_bias) throw std::runtime_error("conv3p: the fused first layer needs Cin = 64, Cout <= 64");

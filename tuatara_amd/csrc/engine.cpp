@@ -41,6 +41,7 @@
 #include "../../include/tuatara_hip_debug.h"
 #include "common.h"
 #include "geometry.h"
+#include "host_util.h"
 #include "kernels.h"
 
 namespace ttr {
@@ -68,6 +69,7 @@ struct Tuning {
   int ln_fuse = 1;            // bf16 decoder steps: LayerNorm computed inside the skinny GEMM's loader (gemm_sk ln_in)
   int fuse_first = 1;         // bf16: CRAFT conv1_1 fused into conv1_2's loader (conv3p FIRST)
   int enc_chunk = 0;          // crops per encoder group (0 = all crops at once)
+  int craft_products = 3;     // split-operand engines, CRAFT: 3 = activation pairs (~23.5 bits; the heat map stays at fp32 noise level), 4 = exact triples
   int bench_grid_boxes = 0;   // benchmark workload control (bench.py --boxes=grid40): the detector runs in full, then every page's boxes are replaced by a fixed 5 x 8 grid
   int split_planes = 1;       // split-operand engines: activations stay in planes between the layers (0: fp32 tensors + a split pass in front of every GEMM)
   int split_conv3p = 1;       // split-operand engines: 3x3 layers on the patch-stationary kernel (0: gemm2)
@@ -88,6 +90,7 @@ struct Tuning {
     else if (k == "ar_tail_step") ar_tail_step = value;
     else if (k == "split_gemm") split_gemm = value;
     else if (k == "bench_grid_boxes") bench_grid_boxes = value;
+    else if (k == "craft_products") craft_products = value == 4 ? 4 : 3;
     else if (k == "split_conv3p") split_conv3p = value;
     else if (k == "split_planes") split_planes = value;
     else if (k == "craft_group") craft_group = value < 1 ? 1 : (value > 32 ? 32 : value);
@@ -174,49 +177,6 @@ struct PinnedBuf {
   PinnedBuf& operator=(const PinnedBuf&) = delete;
 };
 
-struct HostTensor { std::vector<uint32_t> dims; std::vector<float> data; };
-
-struct WeightFile {
-  std::map<std::string, HostTensor> t;
-  explicit WeightFile(const std::string& path) {
-    std::ifstream f(path, std::ios::binary);
-    if (!f) throw std::runtime_error("cannot open weight file " + path);
-    std::vector<char> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-    if (buf.size() < 12 || memcmp(buf.data(), "TTRW0001", 8) != 0) throw std::runtime_error("not a .ttrw file: " + path);
-    size_t p = 8;
-    auto rd = [&](void* dst, size_t n) { if (p + n > buf.size()) throw std::runtime_error("truncated .ttrw: " + path); memcpy(dst, buf.data() + p, n); p += n; };
-    uint32_t n; rd(&n, 4);
-    struct Ent { std::string name; std::vector<uint32_t> dims; uint64_t off, nb; };
-    std::vector<Ent> ents(n);
-    for (auto& e : ents) {
-      uint16_t ln; rd(&ln, 2);
-      e.name.resize(ln); rd(&e.name[0], ln);
-      uint8_t dt, nd; rd(&dt, 1); rd(&nd, 1);
-      if (dt != 0) throw std::runtime_error("unsupported dtype in " + path);
-      e.dims.resize(nd); rd(e.dims.data(), 4 * nd);
-      rd(&e.off, 8); rd(&e.nb, 8);
-    }
-    uint64_t data0; rd(&data0, 8);
-    if (data0 > buf.size()) throw std::runtime_error("corrupt .ttrw (data offset): " + path);
-    const uint64_t room = buf.size() - data0;
-    for (auto& e : ents) {
-      uint64_t numel = 1;
-      for (uint32_t d : e.dims) { if (d && numel > (uint64_t)1 << 40) throw std::runtime_error("corrupt .ttrw (dims): " + path); numel *= d; }
-      if (e.nb % 4 != 0 || e.nb != 4 * numel) throw std::runtime_error("corrupt .ttrw (byte count of " + e.name + "): " + path);
-      if (e.off > room || e.nb > room - e.off) throw std::runtime_error("tensor out of range in " + path);   // overflow-safe
-      HostTensor ht; ht.dims = e.dims; ht.data.resize(e.nb / 4);
-      memcpy(ht.data.data(), buf.data() + data0 + e.off, e.nb);
-      t[e.name] = std::move(ht);
-    }
-  }
-  const HostTensor& get(const std::string& name, size_t numel) const {
-    auto it = t.find(name);
-    if (it == t.end()) throw std::runtime_error("weight tensor missing: " + name);
-    if (it->second.data.size() != numel) throw std::runtime_error("weight tensor has wrong size: " + name);
-    return it->second;
-  }
-};
-
 // A GEMM-shaped weight on the device: T [Cout_pad][K_pad] + f32 bias
 // mlp_fused.hip's weight operands are stored as the LDS images the kernel multiplies from (see the layout notes there)
 void pack_mlp_w1(const float* w1, uint16_t* out) {               // w1 [1536][384] -> [48 chunks][3 segments][32 rows][16 positions][8]
@@ -281,78 +241,7 @@ struct CclBatch {   // device workspaces of the CCL stage for a batch of equally
   }
 };
 
-// A few persistent host threads for the per-page host work (calipers, token decode): spawning threads per batch cost more
-// than the work itself.  run(n, f) calls f(0..n-1) across the workers and the caller; the first exception is rethrown.
-class HostPool {
- public:
-  explicit HostPool(int workers) {
-    for (int t = 0; t < workers; ++t) th_.emplace_back([this] { loop(); });
-  }
-  ~HostPool() {
-    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++gen_; }
-    cv_.notify_all();
-    for (auto& t : th_) t.join();
-  }
-  void run(int n, const std::function<void(int)>& f) {
-    if (n <= 0) return;
-    if (n == 1 || th_.empty()) { for (int i = 0; i < n; ++i) f(i); return; }
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      fn_ = &f; n_ = n; next_.store(0); pending_ = n; err_ = nullptr; ++gen_;
-    }
-    cv_.notify_all();
-    work();
-    std::unique_lock<std::mutex> lk(mu_);
-    done_.wait(lk, [this] { return pending_ == 0 && busy_ == 0; });
-    fn_ = nullptr;
-    if (err_) std::rethrow_exception(err_);
-  }
 
- private:
-  void work() {
-    int finished = 0;
-    std::exception_ptr err;
-    for (;;) {
-      const int i = next_.fetch_add(1);
-      if (i >= n_) break;
-      try { (*fn_)(i); } catch (...) { if (!err) err = std::current_exception(); }
-      ++finished;
-    }
-    if (finished || err) {
-      std::lock_guard<std::mutex> lk(mu_);
-      pending_ -= finished;
-      if (err && !err_) err_ = err;
-    }
-  }
-  void loop() {
-    unsigned long long seen = 0;
-    for (;;) {
-      {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return gen_ != seen; });
-        seen = gen_;
-        if (stop_) return;
-        if (!fn_) continue;
-        ++busy_;
-      }
-      work();
-      {
-        std::lock_guard<std::mutex> lk(mu_);
-        --busy_;
-        if (pending_ == 0 && busy_ == 0) done_.notify_all();
-      }
-    }
-  }
-  std::vector<std::thread> th_;
-  std::mutex mu_;
-  std::condition_variable cv_, done_;
-  const std::function<void(int)>* fn_ = nullptr;
-  std::atomic<int> next_{0};
-  int n_ = 0, pending_ = 0, busy_ = 0;
-  unsigned long long gen_ = 0;
-  bool stop_ = false;
-  std::exception_ptr err_;
-};
 
 
 #define TTR_NCCL_CHECK(expr)                                                                                          \
@@ -489,7 +378,7 @@ struct Engine {
     if (it == split_by_w.end() || !tn.split_gemm || p.relu0 || p.relu1 || p.ln_in || p.pre_wgt) return false;
     const Linear& L = *it->second;
     ConvParams q = p;
-    q.split = 1; q.wgt = L.ws.p; q.out_scale = L.inv_scale; q.out_planes = 0; q.store_policy = 0;
+    q.split = 4; q.wgt = L.ws.p; q.out_scale = L.inv_scale; q.out_planes = 0; q.store_policy = 0;
     split_in[0].ensure((size_t)p.M * p.C0 * 6);
     q.in0 = split_in[0].p;
     if (p.C1) { split_in[1].ensure((size_t)p.M * p.C1 * 6); q.in1 = split_in[1].p; }
@@ -872,7 +761,9 @@ struct Engine {
   // value); the convolutions' epilogues write them (bias, ReLU, ReLU copy, 2x2 max-pool fused), so no fp32 tensor and no separate
   // split pass exists up to the 32-channel head, which stays on the fp32 MFMA kernel (thin layers: 3 % of the FLOPs).
   void sconv(const char* name, const void* in0, int C0, const void* in1, int C1, int B, int H, int W, void* out, int act,
-             void* out_relu = nullptr, void* out_pool = nullptr, int pool_relu = 0, int out_planes = 1) {
+             void* out_relu = nullptr, void* out_pool = nullptr, int pool_relu = 0, int out_planes = -1) {
+    const int np = tn.craft_products == 4 ? 4 : 3;             // products per value: 3 = activation pairs (default), 4 = exact triples
+    if (out_planes < 0) out_planes = np - 1;
     const Linear& L = craft.at(name);
     ConvParams p{};
     p.in0 = in0; p.C0 = C0; p.in1 = in1; p.C1 = C1; p.B = B; p.H = H; p.W = W;
@@ -880,7 +771,7 @@ struct Engine {
     p.ks = (L.k == Ct) ? 1 : 3;
     if (L.k != p.ks * p.ks * Ct || !L.ws.p) throw std::runtime_error(std::string("split conv shape mismatch at ") + name);
     p.dil = std::string(name) == "slice5.1" ? 6 : 1;
-    p.wgt = L.ws.p; p.bias = L.b.as<float>(); p.split = 1; p.out_scale = L.inv_scale; p.out_planes = out_planes;
+    p.wgt = L.ws.p; p.bias = L.b.as<float>(); p.split = np; p.out_scale = L.inv_scale; p.out_planes = out_planes;
     p.out = out; p.out_ld = L.cout; p.out_relu = out_relu; p.out_pool = out_pool; p.pool_relu = pool_relu;
     p.Cout = L.cout; p.M = B * H * W; p.act = act;
     double flops = 0;
@@ -894,12 +785,13 @@ struct Engine {
     const size_t M0 = (size_t)B * H * W, M1 = M0 / 4, M2 = M1 / 4, M3 = M2 / 4, M4 = M3 / 4;
     const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8, H4 = H / 16, W4 = W / 16;
     size_t k = 0;
-    auto pbuf = [&](size_t rows, int C) -> void* { return ws(k++, rows * C * 6).p; };   // planes
+    const int npl = tn.craft_products == 4 ? 3 : 2;                                       // planes per value
+    auto pbuf = [&](size_t rows, int C) -> void* { return ws(k++, rows * C * 2 * npl).p; };   // planes
     auto fbuf = [&](size_t rows, int C) -> void* { return ws(k++, rows * C * 4).p; };   // fp32
     void* c11 = pbuf(M0, 64);
     {
       const Linear& L0 = craft.at("slice1.0");
-      timed(2.0 * M0 * 64 * 27, [&] { launch_conv1_split(d_canvas, L0.ws.p, L0.b.as<float>(), L0.inv_scale, c11, B, H, W, stream); });
+      timed(2.0 * M0 * 64 * 27, [&] { launch_conv1_split(d_canvas, L0.ws.p, L0.b.as<float>(), L0.inv_scale, c11, B, H, W, stream, npl); });
     }
     void* p1 = pbuf(M1, 64);   sconv("slice1.3", c11, 64, nullptr, 0, B, H, W, nullptr, kActRelu, nullptr, p1, 0);
     void* c21 = pbuf(M1, 128); sconv("slice1.7", p1, 64, nullptr, 0, B, H1, W1, c21, kActRelu);
@@ -915,18 +807,18 @@ struct Engine {
     void* p4 = pbuf(M4, 512);  sconv("slice4.30", c42r, 512, nullptr, 0, B, H3, W3, nullptr, kActRelu, nullptr, p4, 0);
     void* c51 = pbuf(M4, 512); sconv("slice4.34", p4, 512, nullptr, 0, B, H4, W4, c51, kActRelu);
     void* c52 = pbuf(M4, 512); sconv("slice4.37", c51, 512, nullptr, 0, B, H4, W4, c52, kActNone);          // relu5_3 skip
-    void* mp = pbuf(M4, 512);  prof_break(), launch_maxpool3x3s1_planes(c52, mp, B, H4, W4, 512, stream);
+    void* mp = pbuf(M4, 512);  prof_break(), launch_maxpool3x3s1_planes(c52, mp, B, H4, W4, 512, stream, npl);
     void* c6 = pbuf(M4, 1024); sconv("slice5.1", mp, 512, nullptr, 0, B, H4, W4, c6, kActNone);
     void* fc7 = pbuf(M4, 1024); sconv("slice5.2", c6, 1024, nullptr, 0, B, H4, W4, fc7, kActNone);
     void* u1a = pbuf(M4, 512); sconv("upconv1.0", fc7, 1024, c52, 512, B, H4, W4, u1a, kActRelu);
     void* u1b = pbuf(M4, 256); sconv("upconv1.3", u1a, 512, nullptr, 0, B, H4, W4, u1b, kActRelu);
-    void* up1 = pbuf(M3, 256); prof_break(), launch_upsample2x_planes(u1b, up1, B, H4, W4, 256, stream);
+    void* up1 = pbuf(M3, 256); prof_break(), launch_upsample2x_planes(u1b, up1, B, H4, W4, 256, stream, npl);
     void* u2a = pbuf(M3, 256); sconv("upconv2.0", up1, 256, c42, 512, B, H3, W3, u2a, kActRelu);
     void* u2b = pbuf(M3, 128); sconv("upconv2.3", u2a, 256, nullptr, 0, B, H3, W3, u2b, kActRelu);
-    void* up2 = pbuf(M2, 128); prof_break(), launch_upsample2x_planes(u2b, up2, B, H3, W3, 128, stream);
+    void* up2 = pbuf(M2, 128); prof_break(), launch_upsample2x_planes(u2b, up2, B, H3, W3, 128, stream, npl);
     void* u3a = pbuf(M2, 128); sconv("upconv3.0", up2, 128, c32, 256, B, H2, W2, u3a, kActRelu);
     void* u3b = pbuf(M2, 64);  sconv("upconv3.3", u3a, 128, nullptr, 0, B, H2, W2, u3b, kActRelu);
-    void* up3 = pbuf(M1, 64);  prof_break(), launch_upsample2x_planes(u3b, up3, B, H2, W2, 64, stream);
+    void* up3 = pbuf(M1, 64);  prof_break(), launch_upsample2x_planes(u3b, up3, B, H2, W2, 64, stream, npl);
     void* u4a = pbuf(M1, 64);  sconv("upconv4.0", up3, 64, c22, 128, B, H1, W1, u4a, kActRelu);
     void* u4b = fbuf(M1, 32);  sconv("upconv4.3", u4a, 64, nullptr, 0, B, H1, W1, u4b, kActRelu, nullptr, nullptr, 0, /*out_planes=*/0);
     // 32-channel head on the fp32 MFMA kernel
@@ -948,7 +840,7 @@ struct Engine {
     if (!L.ws.p) throw std::runtime_error("split GEMM: the layer has no weight planes");
     ConvParams p{};
     p.in0 = in_planes; p.C0 = L.k; p.B = 1; p.H = 1; p.W = M; p.ks = 1; p.dil = 1;
-    p.wgt = L.ws.p; p.bias = L.b.as<float>(); p.split = 1; p.out_scale = L.inv_scale; p.out_planes = out_planes;
+    p.wgt = L.ws.p; p.bias = L.b.as<float>(); p.split = 4; p.out_scale = L.inv_scale; p.out_planes = out_planes ? 3 : 0;
     p.out = out; p.out_ld = out_ld; p.out_f32 = out_f32; p.out_f32_ld = out_f32_ld; p.resid = resid; p.resid_ld = resid_ld;
     p.Cout = L.cout; p.M = M; p.act = act;
     if (const char* e = gemm2_check(p)) throw std::runtime_error(e);
@@ -1177,6 +1069,7 @@ struct Engine {
     // with the early exit, the steps from ar_tail_step on are ONE launch of the fused kernel in its tail form: when every crop
     // has emitted EOS by then (the usual case: words are short) it returns at once, instead of ~9 returning launches per step
     const int tail_at = (early && tn.ar_tail_step > 0 && tn.ar_tail_step < nsteps) ? tn.ar_tail_step : 26;
+    struct SkipGuard { Engine& E; ~SkipGuard() { E.cur_skip = nullptr; E.cur_skip_n = 0; } } skip_guard{*this};   // also when a launch throws mid-loop
     for (int i = 0; i < 26; ++i) {
       if (i == tail_at) {
         DecArParams q = dec_params();
@@ -1311,8 +1204,9 @@ struct Engine {
     // group g's components back (and runs its calipers) while the GPU is busy with group g + 1.
     int GP = tn.craft_group;
     if (prec == kSplit) {   // three f16 planes per value: the widest tensor (64 channels at full resolution) must stay inside the 2 GiB window
-      const size_t per_page = (size_t)H * W * 64 * 6;
+      const size_t per_page = (size_t)H * W * 64 * (tn.craft_products == 4 ? 6 : 4);
       GP = (int)std::max<size_t>(1, std::min<size_t>(GP, (((size_t)1 << 31) - 1) / per_page));
+      if (GP >= 8 && n % 8 == 0 && tn.craft_group >= 8) GP = 8;   // (even groups: 32 pages = 4 x 8 rather than 10 + 10 + 10 + 2)
     }
     B.group = GP;
     const int groups = (n + GP - 1) / GP;
@@ -2168,6 +2062,8 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "ws_lean") set_gemm_ws_lean(value);
   else if (k == "store_policy") set_store_policy(value);
   else if (k == "g2_x_ring3") set_gemm2_x_ring3(value);
+  else if (k == "g2_split_reuse") set_gemm2_split_reuse(value);
+  else if (k == "g2_split_cfg") set_gemm2_split_cfg(value);
   else if (k == "c3_xs1_max_cin") set_conv3p_single_stage_max_cin(value);
   else if (k == "c3_force_bn128") set_conv3p_force_bn128(value);
   else if (k == "c3_c64_waves") set_conv3p_c64_waves(value);
@@ -2187,13 +2083,15 @@ int ttr_set_tuning(const char* key, int value) {
 }
 // per engine (under the engine's lock: a batch in flight on another thread keeps the selection it started with)
 int ttr_engine_set_tuning(ttr_engine* e, const char* key, int value) {
+  TTR_GUARD_BEGIN
   if (!e) return -1;
   const std::string k = key ? key : "";
   {
     std::lock_guard<std::mutex> lk(e->e->mu);
     if (e->e->tn.set(k, value)) return 0;
   }
-  return ttr_set_tuning(key, value);
+  return ttr_set_tuning(key, value);   // not an engine key: the process-wide diagnostics setter (documented in tuatara_hip.h)
+  TTR_GUARD_END(-1)
 }
 
 int ttr_bench_conv(ttr_engine* e, int B, int H, int W, int C0, int C1, int ks, int dil, int Cout, int act, int f32_resid, int iters, float* avg_us) {
@@ -2271,19 +2169,25 @@ int ttr_dev_upload(void* dst, const void* src, size_t bytes) { return hipMemcpy(
 int ttr_dev_download(void* dst, const void* src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
 int ttr_dev_sync(ttr_engine* e) { return hipStreamSynchronize(e->e->stream) == hipSuccess ? 0 : -1; }
 int ttr_set_profiling(ttr_engine* e, int on) {
+  TTR_GUARD_BEGIN
+  if (!e) throw std::runtime_error("null argument");
   Engine& E = *e->e;
   EngineScope lk(E);
   E.profiling = on < 0 ? 0 : (on > 2 ? 2 : on);
   E.prof_recs.clear();
   for (int i = 0; i < 3; ++i) { E.prof_ms[i] = 0; E.prof_flops[i] = 0; E.prof_launches[i] = 0; }
   return 0;
+  TTR_GUARD_END(-1)
 }
 int ttr_get_profile(ttr_engine* e, double ms[3], double flops[3], long long launches[3]) {
+  TTR_GUARD_BEGIN
+  if (!e) throw std::runtime_error("null argument");
   Engine& E = *e->e;
   EngineScope lk(E);
   E.prof_collect();          // records whose events completed since the last batch was finished
   for (int i = 0; i < 3; ++i) { ms[i] = E.prof_ms[i]; flops[i] = E.prof_flops[i]; launches[i] = E.prof_launches[i]; }
   return 0;
+  TTR_GUARD_END(-1)
 }
 int ttr_last_stage_ms(ttr_engine* e, float ms[4]) { memcpy(ms, e->e->stage_ms, sizeof(float) * 4); return 0; }
 

@@ -41,20 +41,6 @@ __device__ __forceinline__ void st_out(bf16* dst, bf16x8 v, int policy) {
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
-// split-operand mode: 8 consecutive channels of pixel m -> fp32 [m][ld] or the three f16 planes [m][3 ld]
-__device__ __forceinline__ void st_split(void* out, int64_t m, int ld, int n, const float (&v)[8], int planes) {
-  if (planes) {
-    f16x8 a, b, c;
-    split3_x8(v, a, b, c);
-    f16* o = reinterpret_cast<f16*>(out) + m * (3 * (int64_t)ld) + n;
-    *reinterpret_cast<f16x8*>(o) = a; *reinterpret_cast<f16x8*>(o + ld) = b; *reinterpret_cast<f16x8*>(o + 2 * ld) = c;
-  } else {
-    float* o = reinterpret_cast<float*>(out) + m * ld + n;
-    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-    *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-  }
-}
-
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
@@ -80,9 +66,12 @@ struct G2Cfg {
 // rows [w0 | w0/2^11 | w1] of 3 K - and the K loop runs over K' = 4 K (quarter q: activation plane {0,1,2,0}, weight plane {0,1,1,2}); the
 // accumulator times p.out_scale is the fp32 product.  Every output (out, out_relu, out_pool, out_f32) is fp32 then, or, with
 // p.out_planes, out / out_relu / out_pool are written as the three planes of the value (row stride 3 out_ld halves).
-template <int BM, int BN, int WM, int WN, int MINB, int XST, bool SP>
+// NP = products per value: 0 = the bf16 kernel, 4 = exact activation triples (planes x0 | x1 | x2), 3 = activation pairs (x0 | x1).
+template <int BM, int BN, int WM, int WN, int MINB, int XST, int NP>
 __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p) {
   using C = G2Cfg<BM, BN, WM, WN, XST>;
+  constexpr bool SP = NP != 0;
+  static_assert(NP == 0 || NP == 4 || (NP == 3 && XST == 3), "pairs run in the reuse-order loop only");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -92,7 +81,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
   // GELU epilogue: Phi(x) by linear interpolation in an 8 KiB table kept in LDS behind the operand stages (the
   // erf polynomial + exp + rcp form made the epilogue, not the MFMAs, the longest part of the K = 384 PARSeq GEMMs)
   float2* const glut = reinterpret_cast<float2*>(smem + C::LDS);
-  if (p.act == kActGelu) {
+  if (!SP && p.act == kActGelu) {
     for (int i = tid; i < 512; i += C::NT) reinterpret_cast<uint4*>(glut)[i] = reinterpret_cast<const uint4*>(p.gelu_lut)[i];
   }   // visible after the first K-step barrier
 
@@ -114,8 +103,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
 
   const int Ctot = p.C0 + p.C1;
   const int K = p.ks * p.ks * Ctot;
-  constexpr int PL = SP ? 3 : 1;                 // activation planes per pixel
-  const int KP = SP ? 4 * K : K;                 // K as the loop sees it
+  constexpr int PL = NP == 4 ? 3 : NP == 3 ? 2 : 1;   // activation planes per pixel
+  const int KP = NP == 4 ? 4 * K : K;            // K as the plane-major loop sees it
   const int nk = KP >> 6;
   const int HW = p.H * p.W;
 
@@ -226,11 +215,58 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
   }
   const int fg = lane >> 4, fr = lane & 15;
 
+  // ---- SP with a three-slot X ring: the K loop in REUSE order.  Per 64-wide k0 the four products run as
+  //   ph0 (X0, W0)   ph1 (X0, W1)   ph2 (X1, W0b)   ph3 (X2, W0b)
+  // so X0 and W0b are staged once and multiplied twice: six tile loads per k0 instead of the eight of the plane-major order
+  // (the kernel is bound by the L2 -> LDS fill rate).  X slot = activation plane (0, 1, 2); the W ring's two slots alternate
+  // with every load (W0, W1, W0b, W0', ...).  A tile is requested as soon as its slot is free:
+  //   ph0: W1(k0), X2(k0)   ph1: W0b(k0)   ph2: W0(k0+1), X0(k0+1)   ph3: X1(k0+1)       (prologue: X0, W0, X1 of the first k0)
+  // every load has at least one phase of MFMA work (256 x 128 tile: ~1 k cycles) in front of its first use, the X tiles two or three.
+  constexpr bool RU = SP && XST == 3;            // (NP = 3: three phases per k0 - (X0, W0) (X0, W1) (X1, W0b) - on rotating X slots)
+  const int nk0 = K >> 6;
+  int rx_idx = idx, rx_k0 = 0, rx_pl = 0, rx_slot = 0; bool rx_ok = true;      // X stream position: (tile, k0, plane); slot = plane for triples, rotating for pairs
+  int rw_idx = idx, rw_k0 = 0, rw_j = 0, rw_slot = 0; bool rw_ok = true;   // W stream: j = 0, 1, 2 -> weight plane 0 (w0), 2 (w1), 1 (w0b)
+  auto ru_issue_x = [&]() {
+    unsigned char* sb = xring + (NP == 3 ? rx_slot : rx_pl) * C::XBYTES;
+    if (NP == 3) rx_slot = rx_slot == 2 ? 0 : rx_slot + 1;
+    const int k0 = rx_k0 << 6, tap = k0 / Ctot, cc = k0 - tap * Ctot;
+    const bool s1 = cc >= p.C0;
+    int dpix = 0;
+    if (p.ks == 3) { const int ky = tap / 3, kx = tap - ky * 3; dpix = ((ky - 1) * p.W + (kx - 1)) * p.dil; }
+    const int Cs = s1 ? p.C1 : p.C0;
+    const unsigned soff = (unsigned)((dpix * Cs * PL + rx_pl * Cs + (s1 ? cc - p.C0 : cc)) * 2);
+    const unsigned bit = 1u << tap;
+#pragma unroll
+    for (int i = 0; i < C::XPW; ++i) {
+      const unsigned vo = (xmask[i] & bit) ? (s1 ? xb1[i] : xb0[i]) + soff : OOB;
+      lds_ptr dst = (lds_ptr)(sb + (i * C::NW + wave) * 1024);
+      if (s1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, vo, 0, 0, 0);
+      else    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, vo, 0, 0, 0);
+    }
+    if (++rx_pl == PL) { rx_pl = 0; if (++rx_k0 == nk0) { rx_k0 = 0; rx_idx += J; rx_ok = rx_idx < xcd_count; if (rx_ok) setup_x(rx_idx); } }
+  };
+  auto ru_issue_w = [&]() {
+    unsigned char* sb = wring + rw_slot * C::WBYTES;
+    const int wpl = rw_j == 0 ? 0 : rw_j == 1 ? 2 : 1;
+    const unsigned koff = (unsigned)((wpl * K + (rw_k0 << 6)) * 2);
+#pragma unroll
+    for (int j = 0; j < C::WPW; ++j) {
+      const unsigned vo = wb[j] == OOB ? OOB : wb[j] + koff;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sb + (j * C::NW + wave) * 1024), 16, vo, 0, 0, 0);
+    }
+    rw_slot ^= 1;
+    if (++rw_j == 3) { rw_j = 0; if (++rw_k0 == nk0) { rw_k0 = 0; rw_idx += J; rw_ok = rw_idx < xcd_count; if (rw_ok) setup_w(rw_idx); } }
+  };
+
   setup_x(idx); setup_w(idx);
-  issue_x(); issue_w();                                  // X(0), W(0)
   bool x_ahead = false;                                  // an X stage younger than the step about to run is in flight
-  if (XST == 3 && x_ok) { issue_x(); x_ahead = true; }   // X(1)
   int xr = 0, wr = 0;                                    // ring slots the MFMAs read next
+  if constexpr (RU) {
+    ru_issue_x(); ru_issue_w(); ru_issue_x();            // X0, W0, X1 of the first k0
+  } else {
+    issue_x(); issue_w();                                // X(0), W(0)
+    if (XST == 3 && x_ok) { issue_x(); x_ahead = true; } // X(1)
+  }
   while (true) {
     f32x4 acc[C::NJ][C::MI];
 #pragma unroll
@@ -239,6 +275,67 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
       for (int i = 0; i < C::MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ctile = xcd_first + idx;
     const int m0c = (ctile / tilesN) * BM, n0c = (ctile % tilesN) * BN;
+    using frag_t = typename std::conditional<SP, f16x8, bf16x8>::type;
+    if constexpr (RU) {
+      // one phase: wait until at most `pend` of this wave's loads are outstanding, barrier, fragments of (X slot xs, W slot ws), the
+      // phase's loads, MFMAs
+      auto phase = [&](int xs, int ws, auto pend, bool iss_w, bool iss_x, bool strict = false) -> bool {
+        constexpr int PEND = decltype(pend)::value;
+        if (strict) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the younger load the count allows for was not issued)
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PEND) : "memory");
+        __builtin_amdgcn_s_barrier();
+        const int xo = xs * C::XBYTES, wo = ws * C::WBYTES;
+        frag_t fx[2][C::MI], fw[2][C::NJ];
+#pragma unroll
+        for (int j = 0; j < C::NJ; ++j) fw[0][j] = *reinterpret_cast<const frag_t*>(wfrag[0] + wo + j * 2048);
+#pragma unroll
+        for (int i = 0; i < C::MI; ++i) fx[0][i] = *reinterpret_cast<const frag_t*>(xfrag[0] + xo + i * 2048);
+        if (iss_w && rw_ok) ru_issue_w();
+        const bool x_issued = iss_x && rx_ok;
+        if (x_issued) ru_issue_x();
+#pragma unroll
+        for (int j = 0; j < C::NJ; ++j) fw[1][j] = *reinterpret_cast<const frag_t*>(wfrag[1] + wo + j * 2048);
+#pragma unroll
+        for (int i = 0; i < C::MI; ++i) fx[1][i] = *reinterpret_cast<const frag_t*>(xfrag[1] + xo + i * 2048);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+            for (int j = 0; j < C::NJ; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[kk][j], fx[kk][i], acc[j][i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        return x_issued;
+      };
+      // Outstanding loads of this wave, oldest first, at the START of each phase (a stream that has run out issues nothing, which only
+      // makes the counts smaller than assumed - a stricter wait is always safe):
+      //   ph0: X0 W0 X1          need X0, W0  -> <= XPW left
+      //   ph1: X1 W1 X2          need W1      -> <= XPW left          (ph0 issues W1 before X2)
+      //   ph2: X2 W0b            need X1, W0b -> 0 left
+      //   ph3: W0' X0'           need X2      -> <= WPW + XPW left    (X2 was complete at ph2's wait)
+      if constexpr (NP == 4) {
+      for (int k0 = 0; k0 < nk0; ++k0) {
+        phase(0, wr, std::integral_constant<int, C::XPW>{}, true, true);          // (X0, W0); requests W1, X2
+        phase(0, wr ^ 1, std::integral_constant<int, C::XPW>{}, true, false);     // (X0, W1); requests W0b
+        phase(1, wr, std::integral_constant<int, 0>{}, true, true);               // (X1, W0b); requests W0', X0'
+        phase(2, wr, std::integral_constant<int, C::XPW + C::WPW>{}, false, true);   // (X2, W0b); requests X1'
+        wr ^= 1;
+      }
+      } else {
+      // pairs: X0(k0) sits in slot xr, X1(k0) in xr + 1, X0(k0+1) in xr + 2 (mod 3).  Outstanding loads at the start of a phase:
+      //   ph0: X0 .. W0 X1      need X0, W0  -> <= XPW left
+      //   ph1: X1 W1 X0'        need W1      -> <= XPW left          (ph0 issues W1 before X0')
+      //   ph2: X0' W0b          need X1, W0b -> 0 left
+      for (int k0 = 0; k0 < nk0; ++k0) {
+        const int x1s = xr == 2 ? 0 : xr + 1;
+        const bool xn = phase(xr, wr, std::integral_constant<int, C::XPW>{}, true, true);   // (X0, W0); requests W1, X0'
+        phase(xr, wr ^ 1, std::integral_constant<int, C::XPW>{}, true, false, !xn);         // (X0, W1); requests W0b   (at the very end of the X stream W1 is the youngest load)
+        phase(x1s, wr, std::integral_constant<int, 0>{}, true, true);             // (X1, W0b); requests W0', X1'
+        wr ^= 1;
+        xr = x1s == 2 ? 0 : x1s + 1;
+      }
+      }
+    } else {
     for (int kt = 0; kt < nk; ++kt) {
       const int xo = xr * C::XBYTES, wo = wr * C::WBYTES;
       // my pieces of this K step have landed (loads retire in order: only the younger X stage may still be in flight)
@@ -247,7 +344,6 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
       __builtin_amdgcn_s_barrier();                      // everyone's have; everyone is done reading the slots refilled below
       // all fragment reads of this K step are issued up front (their latency hides behind the
       // loader's address arithmetic), then the MFMAs run back to back
-      using frag_t = typename std::conditional<SP, f16x8, bf16x8>::type;
       frag_t fx[2][C::MI], fw[2][C::NJ];
 #pragma unroll
       for (int j = 0; j < C::NJ; ++j) fw[0][j] = *reinterpret_cast<const frag_t*>(wfrag[0] + wo + j * 2048);
@@ -273,6 +369,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
       __builtin_amdgcn_sched_barrier(0);
       xr = xr + 1 == XST ? 0 : xr + 1;
       wr ^= 1;
+    }
     }
     idx += J;
     const bool has_next = idx < xcd_count;
@@ -314,12 +411,12 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
           for (int e = 0; e < 8; ++e) v[e] = SP ? gelu_exact(v[e]) : gelu_lut(v[e], glut);   // (fp32-equivalent mode: erf, as the f32 kernels)
         }
         if constexpr (SP) {
-          if (p.out && valid) st_split(p.out, (int64_t)m, p.out_ld, n, v, p.out_planes);
+          if (p.out && valid) st_split_n(p.out, (int64_t)m, p.out_ld, n, v, p.out_planes);
           if (p.out_relu && valid) {
             float w[8];
   #pragma unroll
             for (int e = 0; e < 8; ++e) w[e] = fmaxf(v[e], 0.f);
-            st_split(p.out_relu, (int64_t)m, p.out_ld, n, w, p.out_planes);
+            st_split_n(p.out_relu, (int64_t)m, p.out_ld, n, w, p.out_planes);
           }
         } else {
         if (p.out && valid) {
@@ -350,7 +447,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
             w[e] = x;
           }
           if constexpr (SP) {
-            if (valid && (fr & 3) == 0) st_split(p.out_pool, (int64_t)(grow >> 2), p.out_ld, n, w, p.out_planes);
+            if (valid && (fr & 3) == 0) st_split_n(p.out_pool, (int64_t)(grow >> 2), p.out_ld, n, w, p.out_planes);
           } else {
             bf16x8 o;
   #pragma unroll
@@ -366,18 +463,19 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
 
 static int num_cus() { return device_cu_count(256); }   // (per device: a process may drive several)
 
-template <int BM, int BN, int WM, int WN, int MINB, int XST, bool SP = false>
+template <int BM, int BN, int WM, int WN, int MINB, int XST, int NP = 0>
 static void launch_g2(const ConvParams& p, hipStream_t s) {
+  constexpr bool SP = NP != 0;
   using C = G2Cfg<BM, BN, WM, WN, XST>;
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
   static PerDeviceOnce once;
-  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WM, WN, MINB, XST, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + (XST == 2 ? 8192 : 0))); });
-  const size_t lds = C::LDS + (p.act == kActGelu ? 8192 : 0);
+  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WM, WN, MINB, XST, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + (XST == 2 ? 8192 : 0))); });
+  const size_t lds = C::LDS + (p.act == kActGelu && !SP ? 8192 : 0);
   // persistent grid: as many workgroups as fit the chip at once (a multiple of 8: one share per XCD), never more than tiles
   const int per_cu = std::max(1, std::min((int)(160 * 1024 / lds), 2048 / C::NT));
   const int cap = num_cus() * per_cu / 8 * 8;
   const int grid = std::min((tilesM * tilesN + 7) / 8 * 8, std::max(cap, 8));
-  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM, WN, MINB, XST, SP>), dim3(grid), dim3(C::NT), lds, s, p);
+  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM, WN, MINB, XST, NP>), dim3(grid), dim3(C::NT), lds, s, p);
 }
 
 // Phi table of the GELU epilogue, one per device, built on first use (host erf in double)
@@ -405,10 +503,16 @@ const void* gelu_lut_for_current_device() {
 
 static int g_x_ring3 = 1;
 void set_gemm2_x_ring3(int v) { g_x_ring3 = v; }
+static int g_split_cfg = 0;     // split mode: force a tile configuration (0 = automatic)
+void set_gemm2_split_cfg(int v) { g_split_cfg = v; }
+static int g_split_reuse = 1;   // split mode: 1 = reuse-order K loop (X0 and W0b staged once per k0), 0 = plane-major order with a two-slot X ring
+void set_gemm2_split_reuse(int v) { g_split_reuse = v; }
 
 const char* gemm2_check(const ConvParams& p) {
   const int Ctot = p.C0 + p.C1;
-  const int es_in = p.split ? 6 : 2;                                  // bytes per activation element (three f16 planes when split)
+  const int es_in = p.split == 4 ? 6 : p.split == 3 ? 4 : 2;          // bytes per activation element (three / two f16 planes when split)
+  if (p.split && p.split != 3 && p.split != 4) return "gemm2: split must be 3 (pairs) or 4 (triples)";
+  if (p.split && p.out_planes != 0 && p.out_planes != 2 && p.out_planes != 3) return "gemm2: out_planes must be 0, 2 or 3";
   const int es_out = p.split ? (p.out_planes ? 2 : 4) : 2;            // bytes per element of out / out_relu / out_pool (per plane)
   const int ovec = 16 / es_out;                                        // elements per 16-byte store
   if (p.ks != 1 && p.ks != 3) return "gemm2: ks must be 1 or 3";
@@ -435,6 +539,13 @@ void launch_gemm2(const ConvParams& p_in, int cfg, hipStream_t s) {
   if (const char* e = gemm2_check(p_in)) throw std::runtime_error(e);
   ConvParams p = p_in;
   p.gelu_lut = p.act == kActGelu ? gelu_lut_for_current_device() : nullptr;
+  if (cfg == 0 && p.split && g_split_cfg) cfg = g_split_cfg;
+  if (cfg == 0 && p.split && p.Cout > 64) {
+    // split mode (reuse-order K loop): 256 x 128 tiles, one workgroup per CU - the 256 x 256 tile with its 160 KB of LDS loses to it on
+    // every shape measured (fc1 1.79 vs ~1.0 ms); small problems keep the 128-wide tiles so that the chip fills
+    const int64_t t2 = (int64_t)((p.M + 255) / 256) * ((p.Cout + 127) / 128);
+    cfg = t2 >= 2 * num_cus() ? 2 : 3;
+  }
   if (cfg == 0) {   // measured on MI355X (tools/gemm_sweep.py, profiles/r01_gemm_sweep.txt)
     if (p.Cout <= 64) cfg = 5;
     else {
@@ -451,14 +562,26 @@ void launch_gemm2(const ConvParams& p_in, int cfg, hipStream_t s) {
   // X ring depth: 3 (activation tiles two K steps ahead) wherever the LDS budget keeps the configuration's workgroups-per-CU;
   // the GELU table (8 KiB) pushes the 256x256 and 128x128 tiles back to 2
   const bool deep = g_x_ring3 && p.act != kActGelu;
-  if (p.split) {
+  if (p.split) {   // three-slot X ring everywhere (the GELU epilogue of this mode uses erf: no table in LDS): the reuse-order K loop
+    const bool ru = g_split_reuse != 0 || p.split == 3;
+    if (p.split == 3) {
+      switch (cfg) {
+        case 1: return launch_g2<256, 256, 2, 4, 1, 3, 3>(p, s);
+        case 2: return launch_g2<256, 128, 4, 2, 1, 3, 3>(p, s);
+        case 3: return launch_g2<128, 128, 2, 2, 2, 3, 3>(p, s);
+        case 4: return launch_g2<256, 64, 4, 1, 1, 3, 3>(p, s);
+        case 5: return launch_g2<128, 64, 2, 2, 2, 3, 3>(p, s);
+        case 6: return launch_g2<128, 256, 2, 4, 1, 3, 3>(p, s);
+        default: throw std::runtime_error("gemm2: unknown configuration");
+      }
+    }
     switch (cfg) {
-      case 1: return deep ? launch_g2<256, 256, 2, 4, 1, 3, true>(p, s) : launch_g2<256, 256, 2, 4, 1, 2, true>(p, s);
-      case 2: return deep ? launch_g2<256, 128, 4, 2, 1, 3, true>(p, s) : launch_g2<256, 128, 4, 2, 1, 2, true>(p, s);
-      case 3: return deep ? launch_g2<128, 128, 2, 2, 2, 3, true>(p, s) : launch_g2<128, 128, 2, 2, 2, 2, true>(p, s);
-      case 4: return launch_g2<256, 64, 4, 1, 2, 2, true>(p, s);
-      case 5: return launch_g2<128, 64, 2, 2, 2, 2, true>(p, s);
-      case 6: return deep ? launch_g2<128, 256, 2, 4, 1, 3, true>(p, s) : launch_g2<128, 256, 2, 4, 1, 2, true>(p, s);
+      case 1: return ru ? launch_g2<256, 256, 2, 4, 1, 3, 4>(p, s) : launch_g2<256, 256, 2, 4, 1, 2, 4>(p, s);
+      case 2: return ru ? launch_g2<256, 128, 4, 2, 1, 3, 4>(p, s) : launch_g2<256, 128, 4, 2, 1, 2, 4>(p, s);
+      case 3: return ru ? launch_g2<128, 128, 2, 2, 2, 3, 4>(p, s) : launch_g2<128, 128, 2, 2, 2, 2, 4>(p, s);
+      case 4: return ru ? launch_g2<256, 64, 4, 1, 1, 3, 4>(p, s) : launch_g2<256, 64, 4, 1, 2, 2, 4>(p, s);
+      case 5: return ru ? launch_g2<128, 64, 2, 2, 2, 3, 4>(p, s) : launch_g2<128, 64, 2, 2, 2, 2, 4>(p, s);
+      case 6: return ru ? launch_g2<128, 256, 2, 4, 1, 3, 4>(p, s) : launch_g2<128, 256, 2, 4, 1, 2, 4>(p, s);
       default: throw std::runtime_error("gemm2: unknown configuration");
     }
   }

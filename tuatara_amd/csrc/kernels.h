@@ -16,6 +16,8 @@ int gemm_config();
 // ---- gemm2.hip (bf16, LDS-DMA staged)
 const char* gemm2_check(const ConvParams& p);   // nullptr when gemm2 can run the problem
 void launch_gemm2(const ConvParams& p, int cfg, hipStream_t s);
+void set_gemm2_split_cfg(int v);     // split mode: force gemm2 tile configuration 1..6 (0 = automatic)
+void set_gemm2_split_reuse(int v);   // split mode: 1 (default) reuse-order K loop, 0 plane-major order (A/B)
 void set_gemm2_x_ring3(int v);   // 1 (default): activation tiles two K steps ahead where LDS allows; 0: one step (measurement)
 // device table float2[1024] {Phi(x_i), Phi(x_i + 1/64) - Phi(x_i)}, x_i = -8 + i/64, of the GELU epilogues (built on first use)
 const void* gelu_lut_for_current_device();
@@ -68,16 +70,16 @@ void launch_fill_random(Precision prec, void* p, size_t n, unsigned seed, float 
 
 // ---- split_ops.hip (split-operand mode, split.h)
 // fp32 [M][C] (row stride ld) -> f16 planes [M][3 C], optional ReLU first
-void launch_split_planes(const float* in, int ld, void* out, int64_t M, int C, int relu, hipStream_t s);
+void launch_split_planes(const float* in, int ld, void* out, int64_t M, int C, int relu, hipStream_t s, int planes = 3);
 // planes [B][H][W][3 C] in and out: CRAFT's 3x3 / stride-1 max-pool and its bilinear x2 upsampling (bit-identical to the fp32 kernels)
-void launch_maxpool3x3s1_planes(const void* in, void* out, int B, int H, int W, int C, hipStream_t s);
-void launch_upsample2x_planes(const void* in, void* out, int B, int H, int W, int C, hipStream_t s);
+void launch_maxpool3x3s1_planes(const void* in, void* out, int B, int H, int W, int C, hipStream_t s, int planes = 3);
+void launch_upsample2x_planes(const void* in, void* out, int B, int H, int W, int C, hipStream_t s, int planes = 3);
 // LayerNorm over 384 columns of fp32 rows (stride in_ld) -> planes [M][3 * 384]
 void launch_layernorm_planes(const float* in, int in_ld, const float* gamma, const float* beta, float eps, void* out, int M, hipStream_t s);
 // attn_split.hip: ViT encoder self-attention, qkv planes [N*128][3][1152] -> planes [N*128][3][384]
 void launch_attn_enc_split(const void* qkv_planes, void* out_planes, int N, hipStream_t s);
 // CRAFT's conv1_1 + bias + ReLU from the u8 canvas into planes [M][3 * 64]; wgt_planes f16 [64][3][32] (k = (ky*3+kx)*3+c, 27 used)
-void launch_conv1_split(const uint8_t* canvas, const void* wgt_planes, const float* bias, float out_scale, void* out, int B, int H, int W, hipStream_t s);
+void launch_conv1_split(const uint8_t* canvas, const void* wgt_planes, const float* bias, float out_scale, void* out, int B, int H, int W, hipStream_t s, int planes = 3);
 
 // ---- craft_ops.hip
 // OpenCV-style 8-bit INTER_LINEAR resize of src[sh,sw,3] to [th,tw], zero pad to [H,W], optional channel swap.

@@ -27,7 +27,7 @@ typedef _Float16 f16;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
-// two values -> their three planes (packed pairs)
+// ---- the exact TRIPLE: two values -> their three planes (packed pairs)
 __device__ __forceinline__ void split3_pair(float a, float b, f16x2& p0, f16x2& p1, f16x2& p2) {
   p0 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
   const float ra = fmaf((float)p0[0], -2048.f, a * 2048.f), rb = fmaf((float)p0[1], -2048.f, b * 2048.f);   // exact
@@ -35,7 +35,6 @@ __device__ __forceinline__ void split3_pair(float a, float b, f16x2& p0, f16x2& 
   const float sa = ra - (float)p1[0], sb = rb - (float)p1[1];                                                // exact: the last <= 2 bits
   p2 = f16x2{(f16)sa, (f16)sb};
 }
-
 // eight values -> three 16-byte plane vectors
 __device__ __forceinline__ void split3_x8(const float (&v)[8], f16x8& o0, f16x8& o1, f16x8& o2) {
 #pragma unroll
@@ -45,10 +44,48 @@ __device__ __forceinline__ void split3_x8(const float (&v)[8], f16x8& o0, f16x8&
     o0[e] = a[0]; o0[e + 1] = a[1]; o1[e] = b[0]; o1[e + 1] = b[1]; o2[e] = c[0]; o2[e + 1] = c[1];
   }
 }
-
 __device__ __forceinline__ float join3(f16 a, f16 b, f16 c) { return (float)a + ((float)b + (float)c) * (1.f / 2048.f); }   // (every step exact)
 
-// K quarter q of the four products -> activation plane / weight plane
+// ---- the PAIR (x0, x1), for layers whose result tolerates ~23.5-bit activations (CRAFT: its heat map stays at fp32 noise level
+// with it): x0 = rn_f16(x), x1 = rn_f16((x - x0) 2^11) - round to nearest both times (unbiased; 3 of 4 values are exact,
+// the rest off by one fp32 ulp), |x| clamped to the f16 range first.  THREE MFMAs per product: x0 w0 + x0 w1 + x1 w0b.
+__device__ __forceinline__ void split2_pair(float a, float b, f16x2& p0, f16x2& p1) {
+  a = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f); b = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
+  p0 = f16x2{(f16)a, (f16)b};
+  const float ra = fmaf((float)p0[0], -2048.f, a * 2048.f), rb = fmaf((float)p0[1], -2048.f, b * 2048.f);   // exact
+  p1 = f16x2{(f16)ra, (f16)rb};
+}
+__device__ __forceinline__ void split2_x8(const float (&v)[8], f16x8& o0, f16x8& o1) {
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    f16x2 a, b;
+    split2_pair(v[e], v[e + 1], a, b);
+    o0[e] = a[0]; o0[e + 1] = a[1]; o1[e] = b[0]; o1[e + 1] = b[1];
+  }
+}
+__device__ __forceinline__ float join2(f16 a, f16 b) { return (float)a + (float)b * (1.f / 2048.f); }
+
+// 8 consecutive channels n.. of pixel m -> a tensor of `planes` f16 planes (row = planes * ld halves: 3 = triple, 2 = pair), or plain
+// fp32 [m][ld] when planes == 0
+__device__ __forceinline__ void st_split_n(void* out, int64_t m, int ld, int n, const float (&v)[8], int planes) {
+  if (planes == 3) {
+    f16x8 a, b, c;
+    split3_x8(v, a, b, c);
+    f16* o = reinterpret_cast<f16*>(out) + m * (3 * (int64_t)ld) + n;
+    *reinterpret_cast<f16x8*>(o) = a; *reinterpret_cast<f16x8*>(o + ld) = b; *reinterpret_cast<f16x8*>(o + 2 * ld) = c;
+  } else if (planes == 2) {
+    f16x8 a, b;
+    split2_x8(v, a, b);
+    f16* o = reinterpret_cast<f16*>(out) + m * (2 * (int64_t)ld) + n;
+    *reinterpret_cast<f16x8*>(o) = a; *reinterpret_cast<f16x8*>(o + ld) = b;
+  } else {
+    float* o = reinterpret_cast<float*>(out) + m * ld + n;
+    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+
+// K quarter q of the four products (triple) -> activation plane / weight plane; the pair form uses quarters 0, 3, 1
 __host__ __device__ __forceinline__ constexpr int split_xplane(int q) { return q == 3 ? 0 : q; }
 __host__ __device__ __forceinline__ constexpr int split_wplane(int q) { return q == 0 ? 0 : q == 3 ? 2 : 1; }
 

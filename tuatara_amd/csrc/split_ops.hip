@@ -10,6 +10,7 @@
 
 namespace ttr {
 
+template <int NPL>
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ in, int ld, f16* __restrict__ out, int64_t M, int C, int relu) {
   const int cv = C >> 3;                                   // 8-channel groups per row
   const int64_t total = M * cv;
@@ -23,19 +24,17 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
     }
-    f16x8 p0, p1, p2;
-    split3_x8(v, p0, p1, p2);
-    f16* dst = out + m * (3 * (int64_t)C) + c;
-    *reinterpret_cast<f16x8*>(dst) = p0; *reinterpret_cast<f16x8*>(dst + C) = p1; *reinterpret_cast<f16x8*>(dst + 2 * C) = p2;
+    st_split_n(out, m, C, c, v, NPL);
   }
 }
 
-void launch_split_planes(const float* in, int ld, void* out, int64_t M, int C, int relu, hipStream_t s) {
+void launch_split_planes(const float* in, int ld, void* out, int64_t M, int C, int relu, hipStream_t s, int planes) {
   if (M <= 0) return;
   if (C % 8 || ld % 4 || ((uintptr_t)in & 15) || ((uintptr_t)out & 15)) throw std::runtime_error("split_planes: C must be a multiple of 8 and the tensors 16-byte aligned");
   const int64_t total = M * (C >> 3);
   const int grid = (int)std::min<int64_t>((total + 255) / 256, 256 * 32);
-  hipLaunchKernelGGL(split_planes_kernel, dim3(grid), dim3(256), 0, s, in, ld, (f16*)out, M, C, relu);
+  if (planes == 2) hipLaunchKernelGGL(split_planes_kernel<2>, dim3(grid), dim3(256), 0, s, in, ld, (f16*)out, M, C, relu);
+  else hipLaunchKernelGGL(split_planes_kernel<3>, dim3(grid), dim3(256), 0, s, in, ld, (f16*)out, M, C, relu);
 }
 
 }  // namespace ttr
@@ -48,19 +47,32 @@ namespace ttr {
 namespace {
 
 struct V8 { float v[8]; };
-__device__ __forceinline__ V8 ld_planes(const f16* p, int C) {   // p -> plane 0 of 8 channels of a pixel
-  const f16x8 a = *reinterpret_cast<const f16x8*>(p), b = *reinterpret_cast<const f16x8*>(p + C), c = *reinterpret_cast<const f16x8*>(p + 2 * C);
+template <int NPL> __device__ __forceinline__ V8 ld_planes(const f16* p, int C) {   // p -> plane 0 of 8 channels of a pixel
+  const f16x8 a = *reinterpret_cast<const f16x8*>(p), b = *reinterpret_cast<const f16x8*>(p + C);
   V8 r;
+  if constexpr (NPL == 3) {
+    const f16x8 c = *reinterpret_cast<const f16x8*>(p + 2 * C);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) r.v[e] = join3(a[e], b[e], c[e]);
+    for (int e = 0; e < 8; ++e) r.v[e] = join3(a[e], b[e], c[e]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r.v[e] = join2(a[e], b[e]);
+  }
   return r;
 }
-__device__ __forceinline__ void st_planes(f16* p, int C, const V8& r) {
-  f16x8 a, b, c;
-  split3_x8(r.v, a, b, c);
-  *reinterpret_cast<f16x8*>(p) = a; *reinterpret_cast<f16x8*>(p + C) = b; *reinterpret_cast<f16x8*>(p + 2 * C) = c;
+template <int NPL> __device__ __forceinline__ void st_planes(f16* p, int C, const V8& r) {
+  if constexpr (NPL == 3) {
+    f16x8 a, b, c;
+    split3_x8(r.v, a, b, c);
+    *reinterpret_cast<f16x8*>(p) = a; *reinterpret_cast<f16x8*>(p + C) = b; *reinterpret_cast<f16x8*>(p + 2 * C) = c;
+  } else {
+    f16x8 a, b;
+    split2_x8(r.v, a, b);
+    *reinterpret_cast<f16x8*>(p) = a; *reinterpret_cast<f16x8*>(p + C) = b;
+  }
 }
 
+template <int NPL>
 __global__ __launch_bounds__(256) void maxpool3x3s1_planes_kernel(const f16* __restrict__ in, f16* __restrict__ out, int B, int H, int W, int C) {
   const int Cc = C >> 3;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, total = (int64_t)B * H * W * Cc;
@@ -75,11 +87,11 @@ __global__ __launch_bounds__(256) void maxpool3x3s1_planes_kernel(const f16* __r
     for (int dx = -1; dx <= 1; ++dx) {
       const int yy = y + dy, xx = x + dx;
       if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-      const V8 v = ld_planes(in + (((int64_t)b * H + yy) * W + xx) * (3 * (int64_t)C) + cc * 8, C);
+      const V8 v = ld_planes<NPL>(in + (((int64_t)b * H + yy) * W + xx) * (NPL * (int64_t)C) + cc * 8, C);
 #pragma unroll
       for (int e = 0; e < 8; ++e) m.v[e] = fmaxf(m.v[e], v.v[e]);
     }
-  st_planes(out + (((int64_t)b * H + y) * W + x) * (3 * (int64_t)C) + cc * 8, C, m);
+  st_planes<NPL>(out + (((int64_t)b * H + y) * W + x) * (NPL * (int64_t)C) + cc * 8, C, m);
 }
 
 // F.interpolate(mode='bilinear', align_corners=False), exact x2: the expression of craft_ops.hip's bilerp()
@@ -87,6 +99,7 @@ __device__ __forceinline__ float bilerp_s(float v00, float v01, float v10, float
   const float top = fmaf(lx1, v01, lx0 * v00), bot = fmaf(lx1, v11, lx0 * v10);
   return fmaf(ly1, bot, ly0 * top);
 }
+template <int NPL>
 __global__ __launch_bounds__(256) void upsample2x_planes_kernel(const f16* __restrict__ in, f16* __restrict__ out, int B, int H, int W, int C) {
   const int Ho = 2 * H, Wo = 2 * W, Cc = C >> 3;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, total = (int64_t)B * Ho * Wo * Cc;
@@ -98,25 +111,27 @@ __global__ __launch_bounds__(256) void upsample2x_planes_kernel(const f16* __res
   const int y0 = (int)sy, x0 = (int)sx;
   const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
   const float ly1 = sy - (float)y0, ly0 = 1.f - ly1, lx1 = sx - (float)x0, lx0 = 1.f - lx1;
-  const f16* base = in + (int64_t)b * H * W * (3 * (int64_t)C) + cc * 8;
-  const int64_t ps = 3 * (int64_t)C;
-  const V8 v00 = ld_planes(base + ((int64_t)y0 * W + x0) * ps, C), v01 = ld_planes(base + ((int64_t)y0 * W + x1) * ps, C);
-  const V8 v10 = ld_planes(base + ((int64_t)y1 * W + x0) * ps, C), v11 = ld_planes(base + ((int64_t)y1 * W + x1) * ps, C);
+  const f16* base = in + (int64_t)b * H * W * (NPL * (int64_t)C) + cc * 8;
+  const int64_t ps = NPL * (int64_t)C;
+  const V8 v00 = ld_planes<NPL>(base + ((int64_t)y0 * W + x0) * ps, C), v01 = ld_planes<NPL>(base + ((int64_t)y0 * W + x1) * ps, C);
+  const V8 v10 = ld_planes<NPL>(base + ((int64_t)y1 * W + x0) * ps, C), v11 = ld_planes<NPL>(base + ((int64_t)y1 * W + x1) * ps, C);
   V8 o;
 #pragma unroll
   for (int e = 0; e < 8; ++e) o.v[e] = bilerp_s(v00.v[e], v01.v[e], v10.v[e], v11.v[e], lx0, lx1, ly0, ly1);
-  st_planes(out + (((int64_t)b * Ho + yo) * Wo + xo) * ps + cc * 8, C, o);
+  st_planes<NPL>(out + (((int64_t)b * Ho + yo) * Wo + xo) * ps + cc * 8, C, o);
 }
 
 // CRAFT's conv1_1 (3 -> 64, 3x3, ReLU) from the u8 canvas straight into planes: conv1_direct_kernel's structure (craft_ops.hip)
 // with split operands.  A pixel's 27 inputs are u8 / 255 in fp32 (the reference's division, tuatara.cpp:367-370): their three planes
 // come from three 256-entry tables built once per workgroup; the weights are the layer's three planes [64][3][32].
+template <int NPL>
 __global__ __launch_bounds__(256) void conv1_split_kernel(const uint8_t* __restrict__ canvas, const f16* __restrict__ wgt /*[64][3][32]*/, const float* __restrict__ bias,
                                                          float out_scale, f16* __restrict__ out /*[M][3*64]*/, int B, int H, int W) {
   __shared__ f16 lut[3][256];
   {
-    f16x2 a, b, c;
-    split3_pair((float)threadIdx.x / 255.0f, 0.f, a, b, c);
+    f16x2 a, b, c = f16x2{(f16)0.f, (f16)0.f};
+    if constexpr (NPL == 3) split3_pair((float)threadIdx.x / 255.0f, 0.f, a, b, c);
+    else split2_pair((float)threadIdx.x / 255.0f, 0.f, a, b);
     lut[0][threadIdx.x] = a[0]; lut[1][threadIdx.x] = b[0]; lut[2][threadIdx.x] = c[0];
   }
   __syncthreads();
@@ -158,13 +173,13 @@ __global__ __launch_bounds__(256) void conv1_split_kernel(const uint8_t* __restr
         const bool ok = mv && (fg * 8 + e < 27) && yy >= 0 && yy < H && xx >= 0 && xx < W;
         const int byte = ok ? px[off[e]] : 0;            // table entry 0 = (0, 0, 0)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) fx[pl][e] = lut[pl][byte];
+        for (int pl = 0; pl < NPL; ++pl) fx[pl][e] = lut[pl][byte];
       }
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[0][jj], fx[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         a = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[1][jj], fx[1], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[1][jj], fx[2], a, 0, 0, 0);
+        if constexpr (NPL == 3) a = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[1][jj], fx[2], a, 0, 0, 0);
         acc[jj][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[2][jj], fx[0], a, 0, 0, 0);
       }
     }
@@ -180,7 +195,7 @@ __global__ __launch_bounds__(256) void conv1_split_kernel(const uint8_t* __restr
           o.v[e] = fmaxf(fmaf(acc[2 * t][i][e], out_scale, bv[t][e]), 0.f);
           o.v[4 + e] = fmaxf(fmaf(acc[2 * t + 1][i][e], out_scale, bv[t][4 + e]), 0.f);
         }
-        st_planes(out + m * 192 + 32 * t + fg * 8, 64, o);
+        st_planes<NPL>(out + m * (NPL * 64) + 32 * t + fg * 8, 64, o);
       }
     }
   }
@@ -188,20 +203,25 @@ __global__ __launch_bounds__(256) void conv1_split_kernel(const uint8_t* __restr
 
 }  // namespace
 
-void launch_maxpool3x3s1_planes(const void* in, void* out, int B, int H, int W, int C, hipStream_t s) {
+void launch_maxpool3x3s1_planes(const void* in, void* out, int B, int H, int W, int C, hipStream_t s, int planes) {
   if (C % 8) throw std::runtime_error("maxpool3x3 (planes): C % 8");
   const int64_t total = (int64_t)B * H * W * (C >> 3);
-  hipLaunchKernelGGL(maxpool3x3s1_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f16*)in, (f16*)out, B, H, W, C);
+  const dim3 g((unsigned)((total + 255) / 256));
+  if (planes == 2) hipLaunchKernelGGL(maxpool3x3s1_planes_kernel<2>, g, dim3(256), 0, s, (const f16*)in, (f16*)out, B, H, W, C);
+  else hipLaunchKernelGGL(maxpool3x3s1_planes_kernel<3>, g, dim3(256), 0, s, (const f16*)in, (f16*)out, B, H, W, C);
 }
-void launch_upsample2x_planes(const void* in, void* out, int B, int H, int W, int C, hipStream_t s) {
+void launch_upsample2x_planes(const void* in, void* out, int B, int H, int W, int C, hipStream_t s, int planes) {
   if (C % 8) throw std::runtime_error("upsample2x (planes): C % 8");
   const int64_t total = (int64_t)B * 4 * H * W * (C >> 3);
-  hipLaunchKernelGGL(upsample2x_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const f16*)in, (f16*)out, B, H, W, C);
+  const dim3 g((unsigned)((total + 255) / 256));
+  if (planes == 2) hipLaunchKernelGGL(upsample2x_planes_kernel<2>, g, dim3(256), 0, s, (const f16*)in, (f16*)out, B, H, W, C);
+  else hipLaunchKernelGGL(upsample2x_planes_kernel<3>, g, dim3(256), 0, s, (const f16*)in, (f16*)out, B, H, W, C);
 }
-void launch_conv1_split(const uint8_t* canvas, const void* wgt_planes, const float* bias, float out_scale, void* out, int B, int H, int W, hipStream_t s) {
+void launch_conv1_split(const uint8_t* canvas, const void* wgt_planes, const float* bias, float out_scale, void* out, int B, int H, int W, hipStream_t s, int planes) {
   const int64_t M = (int64_t)B * H * W;
   const int grid = (int)std::min<int64_t>((M + 255) / 256, 256 * 16);
-  hipLaunchKernelGGL(conv1_split_kernel, dim3(grid), dim3(256), 0, s, canvas, (const f16*)wgt_planes, bias, out_scale, (f16*)out, B, H, W);
+  if (planes == 2) hipLaunchKernelGGL(conv1_split_kernel<2>, dim3(grid), dim3(256), 0, s, canvas, (const f16*)wgt_planes, bias, out_scale, (f16*)out, B, H, W);
+  else hipLaunchKernelGGL(conv1_split_kernel<3>, dim3(grid), dim3(256), 0, s, canvas, (const f16*)wgt_planes, bias, out_scale, (f16*)out, B, H, W);
 }
 
 }  // namespace ttr
@@ -243,7 +263,7 @@ __global__ __launch_bounds__(256) void layernorm_planes_kernel(const float* __re
   V8 o;
 #pragma unroll
   for (int e = 0; e < 8; ++e) o.v[e] = (v[e] - mean) * rstd * gg[e] + bb[e];
-  st_planes(out + (int64_t)row * (3 * D) + c, D, o);
+  st_planes<3>(out + (int64_t)row * (3 * D) + c, D, o);
 }
 }  // namespace
 
