@@ -345,7 +345,7 @@ def main():
                                    "configs[4]: synthetic stream of 1024x768 pages, the synthetic detector's own boxes, page-level DP, RCCL all-gather of token ids in the C++ host",
                        "pages_per_gpu_per_pass": P, "passes_per_step": R, "pages_per_gpu_per_step": P * R, "ms_per_pass": dt / n_pass * 1e3, "batches_in_flight": 3 if stream else 1,
                        "words_drawn_per_page": args.words, "crops_per_page": round(crops_per_page, 1), "boxes": args.boxes,
-                       "ar_steps": "26 (no early exit in this precision)" if args.precision != "bf16" else "early exit when every crop of the batch has emitted EOS (upstream PARSeq's break)",
+                       "ar_steps": "early exit when every crop of the batch has emitted EOS (upstream PARSeq's break, system.py); value_full_ar runs all 26 steps",
                        "decoded_string_length_histogram": lens.tolist(),
                        "distinct_pages": NB * P, "page_buffers_rotated": NB, "weights": "seeded synthetic (designed read-outs on random CRAFT / PARSeq, tuatara_amd/weights.py)",
                        "precision": {"f16x4": "fp32-equivalent split-operand f16 MFMA (tuatara_amd/csrc/split.h): PARSeq on exact activation triples x weight pairs (four MFMAs per product), "
@@ -391,6 +391,10 @@ def main():
                                        else "PARSeq batched GEMM launches (gemm_ws / mlp_fused / gemm2)", "bound": "mfma",
                                        "achieved": pq_alg * mpp if pq_alg else None, "peak": peak, "unit": "TFLOP/s", "frac": (pq_alg * mpp / peak) if pq_alg else None,
                                        "algorithmic_tflops": pq_alg, "launches_per_pass": q["launches"], "measured": "one extra pass after the timed region"}
+        # all 26 AR steps (no early exit from the autoregressive loop)
+        eng.set_tuning(b"ar_early_exit", 0)
+        out["value_full_ar"], _ = rate(eng, 2)
+        eng.set_tuning(b"ar_early_exit", 1)
         # detected boxes instead of the grid
         eng.set_tuning(b"bench_grid_boxes", 0 if grid else 1)
         r_det, cpp_det = rate(eng, 2)

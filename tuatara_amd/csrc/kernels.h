@@ -70,7 +70,7 @@ void launch_fill_random(Precision prec, void* p, size_t n, unsigned seed, float 
 
 // ---- split_ops.hip (split-operand mode, split.h)
 // fp32 [M][C] (row stride ld) -> f16 planes [M][3 C], optional ReLU first
-void launch_split_planes(const float* in, int ld, void* out, int64_t M, int C, int relu, hipStream_t s, int planes = 3);
+void launch_split_planes(const float* in, int ld, void* out, int64_t M, int C, int relu, hipStream_t s, int planes = 3, const int* skip = nullptr, int skip_n = 0);
 // planes [B][H][W][3 C] in and out: CRAFT's 3x3 / stride-1 max-pool and its bilinear x2 upsampling (bit-identical to the fp32 kernels)
 void launch_maxpool3x3s1_planes(const void* in, void* out, int B, int H, int W, int C, hipStream_t s, int planes = 3);
 void launch_upsample2x_planes(const void* in, void* out, int B, int H, int W, int C, hipStream_t s, int planes = 3);
@@ -99,7 +99,8 @@ void launch_extract_heat(Precision prec, const void* in, int ld, float* out, int
 
 // ---- parseq_ops.hip
 void launch_patchify(Precision prec, const uint8_t* crops, void* out, int N, int ld, hipStream_t s);   // out [N*128][ld], ld >= 96: columns 96 .. ld-1 are zeroed
-void launch_layernorm(Precision prec, const float* in, int in_ld, const float* gamma, const float* beta, float eps, void* out, int out_ld, int M, int D, hipStream_t s);
+void launch_layernorm(Precision prec, const float* in, int in_ld, const float* gamma, const float* beta, float eps, void* out, int out_ld, int M, int D, hipStream_t s,
+                      const int* skip = nullptr, int skip_n = 0);
 void launch_attn_enc(Precision prec, const void* qkv, void* out, int N, hipStream_t s);  // qkv T [N*128][1152] -> out T [N*128][384]
 void launch_attn_enc2(const bf16* qkv, bf16* out, int N, hipStream_t s);                  // bf16, second generation (attn_enc2.hip)
 // qkv projection + self-attention fused (qkv_attn.hip): x bf16 [N*128][384] (LayerNorm output), w [1152][384], bias [1152] -> out [N*128][384]
@@ -107,7 +108,7 @@ void launch_qkv_attn(const bf16* x, const bf16* w, const float* bias, bf16* out,
 void set_attn_impl(int v);                                                               // 0: bf16 also uses the first generation
 // content token embedding + norm_c.  rows (n, i) for i in [i0,i1): out row n*(i1-i0)+(i-i0)
 void launch_dec_embed_ln(Precision prec, const int* tokens, const float* emb, const float* pos_q, const float* gamma, const float* beta, float eps,
-                         void* out, int N, int i0, int i1, hipStream_t s);
+                         void* out, int N, int i0, int i1, hipStream_t s, const int* skip = nullptr, int skip_n = 0);
 // self attention of R query rows per crop against the K/V cache [N][26][768].
 // mode 0 (AR): R == 1, query index qi0, keys 0..qi0.  mode 1 (refine): R == 26, cloze mask + EOS key padding.
 // skip / skip_n: the kernel returns at once when *skip >= skip_n (AR early exit, ConvParams::skip); bf16 per-row kernels only
@@ -117,7 +118,9 @@ void launch_dec_self_attn(Precision prec, const float* q /*[26][384] f32*/, cons
 void launch_dec_cross_attn(Precision prec, const void* q, const void* kvmem, void* out, int N, int R, hipStream_t s, const int* skip = nullptr, int skip_n = 0,
                            const int* done_tok = nullptr, int done_col = 0);   // done_tok [N][26]: AR steps skip crops with EOS (0) in columns 1 .. done_col
 // tokens[n*tok_ld + col] = argmax over C of logits[n*ld ..]
-void launch_argmax(const float* logits, int ld, int C, int* tokens, int tok_ld, int col, int N, hipStream_t s);
+// skip / skip_n: AR early exit; done_count: incremented once per crop whose FIRST EOS (id eos, columns 1 .. col) is the token formed here
+void launch_argmax(const float* logits, int ld, int C, int* tokens, int tok_ld, int col, int N, hipStream_t s, const int* skip = nullptr, int skip_n = 0,
+                   int* done_count = nullptr, int eos = 0);
 void launch_fill_i32(int* p, int value, int n, int stride, hipStream_t s);
 
 // ---- mlp_fused.hip: x_out = x + fc2(GELU(fc1(LayerNorm(x)))) [+ y = LayerNorm_next(x_out)] for the ViT encoder blocks (bf16, E = 384)

@@ -41,7 +41,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 template <typename T, int PER_LANE>
 __global__ void layernorm_kernel(const float* __restrict__ in, int in_ld, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                 float eps, T* __restrict__ out, int out_ld, int M) {
+                                 float eps, T* __restrict__ out, int out_ld, int M, const int* skip, int skip_n) {
+  if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;   // AR early exit (see ConvParams::skip)
   constexpr int D = PER_LANE * 64;
   int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
@@ -59,12 +60,13 @@ __global__ void layernorm_kernel(const float* __restrict__ in, int in_ld, const 
   for (int i = 0; i < PER_LANE; ++i) { int c = lane + 64 * i; o[c] = (T)((v[i] - mean) * rstd * gamma[c] + beta[c]); }
 }
 
-void launch_layernorm(Precision prec, const float* in, int in_ld, const float* gamma, const float* beta, float eps, void* out, int out_ld, int M, int D, hipStream_t s) {
+void launch_layernorm(Precision prec, const float* in, int in_ld, const float* gamma, const float* beta, float eps, void* out, int out_ld, int M, int D, hipStream_t s,
+                      const int* skip, int skip_n) {
   if (D != 384) throw std::runtime_error("layernorm: D must be 384");
   if (M <= 0) return;
   dim3 grid((M + 3) / 4);
-  if (prec == kBF16) hipLaunchKernelGGL((layernorm_kernel<bf16, 6>), grid, dim3(256), 0, s, in, in_ld, gamma, beta, eps, (bf16*)out, out_ld, M);
-  else hipLaunchKernelGGL((layernorm_kernel<float, 6>), grid, dim3(256), 0, s, in, in_ld, gamma, beta, eps, (float*)out, out_ld, M);
+  if (prec == kBF16) hipLaunchKernelGGL((layernorm_kernel<bf16, 6>), grid, dim3(256), 0, s, in, in_ld, gamma, beta, eps, (bf16*)out, out_ld, M, skip, skip_n);
+  else hipLaunchKernelGGL((layernorm_kernel<float, 6>), grid, dim3(256), 0, s, in, in_ld, gamma, beta, eps, (float*)out, out_ld, M, skip, skip_n);
 }
 
 // ------------------------------------------------------------------ encoder attention
@@ -213,7 +215,9 @@ void launch_attn_enc(Precision prec, const void* qkv, void* out, int N, hipStrea
 // emb is pre-scaled by sqrt(384) at export.  One wave per row.
 template <typename T>
 __global__ void dec_embed_ln_kernel(const int* __restrict__ tokens, const float* __restrict__ emb, const float* __restrict__ pos_q,
-                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, T* __restrict__ out, int N, int i0, int i1) {
+                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, T* __restrict__ out, int N, int i0, int i1,
+                                    const int* skip, int skip_n) {
+  if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;   // AR early exit (see ConvParams::skip)
   const int R = i1 - i0;
   int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= N * R) return;
@@ -238,12 +242,12 @@ __global__ void dec_embed_ln_kernel(const int* __restrict__ tokens, const float*
 }
 
 void launch_dec_embed_ln(Precision prec, const int* tokens, const float* emb, const float* pos_q, const float* gamma, const float* beta, float eps,
-                         void* out, int N, int i0, int i1, hipStream_t s) {
+                         void* out, int N, int i0, int i1, hipStream_t s, const int* skip, int skip_n) {
   int rows = N * (i1 - i0);
   if (rows <= 0) return;
   dim3 grid((rows + 3) / 4);
-  if (prec == kBF16) hipLaunchKernelGGL(dec_embed_ln_kernel<bf16>, grid, dim3(256), 0, s, tokens, emb, pos_q, gamma, beta, eps, (bf16*)out, N, i0, i1);
-  else hipLaunchKernelGGL(dec_embed_ln_kernel<float>, grid, dim3(256), 0, s, tokens, emb, pos_q, gamma, beta, eps, (float*)out, N, i0, i1);
+  if (prec == kBF16) hipLaunchKernelGGL(dec_embed_ln_kernel<bf16>, grid, dim3(256), 0, s, tokens, emb, pos_q, gamma, beta, eps, (bf16*)out, N, i0, i1, skip, skip_n);
+  else hipLaunchKernelGGL(dec_embed_ln_kernel<float>, grid, dim3(256), 0, s, tokens, emb, pos_q, gamma, beta, eps, (float*)out, N, i0, i1, skip, skip_n);
 }
 
 // ------------------------------------------------------------------ decoder self attention
@@ -401,10 +405,15 @@ void launch_dec_self_attn(Precision prec, const float* q, const void* kvcache, c
 // ------------------------------------------------------------------ decoder cross attention
 // one 384-thread workgroup per query row; 12 heads x 32 dims against the crop's 128 memory tokens.
 template <typename T>
-__global__ __launch_bounds__(384) void dec_cross_attn_kernel(const T* __restrict__ q, const T* __restrict__ kvmem, T* __restrict__ out, int R) {
+__global__ __launch_bounds__(384) void dec_cross_attn_kernel(const T* __restrict__ q, const T* __restrict__ kvmem, T* __restrict__ out, int R,
+                                                             const int* skip, int skip_n, const int* done_tok, int done_col) {
+  if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;   // AR early exit (see ConvParams::skip)
   __shared__ float sq[384];
   __shared__ float sp[12][128];
   const int row = blockIdx.x, n = row / R, t = threadIdx.x;
+  if (done_tok) {   // ... and per crop: it has emitted EOS in token columns 1 .. done_col; what this row would produce is never read
+    for (int c = 1; c <= done_col; ++c) if (done_tok[n * 26 + c] == 0) return;
+  }
   sq[t] = (float)q[(int64_t)row * 384 + t];
   __syncthreads();
   const T* kvn = kvmem + (int64_t)n * 128 * 768;
@@ -536,11 +545,13 @@ void launch_dec_cross_attn(Precision prec, const void* q, const void* kvmem, voi
   if (prec == kBF16 && g_cross_mfma && (R == 26 || g_cross_mfma == 2)) return launch_dec_cross_attn_mfma((const bf16*)q, (const bf16*)kvmem, (bf16*)out, N, R, s);   // refinement pass (attn_dec2.hip); 2: the AR steps' single row too
   dim3 grid(N * R);
   if (prec == kBF16) hipLaunchKernelGGL(dec_cross_attn_rows_kernel, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)kvmem, (bf16*)out, R, skip, skip_n, R == 1 ? done_tok : nullptr, done_col);
-  else hipLaunchKernelGGL(dec_cross_attn_kernel<float>, grid, dim3(384), 0, s, (const float*)q, (const float*)kvmem, (float*)out, R);
+  else hipLaunchKernelGGL(dec_cross_attn_kernel<float>, grid, dim3(384), 0, s, (const float*)q, (const float*)kvmem, (float*)out, R, skip, skip_n, R == 1 ? done_tok : nullptr, done_col);
 }
 
 // ------------------------------------------------------------------ argmax (first maximal index, like torch.argmax on CPU)
-__global__ void argmax_kernel(const float* __restrict__ logits, int ld, int C, int* __restrict__ tokens, int tok_ld, int col, int N) {
+__global__ void argmax_kernel(const float* __restrict__ logits, int ld, int C, int* __restrict__ tokens, int tok_ld, int col, int N,
+                              const int* skip, int skip_n, int* done_count, int eos) {
+  if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;   // AR early exit (see ConvParams::skip)
   int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (n >= N) return;
   const float* x = logits + (int64_t)n * ld;
@@ -551,12 +562,19 @@ __global__ void argmax_kernel(const float* __restrict__ logits, int ld, int C, i
     float ov = __shfl_xor(best, o); int oi = __shfl_xor(bi, o);
     if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
   }
-  if (lane == 0) tokens[n * tok_ld + col] = bi;
+  if (lane == 0) {
+    tokens[n * tok_ld + col] = bi;
+    if (done_count && bi == eos) {   // upstream PARSeq's break (system.py): count the crops whose FIRST EOS is this token
+      bool first = true;
+      for (int c = 1; c < col; ++c) first = first && tokens[n * tok_ld + c] != eos;
+      if (first) atomicAdd(done_count, 1);
+    }
+  }
 }
 
-void launch_argmax(const float* logits, int ld, int C, int* tokens, int tok_ld, int col, int N, hipStream_t s) {
+void launch_argmax(const float* logits, int ld, int C, int* tokens, int tok_ld, int col, int N, hipStream_t s, const int* skip, int skip_n, int* done_count, int eos) {
   if (N <= 0) return;
-  hipLaunchKernelGGL(argmax_kernel, dim3((N + 3) / 4), dim3(256), 0, s, logits, ld, C, tokens, tok_ld, col, N);
+  hipLaunchKernelGGL(argmax_kernel, dim3((N + 3) / 4), dim3(256), 0, s, logits, ld, C, tokens, tok_ld, col, N, skip, skip_n, done_count, eos);
 }
 
 __global__ void fill_i32_kernel(int* p, int value, int n, int stride) {

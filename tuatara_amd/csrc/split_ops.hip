@@ -11,7 +11,8 @@
 namespace ttr {
 
 template <int NPL>
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ in, int ld, f16* __restrict__ out, int64_t M, int C, int relu) {
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ in, int ld, f16* __restrict__ out, int64_t M, int C, int relu, const int* skip, int skip_n) {
+  if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;   // AR early exit (see ConvParams::skip)
   const int cv = C >> 3;                                   // 8-channel groups per row
   const int64_t total = M * cv;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -28,13 +29,13 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
   }
 }
 
-void launch_split_planes(const float* in, int ld, void* out, int64_t M, int C, int relu, hipStream_t s, int planes) {
+void launch_split_planes(const float* in, int ld, void* out, int64_t M, int C, int relu, hipStream_t s, int planes, const int* skip, int skip_n) {
   if (M <= 0) return;
   if (C % 8 || ld % 4 || ((uintptr_t)in & 15) || ((uintptr_t)out & 15)) throw std::runtime_error("split_planes: C must be a multiple of 8 and the tensors 16-byte aligned");
   const int64_t total = M * (C >> 3);
   const int grid = (int)std::min<int64_t>((total + 255) / 256, 256 * 32);
-  if (planes == 2) hipLaunchKernelGGL(split_planes_kernel<2>, dim3(grid), dim3(256), 0, s, in, ld, (f16*)out, M, C, relu);
-  else hipLaunchKernelGGL(split_planes_kernel<3>, dim3(grid), dim3(256), 0, s, in, ld, (f16*)out, M, C, relu);
+  if (planes == 2) hipLaunchKernelGGL(split_planes_kernel<2>, dim3(grid), dim3(256), 0, s, in, ld, (f16*)out, M, C, relu, skip, skip_n);
+  else hipLaunchKernelGGL(split_planes_kernel<3>, dim3(grid), dim3(256), 0, s, in, ld, (f16*)out, M, C, relu, skip, skip_n);
 }
 
 }  // namespace ttr
