@@ -546,6 +546,9 @@ void launch_gemm2(const ConvParams& p_in, int cfg, hipStream_t s) {
     // every shape measured (fc1 1.79 vs ~1.0 ms); small problems keep the 128-wide tiles so that the chip fills
     const int64_t t2 = (int64_t)((p.M + 255) / 256) * ((p.Cout + 127) / 128);
     cfg = t2 >= 2 * num_cus() ? 2 : 3;
+    // wide outputs of many rows: 128 x 256 tiles halve the number of passes over the activation planes (the big operand; the weights
+    // stay in L2): qkv 848 -> 774 us at 1280 crops.  Not for Cout = 384 (1.5 tiles of 256)
+    if (cfg == 2 && p.Cout >= 1024 && p.ks == 1 && p.M >= 65536) cfg = 6;
   }
   if (cfg == 0) {   // measured on MI355X (tools/gemm_sweep.py, profiles/r01_gemm_sweep.txt)
     if (p.Cout <= 64) cfg = 5;
