@@ -69,6 +69,7 @@ struct Tuning {
   int ln_fuse = 1;            // bf16 decoder steps: LayerNorm computed inside the skinny GEMM's loader (gemm_sk ln_in)
   int fuse_first = 1;         // bf16: CRAFT conv1_1 fused into conv1_2's loader (conv3p FIRST)
   int enc_chunk = 0;          // crops per encoder group (0 = all crops at once)
+  int enc_ln_pairs = 1;       // split-operand engines, PARSeq encoder: LayerNorm outputs as pairs (qkv and fc1 on three MFMAs per product: their inputs tolerate ~23.5 bits - 3 x 1280 crops: max |dlogit| 7.6e-4 vs 6.9e-4 with triples; proj and fc2 keep exact triples); 0 = triples
   int craft_products = 3;     // split-operand engines, CRAFT: 3 = activation pairs (~23.5 bits; the heat map stays at fp32 noise level), 4 = exact triples
   int bench_grid_boxes = 0;   // benchmark workload control (bench.py --boxes=grid40): the detector runs in full, then every page's boxes are replaced by a fixed 5 x 8 grid
   int split_planes = 1;       // split-operand engines: activations stay in planes between the layers (0: fp32 tensors + a split pass in front of every GEMM)
@@ -91,6 +92,7 @@ struct Tuning {
     else if (k == "split_gemm") split_gemm = value;
     else if (k == "bench_grid_boxes") bench_grid_boxes = value;
     else if (k == "craft_products") craft_products = value == 4 ? 4 : 3;
+    else if (k == "enc_ln_pairs") enc_ln_pairs = value;
     else if (k == "split_conv3p") split_conv3p = value;
     else if (k == "split_planes") split_planes = value;
     else if (k == "craft_group") craft_group = value < 1 ? 1 : (value > 32 ? 32 : value);
@@ -836,11 +838,11 @@ struct Engine {
   // ---- PARSeq
   // split-operand linear on planes: in [M][3 K] -> out (planes [M][3 out_ld] or fp32 [M][out_ld]) and / or out_f32 (+ fp32 residual)
   void sgemm(const Linear& L, const void* in_planes, int M, void* out, int out_ld, int act, int out_planes,
-             float* out_f32 = nullptr, int out_f32_ld = 0, const float* resid = nullptr, int resid_ld = 0) {
+             float* out_f32 = nullptr, int out_f32_ld = 0, const float* resid = nullptr, int resid_ld = 0, int np = 4) {
     if (!L.ws.p) throw std::runtime_error("split GEMM: the layer has no weight planes");
     ConvParams p{};
     p.in0 = in_planes; p.C0 = L.k; p.B = 1; p.H = 1; p.W = M; p.ks = 1; p.dil = 1;
-    p.wgt = L.ws.p; p.bias = L.b.as<float>(); p.split = 4; p.out_scale = L.inv_scale; p.out_planes = out_planes ? 3 : 0;
+    p.wgt = L.ws.p; p.bias = L.b.as<float>(); p.split = np; p.out_scale = L.inv_scale; p.out_planes = out_planes ? 3 : 0;
     p.out = out; p.out_ld = out_ld; p.out_f32 = out_f32; p.out_f32_ld = out_f32_ld; p.resid = resid; p.resid_ld = resid_ld;
     p.Cout = L.cout; p.M = M; p.act = act;
     if (const char* e = gemm2_check(p)) throw std::runtime_error(e);
@@ -939,17 +941,18 @@ struct Engine {
       void* bigp = (pq_ws[12].ensure((size_t)std::min(N, CHS) * 128 * 1536 * 6), pq_ws[12].p);   // qkv / MLP hidden planes
       void* attp = (pq_ws[13].ensure((size_t)std::min(N, CHS) * 128 * E * 6), pq_ws[13].p);      // attention output planes
       auto lnp_at = [&](int c0) { return (char*)lnp + (size_t)c0 * 128 * E * 6; };
+      const int lnpl = tn.enc_ln_pairs ? 2 : 3;        // planes of the LayerNorm outputs that feed qkv / fc1 (pairs: three MFMAs per product there)
       for (int c0 = 0; c0 < N; c0 += CHS) {
         const int nc = std::min(CHS, N - c0), Mc = nc * 128;
         float* xc = x + (size_t)c0 * 128 * E;
         for (int l = 0; l < 12; ++l) {
           const std::string p = "encoder.blocks." + std::to_string(l) + ".";
-          launch_layernorm_planes(xc, E, pqf.at(p + "norm1.weight").as<float>(), pqf.at(p + "norm1.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream);
-          sgemm(pq.at(p + "qkv"), lnp_at(c0), Mc, bigp, 3 * E, kActNone, 1);
+          launch_layernorm_planes(xc, E, pqf.at(p + "norm1.weight").as<float>(), pqf.at(p + "norm1.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream, lnpl);
+          sgemm(pq.at(p + "qkv"), lnp_at(c0), Mc, bigp, 3 * E, kActNone, 1, nullptr, 0, nullptr, 0, lnpl + 1);
           launch_attn_enc_split(bigp, attp, nc, stream);
           sgemm(pq.at(p + "proj"), attp, Mc, nullptr, 0, kActNone, 0, xc, E, xc, E);
-          launch_layernorm_planes(xc, E, pqf.at(p + "norm2.weight").as<float>(), pqf.at(p + "norm2.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream);
-          sgemm(pq.at(p + "fc1"), lnp_at(c0), Mc, bigp, 4 * E, kActGelu, 1);
+          launch_layernorm_planes(xc, E, pqf.at(p + "norm2.weight").as<float>(), pqf.at(p + "norm2.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream, lnpl);
+          sgemm(pq.at(p + "fc1"), lnp_at(c0), Mc, bigp, 4 * E, kActGelu, 1, nullptr, 0, nullptr, 0, lnpl + 1);
           sgemm(pq.at(p + "fc2"), bigp, Mc, nullptr, 0, kActNone, 0, xc, E, xc, E);
         }
         launch_layernorm_planes(xc, E, pqf.at("encoder.norm.weight").as<float>(), pqf.at("encoder.norm.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream);

@@ -75,7 +75,7 @@ void launch_split_planes(const float* in, int ld, void* out, int64_t M, int C, i
 void launch_maxpool3x3s1_planes(const void* in, void* out, int B, int H, int W, int C, hipStream_t s, int planes = 3);
 void launch_upsample2x_planes(const void* in, void* out, int B, int H, int W, int C, hipStream_t s, int planes = 3);
 // LayerNorm over 384 columns of fp32 rows (stride in_ld) -> planes [M][3 * 384]
-void launch_layernorm_planes(const float* in, int in_ld, const float* gamma, const float* beta, float eps, void* out, int M, hipStream_t s);
+void launch_layernorm_planes(const float* in, int in_ld, const float* gamma, const float* beta, float eps, void* out, int M, hipStream_t s, int planes = 3);
 // attn_split.hip: ViT encoder self-attention, qkv planes [N*128][3][1152] -> planes [N*128][3][384]
 void launch_attn_enc_split(const void* qkv_planes, void* out_planes, int N, hipStream_t s);
 // CRAFT's conv1_1 + bias + ReLU from the u8 canvas into planes [M][3 * 64]; wgt_planes f16 [64][3][32] (k = (ky*3+kx)*3+c, 27 used)

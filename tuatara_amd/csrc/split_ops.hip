@@ -232,6 +232,7 @@ void launch_conv1_split(const uint8_t* canvas, const void* wgt_planes, const flo
 // 16-byte plane stores per lane); statistics as layernorm_kernel (parseq_ops.hip): mean, then the centred sum of squares.
 namespace ttr {
 namespace {
+template <int NPL>
 __global__ __launch_bounds__(256) void layernorm_planes_kernel(const float* __restrict__ in, int in_ld, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float eps, f16* __restrict__ out, int M) {
   constexpr int D = 384;
@@ -264,13 +265,14 @@ __global__ __launch_bounds__(256) void layernorm_planes_kernel(const float* __re
   V8 o;
 #pragma unroll
   for (int e = 0; e < 8; ++e) o.v[e] = (v[e] - mean) * rstd * gg[e] + bb[e];
-  st_planes<3>(out + (int64_t)row * (3 * D) + c, D, o);
+  st_planes<NPL>(out + (int64_t)row * (NPL * D) + c, D, o);
 }
 }  // namespace
 
-void launch_layernorm_planes(const float* in, int in_ld, const float* gamma, const float* beta, float eps, void* out, int M, hipStream_t s) {
+void launch_layernorm_planes(const float* in, int in_ld, const float* gamma, const float* beta, float eps, void* out, int M, hipStream_t s, int planes) {
   if (M <= 0) return;
   if (in_ld % 4 || (((uintptr_t)in | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15)) throw std::runtime_error("layernorm (planes): 16-byte alignment");
-  hipLaunchKernelGGL(layernorm_planes_kernel, dim3((M + 3) / 4), dim3(256), 0, s, in, in_ld, gamma, beta, eps, (f16*)out, M);
+  if (planes == 2) hipLaunchKernelGGL(layernorm_planes_kernel<2>, dim3((M + 3) / 4), dim3(256), 0, s, in, in_ld, gamma, beta, eps, (f16*)out, M);
+  else hipLaunchKernelGGL(layernorm_planes_kernel<3>, dim3((M + 3) / 4), dim3(256), 0, s, in, in_ld, gamma, beta, eps, (f16*)out, M);
 }
 }  // namespace ttr
