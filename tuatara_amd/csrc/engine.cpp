@@ -327,6 +327,7 @@ struct Engine {
 
   // workspaces
   std::vector<std::unique_ptr<DevBuf>> craft_ws;  // per-layer activations
+  int craft_ws_npl = 0;                           // planes per value the split CRAFT workspaces were laid out for
   DevBuf pq_ws[16];
   DevBuf canvas, heat, staging_img, crops, rects_dev, logits, ar_logits, ids_dev, tokens;
   CclBatch ccl;
@@ -389,7 +390,7 @@ struct Engine {
     prof_break_if_craft();
     launch_split_planes((const float*)p.in0, p.C0, split_in[0].p, p.M, p.C0, 0, stream, 3, p.skip, p.skip_n);
     if (p.C1) launch_split_planes((const float*)p.in1, p.C1, split_in[1].p, p.M, p.C1, 0, stream, 3, p.skip, p.skip_n);
-    timed(true_flops, [&] { if (c3) launch_conv3p(q, stream); else launch_gemm2(q, 0, stream); });
+    timed(true_flops * 4, [&] { if (c3) launch_conv3p(q, stream); else launch_gemm2(q, 0, stream); });   // (split engines report MFMA-executed flops: algorithmic x products)
     return true;
   }
   void prof_break_if_craft() { if (prof_stage == 0) prof_break(); }
@@ -487,7 +488,12 @@ struct Engine {
         continue;
       }
       // channel padding to multiples of 32 (only the 16-channel head tensors need it)
-      const int cin_pad = (c.cin + 31) / 32 * 32;
+      int cin_pad = (c.cin + 31) / 32 * 32;
+      // split-operand engines: the three 3x3 layers of the 32-channel head run on the f16 kernels too, which want Cin % 64: their inputs
+      // carry 32 zero channels (the layers are thin: 3 % of CRAFT's flops; on the fp32 MFMA kernel they took 5 % of the time)
+      const std::string nm(c.name);
+      const bool head3 = prec == kSplit && (nm == "conv_cls.0" || nm == "conv_cls.2" || nm == "conv_cls.4");
+      if (head3) cin_pad = 64;
       int cout_pad = c.cout;
       if (std::string(c.name) == "conv_cls.4" || std::string(c.name) == "conv_cls.6") cout_pad = 32;  // feeds a padded-Cin layer
       std::vector<int> kmap((size_t)taps * cin_pad, -1);
@@ -641,10 +647,13 @@ struct Engine {
   }
 
   // ---- CRAFT
-  DevBuf& ws(size_t idx, size_t bytes) {
+  DevBuf& ws(size_t idx, size_t bytes, bool zero_new = false) {
     while (craft_ws.size() <= idx) craft_ws.emplace_back(new DevBuf());
-    craft_ws[idx]->ensure(bytes);
-    return *craft_ws[idx];
+    DevBuf& d = *craft_ws[idx];
+    const void* before = d.p;
+    d.ensure(bytes);
+    if (zero_new && d.p != before) TTR_HIP_CHECK(hipMemsetAsync(d.p, 0, d.cap, stream));   // padding channels are written once, here
+    return d;
   }
 
   void conv(const char* name, const void* in0, int C0, const void* in1, int C1, int relu0, int B, int H, int W, void* out, int act,
@@ -668,7 +677,7 @@ struct Engine {
   // canvas u8 [B][H][W][3] (device) -> heat f32 [B][H/2][W/2][2] (device)
   void craft_forward(const uint8_t* d_canvas, int B, int H, int W, float* d_heat) {
     if (H % 32 || W % 32) throw std::runtime_error("CRAFT canvas must be a multiple of 32");
-    if (prec == kSplit && tn.split_gemm && tn.split_planes) return craft_forward_split(d_canvas, B, H, W, d_heat);
+    if (prec == kSplit) return craft_forward_split(d_canvas, B, H, W, d_heat);   // (the split_gemm / split_planes knobs act on PARSeq only)
     prof_stage = 0;
     const size_t M0 = (size_t)B * H * W, M1 = M0 / 4, M2 = M1 / 4, M3 = M2 / 4, M4 = M3 / 4;
     const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8, H4 = H / 16, W4 = W / 16;
@@ -763,7 +772,7 @@ struct Engine {
   // value); the convolutions' epilogues write them (bias, ReLU, ReLU copy, 2x2 max-pool fused), so no fp32 tensor and no separate
   // split pass exists up to the 32-channel head, which stays on the fp32 MFMA kernel (thin layers: 3 % of the FLOPs).
   void sconv(const char* name, const void* in0, int C0, const void* in1, int C1, int B, int H, int W, void* out, int act,
-             void* out_relu = nullptr, void* out_pool = nullptr, int pool_relu = 0, int out_planes = -1) {
+             void* out_relu = nullptr, void* out_pool = nullptr, int pool_relu = 0, int out_planes = -1, int out_ld = 0) {
     const int np = tn.craft_products == 4 ? 4 : 3;             // products per value: 3 = activation pairs (default), 4 = exact triples
     if (out_planes < 0) out_planes = np - 1;
     const Linear& L = craft.at(name);
@@ -774,13 +783,13 @@ struct Engine {
     if (L.k != p.ks * p.ks * Ct || !L.ws.p) throw std::runtime_error(std::string("split conv shape mismatch at ") + name);
     p.dil = std::string(name) == "slice5.1" ? 6 : 1;
     p.wgt = L.ws.p; p.bias = L.b.as<float>(); p.split = np; p.out_scale = L.inv_scale; p.out_planes = out_planes;
-    p.out = out; p.out_ld = L.cout; p.out_relu = out_relu; p.out_pool = out_pool; p.pool_relu = pool_relu;
+    p.out = out; p.out_ld = out_ld ? out_ld : L.cout; p.out_relu = out_relu; p.out_pool = out_pool; p.pool_relu = pool_relu;
     p.Cout = L.cout; p.M = B * H * W; p.act = act;
     double flops = 0;
     for (const auto& c : craft_convs()) if (std::string(c.name) == name) flops = 2.0 * p.M * c.cout * c.ks * c.ks * c.cin;
     const bool c3 = tn.split_conv3p && p.Cout >= 32 && conv3p_check(p) == nullptr;
     if (!c3) { if (const char* e = gemm2_check(p)) throw std::runtime_error(std::string(name) + ": " + e); }
-    timed(flops, [&] { if (c3) launch_conv3p(p, stream); else launch_gemm2(p, 0, stream); });
+    timed(flops * np, [&] { if (c3) launch_conv3p(p, stream); else launch_gemm2(p, 0, stream); });
   }
   void craft_forward_split(const uint8_t* d_canvas, int B, int H, int W, float* d_heat) {
     prof_stage = 0;
@@ -788,12 +797,17 @@ struct Engine {
     const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8, H4 = H / 16, W4 = W / 16;
     size_t k = 0;
     const int npl = tn.craft_products == 4 ? 3 : 2;                                       // planes per value
+    if (npl != craft_ws_npl) {   // another plane count: the zero padding channels of the head tensors sit elsewhere - start from fresh buffers
+      TTR_HIP_CHECK(hipStreamSynchronize(stream));
+      craft_ws.clear();
+      craft_ws_npl = npl;
+    }
     auto pbuf = [&](size_t rows, int C) -> void* { return ws(k++, rows * C * 2 * npl).p; };   // planes
     auto fbuf = [&](size_t rows, int C) -> void* { return ws(k++, rows * C * 4).p; };   // fp32
     void* c11 = pbuf(M0, 64);
     {
       const Linear& L0 = craft.at("slice1.0");
-      timed(2.0 * M0 * 64 * 27, [&] { launch_conv1_split(d_canvas, L0.ws.p, L0.b.as<float>(), L0.inv_scale, c11, B, H, W, stream, npl); });
+      timed(2.0 * M0 * 64 * 27 * (npl + 1), [&] { launch_conv1_split(d_canvas, L0.ws.p, L0.b.as<float>(), L0.inv_scale, c11, B, H, W, stream, npl); });
     }
     void* p1 = pbuf(M1, 64);   sconv("slice1.3", c11, 64, nullptr, 0, B, H, W, nullptr, kActRelu, nullptr, p1, 0);
     void* c21 = pbuf(M1, 128); sconv("slice1.7", p1, 64, nullptr, 0, B, H1, W1, c21, kActRelu);
@@ -822,13 +836,15 @@ struct Engine {
     void* u3b = pbuf(M2, 64);  sconv("upconv3.3", u3a, 128, nullptr, 0, B, H2, W2, u3b, kActRelu);
     void* up3 = pbuf(M1, 64);  prof_break(), launch_upsample2x_planes(u3b, up3, B, H2, W2, 64, stream, npl);
     void* u4a = pbuf(M1, 64);  sconv("upconv4.0", up3, 64, c22, 128, B, H1, W1, u4a, kActRelu);
-    void* u4b = fbuf(M1, 32);  sconv("upconv4.3", u4a, 64, nullptr, 0, B, H1, W1, u4b, kActRelu, nullptr, nullptr, 0, /*out_planes=*/0);
-    // 32-channel head on the fp32 MFMA kernel
+    // 32-channel head: the 3x3 layers on the f16 kernels over planes with 32 zero channels behind the 32 real ones (row = 64 channels);
+    // the two 1x1 layers (16 -> 16 -> 2) on the fp32 MFMA kernel
+    auto zbuf = [&](size_t rows) -> void* { return ws(k++, rows * 64 * 2 * npl, true).p; };
+    void* u4b = zbuf(M1); sconv("upconv4.3", u4a, 64, nullptr, 0, B, H1, W1, u4b, kActRelu, nullptr, nullptr, 0, -1, 64);
+    void* h0 = zbuf(M1);  sconv("conv_cls.0", u4b, 64, nullptr, 0, B, H1, W1, h0, kActRelu, nullptr, nullptr, 0, -1, 64);
+    void* h2 = zbuf(M1);  sconv("conv_cls.2", h0, 64, nullptr, 0, B, H1, W1, h2, kActRelu, nullptr, nullptr, 0, -1, 64);
+    void* h4 = fbuf(M1, 32); sconv("conv_cls.4", h2, 64, nullptr, 0, B, H1, W1, h4, kActRelu, nullptr, nullptr, 0, /*out_planes=*/0);   // fp32, 16 real + 16 zero channels
     const int sg = tn.split_gemm; tn.split_gemm = 0;
-    void* h0 = fbuf(M1, 32); void* h2 = fbuf(M1, 32); void* h4 = fbuf(M1, 32); void* h6 = fbuf(M1, 32);
-    conv("conv_cls.0", u4b, 32, nullptr, 0, 0, B, H1, W1, h0, kActRelu);
-    conv("conv_cls.2", h0, 32, nullptr, 0, 0, B, H1, W1, h2, kActRelu);
-    conv("conv_cls.4", h2, 32, nullptr, 0, 0, B, H1, W1, h4, kActRelu);
+    void* h6 = fbuf(M1, 32);
     conv("conv_cls.6", h4, 32, nullptr, 0, 0, B, H1, W1, h6, kActRelu);
     conv("conv_cls.8", h6, 32, nullptr, 0, 0, B, H1, W1, nullptr, kActNone, d_heat);
     tn.split_gemm = sg;
@@ -846,7 +862,7 @@ struct Engine {
     p.out = out; p.out_ld = out_ld; p.out_f32 = out_f32; p.out_f32_ld = out_f32_ld; p.resid = resid; p.resid_ld = resid_ld;
     p.Cout = L.cout; p.M = M; p.act = act;
     if (const char* e = gemm2_check(p)) throw std::runtime_error(e);
-    timed(2.0 * M * L.cout * L.k, [&] { launch_gemm2(p, 0, stream); });
+    timed(2.0 * M * L.cout * L.k * np, [&] { launch_gemm2(p, 0, stream); });
   }
   // out = L(LayerNorm(x)) for the decoder's per-step rows: the skinny GEMM normalises its own activation rows (bf16, few rows);
   // otherwise the LayerNorm kernel writes `scratch` and the plain GEMM follows
