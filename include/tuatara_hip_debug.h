@@ -69,6 +69,9 @@ int ttr_bench_conv(ttr_engine* e, int B, int H, int W, int C0, int C1, int ks, i
 /* ---- host-side geometry hooks (no GPU touched; used by the CPU test-suite) -------------------- */
 /* cv::minAreaRect stand-in used at tuatara.cpp:179,:248: n points (x,y) float32 -> {cx,cy,w,h,angle}. */
 int ttr_dbg_min_area_rect(const float* xy, int n, float* rect5);
+/* the TCP rendezvous of ttr_comm_create_tcp on its own (no GPU, no RCCL): rank 0 listens on addr:port and hands its `bytes` bytes to the
+ * world - 1 ranks that connect.  Returns 0, or -1 (ttr_last_error).  tests/test_comm_cpu.py runs it with two processes. */
+int ttr_dbg_tcp_share(int rank, int world, const char* addr, int port, void* buf, size_t bytes);
 /* tuatara.cpp:162-179 for one component given its stats and per-row x extremes
  * rows[(y1-y0+1)][2] = {min x, max x} ({INT_MAX,-1} = empty row).  Returns 1 if a rect was produced. */
 int ttr_dbg_component_rect(int area, int x0, int y0, int x1, int y1, const int32_t* rows, int H, int W, float* rect5);

@@ -57,6 +57,7 @@ SYMBOLS = [
     ("ttr_engine_set_tuning", _I, [_VP, C.c_char_p, _I]),
     ("ttr_dbg_conv", _I, [_VP, _PF, _I, _PF, _I, _I, _I, _I, _I, _I, _I, _I, _PF, _PF, _I, _I, _PF]),
     ("ttr_dbg_min_area_rect", _I, [_PF, _I, _PF]),
+    ("ttr_dbg_tcp_share", _I, [_I, _I, C.c_char_p, _I, _VP, C.c_size_t]),
     ("ttr_dbg_component_rect", _I, [_I, _I, _I, _I, _I, _PI, _I, _I, _PF]),
     ("ttr_dbg_box_geometry", _I, [_PF, _F, _PF, _PI, _PF]),
     ("ttr_dev_alloc", _VP, [C.c_size_t]),
