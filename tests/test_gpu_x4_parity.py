@@ -239,3 +239,25 @@ def test_x4_config5_32_pages(eng_x4, eng_f32, oracle_models):
     assert d < TOL
     assert np.array_equal(np.asarray(ids).reshape(-1, 26)[mask], np.asarray(idf).reshape(-1, 26)[mask])
     buf.free()
+
+
+def test_strict_crops_fails_like_the_reference_on_an_edge_box(weights, oracle_models):
+    """A word that touches the image border: its dilated box leaves the image.  The reference's crop throws there (cv::Exception at
+    tuatara.cpp:416); with strict_crops = 1 the engine fails the call the same way, by default it clamps the crop (documented deviation)
+    and returns what the oracle returns with clamping."""
+    from oracle import pipeline
+    from tuatara_amd.engine import Engine, EngineError
+    craft, parseq = oracle_models
+    rng = np.random.default_rng(0)
+    img = np.full((96, 160, 3), 255, np.uint8)
+    img[40:54, 0:70] = rng.integers(0, 2, (14, 70, 1), dtype=np.uint8) * 255
+    img[10:24, 60:120] = rng.integers(0, 2, (14, 60, 1), dtype=np.uint8) * 255
+    with pytest.raises(RuntimeError):
+        pipeline.image_to_data(craft, parseq, img, clamp=False)
+    ref = pipeline.image_to_data(craft, parseq, img, clamp=True)
+    strict = Engine(weights["dir"], strict_crops=True)
+    with pytest.raises(EngineError):
+        strict.image_to_data(img)
+    strict.close()
+    got = Engine(weights["dir"]).image_to_data(img)
+    assert len(ref) == 2 and [g["bbox"] for g in got] == [list(r["bbox"]) for r in ref] and [g["text"] for g in got] == [r["text"] for r in ref]

@@ -15,6 +15,8 @@ eng = Engine(d, precision=os.environ.get("TTR_PREC", "bf16"))
 for kv in sys.argv[4:]:                      # key=value tuning knobs (Engine.set_tuning)
     k, v = kv.split("=")
     assert eng.set_tuning(k, int(v)) == 0, kv
+if not words:
+    assert eng.set_tuning("detector_only", 1) == 0
 pages = np.stack([synth.synthetic_page(i, 1024, 768, n_words=words) for i in range(P)]) if words else np.full((P, 1024, 768, 3), 255, np.uint8)
 buf = DeviceBuffer(pages.nbytes)
 buf.upload(pages)

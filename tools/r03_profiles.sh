@@ -15,7 +15,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pc_$c; rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pc_$c -o p -- python3 $R/tools/prof_pages.py 8 3 0 > /tmp/pc_$c.log 2>&1
   cp $(ls /tmp/pc_$c/*/*counter_collection.csv /tmp/pc_$c/*counter_collection.csv 2>/dev/null | tail -1) $O/r03_pmc_craft_x4_$(echo $c | tr A-Z a-z | sed s/_size//)_counter_collection.csv
 done
-PMC_EXCLUDE=", 4>(ttr::ConvParams);igemm_kernel<float, 2, 2>;igemm_kernel<float, 4, 4>" python3 $R/tools/pmc_to_json.py $O/r03_pmc_craft_x4_fetch_counter_collection.csv $O/r03_pmc_craft_x4_write_counter_collection.csv 8 3 $O/r03_pmc_craft_x4.json | tail -2
+python3 $R/tools/pmc_to_json.py $O/r03_pmc_craft_x4_fetch_counter_collection.csv $O/r03_pmc_craft_x4_write_counter_collection.csv 8 3 $O/r03_pmc_craft_x4.json | tail -2
 python3 - $O/r03_pmc_craft_x4.json "$B" <<'PY'
 import json, sys
 j = json.load(open(sys.argv[1])); j["build"] = sys.argv[2]; json.dump(j, open(sys.argv[1], "w"), indent=1)

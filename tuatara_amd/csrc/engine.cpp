@@ -72,6 +72,7 @@ struct Tuning {
   int enc_ln_pairs = 1;       // split-operand engines, PARSeq encoder: LayerNorm outputs as pairs (qkv and fc1 on three MFMAs per product: their inputs tolerate ~23.5 bits - 3 x 1280 crops: max |dlogit| 7.6e-4 vs 6.9e-4 with triples; proj and fc2 keep exact triples); 0 = triples
   int enc_fc2_pairs = 1;      // ... and the MLP hidden activation as pairs (fc2 on three MFMAs per product; 3 x 640 crops: max |dlogit| 5.1 - 6.7e-4 vs 5.6 - 7.6e-4 with triples); the attention output - the projection input - stays an exact triple: the one encoder linear whose result moves with the 24th bit (oracle/splitsim.py)
   int craft_products = 3;     // split-operand engines, CRAFT: 3 = activation pairs (~23.5 bits; the heat map stays at fp32 noise level), 4 = exact triples
+  int detector_only = 0;      // profiling: drop every detected box, so that a batch runs the detector + CCL only
   int bench_grid_boxes = 0;   // benchmark workload control (bench.py --boxes=grid40): the detector runs in full, then every page's boxes are replaced by a fixed 5 x 8 grid
   int split_planes = 1;       // split-operand engines: activations stay in planes between the layers (0: fp32 tensors + a split pass in front of every GEMM)
   int split_conv3p = 1;       // split-operand engines: 3x3 layers on the patch-stationary kernel (0: gemm2)
@@ -92,6 +93,7 @@ struct Tuning {
     else if (k == "ar_tail_step") ar_tail_step = value;
     else if (k == "split_gemm") split_gemm = value;
     else if (k == "bench_grid_boxes") bench_grid_boxes = value;
+    else if (k == "detector_only") detector_only = value;
     else if (k == "craft_products") craft_products = value == 4 ? 4 : 3;
     else if (k == "enc_ln_pairs") enc_ln_pairs = value;
     else if (k == "enc_fc2_pairs") enc_fc2_pairs = value;
@@ -1253,6 +1255,7 @@ struct Engine {
     B.rects.clear(); B.page_of.clear();        // x0,y0,x1,y1,page per crop; page index per crop
     host_us[1] = host_us[2] = host_us[3] = 0.f;
     for (int gi = 0; gi < groups; ++gi) ccl_collect(gi * GP, std::min(GP, n - gi * GP), gi, B.H2, B.W2, dets);
+    if (tn.detector_only) for (auto& d : dets) d.clear();   // profiling (tools/prof_pages.py): the detector and CCL run, nothing goes to the recogniser
     if (tn.bench_grid_boxes) {   // benchmark workload control (tuning key "bench_grid_boxes", tuatara_hip_debug.h): the detector's work is done (and timed); 40 fixed boxes per page go on
       for (int i = 0; i < n; ++i) {
         dets[i].clear();

@@ -82,8 +82,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
   // GELU epilogue: Phi(x) by linear interpolation in an 8 KiB table kept in LDS behind the operand stages (the
   // erf polynomial + exp + rcp form made the epilogue, not the MFMAs, the longest part of the K = 384 PARSeq GEMMs)
   float2* const glut = reinterpret_cast<float2*>(smem + C::LDS);
-  if (!SP && p.act == kActGelu) {
-    for (int i = tid; i < 512; i += C::NT) reinterpret_cast<uint4*>(glut)[i] = reinterpret_cast<const uint4*>(p.gelu_lut)[i];
+  if (p.act == kActGelu && p.gelu_lut) {   // (split mode: the Hermite table of gelu_hermite(), 1026 entries)
+    for (int i = tid; i < (SP ? 513 : 512); i += C::NT) reinterpret_cast<uint4*>(glut)[i] = reinterpret_cast<const uint4*>(p.gelu_lut)[i];
   }   // visible after the first K-step barrier
 
   // ---- persistent, XCD-aware tile schedule.  Workgroups bid and bid+8 share an XCD (round-robin placement, speed only);
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
           for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         } else if (p.act == kActGelu) {
   #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = SP ? gelu_exact(v[e]) : gelu_lut(v[e], glut);   // (fp32-equivalent mode: erf, as the f32 kernels)
+          for (int e = 0; e < 8; ++e) v[e] = SP ? (p.gelu_lut ? gelu_hermite(v[e], glut) : gelu_exact(v[e])) : gelu_lut(v[e], glut);
         }
         if constexpr (SP) {
           if (p.out && valid) st_split_n(p.out, (int64_t)m, p.out_ld, n, v, p.out_planes);
@@ -470,8 +470,8 @@ static void launch_g2(const ConvParams& p, hipStream_t s) {
   using C = G2Cfg<BM, BN, WM, WN, XST>;
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
   static PerDeviceOnce once;
-  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WM, WN, MINB, XST, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + (XST == 2 ? 8192 : 0))); });
-  const size_t lds = C::LDS + (p.act == kActGelu && !SP ? 8192 : 0);
+  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WM, WN, MINB, XST, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + (C::LDS + 8208 <= 160 * 1024 ? 8208 : 0))); });
+  const size_t lds = C::LDS + (p.act == kActGelu && p.gelu_lut ? (SP ? 8208 : 8192) : 0);
   // persistent grid: as many workgroups as fit the chip at once (a multiple of 8: one share per XCD), never more than tiles
   const int per_cu = std::max(1, std::min((int)(160 * 1024 / lds), 2048 / C::NT));
   const int cap = num_cus() * per_cu / 8 * 8;
@@ -497,6 +497,29 @@ const void* gelu_lut_for_current_device() {
     void* d = nullptr;
     TTR_HIP_CHECK(hipMalloc(&d, 8192));
     TTR_HIP_CHECK(hipMemcpy(d, h.data(), 8192, hipMemcpyHostToDevice));
+    lut[dev] = d;
+  }
+  return lut[dev];
+}
+
+// Hermite table of the split mode's GELU epilogue: float2[1026] {Phi(x_i), dPhi/dx(x_i) / 64}, x_i = -8 + i / 64 (host erf / exp in double)
+const void* gelu_hermite_lut_for_current_device() {
+  static std::mutex mu;
+  static const void* lut[64] = {nullptr};
+  int dev = 0;
+  TTR_HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  if (dev < 0 || dev >= 64) throw std::runtime_error("gemm2: device index out of range");
+  if (!lut[dev]) {
+    std::vector<float> h(2 * 1026);
+    for (int i = 0; i < 1026; ++i) {
+      const double x = -8.0 + i / 64.0;
+      h[2 * i] = (float)(0.5 * (1.0 + std::erf(x * 0.70710678118654752440)));
+      h[2 * i + 1] = (float)(std::exp(-0.5 * x * x) * 0.39894228040143267794 / 64.0);
+    }
+    void* d = nullptr;
+    TTR_HIP_CHECK(hipMalloc(&d, h.size() * 4));
+    TTR_HIP_CHECK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     lut[dev] = d;
   }
   return lut[dev];
@@ -539,7 +562,7 @@ const char* gemm2_check(const ConvParams& p) {
 void launch_gemm2(const ConvParams& p_in, int cfg, hipStream_t s) {
   if (const char* e = gemm2_check(p_in)) throw std::runtime_error(e);
   ConvParams p = p_in;
-  p.gelu_lut = p.act == kActGelu ? gelu_lut_for_current_device() : nullptr;
+  p.gelu_lut = p.act == kActGelu ? (p.split ? gelu_hermite_lut_for_current_device() : gelu_lut_for_current_device()) : nullptr;
   if (cfg == 0 && p.split && g_split_cfg) cfg = g_split_cfg;
   if (cfg == 0 && p.split && p.Cout > 64) {
     // split mode (reuse-order K loop): 256 x 128 tiles, one workgroup per CU - the 256 x 256 tile with its 160 KB of LDS loses to it on
@@ -566,7 +589,8 @@ void launch_gemm2(const ConvParams& p_in, int cfg, hipStream_t s) {
   // X ring depth: 3 (activation tiles two K steps ahead) wherever the LDS budget keeps the configuration's workgroups-per-CU;
   // the GELU table (8 KiB) pushes the 256x256 and 128x128 tiles back to 2
   const bool deep = g_x_ring3 && p.act != kActGelu;
-  if (p.split) {   // three-slot X ring everywhere (the GELU epilogue of this mode uses erf: no table in LDS): the reuse-order K loop
+  if (p.split && cfg == 1) p.gelu_lut = nullptr;   // 256 x 256 tiles fill the LDS: erf instead of the table
+  if (p.split) {   // three-slot X ring everywhere: the reuse-order K loop
     const bool ru = g_split_reuse != 0 || p.split == 3;
     if (p.split == 3) {
       switch (cfg) {
