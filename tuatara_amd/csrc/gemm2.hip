@@ -412,6 +412,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
           for (int e = 0; e < 8; ++e) v[e] = SP ? (p.gelu_lut ? gelu_hermite(v[e], glut) : gelu_exact(v[e])) : gelu_lut(v[e], glut);
         }
         if constexpr (SP) {
+          if (p.dbg_flags & 1) { if (v[0] == 1.2345e30f) reinterpret_cast<float*>(p.out)[0] = v[1]; continue; }   // timing experiment: no output stores
           if (p.out && valid) st_split_n(p.out, (int64_t)m, p.out_ld, n, v, p.out_planes);
           if (p.out_relu && valid) {
             float w[8];
@@ -527,6 +528,8 @@ const void* gelu_hermite_lut_for_current_device() {
 
 static int g_x_ring3 = 1;
 void set_gemm2_x_ring3(int v) { g_x_ring3 = v; }
+static int g_split_dbg = 0;     // split mode timing experiments (results are wrong): 1 = no output stores
+void set_gemm2_split_dbg(int v) { g_split_dbg = v; }
 static int g_split_cfg = 0;     // split mode: force a tile configuration (0 = automatic)
 void set_gemm2_split_cfg(int v) { g_split_cfg = v; }
 static int g_split_reuse = 1;   // split mode: 1 = reuse-order K loop (X0 and W0b staged once per k0), 0 = plane-major order with a two-slot X ring
@@ -589,6 +592,7 @@ void launch_gemm2(const ConvParams& p_in, int cfg, hipStream_t s) {
   // X ring depth: 3 (activation tiles two K steps ahead) wherever the LDS budget keeps the configuration's workgroups-per-CU;
   // the GELU table (8 KiB) pushes the 256x256 and 128x128 tiles back to 2
   const bool deep = g_x_ring3 && p.act != kActGelu;
+  if (p.split) p.dbg_flags = g_split_dbg;
   if (p.split && cfg == 1) p.gelu_lut = nullptr;   // 256 x 256 tiles fill the LDS: erf instead of the table
   if (p.split) {   // three-slot X ring everywhere: the reuse-order K loop
     const bool ru = g_split_reuse != 0 || p.split == 3;
