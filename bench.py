@@ -433,6 +433,12 @@ def main():
         # the other precisions on the same workload
         if args.precision == "f16x4":
             eb = Engine(wdir, precision="bf16", device=local_rank, bench_grid_boxes=grid)
+            latb = []
+            for _ in range(args.latency_iters):
+                t1 = time.perf_counter()
+                eb.pages_to_data_dev(one, 1, H, Wd)
+                latb.append((time.perf_counter() - t1) * 1e3)
+            out["bf16_p50_page_latency_ms"] = float(np.median(latb)) if latb else None
             out["bf16_pages_per_s"], _ = rate(eb, 6)
             eb.set_tuning(b"ar_early_exit", 0)
             out["bf16_full_ar_pages_per_s"], _ = rate(eb, 4)
