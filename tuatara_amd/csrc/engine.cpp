@@ -70,6 +70,7 @@ struct Tuning {
   int fuse_first = 1;         // bf16: CRAFT conv1_1 fused into conv1_2's loader (conv3p FIRST)
   int enc_chunk = 0;          // crops per encoder group (0 = all crops at once)
   int enc_ln_pairs = 1;       // split-operand engines, PARSeq encoder: LayerNorm outputs as pairs (qkv and fc1 on three MFMAs per product: their inputs tolerate ~23.5 bits - 3 x 1280 crops: max |dlogit| 7.6e-4 vs 6.9e-4 with triples; proj and fc2 keep exact triples); 0 = triples
+  int dec_planes = 1;         // split-operand engines: the decoder's layers hand each other planes (13 launches per AR step instead of 20); 0 = fp32 tensors + split passes
   int enc_fc2_pairs = 1;      // ... and the MLP hidden activation as pairs (fc2 on three MFMAs per product; 3 x 640 crops: max |dlogit| 5.1 - 6.7e-4 vs 5.6 - 7.6e-4 with triples); the attention output - the projection input - stays an exact triple: the one encoder linear whose result moves with the 24th bit (oracle/splitsim.py)
   int craft_products = 3;     // split-operand engines, CRAFT: 3 = activation pairs (~23.5 bits; the heat map stays at fp32 noise level), 4 = exact triples
   int detector_only = 0;      // profiling: drop every detected box, so that a batch runs the detector + CCL only
@@ -97,6 +98,7 @@ struct Tuning {
     else if (k == "craft_products") craft_products = value == 4 ? 4 : 3;
     else if (k == "enc_ln_pairs") enc_ln_pairs = value;
     else if (k == "enc_fc2_pairs") enc_fc2_pairs = value;
+    else if (k == "dec_planes") dec_planes = value;
     else if (k == "split_conv3p") split_conv3p = value;
     else if (k == "split_planes") split_planes = value;
     else if (k == "craft_group") craft_group = value < 1 ? 1 : (value > 32 ? 32 : value);
@@ -332,7 +334,7 @@ struct Engine {
   // workspaces
   std::vector<std::unique_ptr<DevBuf>> craft_ws;  // per-layer activations
   int craft_ws_npl = 0;                           // planes per value the split CRAFT workspaces were laid out for
-  DevBuf pq_ws[16];
+  DevBuf pq_ws[24];
   DevBuf canvas, heat, staging_img, crops, rects_dev, logits, ar_logits, ids_dev, tokens;
   CclBatch ccl;
   PinnedBuf h_counters, h_cand, h_rows, h_rects[2], h_ids[2];   // pinned staging of the small host <-> device transfers
@@ -858,13 +860,14 @@ struct Engine {
   // ---- PARSeq
   // split-operand linear on planes: in [M][3 K] -> out (planes [M][3 out_ld] or fp32 [M][out_ld]) and / or out_f32 (+ fp32 residual)
   void sgemm(const Linear& L, const void* in_planes, int M, void* out, int out_ld, int act, int out_planes,
-             float* out_f32 = nullptr, int out_f32_ld = 0, const float* resid = nullptr, int resid_ld = 0, int np = 4) {
+             float* out_f32 = nullptr, int out_f32_ld = 0, const float* resid = nullptr, int resid_ld = 0, int np = 4, int resid_mod = 0) {
     if (!L.ws.p) throw std::runtime_error("split GEMM: the layer has no weight planes");
     ConvParams p{};
     p.in0 = in_planes; p.C0 = L.k; p.B = 1; p.H = 1; p.W = M; p.ks = 1; p.dil = 1;
     p.wgt = L.ws.p; p.bias = L.b.as<float>(); p.split = np; p.out_scale = L.inv_scale; p.out_planes = out_planes == 1 ? 3 : out_planes;   // (1 = triples)
-    p.out = out; p.out_ld = out_ld; p.out_f32 = out_f32; p.out_f32_ld = out_f32_ld; p.resid = resid; p.resid_ld = resid_ld;
+    p.out = out; p.out_ld = out_ld; p.out_f32 = out_f32; p.out_f32_ld = out_f32_ld; p.resid = resid; p.resid_ld = resid_ld; p.resid_mod = resid_mod;
     p.Cout = L.cout; p.M = M; p.act = act;
+    p.skip = cur_skip; p.skip_n = cur_skip_n;
     if (const char* e = gemm2_check(p)) throw std::runtime_error(e);
     timed(2.0 * M * L.cout * L.k * np, [&] { launch_gemm2(p, 0, stream); });
   }
@@ -904,6 +907,26 @@ struct Engine {
   size_t kvcache_zeroed = 0;
   void ln(const float* x, const std::string& name, float eps, void* out, int M) {
     launch_layernorm(prec, x, 384, pqf.at(name + ".weight").as<float>(), pqf.at(name + ".bias").as<float>(), eps, out, 384, M, 384, stream, cur_skip, cur_skip_n);
+  }
+
+  // The decoder tail of the split-operand engines: the same layers as decoder_tail() below, handing each other f16 planes (split.h) instead of
+  // fp32 tensors + split passes - 13 launches per AR step instead of 20.  sa: planes [rows][3 * 384] (self-attention output).
+  void decoder_tail_split(const void* sa, int N, int R, const float* resid_pos, int resid_mod, float* tgt, void* pa, void* pb, void* p1536, float* q384,
+                          void* t384, const void* kvmem, float* logits_out, int logits_ld, const int* done_tok = nullptr, int done_col = 0) {
+    const int rows = N * R;
+    const std::string d = "decoder.layers.0.";
+    auto lnp = [&](const std::string& nm, void* out) {
+      launch_layernorm_planes(tgt, 384, pqf.at(nm + ".weight").as<float>(), pqf.at(nm + ".bias").as<float>(), 1e-5f, out, rows, stream, 3, cur_skip, cur_skip_n);
+    };
+    sgemm(pq.at("self_out"), sa, rows, nullptr, 0, kActNone, 0, tgt, 384, resid_pos, 384, 4, resid_mod);      // tgt = query + self_attn
+    lnp(d + "norm1", pa);
+    sgemm(pq.at("cross_q"), pa, rows, q384, 384, kActNone, 0);                                                   // fp32 queries for the attention kernel
+    launch_dec_cross_attn(kF32, q384, kvmem, pb, N, R, stream, cur_skip, cur_skip_n, done_tok, done_col, 3);    // planes out
+    sgemm(pq.at("cross_out"), pb, rows, nullptr, 0, kActNone, 0, tgt, 384, tgt, 384);                            // tgt += cross_attn
+    lnp(d + "norm2", pa);
+    sgemm(pq.at("ffn1"), pa, rows, p1536, 1536, kActGelu, 3);
+    sgemm(pq.at("ffn2"), p1536, rows, nullptr, 0, kActNone, 0, tgt, 384, tgt, 384);                              // tgt += ffn
+    ln_gemm(tgt, "decoder.norm", 1e-5f, t384, pq.at("head"), rows, nullptr, 0, kActNone, logits_out, logits_ld);
   }
 
   // decoder tail shared by the AR steps (R = 1) and the refinement pass (R = 26):
@@ -1041,6 +1064,13 @@ struct Engine {
     void* d384b = (pq_ws[8].ensure((size_t)N * 26 * E * es), pq_ws[8].p);
     void* d1536 = (pq_ws[9].ensure((size_t)N * 26 * 1536 * es), pq_ws[9].p);
     float* step_logits = (float*)(pq_ws[10].ensure((size_t)N * 26 * 95 * 4), pq_ws[10].p);
+    // split-operand engines: the decoder's layers hand each other planes (decoder_tail_split)
+    const bool dec_split = prec == kSplit && tn.split_gemm && tn.split_planes && tn.dec_planes;
+    void *dpa = nullptr, *dpb = nullptr, *dp1536 = nullptr, *dsa = nullptr;
+    if (dec_split) {
+      dpa = (pq_ws[14].ensure((size_t)N * 26 * E * 6), pq_ws[14].p); dpb = (pq_ws[15].ensure((size_t)N * 26 * E * 6), pq_ws[15].p);
+      dp1536 = (pq_ws[16].ensure((size_t)N * 26 * 1536 * 6), pq_ws[16].p); dsa = (pq_ws[17].ensure((size_t)N * 26 * E * 6), pq_ws[17].p);
+    }
     tokens.ensure((size_t)N * 26 * 4);
     int* tk = tokens.as<int>();
     launch_fill_i32(tk, 96, N * 26, 1, stream);   // PAD
@@ -1118,21 +1148,35 @@ struct Engine {
         p.out = (char*)kvcache + (size_t)i * 768 * es; p.out_ld = 26 * 768;
         p.Cout = L.cout; p.M = N; p.act = kActNone;
         igemm(p, 2.0 * N * L.cout * L.k);
+      } else if (dec_split) {
+        launch_dec_embed_ln(prec, tk, emb, posq, gc, bc, 1e-5f, dpa, N, i, i + 1, stream, cur_skip, cur_skip_n, 3);
+        sgemm(pq.at("self_kv"), dpa, N, (char*)kvcache + (size_t)i * 768 * 4, 26 * 768, kActNone, 0);
       } else {
         launch_dec_embed_ln(prec, tk, emb, posq, gc, bc, 1e-5f, t384, N, i, i + 1, stream, cur_skip, cur_skip_n);
         gemm(pq.at("self_kv"), t384, N, (char*)kvcache + (size_t)i * 768 * es, 26 * 768, kActNone);
       }
       if (i >= nsteps) break;
+      const int* crop_done = early && tn.ar_early_exit >= 1 && tn.ar_crop_exit ? tk : nullptr;
+      if (dec_split) {
+        launch_dec_self_attn(prec, qself.as<float>(), kvcache, tk, dsa, N, 1, i, 0, stream, cur_skip, cur_skip_n, 3);
+        decoder_tail_split(dsa, N, 1, posq + (size_t)i * E, 1, tgt, dpa, dpb, dp1536, (float*)d384b, t384, kvmem, ar + (size_t)i * 95, 26 * 95, crop_done, i);
+      } else {
       launch_dec_self_attn(prec, qself.as<float>(), kvcache, tk, att, N, 1, i, 0, stream, cur_skip, cur_skip_n);
-      decoder_tail(att, N, 1, posq + (size_t)i * E, 1, tgt, t384, d384b, d1536, kvmem, ar + (size_t)i * 95, 26 * 95, early && tn.ar_early_exit >= 1 && tn.ar_crop_exit ? tk : nullptr, i);
+      decoder_tail(att, N, 1, posq + (size_t)i * E, 1, tgt, t384, d384b, d1536, kvmem, ar + (size_t)i * 95, 26 * 95, crop_done, i);
+      }
       if (i + 1 < 26 && !tok_fuse) launch_argmax(ar + (size_t)i * 95, 26 * 95, 95, tk, 26, i + 1, N, stream, cur_skip, cur_skip_n, early ? ar_done.as<int>() : nullptr, 0);
     }
     cur_skip = nullptr; cur_skip_n = 0;
     prof_stage = 1;
     }
     // ---- refinement pass (cloze mask + EOS key padding), R = 26 query rows per crop
+    if (dec_split) {
+      launch_dec_self_attn(prec, qself.as<float>(), kvcache, tk, dsa, N, 26, 0, 1, stream, nullptr, 0, 3);
+      decoder_tail_split(dsa, N, 26, posq, 26, tgt, dpa, dpb, dp1536, (float*)d384b, t384, kvmem, d_logits, 95);
+    } else {
     launch_dec_self_attn(prec, qself.as<float>(), kvcache, tk, att, N, 26, 0, 1, stream);
     decoder_tail(att, N, 26, posq, 26, tgt, t384, d384b, d1536, kvmem, d_logits, 95);
+    }
     launch_argmax(d_logits, 95, 95, d_ids, 1, 0, N * 26, stream);
   }
 

@@ -77,7 +77,8 @@ void launch_split_planes(const float* in, int ld, void* out, int64_t M, int C, i
 void launch_maxpool3x3s1_planes(const void* in, void* out, int B, int H, int W, int C, hipStream_t s, int planes = 3);
 void launch_upsample2x_planes(const void* in, void* out, int B, int H, int W, int C, hipStream_t s, int planes = 3);
 // LayerNorm over 384 columns of fp32 rows (stride in_ld) -> planes [M][3 * 384]
-void launch_layernorm_planes(const float* in, int in_ld, const float* gamma, const float* beta, float eps, void* out, int M, hipStream_t s, int planes = 3);
+void launch_layernorm_planes(const float* in, int in_ld, const float* gamma, const float* beta, float eps, void* out, int M, hipStream_t s, int planes = 3,
+                             const int* skip = nullptr, int skip_n = 0);
 // attn_split.hip: ViT encoder self-attention, qkv planes [N*128][3][1152] -> planes [N*128][3][384]
 void launch_attn_enc_split(const void* qkv_planes, void* out_planes, int N, hipStream_t s);
 // CRAFT's conv1_1 + bias + ReLU from the u8 canvas into planes [M][3 * 64]; wgt_planes f16 [64][3][32] (k = (ky*3+kx)*3+c, 27 used)
@@ -110,15 +111,15 @@ void launch_qkv_attn(const bf16* x, const bf16* w, const float* bias, bf16* out,
 void set_attn_impl(int v);                                                               // 0: bf16 also uses the first generation
 // content token embedding + norm_c.  rows (n, i) for i in [i0,i1): out row n*(i1-i0)+(i-i0)
 void launch_dec_embed_ln(Precision prec, const int* tokens, const float* emb, const float* pos_q, const float* gamma, const float* beta, float eps,
-                         void* out, int N, int i0, int i1, hipStream_t s, const int* skip = nullptr, int skip_n = 0);
+                         void* out, int N, int i0, int i1, hipStream_t s, const int* skip = nullptr, int skip_n = 0, int planes = 0);   // planes = 3 (fp32 engines): f16 triple planes out
 // self attention of R query rows per crop against the K/V cache [N][26][768].
 // mode 0 (AR): R == 1, query index qi0, keys 0..qi0.  mode 1 (refine): R == 26, cloze mask + EOS key padding.
 // skip / skip_n: the kernel returns at once when *skip >= skip_n (AR early exit, ConvParams::skip); bf16 per-row kernels only
 void launch_dec_self_attn(Precision prec, const float* q /*[26][384] f32*/, const void* kvcache, const int* tokens, void* out, int N, int R, int qi0, int mode, hipStream_t s,
-                          const int* skip = nullptr, int skip_n = 0);
+                          const int* skip = nullptr, int skip_n = 0, int planes = 0);
 // cross attention of rows [N*R] (Q: T [N*R][384]) against kvmem T [N*128][768]
 void launch_dec_cross_attn(Precision prec, const void* q, const void* kvmem, void* out, int N, int R, hipStream_t s, const int* skip = nullptr, int skip_n = 0,
-                           const int* done_tok = nullptr, int done_col = 0);   // done_tok [N][26]: AR steps skip crops with EOS (0) in columns 1 .. done_col
+                           const int* done_tok = nullptr, int done_col = 0, int planes = 0);   // done_tok [N][26]: AR steps skip crops with EOS (0) in columns 1 .. done_col
 // tokens[n*tok_ld + col] = argmax over C of logits[n*ld ..]
 // skip / skip_n: AR early exit; done_count: incremented once per crop whose FIRST EOS (id eos, columns 1 .. col) is the token formed here
 void launch_argmax(const float* logits, int ld, int C, int* tokens, int tok_ld, int col, int N, hipStream_t s, const int* skip = nullptr, int skip_n = 0,

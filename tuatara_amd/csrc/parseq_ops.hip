@@ -5,6 +5,7 @@
 // run inside the TorchScript module the reference calls at tuatara.cpp:307.
 #include "common.h"
 #include "kernels.h"
+#include "split.h"
 
 namespace ttr {
 
@@ -216,7 +217,7 @@ void launch_attn_enc(Precision prec, const void* qkv, void* out, int N, hipStrea
 template <typename T>
 __global__ void dec_embed_ln_kernel(const int* __restrict__ tokens, const float* __restrict__ emb, const float* __restrict__ pos_q,
                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, T* __restrict__ out, int N, int i0, int i1,
-                                    const int* skip, int skip_n) {
+                                    const int* skip, int skip_n, int planes) {
   if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;   // AR early exit (see ConvParams::skip)
   const int R = i1 - i0;
   int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -238,16 +239,20 @@ __global__ void dec_embed_ln_kernel(const int* __restrict__ tokens, const float*
   for (int k = 0; k < 6; ++k) { float d = v[k] - mean; q += d * d; }
   const float rstd = rsqrtf(wave_sum(q) * (1.0f / 384) + eps);
 #pragma unroll
-  for (int k = 0; k < 6; ++k) { int c = lane + 64 * k; out[(int64_t)row * 384 + c] = (T)((v[k] - mean) * rstd * gamma[c] + beta[c]); }
+  for (int k = 0; k < 6; ++k) {
+    int c = lane + 64 * k;
+    const float y = (v[k] - mean) * rstd * gamma[c] + beta[c];
+    if (planes) st_split_one(out, row, 384, c, y, planes); else out[(int64_t)row * 384 + c] = (T)y;
+  }
 }
 
 void launch_dec_embed_ln(Precision prec, const int* tokens, const float* emb, const float* pos_q, const float* gamma, const float* beta, float eps,
-                         void* out, int N, int i0, int i1, hipStream_t s, const int* skip, int skip_n) {
+                         void* out, int N, int i0, int i1, hipStream_t s, const int* skip, int skip_n, int planes) {
   int rows = N * (i1 - i0);
   if (rows <= 0) return;
   dim3 grid((rows + 3) / 4);
-  if (prec == kBF16) hipLaunchKernelGGL(dec_embed_ln_kernel<bf16>, grid, dim3(256), 0, s, tokens, emb, pos_q, gamma, beta, eps, (bf16*)out, N, i0, i1, skip, skip_n);
-  else hipLaunchKernelGGL(dec_embed_ln_kernel<float>, grid, dim3(256), 0, s, tokens, emb, pos_q, gamma, beta, eps, (float*)out, N, i0, i1, skip, skip_n);
+  if (prec == kBF16) hipLaunchKernelGGL(dec_embed_ln_kernel<bf16>, grid, dim3(256), 0, s, tokens, emb, pos_q, gamma, beta, eps, (bf16*)out, N, i0, i1, skip, skip_n, 0);
+  else hipLaunchKernelGGL(dec_embed_ln_kernel<float>, grid, dim3(256), 0, s, tokens, emb, pos_q, gamma, beta, eps, (float*)out, N, i0, i1, skip, skip_n, planes);
 }
 
 // ------------------------------------------------------------------ decoder self attention
@@ -258,7 +263,7 @@ void launch_dec_embed_ln(Precision prec, const int* tokens, const float* emb, co
 //   mode 1 (refine): key j hidden iff j == qi+1 (cloze) or tokens[n][0..j] contains EOS (key padding).
 template <typename T>
 __global__ __launch_bounds__(384) void dec_self_attn_kernel(const float* __restrict__ q, const T* __restrict__ kv, const int* __restrict__ tokens,
-                                                            T* __restrict__ out, int R, int qi0, int mode, const int* skip, int skip_n) {
+                                                            T* __restrict__ out, int R, int qi0, int mode, const int* skip, int skip_n, int planes) {
   if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;   // AR early exit (see ConvParams::skip)
   __shared__ float sq[384];
   __shared__ float sp[12][28];
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(384) void dec_self_attn_kernel(const float* __restr
     int h = t >> 5;
     float acc = 0.f;
     for (int j = 0; j < nkeys; ++j) acc += sp[h][j] * (float)kvn[j * 768 + 384 + t];
-    out[(int64_t)row * 384 + t] = (T)acc;
+    if (planes) st_split_one(out, row, 384, t, acc, planes); else out[(int64_t)row * 384 + t] = (T)acc;
   }
 }
 
@@ -389,7 +394,7 @@ static int g_self_refine = 1;
 void set_dec_self_refine(int v) { g_self_refine = v; }
 
 void launch_dec_self_attn(Precision prec, const float* q, const void* kvcache, const int* tokens, void* out, int N, int R, int qi0, int mode, hipStream_t s,
-                          const int* skip, int skip_n) {
+                          const int* skip, int skip_n, int planes) {
   if (N <= 0) return;
   if (prec == kBF16 && mode == 1 && R == 26 && g_self_refine) {
     static PerDeviceOnce once;
@@ -398,15 +403,15 @@ void launch_dec_self_attn(Precision prec, const float* q, const void* kvcache, c
     return;
   }
   dim3 grid(N * R);
-  if (prec == kBF16) hipLaunchKernelGGL(dec_self_attn_kernel<bf16>, grid, dim3(384), 0, s, q, (const bf16*)kvcache, tokens, (bf16*)out, R, qi0, mode, skip, skip_n);
-  else hipLaunchKernelGGL(dec_self_attn_kernel<float>, grid, dim3(384), 0, s, q, (const float*)kvcache, tokens, (float*)out, R, qi0, mode, skip, skip_n);
+  if (prec == kBF16) hipLaunchKernelGGL(dec_self_attn_kernel<bf16>, grid, dim3(384), 0, s, q, (const bf16*)kvcache, tokens, (bf16*)out, R, qi0, mode, skip, skip_n, 0);
+  else hipLaunchKernelGGL(dec_self_attn_kernel<float>, grid, dim3(384), 0, s, q, (const float*)kvcache, tokens, (float*)out, R, qi0, mode, skip, skip_n, planes);
 }
 
 // ------------------------------------------------------------------ decoder cross attention
 // one 384-thread workgroup per query row; 12 heads x 32 dims against the crop's 128 memory tokens.
 template <typename T>
 __global__ __launch_bounds__(384) void dec_cross_attn_kernel(const T* __restrict__ q, const T* __restrict__ kvmem, T* __restrict__ out, int R,
-                                                             const int* skip, int skip_n, const int* done_tok, int done_col) {
+                                                             const int* skip, int skip_n, const int* done_tok, int done_col, int planes) {
   if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;   // AR early exit (see ConvParams::skip)
   __shared__ float sq[384];
   __shared__ float sp[12][128];
@@ -447,7 +452,7 @@ __global__ __launch_bounds__(384) void dec_cross_attn_kernel(const T* __restrict
     int h = t >> 5;
     float acc = 0.f;
     for (int j = 0; j < 128; ++j) acc += sp[h][j] * (float)kvn[j * 768 + 384 + t];
-    out[(int64_t)row * 384 + t] = (T)acc;
+    if (planes) st_split_one(out, row, 384, t, acc, planes); else out[(int64_t)row * 384 + t] = (T)acc;
   }
 }
 
@@ -540,12 +545,12 @@ static int g_cross_mfma = 1;
 void set_dec_cross_mfma(int v) { g_cross_mfma = v; }
 
 void launch_dec_cross_attn(Precision prec, const void* q, const void* kvmem, void* out, int N, int R, hipStream_t s, const int* skip, int skip_n,
-                           const int* done_tok, int done_col) {
+                           const int* done_tok, int done_col, int planes) {
   if (N <= 0) return;
   if (prec == kBF16 && g_cross_mfma && (R == 26 || g_cross_mfma == 2)) return launch_dec_cross_attn_mfma((const bf16*)q, (const bf16*)kvmem, (bf16*)out, N, R, s);   // refinement pass (attn_dec2.hip); 2: the AR steps' single row too
   dim3 grid(N * R);
   if (prec == kBF16) hipLaunchKernelGGL(dec_cross_attn_rows_kernel, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)kvmem, (bf16*)out, R, skip, skip_n, R == 1 ? done_tok : nullptr, done_col);
-  else hipLaunchKernelGGL(dec_cross_attn_kernel<float>, grid, dim3(384), 0, s, (const float*)q, (const float*)kvmem, (float*)out, R, skip, skip_n, R == 1 ? done_tok : nullptr, done_col);
+  else hipLaunchKernelGGL(dec_cross_attn_kernel<float>, grid, dim3(384), 0, s, (const float*)q, (const float*)kvmem, (float*)out, R, skip, skip_n, R == 1 ? done_tok : nullptr, done_col, planes);
 }
 
 // ------------------------------------------------------------------ argmax (first maximal index, like torch.argmax on CPU)

@@ -85,6 +85,18 @@ __device__ __forceinline__ void st_split_n(void* out, int64_t m, int ld, int n, 
   }
 }
 
+// one value -> element c of row `row` of a tensor with `planes` planes (3 = triple; 0 = plain fp32 [row][ld]): for the thread-per-element kernels
+__device__ __forceinline__ void st_split_one(void* out, int64_t row, int ld, int c, float v, int planes) {
+  if (planes == 3) {
+    f16x2 a, b, d;
+    split3_pair(v, 0.f, a, b, d);
+    f16* o = reinterpret_cast<f16*>(out) + row * (3 * (int64_t)ld) + c;
+    o[0] = a[0]; o[ld] = b[0]; o[2 * ld] = d[0];
+  } else {
+    reinterpret_cast<float*>(out)[row * ld + c] = v;
+  }
+}
+
 // K quarter q of the four products (triple) -> activation plane / weight plane; the pair form uses quarters 0, 3, 1
 __host__ __device__ __forceinline__ constexpr int split_xplane(int q) { return q == 3 ? 0 : q; }
 __host__ __device__ __forceinline__ constexpr int split_wplane(int q) { return q == 0 ? 0 : q == 3 ? 2 : 1; }

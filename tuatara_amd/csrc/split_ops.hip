@@ -234,7 +234,8 @@ namespace ttr {
 namespace {
 template <int NPL>
 __global__ __launch_bounds__(256) void layernorm_planes_kernel(const float* __restrict__ in, int in_ld, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              float eps, f16* __restrict__ out, int M) {
+                                                              float eps, f16* __restrict__ out, int M, const int* skip, int skip_n) {
+  if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;   // AR early exit (see ConvParams::skip)
   constexpr int D = 384;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
@@ -269,10 +270,11 @@ __global__ __launch_bounds__(256) void layernorm_planes_kernel(const float* __re
 }
 }  // namespace
 
-void launch_layernorm_planes(const float* in, int in_ld, const float* gamma, const float* beta, float eps, void* out, int M, hipStream_t s, int planes) {
+void launch_layernorm_planes(const float* in, int in_ld, const float* gamma, const float* beta, float eps, void* out, int M, hipStream_t s, int planes,
+                             const int* skip, int skip_n) {
   if (M <= 0) return;
   if (in_ld % 4 || (((uintptr_t)in | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15)) throw std::runtime_error("layernorm (planes): 16-byte alignment");
-  if (planes == 2) hipLaunchKernelGGL(layernorm_planes_kernel<2>, dim3((M + 3) / 4), dim3(256), 0, s, in, in_ld, gamma, beta, eps, (f16*)out, M);
-  else hipLaunchKernelGGL(layernorm_planes_kernel<3>, dim3((M + 3) / 4), dim3(256), 0, s, in, in_ld, gamma, beta, eps, (f16*)out, M);
+  if (planes == 2) hipLaunchKernelGGL(layernorm_planes_kernel<2>, dim3((M + 3) / 4), dim3(256), 0, s, in, in_ld, gamma, beta, eps, (f16*)out, M, skip, skip_n);
+  else hipLaunchKernelGGL(layernorm_planes_kernel<3>, dim3((M + 3) / 4), dim3(256), 0, s, in, in_ld, gamma, beta, eps, (f16*)out, M, skip, skip_n);
 }
 }  // namespace ttr
