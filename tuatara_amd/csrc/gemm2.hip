@@ -45,7 +45,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
-template <int BM, int BN, int WM, int WN, int XST = 2>
+template <int BM, int BN, int WM, int WN, int XST = 2, int WST = 2>
 struct G2Cfg {
   static constexpr int NW = WM * WN, NT = NW * 64;
   static constexpr int TM = BM / WM, TN = BN / WN;   // wave tile
@@ -53,7 +53,7 @@ struct G2Cfg {
   static constexpr int XP = BM / 8, WP = BN / 8;     // 1-KiB pieces (8 rows x 128 B) per operand tile
   static constexpr int XPW = XP / NW, WPW = WP / NW;  // pieces per wave
   static constexpr int XBYTES = BM * 128, WBYTES = BN * 128;   // one stage of each operand
-  static constexpr int LDS = XST * XBYTES + 2 * WBYTES;        // X ring of XST stages, W ring of 2
+  static constexpr int LDS = XST * XBYTES + WST * WBYTES;      // X ring of XST stages, W ring of WST (2; 3: split mode, w0b formed in registers)
   static_assert(XP % NW == 0 && WP % NW == 0, "tile pieces must divide over the waves");
   static_assert(TN % 32 == 0 && TM % 16 == 0, "wave tile");
 };
@@ -67,9 +67,14 @@ struct G2Cfg {
 // accumulator times p.out_scale is the fp32 product.  Every output (out, out_relu, out_pool, out_f32) is fp32 then, or, with
 // p.out_planes, out / out_relu / out_pool are written as the three planes of the value (row stride 3 out_ld halves).
 // NP = products per value: 0 = the bf16 kernel, 4 = exact activation triples (planes x0 | x1 | x2), 3 = activation pairs (x0 | x1).
-template <int BM, int BN, int WM, int WN, int MINB, int XST, int NP>
+// WST = 3 (split mode, big tiles): the scaled weight copy w0b = w0 / 2^11 is not staged - the phases that need it read the W0 tile and scale
+// the fragments with packed f16 multiplies (exact) - so a k0 costs X0 X1 [X2] W0 W1: 4 (5) tile loads for 3 (4) products instead of 5 (6).
+template <int BM, int BN, int WM, int WN, int MINB, int XST, int NP, int WST = 2>
 __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p) {
-  using C = G2Cfg<BM, BN, WM, WN, XST>;
+  using C = G2Cfg<BM, BN, WM, WN, XST, WST>;
+  static_assert(WST == 2 || ((WST == 3 || WST == 4) && NP != 0 && XST == 3), "three / four W slots: the split mode's reuse-order loop only");
+  constexpr bool WR = WST >= 3;     // w0b formed in registers
+  constexpr bool W4 = WST == 4;     // ... and the W tiles a whole k0 ahead (an L2 hit takes about as long as one phase: a tile requested one phase ahead is waited for)
   constexpr bool SP = NP != 0;
   static_assert(NP == 0 || NP == 4 || (NP == 3 && XST == 3), "pairs run in the reuse-order loop only");
   if (p.skip && __builtin_nontemporal_load(p.skip) >= p.skip_n) return;   // AR early exit (ConvParams::skip): uniform, before any barrier
@@ -248,15 +253,15 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
   };
   auto ru_issue_w = [&]() {
     unsigned char* sb = wring + rw_slot * C::WBYTES;
-    const int wpl = rw_j == 0 ? 0 : rw_j == 1 ? 2 : 1;
+    const int wpl = rw_j == 0 ? 0 : rw_j == 1 ? 2 : 1;          // (WR: j = 0, 1 only: w0, w1)
     const unsigned koff = (unsigned)((wpl * K + (rw_k0 << 6)) * 2);
 #pragma unroll
     for (int j = 0; j < C::WPW; ++j) {
       const unsigned vo = wb[j] == OOB ? OOB : wb[j] + koff;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sb + (j * C::NW + wave) * 1024), 16, vo, 0, 0, 0);
     }
-    rw_slot ^= 1;
-    if (++rw_j == 3) { rw_j = 0; if (++rw_k0 == nk0) { rw_k0 = 0; rw_idx += J; rw_ok = rw_idx < xcd_count; if (rw_ok) setup_w(rw_idx); } }
+    if (WR) rw_slot = rw_slot == WST - 1 ? 0 : rw_slot + 1; else rw_slot ^= 1;
+    if (++rw_j == (WR ? 2 : 3)) { rw_j = 0; if (++rw_k0 == nk0) { rw_k0 = 0; rw_idx += J; rw_ok = rw_idx < xcd_count; if (rw_ok) setup_w(rw_idx); } }
   };
 
   setup_x(idx); setup_w(idx);
@@ -264,6 +269,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
   int xr = 0, wr = 0;                                    // ring slots the MFMAs read next
   if constexpr (RU) {
     ru_issue_x(); ru_issue_w(); ru_issue_x();            // X0, W0, X1 of the first k0
+    if constexpr (W4) ru_issue_w();                      // ... and W1
   } else {
     issue_x(); issue_w();                                // X(0), W(0)
     if (XST == 3 && x_ok) { issue_x(); x_ahead = true; } // X(1)
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
     if constexpr (RU) {
       // one phase: wait until at most `pend` of this wave's loads are outstanding, barrier, fragments of (X slot xs, W slot ws), the
       // phase's loads, MFMAs
-      auto phase = [&](int xs, int ws, auto pend, bool iss_w, bool iss_x, bool strict = false) -> bool {
+      auto phase = [&](int xs, int ws, auto pend, bool iss_w, bool iss_x, bool strict = false, bool scale_w = false) -> bool {
         constexpr int PEND = decltype(pend)::value;
         if (strict) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the younger load the count allows for was not issued)
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PEND) : "memory");
@@ -298,6 +304,14 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
         for (int j = 0; j < C::NJ; ++j) fw[1][j] = *reinterpret_cast<const frag_t*>(wfrag[1] + wo + j * 2048);
 #pragma unroll
         for (int i = 0; i < C::MI; ++i) fx[1][i] = *reinterpret_cast<const frag_t*>(xfrag[1] + xo + i * 2048);
+        if (WR && scale_w) {   // w0b = w0 / 2^11 (exact unless subnormal: the same values the staged copy holds)
+          const f16 sc = (f16)(1.f / 2048.f);
+          const f16x8 scv = {sc, sc, sc, sc, sc, sc, sc, sc};
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < C::NJ; ++j) fw[kk][j] = fw[kk][j] * scv;
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -314,7 +328,57 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
       //   ph1: X1 W1 X2          need W1      -> <= XPW left          (ph0 issues W1 before X2)
       //   ph2: X2 W0b            need X1, W0b -> 0 left
       //   ph3: W0' X0'           need X2      -> <= WPW + XPW left    (X2 was complete at ph2's wait)
-      if constexpr (NP == 4) {
+      if constexpr (W4) {
+      // four W slots: W0(k0) in slot wr, W1(k0) in wr + 1, the next k0's pair behind them (mod 4), requested a whole k0 ahead.
+      // Loads in issue order (pairs):    prologue X0 W0 X1 W1 | ph0: W0' X0' | ph1: W1' | ph2: X1'
+      //   ph0 needs W0, X0 (behind them: W1 X1) | ph1 needs W1 (behind: X1 W0' X0') | ph2 needs X1 (behind: W0' X0' W1')
+      // (triples):                        prologue X0 W0 X1 W1 | ph0: W0' X2 | ph1: W1' | ph2: X0' | ph3: X1'
+      //   ph0 needs W0, X0 (behind them: X1) | ph1 nothing new | ph2 needs X1 (behind: W0' X2 W1') | ph3 needs X2 (behind: W1' X0')
+      // The last k0 of a workgroup's last tile has nothing behind its loads: it waits for everything.
+      constexpr int XW = C::XPW + C::WPW;
+      for (int k0 = 0; k0 < nk0; ++k0) {
+        const bool tail = !rw_ok || !rx_ok;
+        const int w1s = wr == 3 ? 0 : wr + 1;
+        if constexpr (NP == 3) {
+          const int x1s = xr == 2 ? 0 : xr + 1;
+          phase(xr, wr, std::integral_constant<int, XW>{}, true, true, tail);                       // (X0, W0); requests W0', X0'
+          phase(xr, w1s, std::integral_constant<int, XW + C::XPW>{}, true, false, tail);            // (X0, W1); requests W1'
+          phase(x1s, wr, std::integral_constant<int, XW + C::WPW>{}, false, true, tail, true);      // (X1, W0 / 2^11); requests X1'
+          xr = x1s == 2 ? 0 : x1s + 1;
+        } else {
+          phase(0, wr, std::integral_constant<int, C::XPW>{}, true, true, tail);                    // (X0, W0); requests W0', X2
+          phase(0, w1s, std::integral_constant<int, XW + C::XPW>{}, true, false, tail);             // (X0, W1); requests W1'
+          phase(1, wr, std::integral_constant<int, XW + C::WPW>{}, false, true, tail, true);        // (X1, W0 / 2^11); requests X0'
+          phase(2, wr, std::integral_constant<int, XW>{}, false, true, tail, true);                 // (X2, W0 / 2^11); requests X1'
+        }
+        wr = w1s == 3 ? 0 : w1s + 1;
+      }
+      } else if constexpr (WR && NP == 4) {
+      // three W slots: W0(k0) in slot wr, W1(k0) in wr + 1, W0(k0+1) in wr + 2 (mod 3).  Loads in issue order:
+      //   prologue X0 W0 X1 | ph0: W1 X2 | ph1: W0' | ph2: X0' | ph3: X1'
+      //   ph0 needs W0, X0 (<= XPW left: X1) | ph1 needs W1 (<= XPW left: X2) | ph2 needs X1 (complete since ph1's wait) | ph3 needs X2: the
+      //   loads behind it are W0', X0' (<= WPW + XPW left) - strict when the streams have ended and nothing was issued behind it
+      for (int k0 = 0; k0 < nk0; ++k0) {
+        const int w1s = wr == 2 ? 0 : wr + 1;
+        phase(0, wr, std::integral_constant<int, C::XPW>{}, true, true);                          // (X0, W0); requests W1, X2
+        const bool wn = rw_ok;
+        phase(0, w1s, std::integral_constant<int, C::XPW>{}, true, false);                        // (X0, W1); requests W0'
+        const bool xn = phase(1, wr, std::integral_constant<int, C::XPW + C::WPW>{}, false, true, false, true);   // (X1, W0 / 2^11); requests X0'
+        phase(2, wr, std::integral_constant<int, C::XPW + C::WPW>{}, false, true, !(wn && xn), true);             // (X2, W0 / 2^11); requests X1'
+        wr = w1s == 2 ? 0 : w1s + 1;
+      }
+      } else if constexpr (WR && NP == 3) {
+      //   prologue X0 W0 X1 | ph0: W1 X0' | ph1: W0' | ph2: X1'
+      //   ph0 needs X0, W0 (<= XPW left: X1) | ph1 needs W1 (<= XPW left: X0', strict when it was not issued) | ph2 needs X1 (complete)
+      for (int k0 = 0; k0 < nk0; ++k0) {
+        const int x1s = xr == 2 ? 0 : xr + 1, w1s = wr == 2 ? 0 : wr + 1;
+        const bool xn = phase(xr, wr, std::integral_constant<int, C::XPW>{}, true, true);          // (X0, W0); requests W1, X0'
+        phase(xr, w1s, std::integral_constant<int, C::XPW>{}, true, false, !xn);                   // (X0, W1); requests W0'
+        phase(x1s, wr, std::integral_constant<int, C::XPW + C::WPW>{}, false, true, false, true);  // (X1, W0 / 2^11); requests X1'
+        wr = w1s == 2 ? 0 : w1s + 1;
+        xr = x1s == 2 ? 0 : x1s + 1;
+      }
+      } else if constexpr (NP == 4) {
       for (int k0 = 0; k0 < nk0; ++k0) {
         phase(0, wr, std::integral_constant<int, C::XPW>{}, true, true);          // (X0, W0); requests W1, X2
         phase(0, wr ^ 1, std::integral_constant<int, C::XPW>{}, true, false);     // (X0, W1); requests W0b
@@ -465,19 +529,19 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
 
 static int num_cus() { return device_cu_count(256); }   // (per device: a process may drive several)
 
-template <int BM, int BN, int WM, int WN, int MINB, int XST, int NP = 0>
+template <int BM, int BN, int WM, int WN, int MINB, int XST, int NP = 0, int WST = 2>
 static void launch_g2(const ConvParams& p, hipStream_t s) {
   constexpr bool SP = NP != 0;
-  using C = G2Cfg<BM, BN, WM, WN, XST>;
+  using C = G2Cfg<BM, BN, WM, WN, XST, WST>;
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
   static PerDeviceOnce once;
-  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WM, WN, MINB, XST, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + (C::LDS + 8208 <= 160 * 1024 ? 8208 : 0))); });
+  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WM, WN, MINB, XST, NP, WST>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + (C::LDS + 8208 <= 160 * 1024 ? 8208 : 0))); });
   const size_t lds = C::LDS + (p.act == kActGelu && p.gelu_lut ? (SP ? 8208 : 8192) : 0);
   // persistent grid: as many workgroups as fit the chip at once (a multiple of 8: one share per XCD), never more than tiles
   const int per_cu = std::max(1, std::min((int)(160 * 1024 / lds), 2048 / C::NT));
   const int cap = num_cus() * per_cu / 8 * 8;
   const int grid = std::min((tilesM * tilesN + 7) / 8 * 8, std::max(cap, 8));
-  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM, WN, MINB, XST, NP>), dim3(grid), dim3(C::NT), lds, s, p);
+  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM, WN, MINB, XST, NP, WST>), dim3(grid), dim3(C::NT), lds, s, p);
 }
 
 // Phi table of the GELU epilogue, one per device, built on first use (host erf in double)
@@ -528,6 +592,8 @@ const void* gelu_hermite_lut_for_current_device() {
 
 static int g_x_ring3 = 1;
 void set_gemm2_x_ring3(int v) { g_x_ring3 = v; }
+static int g_split_wreg = 1;    // split mode, 256 x 128 / 128 x 256 tiles: w0b formed in registers from the W0 tile (three W slots) instead of staged
+void set_gemm2_split_wreg(int v) { g_split_wreg = v; }
 static int g_split_dbg = 0;     // split mode timing experiments (results are wrong): 1 = no output stores
 void set_gemm2_split_dbg(int v) { g_split_dbg = v; }
 static int g_split_cfg = 0;     // split mode: force a tile configuration (0 = automatic)
@@ -593,27 +659,28 @@ void launch_gemm2(const ConvParams& p_in, int cfg, hipStream_t s) {
   // the GELU table (8 KiB) pushes the 256x256 and 128x128 tiles back to 2
   const bool deep = g_x_ring3 && p.act != kActGelu;
   if (p.split) p.dbg_flags = g_split_dbg;
-  if (p.split && cfg == 1) p.gelu_lut = nullptr;   // 256 x 256 tiles fill the LDS: erf instead of the table
+  if (p.split && (cfg == 1 || (cfg == 2 && g_split_wreg == 2))) p.gelu_lut = nullptr;   // these tiles fill the LDS: erf instead of the table
   if (p.split) {   // three-slot X ring everywhere: the reuse-order K loop
     const bool ru = g_split_reuse != 0 || p.split == 3;
     if (p.split == 3) {
       switch (cfg) {
         case 1: return launch_g2<256, 256, 2, 4, 1, 3, 3>(p, s);
-        case 2: return launch_g2<256, 128, 4, 2, 1, 3, 3>(p, s);
+        case 2: return g_split_wreg == 2 ? launch_g2<256, 128, 4, 2, 1, 3, 3, 4>(p, s) : g_split_wreg ? launch_g2<256, 128, 4, 2, 1, 3, 3, 3>(p, s) : launch_g2<256, 128, 4, 2, 1, 3, 3>(p, s);
         case 3: return launch_g2<128, 128, 2, 2, 2, 3, 3>(p, s);
         case 4: return launch_g2<256, 64, 4, 1, 1, 3, 3>(p, s);
         case 5: return launch_g2<128, 64, 2, 2, 2, 3, 3>(p, s);
-        case 6: return launch_g2<128, 256, 2, 4, 1, 3, 3>(p, s);
+        case 6: return g_split_wreg ? launch_g2<128, 256, 2, 4, 1, 3, 3, 3>(p, s) : launch_g2<128, 256, 2, 4, 1, 3, 3>(p, s);
         default: throw std::runtime_error("gemm2: unknown configuration");
       }
     }
     switch (cfg) {
       case 1: return ru ? launch_g2<256, 256, 2, 4, 1, 3, 4>(p, s) : launch_g2<256, 256, 2, 4, 1, 2, 4>(p, s);
-      case 2: return ru ? launch_g2<256, 128, 4, 2, 1, 3, 4>(p, s) : launch_g2<256, 128, 4, 2, 1, 2, 4>(p, s);
+      case 2: return ru ? (g_split_wreg == 2 ? launch_g2<256, 128, 4, 2, 1, 3, 4, 4>(p, s) : g_split_wreg ? launch_g2<256, 128, 4, 2, 1, 3, 4, 3>(p, s) : launch_g2<256, 128, 4, 2, 1, 3, 4>(p, s))
+                       : launch_g2<256, 128, 4, 2, 1, 2, 4>(p, s);
       case 3: return ru ? launch_g2<128, 128, 2, 2, 2, 3, 4>(p, s) : launch_g2<128, 128, 2, 2, 2, 2, 4>(p, s);
       case 4: return ru ? launch_g2<256, 64, 4, 1, 1, 3, 4>(p, s) : launch_g2<256, 64, 4, 1, 2, 2, 4>(p, s);
       case 5: return ru ? launch_g2<128, 64, 2, 2, 2, 3, 4>(p, s) : launch_g2<128, 64, 2, 2, 2, 2, 4>(p, s);
-      case 6: return ru ? launch_g2<128, 256, 2, 4, 1, 3, 4>(p, s) : launch_g2<128, 256, 2, 4, 1, 2, 4>(p, s);
+      case 6: return ru ? (g_split_wreg ? launch_g2<128, 256, 2, 4, 1, 3, 4, 3>(p, s) : launch_g2<128, 256, 2, 4, 1, 3, 4>(p, s)) : launch_g2<128, 256, 2, 4, 1, 2, 4>(p, s);
       default: throw std::runtime_error("gemm2: unknown configuration");
     }
   }
