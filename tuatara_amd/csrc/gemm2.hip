@@ -594,6 +594,8 @@ static int g_x_ring3 = 1;
 void set_gemm2_x_ring3(int v) { g_x_ring3 = v; }
 static int g_split_wreg = 1;    // split mode, 256 x 128 / 128 x 256 tiles: w0b formed in registers from the W0 tile (three W slots) instead of staged
 void set_gemm2_split_wreg(int v) { g_split_wreg = v; }
+static int g_split_stream = 2;  // split mode, pairs, plain GEMM shapes: the streamlined kernels of gemm_sp.hip (2: tile shape by problem, 1: always two 128 x 128 workgroups per CU, 0: gemm2's own loop)
+void set_gemm2_split_stream(int v) { g_split_stream = v; }
 static int g_split_dbg = 0;     // split mode timing experiments (results are wrong): 1 = no output stores
 void set_gemm2_split_dbg(int v) { g_split_dbg = v; }
 static int g_split_cfg = 0;     // split mode: force a tile configuration (0 = automatic)
@@ -631,6 +633,7 @@ const char* gemm2_check(const ConvParams& p) {
 void launch_gemm2(const ConvParams& p_in, int cfg, hipStream_t s) {
   if (const char* e = gemm2_check(p_in)) throw std::runtime_error(e);
   ConvParams p = p_in;
+  const int Ctot = p.C0 + p.C1;
   p.gelu_lut = p.act == kActGelu ? (p.split ? gelu_hermite_lut_for_current_device() : gelu_lut_for_current_device()) : nullptr;
   if (cfg == 0 && p.split && g_split_cfg) cfg = g_split_cfg;
   if (cfg == 0 && p.split && p.Cout > 64) {
@@ -660,6 +663,14 @@ void launch_gemm2(const ConvParams& p_in, int cfg, hipStream_t s) {
   const bool deep = g_x_ring3 && p.act != kActGelu;
   if (p.split) p.dbg_flags = g_split_dbg;
   if (p.split && (cfg == 1 || (cfg == 2 && g_split_wreg == 2))) p.gelu_lut = nullptr;   // these tiles fill the LDS: erf instead of the table
+  if (p.split == 3 && (cfg == 2 || cfg == 3 || cfg == 6) && g_split_stream && gemm_sp_eligible(p)) {
+    // measured at 1280 crops (tools/x4_parseq_ab.sh): qkv 607 / fc1 835 us on the 128 x 256 tiles against 730 / 892 on two 128 x 128 workgroups per CU
+    // (a third more tile bytes through the L2 -> LDS path); fc2 (Cout 384, K 1536: three long tiles per row block, the epilogue 1 / 24 of a tile)
+    // 630 against 586
+    int sc = cfg;
+    if (g_split_stream == 1 || (p.Cout < 512 && Ctot >= 1024)) sc = 3;
+    return launch_gemm_sp(p, sc, s);
+  }
   if (p.split) {   // three-slot X ring everywhere: the reuse-order K loop
     const bool ru = g_split_reuse != 0 || p.split == 3;
     if (p.split == 3) {

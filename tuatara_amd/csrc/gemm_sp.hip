@@ -1,0 +1,400 @@
+// Split-operand linear layers of the recogniser, streamlined (gfx950 / MI355X):   out = act((X W^T) / S + bias (+ resid))
+// with X as f16 activation PAIRS (planes x0 | x1 per row, split.h) and W as [w0 | w0b | w1] rows.
+//
+// Same contract and the same LDS image as gemm2.hip's split mode (ConvParams, ks = 1, one source; replaces the nn.Linear calls inside
+// the TorchScript PARSeq run at tuatara.cpp:307), for the shapes where that kernel's K loop was bound by its own bookkeeping: rocprof's
+// counters on the 1280-crop encoder GEMMs showed 4 vector and 2.5 scalar instructions per MFMA, all of them - the loader's tap / plane /
+// tile arithmetic with its branches - between the barrier and the MFMAs of every phase, in all eight waves at once, so the matrix pipe idled
+// half of every phase (profiles/r03_pmc_stall_parseq.txt).  Here
+//   * every tile is read from LDS ONCE per k0: products run (X0, W0) (X0, W1) (X1, W0 / 2^11) with the X0 and W0 fragments kept in registers
+//     (32 fragment reads per k0 instead of 48) and w0b formed in registers;
+//   * fragments are read one phase AHEAD of their MFMAs (the barrier of phase s certifies the tile phase s + 1 multiplies), so the LDS latency
+//     sits under 32 MFMAs instead of in front of them;
+//   * the loader is branch-free and costs no vector instruction per load: a lane's row offsets are fixed per tile, the (plane, k0) offset rides
+//     in the instruction's scalar offset, the tile change is an add of a precomputed delta under a scalar mask, and a stream that has run out
+//     keeps issuing out-of-range loads (zero fill, no traffic) so that every s_waitcnt count is exact without special cases;
+//   * three X and three W ring slots: activation tiles are requested 3 - 4 phases before their barrier, weight tiles 3 - 4.
+// Per k0 (phases 0, 1, 2), in steady state:
+//     ph0: MFMA X0(k) W0(k)        reads W1(k)               requests X1(k+1), W1(k+1)
+//     ph1: MFMA X0(k) W1(k)        reads X1(k)               requests W0(k+2)               then  w0s = W0(k) / 2^11 (registers)
+//     ph2: MFMA X1(k) w0s          reads X0(k+1), W0(k+1)    requests X0(k+2)
+// (k runs on across the workgroup's tiles; the epilogue sits between ph2 of a tile's last k0 and ph0 of the next tile, whose first fragments
+// are already in registers and whose later tiles keep landing meanwhile.)
+#include <algorithm>
+#include <stdexcept>
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+#include "split.h"
+
+namespace ttr {
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t sp_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+template <int BM, int BN, int WM, int WN, int XST, int WST>
+struct SpCfg {
+  static constexpr int NW = WM * WN, NT = NW * 64;
+  static constexpr int TM = BM / WM, TN = BN / WN;   // wave tile
+  static constexpr int MI = TM / 16, NJ = TN / 16;
+  static constexpr int XPW = BM / 8 / NW, WPW = BN / 8 / NW;   // 1-KiB pieces (8 rows x 128 B) per wave and tile
+  static constexpr int XBYTES = BM * 128, WBYTES = BN * 128;
+  static constexpr int LDS = XST * XBYTES + WST * WBYTES;
+  static_assert((XST == 2 || XST == 3) && (WST == 2 || WST == 3) && !(XST == 2 && WST == 3), "ring depths: (3, 3), (3, 2) or (2, 2)");
+  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0 && TN % 32 == 0 && TM % 16 == 0, "tile shape");
+};
+
+template <int BM, int BN, int WM, int WN, int XST, int WST, int MINB, bool SCHED>
+__global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_pairs_kernel(ConvParams p) {
+  using C = SpCfg<BM, BN, WM, WN, XST, WST>;
+  if (p.skip && __builtin_nontemporal_load(p.skip) >= p.skip_n) return;   // AR early exit (ConvParams::skip): uniform, before any barrier
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  float2* const glut = reinterpret_cast<float2*>(smem + C::LDS);          // Hermite GELU table behind the rings (common.h: gelu_hermite)
+  if (p.act == kActGelu && p.gelu_lut) {
+    for (int i = tid; i < 513; i += C::NT) reinterpret_cast<uint4*>(glut)[i] = reinterpret_cast<const uint4*>(p.gelu_lut)[i];
+  }   // visible after the first barrier
+
+  // persistent, XCD-aware tile schedule: as gemm2.hip
+  const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
+  const int T = tilesM * tilesN;
+  const int xcd = blockIdx.x & 7, J = gridDim.x >> 3;
+  int xcd_first, xcd_count;
+  {
+    const int q = T >> 3, r = T & 7;
+    xcd_first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    xcd_count = q + (xcd < r ? 1 : 0);
+  }
+  int idx = blockIdx.x >> 3;
+  if (idx >= xcd_count) return;
+
+  const int K = p.C0, nk0 = K >> 6;
+  if (MINB == 2 && (p.dbg_flags & 4) && blockIdx.x >= (gridDim.x >> 1)) {   // experiment: start the second workgroup of a CU half a tile late
+    for (int r = 0; r < (p.dbg_flags >> 4); ++r) __builtin_amdgcn_s_sleep(127);
+  }
+  if (p.dbg_flags & 8) {   // experiment: workgroups start spread over (dbg >> 4) sleep units in 8 steps, so that their epilogues do not all store at once
+    const int steps = (blockIdx.x >> 3) & 7;
+    for (int r = 0; r < steps * (p.dbg_flags >> 4); ++r) __builtin_amdgcn_s_sleep(32);
+  }
+  const __amdgpu_buffer_rsrc_t rsx = sp_rsrc(p.in0, (unsigned)((size_t)p.M * K * 4));      // rows [x0 | x1]
+  const __amdgpu_buffer_rsrc_t rsw = sp_rsrc(p.wgt, (unsigned)((size_t)p.Cout * K * 6));   // rows [w0 | w0b | w1]
+  constexpr unsigned OOB = 0x80000000u;
+
+  unsigned char* const xring = smem;
+  unsigned char* const wring = smem + XST * C::XBYTES;
+
+  // a lane's row offsets for local tile li: piece q = i * NW + wave covers tile rows 8q .. 8q + 7, this lane owns row 8q + (lane >> 3) and the
+  // LDS chunk (lane & 7), which holds global chunk (lane & 7) ^ ((row >> 1) & 7)   (gemm2.hip's image)
+  auto tile_offsets = [&](int li, unsigned (&xo)[C::XPW], unsigned (&wo)[C::WPW]) {
+    const bool live = li < xcd_count;
+    const int tile = xcd_first + li, tm = tile / tilesN, m0 = tm * BM, n0 = (tile - tm * tilesN) * BN;
+#pragma unroll
+    for (int i = 0; i < C::XPW; ++i) {
+      const int row = (i * C::NW + wave) * 8 + (lane >> 3);
+      const int g = (lane & 7) ^ ((row >> 1) & 7);
+      const int m = m0 + row;
+      xo[i] = (live && m < p.M) ? ((unsigned)m * (unsigned)(2 * K) + g * 8) * 2u : OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < C::WPW; ++j) {
+      const int row = (j * C::NW + wave) * 8 + (lane >> 3);
+      const int g = (lane & 7) ^ ((row >> 1) & 7);
+      const int q16 = row & 15;
+      const int nl = (row & ~31) + (q16 >> 2) * 8 + ((row >> 4) & 1) * 4 + (q16 & 3);   // channel held by that LDS row
+      const int n = n0 + nl;
+      wo[j] = (live && n < p.Cout) ? ((unsigned)n * (unsigned)(3 * K) + g * 8) * 2u : OOB;
+    }
+  };
+
+  // ---- the two loader streams: tiles in the order X0(0) X1(0) X0(1) ... / W0(0) W1(0) W0(1) ..., k0 running on into the workgroup's next
+  // tile.  Stream state is scalar; xvo / wvo are the stream's current-tile row offsets, xdl / wdl the delta to its next tile's.
+  unsigned xvo[C::XPW], wvo[C::WPW], xdl[C::XPW], wdl[C::WPW];
+  int xs_k = 0, xs_pl = 0, xs_slot = 0;
+  int ws_k = 0, ws_pl = 0, ws_slot = 0;
+  auto issue_x = [&]() {
+    const unsigned soff = (unsigned)((xs_pl ? K : 0) + (xs_k << 6)) * 2u;
+    unsigned char* sb = xring + xs_slot * C::XBYTES + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < C::XPW; ++i) {
+      const unsigned vo = xvo[i];   // (a local copy: hipcc's host pass fails to instantiate the kernel when the array element is passed directly)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(sb + i * C::NW * 1024), 16, vo, soff, 0, 0);
+    }
+    xs_slot = xs_slot == XST - 1 ? 0 : xs_slot + 1;
+    const int k1 = xs_k + xs_pl;                       // plane 1 -> next k0
+    xs_pl ^= 1;
+    const bool wrap = k1 == nk0;
+    xs_k = wrap ? 0 : k1;
+    const unsigned mask = wrap ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+    for (int i = 0; i < C::XPW; ++i) xvo[i] += xdl[i] & mask;
+  };
+  auto issue_w = [&]() {
+    const unsigned soff = (unsigned)((ws_pl ? 2 * K : 0) + (ws_k << 6)) * 2u;
+    unsigned char* sb = wring + ws_slot * C::WBYTES + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < C::WPW; ++j) {
+      const unsigned vo = wvo[j];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sb + j * C::NW * 1024), 16, vo, soff, 0, 0);
+    }
+    ws_slot = ws_slot == WST - 1 ? 0 : ws_slot + 1;
+    const int k1 = ws_k + ws_pl;
+    ws_pl ^= 1;
+    const bool wrap = k1 == nk0;
+    ws_k = wrap ? 0 : k1;
+    const unsigned mask = wrap ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+    for (int j = 0; j < C::WPW; ++j) wvo[j] += wdl[j] & mask;
+  };
+  // deltas from the tile the streams are in (local index LI) to the one after it; once per tile, outside the K loop
+#define TTR_SP_NEXT_DELTAS(LI)                                                   \
+  {                                                                              \
+    unsigned xa_[C::XPW], wa_[C::WPW], xb_[C::XPW], wb_[C::WPW];                 \
+    tile_offsets((LI), xa_, wa_);                                                \
+    tile_offsets((LI) + J, xb_, wb_);                                            \
+    _Pragma("unroll") for (int i = 0; i < C::XPW; ++i) xdl[i] = xb_[i] - xa_[i]; \
+    _Pragma("unroll") for (int j = 0; j < C::WPW; ++j) wdl[j] = wb_[j] - wa_[j]; \
+  }
+
+  // fragment addressing (gemm2.hip): row = tile-aligned base + (lane & 15), so (row >> 1) & 7 == (lane >> 1) & 7
+  const int frag_lane = (lane & 15) * 128 + ((((lane >> 4)) ^ ((lane >> 1) & 7)) << 4);
+  const int xfo[2] = {wm * C::TM * 128 + frag_lane, wm * C::TM * 128 + (frag_lane ^ 64)};
+  const int wfo[2] = {wn * C::TN * 128 + frag_lane, wn * C::TN * 128 + (frag_lane ^ 64)};
+  const int fg = lane >> 4, fr = lane & 15;
+  int xr = 0, wr = 0;                     // ring slots the next fragment reads take
+  f16x8 fx0[2][C::MI], fx1[2][C::MI], fw0[2][C::NJ], fw1[2][C::NJ];
+  auto read_x = [&](f16x8 (&f)[2][C::MI]) {
+    const unsigned char* b = xring + xr * C::XBYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < C::MI; ++i) f[kk][i] = *reinterpret_cast<const f16x8*>(b + xfo[kk] + i * 2048);
+    xr = xr == XST - 1 ? 0 : xr + 1;
+  };
+  auto read_w = [&](f16x8 (&f)[2][C::NJ]) {
+    const unsigned char* b = wring + wr * C::WBYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < C::NJ; ++j) f[kk][j] = *reinterpret_cast<const f16x8*>(b + wfo[kk] + j * 2048);
+    wr = wr == WST - 1 ? 0 : wr + 1;
+  };
+
+  // ---- prologue: the loads the steady state would have issued before ph0 of the first k0, in its order
+  tile_offsets(idx, xvo, wvo);
+  TTR_SP_NEXT_DELTAS(idx)
+  // Requests per phase in steady state, by ring depth (a tile is requested as soon as the slot it takes has been read):
+  //   X ring 3:  ph0 X1(k+1)   ph2 X0(k+2)        X ring 2:  ph0 X0(k+1)   ph2 X1(k+1)
+  //   W ring 3:  ph0 W1(k+1)   ph1 W0(k+2)        W ring 2:  ph0 W0(k+1)   ph1 W1(k+1)
+  // (ph0 requests X before W).  PH0 / PH1 / PH2 = loads that may still be in flight at that phase's barrier = those requested after the
+  // youngest tile the phase's reads need (ph0: W1(k); ph1: X1(k); ph2: X0(k+1), W0(k+1)):
+  //   (3, 3)  ... X1(k) W1(k) | W0(k+1) | X0(k+1) | X1(k+1) W1(k+1) | W0(k+2) | X0(k+2) ...     PH0 = W + X, PH2 = X + 2 W
+  //   (3, 2)  ... X1(k) W0(k) | W1(k)   | X0(k+1) | X1(k+1) W0(k+1) | W1(k+1) | X0(k+2) ...     PH0 = X,     PH2 = W
+  //   (2, 2)  ... X0(k) W0(k) | W1(k)   | X1(k)   | X0(k+1) W0(k+1) | W1(k+1) | X1(k+1) ...     PH0 = X, PH1 = X + W, PH2 = W
+  constexpr int XW = C::XPW + C::WPW;
+  constexpr int PH0 = WST == 3 ? XW : C::XPW;
+  constexpr int PH1 = XST == 2 ? XW : 63;                 // (rings of 3: X1(k) was complete at ph0's wait)
+  constexpr int PH2 = WST == 3 ? XW + C::WPW : C::WPW;
+  issue_x(); issue_w();                    // X0(0), W0(0)
+  if constexpr (XST == 3 && WST == 3) {
+    issue_x(); issue_w();                  // X1(0), W1(0)          (as ph0 of k = -1)
+    issue_w();                             // W0(1)                 (ph1)
+    issue_x();                             // X0(1)                 (ph2)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * XW) : "memory");
+  } else if constexpr (XST == 3) {
+    issue_x();                             // X1(0)                 (ph0; W0(0) is out already)
+    issue_w();                             // W1(0)                 (ph1)
+    issue_x();                             // X0(1)                 (ph2)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XW + C::XPW) : "memory");
+  } else {
+    issue_w();                             // W1(0)                 (ph1)
+    issue_x();                             // X1(0)                 (ph2)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XW) : "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  read_x(fx0); read_w(fw0);
+
+  while (true) {
+    f32x4 acc[C::NJ][C::MI];
+#pragma unroll
+    for (int j = 0; j < C::NJ; ++j)
+#pragma unroll
+      for (int i = 0; i < C::MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ctile = xcd_first + idx;
+    const int m0c = (ctile / tilesN) * BM, n0c = (ctile % tilesN) * BN;
+
+    // One phase: [wait, barrier] - requests and fragment reads (for the NEXT phase's MFMAs) - this phase's MFMAs.  The scheduling fences keep
+    // the compiler from sinking the reads down to their consumers on the far side of the next barrier (which puts the LDS latency back in front
+    // of the MFMAs) and from hoisting MFMAs over a barrier; inside a phase the reads and requests are spread over the first MFMAs.
+    auto mfmas = [&](const f16x8 (&fw)[2][C::NJ], const f16x8 (&fx)[2][C::MI]) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+          for (int j = 0; j < C::NJ; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[kk][j], fx[kk][i], acc[j][i], 0, 0, 0);
+    };
+    auto interleave = [&](auto reads_c, auto loads_c) {   // per MFMA at the head of the phase: one fragment read (two when there are 16), one request
+      constexpr int READS = decltype(reads_c)::value, LOADS = decltype(loads_c)::value;
+#define TTR_SP_GROUP(G)                                                                      \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
+      __builtin_amdgcn_sched_group_barrier(0x100, READS > 8 ? 2 : 1, 0);                     \
+      if constexpr (G < LOADS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      TTR_SP_GROUP(0) TTR_SP_GROUP(1) TTR_SP_GROUP(2) TTR_SP_GROUP(3) TTR_SP_GROUP(4) TTR_SP_GROUP(5) TTR_SP_GROUP(6) TTR_SP_GROUP(7)
+#undef TTR_SP_GROUP
+    };
+    for (int k0 = 0; k0 < nk0; ++k0) {
+      // ph0
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PH0) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      issue_x(); issue_w();                // X1(k+1) [X0(k+1)], W1(k+1) [W0(k+1)]
+      read_w(fw1);                         // W1(k)
+      mfmas(fw0, fx0);
+      if constexpr (SCHED) interleave(std::integral_constant<int, 2 * C::NJ>{}, std::integral_constant<int, XW>{});
+      // ph1
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PH1) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      issue_w();                           // W0(k+2) [W1(k+1)]
+      read_x(fx1);                         // X1(k)
+      mfmas(fw1, fx0);
+      if constexpr (SCHED) interleave(std::integral_constant<int, 2 * C::MI>{}, std::integral_constant<int, C::WPW>{});
+      __builtin_amdgcn_sched_barrier(0);
+      {   // w0s = w0 / 2^11 (exact unless subnormal: the values the staged w0b plane holds), into the registers W1 has left
+        const f16 sc = (f16)(1.f / 2048.f);
+        const f16x8 scv = {sc, sc, sc, sc, sc, sc, sc, sc};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int j = 0; j < C::NJ; ++j) fw1[kk][j] = fw0[kk][j] * scv;
+      }
+      // ph2
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PH2) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      issue_x();                           // X0(k+2) [X1(k+1)]
+      read_x(fx0); read_w(fw0);            // X0(k+1), W0(k+1)
+      mfmas(fw1, fx1);
+      if constexpr (SCHED) interleave(std::integral_constant<int, 2 * C::MI + 2 * C::NJ>{}, std::integral_constant<int, C::XPW>{});
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    idx += J;
+    const bool has_next = idx < xcd_count;
+    TTR_SP_NEXT_DELTAS(idx)                 // the streams are inside tile idx now (nk0 >= 3: they run at most two k0 ahead)
+
+    if (p.dbg_flags & 2) {   // timing experiment: no epilogue at all
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < C::NJ; ++j)
+#pragma unroll
+        for (int i = 0; i < C::MI; ++i) sum += acc[j][i][0] + acc[j][i][1] + acc[j][i][2] + acc[j][i][3];
+      if (sum == 1.2345e30f) reinterpret_cast<float*>(p.out ? p.out : (void*)p.out_f32)[0] = sum;
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      if (!has_next) break;
+      continue;
+    }
+    // ---- epilogue: lane holds channels n = nb + 32t + (lane>>4)*8 + 0..7 of row m = mb + 16i + (lane&15)
+#pragma unroll
+    for (int t = 0; t < C::NJ / 2; ++t) {
+      const int n = n0c + wn * C::TN + t * 32 + fg * 8;
+      if (n >= p.Cout) continue;
+      float bv[8];
+      if (p.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < C::MI; ++i) {
+        const int m = m0c + wm * C::TM + i * 16 + fr;
+        if (m >= p.M) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = fmaf(acc[2 * t][i][e], p.out_scale, bv[e]); v[4 + e] = fmaf(acc[2 * t + 1][i][e], p.out_scale, bv[4 + e]); }
+        if (p.resid) {
+          const float* rp = p.resid + (int64_t)(p.resid_mod ? m % p.resid_mod : m) * p.resid_ld + n;
+          const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+          v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+        }
+        if (p.act == kActRelu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (p.act == kActGelu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = p.gelu_lut ? gelu_hermite(v[e], glut) : gelu_exact(v[e]);
+        }
+        if (p.dbg_flags & 1) { if (v[0] == 1.2345e30f) reinterpret_cast<float*>(p.out)[0] = v[1]; continue; }   // timing experiment: no output stores
+        if (p.out) st_split_n(p.out, (int64_t)m, p.out_ld, n, v, p.out_planes);
+        if (p.out_f32) {
+          float* op = p.out_f32 + (int64_t)m * p.out_f32_ld + n;
+          *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+      }
+    }
+    // Every vector-memory load has landed, in the compiler's book-keeping too: an epilogue load it still counts as pending here (the bias of
+    // a channel block whose rows were all skipped) would make it put its own s_waitcnt vmcnt(0) INSIDE the K loop, in front of the first
+    // MFMA that reuses that load's registers - a wait for every prefetch in flight, every k0.  The youngest prefetch was requested a phase
+    // and an epilogue ago: this wait is free.
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) (gfx9 encoding: expcnt 7, lgkmcnt 15 = no wait)
+    if (!has_next) break;
+  }   // (the streams' trailing out-of-range loads, which target this workgroup's LDS, have landed: the wait above)
+}
+
+#undef TTR_SP_NEXT_DELTAS
+
+template <int BM, int BN, int WM, int WN, int XST, int WST, int MINB, bool SCHED>
+static void launch_sp(const ConvParams& p, hipStream_t s) {
+  using C = SpCfg<BM, BN, WM, WN, XST, WST>;
+  constexpr int TABLE = 8208;
+  static_assert((C::LDS + TABLE) * MINB <= 160 * 1024 || XST == 3, "LDS budget");
+  static PerDeviceOnce once;
+  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_sp_pairs_kernel<BM, BN, WM, WN, XST, WST, MINB, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, std::min(C::LDS + TABLE, 160 * 1024))); });
+  const size_t lds = C::LDS + (p.act == kActGelu && p.gelu_lut ? TABLE : 0);
+  if (lds * MINB > 160 * 1024) throw std::runtime_error("gemm_sp: this configuration has no room for the GELU table");
+  const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
+  const int cap = device_cu_count(256) * MINB / 8 * 8;
+  const int grid = std::min((tilesM * tilesN + 7) / 8 * 8, std::max(cap, 8));
+  hipLaunchKernelGGL((gemm_sp_pairs_kernel<BM, BN, WM, WN, XST, WST, MINB, SCHED>), dim3(grid), dim3(C::NT), lds, s, p);
+}
+
+static int g_sp_sched = 1;   // 1: fragment reads and requests interleaved with the first MFMAs of a phase; 0: in front of them
+void set_gemm_sp_sched(int v) { g_sp_sched = v; }
+
+// shapes this kernel takes (gemm2.hip's split mode keeps the rest): activation pairs, ks = 1, one source, no pooled / ReLU-copy outputs, K a
+// multiple of 64 of at least 192
+bool gemm_sp_eligible(const ConvParams& p) {
+  return p.split == 3 && p.ks == 1 && p.C1 == 0 && !p.out_pool && !p.out_relu && p.C0 % 64 == 0 && p.C0 >= 192 && p.Cout % 8 == 0 &&
+         (size_t)p.M * p.C0 * 4 < ((size_t)1 << 31) && (size_t)p.Cout * p.C0 * 6 < ((size_t)1 << 31);
+}
+
+// cfg: 2 = 256 x 128 tiles, 6 = 128 x 256 (one workgroup of 8 waves per CU, rings 3 + 3), 3 = 128 x 128 (two workgroups of 4 waves per CU:
+// one's epilogue - its stores have to drain before its next tile's first s_waitcnt vmcnt - runs under the other's MFMAs; rings 3 + 2, or 2 + 2
+// beside the GELU table).  The caller has run gemm2_check and filled p.gelu_lut.
+void launch_gemm_sp(const ConvParams& p, int cfg, hipStream_t s) {
+  if (!gemm_sp_eligible(p)) throw std::runtime_error("gemm_sp: shape not supported");
+  const bool sched = g_sp_sched != 0;
+  const bool table = p.act == kActGelu && p.gelu_lut;
+  if (cfg == 6) { if (sched) launch_sp<128, 256, 2, 4, 3, 3, 1, true>(p, s); else launch_sp<128, 256, 2, 4, 3, 3, 1, false>(p, s); }
+  else if (cfg == 2) { if (sched) launch_sp<256, 128, 4, 2, 3, 3, 1, true>(p, s); else launch_sp<256, 128, 4, 2, 3, 3, 1, false>(p, s); }
+  else if (table) { if (sched) launch_sp<128, 128, 2, 2, 2, 2, 2, true>(p, s); else launch_sp<128, 128, 2, 2, 2, 2, 2, false>(p, s); }
+  else { if (sched) launch_sp<128, 128, 2, 2, 3, 2, 2, true>(p, s); else launch_sp<128, 128, 2, 2, 3, 2, 2, false>(p, s); }
+}
+
+}  // namespace ttr
