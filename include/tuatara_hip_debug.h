@@ -18,6 +18,10 @@ int ttr_dbg_conv(ttr_engine* e, const float* in0, int C0, const float* in1, int 
 
 /* bf16 engines: one conv layer (single source) with the 2x2 max-pool fused into its epilogue, as CRAFT's trunk uses it.
  * out_full (optional) f32 [B][H][W][Cout] and out_pool f32 [B][H/2][W/2][Cout] receive the bf16 results widened to f32. */
+/* One split-operand linear layer of the f16x4 engine on its own: out[M][N] = act(x w^T + bias (+ resid)), np = 3 (activation pairs) / 4 (triples),
+ * out_planes = 0 (fp32 from the kernel) / 2 / 3 (f16 planes from the kernel, joined on the host), cfg = gemm2's tile configuration (0 = automatic). */
+int ttr_dbg_split_gemm(ttr_engine* e, const float* x, int M, int K, const float* w, const float* bias, int N, int np, int act, int out_planes,
+                       const float* resid, int cfg, float* out);
 int ttr_dbg_conv_pool(ttr_engine* e, const float* in0, int C0, int B, int H, int W, int ks, const float* wgt, const float* bias,
                       int Cout, int act, int pool_relu, float* out_full, float* out_pool);
 /* Which kernel serves bf16 layers: -1 = first-generation igemm only, 0 = automatic (default),

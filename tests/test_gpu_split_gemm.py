@@ -1,0 +1,88 @@
+"""The split-operand linear kernels on their own (gemm_sp.hip's streamlined pairs kernels and gemm2.hip's split mode behind launch_gemm2): products of
+f16 activation pairs / triples with weight pairs must reproduce the fp32 linear layer the reference runs inside its TorchScript PARSeq
+(/root/reference/tuatara.cpp:307) on ragged shapes - rows and channels that do not fill the last tile, every tile configuration, every epilogue."""
+import math
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+
+
+@pytest.fixture(scope="module")
+def eng(tmp_path_factory):
+    from tuatara_amd import weights as W
+    from tuatara_amd.engine import Engine
+    d = str(tmp_path_factory.mktemp("w"))
+    W.make_synthetic_weights(d, seed=0, structured=True)
+    e = Engine(d, precision="f16x4")
+    yield e
+    e.close()
+
+
+def _ref(x, w, b, act, resid):
+    y = x.astype(np.float64) @ w.astype(np.float64).T
+    if b is not None:
+        y = y + b.astype(np.float64)
+    if resid is not None:
+        y = y + resid.astype(np.float64)
+    if act == ACT_RELU:
+        y = np.maximum(y, 0.0)
+    elif act == ACT_GELU:
+        y = 0.5 * y * (1.0 + np.vectorize(math.erf)(y / math.sqrt(2.0)))
+    return y
+
+
+def _case(eng, M, K, N, npd, act, planes, with_resid, cfg, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / math.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    r = rng.standard_normal((M, N)).astype(np.float32) if with_resid else None
+    got = eng.dbg_split_gemm(x, w, b, np_products=npd, act=act, out_planes=planes, resid=r, cfg=cfg)
+    ref = _ref(x, w, b, act, r)
+    # fp32-equivalent: the error of an fp32 dot product of K terms of size ~1 (pairs drop the 24th bit of half the activations)
+    tol = (6e-6 if npd == 3 else 3e-6) * math.sqrt(K / 384.0) + (1e-6 if planes == 2 else 0.0)
+    err = np.abs(got - ref).max()
+    assert np.isfinite(got).all() and err < tol * max(1.0, np.abs(ref).max() / 4.0), (M, K, N, npd, act, planes, with_resid, cfg, err)
+
+
+# (M, K, N): rows / channels that leave partial tiles for 128 x 128, 128 x 256 and 256 x 128; K = 192 is the shortest the streamlined kernel takes
+SHAPES = [(128 * 37 + 40, 384, 1152), (128 * 40, 384, 1536), (128 * 33 + 8, 1536, 384), (128 * 3 + 16, 192, 392), (128 * 21, 384, 384)]
+
+
+@pytest.mark.parametrize("cfg", [0, 2, 3, 6])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_pairs_linear_matches_fp32(eng, shape, cfg):
+    """activation pairs (three MFMAs per product): plain fp32 output, every tile configuration (0 = the engine's own choice)"""
+    M, K, N = shape
+    _case(eng, M, K, N, 3, ACT_NONE, 0, False, cfg, 1)
+
+
+@pytest.mark.parametrize("act,planes,resid", [(ACT_GELU, 2, False), (ACT_NONE, 3, False), (ACT_NONE, 0, True), (ACT_RELU, 2, False), (ACT_GELU, 0, True)])
+@pytest.mark.parametrize("cfg", [3, 6])
+def test_pairs_linear_epilogues(eng, act, planes, resid, cfg):
+    """the epilogues PARSeq uses: GELU -> pairs (fc1), triples (qkv), fp32 + residual (fc2), on a ragged shape"""
+    _case(eng, 128 * 19 + 72, 384, 1152 if planes else 392, 3, act, planes, resid, cfg, 2)
+
+
+@pytest.mark.parametrize("shape", SHAPES[:3])
+def test_triples_linear_matches_fp32(eng, shape):
+    """exact activation triples (four MFMAs per product: gemm2.hip's split mode), fp32 output + residual"""
+    M, K, N = shape
+    _case(eng, M, K, N, 4, ACT_NONE, 0, True, 0, 3)
+
+
+def test_streamlined_and_general_kernels_agree(eng):
+    """gemm_sp.hip against gemm2.hip's own K loop on the same operands: the same products in a different order"""
+    rng = np.random.default_rng(4)
+    M, K, N = 128 * 24, 384, 1152
+    x = rng.standard_normal((M, K)).astype(np.float32); w = (rng.standard_normal((N, K)) / 20).astype(np.float32); b = rng.standard_normal(N).astype(np.float32)
+    a = eng.dbg_split_gemm(x, w, b, np_products=3, cfg=6)
+    assert eng.set_tuning("g2_split_stream", 0) == 0
+    try:
+        c = eng.dbg_split_gemm(x, w, b, np_products=3, cfg=6)
+    finally:
+        assert eng.set_tuning("g2_split_stream", 2) == 0
+    assert np.abs(a - c).max() < 2e-6 * max(1.0, np.abs(a).max())

@@ -2001,6 +2001,57 @@ int ttr_dbg_conv(ttr_engine* e, const float* in0, int C0, const float* in1, int 
   TTR_GUARD_END(-1)
 }
 
+// One split-operand linear layer on its own (tests): out[M][N] = act(x w^T + bias (+ resid)) through launch_gemm2's split mode (gemm_sp.hip's kernels
+// where they apply), np = 3 (activation pairs) or 4 (triples); out_planes = 0 (the kernel writes fp32) or 2 / 3 (it writes f16 planes, joined here).
+int ttr_dbg_split_gemm(ttr_engine* e, const float* x, int M, int K, const float* w, const float* bias, int N, int np, int act, int out_planes,
+                       const float* resid, int cfg, float* out) {
+  TTR_GUARD_BEGIN
+  Engine& E = *e->e;
+  EngineScope lk(E);
+  if (E.prec != kSplit) throw std::runtime_error("ttr_dbg_split_gemm: f16x4 engines only");
+  if ((np != 3 && np != 4) || (out_planes != 0 && out_planes != 2 && out_planes != 3)) throw std::runtime_error("ttr_dbg_split_gemm: np must be 3 or 4, out_planes 0, 2 or 3");
+  const int ipl = np == 3 ? 2 : 3;
+  DevBuf dx, dxp, dout, dres;
+  Linear L;
+  dx.ensure((size_t)M * K * 4); TTR_HIP_CHECK(hipMemcpy(dx.p, x, (size_t)M * K * 4, hipMemcpyHostToDevice));
+  dxp.ensure((size_t)M * K * 2 * ipl);
+  launch_split_planes(dx.as<float>(), K, dxp.p, M, K, 0, E.stream, ipl);
+  E.upload_linear(L, w, N, K, bias, N, K);
+  if (!L.ws.p) throw std::runtime_error("ttr_dbg_split_gemm: the layer has no weight planes");
+  if (resid) { dres.ensure((size_t)M * N * 4); TTR_HIP_CHECK(hipMemcpy(dres.p, resid, (size_t)M * N * 4, hipMemcpyHostToDevice)); }
+  dout.ensure((size_t)M * N * (out_planes ? 2 * out_planes : 4));
+  ConvParams p{};
+  p.in0 = dxp.p; p.C0 = K; p.B = 1; p.H = 1; p.W = M; p.ks = 1; p.dil = 1;
+  p.wgt = L.ws.p; p.bias = bias ? L.b.as<float>() : nullptr; p.split = np; p.out_scale = L.inv_scale; p.out_planes = out_planes;
+  if (out_planes) { p.out = dout.p; p.out_ld = N; } else { p.out_f32 = dout.as<float>(); p.out_f32_ld = N; }
+  p.resid = resid ? dres.as<float>() : nullptr; p.resid_ld = N;
+  p.Cout = N; p.M = M; p.act = act;
+  if (const char* err = gemm2_check(p)) throw std::runtime_error(err);
+  launch_gemm2(p, cfg, E.stream);
+  if (!out_planes) {
+    TTR_HIP_CHECK(hipMemcpyAsync(out, dout.p, (size_t)M * N * 4, hipMemcpyDeviceToHost, E.stream));
+    TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
+    return 0;
+  }
+  std::vector<uint16_t> h((size_t)M * N * out_planes);
+  TTR_HIP_CHECK(hipMemcpyAsync(h.data(), dout.p, h.size() * 2, hipMemcpyDeviceToHost, E.stream));
+  TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
+  auto f16_to_f32 = [](uint16_t v) -> double {
+    const int sgn = v >> 15, ex = (v >> 10) & 31, man = v & 1023;
+    double r = ex == 0 ? std::ldexp((double)man, -24) : ex == 31 ? (man ? NAN : INFINITY) : std::ldexp((double)(man | 1024), ex - 25);
+    return sgn ? -r : r;
+  };
+  for (int m = 0; m < M; ++m)
+    for (int n = 0; n < N; ++n) {
+      const uint16_t* row = h.data() + (size_t)m * out_planes * N;
+      double v = f16_to_f32(row[n]), lo = f16_to_f32(row[N + n]);
+      if (out_planes == 3) lo += f16_to_f32(row[2 * N + n]);
+      out[(size_t)m * N + n] = (float)(v + lo / 2048.0);
+    }
+  return 0;
+  TTR_GUARD_END(-1)
+}
+
 int ttr_dbg_mlp(ttr_engine* e, const float* x, int M, const float* ln_g, const float* ln_b, float eps, const float* w1, const float* b1, const float* w2,
                 const float* b2, const float* nln_g, const float* nln_b, float* x_out, float* nln_out, const float* att, const float* wp, const float* bp) {
   TTR_GUARD_BEGIN

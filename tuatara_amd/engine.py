@@ -68,6 +68,7 @@ SYMBOLS = [
     ("ttr_last_stage_ms", _I, [_VP, _PF]),
     ("ttr_set_profiling", _I, [_VP, _I]),
     ("ttr_dbg_conv_pool", _I, [_VP, _PF, _I, _I, _I, _I, _I, _PF, _PF, _I, _I, _I, _PF, _PF]),
+    ("ttr_dbg_split_gemm", _I, [_VP, _PF, _I, _I, _PF, _PF, _I, _I, _I, _I, _PF, _I, _PF]),
     ("ttr_set_gemm_config", None, [_I]),
     ("ttr_set_decoder_mode", None, [_I]),
     ("ttr_set_tuning", _I, [C.c_char_p, _I]),
@@ -473,6 +474,19 @@ class Engine:
         b = np.ascontiguousarray(bias, dtype=np.float32) if bias is not None else None
         self._check(self.lib.ttr_dbg_conv(self.h, _f(x0), C0, _f(x1) if x1 is not None else None, C1, int(relu0), int(relu1), B, H, W_, ks, dil,
                                           _f(w), _f(b) if b is not None else None, Cout, act, _f(out)))
+        return out
+
+    def dbg_split_gemm(self, x: np.ndarray, w: np.ndarray, bias: Optional[np.ndarray] = None, np_products: int = 3, act: int = 0, out_planes: int = 0,
+                       resid: Optional[np.ndarray] = None, cfg: int = 0) -> np.ndarray:
+        """f16x4 engines: one split-operand linear, x f32 [M,K], w f32 [N,K] -> act(x w^T + bias (+ resid)) f32 [M,N] (tests)."""
+        x = np.ascontiguousarray(x, dtype=np.float32); w = np.ascontiguousarray(w, dtype=np.float32)
+        M, K = x.shape
+        N = w.shape[0]
+        out = np.zeros((M, N), np.float32)
+        b = np.ascontiguousarray(bias, dtype=np.float32) if bias is not None else None
+        r = np.ascontiguousarray(resid, dtype=np.float32) if resid is not None else None
+        self._check(self.lib.ttr_dbg_split_gemm(self.h, _f(x), M, K, _f(w), _f(b) if b is not None else None, N, np_products, act, out_planes,
+                                                _f(r) if r is not None else None, cfg, _f(out)))
         return out
 
 
