@@ -391,7 +391,7 @@ def main():
         q = pe["parseq"]
         pq_exec = (q["flops"] / (q["ms"] * 1e-3) / 1e12) if q["ms"] else None   # f16x4: executed flops (x 3 for qkv / fc1, x 4 elsewhere); else algorithmic
         pq_alg = pq_exec / 3.53 if (pq_exec and args.precision == "f16x4") else pq_exec   # encoder mix: (3 * (qkv + fc1) + 4 * (proj + fc2)) / total = 3.53
-        out["roofline_parseq_gemm"] = {"kernel": "PARSeq batched GEMM launches (gemm2_kernel<SP>: qkv, proj, fc1, fc2, cross K/V, refinement pass)" if args.precision == "f16x4"
+        out["roofline_parseq_gemm"] = {"kernel": "PARSeq batched GEMM launches (gemm_sp_pairs_kernel: qkv, fc1, fc2; gemm2_kernel<SP>: proj, cross K/V, refinement pass)" if args.precision == "f16x4"
                                        else "PARSeq batched GEMM launches (gemm_ws / mlp_fused / gemm2)", "bound": "mfma",
                                        "achieved": pq_exec, "peak": peak, "unit": "TFLOP/s", "frac": (pq_exec / peak) if pq_exec else None,
                                        "algorithmic_tflops": pq_alg, "launches_per_pass": q["launches"], "measured": "one extra pass after the timed region"}

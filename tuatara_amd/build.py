@@ -88,8 +88,20 @@ def build_examples() -> str:
     return out
 
 
+def stamp_build() -> None:
+    """.build_hash = the commit the library was built from (profile scripts on the GPU box, which has no .git, quote it)."""
+    try:
+        h = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, stderr=subprocess.DEVNULL).decode().strip()
+        dirty = subprocess.call(["git", "diff", "--quiet", "HEAD", "--", "tuatara_amd/csrc"], cwd=ROOT) != 0
+        with open(os.path.join(ROOT, ".build_hash"), "w") as f:
+            f.write(h + ("+" if dirty else "") + "\n")
+    except Exception:
+        pass
+
+
 def build_all() -> None:
     build_lib()
+    stamp_build()
     build_pytuatara()
     build_examples()
 
