@@ -49,6 +49,9 @@ struct ConvParams {
   // split-operand mode (split.h; gemm2 / conv3p): in0 / in1 are f16 planes [M][3 C], wgt f16 [Cout][3 K] = w0 | w0/2^11 | w1; out_scale = 1 / S of
   // the weight tensor; out / out_relu / out_pool are fp32 [M][out_ld] or, with out_planes, f16 planes [M][3 out_ld]
   int split; float out_scale; int out_planes;
+  // out_planes == 3: columns from out_full_cols on may leave their third plane unwritten (0 = write every plane everywhere).  PARSeq's qkv output:
+  // the attention kernel reads K and V as pairs, so only the 384 Q columns need the triple - a fifth of the layer's store traffic
+  int out_full_cols;
 };
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

@@ -71,6 +71,7 @@ struct Tuning {
   int enc_chunk = 0;          // crops per encoder group (0 = all crops at once)
   int enc_ln_pairs = 1;       // split-operand engines, PARSeq encoder: LayerNorm outputs as pairs (qkv and fc1 on three MFMAs per product: their inputs tolerate ~23.5 bits - 3 x 1280 crops: max |dlogit| 7.6e-4 vs 6.9e-4 with triples; proj and fc2 keep exact triples); 0 = triples
   int dec_planes = 1;         // split-operand engines: the decoder's layers hand each other planes (13 launches per AR step instead of 20); 0 = fp32 tensors + split passes
+  int qkv_kv_pairs = 1;       // the qkv GEMM leaves the third plane of its K and V columns unwritten (the attention kernel reads them as pairs)
   int enc_fc2_pairs = 1;      // ... and the MLP hidden activation as pairs (fc2 on three MFMAs per product; 3 x 640 crops: max |dlogit| 5.1 - 6.7e-4 vs 5.6 - 7.6e-4 with triples); the attention output - the projection input - stays an exact triple: the one encoder linear whose result moves with the 24th bit (oracle/splitsim.py)
   int craft_products = 3;     // split-operand engines, CRAFT: 3 = activation pairs (~23.5 bits; the heat map stays at fp32 noise level), 4 = exact triples
   int detector_only = 0;      // profiling: drop every detected box, so that a batch runs the detector + CCL only
@@ -98,6 +99,7 @@ struct Tuning {
     else if (k == "craft_products") craft_products = value == 4 ? 4 : 3;
     else if (k == "enc_ln_pairs") enc_ln_pairs = value;
     else if (k == "enc_fc2_pairs") enc_fc2_pairs = value;
+    else if (k == "qkv_kv_pairs") qkv_kv_pairs = value;
     else if (k == "dec_planes") dec_planes = value;
     else if (k == "split_conv3p") split_conv3p = value;
     else if (k == "split_planes") split_planes = value;
@@ -860,9 +862,10 @@ struct Engine {
   // ---- PARSeq
   // split-operand linear on planes: in [M][3 K] -> out (planes [M][3 out_ld] or fp32 [M][out_ld]) and / or out_f32 (+ fp32 residual)
   void sgemm(const Linear& L, const void* in_planes, int M, void* out, int out_ld, int act, int out_planes,
-             float* out_f32 = nullptr, int out_f32_ld = 0, const float* resid = nullptr, int resid_ld = 0, int np = 4, int resid_mod = 0) {
+             float* out_f32 = nullptr, int out_f32_ld = 0, const float* resid = nullptr, int resid_ld = 0, int np = 4, int resid_mod = 0, int out_full_cols = 0) {
     if (!L.ws.p) throw std::runtime_error("split GEMM: the layer has no weight planes");
     ConvParams p{};
+    p.out_full_cols = out_full_cols;
     p.in0 = in_planes; p.C0 = L.k; p.B = 1; p.H = 1; p.W = M; p.ks = 1; p.dil = 1;
     p.wgt = L.ws.p; p.bias = L.b.as<float>(); p.split = np; p.out_scale = L.inv_scale; p.out_planes = out_planes == 1 ? 3 : out_planes;   // (1 = triples)
     p.out = out; p.out_ld = out_ld; p.out_f32 = out_f32; p.out_f32_ld = out_f32_ld; p.resid = resid; p.resid_ld = resid_ld; p.resid_mod = resid_mod;
@@ -991,7 +994,7 @@ struct Engine {
         for (int l = 0; l < 12; ++l) {
           const std::string p = "encoder.blocks." + std::to_string(l) + ".";
           launch_layernorm_planes(xc, E, pqf.at(p + "norm1.weight").as<float>(), pqf.at(p + "norm1.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream, lnpl);
-          sgemm(pq.at(p + "qkv"), lnp_at(c0), Mc, bigp, 3 * E, kActNone, 1, nullptr, 0, nullptr, 0, lnpl + 1);
+          sgemm(pq.at(p + "qkv"), lnp_at(c0), Mc, bigp, 3 * E, kActNone, 1, nullptr, 0, nullptr, 0, lnpl + 1, 0, tn.qkv_kv_pairs ? E : 0);   // (K, V: read as pairs)
           launch_attn_enc_split(bigp, attp, nc, stream);
           sgemm(pq.at(p + "proj"), attp, Mc, nullptr, 0, kActNone, 0, xc, E, xc, E);
           launch_layernorm_planes(xc, E, pqf.at(p + "norm2.weight").as<float>(), pqf.at(p + "norm2.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream, lnpl);

@@ -340,7 +340,14 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_pairs_kernel(ConvP
           for (int e = 0; e < 8; ++e) v[e] = p.gelu_lut ? gelu_hermite(v[e], glut) : gelu_exact(v[e]);
         }
         if (p.dbg_flags & 1) { if (v[0] == 1.2345e30f) reinterpret_cast<float*>(p.out)[0] = v[1]; continue; }   // timing experiment: no output stores
-        if (p.out) st_split_n(p.out, (int64_t)m, p.out_ld, n, v, p.out_planes);
+        if (p.out) {
+          if (p.out_planes == 3 && p.out_full_cols > 0 && n >= p.out_full_cols) {   // a triple whose third plane nobody reads (ConvParams::out_full_cols)
+            f16x8 a, b, c;
+            split3_x8(v, a, b, c);
+            f16* o = reinterpret_cast<f16*>(p.out) + (int64_t)m * (3 * (int64_t)p.out_ld) + n;
+            *reinterpret_cast<f16x8*>(o) = a; *reinterpret_cast<f16x8*>(o + p.out_ld) = b;
+          } else st_split_n(p.out, (int64_t)m, p.out_ld, n, v, p.out_planes);
+        }
         if (p.out_f32) {
           float* op = p.out_f32 + (int64_t)m * p.out_f32_ld + n;
           *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
