@@ -664,9 +664,8 @@ void launch_gemm2(const ConvParams& p_in, int cfg, hipStream_t s) {
   if (p.split) p.dbg_flags = g_split_dbg;
   if (p.split && (cfg == 1 || (cfg == 2 && g_split_wreg == 2))) p.gelu_lut = nullptr;   // these tiles fill the LDS: erf instead of the table
   if (p.split == 3 && (cfg == 2 || cfg == 3 || cfg == 6) && g_split_stream && gemm_sp_eligible(p)) {
-    // measured at 1280 crops (tools/x4_parseq_ab.sh): qkv 607 / fc1 835 us on the 128 x 256 tiles against 730 / 892 on two 128 x 128 workgroups per CU
-    // ; fc2 (Cout 384, K 1536: three long tiles per row block, the epilogue 1 / 24 of a tile)
-    // 630 against 586
+    // measured at 1280 crops (tools/x4_parseq_ab.sh): qkv 607 / fc1 835 us on the 128 x 256 tiles against 730 / 892 on two 128 x 128 workgroups
+    // per CU; fc2 (Cout 384, K 1536: three long tiles per row block, the epilogue 1 / 24 of a tile) 630 against 586
     int sc = cfg;
     if (g_split_stream == 1 || (p.Cout < 512 && Ctot >= 1024)) sc = 3;
     return launch_gemm_sp(p, sc, s);
