@@ -17,5 +17,5 @@ for path in sys.argv[1:]:
     names = sorted({c for k in acc for c in acc[k]})
     print("==", path.split("/")[-1]); print(f"{'kernel':52s} {'n':>5s} " + " ".join(f"{n[-16:]:>16s}" for n in names))
     for k in sorted(acc, key=lambda k: -max(acc[k].values())):
-        if "gemm" in k or "attn" in k or "layernorm_planes" in k:
+        if "gemm" in k or "attn" in k or "layernorm_planes" in k or "conv" in k:
             print(f"{k:52s} {cnt[k]:5d} " + " ".join(f"{acc[k][n] / cnt[k]:16.0f}" for n in names))
