@@ -72,9 +72,8 @@ struct G2Cfg {
 template <int BM, int BN, int WM, int WN, int MINB, int XST, int NP, int WST = 2>
 __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p) {
   using C = G2Cfg<BM, BN, WM, WN, XST, WST>;
-  static_assert(WST == 2 || ((WST == 3 || WST == 4) && NP != 0 && XST == 3), "three / four W slots: the split mode's reuse-order loop only");
-  constexpr bool WR = WST >= 3;     // w0b formed in registers
-  constexpr bool W4 = WST == 4;     // ... and the W tiles a whole k0 ahead (an L2 hit takes about as long as one phase: a tile requested one phase ahead is waited for)
+  static_assert(WST == 2 || (WST == 3 && NP != 0 && XST == 3), "three W slots: the split mode's reuse-order loop only");
+  constexpr bool WR = WST == 3;     // w0b formed in registers
   constexpr bool SP = NP != 0;
   static_assert(NP == 0 || NP == 4 || (NP == 3 && XST == 3), "pairs run in the reuse-order loop only");
   if (p.skip && __builtin_nontemporal_load(p.skip) >= p.skip_n) return;   // AR early exit (ConvParams::skip): uniform, before any barrier
@@ -260,7 +259,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
       const unsigned vo = wb[j] == OOB ? OOB : wb[j] + koff;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sb + (j * C::NW + wave) * 1024), 16, vo, 0, 0, 0);
     }
-    if (WR) rw_slot = rw_slot == WST - 1 ? 0 : rw_slot + 1; else rw_slot ^= 1;
+    if (WR) rw_slot = rw_slot == 2 ? 0 : rw_slot + 1; else rw_slot ^= 1;
     if (++rw_j == (WR ? 2 : 3)) { rw_j = 0; if (++rw_k0 == nk0) { rw_k0 = 0; rw_idx += J; rw_ok = rw_idx < xcd_count; if (rw_ok) setup_w(rw_idx); } }
   };
 
@@ -269,7 +268,6 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
   int xr = 0, wr = 0;                                    // ring slots the MFMAs read next
   if constexpr (RU) {
     ru_issue_x(); ru_issue_w(); ru_issue_x();            // X0, W0, X1 of the first k0
-    if constexpr (W4) ru_issue_w();                      // ... and W1
   } else {
     issue_x(); issue_w();                                // X(0), W(0)
     if (XST == 3 && x_ok) { issue_x(); x_ahead = true; } // X(1)
@@ -328,32 +326,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
       //   ph1: X1 W1 X2          need W1      -> <= XPW left          (ph0 issues W1 before X2)
       //   ph2: X2 W0b            need X1, W0b -> 0 left
       //   ph3: W0' X0'           need X2      -> <= WPW + XPW left    (X2 was complete at ph2's wait)
-      if constexpr (W4) {
-      // four W slots: W0(k0) in slot wr, W1(k0) in wr + 1, the next k0's pair behind them (mod 4), requested a whole k0 ahead.
-      // Loads in issue order (pairs):    prologue X0 W0 X1 W1 | ph0: W0' X0' | ph1: W1' | ph2: X1'
-      //   ph0 needs W0, X0 (behind them: W1 X1) | ph1 needs W1 (behind: X1 W0' X0') | ph2 needs X1 (behind: W0' X0' W1')
-      // (triples):                        prologue X0 W0 X1 W1 | ph0: W0' X2 | ph1: W1' | ph2: X0' | ph3: X1'
-      //   ph0 needs W0, X0 (behind them: X1) | ph1 nothing new | ph2 needs X1 (behind: W0' X2 W1') | ph3 needs X2 (behind: W1' X0')
-      // The last k0 of a workgroup's last tile has nothing behind its loads: it waits for everything.
-      constexpr int XW = C::XPW + C::WPW;
-      for (int k0 = 0; k0 < nk0; ++k0) {
-        const bool tail = !rw_ok || !rx_ok;
-        const int w1s = wr == 3 ? 0 : wr + 1;
-        if constexpr (NP == 3) {
-          const int x1s = xr == 2 ? 0 : xr + 1;
-          phase(xr, wr, std::integral_constant<int, XW>{}, true, true, tail);                       // (X0, W0); requests W0', X0'
-          phase(xr, w1s, std::integral_constant<int, XW + C::XPW>{}, true, false, tail);            // (X0, W1); requests W1'
-          phase(x1s, wr, std::integral_constant<int, XW + C::WPW>{}, false, true, tail, true);      // (X1, W0 / 2^11); requests X1'
-          xr = x1s == 2 ? 0 : x1s + 1;
-        } else {
-          phase(0, wr, std::integral_constant<int, C::XPW>{}, true, true, tail);                    // (X0, W0); requests W0', X2
-          phase(0, w1s, std::integral_constant<int, XW + C::XPW>{}, true, false, tail);             // (X0, W1); requests W1'
-          phase(1, wr, std::integral_constant<int, XW + C::WPW>{}, false, true, tail, true);        // (X1, W0 / 2^11); requests X0'
-          phase(2, wr, std::integral_constant<int, XW>{}, false, true, tail, true);                 // (X2, W0 / 2^11); requests X1'
-        }
-        wr = w1s == 3 ? 0 : w1s + 1;
-      }
-      } else if constexpr (WR && NP == 4) {
+      if constexpr (WR && NP == 4) {
       // three W slots: W0(k0) in slot wr, W1(k0) in wr + 1, W0(k0+1) in wr + 2 (mod 3).  Loads in issue order:
       //   prologue X0 W0 X1 | ph0: W1 X2 | ph1: W0' | ph2: X0' | ph3: X1'
       //   ph0 needs W0, X0 (<= XPW left: X1) | ph1 needs W1 (<= XPW left: X2) | ph2 needs X1 (complete since ph1's wait) | ph3 needs X2: the
@@ -662,7 +635,7 @@ void launch_gemm2(const ConvParams& p_in, int cfg, hipStream_t s) {
   // the GELU table (8 KiB) pushes the 256x256 and 128x128 tiles back to 2
   const bool deep = g_x_ring3 && p.act != kActGelu;
   if (p.split) p.dbg_flags = g_split_dbg;
-  if (p.split && (cfg == 1 || (cfg == 2 && g_split_wreg == 2))) p.gelu_lut = nullptr;   // these tiles fill the LDS: erf instead of the table
+  if (p.split && cfg == 1) p.gelu_lut = nullptr;   // 256 x 256 tiles fill the LDS: erf instead of the table
   if (p.split == 3 && (cfg == 2 || cfg == 3 || cfg == 6) && g_split_stream && gemm_sp_eligible(p)) {
     // measured at 1280 crops (tools/x4_parseq_ab.sh): qkv 607 / fc1 835 us on the 128 x 256 tiles against 730 / 892 on two 128 x 128 workgroups
     // per CU; fc2 (Cout 384, K 1536: three long tiles per row block, the epilogue 1 / 24 of a tile) 630 against 586
@@ -675,7 +648,7 @@ void launch_gemm2(const ConvParams& p_in, int cfg, hipStream_t s) {
     if (p.split == 3) {
       switch (cfg) {
         case 1: return launch_g2<256, 256, 2, 4, 1, 3, 3>(p, s);
-        case 2: return g_split_wreg == 2 ? launch_g2<256, 128, 4, 2, 1, 3, 3, 4>(p, s) : g_split_wreg ? launch_g2<256, 128, 4, 2, 1, 3, 3, 3>(p, s) : launch_g2<256, 128, 4, 2, 1, 3, 3>(p, s);
+        case 2: return g_split_wreg ? launch_g2<256, 128, 4, 2, 1, 3, 3, 3>(p, s) : launch_g2<256, 128, 4, 2, 1, 3, 3>(p, s);
         case 3: return launch_g2<128, 128, 2, 2, 2, 3, 3>(p, s);
         case 4: return launch_g2<256, 64, 4, 1, 1, 3, 3>(p, s);
         case 5: return launch_g2<128, 64, 2, 2, 2, 3, 3>(p, s);
@@ -685,8 +658,7 @@ void launch_gemm2(const ConvParams& p_in, int cfg, hipStream_t s) {
     }
     switch (cfg) {
       case 1: return ru ? launch_g2<256, 256, 2, 4, 1, 3, 4>(p, s) : launch_g2<256, 256, 2, 4, 1, 2, 4>(p, s);
-      case 2: return ru ? (g_split_wreg == 2 ? launch_g2<256, 128, 4, 2, 1, 3, 4, 4>(p, s) : g_split_wreg ? launch_g2<256, 128, 4, 2, 1, 3, 4, 3>(p, s) : launch_g2<256, 128, 4, 2, 1, 3, 4>(p, s))
-                       : launch_g2<256, 128, 4, 2, 1, 2, 4>(p, s);
+      case 2: return ru ? (g_split_wreg ? launch_g2<256, 128, 4, 2, 1, 3, 4, 3>(p, s) : launch_g2<256, 128, 4, 2, 1, 3, 4>(p, s)) : launch_g2<256, 128, 4, 2, 1, 2, 4>(p, s);
       case 3: return ru ? launch_g2<128, 128, 2, 2, 2, 3, 4>(p, s) : launch_g2<128, 128, 2, 2, 2, 2, 4>(p, s);
       case 4: return ru ? launch_g2<256, 64, 4, 1, 1, 3, 4>(p, s) : launch_g2<256, 64, 4, 1, 2, 2, 4>(p, s);
       case 5: return ru ? launch_g2<128, 64, 2, 2, 2, 3, 4>(p, s) : launch_g2<128, 64, 2, 2, 2, 2, 4>(p, s);

@@ -76,13 +76,6 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_pairs_kernel(ConvP
   if (idx >= xcd_count) return;
 
   const int K = p.C0, nk0 = K >> 6;
-  if (MINB == 2 && (p.dbg_flags & 4) && blockIdx.x >= (gridDim.x >> 1)) {   // experiment: start the second workgroup of a CU half a tile late
-    for (int r = 0; r < (p.dbg_flags >> 4); ++r) __builtin_amdgcn_s_sleep(127);
-  }
-  if (p.dbg_flags & 8) {   // experiment: workgroups start spread over (dbg >> 4) sleep units in 8 steps, so that their epilogues do not all store at once
-    const int steps = (blockIdx.x >> 3) & 7;
-    for (int r = 0; r < steps * (p.dbg_flags >> 4); ++r) __builtin_amdgcn_s_sleep(32);
-  }
   const __amdgpu_buffer_rsrc_t rsx = sp_rsrc(p.in0, (unsigned)((size_t)p.M * K * 4));      // rows [x0 | x1]
   const __amdgpu_buffer_rsrc_t rsw = sp_rsrc(p.wgt, (unsigned)((size_t)p.Cout * K * 6));   // rows [w0 | w0b | w1]
   constexpr unsigned OOB = 0x80000000u;
