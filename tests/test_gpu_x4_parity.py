@@ -86,6 +86,24 @@ def test_x4_ar_early_exit_is_invisible_in_the_refined_logits(eng_x4):
     assert steps_run < 26
 
 
+def test_x4_refinement_cross_attention_per_crop_matches_per_row(eng_x4):
+    """The refinement pass reads a crop's K / V once for its 26 query rows (dec_cross_attn_crop_kernel) instead of once per row.  Same sums in
+    the same order; the compiled code differs in the last bit here and there, which this network turns into ~1e-4 on a logit (the fp32 oracle
+    itself sits 8e-4 from an fp64 evaluation): the two agree like two fp32 evaluations, ids identical."""
+    crops = np.random.default_rng(11).integers(0, 256, (45, 32, 128, 3), dtype=np.uint8)
+    a, ida = eng_x4.parseq_logits(crops)
+    assert eng_x4.set_tuning(b"cross_crop", 0) == 0
+    try:
+        b, idb = eng_x4.parseq_logits(crops)
+    finally:
+        eng_x4.set_tuning(b"cross_crop", 1)
+    up = R.upto_eos(idb.reshape(-1, 26))
+    mask = np.arange(26)[None, :] < up[:, None]
+    d = np.abs(a - b).max(-1)
+    print(f"per-crop vs per-row cross-attention: max |dlogit| up to EOS {d[mask].max():.2e}")
+    assert d[mask].max() < 1e-3 and np.array_equal(ida.reshape(-1, 26)[mask], idb.reshape(-1, 26)[mask])
+
+
 def test_x4_parseq_batch_invariance(eng_x4):
     crops = np.random.default_rng(3).integers(0, 256, (9, 32, 128, 3), dtype=np.uint8)
     a, _ = eng_x4.parseq_logits(crops)

@@ -2187,6 +2187,7 @@ int ttr_set_tuning(const char* key, int value) {
   if (k == "gemm_config") set_gemm_config(value);
   else if (k == "self_refine") set_dec_self_refine(value);
   else if (k == "cross_mfma") set_dec_cross_mfma(value);
+  else if (k == "cross_crop") set_dec_cross_crop(value);
   else if (k == "mlp_store_nt") set_mlp_store_nt(value);
   else if (k == "pair_ablate") set_mlp_pair_ablate(value);
   else if (k == "mlp_stagger") set_mlp_stagger(value);

@@ -456,6 +456,77 @@ __global__ __launch_bounds__(384) void dec_cross_attn_kernel(const T* __restrict
   }
 }
 
+// fp32 / f16x4 engines, refinement pass (R = 26 query rows per crop): ONE workgroup per crop instead of one per row, so the crop's 393 KB of K / V
+// are read once instead of 26 times (1.16 ms -> the read time at 1280 crops).  Head by head: K_h and V_h (128 x 32 floats each) go to LDS, then
+// the 26 x 128 scores, the row softmaxes and P V, every sum in the order dec_cross_attn_kernel uses (d, lanes and j ascending, the same
+// shuffles); the two agree like two fp32 evaluations (tests/test_gpu_x4_parity.py).
+__global__ __launch_bounds__(384) void dec_cross_attn_crop_kernel(const float* __restrict__ q, const float* __restrict__ kvmem, float* __restrict__ out,
+                                                                  int R, const int* skip, int skip_n, int planes) {
+  if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;
+  constexpr int RMAX = 26;
+  __shared__ float sq[RMAX][384];
+  __shared__ float sk[128][33];          // (+1: lanes of a wave read 64 different rows at one d)
+  __shared__ float sv[128][32];
+  __shared__ float sp[RMAX][128];
+  const int n = blockIdx.x, t = threadIdx.x;
+  for (int i = t; i < R * 96; i += 384) {
+    const int r = i / 96, c = i - r * 96;
+    const float4 v = *reinterpret_cast<const float4*>(q + ((int64_t)n * R + r) * 384 + c * 4);
+    sq[r][c * 4] = v.x; sq[r][c * 4 + 1] = v.y; sq[r][c * 4 + 2] = v.z; sq[r][c * 4 + 3] = v.w;
+  }
+  const float* kvn = kvmem + (int64_t)n * 128 * 768;
+  for (int h = 0; h < 12; ++h) {
+    __syncthreads();                       // sq written (first head); the previous head's sk / sv / sp no longer read
+    for (int i = t; i < 128 * 8; i += 384) {
+      const int j = i >> 3, c = i & 7;
+      const float4 kk = *reinterpret_cast<const float4*>(kvn + j * 768 + h * 32 + c * 4);
+      const float4 vv = *reinterpret_cast<const float4*>(kvn + j * 768 + 384 + h * 32 + c * 4);
+      sk[j][c * 4] = kk.x; sk[j][c * 4 + 1] = kk.y; sk[j][c * 4 + 2] = kk.z; sk[j][c * 4 + 3] = kk.w;
+      *reinterpret_cast<float4*>(&sv[j][c * 4]) = vv;
+    }
+    __syncthreads();
+    {   // scores: thread = key j, rows rg, rg + 3, ...
+      const int j = t & 127, rg = t >> 7;
+      float kr[32];
+#pragma unroll
+      for (int d = 0; d < 32; ++d) kr[d] = sk[j][d];
+      for (int r = rg; r < R; r += 3) {
+        float sc = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) sc += sq[r][h * 32 + d] * kr[d];
+        sp[r][j] = sc * 0.17677669529663687f;
+      }
+    }
+    __syncthreads();
+    for (int r = t >> 5; r < R; r += 12) {   // softmax: 32 lanes per row, as dec_cross_attn_kernel
+      const int l = t & 31;
+      float v[4], mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[i] = sp[r][l + 32 * i]; mx = fmaxf(mx, v[i]); }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[i] = __expf(v[i] - mx); sum += v[i]; }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      const float inv = 1.0f / sum;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sp[r][l + 32 * i] = v[i] * inv;
+    }
+    __syncthreads();
+    {   // P V: thread = dim d of rows rg, rg + 12, rg + 24
+      const int d = t & 31, rg = t >> 5;
+      for (int r = rg; r < R; r += 12) {
+        float acc = 0.f;
+        for (int j = 0; j < 128; ++j) acc += sp[r][j] * sv[j][d];
+        const int64_t row = (int64_t)n * R + r;
+        if (planes) st_split_one(out, row, 384, h * 32 + d, acc, planes); else out[row * 384 + h * 32 + d] = acc;
+      }
+    }
+  }
+}
+
 // bf16 fast path: a K (or V) row of the crop's memory is 768 bytes = 48 lanes x 16 bytes, so one wave instruction fetches one
 // whole row (the kernel above reads 2 bytes per lane at a 1.5 KB stride).  4 waves x 32 keys each, online softmax per wave,
 // partial (max, sum, out) merged through LDS.  Lane c < 48 holds dims 8c..8c+7, head = c / 4.
@@ -543,11 +614,17 @@ __global__ __launch_bounds__(256) void dec_cross_attn_rows_kernel(const bf16* __
 
 static int g_cross_mfma = 1;
 void set_dec_cross_mfma(int v) { g_cross_mfma = v; }
+static int g_cross_crop = 1;    // fp32 / f16x4 engines, refinement pass: one workgroup per crop (dec_cross_attn_crop_kernel); 0 = one per row
+void set_dec_cross_crop(int v) { g_cross_crop = v; }
 
 void launch_dec_cross_attn(Precision prec, const void* q, const void* kvmem, void* out, int N, int R, hipStream_t s, const int* skip, int skip_n,
                            const int* done_tok, int done_col, int planes) {
   if (N <= 0) return;
   if (prec == kBF16 && g_cross_mfma && (R == 26 || g_cross_mfma == 2)) return launch_dec_cross_attn_mfma((const bf16*)q, (const bf16*)kvmem, (bf16*)out, N, R, s);   // refinement pass (attn_dec2.hip); 2: the AR steps' single row too
+  if (prec != kBF16 && g_cross_crop && R > 1 && R <= 26) {
+    hipLaunchKernelGGL(dec_cross_attn_crop_kernel, dim3(N), dim3(384), 0, s, (const float*)q, (const float*)kvmem, (float*)out, R, skip, skip_n, planes);
+    return;
+  }
   dim3 grid(N * R);
   if (prec == kBF16) hipLaunchKernelGGL(dec_cross_attn_rows_kernel, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)kvmem, (bf16*)out, R, skip, skip_n, R == 1 ? done_tok : nullptr, done_col);
   else hipLaunchKernelGGL(dec_cross_attn_kernel<float>, grid, dim3(384), 0, s, (const float*)q, (const float*)kvmem, (float*)out, R, skip, skip_n, R == 1 ? done_tok : nullptr, done_col, planes);
