@@ -67,11 +67,18 @@ def test_pairs_linear_epilogues(eng, act, planes, resid, cfg):
     _case(eng, 128 * 19 + 72, 384, 1152 if planes else 392, 3, act, planes, resid, cfg, 2)
 
 
-@pytest.mark.parametrize("shape", SHAPES[:3])
-def test_triples_linear_matches_fp32(eng, shape):
-    """exact activation triples (four MFMAs per product: gemm2.hip's split mode), fp32 output + residual"""
+@pytest.mark.parametrize("cfg", [0, 2, 3, 6])
+@pytest.mark.parametrize("shape", SHAPES[:3] + [(128 * 3 + 16, 192, 392)])
+def test_triples_linear_matches_fp32(eng, shape, cfg):
+    """exact activation triples (four MFMAs per product), fp32 output + residual; K / 64 odd (192) stays on gemm2.hip's loop"""
     M, K, N = shape
-    _case(eng, M, K, N, 4, ACT_NONE, 0, True, 0, 3)
+    _case(eng, M, K, N, 4, ACT_NONE, 0, True, cfg, 3)
+
+
+@pytest.mark.parametrize("act,planes", [(ACT_GELU, 3), (ACT_NONE, 3), (ACT_NONE, 0)])
+def test_triples_linear_epilogues(eng, act, planes):
+    """the decoder's epilogues on the triples kernel: GELU -> triples (ffn1), triples, fp32"""
+    _case(eng, 128 * 9 + 40, 384, 1536 if act == ACT_GELU else 392, 4, act, planes, False, 3, 5)
 
 
 def test_streamlined_and_general_kernels_agree(eng):

@@ -569,6 +569,8 @@ static int g_split_wreg = 1;    // split mode, 256 x 128 / 128 x 256 tiles: w0b 
 void set_gemm2_split_wreg(int v) { g_split_wreg = v; }
 static int g_split_stream = 2;  // split mode, pairs, plain GEMM shapes: the streamlined kernels of gemm_sp.hip (2: tile shape by problem, 1: always two 128 x 128 workgroups per CU, 0: gemm2's own loop)
 void set_gemm2_split_stream(int v) { g_split_stream = v; }
+static int g_split_stream4 = 1; // ... and for activation triples (proj, the decoder's linears)
+void set_gemm2_split_stream4(int v) { g_split_stream4 = v; }
 static int g_split_dbg = 0;     // split mode timing experiments (results are wrong): 1 = no output stores
 void set_gemm2_split_dbg(int v) { g_split_dbg = v; }
 static int g_split_cfg = 0;     // split mode: force a tile configuration (0 = automatic)
@@ -636,6 +638,7 @@ void launch_gemm2(const ConvParams& p_in, int cfg, hipStream_t s) {
   const bool deep = g_x_ring3 && p.act != kActGelu;
   if (p.split) p.dbg_flags = g_split_dbg;
   if (p.split && cfg == 1) p.gelu_lut = nullptr;   // 256 x 256 tiles fill the LDS: erf instead of the table
+  if (p.split == 4 && (cfg == 2 || cfg == 3 || cfg == 6) && g_split_stream && g_split_stream4 && gemm_sp_eligible(p)) return launch_gemm_sp(p, cfg, s);   // triples
   if (p.split == 3 && (cfg == 2 || cfg == 3 || cfg == 6) && g_split_stream && gemm_sp_eligible(p)) {
     // measured at 1280 crops (tools/x4_parseq_ab.sh): qkv 607 / fc1 835 us on the 128 x 256 tiles against 730 / 892 on two 128 x 128 workgroups
     // per CU; fc2 (Cout 384, K 1536: three long tiles per row block, the epilogue 1 / 24 of a tile) 630 against 586

@@ -1,5 +1,5 @@
 // Split-operand linear layers of the recogniser, streamlined (gfx950 / MI355X):   out = act((X W^T) / S + bias (+ resid))
-// with X as f16 activation PAIRS (planes x0 | x1 per row, split.h) and W as [w0 | w0b | w1] rows.
+// with X as f16 activation PAIRS (planes x0 | x1 per row, split.h) or exact TRIPLES (x0 | x1 | x2) and W as [w0 | w0b | w1] rows.
 //
 // Same contract and the same LDS image as gemm2.hip's split mode (ConvParams, ks = 1, one source; replaces the nn.Linear calls inside
 // the TorchScript PARSeq run at tuatara.cpp:307), for the shapes where that kernel's K loop was bound by its own bookkeeping: rocprof's
@@ -48,9 +48,18 @@ struct SpCfg {
   static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0 && TN % 32 == 0 && TM % 16 == 0, "tile shape");
 };
 
-template <int BM, int BN, int WM, int WN, int XST, int WST, int MINB, bool SCHED>
-__global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_pairs_kernel(ConvParams p) {
+// NP = 3: activation pairs, phases (X0, W0) (X0, W1) (X1, w0s) as described above.  NP = 4: exact triples, a fourth phase (X2, w0s); X2 goes into the
+// registers X0 has left and the next k0's X0 into X1's, so the two activation fragment sets swap roles every k0 (the K loop runs in pairs of k0;
+// K / 64 must be even); rings X 3 + W 2:
+//     ph0: MFMA X0(k) W0(k)   reads W1(k)               requests X0(k+1), W0(k+1)
+//     ph1: MFMA X0(k) W1(k)   reads X1(k)               requests W1(k+1)              then  w0s = W0(k) / 2^11
+//     ph2: MFMA X1(k) w0s     reads X2(k)               requests X1(k+1)
+//     ph3: MFMA X2(k) w0s     reads X0(k+1), W0(k+1)    requests X2(k+1)
+template <int BM, int BN, int WM, int WN, int XST, int WST, int MINB, bool SCHED, int NP>
+__global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams p) {
   using C = SpCfg<BM, BN, WM, WN, XST, WST>;
+  static_assert(NP == 3 || (NP == 4 && XST == 3 && WST == 2), "pairs, or triples on rings 3 + 2");
+  constexpr int PLX = NP == 3 ? 2 : 3;                                    // activation planes per row
   if (p.skip && __builtin_nontemporal_load(p.skip) >= p.skip_n) return;   // AR early exit (ConvParams::skip): uniform, before any barrier
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -76,7 +85,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_pairs_kernel(ConvP
   if (idx >= xcd_count) return;
 
   const int K = p.C0, nk0 = K >> 6;
-  const __amdgpu_buffer_rsrc_t rsx = sp_rsrc(p.in0, (unsigned)((size_t)p.M * K * 4));      // rows [x0 | x1]
+  const __amdgpu_buffer_rsrc_t rsx = sp_rsrc(p.in0, (unsigned)((size_t)p.M * K * 2 * PLX));   // rows [x0 | x1 (| x2)]
   const __amdgpu_buffer_rsrc_t rsw = sp_rsrc(p.wgt, (unsigned)((size_t)p.Cout * K * 6));   // rows [w0 | w0b | w1]
   constexpr unsigned OOB = 0x80000000u;
 
@@ -93,7 +102,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_pairs_kernel(ConvP
       const int row = (i * C::NW + wave) * 8 + (lane >> 3);
       const int g = (lane & 7) ^ ((row >> 1) & 7);
       const int m = m0 + row;
-      xo[i] = (live && m < p.M) ? ((unsigned)m * (unsigned)(2 * K) + g * 8) * 2u : OOB;
+      xo[i] = (live && m < p.M) ? ((unsigned)m * (unsigned)(PLX * K) + g * 8) * 2u : OOB;
     }
 #pragma unroll
     for (int j = 0; j < C::WPW; ++j) {
@@ -112,7 +121,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_pairs_kernel(ConvP
   int xs_k = 0, xs_pl = 0, xs_slot = 0;
   int ws_k = 0, ws_pl = 0, ws_slot = 0;
   auto issue_x = [&]() {
-    const unsigned soff = (unsigned)((xs_pl ? K : 0) + (xs_k << 6)) * 2u;
+    const unsigned soff = (unsigned)(xs_pl * K + (xs_k << 6)) * 2u;
     unsigned char* sb = xring + xs_slot * C::XBYTES + wave * 1024;
 #pragma unroll
     for (int i = 0; i < C::XPW; ++i) {
@@ -120,8 +129,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_pairs_kernel(ConvP
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(sb + i * C::NW * 1024), 16, vo, soff, 0, 0);
     }
     xs_slot = xs_slot == XST - 1 ? 0 : xs_slot + 1;
-    const int k1 = xs_k + xs_pl;                       // plane 1 -> next k0
-    xs_pl ^= 1;
+    const bool lastpl = xs_pl == PLX - 1;              // the last plane -> next k0
+    const int k1 = xs_k + (lastpl ? 1 : 0);
+    xs_pl = lastpl ? 0 : xs_pl + 1;
     const bool wrap = k1 == nk0;
     xs_k = wrap ? 0 : k1;
     const unsigned mask = wrap ? 0xFFFFFFFFu : 0u;
@@ -194,8 +204,17 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_pairs_kernel(ConvP
   constexpr int PH0 = WST == 3 ? XW : C::XPW;
   constexpr int PH1 = XST == 2 ? XW : 63;                 // (rings of 3: X1(k) was complete at ph0's wait)
   constexpr int PH2 = WST == 3 ? XW + C::WPW : C::WPW;
+  // Triples (rings 3 + 2):  ... | W1(k) | X1(k) | X2(k) | X0(k+1) W0(k+1) | W1(k+1) | X1(k+1) | X2(k+1) | ...   (ph1, ph2, ph3, ph0, ...)
+  //   ph0 reads W1(k): behind it X1(k) X2(k)                      ph1 reads X1(k): behind it X2(k) X0(k+1) W0(k+1)
+  //   ph2 reads X2(k): behind it X0(k+1) W0(k+1) W1(k+1)          ph3 reads X0(k+1), W0(k+1): behind them W1(k+1) X1(k+1)
+  constexpr int T0 = 2 * C::XPW, T1 = 2 * C::XPW + C::WPW, T2 = C::XPW + 2 * C::WPW, T3 = XW;
   issue_x(); issue_w();                    // X0(0), W0(0)
-  if constexpr (XST == 3 && WST == 3) {
+  if constexpr (NP == 4) {
+    issue_w();                             // W1(0)                 (ph1 of k = -1)
+    issue_x();                             // X1(0)                 (ph2)
+    issue_x();                             // X2(0)                 (ph3)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::WPW + 2 * C::XPW) : "memory");
+  } else if constexpr (XST == 3 && WST == 3) {
     issue_x(); issue_w();                  // X1(0), W1(0)          (as ph0 of k = -1)
     issue_w();                             // W0(1)                 (ph1)
     issue_x();                             // X0(1)                 (ph2)
@@ -243,6 +262,49 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_pairs_kernel(ConvP
       TTR_SP_GROUP(0) TTR_SP_GROUP(1) TTR_SP_GROUP(2) TTR_SP_GROUP(3) TTR_SP_GROUP(4) TTR_SP_GROUP(5) TTR_SP_GROUP(6) TTR_SP_GROUP(7)
 #undef TTR_SP_GROUP
     };
+    auto scale_w0 = [&]() {   // w0s = w0 / 2^11 (exact unless subnormal: the values the staged w0b plane holds), into the registers W1 has left
+      const f16 sc = (f16)(1.f / 2048.f);
+      const f16x8 scv = {sc, sc, sc, sc, sc, sc, sc, sc};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < C::NJ; ++j) fw1[kk][j] = fw0[kk][j] * scv;
+    };
+    if constexpr (NP == 4) {
+      auto phase_head = [&](auto allow_c) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(decltype(allow_c)::value) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      // one k0 with X0 (then X2) in `a` and X1 (then the next k0's X0) in `b`
+      auto k_step = [&](f16x8 (&a)[2][C::MI], f16x8 (&b)[2][C::MI]) {
+        phase_head(std::integral_constant<int, T0>{});
+        issue_x(); issue_w();              // X0(k+1), W0(k+1)
+        read_w(fw1);                       // W1(k)
+        mfmas(fw0, a);
+        if constexpr (SCHED) interleave(std::integral_constant<int, 2 * C::NJ>{}, std::integral_constant<int, XW>{});
+        phase_head(std::integral_constant<int, T1>{});
+        issue_w();                         // W1(k+1)
+        read_x(b);                         // X1(k)
+        mfmas(fw1, a);
+        if constexpr (SCHED) interleave(std::integral_constant<int, 2 * C::MI>{}, std::integral_constant<int, C::WPW>{});
+        __builtin_amdgcn_sched_barrier(0);
+        scale_w0();
+        phase_head(std::integral_constant<int, T2>{});
+        issue_x();                         // X1(k+1)
+        read_x(a);                         // X2(k)
+        mfmas(fw1, b);
+        if constexpr (SCHED) interleave(std::integral_constant<int, 2 * C::MI>{}, std::integral_constant<int, C::XPW>{});
+        phase_head(std::integral_constant<int, T3>{});
+        issue_x();                         // X2(k+1)
+        read_x(b); read_w(fw0);            // X0(k+1), W0(k+1)
+        mfmas(fw1, a);
+        if constexpr (SCHED) interleave(std::integral_constant<int, 2 * C::MI + 2 * C::NJ>{}, std::integral_constant<int, C::XPW>{});
+      };
+      for (int k0 = 0; k0 < nk0; k0 += 2) { k_step(fx0, fx1); k_step(fx1, fx0); }
+    } else {
     for (int k0 = 0; k0 < nk0; ++k0) {
       // ph0
       __builtin_amdgcn_sched_barrier(0);
@@ -265,14 +327,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_pairs_kernel(ConvP
       mfmas(fw1, fx0);
       if constexpr (SCHED) interleave(std::integral_constant<int, 2 * C::MI>{}, std::integral_constant<int, C::WPW>{});
       __builtin_amdgcn_sched_barrier(0);
-      {   // w0s = w0 / 2^11 (exact unless subnormal: the values the staged w0b plane holds), into the registers W1 has left
-        const f16 sc = (f16)(1.f / 2048.f);
-        const f16x8 scv = {sc, sc, sc, sc, sc, sc, sc, sc};
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-          for (int j = 0; j < C::NJ; ++j) fw1[kk][j] = fw0[kk][j] * scv;
-      }
+      scale_w0();
       // ph2
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PH2) : "memory");
@@ -283,6 +338,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_pairs_kernel(ConvP
       read_x(fx0); read_w(fw0);            // X0(k+1), W0(k+1)
       mfmas(fw1, fx1);
       if constexpr (SCHED) interleave(std::integral_constant<int, 2 * C::MI + 2 * C::NJ>{}, std::integral_constant<int, C::XPW>{});
+    }
     }
     __builtin_amdgcn_sched_barrier(0);
     idx += J;
@@ -359,38 +415,45 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_pairs_kernel(ConvP
 
 #undef TTR_SP_NEXT_DELTAS
 
-template <int BM, int BN, int WM, int WN, int XST, int WST, int MINB, bool SCHED>
-static void launch_sp(const ConvParams& p, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int XST, int WST, int MINB, bool SCHED, int NP = 3>
+static void launch_sp(const ConvParams& p_in, hipStream_t s) {
   using C = SpCfg<BM, BN, WM, WN, XST, WST>;
   constexpr int TABLE = 8208;
-  static_assert((C::LDS + TABLE) * MINB <= 160 * 1024 || XST == 3, "LDS budget");
+  ConvParams p = p_in;
+  if ((size_t)(C::LDS + TABLE) * MINB > 160 * 1024) p.gelu_lut = nullptr;   // no room for the table beside these rings: erf
   static PerDeviceOnce once;
-  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_sp_pairs_kernel<BM, BN, WM, WN, XST, WST, MINB, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, std::min(C::LDS + TABLE, 160 * 1024))); });
+  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_sp_kernel<BM, BN, WM, WN, XST, WST, MINB, SCHED, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, std::min(C::LDS + TABLE, 160 * 1024))); });
   const size_t lds = C::LDS + (p.act == kActGelu && p.gelu_lut ? TABLE : 0);
-  if (lds * MINB > 160 * 1024) throw std::runtime_error("gemm_sp: this configuration has no room for the GELU table");
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
   const int cap = device_cu_count(256) * MINB / 8 * 8;
   const int grid = std::min((tilesM * tilesN + 7) / 8 * 8, std::max(cap, 8));
-  hipLaunchKernelGGL((gemm_sp_pairs_kernel<BM, BN, WM, WN, XST, WST, MINB, SCHED>), dim3(grid), dim3(C::NT), lds, s, p);
+  hipLaunchKernelGGL((gemm_sp_kernel<BM, BN, WM, WN, XST, WST, MINB, SCHED, NP>), dim3(grid), dim3(C::NT), lds, s, p);
 }
 
 static int g_sp_sched = 1;   // 1: fragment reads and requests interleaved with the first MFMAs of a phase; 0: in front of them
 void set_gemm_sp_sched(int v) { g_sp_sched = v; }
 
-// shapes this kernel takes (gemm2.hip's split mode keeps the rest): activation pairs, ks = 1, one source, no pooled / ReLU-copy outputs, K a
-// multiple of 64 of at least 192
+// shapes these kernels take (gemm2.hip's split mode keeps the rest): ks = 1, one source, no pooled / ReLU-copy outputs, K a multiple of 64;
+// pairs: K >= 192; triples: K >= 128 and K / 64 even (the K loop runs in pairs of k0)
 bool gemm_sp_eligible(const ConvParams& p) {
-  return p.split == 3 && p.ks == 1 && p.C1 == 0 && !p.out_pool && !p.out_relu && p.C0 % 64 == 0 && p.C0 >= 192 && p.Cout % 8 == 0 &&
-         (size_t)p.M * p.C0 * 4 < ((size_t)1 << 31) && (size_t)p.Cout * p.C0 * 6 < ((size_t)1 << 31);
+  if ((p.split != 3 && p.split != 4) || p.ks != 1 || p.C1 != 0 || p.out_pool || p.out_relu || p.C0 % 64 != 0 || p.Cout % 8 != 0) return false;
+  if (p.split == 3 ? p.C0 < 192 : (p.C0 < 128 || (p.C0 >> 6) % 2 != 0)) return false;
+  return (size_t)p.M * p.C0 * (p.split == 3 ? 4 : 6) < ((size_t)1 << 31) && (size_t)p.Cout * p.C0 * 6 < ((size_t)1 << 31);
 }
 
-// cfg: 2 = 256 x 128 tiles, 6 = 128 x 256 (one workgroup of 8 waves per CU, rings 3 + 3), 3 = 128 x 128 (two workgroups of 4 waves per CU:
-// one's epilogue - its stores have to drain before its next tile's first s_waitcnt vmcnt - runs under the other's MFMAs; rings 3 + 2, or 2 + 2
-// beside the GELU table).  The caller has run gemm2_check and filled p.gelu_lut.
+// cfg: 2 = 256 x 128 tiles, 6 = 128 x 256 (one workgroup of 8 waves per CU), 3 = 128 x 128 (two workgroups of 4 waves per CU: one's epilogue -
+// its stores have to drain before its next tile's first s_waitcnt vmcnt - runs under the other's MFMAs).  Rings: pairs 3 + 3 on the big tiles,
+// 3 + 2 (2 + 2 beside the GELU table) on the small one; triples 3 + 2 everywhere.  The caller has run gemm2_check and filled p.gelu_lut.
 void launch_gemm_sp(const ConvParams& p, int cfg, hipStream_t s) {
   if (!gemm_sp_eligible(p)) throw std::runtime_error("gemm_sp: shape not supported");
   const bool sched = g_sp_sched != 0;
   const bool table = p.act == kActGelu && p.gelu_lut;
+  if (p.split == 4) {
+    if (cfg == 6) launch_sp<128, 256, 2, 4, 3, 2, 1, true, 4>(p, s);
+    else if (cfg == 2) launch_sp<256, 128, 4, 2, 3, 2, 1, true, 4>(p, s);
+    else launch_sp<128, 128, 2, 2, 3, 2, 2, true, 4>(p, s);
+    return;
+  }
   if (cfg == 6) { if (sched) launch_sp<128, 256, 2, 4, 3, 3, 1, true>(p, s); else launch_sp<128, 256, 2, 4, 3, 3, 1, false>(p, s); }
   else if (cfg == 2) { if (sched) launch_sp<256, 128, 4, 2, 3, 3, 1, true>(p, s); else launch_sp<256, 128, 4, 2, 3, 3, 1, false>(p, s); }
   else if (table) { if (sched) launch_sp<128, 128, 2, 2, 2, 2, 2, true>(p, s); else launch_sp<128, 128, 2, 2, 2, 2, 2, false>(p, s); }

@@ -19,6 +19,7 @@ void launch_gemm2(const ConvParams& p, int cfg, hipStream_t s);
 void set_gemm2_split_dbg(int v);     // split mode timing experiments (wrong results): 1 = no output stores
 void set_gemm2_split_wreg(int v);    // split mode: 1 (default) w0b from the W0 tile in registers on the big tiles, 0 = staged copy (A/B)
 void set_gemm2_split_stream(int v);   // split mode, pairs, plain GEMM shapes: gemm_sp.hip's kernel (1, default) or gemm2's (0)
+void set_gemm2_split_stream4(int v);  // the same for activation triples (1, default)
 bool gemm_sp_eligible(const ConvParams& p);
 void set_gemm_sp_sched(int v);
 void launch_gemm_sp(const ConvParams& p, int cfg, hipStream_t s);   // gemm_sp.hip: streamlined split-pairs GEMM (cfg 2 = 256 x 128 tiles, 6 = 128 x 256)
