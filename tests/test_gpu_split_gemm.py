@@ -68,9 +68,10 @@ def test_pairs_linear_epilogues(eng, act, planes, resid, cfg):
 
 
 @pytest.mark.parametrize("cfg", [0, 2, 3, 6])
-@pytest.mark.parametrize("shape", SHAPES[:3] + [(128 * 3 + 16, 192, 392)])
+@pytest.mark.parametrize("shape", SHAPES[:3] + [(128 * 3 + 16, 192, 392), (128 * 5 + 8, 128, 392), (128 * 2, 256, 1152)])
 def test_triples_linear_matches_fp32(eng, shape, cfg):
-    """exact activation triples (four MFMAs per product), fp32 output + residual; K / 64 odd (192) stays on gemm2.hip's loop"""
+    """exact activation triples (four MFMAs per product), fp32 output + residual; K / 64 odd (192) stays on gemm2.hip's loop, K = 128 is the
+    shortest the streamlined kernel takes (two k0)"""
     M, K, N = shape
     _case(eng, M, K, N, 4, ACT_NONE, 0, True, cfg, 3)
 
