@@ -128,7 +128,12 @@ __global__ __launch_bounds__(256) void upsample2x_planes_kernel(const f16* __res
 template <int NPL>
 __global__ __launch_bounds__(256) void conv1_split_kernel(const uint8_t* __restrict__ canvas, const f16* __restrict__ wgt /*[64][3][32]*/, const float* __restrict__ bias,
                                                          float out_scale, f16* __restrict__ out /*[M][3*64]*/, int B, int H, int W) {
+  // A wave takes 64 consecutive pixels of one row (W % 32 == 0: the last segment of a row may hold 32).  The three canvas rows around them come
+  // in as 51 aligned dwords each (row bytes 3 x0 - 4 .. 3 x0 + 199: one pixel of halo either side; 3 W and 3 x0 - 4 are multiples of 4) into the
+  // wave's own LDS strip, zero outside the image, and the 27 taps of a pixel are byte reads from there: byte 1 + 3 px + (k % 9) of row k / 9.
+  // (The earlier form fetched every tap with its own global byte load: 32 per lane and 64 pixels instead of 3 dwords.)
   __shared__ f16 lut[3][256];
+  __shared__ __attribute__((aligned(16))) uint8_t strip[4][3][208];
   {
     f16x2 a, b, c = f16x2{(f16)0.f, (f16)0.f};
     if constexpr (NPL == 3) split3_pair((float)threadIdx.x / 255.0f, 0.f, a, b, c);
@@ -136,9 +141,7 @@ __global__ __launch_bounds__(256) void conv1_split_kernel(const uint8_t* __restr
     lut[0][threadIdx.x] = a[0]; lut[1][threadIdx.x] = b[0]; lut[2][threadIdx.x] = c[0];
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, fr = lane & 15, fg = lane >> 4;
-  const int64_t M = (int64_t)B * H * W;
-  const int HW = H * W;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
   f16x8 fw[3][4];   // [weight plane w0 | w0b | w1][jj]
 #pragma unroll
   for (int jj = 0; jj < 4; ++jj) {
@@ -151,28 +154,38 @@ __global__ __launch_bounds__(256) void conv1_split_kernel(const uint8_t* __restr
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int e = 0; e < 8; ++e) bv[t][e] = bias[32 * t + fg * 8 + e];
-  int off[8], dy[8], dx[8];
+  int srow[8], soff[8];                                  // this lane's 8 inputs k = 8 fg + e: strip row k / 9, byte 1 + k % 9 (+ 3 px); k >= 27: none
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const int k = fg * 8 + e, tap = k / 3;
-    dy[e] = tap / 3 - 1; dx[e] = tap % 3 - 1;
-    off[e] = (dy[e] * W + dx[e]) * 3 + (k - tap * 3);
+    const int k = fg * 8 + e;
+    srow[e] = k < 27 ? k / 9 : -1; soff[e] = 1 + (k % 9);
   }
-  const int64_t nwaves = (int64_t)gridDim.x * 4, wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  for (int64_t g = wave0; g * 64 < M; g += nwaves) {
+  const int segs = (W + 63) >> 6;
+  const int64_t ntasks = (int64_t)B * H * segs;
+  const int64_t nwaves = (int64_t)gridDim.x * 4, wave0 = (int64_t)blockIdx.x * 4 + wave;
+  uint8_t (*st)[208] = strip[wave];
+  for (int64_t task = wave0; task < ntasks; task += nwaves) {
+    const int seg = (int)(task % segs);
+    const int64_t by = task / segs;                      // b * H + y
+    const int y = (int)(by % H), x0 = seg << 6, npx = min(64, W - x0);
+    if (lane < 51) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int yy = y - 1 + r;
+        const bool ok = yy >= 0 && yy < H && !(x0 == 0 && lane == 0) && 4 * lane < 3 * (W - x0) + 4;   // (inside the row: the right halo pixel too, where there is one)
+        unsigned v = 0;
+        if (ok) v = *reinterpret_cast<const unsigned*>(canvas + ((by - y + yy) * W + x0) * 3 - 4 + 4 * lane);
+        *reinterpret_cast<unsigned*>(&st[r][4 * lane]) = v;
+      }
+    }
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int64_t m = g * 64 + i * 16 + fr;
+      const int px = i * 16 + fr;
       f16x8 fx[3];
-      const bool mv = m < M;
-      const int r = (int)((mv ? m : 0) % HW), y = r / W, x = r - y * W;
-      const uint8_t* px = canvas + (mv ? m : 0) * 3;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int yy = y + dy[e], xx = x + dx[e];
-        const bool ok = mv && (fg * 8 + e < 27) && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        const int byte = ok ? px[off[e]] : 0;            // table entry 0 = (0, 0, 0)
+        const int byte = srow[e] >= 0 ? st[srow[e]][soff[e] + 3 * px] : 0;   // table entry 0 = (0, 0, 0)
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) fx[pl][e] = lut[pl][byte];
       }
@@ -184,10 +197,11 @@ __global__ __launch_bounds__(256) void conv1_split_kernel(const uint8_t* __restr
         acc[jj][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[2][jj], fx[0], a, 0, 0, 0);
       }
     }
+    const int64_t m0 = by * W + x0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int64_t m = g * 64 + i * 16 + fr;
-      if (m >= M) continue;
+      const int px = i * 16 + fr;
+      if (px >= npx) continue;
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         V8 o;
@@ -196,7 +210,7 @@ __global__ __launch_bounds__(256) void conv1_split_kernel(const uint8_t* __restr
           o.v[e] = fmaxf(fmaf(acc[2 * t][i][e], out_scale, bv[t][e]), 0.f);
           o.v[4 + e] = fmaxf(fmaf(acc[2 * t + 1][i][e], out_scale, bv[t][4 + e]), 0.f);
         }
-        st_planes<NPL>(out + m * (NPL * 64) + 32 * t + fg * 8, 64, o);
+        st_planes<NPL>(out + (m0 + px) * (NPL * 64) + 32 * t + fg * 8, 64, o);
       }
     }
   }
@@ -219,8 +233,9 @@ void launch_upsample2x_planes(const void* in, void* out, int B, int H, int W, in
   else hipLaunchKernelGGL(upsample2x_planes_kernel<3>, g, dim3(256), 0, s, (const f16*)in, (f16*)out, B, H, W, C);
 }
 void launch_conv1_split(const uint8_t* canvas, const void* wgt_planes, const float* bias, float out_scale, void* out, int B, int H, int W, hipStream_t s, int planes) {
-  const int64_t M = (int64_t)B * H * W;
-  const int grid = (int)std::min<int64_t>((M + 255) / 256, 256 * 16);
+  if (W % 32) throw std::runtime_error("conv1_split: the canvas width must be a multiple of 32");
+  const int64_t tasks = (int64_t)B * H * ((W + 63) / 64);
+  const int grid = (int)std::min<int64_t>((tasks + 3) / 4, 256 * 16);
   if (planes == 2) hipLaunchKernelGGL(conv1_split_kernel<2>, dim3(grid), dim3(256), 0, s, canvas, (const f16*)wgt_planes, bias, out_scale, (f16*)out, B, H, W);
   else hipLaunchKernelGGL(conv1_split_kernel<3>, dim3(grid), dim3(256), 0, s, canvas, (const f16*)wgt_planes, bias, out_scale, (f16*)out, B, H, W);
 }
