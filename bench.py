@@ -162,6 +162,26 @@ def run_cpu_baseline(words: int, grid: int) -> dict:
         return {"value": None, "unit": "pages/s", "cores": None, "kind": "port", "sample": f"failed: {ex} {err[-300:]}"}
 
 
+def stub_rank(kind: str, rank: int, world: int, wd, args) -> None:
+    """A rank body without a GPU (TUATARA_BENCH_STUB, tests/test_launch_cpu.py): ok = every rank reports, rank 0 prints the line;
+    fail = rank 1 leaves with status 7; hang = rank 1 never returns (the launcher's deadline ends it); stage = rank 1 sits in a watched
+    stage past its allowance (the watchdog's status 3)."""
+    if kind == "fail" and rank == 1:
+        raise SystemExit(7)
+    if kind == "hang" and rank == 1:
+        time.sleep(3600)
+    if kind == "stage" and rank == 1:
+        with wd.stage("stub: communicator set-up", 0.5):
+            time.sleep(3600)
+    if kind in ("fail", "hang", "stage") and rank != 1:
+        time.sleep(3600 if kind != "fail" else 30)      # the healthy ranks wait in their collective: the launcher must end them
+    with wd.stage("stub: work", 30):
+        time.sleep(0.2)
+    if rank == 0:
+        print("rank 0 chatter that is not the result line")
+        print(json.dumps({"metric": "stub", "value": 1.0, "n_gpus": world, "steps": args.steps, "warmup": args.warmup}))
+
+
 # --------------------------------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -183,19 +203,31 @@ def main():
     ap.add_argument("--tune", action="append", default=[], help="engine tuning knob key=value (ttr_engine_set_tuning), repeatable")
     ap.add_argument("--mode", default="throughput", choices=["throughput", "latency"], help="latency: single pages through the sharded path (rank 0 detects, the crop batch is "
                     "broadcast and recognised in shards, ids all-gathered): reports p50_page_latency_ms for N GPUs")
+    ap.add_argument("--deadline", type=float, default=1500.0, help="N > 1 started from this one command: seconds the ranks get before the launcher ends them (exit status 124)")
+    ap.add_argument("--stage-deadline", type=float, default=300.0, help="seconds a rank may spend in one of its watched stages (engine / communicator set-up, first gather) before it "
+                    "leaves with status 3 naming the stage")
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child is not None:
         return cpu_baseline_child(args.cpu_baseline_child)
 
+    from tuatara_amd import launch as L
+
+    if L.wants_launch(args.gpus):
+        # `python3 bench.py --gpus N` with no launcher around it: this process starts the N ranks itself (one per GPU, this same command line,
+        # RANK / WORLD_SIZE / MASTER_* in their environment), relays rank 0's JSON line and leaves with their status; it never touches a GPU.
+        # An external `python -m torch.distributed.run ... bench.py --gpus N` keeps working: its ranks arrive here with WORLD_SIZE set.
+        status, _ = L.run_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, deadline_s=args.deadline)
+        raise SystemExit(status)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N")
-        args.gpus = world
+    args.gpus = world
     grid = 1 if args.boxes == "grid40" else 0
+    wd = L.StageWatchdog(rank)            # a rank stuck in one stage leaves with status 3 and the stage's name
+    stub = os.environ.get("TUATARA_BENCH_STUB")
+    if stub:                              # tests/test_launch_cpu.py: the launcher and the watchdog with a rank body that needs no GPU
+        return stub_rank(stub, rank, world, wd, args)
 
     # the CPU leg first, in a child process, while this process has not touched the GPU (and runs nothing else)
     cpu = None
@@ -221,14 +253,18 @@ def main():
     W.make_synthetic_weights(wdir, seed=0, structured=True)
 
     P, H, Wd, R = args.pages, 1024, 768, max(1, args.reps)
-    eng = Engine(wdir, precision=args.precision, device=local_rank, bench_grid_boxes=grid)
+    with wd.stage("engine set-up (weights to the GPU)", args.stage_deadline):
+        eng = Engine(wdir, precision=args.precision, device=local_rank, bench_grid_boxes=grid)
     for kv in args.tune:
         k, v = kv.split("=")
         assert eng.set_tuning(k.encode(), int(v)) == 0, kv
     comm = None
     if world > 1:
         port = int(os.environ.get("TUATARA_COMM_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 1))
-        comm = Comm(eng, rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), port)
+        with wd.stage("communicator set-up (TCP rendezvous + ncclCommInitRank x 2)", args.stage_deadline):
+            comm = Comm(eng, rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), port)
+        with wd.stage("first host all-gather (barrier)", args.stage_deadline):
+            comm.barrier()
         comm.attach(True)          # from here on every batch all-gathers its token ids on the engine's stream (ncclAllGather)
 
     def fence():
@@ -297,8 +333,11 @@ def main():
             if keep is not None:
                 keep.append(last)
 
+    with wd.stage("first pass (workspaces, first token-id all-gather)", args.stage_deadline):
+        run_passes(eng, 1)         # untimed, before the warm-up proper: the one pass that allocates, and with N > 1 the first gather
     if args.warmup:
-        run_passes(eng, args.warmup * R)
+        with wd.stage("warm-up passes", args.stage_deadline + 30.0 * args.warmup * R):
+            run_passes(eng, args.warmup * R)
     eng.set_profiling(1)           # timed region: HIP events around the dominant kernels only (the CRAFT convolutions)
     fence()
     t0 = time.perf_counter()
@@ -313,7 +352,10 @@ def main():
     if comm:
         cts, gids = comm.last_gathered()
         gathered_rows = int(len(gids))
-        assert cts.shape == (world, P) and len(gids) == int(cts.sum())
+        assert cts.shape == (world, P) and len(gids) == int(cts.sum()), (cts.shape, len(gids))
+        if grid:                                   # the fixed grid: every page of every rank contributes exactly 40 rows of 26 ids
+            assert (cts == 40).all() and gathered_rows == world * P * 40, (gathered_rows, world, P)
+        assert gids.shape[1] == 26 and (gids >= 0).all() and (gids < 98).all()
         dt = float(comm.allgather_host(np.array([dt], np.float64)).max())       # MAX over ranks
     res = kept[-1]
     crops_per_page = float(np.mean([len(r) for r in res]))

@@ -68,5 +68,11 @@ def eng_f32(weights):
 
 
 @pytest.fixture(scope="session")
+def eng_x4(weights):
+    """the engine in its DEFAULT precision (f16x4: fp32-equivalent split-operand f16 MFMA)"""
+    return _engine(weights["dir"], "f16x4")
+
+
+@pytest.fixture(scope="session")
 def eng_bf16(weights):
     return _engine(weights["dir"], "bf16")

@@ -72,3 +72,57 @@ def test_qkv_attn_fused_against_numpy(eng_bf16, N):
     tol = 2.0 ** -7 * np.abs(ref) + 6e-3
     assert (err <= tol).all(), float((err - tol).max())
     assert err.mean() < 2e-3
+
+
+def _ref_qkv_attn_f64(x, w, b):
+    N = x.shape[0]
+    qkv = (x.astype(np.float64).reshape(-1, 384) @ w.astype(np.float64).T + b.astype(np.float64)).reshape(N, 128, 3, 6, 64)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    s = np.einsum("nqhd,nkhd->nhqk", q, k) * 0.125
+    p = np.exp(s - s.max(-1, keepdims=True))
+    o = np.einsum("nhqk,nkhd->nqhd", p, v) / p.sum(-1).transpose(0, 2, 1)[..., None]
+    return o.reshape(N, 128, 384)
+
+
+@pytest.mark.parametrize("N", [1, 7, 43, 300])
+def test_x4_qkv_attn_one_launch_against_float64(eng_x4, N):
+    """gemm_sp.hip's attention epilogue (the default precision's encoder: qkv projection + self-attention of a (crop, head) as one
+    128 x 192 tile; timm Attention.forward inside the module run at /root/reference/tuatara.cpp:307): fp32-equivalent against float64 -
+    1 crop = 6 tiles on 6 workgroups, 43 = a ragged last round, 300 = 1800 tiles (seven per workgroup: the persistent loop, ring
+    wrap-around across tiles, the re-read of the next tile's first fragments)."""
+    rng = np.random.default_rng(100 + N)
+    x = rng.standard_normal((N, 128, 384)).astype(np.float32)
+    if N > 1:
+        x[1] *= 3.0                                                       # peaky softmax rows
+    w = (rng.standard_normal((1152, 384)) / np.sqrt(384)).astype(np.float32) * 1.5
+    b = (0.3 * rng.standard_normal(1152)).astype(np.float32)
+    out = eng_x4.dbg_qkv_attn(x, w, b)
+    out2 = eng_x4.dbg_qkv_attn(x, w, b)
+    assert np.array_equal(out, out2)                                      # no race: bit-identical reruns
+    ref = _ref_qkv_attn_f64(x, w, b)
+    err = np.abs(out - ref)
+    assert np.isfinite(out).all()
+    # fp32 noise: ~1e-6 on the projections (|qkv| ~ 1.5 .. 5), ~1e-5 on scores of magnitude ~100 before the 1/8, softmax-weighted sums of |v| ~ 1.5;
+    # the crop scaled by 3 has scores nine times as large (|s| up to ~1000: fp32's own rounding of a 64-term sum there is ~1e-4)
+    per_crop = err.reshape(N, -1).max(1)
+    tol = np.full(N, 4e-5)
+    if N > 1:
+        tol[1] = 6e-4
+    assert (per_crop < tol).all(), per_crop.tolist()[:8]
+    assert np.delete(err, 1, 0).mean() < 2e-6 if N > 1 else err.mean() < 2e-6
+
+
+def test_x4_encoder_with_and_without_the_fused_qkv_attention(eng_x4):
+    """whole recogniser, 200 crops: the one-launch qkv + attention against the separate GEMM + attention kernels (same arithmetic up to
+    the rounding of K / V to pairs: round-to-nearest in the epilogue, truncation in the stored triples) - logits within fp32 noise, ids equal"""
+    rng = np.random.default_rng(5)
+    crops = rng.integers(0, 256, (200, 32, 128, 3), dtype=np.uint8)
+    try:
+        assert eng_x4.set_tuning(b"qkv_attn_split", 0) == 0
+        la, ia = eng_x4.parseq_logits(crops)
+        assert eng_x4.set_tuning(b"qkv_attn_split", 1) == 0
+        lb, ib = eng_x4.parseq_logits(crops)
+    finally:
+        eng_x4.set_tuning(b"qkv_attn_split", 1)
+    assert np.array_equal(ia, ib)
+    assert np.abs(la - lb).max() < 5e-4, float(np.abs(la - lb).max())

@@ -13,12 +13,6 @@ TOL = 1e-3          # north_star: "logits within 1e-3"
 
 
 @pytest.fixture(scope="module")
-def eng_x4(weights):
-    from tests.conftest import _engine
-    return _engine(weights["dir"], "f16x4")
-
-
-@pytest.fixture(scope="module")
 def eng_x4_random(weights_random):
     from tests.conftest import _engine
     return _engine(weights_random["dir"], "f16x4")

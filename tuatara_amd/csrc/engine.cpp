@@ -68,6 +68,7 @@ struct Tuning {
   int tok_fuse = 1;           // bf16 AR steps: argmax of the previous step + token embedding + norm_c inside the self_kv skinny GEMM
   int ln_fuse = 1;            // bf16 decoder steps: LayerNorm computed inside the skinny GEMM's loader (gemm_sk ln_in)
   int fuse_first = 1;         // bf16: CRAFT conv1_1 fused into conv1_2's loader (conv3p FIRST)
+  int qkv_attn_split = 1;     // split-operand engines, PARSeq encoder: qkv projection + self-attention as ONE launch (gemm_sp.hip, attention epilogue); needs enc_ln_pairs
   int enc_chunk = 0;          // crops per encoder group (0 = all crops at once)
   int enc_ln_pairs = 1;       // split-operand engines, PARSeq encoder: LayerNorm outputs as pairs (qkv and fc1 on three MFMAs per product: their inputs tolerate ~23.5 bits - 3 x 1280 crops: max |dlogit| 7.6e-4 vs 6.9e-4 with triples; proj and fc2 keep exact triples); 0 = triples
   int dec_planes = 1;         // split-operand engines: the decoder's layers hand each other planes (13 launches per AR step instead of 20); 0 = fp32 tensors + split passes
@@ -87,6 +88,7 @@ struct Tuning {
   bool set(const std::string& k, int value) {
     if (k == "decoder_mode") decoder_mode = value;
     else if (k == "enc_chunk") enc_chunk = value;
+    else if (k == "qkv_attn_split") qkv_attn_split = value;
     else if (k == "fuse_first") fuse_first = value;
     else if (k == "ln_fuse") ln_fuse = value;
     else if (k == "tok_fuse") tok_fuse = value;
@@ -511,6 +513,13 @@ struct Engine {
     }
   }
 
+  // Row order of the qkv weight for the fused qkv + attention launch: row n = 192 h + c of the head-major matrix is tile channel c of head h,
+  // c = 96 wn + 32 t + dd -> Q (t = 0), K (t = 1), V (t = 2), d = 32 wn + dd; upstream (timm) row = 384 t + 64 h + d
+  static int qkv_tile_row(int n) {
+    const int h = n / 192, c = n % 192, wn = c / 96, t = (c % 96) / 32, dd = c % 32;
+    return 384 * t + 64 * h + 32 * wn + dd;
+  }
+
   void load_parseq(const std::string& dir) {
     WeightFile wf(dir + "/parseq.ttrw");
     auto lin = [&](const std::string& key, const std::string& wname, const std::string& bname, int cout, int k, int row0 = 0, int rows_total = -1) {
@@ -532,6 +541,17 @@ struct Engine {
       std::string p = "encoder.blocks." + std::to_string(i) + ".";
       vec(p + "norm1.weight", E); vec(p + "norm1.bias", E); vec(p + "norm2.weight", E); vec(p + "norm2.bias", E);
       lin(p + "qkv", p + "attn.qkv.weight", p + "attn.qkv.bias", 3 * E, E);
+      if (prec == kSplit) {   // the fused qkv + attention launch (gemm_sp.hip, attention epilogue) wants the rows tile by tile: head-major, see qkv_tile_row
+        const auto& w = wf.get(p + "attn.qkv.weight", (size_t)3 * E * E).data;
+        const auto& b = wf.get(p + "attn.qkv.bias", (size_t)3 * E).data;
+        std::vector<float> wp((size_t)3 * E * E), bp((size_t)3 * E);
+        for (int n = 0; n < 3 * E; ++n) {
+          const int src = qkv_tile_row(n);
+          memcpy(&wp[(size_t)n * E], &w[(size_t)src * E], sizeof(float) * E);
+          bp[n] = b[src];
+        }
+        upload_linear(pq[p + "qkv_hm"], wp.data(), 3 * E, E, bp.data(), 3 * E, E);
+      }
       lin(p + "proj", p + "attn.proj.weight", p + "attn.proj.bias", E, E);
       lin(p + "fc1", p + "mlp.fc1.weight", p + "mlp.fc1.bias", 4 * E, E);
       lin(p + "fc2", p + "mlp.fc2.weight", p + "mlp.fc2.bias", E, 4 * E);
@@ -994,8 +1014,15 @@ struct Engine {
         for (int l = 0; l < 12; ++l) {
           const std::string p = "encoder.blocks." + std::to_string(l) + ".";
           launch_layernorm_planes(xc, E, pqf.at(p + "norm1.weight").as<float>(), pqf.at(p + "norm1.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream, lnpl);
+          if (tn.qkv_attn_split && lnpl == 2) {   // one launch: the attention of a (crop, head) is the epilogue of its 128 x 192 qkv tile
+            const Linear& L = pq.at(p + "qkv_hm");
+            // executed flops: qkv on pairs (x 3), Q K^T and P V on a triple and a pair (x 4)
+            timed(2.0 * Mc * 3 * E * E * 3 + 2.0 * 2 * nc * 6 * 128.0 * 128 * 64 * 4,
+                  [&] { launch_qkv_attn_split(lnp_at(c0), L.ws.p, L.b.as<float>(), L.inv_scale, attp, nc, stream); });
+          } else {
           sgemm(pq.at(p + "qkv"), lnp_at(c0), Mc, bigp, 3 * E, kActNone, 1, nullptr, 0, nullptr, 0, lnpl + 1, 0, tn.qkv_kv_pairs ? E : 0);   // (K, V: read as pairs)
           launch_attn_enc_split(bigp, attp, nc, stream);
+          }
           sgemm(pq.at(p + "proj"), attp, Mc, nullptr, 0, kActNone, 0, xc, E, xc, E);
           launch_layernorm_planes(xc, E, pqf.at(p + "norm2.weight").as<float>(), pqf.at(p + "norm2.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream, lnpl);
           const int hpl = tn.enc_fc2_pairs ? 2 : 3;                                      // planes of the MLP's hidden activation
@@ -2102,7 +2129,30 @@ int ttr_dbg_qkv_attn(ttr_engine* e, const float* x, int N, const float* w, const
   TTR_GUARD_BEGIN
   Engine& E = *e->e;
   EngineScope lk(E);
-  if (E.prec != kBF16) throw std::runtime_error("ttr_dbg_qkv_attn: bf16 engines only");
+  if (E.prec == kSplit) {   // the fused launch of the default precision: x -> pairs, weight rows head-major, output triples joined here
+    const size_t nx = (size_t)N * 128 * 384;
+    DevBuf dx, dxp, dout;
+    Linear L;
+    dx.ensure(nx * 4); TTR_HIP_CHECK(hipMemcpy(dx.p, x, nx * 4, hipMemcpyHostToDevice));
+    dxp.ensure(nx * 4);
+    launch_split_planes(dx.as<float>(), 384, dxp.p, (int64_t)N * 128, 384, 0, E.stream, 2);
+    std::vector<float> wp((size_t)1152 * 384), bp(1152);
+    for (int n = 0; n < 1152; ++n) { const int src = Engine::qkv_tile_row(n); memcpy(&wp[(size_t)n * 384], &w[(size_t)src * 384], 384 * 4); bp[n] = b[src]; }
+    E.upload_linear(L, wp.data(), 1152, 384, bp.data(), 1152, 384);
+    E.split_by_w.erase(L.w.p);                        // (a local Linear: nothing may find it later)
+    dout.ensure(nx * 6);
+    launch_qkv_attn_split(dxp.p, L.ws.p, L.b.as<float>(), L.inv_scale, dout.p, N, E.stream);
+    std::vector<_Float16> h(nx * 3);
+    TTR_HIP_CHECK(hipMemcpyAsync(h.data(), dout.p, nx * 6, hipMemcpyDeviceToHost, E.stream));
+    TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
+    for (size_t m = 0; m < (size_t)N * 128; ++m)
+      for (int c = 0; c < 384; ++c) {
+        const _Float16* row = h.data() + m * 1152;
+        out[m * 384 + c] = (float)((double)(float)row[c] + ((double)(float)row[384 + c] + (double)(float)row[768 + c]) / 2048.0);
+      }
+    return 0;
+  }
+  if (E.prec != kBF16) throw std::runtime_error("ttr_dbg_qkv_attn: bf16 and f16x4 engines only");
   const size_t nx = (size_t)N * 128 * 384, nw = (size_t)1152 * 384;
   DevBuf dx, dw, db, dout;
   std::vector<uint16_t> h(std::max(nx, nw));

@@ -55,10 +55,13 @@ struct SpCfg {
 //     ph1: MFMA X0(k) W1(k)   reads X1(k)               requests W1(k+1)              then  w0s = W0(k) / 2^11
 //     ph2: MFMA X1(k) w0s     reads X2(k)               requests X1(k+1)
 //     ph3: MFMA X2(k) w0s     reads X0(k+1), W0(k+1)    requests X2(k+1)
-template <int BM, int BN, int WM, int WN, int XST, int WST, int MINB, bool SCHED, int NP>
+// EPI = 1: the encoder's qkv projection with the self-attention of a (crop, head) as its epilogue (below, "attention epilogue"): tiles of
+// 128 rows (one crop) x 192 channels (Q | K | V of one head: the caller passes the weight rows in head-major order), eight waves as 4 x 2.
+template <int BM, int BN, int WM, int WN, int XST, int WST, int MINB, bool SCHED, int NP, int EPI = 0>
 __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams p) {
   using C = SpCfg<BM, BN, WM, WN, XST, WST>;
   static_assert(NP == 3 || (NP == 4 && XST == 3 && WST == 2), "pairs, or triples on rings 3 + 2");
+  static_assert(EPI == 0 || (EPI == 1 && BM == 128 && BN == 192 && WM == 4 && WN == 2 && NP == 3), "attention epilogue: 128 x 192 tiles on 4 x 2 waves, activation pairs");
   constexpr int PLX = NP == 3 ? 2 : 3;                                    // activation planes per row
   if (p.skip && __builtin_nontemporal_load(p.skip) >= p.skip_n) return;   // AR early exit (ConvParams::skip): uniform, before any barrier
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -356,6 +359,187 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
       if (!has_next) break;
       continue;
     }
+    if constexpr (EPI == 1) {
+      // ---- attention epilogue (timm Attention.forward inside the TorchScript module run at tuatara.cpp:307; attn_split.hip is the stand-alone
+      // form): the tile is Q | K | V [128 rows][64] of one (crop, head), its 192 channels ordered so that BOTH waves of a row block hold the
+      // same kinds: tile channel 96 wn + 32 t + dd is Q (t = 0), K (t = 1) or V (t = 2), d = 32 wn + dd.  A lane holds, of row 32 wm + 16 i + q,
+      // the 8 channels 96 wn + 32 t + 8 g + e (e < 4 in acc[2t][i], e >= 4 in acc[2t+1][i]), i.e. d = 32 wn + 8 g + e: an MFMA operand fragment
+      // of that row (k = 8 g + e) for the d half `wn`.  So:
+      //   * wave (wm, wn) takes the 16 queries 32 wm + 16 wn + q: its own d half of their Q (exact triple) stays in registers, the other
+      //     half comes from the partner wave through LDS as fragment images (and the partner's rows of this wave's half go the other way);
+      //   * K (pair) goes to LDS in attn_split.hip's image (rows permuted so that S^T = K Q^T leaves 8 consecutive keys per lane = the P
+      //     fragment of O^T = V^T P^T), V (pair) follows into the same bytes once every wave has its scores, with its d columns permuted so
+      //     that O^T's accumulators hold 8 consecutive d per lane (16-byte stores of the output planes);
+      //   * four MFMAs per product as there: (k0, q0) (k0/2^11, q1) (k0/2^11, q2) (k1/2^11, q0).
+      // The rings are not touched: the loader streams run on into the next tile meanwhile.  No wave-dependent control flow.
+      typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+      constexpr int KV = 16384;                                   // one plane of K or V: 128 rows x 128 B
+      unsigned char* const sQ = smem + C::LDS;                    // [4 wm][2 reader wn][3 planes][64 lanes][16 B]
+      unsigned char* const sK = sQ + 24576;                       // [2 planes][128 rows][128 B]; V afterwards
+      __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0): the prefetched tiles have landed (they were requested >= a phase ago)
+      const float osc = p.out_scale;
+      // lane-constant LDS offsets (few, so that they stay in registers across the K loop): everything else is an immediate
+      const int kR0 = wm * 32 + (((fr >> 2) & 1) << 4) + ((fr >> 3) << 2) + (fr & 3);   // LDS row of key 32 wm + q (key + 16: row + 8)
+      const int kwr = kR0 * 128 + (((wn * 4 + fg) ^ ((kR0 >> 1) & 7)) << 4);           // K write, i = 0: chunk 4 wn + g at position chunk ^ ((row >> 1) & 7)
+      const int krd = fr * 128 + (((wn * 4 + fg) ^ ((fr >> 1) & 7)) << 4);             // K fragment read, kt = 0, this wave's d half (the other: ^ 64)
+      const int qwr = (wm * 2 + (1 - wn)) * 3072 + lane * 16, qrd = (wm * 2 + wn) * 3072 + lane * 16;   // Q exchange image: written for the partner, read as reader
+      const int vwr = (wm * 32 + fr) * 128 + wn * 64 + fg * 8;                          // V write, i = 0
+      const float* const bp = p.bias + n0c + wn * 96 + fg * 8;
+      f16x8 fq[2][3];                                             // [own d half, other d half][plane]
+      f16x8 vp[2][2];                                             // V pairs [plane][i]
+      auto tile_values = [&](int t, int i, float (&v)[8]) {       // bias + scale of the lane's 8 channels of block t, row half i
+        const float4 b0 = *reinterpret_cast<const float4*>(bp + t * 32), b1 = *reinterpret_cast<const float4*>(bp + t * 32 + 4);
+        const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = fmaf(acc[2 * t][i][e], osc, bv[e]); v[4 + e] = fmaf(acc[2 * t + 1][i][e], osc, bv[4 + e]); }
+      };
+      {   // Q: the rows of this wave's queries (i = wn) stay, the other 16 go to the partner
+        float v0[8], v1[8], keep[8], send[8];
+        tile_values(0, 0, v0); tile_values(0, 1, v1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { keep[e] = wn ? v1[e] : v0[e]; send[e] = wn ? v0[e] : v1[e]; }
+        split3_x8(keep, fq[0][0], fq[0][1], fq[0][2]);
+        f16x8 a, b, c;
+        split3_x8(send, a, b, c);
+        unsigned char* d = sQ + qwr;
+        *reinterpret_cast<f16x8*>(d) = a; *reinterpret_cast<f16x8*>(d + 1024) = b; *reinterpret_cast<f16x8*>(d + 2048) = c;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {   // K: key 16 i + q of the wave's 32: i = 1 is 1024 bytes on with position bit 2 flipped
+        float v[8];
+        tile_values(1, i, v);
+        f16x8 a, b;
+        split2_x8(v, a, b);
+        unsigned char* d = sK + (kwr + i * 1024 ^ i * 64);
+        *reinterpret_cast<f16x8*>(d) = a; *reinterpret_cast<f16x8*>(d + KV) = b;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {   // V: kept until every wave is through with K
+        float v[8];
+        tile_values(2, i, v);
+        split2_x8(v, vp[0][i], vp[1][i]);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) fq[1][pl] = *reinterpret_cast<const f16x8*>(sQ + qrd + pl * 1024);
+      const f16 dn = (f16)(1.f / 2048.f);
+      const f16x8 dnv = {dn, dn, dn, dn, dn, dn, dn, dn};
+      // S^T = K Q^T: sacc[kt], lane = query q, LDS key rows 16 kt + 4 g + r = keys 32 (kt >> 1) + 8 g + 4 (kt & 1) + r
+      f32x4 sacc[8];
+      {
+        const unsigned char* const kb[2] = {sK + krd, sK + (krd ^ 64)};
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) {
+          f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const f16x8 k0 = *reinterpret_cast<const f16x8*>(kb[hf] + kt * 2048), x1 = *reinterpret_cast<const f16x8*>(kb[hf] + KV + kt * 2048);
+            const f16x8 k0b = k0 * dnv, k1 = x1 * dnv;
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, fq[hf][0], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0b, fq[hf][1], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0b, fq[hf][2], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, fq[hf][0], a, 0, 0, 0);
+          }
+          sacc[kt] = a;
+        }
+      }
+      // softmax over the 128 keys of a query: 32 values here, the rest in lanes q + 16 g'
+      f16x8 fp[3][4];                                             // [plane][32-key step]: keys 32 s + 8 g + e
+      float rinv;
+      {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[kt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          float ev[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            ev[e] = __expf((sacc[2 * s4 + (e >> 2)][e & 3] - mx) * 0.125f);
+            sum += ev[e];
+          }
+          split3_x8(ev, fp[0][s4], fp[1][s4], fp[2][s4]);
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        rinv = 1.0f / sum;
+      }
+      __syncthreads();                                            // every wave has read K
+      // V: row = key, the 8 values d = 32 wn + 8 g + e go to column positions 32 wn + 4 g + e (e < 4) and 32 wn + 16 + 4 g + e - 4
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const f16x8 v = vp[pl][i];
+          unsigned char* d = sK + vwr + (pl * KV + i * 2048);
+          *reinterpret_cast<f16x4*>(d) = f16x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f16x4*>(d + 32) = f16x4{v[4], v[5], v[6], v[7]};
+        }
+      __syncthreads();
+      // O^T = V^T P^T: A = V^T fragment (16 column positions x 32 keys) by transposed reads of the row-major planes (attn_split.hip)
+      f32x4 oacc[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      {
+        const unsigned vbase = (unsigned)(size_t)(lds_ptr)sK + (unsigned)((8 * fg + (fr >> 2)) * 128 + (fr & 3) * 8);
+#define TTR_SPA_TR(dst, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(vbase), "n"(off))
+#define TTR_SPA_STEP(s)                                                                                        \
+        {                                                                                                      \
+          f16x4 lo[2][4], hi[2][4];                                                                            \
+          TTR_SPA_TR(lo[0][0], (s) * 4096 + 0);  TTR_SPA_TR(hi[0][0], (s) * 4096 + 512 + 0);                   \
+          TTR_SPA_TR(lo[0][1], (s) * 4096 + 32); TTR_SPA_TR(hi[0][1], (s) * 4096 + 512 + 32);                  \
+          TTR_SPA_TR(lo[0][2], (s) * 4096 + 64); TTR_SPA_TR(hi[0][2], (s) * 4096 + 512 + 64);                  \
+          TTR_SPA_TR(lo[0][3], (s) * 4096 + 96); TTR_SPA_TR(hi[0][3], (s) * 4096 + 512 + 96);                  \
+          TTR_SPA_TR(lo[1][0], KV + (s) * 4096 + 0);  TTR_SPA_TR(hi[1][0], KV + (s) * 4096 + 512 + 0);         \
+          TTR_SPA_TR(lo[1][1], KV + (s) * 4096 + 32); TTR_SPA_TR(hi[1][1], KV + (s) * 4096 + 512 + 32);        \
+          TTR_SPA_TR(lo[1][2], KV + (s) * 4096 + 64); TTR_SPA_TR(hi[1][2], KV + (s) * 4096 + 512 + 64);        \
+          TTR_SPA_TR(lo[1][3], KV + (s) * 4096 + 96); TTR_SPA_TR(hi[1][3], KV + (s) * 4096 + 512 + 96);        \
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0][0]), "+v"(lo[0][1]), "+v"(lo[0][2]), "+v"(lo[0][3]), "+v"(hi[0][0]), "+v"(hi[0][1]), "+v"(hi[0][2]), "+v"(hi[0][3]), \
+                       "+v"(lo[1][0]), "+v"(lo[1][1]), "+v"(lo[1][2]), "+v"(lo[1][3]), "+v"(hi[1][0]), "+v"(hi[1][1]), "+v"(hi[1][2]), "+v"(hi[1][3])); \
+          _Pragma("unroll") for (int dt = 0; dt < 4; ++dt) {                                                   \
+            const f16x8 v0 = __builtin_shufflevector(lo[0][dt], hi[0][dt], 0, 1, 2, 3, 4, 5, 6, 7);            \
+            const f16x8 x1 = __builtin_shufflevector(lo[1][dt], hi[1][dt], 0, 1, 2, 3, 4, 5, 6, 7);            \
+            const f16x8 v0b = v0 * dnv, v1 = x1 * dnv;                                                         \
+            f32x4 a = oacc[dt];                                                                                \
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0, fp[0][s], a, 0, 0, 0);                              \
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0b, fp[1][s], a, 0, 0, 0);                             \
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0b, fp[2][s], a, 0, 0, 0);                             \
+            oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1, fp[0][s], a, 0, 0, 0);                       \
+          }                                                                                                    \
+        }
+        TTR_SPA_STEP(0)
+        TTR_SPA_STEP(1)
+        TTR_SPA_STEP(2)
+        TTR_SPA_STEP(3)
+#undef TTR_SPA_STEP
+#undef TTR_SPA_TR
+      }
+      // out planes [M][3][384]: oacc[2u], oacc[2u+1] hold d = 32 u + 8 g + 0..7 of query q
+      {
+        f16* const op = reinterpret_cast<f16*>(p.out) + (int64_t)(m0c + wm * 32 + wn * 16 + fr) * (3 * 384) + (n0c / 192) * 64 + fg * 8;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] = oacc[2 * u][e] * rinv; v[4 + e] = oacc[2 * u + 1][e] * rinv; }
+          f16x8 a, b, c;
+          split3_x8(v, a, b, c);
+          *reinterpret_cast<f16x8*>(op + u * 32) = a; *reinterpret_cast<f16x8*>(op + 384 + u * 32) = b; *reinterpret_cast<f16x8*>(op + 768 + u * 32) = c;
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      if (!has_next) break;
+      // The next tile's first fragments were read in the last phase above, like every k0's; this epilogue needs their 64 registers, so they are
+      // read AGAIN here (their ring slots are untouched: nothing was requested meanwhile) and the first copies die at the top of the epilogue.
+      xr = xr == 0 ? XST - 1 : xr - 1; wr = wr == 0 ? WST - 1 : wr - 1;
+      read_x(fx0); read_w(fw0);
+      continue;
+    }
     // ---- epilogue: lane holds channels n = nb + 32t + (lane>>4)*8 + 0..7 of row m = mb + 16i + (lane&15)
 #pragma unroll
     for (int t = 0; t < C::NJ / 2; ++t) {
@@ -415,19 +599,20 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
 
 #undef TTR_SP_NEXT_DELTAS
 
-template <int BM, int BN, int WM, int WN, int XST, int WST, int MINB, bool SCHED, int NP = 3>
+template <int BM, int BN, int WM, int WN, int XST, int WST, int MINB, bool SCHED, int NP = 3, int EPI = 0>
 static void launch_sp(const ConvParams& p_in, hipStream_t s) {
   using C = SpCfg<BM, BN, WM, WN, XST, WST>;
-  constexpr int TABLE = 8208;
+  constexpr int TABLE = EPI == 1 ? 57344 : 8208;   // behind the rings: the GELU table, or the attention epilogue's Q / K / V images
   ConvParams p = p_in;
   if ((size_t)(C::LDS + TABLE) * MINB > 160 * 1024) p.gelu_lut = nullptr;   // no room for the table beside these rings: erf
   static PerDeviceOnce once;
-  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_sp_kernel<BM, BN, WM, WN, XST, WST, MINB, SCHED, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, std::min(C::LDS + TABLE, 160 * 1024))); });
-  const size_t lds = C::LDS + (p.act == kActGelu && p.gelu_lut ? TABLE : 0);
+  static_assert(EPI == 0 || C::LDS + TABLE <= 160 * 1024, "attention epilogue: rings + images must fit the LDS");
+  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_sp_kernel<BM, BN, WM, WN, XST, WST, MINB, SCHED, NP, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, std::min(C::LDS + TABLE, 160 * 1024))); });
+  const size_t lds = C::LDS + (EPI == 1 || (p.act == kActGelu && p.gelu_lut) ? TABLE : 0);
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
   const int cap = device_cu_count(256) * MINB / 8 * 8;
   const int grid = std::min((tilesM * tilesN + 7) / 8 * 8, std::max(cap, 8));
-  hipLaunchKernelGGL((gemm_sp_kernel<BM, BN, WM, WN, XST, WST, MINB, SCHED, NP>), dim3(grid), dim3(C::NT), lds, s, p);
+  hipLaunchKernelGGL((gemm_sp_kernel<BM, BN, WM, WN, XST, WST, MINB, SCHED, NP, EPI>), dim3(grid), dim3(C::NT), lds, s, p);
 }
 
 static int g_sp_sched = 1;   // 1: fragment reads and requests interleaved with the first MFMAs of a phase; 0: in front of them
@@ -458,6 +643,20 @@ void launch_gemm_sp(const ConvParams& p, int cfg, hipStream_t s) {
   else if (cfg == 2) { if (sched) launch_sp<256, 128, 4, 2, 3, 3, 1, true>(p, s); else launch_sp<256, 128, 4, 2, 3, 3, 1, false>(p, s); }
   else if (table) { if (sched) launch_sp<128, 128, 2, 2, 2, 2, 2, true>(p, s); else launch_sp<128, 128, 2, 2, 2, 2, 2, false>(p, s); }
   else { if (sched) launch_sp<128, 128, 2, 2, 3, 2, 2, true>(p, s); else launch_sp<128, 128, 2, 2, 3, 2, 2, false>(p, s); }
+}
+
+// The encoder's qkv projection + self-attention as ONE launch (EPI = 1 above).  x_pairs: LayerNorm output as f16 pairs [N * 128][2][384];
+// w_planes: the qkv weight planes [1152][3][384] with the rows in HEAD-MAJOR order (row 192 h + 64 c + d = upstream row 384 c + 64 h + d,
+// c = 0 / 1 / 2 for Q / K / V), bias likewise; out: attention output as exact triples [N * 128][3][384] (the projection GEMM's input).
+void launch_qkv_attn_split(const void* x_pairs, const void* w_planes, const float* bias, float inv_scale, void* out_planes, int N, hipStream_t s) {
+  if (N <= 0) return;
+  if (((uintptr_t)x_pairs | (uintptr_t)w_planes | (uintptr_t)bias | (uintptr_t)out_planes) & 15) throw std::runtime_error("qkv_attn_split: operands must be 16-byte aligned");
+  if ((size_t)N * 128 * 384 * 6 >= ((size_t)1 << 31)) throw std::runtime_error("qkv_attn_split: too many crops for 32-bit buffer offsets (the caller groups them)");
+  ConvParams p{};
+  p.in0 = x_pairs; p.C0 = 384; p.B = 1; p.H = 1; p.W = N * 128; p.ks = 1; p.dil = 1;
+  p.wgt = w_planes; p.bias = bias; p.split = 3; p.out_scale = inv_scale; p.out_planes = 3;
+  p.out = out_planes; p.out_ld = 384; p.Cout = 1152; p.M = N * 128; p.act = kActNone;
+  launch_sp<128, 192, 4, 2, 3, 2, 1, true, 3, 1>(p, s);
 }
 
 }  // namespace ttr

@@ -88,6 +88,9 @@ void launch_layernorm_planes(const float* in, int in_ld, const float* gamma, con
                              const int* skip = nullptr, int skip_n = 0);
 // attn_split.hip: ViT encoder self-attention, qkv planes [N*128][3][1152] -> planes [N*128][3][384]
 void launch_attn_enc_split(const void* qkv_planes, void* out_planes, int N, hipStream_t s);
+// gemm_sp.hip: qkv projection + self-attention of the ViT encoder as one launch.  x_pairs [N*128][2][384] (LayerNorm output as pairs), weight planes
+// [1152][3][384] and bias [1152] with the rows in head-major order (192 h + 64 c + d <- upstream 384 c + 64 h + d) -> out triples [N*128][3][384]
+void launch_qkv_attn_split(const void* x_pairs, const void* w_planes, const float* bias, float inv_scale, void* out_planes, int N, hipStream_t s);
 // CRAFT's conv1_1 + bias + ReLU from the u8 canvas into planes [M][3 * 64]; wgt_planes f16 [64][3][32] (k = (ky*3+kx)*3+c, 27 used)
 void launch_conv1_split(const uint8_t* canvas, const void* wgt_planes, const float* bias, float out_scale, void* out, int B, int H, int W, hipStream_t s, int planes = 3);
 
