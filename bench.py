@@ -72,7 +72,7 @@ def cpu_baseline_child(args_json: str) -> None:
     os.makedirs(wdir, exist_ok=True)
     craft_state, parseq_state = W.synth_craft(0, True), W.synth_parseq(0)
     craft, parseq = pipeline.load_models(craft_state, parseq_state)
-    pages = [synth.synthetic_page(sd, H, Wd, n_words=words) for sd in range(a["n_pages"])]
+    pages = [synth.synthetic_page(sd, H, Wd, n_words=words, layout=a.get("layout", "jitter4")) for sd in range(a["n_pages"])]
     ncpu = os.cpu_count() or 1
 
     def one_page(img, det_model, rec):
@@ -150,8 +150,8 @@ def cpu_baseline_child(args_json: str) -> None:
         "implementation": "Python port (oracle/): torch CPU fp32 + C restatement of the OpenCV steps"}))
 
 
-def run_cpu_baseline(words: int, grid: int) -> dict:
-    a = {"words": words, "grid": grid, "n_pages": 2, "pages_per_setting": 2, "threads": [8, 16, 32, 64, 128],
+def run_cpu_baseline(words: int, grid: int, layout: str) -> dict:
+    a = {"words": words, "grid": grid, "layout": layout, "n_pages": 2, "pages_per_setting": 2, "threads": [8, 16, 32, 64, 128],
          "wdir": os.path.join(tempfile.gettempdir(), f"tuatara_bench_cpu_{os.getuid()}")}
     try:
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", json.dumps(a)], stdout=subprocess.PIPE,
@@ -224,6 +224,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world
     grid = 1 if args.boxes == "grid40" else 0
+    # grid40: each word is drawn inside its cell's 150 x 40 px box, so the 40 crops of a page frame text (tuatara_amd/synth.py)
+    layout = "cells5x8" if grid else "jitter4"
     wd = L.StageWatchdog(rank)            # a rank stuck in one stage leaves with status 3 and the stage's name
     stub = os.environ.get("TUATARA_BENCH_STUB")
     if stub:                              # tests/test_launch_cpu.py: the launcher and the watchdog with a rank body that needs no GPU
@@ -232,7 +234,7 @@ def main():
     # the CPU leg first, in a child process, while this process has not touched the GPU (and runs nothing else)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "throughput":
-        cpu = run_cpu_baseline(args.words, grid)
+        cpu = run_cpu_baseline(args.words, grid, layout)
 
     os.environ.setdefault("TUATARA_PRELOAD_TORCH", "0")   # the GPU processes of the benchmark stay torch-free (tuatara_amd/engine.py: load)
     import fcntl
@@ -277,7 +279,7 @@ def main():
     # ------------------------------------------------------------------ latency mode
     if args.mode == "latency":
         one = DeviceBuffer(H * Wd * 3)
-        one.upload(synth.synthetic_page(0, H, Wd, n_words=args.words))
+        one.upload(synth.synthetic_page(0, H, Wd, n_words=args.words, layout=layout))
         if comm:
             comm.attach(False)
         call = (lambda: comm.pages_to_data_sharded(one if rank == 0 else None, 1, H, Wd)) if comm else (lambda: eng.pages_to_data_dev(one, 1, H, Wd))
@@ -309,7 +311,7 @@ def main():
     # device-resident buffers rotated so that consecutive passes never see the same pages
     NB = max(3, args.buffers)
     seeds = [[(((rank * NB + b) * P + i) % 512) for i in range(P)] for b in range(NB)]
-    host_pages = [[synth.synthetic_page(sd, H, Wd, n_words=args.words) for sd in seeds[b]] for b in range(NB)]
+    host_pages = [[synth.synthetic_page(sd, H, Wd, n_words=args.words, layout=layout) for sd in seeds[b]] for b in range(NB)]
     dbufs = []
     for b in range(NB):
         d = DeviceBuffer(P * H * Wd * 3)
@@ -346,6 +348,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     prof = eng.get_profile()
+    kinds = eng.get_profile_kinds()
     eng.set_profiling(0)
     stage = eng.last_stage_ms()
     gathered_rows = None
@@ -364,22 +367,48 @@ def main():
     out = None
     n_pass = args.steps * R
     if rank == 0:
-        mpp = CRAFT_MFMA_PER_PRODUCT[args.precision]
         peak = MFMA_F32_PEAK_TFLOPS if args.precision == "f32" else MFMA_16BIT_PEAK_TFLOPS
-        c = prof["craft"]
-        craft_alg = (CRAFT_GFLOP_PER_PAGE * 1e9 * P * n_pass) / (c["ms"] * 1e-3) / 1e12 if c["ms"] else None
-        # the split-operand engine's launch records carry the flops its matrix cores EXECUTE (algorithmic x 3 or 4 products per value)
-        craft_exec = (c["flops"] / (c["ms"] * 1e-3) / 1e12) if c["ms"] and args.precision == "f16x4" else (craft_alg * mpp if craft_alg else None)
-        traffic = traffic_src = None
-        for name in (("r03_pmc_craft_x4.json",) if args.precision == "f16x4" else ("r02_pmc_craft_b16_v2.json",)):
+        craft_kinds = [k for k in kinds if k["stage"] == 0 and k["ms"] > 0]
+
+        def line(k):
+            """one kernel kind -> its roofline figures: ALGORITHMIC flops / time is `achieved`; what the matrix pipe executes beside it"""
+            sec = k["ms"] * 1e-3
+            return {"kernel": k["kind"], "launches_per_pass": k["launches"] / max(1, n_pass), "avg_launch_us": k["ms"] * 1e3 / max(1, k["launches"]),
+                    "algorithmic_gflop_per_launch": k["alg_flops"] / max(1, k["launches"]) / 1e9,
+                    "achieved": k["alg_flops"] / sec / 1e12, "frac": k["alg_flops"] / sec / 1e12 / peak,
+                    "mfma_pipe_tflops": k["exec_flops"] / sec / 1e12, "mfma_pipe_frac": k["exec_flops"] / sec / 1e12 / peak,
+                    "mfma_flops_per_algorithmic_flop": k["exec_flops"] / k["alg_flops"] if k["alg_flops"] else None}
+
+        dom = max(craft_kinds, key=lambda k: k["ms"]) if craft_kinds else None
+        fam_ms = sum(k["ms"] for k in craft_kinds)
+        fam_alg, fam_exec = sum(k["alg_flops"] for k in craft_kinds), sum(k["exec_flops"] for k in craft_kinds)
+        # HBM bytes per launch of the dominant kernel: the two --pmc passes (FETCH_SIZE doubled, WRITE_SIZE) committed under profiles/
+        traffic = traffic_src = fam_traffic = None
+        for name in (("r04_pmc_craft_x4.json", "r03_pmc_craft_x4.json") if args.precision == "f16x4" else ("r02_pmc_craft_b16_v2.json",)):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     tj = json.load(f)
-                traffic = tj["craft_conv_kernels"]["hbm_bytes_per_launch"]
+                fam_traffic = tj["craft_conv_kernels"]["hbm_bytes_per_launch"]
+                tag = dom["kind"].split("<")[0] if dom else ""
+                width = dom["kind"].split("<")[1].split(",")[0] if dom and "<" in dom["kind"] else ""
+                for kn, kv in tj["kernels"].items():
+                    if tag and tag in kn and (f"<{width}," in kn or f"ILi{width}E" in kn):
+                        traffic = kv["fetch_bytes_per_launch"] + kv["write_bytes_per_launch"]
                 traffic_src = {"file": "profiles/" + name, "build": tj.get("build"), "pages_per_group": tj.get("pages")}
+                break
             except Exception:
                 pass
         total_pages = world * P * n_pass
+        roof = {"bound": "mfma", "peak": peak, "unit": "TFLOP/s"}
+        if dom:
+            roof.update(line(dom))
+            roof["achieved_is"] = ("ALGORITHMIC flops of this kernel's launches (2 x MACs of the unpadded layers it runs: SURVEY.md section 8(d)) / their summed durations, "
+                                   "HIP events on the engine's stream inside the timed region; a run of consecutive launches of the kernel shares one event pair, so the "
+                                   "dispatch gaps inside a run are charged to it.  mfma_pipe_* = the flops the matrix cores execute for them (three f16 MFMAs per product "
+                                   "on activation pairs, four on exact triples: tuatara_amd/csrc/split.h)")
+            roof["share_of_craft_time"] = dom["ms"] / fam_ms if fam_ms else None
+        roof.update({"traffic": traffic, "traffic_unit": "HBM bytes per launch of this kernel (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes over one CRAFT group)",
+                     "traffic_source": traffic_src})
         out = {
             "metric": "pages/sec whole-node (1024x768, ~40 crops/page)", "value": total_pages / dt, "unit": "pages/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -388,7 +417,7 @@ def main():
                                     "of boxes goes to the recogniser: --boxes=grid40), page-level DP, RCCL all-gather of token ids in the C++ host") if grid else
                                    "configs[4]: synthetic stream of 1024x768 pages, the synthetic detector's own boxes, page-level DP, RCCL all-gather of token ids in the C++ host",
                        "pages_per_gpu_per_pass": P, "passes_per_step": R, "pages_per_gpu_per_step": P * R, "ms_per_pass": dt / n_pass * 1e3, "batches_in_flight": 3 if stream else 1,
-                       "words_drawn_per_page": args.words, "crops_per_page": round(crops_per_page, 1), "boxes": args.boxes,
+                       "words_drawn_per_page": args.words, "page_layout": layout + (" (one word inside each of the 40 grid boxes)" if grid else ""), "crops_per_page": round(crops_per_page, 1), "boxes": args.boxes,
                        "ar_steps": "early exit when every crop of the batch has emitted EOS (upstream PARSeq's break, system.py); value_full_ar runs all 26 steps",
                        "decoded_string_length_histogram": lens.tolist(),
                        "distinct_pages": NB * P, "page_buffers_rotated": NB, "weights": "seeded synthetic (designed read-outs on random CRAFT / PARSeq, tuatara_amd/weights.py)",
@@ -399,16 +428,14 @@ def main():
                        "parallelism": f"dp{world}"},
             "gathered_id_rows_last_pass": gathered_rows,
             "stage_ms_last_pass": {k: round(v, 3) for k, v in stage.items()},
-            "roofline": {"kernel": "CRAFT convolutions (conv1_split / conv3p_kernel<SP> / gemm2_kernel<SP> / igemm head)" if args.precision == "f16x4"
-                         else "CRAFT convolutions: conv3p_first2s_kernel / conv3p_kernel / conv3s_kernel / gemm2_kernel",
-                         "bound": "mfma", "achieved": craft_exec, "peak": peak, "unit": "TFLOP/s",
-                         "frac": (craft_exec / peak) if craft_exec else None,
-                         "achieved_is": f"flops the matrix cores execute (algorithmic x {mpp} products per value in this precision; the fp32 head layers x 1) / summed launch "
-                                        "durations (HIP events on the engine's stream, timed region)",
-                         "algorithmic_tflops": craft_alg, "mfma_flops_per_algorithmic_flop": mpp,
-                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes over one CRAFT group)", "traffic_source": traffic_src,
-                         "launches_per_pass": c["launches"] / max(1, n_pass), "avg_launch_us": c["ms"] * 1e3 / max(1, c["launches"]),
-                         "algorithmic_gflop_per_page": CRAFT_GFLOP_PER_PAGE},
+            "roofline": roof,
+            "roofline_craft_family": {"kernel": "all CRAFT convolution launches", "bound": "mfma", "peak": peak, "unit": "TFLOP/s",
+                                      "achieved": fam_alg / (fam_ms * 1e-3) / 1e12 if fam_ms else None, "frac": fam_alg / (fam_ms * 1e-3) / 1e12 / peak if fam_ms else None,
+                                      "mfma_pipe_tflops": fam_exec / (fam_ms * 1e-3) / 1e12 if fam_ms else None,
+                                      "mfma_pipe_frac": fam_exec / (fam_ms * 1e-3) / 1e12 / peak if fam_ms else None,
+                                      "ms_per_pass": fam_ms / max(1, n_pass), "algorithmic_gflop_per_page": fam_alg / max(1, P * n_pass) / 1e9,
+                                      "survey_gflop_per_page": CRAFT_GFLOP_PER_PAGE, "traffic_bytes_per_launch_all_kinds": fam_traffic,
+                                      "by_kernel": sorted((line(k) for k in craft_kinds), key=lambda d: -d["avg_launch_us"] * d["launches_per_pass"])},
         }
 
     # ------------------------------------------------------------------ comparison legs (outside the timed region; 1 GPU only)
@@ -422,21 +449,28 @@ def main():
             e.lib.ttr_dev_sync(e.h)
             return P * passes / (time.perf_counter() - t1), float(np.mean([len(r) for r in kk[-1]]))
 
-        # secondary rooflines (ViT / decoder GEMMs): one pass with every launch bracketed by events
+        # secondary rooflines (ViT / decoder GEMMs): one pass with every launch bracketed by events, by kernel kind
         eng.set_profiling(2)
         run_passes(eng, 1)
         eng.lib.ttr_dev_sync(eng.h)
-        pe = eng.get_profile()
+        pk = [k for k in eng.get_profile_kinds() if k["stage"] == 1 and k["ms"] > 0]
         eng.set_profiling(0)
-        mpp = MFMA_PER_PRODUCT[args.precision]
         peak = MFMA_F32_PEAK_TFLOPS if args.precision == "f32" else MFMA_16BIT_PEAK_TFLOPS
-        q = pe["parseq"]
-        pq_exec = (q["flops"] / (q["ms"] * 1e-3) / 1e12) if q["ms"] else None   # f16x4: executed flops (x 3 for qkv / fc1, x 4 elsewhere); else algorithmic
-        pq_alg = pq_exec / 3.53 if (pq_exec and args.precision == "f16x4") else pq_exec   # encoder mix: (3 * (qkv + fc1) + 4 * (proj + fc2)) / total = 3.53
-        out["roofline_parseq_gemm"] = {"kernel": "PARSeq batched GEMM launches (gemm_sp_pairs_kernel: qkv, fc1, fc2; gemm2_kernel<SP>: proj, cross K/V, refinement pass)" if args.precision == "f16x4"
-                                       else "PARSeq batched GEMM launches (gemm_ws / mlp_fused / gemm2)", "bound": "mfma",
-                                       "achieved": pq_exec, "peak": peak, "unit": "TFLOP/s", "frac": (pq_exec / peak) if pq_exec else None,
-                                       "algorithmic_tflops": pq_alg, "launches_per_pass": q["launches"], "measured": "one extra pass after the timed region"}
+
+        def pline(k):
+            sec = k["ms"] * 1e-3
+            return {"kernel": k["kind"], "launches_per_pass": k["launches"], "avg_launch_us": k["ms"] * 1e3 / max(1, k["launches"]),
+                    "algorithmic_gflop_per_launch": k["alg_flops"] / max(1, k["launches"]) / 1e9, "achieved": k["alg_flops"] / sec / 1e12,
+                    "frac": k["alg_flops"] / sec / 1e12 / peak, "mfma_pipe_frac": k["exec_flops"] / sec / 1e12 / peak}
+
+        p_ms, p_alg, p_exec = sum(k["ms"] for k in pk), sum(k["alg_flops"] for k in pk), sum(k["exec_flops"] for k in pk)
+        out["roofline_parseq_gemm"] = {"kernel": "PARSeq batched matrix launches (encoder linears, the fused qkv + attention launch, cross K/V, refinement pass)", "bound": "mfma",
+                                       "peak": peak, "unit": "TFLOP/s", "achieved": p_alg / (p_ms * 1e-3) / 1e12 if p_ms else None,
+                                       "frac": p_alg / (p_ms * 1e-3) / 1e12 / peak if p_ms else None,
+                                       "mfma_pipe_tflops": p_exec / (p_ms * 1e-3) / 1e12 if p_ms else None, "mfma_pipe_frac": p_exec / (p_ms * 1e-3) / 1e12 / peak if p_ms else None,
+                                       "achieved_is": "per-launch algorithmic flops (2 x MACs of each layer; attention: 4 x keys x d per query and head) / per-launch durations",
+                                       "launches_per_pass": sum(k["launches"] for k in pk), "ms_per_pass": p_ms, "measured": "one extra pass after the timed region, every launch bracketed",
+                                       "by_kernel": sorted((pline(k) for k in pk), key=lambda d: -d["avg_launch_us"] * d["launches_per_pass"])}
         # all 26 AR steps (no early exit from the autoregressive loop)
         eng.set_tuning(b"ar_early_exit", 0)
         out["value_full_ar"], _ = rate(eng, 2)

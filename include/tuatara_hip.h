@@ -99,11 +99,19 @@ int ttr_comm_unique_id(void* id256);
 ttr_comm* ttr_comm_create(ttr_engine* e, int rank, int world, const void* id256);
 /* ... or let rank 0 listen on addr:port (TCP) and hand them over itself (single node: addr = 127.0.0.1) */
 ttr_comm* ttr_comm_create_tcp(ttr_engine* e, int rank, int world, const char* addr, int port);
+/* The same communicator over a TCP transport through rank 0 instead of RCCL (device buffers staged through host memory, every collective
+ * framed with a sequence number and its size: a mismatched call sequence raises instead of hanging).  For ranks that share ONE GPU - RCCL
+ * refuses two ranks on a device -, which is how the multi-rank paths run at world size 2 on a single-GPU box, and as a fallback.
+ * Rendezvous (both forms): rank 0 listens on addr:port for TUATARA_COMM_TIMEOUT seconds (default 120). */
+ttr_comm* ttr_comm_create_socket(ttr_engine* e, int rank, int world, const char* addr, int port);
+const char* ttr_comm_transport(const ttr_comm* c);   /* "rccl" or "socket" */
 void ttr_comm_destroy(ttr_comm* c);
 int ttr_comm_rank(const ttr_comm* c);
 int ttr_comm_world(const ttr_comm* c);
 /* c != NULL: from now on ttr_pages_to_data_dev / ttr_stream_push / ttr_stream_flush all-gather the token ids of every batch (every rank
- * must then make the same sequence of calls with the same page counts); c == NULL: detach. */
+ * must then make the same sequence of calls with the same page counts: a {status, pages} header travels first, and a rank that failed in
+ * its detector or passed another page count makes the call fail on EVERY rank instead of leaving the others in the collective);
+ * c == NULL: detach. */
 int ttr_engine_attach_comm(ttr_engine* e, ttr_comm* c);
 /* The gathered ids of the batch whose results the last such call returned: counts[world][pages] crops per page, ids[sum][26] in
  * (rank, page, crop) order.  Returns the number of id rows (and the sizes through world / pages / ids_need); buffers that are too
@@ -164,6 +172,11 @@ int ttr_last_stage_ms(ttr_engine* e, float ms[4]);
  * index 0 = CRAFT convolutions, 1 = PARSeq encoder (ViT) and batched decoder GEMMs, 2 = the per-step AR decoder GEMMs.  flops = algorithmic 2*M*N*K of the unpadded layers. */
 int ttr_set_profiling(ttr_engine* e, int on);
 int ttr_get_profile(ttr_engine* e, double ms[3], double flops[3], long long launches[3]);
+/* the same records by kernel kind, as JSON text written to buf (at most cap - 1 characters + terminator; returns the full length or -1):
+ *   [{"kind": "conv3p_kernel<128,NP=3>", "stage": 0, "launches": n, "ms": t, "alg_flops": a, "exec_flops": x}, ...]
+ * alg_flops = 2 x MACs of the layers (the figure a roofline is priced with), exec_flops = what the matrix cores execute for them (x 3 / x 4 in
+ * the split-operand precision).  With on = 1 a record spans a run of consecutive launches of one kind (inter-kernel gaps included). */
+int ttr_get_profile_kinds(ttr_engine* e, char* buf, size_t cap);
 
 #ifdef __cplusplus
 }

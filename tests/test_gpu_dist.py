@@ -87,3 +87,98 @@ def test_rccl_gather_beside_torch(weights):
     assert [[x["text"] for x in p] for p in lat] == [[x["text"] for x in p] for p in res]
     comm.close()
     buf.free()
+
+
+# ------------------------------------------------------------------------------------------------------------ world size 2 on ONE GPU
+# RCCL refuses two ranks on one device, so the two processes speak through the engine's socket transport (ttr_comm_create_socket): the
+# SAME C++ code paths as over RCCL - header exchange, counts then payload, the streamed batches' gather on every pass, latency mode's
+# broadcast + shard + gather, failure propagation - only the three collective calls themselves go over TCP (and are checked call by call).
+RANK2 = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, {root!r})
+from tuatara_amd import synth
+from tuatara_amd.engine import Comm, DeviceBuffer, Engine, EngineError
+rank, world, port = int(sys.argv[1]), 2, int(sys.argv[2])
+eng = Engine({wdir!r})
+comm = Comm(eng, rank, world, "127.0.0.1", port, transport="socket")
+assert comm.lib.ttr_comm_transport(comm.h) == b"socket"
+# every rank its own pages (page-level DP): rank r takes seeds 40 + 3 r ..., with different word counts so that the totals differ
+mine = np.stack([synth.synthetic_page(40 + 3 * rank + i, 1024, 768, n_words=6 + 7 * rank + 3 * i) for i in range(3)])
+other = np.stack([synth.synthetic_page(40 + 3 * (1 - rank) + i, 1024, 768, n_words=6 + 7 * (1 - rank) + 3 * i) for i in range(3)])
+buf = DeviceBuffer(mine.nbytes); buf.upload(mine)
+obuf = DeviceBuffer(other.nbytes); obuf.upload(other)
+solo_mine = eng.pages_to_data_dev(buf, 3, 1024, 768)                 # no communicator attached yet: plain calls
+solo_other = eng.pages_to_data_dev(obuf, 3, 1024, 768)
+by_rank = [solo_mine, solo_other] if rank == 0 else [solo_other, solo_mine]
+want_counts = [[len(p) for p in by_rank[r]] for r in range(world)]
+want_ids = np.concatenate([p.ids for r in range(world) for p in by_rank[r]])
+assert sum(want_counts[0]) != sum(want_counts[1])                     # ragged totals: the payload is padded to the larger one
+comm.attach(True)
+res = eng.pages_to_data_dev(buf, 3, 1024, 768)                        # synchronous batch: header, counts, payload
+c, ids = comm.last_gathered()
+assert c.tolist() == want_counts, (c.tolist(), want_counts)
+assert np.array_equal(ids, want_ids)
+assert [[x["text"] for x in p] for p in res] == [[x["text"] for x in p] for p in solo_mine]
+got = []
+for k in range(4):                                                    # streamed batches, three in flight: the gather rides every pass
+    prev = eng.stream_push(buf, 3, 1024, 768)
+    if prev:
+        got.append(comm.last_gathered())
+while True:
+    last = eng.stream_flush()
+    if not last:
+        break
+    got.append(comm.last_gathered())
+assert len(got) == 4
+for c, ids in got:
+    assert c.tolist() == want_counts and np.array_equal(ids, want_ids)
+# a rank that passes another page count: the call fails on BOTH ranks (status / page header), nobody is left in a gather
+try:
+    eng.pages_to_data_dev(buf, 3 if rank == 0 else 2, 1024, 768)
+    raise SystemExit("mismatched page counts went through")
+except EngineError as ex:
+    assert "pages" in str(ex), str(ex)
+# a rank whose detector fails (rank 1: an image too thin to resize): both ranks raise, the next batch works again
+thin = DeviceBuffer(3 * 4 * 3000 * 3)
+try:
+    if rank == 1:
+        eng.pages_to_data_dev(thin, 3, 1, 3000)
+    else:
+        eng.pages_to_data_dev(buf, 3, 1024, 768)
+    raise SystemExit("a failed rank went unnoticed")
+except EngineError as ex:
+    assert ("rank 1 failed" in str(ex)) if rank == 0 else ("thin" in str(ex) or "resize" in str(ex)), str(ex)
+res = eng.pages_to_data_dev(buf, 3, 1024, 768)
+c, ids = comm.last_gathered()
+assert c.tolist() == want_counts and np.array_equal(ids, want_ids)
+comm.attach(False)
+# latency mode: rank 0 detects and packs, the crop batch is broadcast, each rank recognises its shard, the ids are gathered
+lat = comm.pages_to_data_sharded(obuf if rank == 0 else None, 3 if rank == 0 else 0, 1024, 768)
+if rank == 0:
+    assert [[x["text"] for x in p] for p in lat] == [[x["text"] for x in p] for p in solo_other]
+    assert [[x["bbox"] for x in p] for p in lat] == [[x["bbox"] for x in p] for p in solo_other]
+assert comm.allgather_host(np.array([10 + rank], np.int32)).ravel().tolist() == [10, 11]
+comm.close()
+print("OK rank", rank, json.dumps(want_counts))
+'''
+
+
+def test_world_size_two_on_one_gpu_over_the_socket_transport(weights):
+    """Two torch-free processes, one engine each, the same GPU: throughput mode (synchronous and streamed), both failure modes, latency mode."""
+    from tuatara_amd.launch import free_port
+    port = free_port()
+    code = RANK2.format(root=ROOT, wdir=weights["dir"])
+    env = dict(os.environ, TUATARA_PRELOAD_TORCH="0", TUATARA_COMM_TIMEOUT="240")
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(port)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            o, e = p.communicate(timeout=900)
+            outs.append((p.returncode, o, e))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (rc, o, e) in enumerate(outs):
+        assert rc == 0 and f"OK rank {r}" in o, (r, rc, o[-800:], e[-3000:])

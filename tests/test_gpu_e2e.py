@@ -76,18 +76,22 @@ def test_funsd_bf16_margin_aware_equivalence(eng_bf16, oracle_models, funsd):
     assert n_pair >= 0.6 * len(ref) and n_eq == n_pair
 
 
-def test_pytuatara_run_ocr_counterpart(weights, eng_f32, funsd, monkeypatch):
-    """bindings/run_ocr.py:88-93: PIL -> RGB numpy -> pytuatara.image_to_data(img, weights, outputs) -> list of dicts."""
+def test_pytuatara_run_ocr_counterpart(weights, oracle_models, funsd, monkeypatch):
+    """bindings/run_ocr.py:88-93: PIL -> RGB numpy -> pytuatara.image_to_data(img, weights, outputs) -> list of dicts.  What a user of the
+    drop-in gets - the shim's DEFAULT precision (f16x4; no TUATARA_PRECISION in the environment) - against the CPU oracle: same boxes,
+    same order, same strings."""
+    from oracle import pipeline
     from tuatara_amd import build
     build.build_pytuatara()
     sys.path.insert(0, os.path.join(ROOT, "build", "bindings"))
     import pytuatara
-    monkeypatch.setenv("TUATARA_PRECISION", "f32")
+    monkeypatch.delenv("TUATARA_PRECISION", raising=False)
     res = pytuatara.image_to_data(funsd, weights["dir"], "../outputs")
-    ref = eng_f32.image_to_data(funsd)
+    ref = pipeline.image_to_data(*oracle_models, funsd)
     assert isinstance(res, list) and set(res[0].keys()) == {"text", "bbox"}
+    assert len(res) == len(ref) > 20
     assert [r["text"] for r in res] == [r["text"] for r in ref]
-    assert [list(r["bbox"]) for r in res] == [r["bbox"] for r in ref]
+    assert [list(r["bbox"]) for r in res] == [list(r["bbox"]) for r in ref]
 
 
 def test_batch_of_pages_matches_single_pages(eng_f32, funsd):
@@ -128,14 +132,14 @@ def test_batch_of_pages_matches_single_pages_bf16(eng_bf16, funsd):
     assert len(batch[0]) > 5
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16"])
-def test_streamed_batches_equal_synchronous_calls(eng_f32, eng_bf16, funsd, prec):
+@pytest.mark.parametrize("prec", ["f16x4", "f32", "bf16"])
+def test_streamed_batches_equal_synchronous_calls(eng_x4, eng_f32, eng_bf16, funsd, prec):
     """ttr_stream_push / ttr_stream_flush: batch j's detector and batch j-1's recogniser are enqueued before batch j-2's results are
     awaited, and results come back two calls later — same kernels over the same batches, so boxes and strings must equal the
     synchronous call's exactly.  Five batches of different sizes (one of a single page, one of blank pages) and a refusal of synchronous
     calls mid-stream."""
     from tuatara_amd.engine import DeviceBuffer, EngineError
-    eng = eng_f32 if prec == "f32" else eng_bf16
+    eng = {"f16x4": eng_x4, "f32": eng_f32, "bf16": eng_bf16}[prec]
     crops3 = [funsd[:512, :384].copy(), np.ascontiguousarray(funsd[300:812, 200:584]), np.ascontiguousarray(funsd[100:612, 300:684])]
     batches = [crops3, [crops3[1]], [np.full((512, 384, 3), 255, np.uint8)] * 2, crops3[::-1] + crops3, [crops3[2], crops3[0]]]
     bufs = []
@@ -177,7 +181,7 @@ def test_empty_and_blank_inputs(eng_f32):
         eng_f32.image_to_data(np.zeros((8, 8), np.uint8))
 
 
-def test_cpp_cli_and_pytuatara_callers(weights, funsd, tmp_path):
+def test_cpp_cli_and_pytuatara_callers(weights, oracle_models, funsd, tmp_path):
     """The two caller shapes of the reference: the C++ CLI (BGR from its own PNG reader, examples/resume.cpp) and
     pytuatara.image_to_data (RGB array, bindings/run_ocr.py:88-92) — both through the cached-engine C++ shim."""
     import subprocess
@@ -185,16 +189,17 @@ def test_cpp_cli_and_pytuatara_callers(weights, funsd, tmp_path):
     from tuatara_amd import build as B
     from tuatara_amd.engine import Engine
     B.build_all()
-    env = dict(os.environ, TUATARA_PRECISION="f32")
+    from oracle import pipeline
+    env = {k: v for k, v in os.environ.items() if k != "TUATARA_PRECISION"}   # the shim's default precision: what ships
     png = os.path.join(DATA, "funsd_0001129658.png")
     out = subprocess.run([os.path.join(B.ROOT, "build", "examples", "ocr_cli"), png, weights["dir"], str(tmp_path)], capture_output=True, text=True, env=env)
     assert out.returncode == 0, out.stderr
     lines = [ln.split("\t") for ln in out.stdout.splitlines()]
-    eng = Engine(weights["dir"], precision="f32")
-    ref = eng.image_to_data(np.ascontiguousarray(funsd[:, :, ::-1]))       # the CLI feeds BGR
+    ref = pipeline.image_to_data(*oracle_models, np.ascontiguousarray(funsd[:, :, ::-1]))       # the CLI feeds BGR (examples/resume.cpp:9)
     assert len(lines) == len(ref) > 20
     for (bb, text), r in zip(lines, ref):
-        assert [float(v) for v in bb.split()] == r["bbox"] and text == r["text"]
+        assert [float(v) for v in bb.split()] == list(r["bbox"]) and text == r["text"]
+    eng = Engine(weights["dir"])
     # pytuatara in a child process (it caches an engine per weights dir for the life of the process)
     code = ("import sys, numpy as np; from PIL import Image; sys.path.insert(0, %r); import pytuatara;"
             "r = pytuatara.image_to_data(np.array(Image.open(%r).convert('RGB')), %r, %r); print(len(r)); print(r[0])"
@@ -214,10 +219,12 @@ def test_decode_ids_matches_the_reference_tokenizer_on_the_gpu_box():
         assert [ord(ch) for ch in decode_ids(c["ids"])] == c["text"], c["ids"]
 
 
-def test_stream_survives_a_failed_push(eng_bf16, funsd):
+@pytest.mark.parametrize("prec", ["f16x4", "bf16"])
+def test_stream_survives_a_failed_push(eng_x4, eng_bf16, funsd, prec):
     """A push that throws (here: a page too thin to resize, tuatara.cpp:206-234 would produce an empty canvas) must leave the
     two batches in flight, and the staging-slot parity, as they were: the following results belong to the right batches."""
     from tuatara_amd.engine import DeviceBuffer, EngineError
+    eng_bf16 = eng_x4 if prec == "f16x4" else eng_bf16          # (the body below drives `eng_bf16`: whichever engine the case names)
     pages = [np.ascontiguousarray(funsd[:512, :384]), np.ascontiguousarray(funsd[300:812, 200:584]), np.ascontiguousarray(funsd[100:612, 100:484])]
     bufs = []
     for p in pages:
@@ -351,3 +358,26 @@ def test_craft_group_size_does_not_change_results(eng_bf16):
     assert sum(len(p) for p in res[16]) > 20 * P
     assert res[20] == res[16]
     assert res[32] == res[16]
+
+
+def test_craft_group_size_does_not_change_results_in_the_default_precision(eng_x4):
+    """The same in f16x4, whose CRAFT groups are smaller (four bytes per value as f16 pairs: at most 10 pages of 1024x768 keep the widest
+    tensor inside the 2 GiB window of 32-bit buffer offsets; 8 by default): 16 pages in groups of 8, 5 and 3 (the last group ragged)."""
+    from tuatara_amd import synth
+    from tuatara_amd.engine import DeviceBuffer
+    P = 16
+    pages = np.stack([synth.synthetic_page(200 + i, 1024, 768, n_words=24) for i in range(P)])
+    buf = DeviceBuffer(pages.nbytes)
+    buf.upload(pages)
+    res = {}
+    try:
+        for g in (8, 5, 3):
+            eng_x4.set_tuning("craft_group", g)
+            r = eng_x4.pages_to_data_dev(buf, P, 1024, 768)
+            res[g] = [[(tuple(x["bbox"]), x["text"]) for x in pg] for pg in r]
+    finally:
+        eng_x4.set_tuning("craft_group", 16)
+    assert sum(len(p) for p in res[8]) > 20 * P
+    assert res[5] == res[8]
+    assert res[3] == res[8]
+    buf.free()

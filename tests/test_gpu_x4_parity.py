@@ -253,6 +253,58 @@ def test_x4_config5_32_pages(eng_x4, eng_f32, oracle_models):
     buf.free()
 
 
+def test_x4_the_benchmark_combination_streamed_equals_synchronous_equals_oracle(eng_x4, oracle_models):
+    """What bench.py times, held to the parity bar: the default precision, 32 pages of the benchmark's own layout per batch (one word in each
+    of the 40 grid cells), CRAFT in 8-page groups, batches fed through ttr_stream_push with three in flight, the detector's own boxes going
+    to the recogniser.  Every streamed batch must equal the synchronous call on the same pages (boxes, strings, ids), and pages 0..2 the
+    CPU oracle (/root/reference/tuatara.cpp:314-512 restated: boxes np.array_equal, strings identical)."""
+    from oracle import pipeline
+    from tuatara_amd import synth
+    from tuatara_amd.engine import DeviceBuffer
+    craft, parseq = oracle_models
+    P = 32
+    sets = [[synth.synthetic_page(s0 + i, 1024, 768, n_words=40, layout="cells5x8") for i in range(P)] for s0 in (0, 32, 64)]
+    bufs = []
+    for pg in sets:
+        b = DeviceBuffer(P * 1024 * 768 * 3)
+        b.upload(np.stack(pg))
+        bufs.append(b)
+    key = lambda batch: [[(tuple(x["bbox"]), x["text"], tuple(x["ids"])) for x in pg] for pg in batch]
+    sync = [key(eng_x4.pages_to_data_dev(b, P, 1024, 768)) for b in bufs]
+    assert sum(len(pg) for pg in sync[0]) >= 20 * P
+    order = [0, 1, 2, 0, 1]                                   # five pushes: three in flight from the third on, buffers reused like the benchmark's
+    got = []
+    for k in order:
+        prev = eng_x4.stream_push(bufs[k], P, 1024, 768)
+        if prev:
+            got.append(key(prev))
+    while True:
+        last = eng_x4.stream_flush()
+        if not last:
+            break
+        got.append(key(last))
+    assert len(got) == len(order)
+    for k, g in zip(order, got):
+        assert g == sync[k], k
+    for k in range(3):
+        ref = pipeline.image_to_data(craft, parseq, sets[0][k])
+        assert np.array_equal(np.array([b for b, _, _ in sync[0][k]]), np.array([r["bbox"] for r in ref])), k
+        assert [t for _, t, _ in sync[0][k]] == [r["text"] for r in ref], k
+    # the fixed 5 x 8 grid the benchmark hands the recogniser (bench_grid_boxes): exactly 40 crops per page, streamed == synchronous there too
+    try:
+        assert eng_x4.set_tuning(b"bench_grid_boxes", 1) == 0
+        gs = key(eng_x4.pages_to_data_dev(bufs[0], P, 1024, 768))
+        assert all(len(pg) == 40 for pg in gs)
+        assert eng_x4.stream_push(bufs[0], P, 1024, 768) == []
+        assert key(eng_x4.stream_flush()) == gs and eng_x4.stream_flush() == []
+        empty = sum(1 for pg in gs for _, t, _ in pg if t == "")
+        assert empty < 0.05 * 40 * P, empty                  # the grid crops frame text: (almost) no empty strings
+    finally:
+        eng_x4.set_tuning(b"bench_grid_boxes", 0)
+    for b in bufs:
+        b.free()
+
+
 def test_strict_crops_fails_like_the_reference_on_an_edge_box(weights, oracle_models):
     """A word that touches the image border: its dilated box leaves the image.  The reference's crop throws there (cv::Exception at
     tuatara.cpp:416); with strict_crops = 1 the engine fails the call the same way, by default it clamps the crop (documented deviation)

@@ -73,16 +73,15 @@ __device__ __forceinline__ float gelu_lut(float x, const float2* lut) {
   return x * fmaf(__builtin_amdgcn_fractf(u), t.y, t.x);                                 // fract(u) == u - floor(u) exactly
 }
 
-// GELU(x) = x * Phi(x) to fp32 accuracy at half the instructions of erff: cubic Hermite interpolation of Phi in the float2[1026] table
-// {Phi(x_i), dPhi/dx(x_i) / 64}, x_i = -8 + i / 64 (interpolation error <= h^4 max|d4Phi| / 384 = 9e-11; beyond +-8 Phi is 0 / 1 to fp32)
+// GELU(x) = x * Phi(x) to fp32 accuracy at a third of the instructions of erff: Phi as one cubic per interval of 1/32 over [-8, 8), its four
+// coefficients one 16-byte table entry (float4[512] {a0, a1, a2, a3}: Phi(x_i + t / 32) ~ a0 + t (a1 + t (a2 + t a3)), the Hermite cubic through
+// Phi and its derivative at both ends: interpolation error <= h^4 max|d4 Phi| / 384 = 1.4e-9; beyond +-8 Phi is 0 / 1 to fp32).  One LDS read
+// and three fmas per value - the form with {Phi, dPhi} pairs (two reads, the coefficients formed per value) cost 224 us of fc1's 835 at 1280 crops.
 __device__ __forceinline__ float gelu_hermite(float x, const float2* lut) {
-  const float u = fmaf(__builtin_amdgcn_fmed3f(x, -8.0f, 7.984375f), 64.0f, 512.0f);   // 0 <= u < 1024
-  const int i = (int)u;
+  const float u = fmaf(__builtin_amdgcn_fmed3f(x, -8.0f, 7.96875f), 32.0f, 256.0f);   // 0 <= u < 512
+  const float4 c = reinterpret_cast<const float4*>(lut)[(int)u];                       // u >= 0: truncation is floor
   const float t = __builtin_amdgcn_fractf(u);
-  const float2 a = lut[i], b = lut[i + 1];
-  const float d = b.x - a.x;
-  const float c2 = fmaf(3.0f, d, fmaf(-2.0f, a.y, -b.y)), c3 = fmaf(-2.0f, d, a.y + b.y);
-  return x * fmaf(fmaf(fmaf(c3, t, c2), t, a.y), t, a.x);
+  return x * fmaf(fmaf(fmaf(c.w, t, c.z), t, c.y), t, c.x);
 }
 
 // GELU of 8 values with the table in LDS at byte address lut_lds.  The table reads are inline asm: hipcc orders every LDS

@@ -1105,6 +1105,15 @@ const char* conv3p_check(const ConvParams& p) {
   return nullptr;
 }
 
+// tile width (output channels per workgroup) launch_conv3p picks for a split-operand layer: 128, 64 or 32 (the profile's kernel kinds)
+int conv3p_split_bn(const ConvParams& p) {
+  const bool wide = p.H % 8 == 0 && p.W % 32 == 0;
+  if (p.Cout <= 64) return (wide && p.Cout <= 32) ? 32 : 64;
+  if (wide) return 128;
+  const int tiles128 = p.B * (p.H / 16) * (p.W / 16) * ((p.Cout + 127) / 128);
+  return tiles128 < 2 * device_cu_count(256) ? 64 : 128;
+}
+
 void launch_conv3p(const ConvParams& p, hipStream_t s) {
   if (const char* e = conv3p_check(p)) throw std::runtime_error(e);
   if (p.split) {   // the one-patch-stage tiles (two workgroups per CU)

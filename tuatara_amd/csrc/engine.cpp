@@ -262,20 +262,201 @@ struct CclBatch {   // device workspaces of the CCL stage for a batch of equally
     if (_r != ncclSuccess) throw std::runtime_error(std::string("RCCL: ") + ncclGetErrorString(_r) + " at " #expr);   \
   } while (0)
 
-// Multi-GPU exchange in the C++ host (RCCL = the NCCL API of /opt/rocm/include/rccl/rccl.h): one process per GPU,
-// two communicators per process - `data` carries the per-batch token-id all-gather (and the latency mode's crop broadcast) on the
-// engine's main stream, `ctl` the small host-side exchanges (crop counts, barriers) on the engine's copy stream: collectives of one
-// communicator must be issued in one order on every rank, and the two kinds interleave differently from batch to batch.
-struct Comm {
+// Multi-GPU exchange in the C++ host (RCCL = the NCCL API of /opt/rocm/include/rccl/rccl.h): one process per GPU.
+// The engine speaks to a Transport: two kinds of collective on device buffers, enqueued on a stream -
+//   all_gather (data: the per-batch token ids on the engine's main stream; control: the small host-side exchanges - crop counts, status
+//   headers, barriers - on the copy stream) and broadcast (latency mode's crop batch).
+// RcclTransport is the product: two communicators per process (collectives of one communicator must be issued in one order on every rank,
+// and the two kinds interleave differently from batch to batch).  SocketTransport carries the SAME calls over TCP through rank 0, staged
+// through host memory, every call framed with a sequence number and its size so that a mismatched call sequence is an error, not a hang: it
+// is what lets two ranks share ONE GPU (RCCL refuses two ranks on a device), i.e. what runs the engine's multi-rank code paths at world
+// size 2 on a single-GPU box (tests/test_gpu_dist.py), and a fallback where RCCL cannot initialise.
+struct Transport {
+  virtual ~Transport() {}
+  virtual const char* name() const = 0;
+  virtual void all_gather(const void* d_send, void* d_recv, size_t bytes, bool control, hipStream_t stream) = 0;   // d_recv: world * bytes, by rank
+  virtual void broadcast(void* d_buf, size_t bytes, int root, hipStream_t stream) = 0;
+};
+
+struct RcclTransport : Transport {
   ncclComm_t data = nullptr, ctl = nullptr;
+  RcclTransport(int rank, int world, const ncclUniqueId ids[2]) {
+    TTR_NCCL_CHECK(ncclCommInitRank(&data, world, ids[0], rank));
+    TTR_NCCL_CHECK(ncclCommInitRank(&ctl, world, ids[1], rank));
+  }
+  ~RcclTransport() override {
+    if (data) (void)ncclCommDestroy(data);
+    if (ctl) (void)ncclCommDestroy(ctl);
+  }
+  const char* name() const override { return "rccl"; }
+  void all_gather(const void* d_send, void* d_recv, size_t bytes, bool control, hipStream_t stream) override {
+    TTR_NCCL_CHECK(ncclAllGather(d_send, d_recv, bytes, ncclChar, control ? ctl : data, stream));
+  }
+  void broadcast(void* d_buf, size_t bytes, int root, hipStream_t stream) override {
+    TTR_NCCL_CHECK(ncclBroadcast(d_buf, d_buf, bytes, ncclChar, root, data, stream));
+  }
+};
+
+// ---- TCP rendezvous: rank 0 listens on addr:port until every other rank has said hello exactly once; strays, duplicates and ranks out of
+// range are turned away; every socket has send / receive timeouts and the whole meeting a deadline.
+namespace rendezvous {
+constexpr uint32_t kMagic = 0x54545243u;   // "TTRC"
+struct Hello { uint32_t magic; int32_t rank, world; };
+inline void fail(const std::string& m) { throw std::runtime_error("comm rendezvous: " + m + (errno ? std::string(": ") + strerror(errno) : std::string())); }
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+inline void set_timeouts(int fd, double seconds) {
+  timeval tv; tv.tv_sec = (long)seconds; tv.tv_usec = (long)((seconds - (long)seconds) * 1e6);
+  setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+  setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
+  int one = 1; setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+}
+inline bool send_all(int fd, const void* p, size_t n) {
+  size_t off = 0;
+  while (off < n) { const ssize_t w = send(fd, (const char*)p + off, n - off, MSG_NOSIGNAL); if (w <= 0) return false; off += (size_t)w; }
+  return true;
+}
+inline bool recv_all(int fd, void* p, size_t n) {
+  size_t off = 0;
+  while (off < n) { const ssize_t r = recv(fd, (char*)p + off, n - off, 0); if (r <= 0) return false; off += (size_t)r; }
+  return true;
+}
+inline sockaddr_in resolve(const char* addr, int port) {
+  sockaddr_in sa{};
+  sa.sin_family = AF_INET; sa.sin_port = htons((uint16_t)port);
+  const char* a = (addr && *addr) ? addr : "127.0.0.1";
+  if (inet_pton(AF_INET, a, &sa.sin_addr) != 1) {
+    hostent* he = gethostbyname(a);
+    if (!he) { errno = 0; fail(std::string("cannot resolve ") + a); }
+    memcpy(&sa.sin_addr, he->h_addr_list[0], sizeof(sa.sin_addr));
+  }
+  return sa;
+}
+inline double deadline_seconds() { const char* v = getenv("TUATARA_COMM_TIMEOUT"); const double d = v ? atof(v) : 0.0; return d > 0 ? d : 120.0; }
+// rank 0: fds[r] = the connection of rank r (fds[0] = -1).  The listener binds the given address (not INADDR_ANY)
+inline std::vector<int> serve(int world, const char* addr, int port, double deadline_s) {
+  std::vector<int> fds(world, -1);
+  const double t_end = now_s() + deadline_s;
+  int ls = socket(AF_INET, SOCK_STREAM, 0);
+  if (ls < 0) fail("socket");
+  auto close_all = [&]() { for (int& f : fds) if (f >= 0) { close(f); f = -1; } close(ls); };
+  int one = 1;
+  setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+  sockaddr_in sa = resolve(addr, port);
+  while (bind(ls, (sockaddr*)&sa, sizeof(sa)) < 0) {   // (a previous run's listener may still be closing)
+    if (errno != EADDRINUSE || now_s() > t_end) { const int e = errno; close(ls); errno = e; fail("bind " + std::string(addr ? addr : "") + ":" + std::to_string(port)); }
+    usleep(100000);
+  }
+  if (listen(ls, world + 8) < 0) { const int e = errno; close(ls); errno = e; fail("listen"); }
+  timeval tv{1, 0};
+  setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);   // accept() wakes up once a second to look at the deadline
+  int have = 0;
+  while (have < world - 1) {
+    if (now_s() > t_end) { close_all(); errno = 0; fail("rank 0 waited " + std::to_string((int)deadline_s) + " s and " + std::to_string(world - 1 - have) + " rank(s) never arrived"); }
+    int cs = accept(ls, nullptr, nullptr);
+    if (cs < 0) { if (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR) continue; const int e = errno; close_all(); errno = e; fail("accept"); }
+    set_timeouts(cs, 5.0);
+    Hello h{};
+    if (!recv_all(cs, &h, sizeof h) || h.magic != kMagic || h.world != world || h.rank <= 0 || h.rank >= world || fds[h.rank] >= 0) { close(cs); continue; }   // a stray, a stranger or a duplicate
+    set_timeouts(cs, deadline_s);
+    fds[h.rank] = cs; ++have;
+  }
+  close(ls);
+  return fds;
+}
+inline int join(int rank, int world, const char* addr, int port, double deadline_s) {
+  const sockaddr_in sa = resolve(addr, port);
+  const double t_end = now_s() + deadline_s;
+  for (;;) {          // rank 0 may not be listening yet
+    int cs = socket(AF_INET, SOCK_STREAM, 0);
+    if (cs < 0) fail("socket");
+    if (connect(cs, (const sockaddr*)&sa, sizeof(sa)) == 0) {
+      set_timeouts(cs, deadline_s);
+      const Hello h{kMagic, rank, world};
+      if (!send_all(cs, &h, sizeof h)) { const int e = errno; close(cs); errno = e; fail("hello"); }
+      return cs;
+    }
+    close(cs);
+    if (now_s() > t_end) fail("connect to " + std::string(addr ? addr : "") + ":" + std::to_string(port));
+    usleep(20000);
+  }
+}
+}  // namespace rendezvous
+
+struct SocketTransport : Transport {
+  int rank, world;
+  std::vector<int> fds;      // rank 0: one per peer; else fds[0] = the connection to rank 0
+  uint64_t seq = 0;
+  PinnedBuf h_send, h_all;
+  struct Frame { uint32_t magic; uint32_t kind; uint64_t seq, bytes; };   // kind: 1 all_gather data, 2 all_gather control, 3 broadcast
+  SocketTransport(int rank_, int world_, const char* addr, int port) : rank(rank_), world(world_) {
+    if (world > 1) {
+      if (rank == 0) fds = rendezvous::serve(world, addr, port, rendezvous::deadline_seconds());
+      else fds.assign(1, rendezvous::join(rank, world, addr, port, rendezvous::deadline_seconds()));
+    }
+  }
+  ~SocketTransport() override { for (int f : fds) if (f >= 0) close(f); }
+  const char* name() const override { return "socket"; }
+  void need(bool ok, const char* what) { if (!ok) { throw std::runtime_error(std::string("socket transport: ") + what + " (peer gone, timeout, or a mismatched collective)"); } }
+  // every rank announces what it is about to do; rank 0 checks that all announcements agree before any payload moves
+  void announce(uint32_t kind, size_t bytes) {
+    ++seq;
+    const Frame mine{rendezvous::kMagic, kind, seq, (uint64_t)bytes};
+    if (rank == 0) {
+      bool ok = true; Frame bad{};
+      for (int r = 1; r < world; ++r) {
+        Frame f{};
+        need(rendezvous::recv_all(fds[r], &f, sizeof f), "receiving a frame");
+        if (f.magic != mine.magic || f.kind != kind || f.seq != seq || f.bytes != mine.bytes) { ok = false; bad = f; }
+      }
+      const uint32_t verdict = ok ? 1u : 0u;
+      for (int r = 1; r < world; ++r) need(rendezvous::send_all(fds[r], &verdict, 4), "sending the verdict");
+      if (!ok) throw std::runtime_error("socket transport: collective mismatch at call " + std::to_string(seq) + ": rank 0 has kind " + std::to_string(kind) + " / " +
+                                        std::to_string(bytes) + " bytes, a peer kind " + std::to_string(bad.kind) + " / " + std::to_string(bad.bytes) + " bytes (call " + std::to_string(bad.seq) + ")");
+    } else {
+      need(rendezvous::send_all(fds[0], &mine, sizeof mine), "sending a frame");
+      uint32_t verdict = 0;
+      need(rendezvous::recv_all(fds[0], &verdict, 4), "receiving the verdict");
+      if (!verdict) throw std::runtime_error("socket transport: collective mismatch at call " + std::to_string(seq) + " (this rank: kind " + std::to_string(kind) + ", " + std::to_string(bytes) + " bytes)");
+    }
+  }
+  void all_gather(const void* d_send, void* d_recv, size_t bytes, bool control, hipStream_t stream) override {
+    h_send.ensure(std::max<size_t>(bytes, 1)); h_all.ensure(std::max<size_t>(bytes * world, 1));
+    if (bytes) TTR_HIP_CHECK(hipMemcpyAsync(h_send.p, d_send, bytes, hipMemcpyDeviceToHost, stream));
+    TTR_HIP_CHECK(hipStreamSynchronize(stream));
+    announce(control ? 2u : 1u, bytes);
+    char* all = h_all.as<char>();
+    if (rank == 0) {
+      if (bytes) memcpy(all, h_send.p, bytes);
+      for (int r = 1; r < world; ++r) need(bytes == 0 || rendezvous::recv_all(fds[r], all + (size_t)r * bytes, bytes), "gathering");
+      for (int r = 1; r < world; ++r) need(bytes == 0 || rendezvous::send_all(fds[r], all, bytes * world), "returning the gather");
+    } else {
+      need(bytes == 0 || rendezvous::send_all(fds[0], h_send.p, bytes), "contributing");
+      need(bytes == 0 || rendezvous::recv_all(fds[0], all, bytes * world), "receiving the gather");
+    }
+    if (bytes) TTR_HIP_CHECK(hipMemcpyAsync(d_recv, all, bytes * world, hipMemcpyHostToDevice, stream));
+    TTR_HIP_CHECK(hipStreamSynchronize(stream));     // (the staging buffer is reused by the next call)
+  }
+  void broadcast(void* d_buf, size_t bytes, int root, hipStream_t stream) override {
+    if (root != 0) throw std::runtime_error("socket transport: broadcast from rank 0 only");
+    h_all.ensure(std::max<size_t>(bytes, 1));
+    if (rank == 0 && bytes) TTR_HIP_CHECK(hipMemcpyAsync(h_all.p, d_buf, bytes, hipMemcpyDeviceToHost, stream));
+    TTR_HIP_CHECK(hipStreamSynchronize(stream));
+    announce(3u, bytes);
+    if (rank == 0) { for (int r = 1; r < world; ++r) need(bytes == 0 || rendezvous::send_all(fds[r], h_all.p, bytes), "broadcasting"); }
+    else {
+      need(bytes == 0 || rendezvous::recv_all(fds[0], h_all.p, bytes), "receiving the broadcast");
+      if (bytes) TTR_HIP_CHECK(hipMemcpyAsync(d_buf, h_all.p, bytes, hipMemcpyHostToDevice, stream));
+      TTR_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+  }
+};
+
+struct Comm {
+  std::unique_ptr<Transport> tr;
   int rank = 0, world = 1;
   struct Engine* E = nullptr;
   DevBuf d_in, d_out;
   PinnedBuf h_in, h_out;
-  ~Comm() {
-    if (data) (void)ncclCommDestroy(data);
-    if (ctl) (void)ncclCommDestroy(ctl);
-  }
 };
 
 // The layout of a gathered batch (pure host logic, tests/test_comm_cpu.py drives it through ttr_gather_layout): every rank
@@ -350,43 +531,62 @@ struct Engine {
   int profiling = 0;                                   // 0 off, 1 = CRAFT conv launches only, 2 = every conv / GEMM launch
   int prof_stage = 0;                                  // 0 = CRAFT convs, 1 = PARSeq encoder (ViT) + batched decoder GEMMs, 2 = per-step AR decoder GEMMs
   std::vector<hipEvent_t> prof_pool;
-  struct ProfRec { int stage; double flops; int launches; };
-  bool seg_open = false;                               // profiling == 1: an event pair brackets a RUN of consecutive CRAFT conv launches
-  double seg_flops = 0; int seg_launches = 0;          // (an event record between two kernels costs ~8 us of idle GPU)
+  // Every timed launch carries its KIND (which kernel family / which layer role), its ALGORITHMIC flops (2 x MACs of the layer: the figure
+  // SURVEY.md section 8(d) prices the roofline with) and the flops the matrix cores EXECUTE for it (x 3 or x 4 in the split-operand mode).
+  struct ProfRec { int stage; int kind; double alg, exec; int launches; };
+  struct ProfKind { std::string name; int stage = 0; double ms = 0, alg = 0, exec = 0; long launches = 0; };
+  std::vector<ProfKind> prof_kinds;
+  std::map<std::string, int> prof_kind_ids;
+  int kind_id(const char* name) {   // (a kind is a name in a stage: the decoder's linears run in the batched stage and in the AR steps)
+    const std::string key = std::string(name) + "#" + std::to_string(prof_stage);
+    auto it = prof_kind_ids.find(key);
+    if (it != prof_kind_ids.end()) return it->second;
+    const int id = (int)prof_kinds.size();
+    prof_kinds.push_back(ProfKind{name, prof_stage});
+    prof_kind_ids[key] = id;
+    return id;
+  }
+  bool seg_open = false;                               // profiling == 1: an event pair brackets a RUN of consecutive CRAFT conv launches of one kind
+  int seg_kind = -1;                                   // (an event record between two kernels costs ~8 us of idle GPU)
+  double seg_alg = 0, seg_exec = 0; int seg_launches = 0;
   std::vector<ProfRec> prof_recs;
   double prof_ms[3] = {0, 0, 0}, prof_flops[3] = {0, 0, 0};
   long prof_launches[3] = {0, 0, 0};
 
-  template <class F> void timed(double true_flops, F&& launch) {
+  template <class F> void timed(const char* kind, double alg_flops, double exec_flops, F&& launch) {
     if (!profiling || (profiling == 1 && prof_stage != 0)) { launch(); return; }
-    const size_t i = prof_recs.size();
-    while (prof_pool.size() < 2 * (i + 1)) { hipEvent_t e; TTR_HIP_CHECK(hipEventCreate(&e)); prof_pool.push_back(e); }
-    if (profiling == 1) {   // the timed region of bench.py: one event pair per run of convolutions, closed by prof_break()
-      if (!seg_open) { TTR_HIP_CHECK(hipEventRecord(prof_pool[2 * i], stream)); seg_open = true; seg_flops = 0; seg_launches = 0; }
+    const int k = kind_id(kind);
+    if (profiling == 1) {   // the timed region of bench.py: one event pair per run of same-kind convolutions, closed by the next kind or by prof_break()
+      if (seg_open && seg_kind != k) prof_break();
+      const size_t i = prof_recs.size();
+      while (prof_pool.size() < 2 * (i + 1)) { hipEvent_t e; TTR_HIP_CHECK(hipEventCreate(&e)); prof_pool.push_back(e); }
+      if (!seg_open) { TTR_HIP_CHECK(hipEventRecord(prof_pool[2 * i], stream)); seg_open = true; seg_kind = k; seg_alg = seg_exec = 0; seg_launches = 0; }
       launch();
-      seg_flops += true_flops; ++seg_launches;
+      seg_alg += alg_flops; seg_exec += exec_flops; ++seg_launches;
       return;
     }
+    const size_t i = prof_recs.size();
+    while (prof_pool.size() < 2 * (i + 1)) { hipEvent_t e; TTR_HIP_CHECK(hipEventCreate(&e)); prof_pool.push_back(e); }
     TTR_HIP_CHECK(hipEventRecord(prof_pool[2 * i], stream));
     launch();
     TTR_HIP_CHECK(hipEventRecord(prof_pool[2 * i + 1], stream));
-    prof_recs.push_back(ProfRec{prof_stage, true_flops, 1});
+    prof_recs.push_back(ProfRec{prof_stage, k, alg_flops, exec_flops, 1});
   }
   void prof_break() {       // call before any kernel that is not a CRAFT convolution, and at the end of CRAFT
     if (!seg_open) return;
     TTR_HIP_CHECK(hipEventRecord(prof_pool[2 * prof_recs.size() + 1], stream));
-    prof_recs.push_back(ProfRec{0, seg_flops, seg_launches});
+    prof_recs.push_back(ProfRec{0, seg_kind, seg_alg, seg_exec, seg_launches});
     seg_open = false;
   }
-  void igemm(const ConvParams& p, double true_flops) {
-    if (prec == kSplit && split_gemm(p, true_flops)) return;
-    timed(true_flops, [&] { launch_igemm(prec, p, stream); });
+  void igemm(const ConvParams& p, double true_flops, const char* kind = "igemm") {
+    if (prec == kSplit && split_gemm(p, true_flops, kind)) return;
+    timed(kind, true_flops, true_flops, [&] { launch_igemm(prec, p, stream); });
   }
   // split-operand engines: the layer as four f16 MFMAs per product (gemm2.hip, SP) when its shape allows; the fp32 inputs
   // are written as planes first (split_ops.hip)
   std::map<const void*, const Linear*> split_by_w;   // fp32 weight pointer -> its Linear (the one with the planes)
   DevBuf split_in[2];
-  bool split_gemm(const ConvParams& p, double true_flops) {
+  bool split_gemm(const ConvParams& p, double true_flops, const char* kind) {
     auto it = split_by_w.find(p.wgt);
     if (it == split_by_w.end() || !tn.split_gemm || p.relu0 || p.relu1 || p.ln_in || p.pre_wgt) return false;
     const Linear& L = *it->second;
@@ -400,7 +600,7 @@ struct Engine {
     prof_break_if_craft();
     launch_split_planes((const float*)p.in0, p.C0, split_in[0].p, p.M, p.C0, 0, stream, 3, p.skip, p.skip_n);
     if (p.C1) launch_split_planes((const float*)p.in1, p.C1, split_in[1].p, p.M, p.C1, 0, stream, 3, p.skip, p.skip_n);
-    timed(true_flops * 4, [&] { if (c3) launch_conv3p(q, stream); else launch_gemm2(q, 0, stream); });   // (split engines report MFMA-executed flops: algorithmic x products)
+    timed(kind, true_flops, true_flops * 4, [&] { if (c3) launch_conv3p(q, stream); else launch_gemm2(q, 0, stream); });
     return true;
   }
   void prof_break_if_craft() { if (prof_stage == 0) prof_break(); }
@@ -413,7 +613,10 @@ struct Engine {
       if (hipEventQuery(prof_pool[2 * done + 1]) != hipSuccess) { (void)hipGetLastError(); break; }
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, prof_pool[2 * done], prof_pool[2 * done + 1]) == hipSuccess) {
-        prof_ms[prof_recs[done].stage] += ms; prof_flops[prof_recs[done].stage] += prof_recs[done].flops; prof_launches[prof_recs[done].stage] += prof_recs[done].launches;
+        const ProfRec& r = prof_recs[done];
+        prof_ms[r.stage] += ms; prof_flops[r.stage] += r.exec; prof_launches[r.stage] += r.launches;
+        ProfKind& k = prof_kinds[r.kind];
+        k.ms += ms; k.alg += r.alg; k.exec += r.exec; k.launches += r.launches;
       }
     }
     if (done == 0) return;
@@ -423,7 +626,7 @@ struct Engine {
 
   // ---- construction
   void upload_linear(Linear& L, const float* w, int cout, int k, const float* bias, int cout_pad, int k_pad,
-                     const std::vector<int>* kmap = nullptr) {
+                     const std::vector<int>* kmap = nullptr, bool own = true) {
     // kmap: for each padded k index the source k index or -1
     std::vector<float> wp((size_t)cout_pad * k_pad, 0.f);
     for (int o = 0; o < cout; ++o)
@@ -461,7 +664,7 @@ struct Engine {
       L.ws.ensure(h.size() * 2);
       TTR_HIP_CHECK(hipMemcpy(L.ws.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
       L.inv_scale = std::ldexp(1.f, -e);
-      split_by_w[L.w.p] = &L;
+      if (own) split_by_w[L.w.p] = &L;       // (only the engine's own layers: a debug entry's local Linear dies with its call)
     }
     std::vector<float> bp(cout_pad, 0.f);
     if (bias) memcpy(bp.data(), bias, sizeof(float) * cout);
@@ -632,7 +835,7 @@ struct Engine {
     c.h_in.ensure(b); c.h_out.ensure(b * c.world); c.d_in.ensure(b); c.d_out.ensure(b * c.world);
     if (bytes) memcpy(c.h_in.p, mine, bytes);
     TTR_HIP_CHECK(hipMemcpyAsync(c.d_in.p, c.h_in.p, b, hipMemcpyHostToDevice, copy_stream));
-    TTR_NCCL_CHECK(ncclAllGather(c.d_in.p, c.d_out.p, b, ncclChar, c.ctl, copy_stream));
+    c.tr->all_gather(c.d_in.p, c.d_out.p, b, true, copy_stream);
     TTR_HIP_CHECK(hipMemcpyAsync(c.h_out.p, c.d_out.p, b * c.world, hipMemcpyDeviceToHost, copy_stream));
     TTR_HIP_CHECK(hipStreamSynchronize(copy_stream));
     if (bytes && all) memcpy(all, c.h_out.p, bytes * c.world);
@@ -678,9 +881,9 @@ struct Engine {
   DevBuf& ws(size_t idx, size_t bytes, bool zero_new = false) {
     while (craft_ws.size() <= idx) craft_ws.emplace_back(new DevBuf());
     DevBuf& d = *craft_ws[idx];
-    const void* before = d.p;
+    const size_t cap_before = d.cap;          // (not the pointer: the allocator may hand the grown block the old address)
     d.ensure(bytes);
-    if (zero_new && d.p != before) TTR_HIP_CHECK(hipMemsetAsync(d.p, 0, d.cap, stream));   // padding channels are written once, here
+    if (zero_new && d.cap != cap_before) TTR_HIP_CHECK(hipMemsetAsync(d.p, 0, d.cap, stream));   // padding channels are written once, here
     return d;
   }
 
@@ -699,7 +902,7 @@ struct Engine {
     p.Cout = L.cout; p.M = B * H * W; p.act = act;
     double flops = 0;   // algorithmic: 2 * M * Cout * K of the *unpadded* layer
     for (const auto& c : craft_convs()) if (std::string(c.name) == name) flops = 2.0 * p.M * c.cout * c.ks * c.ks * c.cin;
-    igemm(p, flops);
+    igemm(p, flops, prec == kSplit ? "igemm_kernel<f32> (CRAFT head 1x1)" : "CRAFT convolutions (igemm / gemm2 / conv3p)");
   }
 
   // canvas u8 [B][H][W][3] (device) -> heat f32 [B][H/2][W/2][2] (device)
@@ -723,11 +926,11 @@ struct Engine {
       p.in0 = d_canvas; p.C0 = 64; p.B = B; p.H = H; p.W = W; p.ks = 3; p.dil = 1;
       p.pre_wgt = L0.w.p; p.pre_bias = L0.b.as<float>();
       p.wgt = L.w.p; p.bias = L.b.as<float>(); p.out_ld = 64; p.out_pool = p1; p.Cout = 64; p.M = (int)M0; p.act = kActRelu;
-      timed(2.0 * M0 * 64 * (27 + 576), [&] { launch_conv3p(p, stream); });
+      timed("conv3p_first2s (conv1_1 + conv1_2 + pool)", 2.0 * M0 * 64 * (27 + 576), 2.0 * M0 * 64 * (27 + 576), [&] { launch_conv3p(p, stream); });
     } else {
       if (prec == kBF16) {   // conv1_1 straight from the u8 canvas
         const Linear& L = craft.at("slice1.0");
-        timed(2.0 * M0 * 64 * 27, [&] { launch_conv1_direct(d_canvas, L.w.p, L.b.as<float>(), c11, B, H, W, stream); });
+        timed("conv1_direct", 2.0 * M0 * 64 * 27, 2.0 * M0 * 64 * 27, [&] { launch_conv1_direct(d_canvas, L.w.p, L.b.as<float>(), c11, B, H, W, stream); });
       } else {
         prof_break(), launch_im2col_l1(prec, d_canvas, a0, B, H, W, stream);
         conv("slice1.0", a0, 32, nullptr, 0, 0, 1, 1, (int)M0, c11, kActRelu);
@@ -780,7 +983,7 @@ struct Engine {
           q.w6 = L6.w.as<bf16>(); q.b6 = L6.b.as<float>(); q.w8 = L8.w.as<bf16>(); q.b8 = L8.b.as<float>(); q.heat = d_heat; q.out = nullptr;
           flops = 2.0 * M1 * (16 * 288 + 16 * 16 + 2 * 16);
         }
-        timed(flops, [&] { launch_conv3s(q, stream); });
+        timed("conv3s (32-channel head)", flops, flops, [&] { launch_conv3s(q, stream); });
       };
       head("conv_cls.0", u4b, h0, false);
       head("conv_cls.2", h0, h2, false);
@@ -817,7 +1020,12 @@ struct Engine {
     for (const auto& c : craft_convs()) if (std::string(c.name) == name) flops = 2.0 * p.M * c.cout * c.ks * c.ks * c.cin;
     const bool c3 = tn.split_conv3p && p.Cout >= 32 && conv3p_check(p) == nullptr;
     if (!c3) { if (const char* e = gemm2_check(p)) throw std::runtime_error(std::string(name) + ": " + e); }
-    timed(flops * np, [&] { if (c3) launch_conv3p(p, stream); else launch_gemm2(p, 0, stream); });
+    // kinds by kernel: the patch-stationary 3x3 kernel by its tile width (conv3p.hip picks it), everything else on gemm2's split loop
+    const int bn = c3 ? conv3p_split_bn(p) : 0;
+    const char* kind = !c3 ? (np == 3 ? "gemm2_kernel<SP,NP=3> (CRAFT 1x1 / dilated)" : "gemm2_kernel<SP,NP=4> (CRAFT 1x1 / dilated)")
+                     : bn == 128 ? (np == 3 ? "conv3p_kernel<128,NP=3>" : "conv3p_kernel<128,NP=4>")
+                     : bn == 64 ? (np == 3 ? "conv3p_kernel<64,NP=3>" : "conv3p_kernel<64,NP=4>") : (np == 3 ? "conv3p_kernel<32,NP=3>" : "conv3p_kernel<32,NP=4>");
+    timed(kind, flops, flops * np, [&] { if (c3) launch_conv3p(p, stream); else launch_gemm2(p, 0, stream); });
   }
   void craft_forward_split(const uint8_t* d_canvas, int B, int H, int W, float* d_heat) {
     prof_stage = 0;
@@ -835,7 +1043,7 @@ struct Engine {
     void* c11 = pbuf(M0, 64);
     {
       const Linear& L0 = craft.at("slice1.0");
-      timed(2.0 * M0 * 64 * 27 * (npl + 1), [&] { launch_conv1_split(d_canvas, L0.ws.p, L0.b.as<float>(), L0.inv_scale, c11, B, H, W, stream, npl); });
+      timed("conv1_split_kernel", 2.0 * M0 * 64 * 27, 2.0 * M0 * 64 * 27 * (npl + 1), [&] { launch_conv1_split(d_canvas, L0.ws.p, L0.b.as<float>(), L0.inv_scale, c11, B, H, W, stream, npl); });
     }
     void* p1 = pbuf(M1, 64);   sconv("slice1.3", c11, 64, nullptr, 0, B, H, W, nullptr, kActRelu, nullptr, p1, 0);
     void* c21 = pbuf(M1, 128); sconv("slice1.7", p1, 64, nullptr, 0, B, H1, W1, c21, kActRelu);
@@ -871,18 +1079,21 @@ struct Engine {
     void* h0 = zbuf(M1);  sconv("conv_cls.0", u4b, 64, nullptr, 0, B, H1, W1, h0, kActRelu, nullptr, nullptr, 0, -1, 64);
     void* h2 = zbuf(M1);  sconv("conv_cls.2", h0, 64, nullptr, 0, B, H1, W1, h2, kActRelu, nullptr, nullptr, 0, -1, 64);
     void* h4 = fbuf(M1, 32); sconv("conv_cls.4", h2, 64, nullptr, 0, B, H1, W1, h4, kActRelu, nullptr, nullptr, 0, /*out_planes=*/0);   // fp32, 16 real + 16 zero channels
-    const int sg = tn.split_gemm; tn.split_gemm = 0;
-    void* h6 = fbuf(M1, 32);
-    conv("conv_cls.6", h4, 32, nullptr, 0, 0, B, H1, W1, h6, kActRelu);
-    conv("conv_cls.8", h6, 32, nullptr, 0, 0, B, H1, W1, nullptr, kActNone, d_heat);
-    tn.split_gemm = sg;
+    {   // the two 1x1 head layers stay on the fp32 MFMA kernel (restored also when a launch throws)
+      struct Restore { int& v; int keep; ~Restore() { v = keep; } } restore{tn.split_gemm, tn.split_gemm};
+      tn.split_gemm = 0;
+      void* h6 = fbuf(M1, 32);
+      conv("conv_cls.6", h4, 32, nullptr, 0, 0, B, H1, W1, h6, kActRelu);
+      conv("conv_cls.8", h6, 32, nullptr, 0, 0, B, H1, W1, nullptr, kActNone, d_heat);
+    }
     prof_break();
   }
 
   // ---- PARSeq
   // split-operand linear on planes: in [M][3 K] -> out (planes [M][3 out_ld] or fp32 [M][out_ld]) and / or out_f32 (+ fp32 residual)
   void sgemm(const Linear& L, const void* in_planes, int M, void* out, int out_ld, int act, int out_planes,
-             float* out_f32 = nullptr, int out_f32_ld = 0, const float* resid = nullptr, int resid_ld = 0, int np = 4, int resid_mod = 0, int out_full_cols = 0) {
+             float* out_f32 = nullptr, int out_f32_ld = 0, const float* resid = nullptr, int resid_ld = 0, int np = 4, int resid_mod = 0, int out_full_cols = 0,
+             const char* kind = nullptr) {
     if (!L.ws.p) throw std::runtime_error("split GEMM: the layer has no weight planes");
     ConvParams p{};
     p.out_full_cols = out_full_cols;
@@ -892,7 +1103,7 @@ struct Engine {
     p.Cout = L.cout; p.M = M; p.act = act;
     p.skip = cur_skip; p.skip_n = cur_skip_n;
     if (const char* e = gemm2_check(p)) throw std::runtime_error(e);
-    timed(2.0 * M * L.cout * L.k * np, [&] { launch_gemm2(p, 0, stream); });
+    timed(kind ? kind : (np == 3 ? "split linear (pairs)" : "split linear (triples)"), 2.0 * M * L.cout * L.k, 2.0 * M * L.cout * L.k * np, [&] { launch_gemm2(p, 0, stream); });
   }
   // out = L(LayerNorm(x)) for the decoder's per-step rows: the skinny GEMM normalises its own activation rows (bf16, few rows);
   // otherwise the LayerNorm kernel writes `scratch` and the plain GEMM follows
@@ -975,7 +1186,7 @@ struct Engine {
       q.w2p = dec_ffn2_packed.as<bf16>(); q.b2 = pq.at("ffn2").b.as<float>();
       q.nln_g = pqf.at("decoder.norm.weight").as<float>(); q.nln_b = pqf.at("decoder.norm.bias").as<float>(); q.nln_eps = 1e-5f; q.nln_out = (bf16*)t384b;
       q.att = (const bf16*)t384; q.wpp = dec_co_packed.as<bf16>(); q.bp = pq.at("cross_out").b.as<float>();
-      timed(2.0 * rows * 384 * 1536 * 2 + 2.0 * rows * 384 * 384, [&] { launch_mlp_fused(q, stream); });
+      timed("mlp_fused (refinement block)", 2.0 * rows * 384 * 1536 * 2 + 2.0 * rows * 384 * 384, 2.0 * rows * 384 * 1536 * 2 + 2.0 * rows * 384 * 384, [&] { launch_mlp_fused(q, stream); });
       gemm(pq.at("head"), t384b, rows, nullptr, 0, kActNone, logits_out, logits_ld);
       return;
     }
@@ -1017,17 +1228,18 @@ struct Engine {
           if (tn.qkv_attn_split && lnpl == 2) {   // one launch: the attention of a (crop, head) is the epilogue of its 128 x 192 qkv tile
             const Linear& L = pq.at(p + "qkv_hm");
             // executed flops: qkv on pairs (x 3), Q K^T and P V on a triple and a pair (x 4)
-            timed(2.0 * Mc * 3 * E * E * 3 + 2.0 * 2 * nc * 6 * 128.0 * 128 * 64 * 4,
+            const double qa = 2.0 * Mc * 3 * E * E, aa = 2.0 * 2 * nc * 6 * 128.0 * 128 * 64;
+            timed("enc.qkv+attention: gemm_sp_kernel<128,192,NP=3,EPI=1>", qa + aa, qa * 3 + aa * 4,
                   [&] { launch_qkv_attn_split(lnp_at(c0), L.ws.p, L.b.as<float>(), L.inv_scale, attp, nc, stream); });
           } else {
-          sgemm(pq.at(p + "qkv"), lnp_at(c0), Mc, bigp, 3 * E, kActNone, 1, nullptr, 0, nullptr, 0, lnpl + 1, 0, tn.qkv_kv_pairs ? E : 0);   // (K, V: read as pairs)
+          sgemm(pq.at(p + "qkv"), lnp_at(c0), Mc, bigp, 3 * E, kActNone, 1, nullptr, 0, nullptr, 0, lnpl + 1, 0, tn.qkv_kv_pairs ? E : 0, "enc.qkv");   // (K, V: read as pairs)
           launch_attn_enc_split(bigp, attp, nc, stream);
           }
-          sgemm(pq.at(p + "proj"), attp, Mc, nullptr, 0, kActNone, 0, xc, E, xc, E);
+          sgemm(pq.at(p + "proj"), attp, Mc, nullptr, 0, kActNone, 0, xc, E, xc, E, 4, 0, 0, "enc.proj");
           launch_layernorm_planes(xc, E, pqf.at(p + "norm2.weight").as<float>(), pqf.at(p + "norm2.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream, lnpl);
           const int hpl = tn.enc_fc2_pairs ? 2 : 3;                                      // planes of the MLP's hidden activation
-          sgemm(pq.at(p + "fc1"), lnp_at(c0), Mc, bigp, 4 * E, kActGelu, hpl, nullptr, 0, nullptr, 0, lnpl + 1);
-          sgemm(pq.at(p + "fc2"), bigp, Mc, nullptr, 0, kActNone, 0, xc, E, xc, E, hpl + 1);
+          sgemm(pq.at(p + "fc1"), lnp_at(c0), Mc, bigp, 4 * E, kActGelu, hpl, nullptr, 0, nullptr, 0, lnpl + 1, 0, 0, "enc.fc1 + GELU");
+          sgemm(pq.at(p + "fc2"), bigp, Mc, nullptr, 0, kActNone, 0, xc, E, xc, E, hpl + 1, 0, 0, "enc.fc2");
         }
         launch_layernorm_planes(xc, E, pqf.at("encoder.norm.weight").as<float>(), pqf.at("encoder.norm.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream);
       }
@@ -1046,7 +1258,7 @@ struct Engine {
         if (!mlp_fused) ln(xc, p + "norm1", 1e-6f, t384, Mc);
         if (prec == kBF16 && gemm_config() >= 0 && (tn.qkv_attn == 2 || (tn.qkv_attn == 1 && nc >= tn.qkv_attn_min)) && (size_t)Mc * E * 2 < ((size_t)1 << 31)) {   // (32-bit buffer offsets)
           const Linear& L = pq.at(p + "qkv");
-          timed(2.0 * Mc * E * 3 * E, [&] { launch_qkv_attn((const bf16*)t384, L.w.as<bf16>(), L.b.as<float>(), (bf16*)att, nc, stream); });
+          timed("qkv_attn_kernel", 2.0 * Mc * E * 3 * E, 2.0 * Mc * E * 3 * E, [&] { launch_qkv_attn((const bf16*)t384, L.w.as<bf16>(), L.b.as<float>(), (bf16*)att, nc, stream); });
         } else {
           gemm(pq.at(p + "qkv"), t384, Mc, tbig, 3 * E, kActNone);
           launch_attn_enc(prec, tbig, att, nc, stream);
@@ -1065,7 +1277,8 @@ struct Engine {
           q.nln_g = pqf.at(nx + ".weight").as<float>(); q.nln_b = pqf.at(nx + ".bias").as<float>(); q.nln_eps = 1e-6f; q.nln_out = (bf16*)t384;
           if (proj_in) { q.att = (const bf16*)att; q.wpp = proj_packed[l].as<bf16>(); q.bp = pq.at(p + "proj").b.as<float>(); }
           q.no_x_store = l == 11 && !tn.mlp_pair;   // behind the last block only the final norm (the decoder's memory) is read
-          timed(2.0 * Mc * E * 4 * E * 2 + (proj_in ? 2.0 * Mc * E * E : 0.0), [&] { if (tn.mlp_pair) launch_mlp_pair(q, stream); else launch_mlp_fused(q, stream); });
+          const double mf = 2.0 * Mc * E * 4 * E * 2 + (proj_in ? 2.0 * Mc * E * E : 0.0);
+          timed("mlp_fused_kernel", mf, mf, [&] { launch_mlp_fused(q, stream); });
           continue;
         }
         ln(xc, p + "norm2", 1e-6f, t384, Mc);
@@ -1321,7 +1534,31 @@ struct Engine {
     TTR_HIP_CHECK(hipEventRecord(ev[2], stream));
   }
 
-  void detect_collect(PageBatch& B) {
+  // With a communicator attached a batch is a collective: a {status, pages} header travels before anything whose size depends on the
+  // ranks' inputs, so that a rank that failed in its detector (`pre`: what detect_enqueue threw; or the box extraction below) or passed
+  // another page count makes the call fail on EVERY rank - instead of leaving the others inside a gather that never completes.
+  void detect_collect(PageBatch& B, std::exception_ptr pre = nullptr) {
+    if (!comm) { if (pre) std::rethrow_exception(pre); detect_collect_local(B); return; }
+    std::exception_ptr err = pre;
+    if (!err) { try { detect_collect_local(B); } catch (...) { err = std::current_exception(); } }
+    const int world = comm->world, n = B.n;
+    int32_t hdr[2] = {err ? -1 : 0, n};
+    std::vector<int32_t> all(2 * (size_t)world, 0);
+    allgather_host(hdr, 8, all.data());
+    if (err) std::rethrow_exception(err);
+    for (int r = 0; r < world; ++r) {
+      if (all[2 * r] < 0) throw std::runtime_error("multi-GPU batch: rank " + std::to_string(r) + " failed before the exchange; the batch is dropped on every rank");
+      if (all[2 * r + 1] != n) throw std::runtime_error("multi-GPU batch: rank " + std::to_string(r) + " passed " + std::to_string(all[2 * r + 1]) + " pages, this rank " + std::to_string(n) +
+                                                        ": every rank must push the same number of pages per batch");
+    }
+    // counts (host-side exchange on the control communicator), so that every rank knows the payload's size
+    std::vector<int32_t> mine(n, 0);
+    for (int pg : B.page_of) mine[pg]++;
+    B.all_counts.assign((size_t)world * n, 0);
+    allgather_host(mine.data(), (size_t)n * 4, B.all_counts.data());
+    B.cap = GatherLayout::from_counts(B.all_counts.data(), world, n).cap;
+  }
+  void detect_collect_local(PageBatch& B) {
     const int n = B.n, GP = B.group, groups = (n + GP - 1) / GP;
     const float ratio_w = 1.f / B.g.ratio, ratio_h = 1.f / B.g.ratio;   // tuatara.cpp:360-361
     std::vector<std::vector<RRect>> dets(n);
@@ -1359,13 +1596,6 @@ struct Engine {
       }
     }
     B.N = (int)B.page_of.size();
-    if (comm) {   // counts first (host-side exchange on the control communicator), so that every rank knows the payload's size
-      std::vector<int32_t> mine(n, 0);
-      for (int pg : B.page_of) mine[pg]++;
-      B.all_counts.assign((size_t)comm->world * n, 0);
-      allgather_host(mine.data(), (size_t)n * 4, B.all_counts.data());
-      B.cap = GatherLayout::from_counts(B.all_counts.data(), comm->world, n).cap;
-    }
   }
 
   void recog_enqueue(PageBatch& B) {
@@ -1394,7 +1624,7 @@ struct Engine {
       ids_dev.ensure(per * 4);
       gath_dev[sl].ensure(per * 4 * comm->world);
       h_gath[sl].ensure(per * 4 * comm->world);
-      TTR_NCCL_CHECK(ncclAllGather(ids_dev.p, gath_dev[sl].p, per, ncclInt32, comm->data, stream));
+      comm->tr->all_gather(ids_dev.p, gath_dev[sl].p, per * 4, false, stream);
       TTR_HIP_CHECK(hipMemcpyAsync(h_gath[sl].p, gath_dev[sl].p, per * 4 * comm->world, hipMemcpyDeviceToHost, stream));
     }
     TTR_HIP_CHECK(hipEventRecord(done_ev[sl], stream));
@@ -1453,10 +1683,11 @@ struct Engine {
     if (verbose) std::cout << ttr_version() << " (HIP " << HIP_VERSION_MAJOR << "." << HIP_VERSION_MINOR << ")\ncraft model loaded" << std::endl;
     PageBatch B;
     B.d_pages = d_pages; B.n = n; B.h = h; B.w = w; B.slot = 0;
-    { RangeScope r("ttr:detect_enqueue"); detect_enqueue(B); }
+    std::exception_ptr pre;
+    { RangeScope r("ttr:detect_enqueue"); try { detect_enqueue(B); } catch (...) { if (!comm) throw; pre = std::current_exception(); } }
     host_us[0] = (float)(now_us() - th0);
     if (verbose) std::cout << "post processing craft predictions..." << std::endl;
-    { RangeScope r("ttr:detect_collect"); detect_collect(B); }
+    { RangeScope r("ttr:detect_collect"); detect_collect(B, pre); }
     const double th1 = now_us();
     if (verbose) std::cout << "loading parseq model...\nparseq model loaded" << std::endl;
     { RangeScope r("ttr:recog_enqueue"); recog_enqueue(B); }
@@ -1504,13 +1735,13 @@ struct Engine {
       TTR_HIP_CHECK(hipMemcpyAsync(rects_dev.p, h_rects[0].p, B.rects.size() * 4, hipMemcpyHostToDevice, stream));
       launch_pack_crops(B.d_pages, B.page_bytes, B.w * 3, rects_dev.as<int>(), crops.as<uint8_t>(), N, stream);
     }
-    TTR_NCCL_CHECK(ncclBroadcast(crops.p, crops.p, (size_t)N * 32 * 128 * 3, ncclUint8, 0, c->data, stream));
+    c->tr->broadcast(crops.p, (size_t)N * 32 * 128 * 3, 0, stream);
     logits.ensure((size_t)per * 26 * 95 * 4);
     ids_dev.ensure((size_t)per * 26 * 4);
     if (hi > lo) parseq_forward(crops.as<uint8_t>() + (size_t)lo * 32 * 128 * 3, hi - lo, logits.as<float>(), nullptr, ids_dev.as<int>());
     gath_dev[0].ensure((size_t)world * per * 26 * 4);
     h_gath[0].ensure((size_t)world * per * 26 * 4);
-    TTR_NCCL_CHECK(ncclAllGather(ids_dev.p, gath_dev[0].p, (size_t)per * 26, ncclInt32, c->data, stream));
+    c->tr->all_gather(ids_dev.p, gath_dev[0].p, (size_t)per * 26 * 4, false, stream);
     TTR_HIP_CHECK(hipMemcpyAsync(h_gath[0].p, gath_dev[0].p, (size_t)world * per * 26 * 4, hipMemcpyDeviceToHost, stream));
     TTR_HIP_CHECK(hipEventRecord(done_ev[0], stream));
     spin_event(done_ev[0]);
@@ -1541,12 +1772,13 @@ struct Engine {
     PageBatch B;
     B.d_pages = d_pages; B.n = n; B.h = h; B.w = w;
     B.slot = q1.live ? (q1.slot ^ 1) : 0;     // from the pipeline's state, not a counter: a push that throws leaves q1 / q2 and the slot parity as they were
-    { RangeScope r("ttr:detect_enqueue"); detect_enqueue(B); }
+    std::exception_ptr pre;      // (with a communicator: a failing rank still takes part in this batch's header exchange, detect_collect)
+    { RangeScope r("ttr:detect_enqueue"); try { detect_enqueue(B); } catch (...) { if (!comm) throw; pre = std::current_exception(); } }
     host_us[0] = (float)(now_us() - th0);
     const double th1 = now_us();
     if (q1.live && !q1.enqueued) { RangeScope r("ttr:recog_enqueue"); recog_enqueue(q1); }
     host_us[4] = (float)(now_us() - th1);
-    { RangeScope r("ttr:detect_collect"); detect_collect(B); }
+    { RangeScope r("ttr:detect_collect"); detect_collect(B, pre); }
     if (q2.live) { RangeScope r("ttr:finish"); prev_n = q2.n; finish(q2, prev_results); }
     if (q1.live) q2 = std::move(q1);
     q1 = std::move(B);
@@ -1624,68 +1856,36 @@ int ttr_pages_to_data_dev(ttr_engine* e, const uint8_t* d_pages, int n, int h, i
 
 struct ttr_comm { std::unique_ptr<Comm> c; };
 
-// rank 0 listens on addr:port and hands its bytes to the world - 1 peers that connect (each sends its rank first)
+// rank 0 listens on addr:port and hands its bytes to the world - 1 peers that say hello (rendezvous:: above: each distinct rank once, strays turned away, timeouts)
 static void tcp_share(int rank, int world, const char* addr, int port, void* buf, size_t bytes) {
   if (world <= 1) return;
-  auto fail = [](const std::string& m) { throw std::runtime_error("comm rendezvous: " + m + ": " + strerror(errno)); };
+  const double dl = rendezvous::deadline_seconds();
   if (rank == 0) {
-    int ls = socket(AF_INET, SOCK_STREAM, 0);
-    if (ls < 0) fail("socket");
-    int one = 1;
-    setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
-    sockaddr_in sa{};
-    sa.sin_family = AF_INET; sa.sin_port = htons((uint16_t)port); sa.sin_addr.s_addr = htonl(INADDR_ANY);
-    for (int attempt = 0; bind(ls, (sockaddr*)&sa, sizeof(sa)) < 0; ++attempt) {   // (a previous run's listener may still be closing)
-      if (errno != EADDRINUSE || attempt > 100) { close(ls); fail("bind port " + std::to_string(port)); }
-      usleep(100000);
-    }
-    if (listen(ls, world) < 0) { close(ls); fail("listen"); }
-    for (int k = 1; k < world; ++k) {
-      int cs = accept(ls, nullptr, nullptr);
-      if (cs < 0) { close(ls); fail("accept"); }
-      int32_t peer = -1;
-      if (recv(cs, &peer, 4, MSG_WAITALL) != 4) { close(cs); close(ls); fail("recv"); }
-      size_t off = 0;
-      while (off < bytes) { ssize_t w = send(cs, (const char*)buf + off, bytes - off, 0); if (w <= 0) { close(cs); close(ls); fail("send"); } off += (size_t)w; }
-      close(cs);
-    }
-    close(ls);
+    std::vector<int> fds = rendezvous::serve(world, addr, port, dl);
+    bool ok = true;
+    for (int r = 1; r < world; ++r) { ok = ok && rendezvous::send_all(fds[r], buf, bytes); }
+    for (int r = 1; r < world; ++r) close(fds[r]);
+    if (!ok) rendezvous::fail("send");
   } else {
-    sockaddr_in sa{};
-    sa.sin_family = AF_INET; sa.sin_port = htons((uint16_t)port);
-    if (inet_pton(AF_INET, (addr && *addr) ? addr : "127.0.0.1", &sa.sin_addr) != 1) {
-      hostent* he = gethostbyname(addr);
-      if (!he) fail(std::string("cannot resolve ") + addr);
-      memcpy(&sa.sin_addr, he->h_addr_list[0], sizeof(sa.sin_addr));
-    }
-    for (int attempt = 0;; ++attempt) {          // rank 0 may not be listening yet
-      int cs = socket(AF_INET, SOCK_STREAM, 0);
-      if (cs < 0) fail("socket");
-      if (connect(cs, (sockaddr*)&sa, sizeof(sa)) == 0) {
-        int32_t me = rank;
-        if (send(cs, &me, 4, 0) != 4) { close(cs); fail("send"); }
-        size_t off = 0;
-        while (off < bytes) { ssize_t r = recv(cs, (char*)buf + off, bytes - off, 0); if (r <= 0) { close(cs); fail("recv"); } off += (size_t)r; }
-        close(cs);
-        return;
-      }
-      close(cs);
-      if (attempt > 3000) fail("connect to " + std::string(addr ? addr : "") + ":" + std::to_string(port));
-      usleep(20000);
-    }
+    const int fd = rendezvous::join(rank, world, addr, port, dl);
+    const bool ok = rendezvous::recv_all(fd, buf, bytes);
+    close(fd);
+    if (!ok) rendezvous::fail("recv");
   }
 }
 
-static ttr_comm* comm_create(ttr_engine* e, int rank, int world, const ncclUniqueId ids[2]) {
-  if (!e || world < 1 || rank < 0 || rank >= world) throw std::runtime_error("ttr_comm_create: bad arguments");
+static ttr_comm* comm_wrap(ttr_engine* e, int rank, int world, std::unique_ptr<Transport> tr) {
   Engine& E = *e->e;
-  EngineScope lk(E);
   std::unique_ptr<ttr_comm> h(new ttr_comm());
   h->c.reset(new Comm());
   h->c->rank = rank; h->c->world = world; h->c->E = &E;
-  TTR_NCCL_CHECK(ncclCommInitRank(&h->c->data, world, ids[0], rank));
-  TTR_NCCL_CHECK(ncclCommInitRank(&h->c->ctl, world, ids[1], rank));
+  h->c->tr = std::move(tr);
   return h.release();
+}
+static ttr_comm* comm_create(ttr_engine* e, int rank, int world, const ncclUniqueId ids[2]) {
+  if (!e || world < 1 || rank < 0 || rank >= world) throw std::runtime_error("ttr_comm_create: bad arguments");
+  EngineScope lk(*e->e);
+  return comm_wrap(e, rank, world, std::unique_ptr<Transport>(new RcclTransport(rank, world, ids)));
 }
 
 int ttr_dbg_tcp_share(int rank, int world, const char* addr, int port, void* buf, size_t bytes) {
@@ -1725,6 +1925,17 @@ ttr_comm* ttr_comm_create_tcp(ttr_engine* e, int rank, int world, const char* ad
   return comm_create(e, rank, world, ids);
   TTR_GUARD_END(nullptr)
 }
+
+// The same communicator over TCP through rank 0 (SocketTransport above): for ranks that share one GPU - RCCL refuses two ranks on a device -
+// and as a fallback; every collective is framed and checked, so a mismatched call sequence raises instead of hanging.
+ttr_comm* ttr_comm_create_socket(ttr_engine* e, int rank, int world, const char* addr, int port) {
+  TTR_GUARD_BEGIN
+  if (!e || world < 1 || rank < 0 || rank >= world) throw std::runtime_error("ttr_comm_create_socket: bad arguments");
+  EngineScope lk(*e->e);
+  return comm_wrap(e, rank, world, std::unique_ptr<Transport>(new SocketTransport(rank, world, addr, port)));
+  TTR_GUARD_END(nullptr)
+}
+const char* ttr_comm_transport(const ttr_comm* c) { return c && c->c && c->c->tr ? c->c->tr->name() : ""; }
 
 void ttr_comm_destroy(ttr_comm* c) {
   if (!c) return;
@@ -2009,7 +2220,7 @@ int ttr_dbg_conv(ttr_engine* e, const float* in0, int C0, const float* in1, int 
   };
   up(d0, in0, M * C0);
   if (C1) up(d1, in1, M * C1);
-  E.upload_linear(L, wgt, Cout, K, bias, Cout, K);
+  E.upload_linear(L, wgt, Cout, K, bias, Cout, K, nullptr, false);
   dout.ensure(M * Cout * 4);
   ConvParams p{};
   p.in0 = d0.p; p.C0 = C0; p.in1 = C1 ? d1.p : nullptr; p.C1 = C1; p.relu0 = relu0; p.relu1 = relu1;
@@ -2046,7 +2257,7 @@ int ttr_dbg_split_gemm(ttr_engine* e, const float* x, int M, int K, const float*
   dx.ensure((size_t)M * K * 4); TTR_HIP_CHECK(hipMemcpy(dx.p, x, (size_t)M * K * 4, hipMemcpyHostToDevice));
   dxp.ensure((size_t)M * K * 2 * ipl);
   launch_split_planes(dx.as<float>(), K, dxp.p, M, K, 0, E.stream, ipl);
-  E.upload_linear(L, w, N, K, bias, N, K);
+  E.upload_linear(L, w, N, K, bias, N, K, nullptr, false);
   if (!L.ws.p) throw std::runtime_error("ttr_dbg_split_gemm: the layer has no weight planes");
   if (resid) { dres.ensure((size_t)M * N * 4); TTR_HIP_CHECK(hipMemcpy(dres.p, resid, (size_t)M * N * 4, hipMemcpyHostToDevice)); }
   dout.ensure((size_t)M * N * (out_planes ? 2 * out_planes : 4));
@@ -2138,8 +2349,7 @@ int ttr_dbg_qkv_attn(ttr_engine* e, const float* x, int N, const float* w, const
     launch_split_planes(dx.as<float>(), 384, dxp.p, (int64_t)N * 128, 384, 0, E.stream, 2);
     std::vector<float> wp((size_t)1152 * 384), bp(1152);
     for (int n = 0; n < 1152; ++n) { const int src = Engine::qkv_tile_row(n); memcpy(&wp[(size_t)n * 384], &w[(size_t)src * 384], 384 * 4); bp[n] = b[src]; }
-    E.upload_linear(L, wp.data(), 1152, 384, bp.data(), 1152, 384);
-    E.split_by_w.erase(L.w.p);                        // (a local Linear: nothing may find it later)
+    E.upload_linear(L, wp.data(), 1152, 384, bp.data(), 1152, 384, nullptr, false);
     dout.ensure(nx * 6);
     launch_qkv_attn_split(dxp.p, L.ws.p, L.b.as<float>(), L.inv_scale, dout.p, N, E.stream);
     std::vector<_Float16> h(nx * 3);
@@ -2207,7 +2417,7 @@ int ttr_dbg_conv_pool(ttr_engine* e, const float* in0, int C0, int B, int H, int
   for (size_t i = 0; i < hbuf.size(); ++i) hbuf[i] = f32_to_bf16_rne(in0[i]);
   d0.ensure(hbuf.size() * 2);
   TTR_HIP_CHECK(hipMemcpy(d0.p, hbuf.data(), hbuf.size() * 2, hipMemcpyHostToDevice));
-  E.upload_linear(L, wgt, Cout, K, bias, Cout, K);
+  E.upload_linear(L, wgt, Cout, K, bias, Cout, K, nullptr, false);
   dfull.ensure(M * Cout * 2); dpool.ensure(Mp * Cout * 2);
   ConvParams p{};
   p.in0 = d0.p; p.C0 = C0; p.B = B; p.H = H; p.W = W; p.ks = ks; p.dil = 1; p.wgt = L.w.p; p.bias = bias ? L.b.as<float>() : nullptr;
@@ -2370,7 +2580,31 @@ int ttr_set_profiling(ttr_engine* e, int on) {
   E.profiling = on < 0 ? 0 : (on > 2 ? 2 : on);
   E.prof_recs.clear();
   for (int i = 0; i < 3; ++i) { E.prof_ms[i] = 0; E.prof_flops[i] = 0; E.prof_launches[i] = 0; }
+  for (auto& k : E.prof_kinds) { k.ms = 0; k.alg = 0; k.exec = 0; k.launches = 0; }
   return 0;
+  TTR_GUARD_END(-1)
+}
+// The same records by kernel kind, as JSON text: [{"kind": name, "stage": 0|1|2, "launches": n, "ms": t, "alg_flops": a, "exec_flops": x}, ...]
+// (alg_flops: 2 x MACs of the layers, SURVEY.md section 8(d)'s figure; exec_flops: what the matrix cores execute for them).  Returns the
+// text's length (without the terminator); the text is truncated to cap - 1 characters.
+int ttr_get_profile_kinds(ttr_engine* e, char* buf, size_t cap) {
+  TTR_GUARD_BEGIN
+  if (!e) throw std::runtime_error("null argument");
+  Engine& E = *e->e;
+  EngineScope lk(E);
+  E.prof_collect();
+  std::string s = "[";
+  bool first = true;
+  for (const auto& k : E.prof_kinds) {
+    if (!k.launches) continue;
+    char line[512];
+    snprintf(line, sizeof line, "%s{\"kind\": \"%s\", \"stage\": %d, \"launches\": %ld, \"ms\": %.6f, \"alg_flops\": %.6e, \"exec_flops\": %.6e}", first ? "" : ", ",
+             k.name.c_str(), k.stage, k.launches, k.ms, k.alg, k.exec);
+    s += line; first = false;
+  }
+  s += "]";
+  if (buf && cap) { const size_t n = std::min(s.size(), cap - 1); memcpy(buf, s.data(), n); buf[n] = 0; }
+  return (int)s.size();
   TTR_GUARD_END(-1)
 }
 int ttr_get_profile(ttr_engine* e, double ms[3], double flops[3], long long launches[3]) {

@@ -86,8 +86,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
   // GELU epilogue: Phi(x) by linear interpolation in an 8 KiB table kept in LDS behind the operand stages (the
   // erf polynomial + exp + rcp form made the epilogue, not the MFMAs, the longest part of the K = 384 PARSeq GEMMs)
   float2* const glut = reinterpret_cast<float2*>(smem + C::LDS);
-  if (p.act == kActGelu && p.gelu_lut) {   // (split mode: the Hermite table of gelu_hermite(), 1026 entries)
-    for (int i = tid; i < (SP ? 513 : 512); i += C::NT) reinterpret_cast<uint4*>(glut)[i] = reinterpret_cast<const uint4*>(p.gelu_lut)[i];
+  if (p.act == kActGelu && p.gelu_lut) {   // (split mode: the cubic table of gelu_hermite(), 512 x float4)
+    for (int i = tid; i < 512; i += C::NT) reinterpret_cast<uint4*>(glut)[i] = reinterpret_cast<const uint4*>(p.gelu_lut)[i];
   }   // visible after the first K-step barrier
 
   // ---- persistent, XCD-aware tile schedule.  Workgroups bid and bid+8 share an XCD (round-robin placement, speed only);
@@ -540,7 +540,9 @@ const void* gelu_lut_for_current_device() {
   return lut[dev];
 }
 
-// Hermite table of the split mode's GELU epilogue: float2[1026] {Phi(x_i), dPhi/dx(x_i) / 64}, x_i = -8 + i / 64 (host erf / exp in double)
+// Cubic table of the split mode's GELU epilogue (common.h: gelu_hermite): float4[512], entry i = the Hermite cubic of Phi over
+// [x_i, x_i + 1/32], x_i = -8 + i / 32, in t = (x - x_i) 32: {Phi_i, h phi_i, 3 d - h (2 phi_i + phi_i+1), -2 d + h (phi_i + phi_i+1)}, d = Phi_i+1 - Phi_i
+// (host erf / exp in double)
 const void* gelu_hermite_lut_for_current_device() {
   static std::mutex mu;
   static const void* lut[64] = {nullptr};
@@ -549,11 +551,14 @@ const void* gelu_hermite_lut_for_current_device() {
   std::lock_guard<std::mutex> lk(mu);
   if (dev < 0 || dev >= 64) throw std::runtime_error("gemm2: device index out of range");
   if (!lut[dev]) {
-    std::vector<float> h(2 * 1026);
-    for (int i = 0; i < 1026; ++i) {
-      const double x = -8.0 + i / 64.0;
-      h[2 * i] = (float)(0.5 * (1.0 + std::erf(x * 0.70710678118654752440)));
-      h[2 * i + 1] = (float)(std::exp(-0.5 * x * x) * 0.39894228040143267794 / 64.0);
+    std::vector<float> h(4 * 512 + 8, 0.f);
+    auto Phi = [](double x) { return 0.5 * (1.0 + std::erf(x * 0.70710678118654752440)); };
+    auto phi = [](double x) { return std::exp(-0.5 * x * x) * 0.39894228040143267794; };
+    const double hh = 1.0 / 32.0;
+    for (int i = 0; i < 512; ++i) {
+      const double x0 = -8.0 + i * hh, x1 = x0 + hh;
+      const double d = Phi(x1) - Phi(x0), p0 = hh * phi(x0), p1 = hh * phi(x1);
+      h[4 * i] = (float)Phi(x0); h[4 * i + 1] = (float)p0; h[4 * i + 2] = (float)(3.0 * d - 2.0 * p0 - p1); h[4 * i + 3] = (float)(-2.0 * d + p0 + p1);
     }
     void* d = nullptr;
     TTR_HIP_CHECK(hipMalloc(&d, h.size() * 4));

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
 
   float2* const glut = reinterpret_cast<float2*>(smem + C::LDS);          // Hermite GELU table behind the rings (common.h: gelu_hermite)
   if (p.act == kActGelu && p.gelu_lut) {
-    for (int i = tid; i < 513; i += C::NT) reinterpret_cast<uint4*>(glut)[i] = reinterpret_cast<const uint4*>(p.gelu_lut)[i];
+    for (int i = tid; i < 512; i += C::NT) reinterpret_cast<uint4*>(glut)[i] = reinterpret_cast<const uint4*>(p.gelu_lut)[i];
   }   // visible after the first barrier
 
   // persistent, XCD-aware tile schedule: as gemm2.hip

@@ -28,7 +28,7 @@ void set_gemm2_split_reuse(int v);   // split mode: 1 (default) reuse-order K lo
 void set_gemm2_x_ring3(int v);   // 1 (default): activation tiles two K steps ahead where LDS allows; 0: one step (measurement)
 // device table float2[1024] {Phi(x_i), Phi(x_i + 1/64) - Phi(x_i)}, x_i = -8 + i/64, of the GELU epilogues (built on first use)
 const void* gelu_lut_for_current_device();
-const void* gelu_hermite_lut_for_current_device();   // float2[1026] {Phi(x_i), dPhi/dx(x_i) / 64}: the split mode's GELU (common.h: gelu_hermite)
+const void* gelu_hermite_lut_for_current_device();   // float4[512]: one cubic of Phi per interval of 1/32, the split mode's GELU (common.h: gelu_hermite)
 // GELU by that table (g = the table, in LDS)
 // ---- gemm_sk.hip (bf16 skinny GEMM, whole K resident: the per-step decoder linears)
 const char* gemm_sk_check(const ConvParams& p);
@@ -68,6 +68,7 @@ void set_conv3s_wgs_per_cu(int v);   // persistent grid: workgroups per CU (defa
 // ---- conv3p.hip (bf16 3x3 conv with a patch-stationary input tile)
 const char* conv3p_check(const ConvParams& p);   // nullptr when conv3p can run the layer
 void launch_conv3p(const ConvParams& p, hipStream_t s);
+int conv3p_split_bn(const ConvParams& p);   // split-operand layers: the tile width launch_conv3p picks (128 / 64 / 32)
 void set_conv3p_single_stage_max_cin(int c);
 void set_conv3p_force_bn128(int v);
 void set_conv3p_c64_waves(int w);

@@ -79,9 +79,12 @@ SYMBOLS = [
     ("ttr_dbg_dec_stamps", _I, [C.POINTER(C.c_ulonglong)]),
     ("ttr_bench_conv", _I, [_VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _PF]),
     ("ttr_get_profile", _I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    ("ttr_get_profile_kinds", _I, [_VP, C.c_char_p, C.c_size_t]),
     ("ttr_comm_unique_id", _I, [_VP]),
     ("ttr_comm_create", _VP, [_VP, _I, _I, _VP]),
     ("ttr_comm_create_tcp", _VP, [_VP, _I, _I, C.c_char_p, _I]),
+    ("ttr_comm_create_socket", _VP, [_VP, _I, _I, C.c_char_p, _I]),
+    ("ttr_comm_transport", C.c_char_p, [_VP]),
     ("ttr_comm_destroy", None, [_VP]),
     ("ttr_comm_rank", _I, [_VP]),
     ("ttr_comm_world", _I, [_VP]),
@@ -401,6 +404,15 @@ class Engine:
         return {"craft": dict(ms=ms[0], flops=fl[0], launches=n[0]), "parseq": dict(ms=ms[1], flops=fl[1], launches=n[1]),
                 "parseq_ar": dict(ms=ms[2], flops=fl[2], launches=n[2])}
 
+    def get_profile_kinds(self):
+        """The timed launches by kernel kind: list of dicts {kind, stage, launches, ms, alg_flops, exec_flops} (ttr_get_profile_kinds)."""
+        import json
+        buf = C.create_string_buffer(1 << 16)
+        n = self.lib.ttr_get_profile_kinds(self.h, buf, len(buf))
+        if n < 0:
+            raise EngineError(self.lib.ttr_last_error().decode())
+        return json.loads(buf.value.decode())
+
     # ---- stages
     def craft_heatmap(self, canvas: np.ndarray) -> np.ndarray:
         canvas = np.ascontiguousarray(canvas, dtype=np.uint8)
@@ -508,9 +520,12 @@ class Comm:
     addr, port)`: rank 0 listens on addr:port and hands the NCCL ids to the others; `attach()` makes every batch of the engine
     all-gather its token ids on the engine's stream."""
 
-    def __init__(self, engine: "Engine", rank: int, world: int, addr: str = "127.0.0.1", port: int = 29617, unique_id: Optional[bytes] = None):
+    def __init__(self, engine: "Engine", rank: int, world: int, addr: str = "127.0.0.1", port: int = 29617, unique_id: Optional[bytes] = None,
+                 transport: str = "rccl"):
         self.eng, self.lib = engine, engine.lib
-        if unique_id is not None:
+        if transport == "socket":        # TCP through rank 0: ranks that share one GPU (tests), or where RCCL cannot initialise
+            self.h = self.lib.ttr_comm_create_socket(engine.h, rank, world, addr.encode(), port)
+        elif unique_id is not None:
             buf = C.create_string_buffer(unique_id, 256)
             self.h = self.lib.ttr_comm_create(engine.h, rank, world, buf)
         else:

@@ -24,10 +24,13 @@ def synthetic_page(seed: int, h: int = 1024, w: int = 768, n_words: int = 40, sc
             tile = Image.new("L", (70, 14), 255)
             ImageDraw.Draw(tile).text((1, 1), word, fill=0, font=font)
             bbox = Image.eval(tile, lambda v: 255 - v).getbbox()
-            tile = tile.crop((0, 0, bbox[2] + 1, 14)).resize(((bbox[2] + 1) * scale, 14 * scale), Image.NEAREST)
+            # the word fills its box (the recogniser's crop is the box stretched to 128 x 32 with no regard for the aspect ratio,
+            # tuatara.cpp:440: a short word left at font scale would leave most of the crop blank paper)
+            tw, th = int(rng.integers(136, 145)), int(rng.integers(30, 35))
+            tile = tile.crop((bbox[0], bbox[1], bbox[2] + 1, bbox[3] + 1)).resize((tw, th), Image.NEAREST)
             cx, cy = (c + 0.5) * w / 5.0, (r + 0.5) * h / 8.0                      # the grid box: 150 x 40 px about (cx, cy)
-            x0, x1 = int(cx - 75) + 3, int(cx + 75) - 3 - tile.size[0]
-            y0, y1 = int(cy - 20) + 3, int(cy + 20) - 3 - tile.size[1]
+            x0, x1 = int(cx - 75) + 2, int(cx + 75) - 2 - tw
+            y0, y1 = int(cy - 20) + 2, int(cy + 20) - 2 - th
             x = int(rng.integers(x0, max(x0 + 1, x1 + 1)))
             y = int(rng.integers(y0, max(y0 + 1, y1 + 1)))
             page.paste(tile, (x, y))
