@@ -41,7 +41,7 @@ void ttr_set_decoder_mode(int mode);
  * 16x16-patch maps: 0 never / 1 always / 2 when the chip would be under-filled), "c3s_wgs" (persistent conv3s workgroups per CU),
  * "upsample_block" (2x4-block bilinear kernel), "craft_group" (pages per CRAFT launch group), "ar_early_exit" / "ar_crop_exit" /
  * "ar_tail_step" (AR loop: batch-level exit, per-crop exit in the step's attention kernels, step from which the fused tail kernel
- * takes over), "mlp_pair" (pair-split block kernel), "mlp_store_nt".  Timing experiments (results unspecified): "mlp_stagger",
+ * takes over), "mlp_store_nt".  Timing experiments (results unspecified): "mlp_stagger",
  * "mlp_ablate" / "pair_ablate" (libraries built with -DMLP_ABLATE_BUILDS).  Diagnostics: "dec_stamps" (1 fused decoder, 2 gemm_ws, 3 mlp_fused
  * phase stamps, read back with ttr_dbg_dec_stamps), "dbg_bf16_out", "ws_dbg_flags".
  * Returns 0, or -1 for an unknown key.  Selection knobs change fp32 summation order at most (never a rounding point). */

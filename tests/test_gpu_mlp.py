@@ -68,32 +68,6 @@ def test_mlp_fused_with_projection_against_numpy(eng_bf16, M):
     assert np.array_equal(out, out2)
 
 
-@pytest.mark.parametrize("M", [128, 37, 128 * 300 + 77])
-def test_mlp_pair_against_numpy(eng_bf16, M):
-    """mlp_pair.hip (two waves per SIMD: a pair of waves shares 32 rows and splits the hidden units / output channels) against
-    the same float64 restatement, run to run identical, and against mlp_fused.hip (fp32 summation order only)."""
-    rng = np.random.default_rng(M)
-    x = rng.standard_normal((M, 384)).astype(np.float32) * 1.5 + rng.standard_normal((1, 384)).astype(np.float32)
-    ln_g = (1 + 0.2 * rng.standard_normal(384)).astype(np.float32); ln_b = (0.1 * rng.standard_normal(384)).astype(np.float32)
-    w1 = (rng.standard_normal((1536, 384)) / np.sqrt(384)).astype(np.float32); b1 = (0.2 * rng.standard_normal(1536)).astype(np.float32)
-    w2 = (rng.standard_normal((384, 1536)) / np.sqrt(1536)).astype(np.float32); b2 = (0.2 * rng.standard_normal(384)).astype(np.float32)
-    ng = (1 + 0.2 * rng.standard_normal(384)).astype(np.float32); nb = (0.1 * rng.standard_normal(384)).astype(np.float32)
-    out0, nout0 = eng_bf16.dbg_mlp(x, ln_g, ln_b, w1, b1, w2, b2, ng, nb)
-    try:
-        assert eng_bf16.set_tuning(b"mlp_pair", 1) == 0
-        out, nout = eng_bf16.dbg_mlp(x, ln_g, ln_b, w1, b1, w2, b2, ng, nb)
-        out2, nout2 = eng_bf16.dbg_mlp(x, ln_g, ln_b, w1, b1, w2, b2, ng, nb)
-    finally:
-        eng_bf16.set_tuning(b"mlp_pair", 0)
-    rows = slice(0, M) if M < 1000 else np.r_[0:300, M - 300:M]
-    ro, rn = ref_mlp(x[rows], ln_g, ln_b, w1, b1, w2, b2, ng, nb)
-    assert np.isfinite(out).all() and np.isfinite(nout).all()
-    assert np.abs(out[rows] - ro).max() < 0.02, np.abs(out[rows] - ro).max()
-    assert np.abs(nout[rows] - rn).max() < 0.04
-    assert np.array_equal(out, out2) and np.array_equal(nout, nout2)           # no race in the ring or the hidden exchange
-    assert np.abs(out - out0).max() < 0.02
-
-
 def test_mlp_fused_layernorm_statistics_with_a_large_row_offset(eng_bf16):
     """The front and the epilogue gather a row's LayerNorm statistics in one pass (sums shifted by the lane's first value, merged
     over the row's four lanes as mean / M2 pairs).  Rows whose mean is 200 standard deviations away from zero - where a plain

@@ -94,3 +94,37 @@ def test_streamlined_and_general_kernels_agree(eng):
     finally:
         assert eng.set_tuning("g2_split_stream", 2) == 0
     assert np.abs(a - c).max() < 2e-6 * max(1.0, np.abs(a).max())
+
+
+# (M, K, N, act, out_planes, resid): the six linears of an AR step at one page's 40 crops, and the corners of the skinny kernel
+SKINNY = [(40, 384, 768, ACT_NONE, 0, False), (40, 384, 384, ACT_NONE, 0, True), (40, 384, 1536, ACT_GELU, 3, False), (40, 1536, 384, ACT_NONE, 0, True),
+          (1, 384, 384, ACT_NONE, 3, False), (64, 384, 96, ACT_RELU, 2, False), (17, 128, 32, ACT_NONE, 0, False), (33, 96, 416, ACT_NONE, 0, True),
+          (48, 32, 64, ACT_NONE, 0, False)]
+
+
+@pytest.mark.parametrize("case", SKINNY)
+def test_skinny_whole_k_linear_matches_fp32(eng, case):
+    """gemm_skx.hip (cfg 7): <= 64 rows, 32 output channels and the whole K per workgroup, K split over the four waves and joined in LDS -
+    the linears of the AR steps of a single page (the 26 sequential decoder steps inside the module run at /root/reference/tuatara.cpp:307).
+    1, 2, 3 and 4 row blocks; K of 1 .. 48 steps (fewer steps than waves: K = 32, 96); a channel count that leaves half a workgroup empty."""
+    M, K, N, act, planes, with_resid = case
+    _case(eng, M, K, N, 4, act, planes, with_resid, 7, 11)
+
+
+def test_skinny_and_ring_kernels_agree_and_the_engine_picks_the_skinny_one(eng):
+    rng = np.random.default_rng(12)
+    M, K, N = 40, 384, 768
+    x = rng.standard_normal((M, K)).astype(np.float32); w = (rng.standard_normal((N, K)) / 20).astype(np.float32); b = rng.standard_normal(N).astype(np.float32)
+    a = eng.dbg_split_gemm(x, w, b, np_products=4, cfg=7)
+    c = eng.dbg_split_gemm(x, w, b, np_products=4, cfg=3)
+    assert np.abs(a - c).max() < 2e-6 * max(1.0, np.abs(a).max())
+    # whole recogniser at one page's crop count: the AR steps on the skinny kernel against the ring kernels - same ids, logits within fp32 noise
+    crops = rng.integers(0, 256, (40, 32, 128, 3), dtype=np.uint8)
+    try:
+        assert eng.set_tuning("skinny_split", 0) == 0
+        l0, i0 = eng.parseq_logits(crops)
+        assert eng.set_tuning("skinny_split", 1) == 0
+        l1, i1 = eng.parseq_logits(crops)
+    finally:
+        eng.set_tuning("skinny_split", 1)
+    assert np.array_equal(i0, i1) and np.abs(l0 - l1).max() < 3e-4

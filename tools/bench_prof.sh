@@ -2,7 +2,7 @@
 # GPU box: rocprofv3 kernel stats of the default bench command -> gpurun_out/bench_stats.csv
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-rm -rf /tmp/bp; rocprofv3 --kernel-trace --stats -d /tmp/bp -o s --output-format csv -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --parity-pages 0 "$@" > /tmp/bp.log 2>&1
+rm -rf /tmp/bp; rocprofv3 --kernel-trace --stats -d /tmp/bp -o s --output-format csv -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > /tmp/bp.log 2>&1
 tail -1 /tmp/bp.log | cut -c1-300
 f=$(ls /tmp/bp/*/*kernel_stats.csv /tmp/bp/*kernel_stats.csv 2>/dev/null | tail -1)
 mkdir -p $R/gpurun_out; cp $f $R/gpurun_out/bench_stats.csv

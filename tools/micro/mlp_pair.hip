@@ -1,3 +1,5 @@
+// NOT part of the build: the pair-split form of the bf16 fused MLP block (two waves per SIMD), a measured negative of round 2 (no faster than
+// mlp_fused.hip; DESIGN_APPENDIX.md).  Kept as a record; it compiled against csrc/kernels.h of that round.
 // The MLP half of a PARSeq ViT encoder block as one kernel, second generation: TWO waves per SIMD.
 //
 //   x_out = x + fc2( GELU( fc1( LayerNorm_2(x) ) ) )            and, optionally,  y = LayerNorm_next(x_out)  (bf16)

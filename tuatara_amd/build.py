@@ -24,7 +24,9 @@ LIB = os.path.join(LIBDIR, "libtuatara_hip.so")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
-SOURCES = ["igemm.hip", "gemm2.hip", "gemm_sp.hip", "split_ops.hip", "attn_split.hip", "conv3p.hip", "conv3s.hip", "gemm_sk.hip", "gemm_ws.hip", "mlp_fused.hip", "mlp_pair.hip", "attn_enc2.hip", "attn_dec2.hip", "qkv_attn.hip", "craft_ops.hip", "parseq_ops.hip", "dec_fused.hip", "post_ops.hip", "engine.cpp", "geometry.cpp", "tuatara.cpp"]
+SOURCES = ["igemm.hip", "gemm2.hip", "gemm_sp.hip", "split_ops.hip", "attn_split.hip", "conv3p.hip", "conv3s.hip", "gemm_sk.hip", "gemm_skx.hip", "gemm_ws.hip", "mlp_fused.hip", "attn_enc2.hip", "attn_dec2.hip", "qkv_attn.hip", "craft_ops.hip", "parseq_ops.hip", "dec_fused.hip", "post_ops.hip",
+           "engine.cpp", "engine_craft.cpp", "engine_parseq.cpp", "engine_pages.cpp", "comm.cpp", "capi.cpp", "capi_debug.cpp", "geometry.cpp", "tuatara.cpp"]
+HIP_HOST_SOURCES = {"engine.cpp", "engine_craft.cpp", "engine_parseq.cpp", "engine_pages.cpp", "comm.cpp", "capi.cpp", "capi_debug.cpp"}   # host code that sees HIP types: -x hip
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 COMMON += os.environ.get("TUATARA_EXTRA_HIPCC_FLAGS", "").split()   # experiment builds (e.g. -DMLP_ABLATE_BUILDS); touch the source to rebuild
 
@@ -46,7 +48,7 @@ def _compile(src: str) -> str:
     obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
     path = os.path.join(CSRC, src)
     if _stale(obj, [path] + _headers()):
-        cmd = [HIPCC] + COMMON + (["-x", "hip"] if src.endswith(".cpp") and src == "engine.cpp" else []) + ["-c", path, "-o", obj]
+        cmd = [HIPCC] + COMMON + (["-x", "hip"] if src in HIP_HOST_SOURCES else []) + ["-c", path, "-o", obj]
         subprocess.check_call(cmd)
     return obj
 

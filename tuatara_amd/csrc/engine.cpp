@@ -1,48 +1,5 @@
-// Host orchestration + C ABI of the MI355X-native tuatara engine.
-//
-// Re-implements the reference's pipeline function image_to_data (tuatara.cpp:314-512):
-//   resize/pad/swap (:349-358) -> CRAFT (:363-394) -> get_detected_boxes (:400) ->
-//   adjust_result_coordinates (:406) -> crop (:408-418) -> resize 128x32 (:436-448) ->
-//   PARSeq (:450-485) -> argmax + Tokenizer (:486-505) -> format_output (:511)
-// with every tensor op on the GPU (igemm.hip, craft_ops.hip, parseq_ops.hip, post_ops.hip)
-// and only the per-component calipers + string decoding on the host (geometry.cpp).
-// Differences by design: models are loaded once per engine (the reference reloads both
-// per call, :336, :428), crops of all pages of a batch run as one PARSeq batch (the
-// reference chunks by 4 over 6 threads, :452-475; logits are batch-invariant), the AR
-// decoder keeps a K/V cache and runs a fixed 25+1 steps (no data-dependent break).
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <fstream>
-#include <iostream>
-#include <iterator>
-#include <map>
-#include <memory>
-#include <mutex>
-#include <chrono>
-#include <dlfcn.h>
-#include <arpa/inet.h>
-#include <netdb.h>
-#include <netinet/in.h>
-#include <netinet/tcp.h>
-#include <sys/socket.h>
-#include <unistd.h>
-#include <rccl/rccl.h>
-
-#include <atomic>
-#include <functional>
-#include <condition_variable>
-#include <thread>
-#include <stdexcept>
-#include <string>
-#include <vector>
-
-#include "../../include/tuatara_hip_debug.h"
-#include "common.h"
-#include "geometry.h"
-#include "host_util.h"
-#include "kernels.h"
+// Engine construction: weights to the device (BN-folded fp32, bf16 images, f16 weight planes), workspaces, the per-launch profile.
+#include "engine.h"
 
 namespace ttr {
 
@@ -52,144 +9,8 @@ void hip_fail(const char* what, hipError_t e, const char* file, int line) {
   throw std::runtime_error(buf);
 }
 
-static thread_local std::string g_last_error;
-static unsigned long long* g_dec_dbg = nullptr;   // device buffer for dec_ar phase stamps (diagnostics)
-// Kernel-selection knobs, per engine (ttr_engine_set_tuning); g_tuning_default seeds engines created afterwards (ttr_set_tuning)
-struct Tuning {
-  int dbg_bf16_out = 0;       // ttr_dbg_conv on a bf16 engine: take the kernel's bf16 output (the path the engine uses) instead of the f32 one
-  int qkv_attn = 1;           // bf16 encoder: qkv projection + self-attention as one kernel (qkv_attn.hip) from qkv_attn_min crops on
-  int qkv_attn_min = 160;
-  int mlp_proj = 1;           // ... with the attention output projection in front of it in the same launch
-  int mlp_min_rows = 49152;   // = 384 crops
-  int dec_mlp_fused = 1;      // bf16 refinement pass: cross_out + norm2 + linear1 + GELU + linear2 + final norm through mlp_fused.hip
-  int dec_mlp_min_rows = 16384;
-  int mlp_pair = 0;           // the fused MLP block as the pair-split kernel (mlp_pair.hip: two waves per SIMD; the projection stays a separate GEMM)
-  int mlp_fused = 1;          // bf16 encoder: norm2 + fc1 + GELU + fc2 + residual (+ the next LayerNorm) as one kernel (mlp_fused.hip)
-  int tok_fuse = 1;           // bf16 AR steps: argmax of the previous step + token embedding + norm_c inside the self_kv skinny GEMM
-  int ln_fuse = 1;            // bf16 decoder steps: LayerNorm computed inside the skinny GEMM's loader (gemm_sk ln_in)
-  int fuse_first = 1;         // bf16: CRAFT conv1_1 fused into conv1_2's loader (conv3p FIRST)
-  int qkv_attn_split = 1;     // split-operand engines, PARSeq encoder: qkv projection + self-attention as ONE launch (gemm_sp.hip, attention epilogue); needs enc_ln_pairs
-  int enc_chunk = 0;          // crops per encoder group (0 = all crops at once)
-  int enc_ln_pairs = 1;       // split-operand engines, PARSeq encoder: LayerNorm outputs as pairs (qkv and fc1 on three MFMAs per product: their inputs tolerate ~23.5 bits - 3 x 1280 crops: max |dlogit| 7.6e-4 vs 6.9e-4 with triples; proj and fc2 keep exact triples); 0 = triples
-  int dec_planes = 1;         // split-operand engines: the decoder's layers hand each other planes (13 launches per AR step instead of 20); 0 = fp32 tensors + split passes
-  int qkv_kv_pairs = 1;       // the qkv GEMM leaves the third plane of its K and V columns unwritten (the attention kernel reads them as pairs)
-  int enc_fc2_pairs = 1;      // ... and the MLP hidden activation as pairs (fc2 on three MFMAs per product; 3 x 640 crops: max |dlogit| 5.1 - 6.7e-4 vs 5.6 - 7.6e-4 with triples); the attention output - the projection input - stays an exact triple: the one encoder linear whose result moves with the 24th bit (oracle/splitsim.py)
-  int craft_products = 3;     // split-operand engines, CRAFT: 3 = activation pairs (~23.5 bits; the heat map stays at fp32 noise level), 4 = exact triples
-  int detector_only = 0;      // profiling: drop every detected box, so that a batch runs the detector + CCL only
-  int bench_grid_boxes = 0;   // benchmark workload control (bench.py --boxes=grid40): the detector runs in full, then every page's boxes are replaced by a fixed 5 x 8 grid
-  int split_planes = 1;       // split-operand engines: activations stay in planes between the layers (0: fp32 tensors + a split pass in front of every GEMM)
-  int split_conv3p = 1;       // split-operand engines: 3x3 layers on the patch-stationary kernel (0: gemm2)
-  int split_gemm = 1;         // split-operand engines: 0 = every layer on the fp32 MFMA kernel (A/B and tests)
-  int craft_group = 16;       // pages per CRAFT launch group (activation workspace ~0.5 GB/page; every tensor must stay inside the 2 GiB window of 32-bit buffer offsets)
-  int ar_tail_step = 12;      // with ar_early_exit: AR steps from this one on run as ONE launch of the fused kernel (which returns at once when the batch is done)
-  int ar_crop_exit = 1;       // ... and, per crop, the two attention kernels of a step return for crops that have emitted EOS
-  int ar_early_exit = 1;      // bf16 kernel-per-op AR loop: the steps' kernels return at once when every crop of the batch has emitted EOS (upstream's break)
-  int decoder_mode = 1;       // 0 = kernel-per-op AR loop, 4/8/16 = fused kernel with that many crops per workgroup, else automatic
-  bool set(const std::string& k, int value) {
-    if (k == "decoder_mode") decoder_mode = value;
-    else if (k == "enc_chunk") enc_chunk = value;
-    else if (k == "qkv_attn_split") qkv_attn_split = value;
-    else if (k == "fuse_first") fuse_first = value;
-    else if (k == "ln_fuse") ln_fuse = value;
-    else if (k == "tok_fuse") tok_fuse = value;
-    else if (k == "ar_early_exit") ar_early_exit = value;
-    else if (k == "ar_crop_exit") ar_crop_exit = value;
-    else if (k == "ar_tail_step") ar_tail_step = value;
-    else if (k == "split_gemm") split_gemm = value;
-    else if (k == "bench_grid_boxes") bench_grid_boxes = value;
-    else if (k == "detector_only") detector_only = value;
-    else if (k == "craft_products") craft_products = value == 4 ? 4 : 3;
-    else if (k == "enc_ln_pairs") enc_ln_pairs = value;
-    else if (k == "enc_fc2_pairs") enc_fc2_pairs = value;
-    else if (k == "qkv_kv_pairs") qkv_kv_pairs = value;
-    else if (k == "dec_planes") dec_planes = value;
-    else if (k == "split_conv3p") split_conv3p = value;
-    else if (k == "split_planes") split_planes = value;
-    else if (k == "craft_group") craft_group = value < 1 ? 1 : (value > 32 ? 32 : value);
-    else if (k == "mlp_fused") mlp_fused = value;     // 0 off, 1 from mlp_min_rows rows on, 2 always
-    else if (k == "mlp_min_rows") mlp_min_rows = value;
-    else if (k == "dec_mlp_fused") dec_mlp_fused = value;
-    else if (k == "dec_mlp_min_rows") dec_mlp_min_rows = value;
-    else if (k == "mlp_proj") mlp_proj = value;
-    else if (k == "mlp_pair") mlp_pair = value;
-    else if (k == "qkv_attn") qkv_attn = value;        // 0 off, 1 from qkv_attn_min crops on, 2 always
-    else if (k == "qkv_attn_min") qkv_attn_min = value;
-    else if (k == "dbg_bf16_out") dbg_bf16_out = value;
-    else return false;
-    return true;
-  }
-};
-static Tuning g_tuning_default;
+Tuning g_tuning_default;
 
-// ------------------------------------------------------------------ small utilities
-// roctx ranges around the host phases of a batch (rocprofv3 --marker-trace shows them next to the kernels).
-// The marker library is looked up at run time: without it the ranges are no-ops.
-struct Roctx {
-  int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
-  Roctx() {
-    for (const char* n : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
-      if (void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) {
-        push = (int (*)(const char*))dlsym(h, "roctxRangePushA"); pop = (int (*)())dlsym(h, "roctxRangePop");
-        if (push && pop) return;
-        push = nullptr; pop = nullptr;
-      }
-    }
-  }
-};
-static Roctx& roctx() { static Roctx r; return r; }
-struct RangeScope {
-  bool on;
-  explicit RangeScope(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
-  ~RangeScope() { if (on) roctx().pop(); }
-};
-
-struct DevBuf {
-  void* p = nullptr;
-  size_t cap = 0;
-  void ensure(size_t bytes) {
-    if (bytes <= cap) return;
-    void* old = p;
-    p = nullptr; cap = 0;                       // a throwing hipFree must not leave a dangling pointer for the destructor
-    if (old) TTR_HIP_CHECK(hipFree(old));
-    size_t want = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
-    TTR_HIP_CHECK(hipMalloc(&p, want));
-    cap = want;
-  }
-  template <typename U> U* as() const { return reinterpret_cast<U*>(p); }
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  DevBuf() = default;
-  DevBuf(const DevBuf&) = delete;
-  DevBuf& operator=(const DevBuf&) = delete;
-};
-
-static inline uint16_t f32_to_bf16_rne(float f) {
-  uint32_t u; memcpy(&u, &f, 4);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
-
-// grow-only pinned host buffer: async copies to / from it need no staging and do not serialise the stream
-struct PinnedBuf {
-  void* p = nullptr;
-  size_t cap = 0;
-  void ensure(size_t bytes) {
-    if (bytes <= cap) return;
-    void* old = p;
-    p = nullptr; cap = 0;
-    if (old) TTR_HIP_CHECK(hipHostFree(old));
-    size_t want = (bytes + 65535) & ~(size_t)65535;
-    TTR_HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
-    cap = want;
-  }
-  template <typename U> U* as() const { return reinterpret_cast<U*>(p); }
-  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
-  PinnedBuf() = default;
-  PinnedBuf(const PinnedBuf&) = delete;
-  PinnedBuf& operator=(const PinnedBuf&) = delete;
-};
-
-// A GEMM-shaped weight on the device: T [Cout_pad][K_pad] + f32 bias
 // mlp_fused.hip's weight operands are stored as the LDS images the kernel multiplies from (see the layout notes there)
 void pack_mlp_w1(const float* w1, uint16_t* out) {               // w1 [1536][384] -> [48 chunks][3 segments][32 rows][16 positions][8]
   for (int c = 0; c < 48; ++c)
@@ -216,2407 +37,270 @@ void pack_mlp_w2(const float* w, int K, uint16_t* out) {          // w [384][K] 
     }
 }
 
-struct Linear {
-  DevBuf w, b;
-  int cout = 0, k = 0;  // padded sizes as the kernel sees them
-  DevBuf ws;            // split-operand engines (split.h): f16 [cout][3][k] = w0 | w0/2^11 | w1 of w S
-  float inv_scale = 0;  // 1 / S
-};
-
-// ------------------------------------------------------------------ the engine
-struct CraftConv { const char* name; int cin, cout, ks, dil; };
-
-struct Result {
-  std::vector<std::string> text;
-  std::vector<float> bbox;   // 4 per item
-  std::vector<int32_t> ids;  // 26 per item
-};
-
-struct CclBatch {   // device workspaces of the CCL stage for a batch of equally sized pages
-  DevBuf tnorm, flags, parent, mm, area, bbox, maxt, cand_slot, cand, counters, rows;
-  int pages = 0, npx = 0, max_cand = 0;
-  CclBuffers view(int p0 = 0) {   // the slices of pages p0.. (every array is strided by the page)
-    CclBuffers b;
-    const size_t o = (size_t)p0 * npx;
-    b.tnorm = tnorm.as<float>() + o; b.flags = flags.as<uint8_t>() + o; b.parent = parent.as<int>() + o; b.mm = mm.as<unsigned>() + (size_t)p0 * 4;
-    b.area = area.as<int>() + o; b.bbox = bbox.as<int>() + o * 4; b.maxt = maxt.as<unsigned>() + o; b.cand_slot = cand_slot.as<int>() + o;
-    b.cand = cand.as<int>() + (size_t)p0 * max_cand * 8; b.counters = counters.as<int>() + (size_t)p0 * 2; b.rows_packed = rows.as<int>() + o * 2;
-    b.max_cand = max_cand;
-    return b;
-  }
-  void ensure(int pages_, int npx_, int max_cand_) {
-    pages = pages_; npx = npx_; max_cand = max_cand_;
-    const size_t n = (size_t)pages * npx;
-    tnorm.ensure(n * 4); flags.ensure(n); parent.ensure(n * 4); mm.ensure((size_t)pages * 16);
-    area.ensure(n * 4); bbox.ensure(n * 16); maxt.ensure(n * 4); cand_slot.ensure(n * 4);
-    cand.ensure((size_t)pages * max_cand * 32); counters.ensure((size_t)pages * 8); rows.ensure(n * 8);
-  }
-};
-
-
-
-
-#define TTR_NCCL_CHECK(expr)                                                                                          \
-  do {                                                                                                                \
-    ncclResult_t _r = (expr);                                                                                         \
-    if (_r != ncclSuccess) throw std::runtime_error(std::string("RCCL: ") + ncclGetErrorString(_r) + " at " #expr);   \
-  } while (0)
-
-// Multi-GPU exchange in the C++ host (RCCL = the NCCL API of /opt/rocm/include/rccl/rccl.h): one process per GPU.
-// The engine speaks to a Transport: two kinds of collective on device buffers, enqueued on a stream -
-//   all_gather (data: the per-batch token ids on the engine's main stream; control: the small host-side exchanges - crop counts, status
-//   headers, barriers - on the copy stream) and broadcast (latency mode's crop batch).
-// RcclTransport is the product: two communicators per process (collectives of one communicator must be issued in one order on every rank,
-// and the two kinds interleave differently from batch to batch).  SocketTransport carries the SAME calls over TCP through rank 0, staged
-// through host memory, every call framed with a sequence number and its size so that a mismatched call sequence is an error, not a hang: it
-// is what lets two ranks share ONE GPU (RCCL refuses two ranks on a device), i.e. what runs the engine's multi-rank code paths at world
-// size 2 on a single-GPU box (tests/test_gpu_dist.py), and a fallback where RCCL cannot initialise.
-struct Transport {
-  virtual ~Transport() {}
-  virtual const char* name() const = 0;
-  virtual void all_gather(const void* d_send, void* d_recv, size_t bytes, bool control, hipStream_t stream) = 0;   // d_recv: world * bytes, by rank
-  virtual void broadcast(void* d_buf, size_t bytes, int root, hipStream_t stream) = 0;
-};
-
-struct RcclTransport : Transport {
-  ncclComm_t data = nullptr, ctl = nullptr;
-  RcclTransport(int rank, int world, const ncclUniqueId ids[2]) {
-    TTR_NCCL_CHECK(ncclCommInitRank(&data, world, ids[0], rank));
-    TTR_NCCL_CHECK(ncclCommInitRank(&ctl, world, ids[1], rank));
-  }
-  ~RcclTransport() override {
-    if (data) (void)ncclCommDestroy(data);
-    if (ctl) (void)ncclCommDestroy(ctl);
-  }
-  const char* name() const override { return "rccl"; }
-  void all_gather(const void* d_send, void* d_recv, size_t bytes, bool control, hipStream_t stream) override {
-    TTR_NCCL_CHECK(ncclAllGather(d_send, d_recv, bytes, ncclChar, control ? ctl : data, stream));
-  }
-  void broadcast(void* d_buf, size_t bytes, int root, hipStream_t stream) override {
-    TTR_NCCL_CHECK(ncclBroadcast(d_buf, d_buf, bytes, ncclChar, root, data, stream));
-  }
-};
-
-// ---- TCP rendezvous: rank 0 listens on addr:port until every other rank has said hello exactly once; strays, duplicates and ranks out of
-// range are turned away; every socket has send / receive timeouts and the whole meeting a deadline.
-namespace rendezvous {
-constexpr uint32_t kMagic = 0x54545243u;   // "TTRC"
-struct Hello { uint32_t magic; int32_t rank, world; };
-inline void fail(const std::string& m) { throw std::runtime_error("comm rendezvous: " + m + (errno ? std::string(": ") + strerror(errno) : std::string())); }
-inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-inline void set_timeouts(int fd, double seconds) {
-  timeval tv; tv.tv_sec = (long)seconds; tv.tv_usec = (long)((seconds - (long)seconds) * 1e6);
-  setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
-  setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
-  int one = 1; setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+void Engine::igemm(const ConvParams& p, double true_flops, const char* kind) {
+  if (prec == kSplit && split_gemm(p, true_flops, kind)) return;
+  timed(kind, true_flops, true_flops, [&] { launch_igemm(prec, p, stream); });
 }
-inline bool send_all(int fd, const void* p, size_t n) {
-  size_t off = 0;
-  while (off < n) { const ssize_t w = send(fd, (const char*)p + off, n - off, MSG_NOSIGNAL); if (w <= 0) return false; off += (size_t)w; }
+
+bool Engine::split_gemm(const ConvParams& p, double true_flops, const char* kind) {
+  auto it = split_by_w.find(p.wgt);
+  if (it == split_by_w.end() || !tn.split_gemm || p.relu0 || p.relu1 || p.ln_in || p.pre_wgt) return false;
+  const Linear& L = *it->second;
+  ConvParams q = p;
+  q.split = 4; q.wgt = L.ws.p; q.out_scale = L.inv_scale; q.out_planes = 0; q.store_policy = 0;
+  split_in[0].ensure((size_t)p.M * p.C0 * 6);
+  q.in0 = split_in[0].p;
+  if (p.C1) { split_in[1].ensure((size_t)p.M * p.C1 * 6); q.in1 = split_in[1].p; }
+  const bool c3 = tn.split_conv3p && p.Cout >= 32 && conv3p_check(q) == nullptr;
+  if (!c3 && gemm2_check(q) != nullptr) return false;
+  prof_break_if_craft();
+  launch_split_planes((const float*)p.in0, p.C0, split_in[0].p, p.M, p.C0, 0, stream, 3, p.skip, p.skip_n);
+  if (p.C1) launch_split_planes((const float*)p.in1, p.C1, split_in[1].p, p.M, p.C1, 0, stream, 3, p.skip, p.skip_n);
+  timed(kind, true_flops, true_flops * 4, [&] { if (c3) launch_conv3p(q, stream); else launch_gemm2(q, 0, stream); });
   return true;
 }
-inline bool recv_all(int fd, void* p, size_t n) {
-  size_t off = 0;
-  while (off < n) { const ssize_t r = recv(fd, (char*)p + off, n - off, 0); if (r <= 0) return false; off += (size_t)r; }
-  return true;
+
+void Engine::prof_collect() {
+  if (seg_open) return;                        // (never between the two events of a run)
+  size_t done = 0;
+  for (; done < prof_recs.size(); ++done) {
+    if (hipEventQuery(prof_pool[2 * done + 1]) != hipSuccess) { (void)hipGetLastError(); break; }
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, prof_pool[2 * done], prof_pool[2 * done + 1]) == hipSuccess) {
+      const ProfRec& r = prof_recs[done];
+      prof_ms[r.stage] += ms; prof_flops[r.stage] += r.exec; prof_launches[r.stage] += r.launches;
+      ProfKind& k = prof_kinds[r.kind];
+      k.ms += ms; k.alg += r.alg; k.exec += r.exec; k.launches += r.launches;
+    }
+  }
+  if (done == 0) return;
+  std::rotate(prof_pool.begin(), prof_pool.begin() + 2 * done, prof_pool.begin() + 2 * prof_recs.size());
+  prof_recs.erase(prof_recs.begin(), prof_recs.begin() + done);
 }
-inline sockaddr_in resolve(const char* addr, int port) {
-  sockaddr_in sa{};
-  sa.sin_family = AF_INET; sa.sin_port = htons((uint16_t)port);
-  const char* a = (addr && *addr) ? addr : "127.0.0.1";
-  if (inet_pton(AF_INET, a, &sa.sin_addr) != 1) {
-    hostent* he = gethostbyname(a);
-    if (!he) { errno = 0; fail(std::string("cannot resolve ") + a); }
-    memcpy(&sa.sin_addr, he->h_addr_list[0], sizeof(sa.sin_addr));
-  }
-  return sa;
-}
-inline double deadline_seconds() { const char* v = getenv("TUATARA_COMM_TIMEOUT"); const double d = v ? atof(v) : 0.0; return d > 0 ? d : 120.0; }
-// rank 0: fds[r] = the connection of rank r (fds[0] = -1).  The listener binds the given address (not INADDR_ANY)
-inline std::vector<int> serve(int world, const char* addr, int port, double deadline_s) {
-  std::vector<int> fds(world, -1);
-  const double t_end = now_s() + deadline_s;
-  int ls = socket(AF_INET, SOCK_STREAM, 0);
-  if (ls < 0) fail("socket");
-  auto close_all = [&]() { for (int& f : fds) if (f >= 0) { close(f); f = -1; } close(ls); };
-  int one = 1;
-  setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
-  sockaddr_in sa = resolve(addr, port);
-  while (bind(ls, (sockaddr*)&sa, sizeof(sa)) < 0) {   // (a previous run's listener may still be closing)
-    if (errno != EADDRINUSE || now_s() > t_end) { const int e = errno; close(ls); errno = e; fail("bind " + std::string(addr ? addr : "") + ":" + std::to_string(port)); }
-    usleep(100000);
-  }
-  if (listen(ls, world + 8) < 0) { const int e = errno; close(ls); errno = e; fail("listen"); }
-  timeval tv{1, 0};
-  setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);   // accept() wakes up once a second to look at the deadline
-  int have = 0;
-  while (have < world - 1) {
-    if (now_s() > t_end) { close_all(); errno = 0; fail("rank 0 waited " + std::to_string((int)deadline_s) + " s and " + std::to_string(world - 1 - have) + " rank(s) never arrived"); }
-    int cs = accept(ls, nullptr, nullptr);
-    if (cs < 0) { if (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR) continue; const int e = errno; close_all(); errno = e; fail("accept"); }
-    set_timeouts(cs, 5.0);
-    Hello h{};
-    if (!recv_all(cs, &h, sizeof h) || h.magic != kMagic || h.world != world || h.rank <= 0 || h.rank >= world || fds[h.rank] >= 0) { close(cs); continue; }   // a stray, a stranger or a duplicate
-    set_timeouts(cs, deadline_s);
-    fds[h.rank] = cs; ++have;
-  }
-  close(ls);
-  return fds;
-}
-inline int join(int rank, int world, const char* addr, int port, double deadline_s) {
-  const sockaddr_in sa = resolve(addr, port);
-  const double t_end = now_s() + deadline_s;
-  for (;;) {          // rank 0 may not be listening yet
-    int cs = socket(AF_INET, SOCK_STREAM, 0);
-    if (cs < 0) fail("socket");
-    if (connect(cs, (const sockaddr*)&sa, sizeof(sa)) == 0) {
-      set_timeouts(cs, deadline_s);
-      const Hello h{kMagic, rank, world};
-      if (!send_all(cs, &h, sizeof h)) { const int e = errno; close(cs); errno = e; fail("hello"); }
-      return cs;
-    }
-    close(cs);
-    if (now_s() > t_end) fail("connect to " + std::string(addr ? addr : "") + ":" + std::to_string(port));
-    usleep(20000);
-  }
-}
-}  // namespace rendezvous
 
-struct SocketTransport : Transport {
-  int rank, world;
-  std::vector<int> fds;      // rank 0: one per peer; else fds[0] = the connection to rank 0
-  uint64_t seq = 0;
-  PinnedBuf h_send, h_all;
-  struct Frame { uint32_t magic; uint32_t kind; uint64_t seq, bytes; };   // kind: 1 all_gather data, 2 all_gather control, 3 broadcast
-  SocketTransport(int rank_, int world_, const char* addr, int port) : rank(rank_), world(world_) {
-    if (world > 1) {
-      if (rank == 0) fds = rendezvous::serve(world, addr, port, rendezvous::deadline_seconds());
-      else fds.assign(1, rendezvous::join(rank, world, addr, port, rendezvous::deadline_seconds()));
+void Engine::upload_linear(Linear& L, const float* w, int cout, int k, const float* bias, int cout_pad, int k_pad,
+                   const std::vector<int>* kmap, bool own) {
+  // kmap: for each padded k index the source k index or -1
+  std::vector<float> wp((size_t)cout_pad * k_pad, 0.f);
+  for (int o = 0; o < cout; ++o)
+    for (int kk = 0; kk < k_pad; ++kk) {
+      int src = kmap ? (*kmap)[kk] : (kk < k ? kk : -1);
+      if (src >= 0) wp[(size_t)o * k_pad + kk] = w[(size_t)o * k + src];
     }
+  L.cout = cout_pad; L.k = k_pad;
+  L.w.ensure(wp.size() * es);
+  if (prec == kBF16) {
+    std::vector<uint16_t> h(wp.size());
+    for (size_t i = 0; i < wp.size(); ++i) h[i] = f32_to_bf16_rne(wp[i]);
+    TTR_HIP_CHECK(hipMemcpy(L.w.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  } else {
+    TTR_HIP_CHECK(hipMemcpy(L.w.p, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
   }
-  ~SocketTransport() override { for (int f : fds) if (f >= 0) close(f); }
-  const char* name() const override { return "socket"; }
-  void need(bool ok, const char* what) { if (!ok) { throw std::runtime_error(std::string("socket transport: ") + what + " (peer gone, timeout, or a mismatched collective)"); } }
-  // every rank announces what it is about to do; rank 0 checks that all announcements agree before any payload moves
-  void announce(uint32_t kind, size_t bytes) {
-    ++seq;
-    const Frame mine{rendezvous::kMagic, kind, seq, (uint64_t)bytes};
-    if (rank == 0) {
-      bool ok = true; Frame bad{};
-      for (int r = 1; r < world; ++r) {
-        Frame f{};
-        need(rendezvous::recv_all(fds[r], &f, sizeof f), "receiving a frame");
-        if (f.magic != mine.magic || f.kind != kind || f.seq != seq || f.bytes != mine.bytes) { ok = false; bad = f; }
-      }
-      const uint32_t verdict = ok ? 1u : 0u;
-      for (int r = 1; r < world; ++r) need(rendezvous::send_all(fds[r], &verdict, 4), "sending the verdict");
-      if (!ok) throw std::runtime_error("socket transport: collective mismatch at call " + std::to_string(seq) + ": rank 0 has kind " + std::to_string(kind) + " / " +
-                                        std::to_string(bytes) + " bytes, a peer kind " + std::to_string(bad.kind) + " / " + std::to_string(bad.bytes) + " bytes (call " + std::to_string(bad.seq) + ")");
-    } else {
-      need(rendezvous::send_all(fds[0], &mine, sizeof mine), "sending a frame");
-      uint32_t verdict = 0;
-      need(rendezvous::recv_all(fds[0], &verdict, 4), "receiving the verdict");
-      if (!verdict) throw std::runtime_error("socket transport: collective mismatch at call " + std::to_string(seq) + " (this rank: kind " + std::to_string(kind) + ", " + std::to_string(bytes) + " bytes)");
-    }
-  }
-  void all_gather(const void* d_send, void* d_recv, size_t bytes, bool control, hipStream_t stream) override {
-    h_send.ensure(std::max<size_t>(bytes, 1)); h_all.ensure(std::max<size_t>(bytes * world, 1));
-    if (bytes) TTR_HIP_CHECK(hipMemcpyAsync(h_send.p, d_send, bytes, hipMemcpyDeviceToHost, stream));
-    TTR_HIP_CHECK(hipStreamSynchronize(stream));
-    announce(control ? 2u : 1u, bytes);
-    char* all = h_all.as<char>();
-    if (rank == 0) {
-      if (bytes) memcpy(all, h_send.p, bytes);
-      for (int r = 1; r < world; ++r) need(bytes == 0 || rendezvous::recv_all(fds[r], all + (size_t)r * bytes, bytes), "gathering");
-      for (int r = 1; r < world; ++r) need(bytes == 0 || rendezvous::send_all(fds[r], all, bytes * world), "returning the gather");
-    } else {
-      need(bytes == 0 || rendezvous::send_all(fds[0], h_send.p, bytes), "contributing");
-      need(bytes == 0 || rendezvous::recv_all(fds[0], all, bytes * world), "receiving the gather");
-    }
-    if (bytes) TTR_HIP_CHECK(hipMemcpyAsync(d_recv, all, bytes * world, hipMemcpyHostToDevice, stream));
-    TTR_HIP_CHECK(hipStreamSynchronize(stream));     // (the staging buffer is reused by the next call)
-  }
-  void broadcast(void* d_buf, size_t bytes, int root, hipStream_t stream) override {
-    if (root != 0) throw std::runtime_error("socket transport: broadcast from rank 0 only");
-    h_all.ensure(std::max<size_t>(bytes, 1));
-    if (rank == 0 && bytes) TTR_HIP_CHECK(hipMemcpyAsync(h_all.p, d_buf, bytes, hipMemcpyDeviceToHost, stream));
-    TTR_HIP_CHECK(hipStreamSynchronize(stream));
-    announce(3u, bytes);
-    if (rank == 0) { for (int r = 1; r < world; ++r) need(bytes == 0 || rendezvous::send_all(fds[r], h_all.p, bytes), "broadcasting"); }
-    else {
-      need(bytes == 0 || rendezvous::recv_all(fds[0], h_all.p, bytes), "receiving the broadcast");
-      if (bytes) TTR_HIP_CHECK(hipMemcpyAsync(d_buf, h_all.p, bytes, hipMemcpyHostToDevice, stream));
-      TTR_HIP_CHECK(hipStreamSynchronize(stream));
-    }
-  }
-};
-
-struct Comm {
-  std::unique_ptr<Transport> tr;
-  int rank = 0, world = 1;
-  struct Engine* E = nullptr;
-  DevBuf d_in, d_out;
-  PinnedBuf h_in, h_out;
-};
-
-// The layout of a gathered batch (pure host logic, tests/test_comm_cpu.py drives it through ttr_gather_layout): every rank
-// contributes its crops-per-page counts first; the payload then travels as `cap` = the largest rank total rows of 26 ids per rank.
-// Nothing is truncated: a page may hold any number of crops.
-struct GatherLayout {
-  int world = 0, pages = 0, cap = 0;
-  std::vector<int> total;      // crops of rank r
-  std::vector<int64_t> first;  // row of (rank r, page p)'s first crop in the compacted [sum(total)][26] array
-  static GatherLayout from_counts(const int32_t* counts, int world, int pages) {
-    GatherLayout L;
-    L.world = world; L.pages = pages; L.total.assign(world, 0); L.first.assign((size_t)world * pages + 1, 0);
-    int64_t run = 0;
-    for (int r = 0; r < world; ++r)
-      for (int p = 0; p < pages; ++p) {
-        const int c = counts[(size_t)r * pages + p];
-        if (c < 0) throw std::runtime_error("gather: negative crop count");
-        L.first[(size_t)r * pages + p] = run;
-        run += c; L.total[r] += c;
-      }
-    L.first[(size_t)world * pages] = run;
-    for (int r = 0; r < world; ++r) L.cap = std::max(L.cap, L.total[r]);
-    return L;
-  }
-};
-
-struct Engine {
-  ttr_config cfg;
-  Tuning tn = g_tuning_default;
-  Precision prec;
-  size_t es;  // element size of T
-  hipStream_t stream = nullptr;
-  std::unique_ptr<HostPool> host_pool;
-  hipStream_t copy_stream = nullptr;              // device -> host copies of one page group's components while the next group's CRAFT runs
-  hipEvent_t copy_ev = nullptr, done_ev[2] = {nullptr, nullptr};   // done_ev[slot]: a batch's token ids have landed
-  hipEvent_t evr[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};   // per slot: before the packer, after it, after PARSeq
-  // hand-over points of a batch are polled, not slept on: a blocking wait costs tens of microseconds of wake-up per sync
-  static void spin_event(hipEvent_t e) {
-    for (;;) {
-      const hipError_t r = hipEventQuery(e);
-      if (r == hipSuccess) return;
-      if (r != hipErrorNotReady) hip_fail("hipEventQuery", r, __FILE__, __LINE__);
-    }
-  }
-  std::vector<hipEvent_t> group_ev;               // per page group: component counters are on the host
-  std::mutex mu;
-  Tokenizer tok;
-
-  // CRAFT
-  std::map<std::string, Linear> craft;
-  // PARSeq
-  std::map<std::string, Linear> pq;               // linears by upstream name
-  std::map<std::string, DevBuf> pqf;              // f32 vectors (LayerNorm params, pos embed, ...)
-  DevBuf fc1_packed[12];                          // bf16 engines: encoder fc1 / fc2 / attn.proj weights as mlp_fused.hip's LDS images
-  DevBuf proj_packed[12];                         // bf16 engines: encoder attn.proj weights k-step-major [12][384][32] (mlp_fused.hip, PROJ)
-  DevBuf dec_ffn1_packed, dec_ffn2_packed, dec_co_packed;   // bf16 engines: decoder linear1 / linear2 / cross_attn.out_proj as mlp_fused images (refinement pass)
-  DevBuf fc2_packed[12];                          // bf16 engines: encoder fc2 weights chunk-major [48][384][32] for mlp_fused.hip
-  DevBuf qself;                                   // f32 [26][384]
-
-  // workspaces
-  std::vector<std::unique_ptr<DevBuf>> craft_ws;  // per-layer activations
-  int craft_ws_npl = 0;                           // planes per value the split CRAFT workspaces were laid out for
-  DevBuf pq_ws[24];
-  DevBuf canvas, heat, staging_img, crops, rects_dev, logits, ar_logits, ids_dev, tokens;
-  CclBatch ccl;
-  PinnedBuf h_counters, h_cand, h_rows, h_rects[2], h_ids[2];   // pinned staging of the small host <-> device transfers
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  float stage_ms[4] = {0, 0, 0, 0};
-  float host_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // host wall-clock splits of the last run_pages (ttr_last_host_us)
-  static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-  // optional per-launch timing of the igemm kernel (bench.py's roofline): events bracket every launch
-  int profiling = 0;                                   // 0 off, 1 = CRAFT conv launches only, 2 = every conv / GEMM launch
-  int prof_stage = 0;                                  // 0 = CRAFT convs, 1 = PARSeq encoder (ViT) + batched decoder GEMMs, 2 = per-step AR decoder GEMMs
-  std::vector<hipEvent_t> prof_pool;
-  // Every timed launch carries its KIND (which kernel family / which layer role), its ALGORITHMIC flops (2 x MACs of the layer: the figure
-  // SURVEY.md section 8(d) prices the roofline with) and the flops the matrix cores EXECUTE for it (x 3 or x 4 in the split-operand mode).
-  struct ProfRec { int stage; int kind; double alg, exec; int launches; };
-  struct ProfKind { std::string name; int stage = 0; double ms = 0, alg = 0, exec = 0; long launches = 0; };
-  std::vector<ProfKind> prof_kinds;
-  std::map<std::string, int> prof_kind_ids;
-  int kind_id(const char* name) {   // (a kind is a name in a stage: the decoder's linears run in the batched stage and in the AR steps)
-    const std::string key = std::string(name) + "#" + std::to_string(prof_stage);
-    auto it = prof_kind_ids.find(key);
-    if (it != prof_kind_ids.end()) return it->second;
-    const int id = (int)prof_kinds.size();
-    prof_kinds.push_back(ProfKind{name, prof_stage});
-    prof_kind_ids[key] = id;
-    return id;
-  }
-  bool seg_open = false;                               // profiling == 1: an event pair brackets a RUN of consecutive CRAFT conv launches of one kind
-  int seg_kind = -1;                                   // (an event record between two kernels costs ~8 us of idle GPU)
-  double seg_alg = 0, seg_exec = 0; int seg_launches = 0;
-  std::vector<ProfRec> prof_recs;
-  double prof_ms[3] = {0, 0, 0}, prof_flops[3] = {0, 0, 0};
-  long prof_launches[3] = {0, 0, 0};
-
-  template <class F> void timed(const char* kind, double alg_flops, double exec_flops, F&& launch) {
-    if (!profiling || (profiling == 1 && prof_stage != 0)) { launch(); return; }
-    const int k = kind_id(kind);
-    if (profiling == 1) {   // the timed region of bench.py: one event pair per run of same-kind convolutions, closed by the next kind or by prof_break()
-      if (seg_open && seg_kind != k) prof_break();
-      const size_t i = prof_recs.size();
-      while (prof_pool.size() < 2 * (i + 1)) { hipEvent_t e; TTR_HIP_CHECK(hipEventCreate(&e)); prof_pool.push_back(e); }
-      if (!seg_open) { TTR_HIP_CHECK(hipEventRecord(prof_pool[2 * i], stream)); seg_open = true; seg_kind = k; seg_alg = seg_exec = 0; seg_launches = 0; }
-      launch();
-      seg_alg += alg_flops; seg_exec += exec_flops; ++seg_launches;
-      return;
-    }
-    const size_t i = prof_recs.size();
-    while (prof_pool.size() < 2 * (i + 1)) { hipEvent_t e; TTR_HIP_CHECK(hipEventCreate(&e)); prof_pool.push_back(e); }
-    TTR_HIP_CHECK(hipEventRecord(prof_pool[2 * i], stream));
-    launch();
-    TTR_HIP_CHECK(hipEventRecord(prof_pool[2 * i + 1], stream));
-    prof_recs.push_back(ProfRec{prof_stage, k, alg_flops, exec_flops, 1});
-  }
-  void prof_break() {       // call before any kernel that is not a CRAFT convolution, and at the end of CRAFT
-    if (!seg_open) return;
-    TTR_HIP_CHECK(hipEventRecord(prof_pool[2 * prof_recs.size() + 1], stream));
-    prof_recs.push_back(ProfRec{0, seg_kind, seg_alg, seg_exec, seg_launches});
-    seg_open = false;
-  }
-  void igemm(const ConvParams& p, double true_flops, const char* kind = "igemm") {
-    if (prec == kSplit && split_gemm(p, true_flops, kind)) return;
-    timed(kind, true_flops, true_flops, [&] { launch_igemm(prec, p, stream); });
-  }
-  // split-operand engines: the layer as four f16 MFMAs per product (gemm2.hip, SP) when its shape allows; the fp32 inputs
-  // are written as planes first (split_ops.hip)
-  std::map<const void*, const Linear*> split_by_w;   // fp32 weight pointer -> its Linear (the one with the planes)
-  DevBuf split_in[2];
-  bool split_gemm(const ConvParams& p, double true_flops, const char* kind) {
-    auto it = split_by_w.find(p.wgt);
-    if (it == split_by_w.end() || !tn.split_gemm || p.relu0 || p.relu1 || p.ln_in || p.pre_wgt) return false;
-    const Linear& L = *it->second;
-    ConvParams q = p;
-    q.split = 4; q.wgt = L.ws.p; q.out_scale = L.inv_scale; q.out_planes = 0; q.store_policy = 0;
-    split_in[0].ensure((size_t)p.M * p.C0 * 6);
-    q.in0 = split_in[0].p;
-    if (p.C1) { split_in[1].ensure((size_t)p.M * p.C1 * 6); q.in1 = split_in[1].p; }
-    const bool c3 = tn.split_conv3p && p.Cout >= 32 && conv3p_check(q) == nullptr;
-    if (!c3 && gemm2_check(q) != nullptr) return false;
-    prof_break_if_craft();
-    launch_split_planes((const float*)p.in0, p.C0, split_in[0].p, p.M, p.C0, 0, stream, 3, p.skip, p.skip_n);
-    if (p.C1) launch_split_planes((const float*)p.in1, p.C1, split_in[1].p, p.M, p.C1, 0, stream, 3, p.skip, p.skip_n);
-    timed(kind, true_flops, true_flops * 4, [&] { if (c3) launch_conv3p(q, stream); else launch_gemm2(q, 0, stream); });
-    return true;
-  }
-  void prof_break_if_craft() { if (prof_stage == 0) prof_break(); }
-  // Folds the records whose events have completed (one stream: they complete in order).  With streamed batches the newest records
-  // belong to a pass that is still running: they stay, with their events, for the next call.
-  void prof_collect() {
-    if (seg_open) return;                        // (never between the two events of a run)
-    size_t done = 0;
-    for (; done < prof_recs.size(); ++done) {
-      if (hipEventQuery(prof_pool[2 * done + 1]) != hipSuccess) { (void)hipGetLastError(); break; }
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, prof_pool[2 * done], prof_pool[2 * done + 1]) == hipSuccess) {
-        const ProfRec& r = prof_recs[done];
-        prof_ms[r.stage] += ms; prof_flops[r.stage] += r.exec; prof_launches[r.stage] += r.launches;
-        ProfKind& k = prof_kinds[r.kind];
-        k.ms += ms; k.alg += r.alg; k.exec += r.exec; k.launches += r.launches;
-      }
-    }
-    if (done == 0) return;
-    std::rotate(prof_pool.begin(), prof_pool.begin() + 2 * done, prof_pool.begin() + 2 * prof_recs.size());
-    prof_recs.erase(prof_recs.begin(), prof_recs.begin() + done);
-  }
-
-  // ---- construction
-  void upload_linear(Linear& L, const float* w, int cout, int k, const float* bias, int cout_pad, int k_pad,
-                     const std::vector<int>* kmap = nullptr, bool own = true) {
-    // kmap: for each padded k index the source k index or -1
-    std::vector<float> wp((size_t)cout_pad * k_pad, 0.f);
-    for (int o = 0; o < cout; ++o)
+  if (prec == kSplit && k_pad % 32 == 0 && cout_pad % 8 == 0) {   // the f16x4 GEMM's weight planes (the fp32 copy stays for the layers it cannot run)
+    float mx = 0.f;
+    for (float v : wp) mx = std::max(mx, std::fabs(v));
+    int e = 0;
+    if (mx > 0.f) { (void)std::frexp(mx, &e); e = 14 - e; }            // max |w| 2^e in [2^13, 2^14)
+    e = std::max(-24, std::min(40, e));
+    const float S = std::ldexp(1.f, e);
+    std::vector<_Float16> h((size_t)cout_pad * 3 * k_pad);
+    for (int o = 0; o < cout_pad; ++o)
       for (int kk = 0; kk < k_pad; ++kk) {
-        int src = kmap ? (*kmap)[kk] : (kk < k ? kk : -1);
-        if (src >= 0) wp[(size_t)o * k_pad + kk] = w[(size_t)o * k + src];
+        const float v = wp[(size_t)o * k_pad + kk] * S;               // exact
+        const _Float16 w0 = (_Float16)v;
+        const _Float16 w1 = (_Float16)(v - (float)w0);                 // exact difference, then rounded: 22+ bits in the pair
+        _Float16* row = h.data() + (size_t)o * 3 * k_pad;
+        row[kk] = w0;
+        row[k_pad + kk] = (_Float16)((float)w0 * (1.f / 2048.f));
+        row[2 * k_pad + kk] = w1;
       }
-    L.cout = cout_pad; L.k = k_pad;
-    L.w.ensure(wp.size() * es);
-    if (prec == kBF16) {
-      std::vector<uint16_t> h(wp.size());
-      for (size_t i = 0; i < wp.size(); ++i) h[i] = f32_to_bf16_rne(wp[i]);
-      TTR_HIP_CHECK(hipMemcpy(L.w.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
-    } else {
-      TTR_HIP_CHECK(hipMemcpy(L.w.p, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
-    }
-    if (prec == kSplit && k_pad % 32 == 0 && cout_pad % 8 == 0) {   // the f16x4 GEMM's weight planes (the fp32 copy stays for the layers it cannot run)
-      float mx = 0.f;
-      for (float v : wp) mx = std::max(mx, std::fabs(v));
-      int e = 0;
-      if (mx > 0.f) { (void)std::frexp(mx, &e); e = 14 - e; }            // max |w| 2^e in [2^13, 2^14)
-      e = std::max(-24, std::min(40, e));
-      const float S = std::ldexp(1.f, e);
-      std::vector<_Float16> h((size_t)cout_pad * 3 * k_pad);
-      for (int o = 0; o < cout_pad; ++o)
-        for (int kk = 0; kk < k_pad; ++kk) {
-          const float v = wp[(size_t)o * k_pad + kk] * S;               // exact
-          const _Float16 w0 = (_Float16)v;
-          const _Float16 w1 = (_Float16)(v - (float)w0);                 // exact difference, then rounded: 22+ bits in the pair
-          _Float16* row = h.data() + (size_t)o * 3 * k_pad;
-          row[kk] = w0;
-          row[k_pad + kk] = (_Float16)((float)w0 * (1.f / 2048.f));
-          row[2 * k_pad + kk] = w1;
-        }
-      L.ws.ensure(h.size() * 2);
-      TTR_HIP_CHECK(hipMemcpy(L.ws.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
-      L.inv_scale = std::ldexp(1.f, -e);
-      if (own) split_by_w[L.w.p] = &L;       // (only the engine's own layers: a debug entry's local Linear dies with its call)
-    }
-    std::vector<float> bp(cout_pad, 0.f);
-    if (bias) memcpy(bp.data(), bias, sizeof(float) * cout);
-    L.b.ensure(bp.size() * 4);
-    TTR_HIP_CHECK(hipMemcpy(L.b.p, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+    L.ws.ensure(h.size() * 2);
+    TTR_HIP_CHECK(hipMemcpy(L.ws.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    L.inv_scale = std::ldexp(1.f, -e);
+    if (own) split_by_w[L.w.p] = &L;       // (only the engine's own layers: a debug entry's local Linear dies with its call)
   }
-  void upload_f32(DevBuf& d, const float* p, size_t n) {
-    d.ensure(n * 4);
-    TTR_HIP_CHECK(hipMemcpy(d.p, p, n * 4, hipMemcpyHostToDevice));
-  }
+  std::vector<float> bp(cout_pad, 0.f);
+  if (bias) memcpy(bp.data(), bias, sizeof(float) * cout);
+  L.b.ensure(bp.size() * 4);
+  TTR_HIP_CHECK(hipMemcpy(L.b.p, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+}
 
-  static const std::vector<CraftConv>& craft_convs() {
-    static const std::vector<CraftConv> v = {
-        {"slice1.0", 3, 64, 3, 1},     {"slice1.3", 64, 64, 3, 1},    {"slice1.7", 64, 128, 3, 1},   {"slice1.10", 128, 128, 3, 1},
-        {"slice2.14", 128, 256, 3, 1}, {"slice2.17", 256, 256, 3, 1}, {"slice3.20", 256, 256, 3, 1}, {"slice3.24", 256, 512, 3, 1},
-        {"slice3.27", 512, 512, 3, 1}, {"slice4.30", 512, 512, 3, 1}, {"slice4.34", 512, 512, 3, 1}, {"slice4.37", 512, 512, 3, 1},
-        {"slice5.1", 512, 1024, 3, 6}, {"slice5.2", 1024, 1024, 1, 1},
-        {"upconv1.0", 1536, 512, 1, 1}, {"upconv1.3", 512, 256, 3, 1}, {"upconv2.0", 768, 256, 1, 1}, {"upconv2.3", 256, 128, 3, 1},
-        {"upconv3.0", 384, 128, 1, 1},  {"upconv3.3", 128, 64, 3, 1},  {"upconv4.0", 192, 64, 1, 1},  {"upconv4.3", 64, 32, 3, 1},
-        {"conv_cls.0", 32, 32, 3, 1},   {"conv_cls.2", 32, 32, 3, 1},  {"conv_cls.4", 32, 16, 3, 1},  {"conv_cls.6", 16, 16, 1, 1},
-        {"conv_cls.8", 16, 2, 1, 1}};
-    return v;
-  }
+void Engine::upload_f32(DevBuf& d, const float* p, size_t n) {
+  d.ensure(n * 4);
+  TTR_HIP_CHECK(hipMemcpy(d.p, p, n * 4, hipMemcpyHostToDevice));
+}
 
-  void load_craft(const std::string& dir) {
-    WeightFile wf(dir + "/craft.ttrw");
-    for (const auto& c : craft_convs()) {
-      const int taps = c.ks * c.ks;
-      const auto& w = wf.get(std::string(c.name) + ".w", (size_t)c.cout * taps * c.cin);
-      const auto& b = wf.get(std::string(c.name) + ".b", (size_t)c.cout);
-      Linear& L = craft[c.name];
-      if (std::string(c.name) == "slice1.0") {
-        upload_linear(L, w.data.data(), c.cout, 27, b.data.data(), c.cout, 32);  // im2col K 27 -> 32
-        continue;
-      }
-      // channel padding to multiples of 32 (only the 16-channel head tensors need it)
-      int cin_pad = (c.cin + 31) / 32 * 32;
-      // split-operand engines: the three 3x3 layers of the 32-channel head run on the f16 kernels too, which want Cin % 64: their inputs
-      // carry 32 zero channels (the layers are thin: 3 % of CRAFT's flops; on the fp32 MFMA kernel they took 5 % of the time)
-      const std::string nm(c.name);
-      const bool head3 = prec == kSplit && (nm == "conv_cls.0" || nm == "conv_cls.2" || nm == "conv_cls.4");
-      if (head3) cin_pad = 64;
-      int cout_pad = c.cout;
-      if (std::string(c.name) == "conv_cls.4" || std::string(c.name) == "conv_cls.6") cout_pad = 32;  // feeds a padded-Cin layer
-      std::vector<int> kmap((size_t)taps * cin_pad, -1);
-      for (int t = 0; t < taps; ++t)
-        for (int ci = 0; ci < c.cin; ++ci) kmap[(size_t)t * cin_pad + ci] = t * c.cin + ci;
-      upload_linear(L, w.data.data(), c.cout, taps * c.cin, b.data.data(), cout_pad, taps * cin_pad, &kmap);
+void Engine::load_craft(const std::string& dir) {
+  WeightFile wf(dir + "/craft.ttrw");
+  for (const auto& c : craft_convs()) {
+    const int taps = c.ks * c.ks;
+    const auto& w = wf.get(std::string(c.name) + ".w", (size_t)c.cout * taps * c.cin);
+    const auto& b = wf.get(std::string(c.name) + ".b", (size_t)c.cout);
+    Linear& L = craft[c.name];
+    if (std::string(c.name) == "slice1.0") {
+      upload_linear(L, w.data.data(), c.cout, 27, b.data.data(), c.cout, 32);  // im2col K 27 -> 32
+      continue;
     }
+    // channel padding to multiples of 32 (only the 16-channel head tensors need it)
+    int cin_pad = (c.cin + 31) / 32 * 32;
+    // split-operand engines: the three 3x3 layers of the 32-channel head run on the f16 kernels too, which want Cin % 64: their inputs
+    // carry 32 zero channels (the layers are thin: 3 % of CRAFT's flops; on the fp32 MFMA kernel they took 5 % of the time)
+    const std::string nm(c.name);
+    const bool head3 = prec == kSplit && (nm == "conv_cls.0" || nm == "conv_cls.2" || nm == "conv_cls.4");
+    if (head3) cin_pad = 64;
+    int cout_pad = c.cout;
+    if (std::string(c.name) == "conv_cls.4" || std::string(c.name) == "conv_cls.6") cout_pad = 32;  // feeds a padded-Cin layer
+    std::vector<int> kmap((size_t)taps * cin_pad, -1);
+    for (int t = 0; t < taps; ++t)
+      for (int ci = 0; ci < c.cin; ++ci) kmap[(size_t)t * cin_pad + ci] = t * c.cin + ci;
+    upload_linear(L, w.data.data(), c.cout, taps * c.cin, b.data.data(), cout_pad, taps * cin_pad, &kmap);
   }
+}
 
-  // Row order of the qkv weight for the fused qkv + attention launch: row n = 192 h + c of the head-major matrix is tile channel c of head h,
-  // c = 96 wn + 32 t + dd -> Q (t = 0), K (t = 1), V (t = 2), d = 32 wn + dd; upstream (timm) row = 384 t + 64 h + d
-  static int qkv_tile_row(int n) {
-    const int h = n / 192, c = n % 192, wn = c / 96, t = (c % 96) / 32, dd = c % 32;
-    return 384 * t + 64 * h + 32 * wn + dd;
-  }
-
-  void load_parseq(const std::string& dir) {
-    WeightFile wf(dir + "/parseq.ttrw");
-    auto lin = [&](const std::string& key, const std::string& wname, const std::string& bname, int cout, int k, int row0 = 0, int rows_total = -1) {
-      if (rows_total < 0) rows_total = cout;
-      const auto& w = wf.get(wname, (size_t)rows_total * k);
-      const auto& b = wf.get(bname, (size_t)rows_total);
-      upload_linear(pq[key], w.data.data() + (size_t)row0 * k, cout, k, b.data.data() + row0, cout, k);
-    };
-    auto vec = [&](const std::string& name, size_t n) { upload_f32(pqf[name], wf.get(name, n).data.data(), n); };
-    const int E = 384;
-    {   // patch embedding: K = 96 (4 x 8 x 3); the bf16 engine pads it to 128 so that the linear runs on gemm2 (K % 64) instead of the
-      // first-generation igemm (104 -> ~60 us at 1280 crops); the pad columns are zero in the patches and in the weights
-      const auto& w = wf.get("encoder.patch_embed.proj.weight", (size_t)E * 96);
-      const auto& b = wf.get("encoder.patch_embed.proj.bias", (size_t)E);
-      upload_linear(pq["patch"], w.data.data(), E, 96, b.data.data(), E, prec != kF32 ? 128 : 96);
-    }
-    vec("encoder.pos_embed", 128 * E);
-    for (int i = 0; i < 12; ++i) {
-      std::string p = "encoder.blocks." + std::to_string(i) + ".";
-      vec(p + "norm1.weight", E); vec(p + "norm1.bias", E); vec(p + "norm2.weight", E); vec(p + "norm2.bias", E);
-      lin(p + "qkv", p + "attn.qkv.weight", p + "attn.qkv.bias", 3 * E, E);
-      if (prec == kSplit) {   // the fused qkv + attention launch (gemm_sp.hip, attention epilogue) wants the rows tile by tile: head-major, see qkv_tile_row
-        const auto& w = wf.get(p + "attn.qkv.weight", (size_t)3 * E * E).data;
-        const auto& b = wf.get(p + "attn.qkv.bias", (size_t)3 * E).data;
-        std::vector<float> wp((size_t)3 * E * E), bp((size_t)3 * E);
-        for (int n = 0; n < 3 * E; ++n) {
-          const int src = qkv_tile_row(n);
-          memcpy(&wp[(size_t)n * E], &w[(size_t)src * E], sizeof(float) * E);
-          bp[n] = b[src];
-        }
-        upload_linear(pq[p + "qkv_hm"], wp.data(), 3 * E, E, bp.data(), 3 * E, E);
-      }
-      lin(p + "proj", p + "attn.proj.weight", p + "attn.proj.bias", E, E);
-      lin(p + "fc1", p + "mlp.fc1.weight", p + "mlp.fc1.bias", 4 * E, E);
-      lin(p + "fc2", p + "mlp.fc2.weight", p + "mlp.fc2.bias", E, 4 * E);
-      if (prec == kBF16) {   // mlp_fused.hip's operands as LDS images
-        std::vector<uint16_t> h((size_t)E * 4 * E);
-        pack_mlp_w1(wf.get(p + "mlp.fc1.weight", (size_t)4 * E * E).data.data(), h.data());
-        fc1_packed[i].ensure(h.size() * 2);
-        TTR_HIP_CHECK(hipMemcpy(fc1_packed[i].p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
-        pack_mlp_w2(wf.get(p + "mlp.fc2.weight", (size_t)E * 4 * E).data.data(), 4 * E, h.data());
-        fc2_packed[i].ensure(h.size() * 2);
-        TTR_HIP_CHECK(hipMemcpy(fc2_packed[i].p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
-        std::vector<uint16_t> hp((size_t)E * E);
-        pack_mlp_w2(wf.get(p + "attn.proj.weight", (size_t)E * E).data.data(), E, hp.data());
-        proj_packed[i].ensure(hp.size() * 2);
-        TTR_HIP_CHECK(hipMemcpy(proj_packed[i].p, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
-      }
-    }
-    vec("encoder.norm.weight", E); vec("encoder.norm.bias", E);
-    const std::string d = "decoder.layers.0.";
-    lin("self_kv", d + "self_attn.in_proj_weight", d + "self_attn.in_proj_bias", 2 * E, E, E, 3 * E);
-    lin("self_out", d + "self_attn.out_proj.weight", d + "self_attn.out_proj.bias", E, E);
-    lin("cross_q", d + "cross_attn.in_proj_weight", d + "cross_attn.in_proj_bias", E, E, 0, 3 * E);
-    lin("cross_kv", d + "cross_attn.in_proj_weight", d + "cross_attn.in_proj_bias", 2 * E, E, E, 3 * E);
-    lin("cross_out", d + "cross_attn.out_proj.weight", d + "cross_attn.out_proj.bias", E, E);
-    lin("ffn1", d + "linear1.weight", d + "linear1.bias", 4 * E, E);
-    lin("ffn2", d + "linear2.weight", d + "linear2.bias", E, 4 * E);
-    if (prec == kBF16) {   // the refinement pass runs cross_out + norm2 + FFN + final norm through mlp_fused.hip
-      std::vector<uint16_t> h((size_t)E * 4 * E), hp((size_t)E * E);
-      pack_mlp_w1(wf.get(d + "linear1.weight", (size_t)4 * E * E).data.data(), h.data());
-      dec_ffn1_packed.ensure(h.size() * 2); TTR_HIP_CHECK(hipMemcpy(dec_ffn1_packed.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
-      pack_mlp_w2(wf.get(d + "linear2.weight", (size_t)E * 4 * E).data.data(), 4 * E, h.data());
-      dec_ffn2_packed.ensure(h.size() * 2); TTR_HIP_CHECK(hipMemcpy(dec_ffn2_packed.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
-      pack_mlp_w2(wf.get(d + "cross_attn.out_proj.weight", (size_t)E * E).data.data(), E, hp.data());
-      dec_co_packed.ensure(hp.size() * 2); TTR_HIP_CHECK(hipMemcpy(dec_co_packed.p, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
-    }
-    for (const char* n : {"norm1", "norm2", "norm_q", "norm_c"}) { vec(d + n + ".weight", E); vec(d + n + ".bias", E); }
-    vec("decoder.norm.weight", E); vec("decoder.norm.bias", E);
-    lin("head", "head.weight", "head.bias", 95, E);
-    vec("text_embed.embedding.weight", 97 * E);
-    vec("pos_queries", 26 * E);
-    // Qself[i] = Wq . norm_q(pos_queries[i]) + bq : crop independent, computed once on the host in fp32
-    {
-      const auto& pos = wf.get("pos_queries", 26 * E).data;
-      const auto& g = wf.get(d + "norm_q.weight", E).data;
-      const auto& bt = wf.get(d + "norm_q.bias", E).data;
-      const auto& w = wf.get(d + "self_attn.in_proj_weight", (size_t)3 * E * E).data;
-      const auto& b = wf.get(d + "self_attn.in_proj_bias", 3 * E).data;
-      std::vector<float> q((size_t)26 * E), ln(E);
-      for (int i = 0; i < 26; ++i) {
-        float mean = 0.f;
-        for (int c = 0; c < E; ++c) mean += pos[i * E + c];
-        mean /= E;
-        float var = 0.f;
-        for (int c = 0; c < E; ++c) { float dd = pos[i * E + c] - mean; var += dd * dd; }
-        var /= E;
-        float rstd = 1.0f / std::sqrt(var + 1e-5f);
-        for (int c = 0; c < E; ++c) ln[c] = (pos[i * E + c] - mean) * rstd * g[c] + bt[c];
-        for (int o = 0; o < E; ++o) {
-          float acc = 0.f;
-          for (int c = 0; c < E; ++c) acc += w[(size_t)o * E + c] * ln[c];
-          q[(size_t)i * E + o] = acc + b[o];
-        }
-      }
-      upload_f32(qself, q.data(), q.size());
-    }
-  }
-
-  bool verbose = false;
-  // ---- multi-GPU (ttr_engine_attach_comm): every batch's token ids are all-gathered on the stream, device buffer to device buffer
-  Comm* comm = nullptr;
-  DevBuf gath_dev[2];
-  PinnedBuf h_gath[2];
-  struct Gathered { int world = 0, pages = 0; std::vector<int32_t> counts, ids; } last_gathered;
-  // small host buffers of every rank, concatenated by rank (also the barrier): staged through device memory on the copy stream
-  void allgather_host(const void* mine, size_t bytes, void* all) {
-    Comm& c = *comm;
-    const size_t b = std::max<size_t>(bytes, 1);
-    c.h_in.ensure(b); c.h_out.ensure(b * c.world); c.d_in.ensure(b); c.d_out.ensure(b * c.world);
-    if (bytes) memcpy(c.h_in.p, mine, bytes);
-    TTR_HIP_CHECK(hipMemcpyAsync(c.d_in.p, c.h_in.p, b, hipMemcpyHostToDevice, copy_stream));
-    c.tr->all_gather(c.d_in.p, c.d_out.p, b, true, copy_stream);
-    TTR_HIP_CHECK(hipMemcpyAsync(c.h_out.p, c.d_out.p, b * c.world, hipMemcpyDeviceToHost, copy_stream));
-    TTR_HIP_CHECK(hipStreamSynchronize(copy_stream));
-    if (bytes && all) memcpy(all, c.h_out.p, bytes * c.world);
-  }
-  Engine(const std::string& dir, const ttr_config& c) : cfg(c) {
-    { const char* v = getenv("TUATARA_VERBOSE"); verbose = cfg.verbose != 0 || (v && *v && std::string(v) != "0"); }
-    prec = cfg.precision == TTR_PREC_F32 ? kF32 : cfg.precision == TTR_PREC_F16X4 ? kSplit : kBF16;
-    es = prec == kBF16 ? 2 : 4;
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev <= 0) throw std::runtime_error("no HIP device available: the tuatara engine has no CPU fallback");
-    TTR_HIP_CHECK(hipSetDevice(cfg.device));
-    TTR_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    TTR_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-    TTR_HIP_CHECK(hipEventCreateWithFlags(&copy_ev, hipEventDisableTiming));
-    for (auto& x : done_ev) TTR_HIP_CHECK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
-    for (auto& sl : evr) for (auto& x : sl) TTR_HIP_CHECK(hipEventCreate(&x));
-    {   // host threads for the per-page calipers / decode: at most 15, and a fair share of the box when several ranks run on it
-      // (torch.distributed.run exports LOCAL_WORLD_SIZE); TUATARA_HOST_THREADS overrides
-      int hw = std::max(1, (int)std::thread::hardware_concurrency());
-      if (const char* lw = getenv("LOCAL_WORLD_SIZE")) { const int n = atoi(lw); if (n > 1) hw = std::max(1, hw / n); }
-      int workers = std::min(15, std::max(1, hw - 1));
-      if (const char* ht = getenv("TUATARA_HOST_THREADS")) { const int n = atoi(ht); if (n >= 1) workers = std::min(64, n); }
-      host_pool.reset(new HostPool(workers));
-    }
-    for (auto& x : ev) TTR_HIP_CHECK(hipEventCreate(&x));
-    load_craft(dir);
-    load_parseq(dir);
-  }
-  ~Engine() {
-    (void)hipSetDevice(cfg.device);
-    for (auto& x : ev) if (x) (void)hipEventDestroy(x);
-    for (auto& x : prof_pool) (void)hipEventDestroy(x);
-    for (auto& x : group_ev) (void)hipEventDestroy(x);
-    if (copy_ev) (void)hipEventDestroy(copy_ev);
-    for (auto& x : done_ev) if (x) (void)hipEventDestroy(x);
-    for (auto& sl : evr) for (auto& x : sl) if (x) (void)hipEventDestroy(x);
-    if (copy_stream) (void)hipStreamDestroy(copy_stream);
-    if (stream) (void)hipStreamDestroy(stream);
-  }
-
-  // ---- CRAFT
-  DevBuf& ws(size_t idx, size_t bytes, bool zero_new = false) {
-    while (craft_ws.size() <= idx) craft_ws.emplace_back(new DevBuf());
-    DevBuf& d = *craft_ws[idx];
-    const size_t cap_before = d.cap;          // (not the pointer: the allocator may hand the grown block the old address)
-    d.ensure(bytes);
-    if (zero_new && d.cap != cap_before) TTR_HIP_CHECK(hipMemsetAsync(d.p, 0, d.cap, stream));   // padding channels are written once, here
-    return d;
-  }
-
-  void conv(const char* name, const void* in0, int C0, const void* in1, int C1, int relu0, int B, int H, int W, void* out, int act,
-            float* out_f32 = nullptr, void* out_relu = nullptr, void* out_pool = nullptr, int pool_relu = 0) {
-    const Linear& L = craft.at(name);
-    ConvParams p{};
-    p.in0 = in0; p.C0 = C0; p.in1 = in1; p.C1 = C1; p.relu0 = relu0; p.relu1 = 0;
-    p.B = B; p.H = H; p.W = W;
-    const int Ct = C0 + C1;
-    p.ks = (L.k == Ct) ? 1 : 3;
-    if (L.k != p.ks * p.ks * Ct) throw std::runtime_error(std::string("conv shape mismatch at ") + name);
-    p.dil = std::string(name) == "slice5.1" ? 6 : 1;
-    p.wgt = L.w.p; p.bias = L.b.as<float>();
-    p.out = out; p.out_ld = L.cout; p.out_f32 = out_f32; p.out_f32_ld = L.cout; p.out_relu = out_relu; p.out_pool = out_pool; p.pool_relu = pool_relu;
-    p.Cout = L.cout; p.M = B * H * W; p.act = act;
-    double flops = 0;   // algorithmic: 2 * M * Cout * K of the *unpadded* layer
-    for (const auto& c : craft_convs()) if (std::string(c.name) == name) flops = 2.0 * p.M * c.cout * c.ks * c.ks * c.cin;
-    igemm(p, flops, prec == kSplit ? "igemm_kernel<f32> (CRAFT head 1x1)" : "CRAFT convolutions (igemm / gemm2 / conv3p)");
-  }
-
-  // canvas u8 [B][H][W][3] (device) -> heat f32 [B][H/2][W/2][2] (device)
-  void craft_forward(const uint8_t* d_canvas, int B, int H, int W, float* d_heat) {
-    if (H % 32 || W % 32) throw std::runtime_error("CRAFT canvas must be a multiple of 32");
-    if (prec == kSplit) return craft_forward_split(d_canvas, B, H, W, d_heat);   // (the split_gemm / split_planes knobs act on PARSeq only)
-    prof_stage = 0;
-    const size_t M0 = (size_t)B * H * W, M1 = M0 / 4, M2 = M1 / 4, M3 = M2 / 4, M4 = M3 / 4;
-    const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8, H4 = H / 16, W4 = W / 16;
-    size_t k = 0;
-    auto buf = [&](size_t rows, int C) -> void* { return ws(k++, rows * C * es).p; };
-    // 2x2 max-pools: fused into the producing conv's epilogue in bf16 mode (gemm2 / conv3p), a separate kernel in f32 mode
-    const bool fp = prec == kBF16 && gemm_config() >= 0;
-    const bool first_fused = fp && tn.fuse_first && H % 8 == 0 && W % 32 == 0;   // conv1_1 computed inside conv1_2's loader (conv3p FIRST)
-    void* a0 = buf(prec == kBF16 ? 0 : M0, 32);
-    void* c11 = buf(first_fused ? 0 : M0, 64);
-    void* c12 = buf(fp ? 0 : M0, 64); void* p1 = buf(M1, 64);
-    if (first_fused) {
-      const Linear& L0 = craft.at("slice1.0"); const Linear& L = craft.at("slice1.3");
-      ConvParams p{};
-      p.in0 = d_canvas; p.C0 = 64; p.B = B; p.H = H; p.W = W; p.ks = 3; p.dil = 1;
-      p.pre_wgt = L0.w.p; p.pre_bias = L0.b.as<float>();
-      p.wgt = L.w.p; p.bias = L.b.as<float>(); p.out_ld = 64; p.out_pool = p1; p.Cout = 64; p.M = (int)M0; p.act = kActRelu;
-      timed("conv3p_first2s (conv1_1 + conv1_2 + pool)", 2.0 * M0 * 64 * (27 + 576), 2.0 * M0 * 64 * (27 + 576), [&] { launch_conv3p(p, stream); });
-    } else {
-      if (prec == kBF16) {   // conv1_1 straight from the u8 canvas
-        const Linear& L = craft.at("slice1.0");
-        timed("conv1_direct", 2.0 * M0 * 64 * 27, 2.0 * M0 * 64 * 27, [&] { launch_conv1_direct(d_canvas, L.w.p, L.b.as<float>(), c11, B, H, W, stream); });
-      } else {
-        prof_break(), launch_im2col_l1(prec, d_canvas, a0, B, H, W, stream);
-        conv("slice1.0", a0, 32, nullptr, 0, 0, 1, 1, (int)M0, c11, kActRelu);
-      }
-      if (fp) conv("slice1.3", c11, 64, nullptr, 0, 0, B, H, W, nullptr, kActRelu, nullptr, nullptr, p1);
-      else { conv("slice1.3", c11, 64, nullptr, 0, 0, B, H, W, c12, kActRelu); prof_break(), launch_maxpool2x2(prec, c12, p1, B, H, W, 64, 0, stream); }
-    }
-    void* c21 = buf(M1, 128); conv("slice1.7", p1, 64, nullptr, 0, 0, B, H1, W1, c21, kActRelu);
-    void* c22 = buf(M1, 128); void* p2 = buf(M2, 128);                                                   // relu2_2 skip (pre-ReLU)
-    if (fp) conv("slice1.10", c21, 128, nullptr, 0, 0, B, H1, W1, c22, kActNone, nullptr, nullptr, p2, 1);
-    else { conv("slice1.10", c21, 128, nullptr, 0, 0, B, H1, W1, c22, kActNone); prof_break(), launch_maxpool2x2(prec, c22, p2, B, H1, W1, 128, 1, stream); }
-    void* c31 = buf(M2, 256); conv("slice2.14", p2, 128, nullptr, 0, 0, B, H2, W2, c31, kActRelu);
-    void* c32 = buf(M2, 256); void* c32r = buf(M2, 256);
-    conv("slice2.17", c31, 256, nullptr, 0, 0, B, H2, W2, c32, kActNone, nullptr, c32r);                // relu3_2 skip (pre-ReLU) + its ReLU
-    void* c33 = buf(fp ? 0 : M2, 256); void* p3 = buf(M3, 256);
-    if (fp) conv("slice3.20", c32r, 256, nullptr, 0, 0, B, H2, W2, nullptr, kActRelu, nullptr, nullptr, p3);
-    else { conv("slice3.20", c32r, 256, nullptr, 0, 0, B, H2, W2, c33, kActRelu); prof_break(), launch_maxpool2x2(prec, c33, p3, B, H2, W2, 256, 0, stream); }
-    void* c41 = buf(M3, 512); conv("slice3.24", p3, 256, nullptr, 0, 0, B, H3, W3, c41, kActRelu);
-    void* c42 = buf(M3, 512); void* c42r = buf(M3, 512);
-    conv("slice3.27", c41, 512, nullptr, 0, 0, B, H3, W3, c42, kActNone, nullptr, c42r);                // relu4_3 skip + its ReLU
-    void* c43 = buf(fp ? 0 : M3, 512); void* p4 = buf(M4, 512);
-    if (fp) conv("slice4.30", c42r, 512, nullptr, 0, 0, B, H3, W3, nullptr, kActRelu, nullptr, nullptr, p4);
-    else { conv("slice4.30", c42r, 512, nullptr, 0, 0, B, H3, W3, c43, kActRelu); prof_break(), launch_maxpool2x2(prec, c43, p4, B, H3, W3, 512, 0, stream); }
-    void* c51 = buf(M4, 512); conv("slice4.34", p4, 512, nullptr, 0, 0, B, H4, W4, c51, kActRelu);
-    void* c52 = buf(M4, 512); conv("slice4.37", c51, 512, nullptr, 0, 0, B, H4, W4, c52, kActNone);   // relu5_3 skip
-    void* mp = buf(M4, 512);  prof_break(), launch_maxpool3x3s1(prec, c52, mp, B, H4, W4, 512, stream);
-    void* c6 = buf(M4, 1024); conv("slice5.1", mp, 512, nullptr, 0, 0, B, H4, W4, c6, kActNone);
-    void* fc7 = buf(M4, 1024); conv("slice5.2", c6, 1024, nullptr, 0, 0, B, H4, W4, fc7, kActNone);
-    void* u1a = buf(M4, 512); conv("upconv1.0", fc7, 1024, c52, 512, 0, B, H4, W4, u1a, kActRelu);
-    void* u1b = buf(M4, 256); conv("upconv1.3", u1a, 512, nullptr, 0, 0, B, H4, W4, u1b, kActRelu);
-    void* up1 = buf(M3, 256); prof_break(), launch_upsample2x(prec, u1b, up1, B, H4, W4, 256, stream);
-    void* u2a = buf(M3, 256); conv("upconv2.0", up1, 256, c42, 512, 0, B, H3, W3, u2a, kActRelu);
-    void* u2b = buf(M3, 128); conv("upconv2.3", u2a, 256, nullptr, 0, 0, B, H3, W3, u2b, kActRelu);
-    void* up2 = buf(M2, 128); prof_break(), launch_upsample2x(prec, u2b, up2, B, H3, W3, 128, stream);
-    void* u3a = buf(M2, 128); conv("upconv3.0", up2, 128, c32, 256, 0, B, H2, W2, u3a, kActRelu);
-    void* u3b = buf(M2, 64);  conv("upconv3.3", u3a, 128, nullptr, 0, 0, B, H2, W2, u3b, kActRelu);
-    void* up3 = buf(M1, 64);  prof_break(), launch_upsample2x(prec, u3b, up3, B, H2, W2, 64, stream);
-    void* u4a = buf(M1, 64);  conv("upconv4.0", up3, 64, c22, 128, 0, B, H1, W1, u4a, kActRelu);
-    void* u4b = buf(M1, 32);  conv("upconv4.3", u4a, 64, nullptr, 0, 0, B, H1, W1, u4b, kActRelu);
-    void* h0 = buf(M1, 32); void* h2 = buf(M1, 32);
-    if (fp && H1 % 8 == 0 && W1 % 32 == 0 && M1 * 64 < ((size_t)1 << 31)) {
-      // 32-channel head: conv3s.hip (patch-resident 3x3; conv_cls.4 + .6 + .8 as one kernel writing the f32 heat map)
-      auto head = [&](const char* name, const void* in, void* out, bool tail) {
-        const Linear& L = craft.at(name);
-        Conv3sParams q{};
-        q.in = (const bf16*)in; q.wgt = L.w.as<bf16>(); q.bias = L.b.as<float>(); q.out = (bf16*)out; q.B = B; q.H = H1; q.W = W1;
-        double flops = 2.0 * M1 * 32 * 288;
-        if (tail) {
-          const Linear& L6 = craft.at("conv_cls.6"); const Linear& L8 = craft.at("conv_cls.8");
-          q.w6 = L6.w.as<bf16>(); q.b6 = L6.b.as<float>(); q.w8 = L8.w.as<bf16>(); q.b8 = L8.b.as<float>(); q.heat = d_heat; q.out = nullptr;
-          flops = 2.0 * M1 * (16 * 288 + 16 * 16 + 2 * 16);
-        }
-        timed("conv3s (32-channel head)", flops, flops, [&] { launch_conv3s(q, stream); });
-      };
-      head("conv_cls.0", u4b, h0, false);
-      head("conv_cls.2", h0, h2, false);
-      head("conv_cls.4", h2, nullptr, true);
-    } else {
-      conv("conv_cls.0", u4b, 32, nullptr, 0, 0, B, H1, W1, h0, kActRelu);
-      conv("conv_cls.2", h0, 32, nullptr, 0, 0, B, H1, W1, h2, kActRelu);
-      void* h4 = buf(M1, 32);   conv("conv_cls.4", h2, 32, nullptr, 0, 0, B, H1, W1, h4, kActRelu);   // 16 real + 16 zero channels
-      void* h6 = buf(M1, 32);   conv("conv_cls.6", h4, 32, nullptr, 0, 0, B, H1, W1, h6, kActRelu);
-      conv("conv_cls.8", h6, 32, nullptr, 0, 0, B, H1, W1, nullptr, kActNone, d_heat);
-    }
-    prof_break();
-  }
-
-
-  // ---- CRAFT, split-operand engines: every tensor between the convolutions lives as f16 planes ([pixel][x0 | x1 | x2], 6 bytes per
-  // value); the convolutions' epilogues write them (bias, ReLU, ReLU copy, 2x2 max-pool fused), so no fp32 tensor and no separate
-  // split pass exists up to the 32-channel head, which stays on the fp32 MFMA kernel (thin layers: 3 % of the FLOPs).
-  void sconv(const char* name, const void* in0, int C0, const void* in1, int C1, int B, int H, int W, void* out, int act,
-             void* out_relu = nullptr, void* out_pool = nullptr, int pool_relu = 0, int out_planes = -1, int out_ld = 0) {
-    const int np = tn.craft_products == 4 ? 4 : 3;             // products per value: 3 = activation pairs (default), 4 = exact triples
-    if (out_planes < 0) out_planes = np - 1;
-    const Linear& L = craft.at(name);
-    ConvParams p{};
-    p.in0 = in0; p.C0 = C0; p.in1 = in1; p.C1 = C1; p.B = B; p.H = H; p.W = W;
-    const int Ct = C0 + C1;
-    p.ks = (L.k == Ct) ? 1 : 3;
-    if (L.k != p.ks * p.ks * Ct || !L.ws.p) throw std::runtime_error(std::string("split conv shape mismatch at ") + name);
-    p.dil = std::string(name) == "slice5.1" ? 6 : 1;
-    p.wgt = L.ws.p; p.bias = L.b.as<float>(); p.split = np; p.out_scale = L.inv_scale; p.out_planes = out_planes;
-    p.out = out; p.out_ld = out_ld ? out_ld : L.cout; p.out_relu = out_relu; p.out_pool = out_pool; p.pool_relu = pool_relu;
-    p.Cout = L.cout; p.M = B * H * W; p.act = act;
-    double flops = 0;
-    for (const auto& c : craft_convs()) if (std::string(c.name) == name) flops = 2.0 * p.M * c.cout * c.ks * c.ks * c.cin;
-    const bool c3 = tn.split_conv3p && p.Cout >= 32 && conv3p_check(p) == nullptr;
-    if (!c3) { if (const char* e = gemm2_check(p)) throw std::runtime_error(std::string(name) + ": " + e); }
-    // kinds by kernel: the patch-stationary 3x3 kernel by its tile width (conv3p.hip picks it), everything else on gemm2's split loop
-    const int bn = c3 ? conv3p_split_bn(p) : 0;
-    const char* kind = !c3 ? (np == 3 ? "gemm2_kernel<SP,NP=3> (CRAFT 1x1 / dilated)" : "gemm2_kernel<SP,NP=4> (CRAFT 1x1 / dilated)")
-                     : bn == 128 ? (np == 3 ? "conv3p_kernel<128,NP=3>" : "conv3p_kernel<128,NP=4>")
-                     : bn == 64 ? (np == 3 ? "conv3p_kernel<64,NP=3>" : "conv3p_kernel<64,NP=4>") : (np == 3 ? "conv3p_kernel<32,NP=3>" : "conv3p_kernel<32,NP=4>");
-    timed(kind, flops, flops * np, [&] { if (c3) launch_conv3p(p, stream); else launch_gemm2(p, 0, stream); });
-  }
-  void craft_forward_split(const uint8_t* d_canvas, int B, int H, int W, float* d_heat) {
-    prof_stage = 0;
-    const size_t M0 = (size_t)B * H * W, M1 = M0 / 4, M2 = M1 / 4, M3 = M2 / 4, M4 = M3 / 4;
-    const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8, H4 = H / 16, W4 = W / 16;
-    size_t k = 0;
-    const int npl = tn.craft_products == 4 ? 3 : 2;                                       // planes per value
-    if (npl != craft_ws_npl) {   // another plane count: the zero padding channels of the head tensors sit elsewhere - start from fresh buffers
-      TTR_HIP_CHECK(hipStreamSynchronize(stream));
-      craft_ws.clear();
-      craft_ws_npl = npl;
-    }
-    auto pbuf = [&](size_t rows, int C) -> void* { return ws(k++, rows * C * 2 * npl).p; };   // planes
-    auto fbuf = [&](size_t rows, int C) -> void* { return ws(k++, rows * C * 4).p; };   // fp32
-    void* c11 = pbuf(M0, 64);
-    {
-      const Linear& L0 = craft.at("slice1.0");
-      timed("conv1_split_kernel", 2.0 * M0 * 64 * 27, 2.0 * M0 * 64 * 27 * (npl + 1), [&] { launch_conv1_split(d_canvas, L0.ws.p, L0.b.as<float>(), L0.inv_scale, c11, B, H, W, stream, npl); });
-    }
-    void* p1 = pbuf(M1, 64);   sconv("slice1.3", c11, 64, nullptr, 0, B, H, W, nullptr, kActRelu, nullptr, p1, 0);
-    void* c21 = pbuf(M1, 128); sconv("slice1.7", p1, 64, nullptr, 0, B, H1, W1, c21, kActRelu);
-    void* c22 = pbuf(M1, 128); void* p2 = pbuf(M2, 128);
-    sconv("slice1.10", c21, 128, nullptr, 0, B, H1, W1, c22, kActNone, nullptr, p2, 1);                    // relu2_2 skip (pre-ReLU) + pooled ReLU
-    void* c31 = pbuf(M2, 256); sconv("slice2.14", p2, 128, nullptr, 0, B, H2, W2, c31, kActRelu);
-    void* c32 = pbuf(M2, 256); void* c32r = pbuf(M2, 256);
-    sconv("slice2.17", c31, 256, nullptr, 0, B, H2, W2, c32, kActNone, c32r);                               // relu3_2 skip + its ReLU
-    void* p3 = pbuf(M3, 256);  sconv("slice3.20", c32r, 256, nullptr, 0, B, H2, W2, nullptr, kActRelu, nullptr, p3, 0);
-    void* c41 = pbuf(M3, 512); sconv("slice3.24", p3, 256, nullptr, 0, B, H3, W3, c41, kActRelu);
-    void* c42 = pbuf(M3, 512); void* c42r = pbuf(M3, 512);
-    sconv("slice3.27", c41, 512, nullptr, 0, B, H3, W3, c42, kActNone, c42r);                               // relu4_3 skip + its ReLU
-    void* p4 = pbuf(M4, 512);  sconv("slice4.30", c42r, 512, nullptr, 0, B, H3, W3, nullptr, kActRelu, nullptr, p4, 0);
-    void* c51 = pbuf(M4, 512); sconv("slice4.34", p4, 512, nullptr, 0, B, H4, W4, c51, kActRelu);
-    void* c52 = pbuf(M4, 512); sconv("slice4.37", c51, 512, nullptr, 0, B, H4, W4, c52, kActNone);          // relu5_3 skip
-    void* mp = pbuf(M4, 512);  prof_break(), launch_maxpool3x3s1_planes(c52, mp, B, H4, W4, 512, stream, npl);
-    void* c6 = pbuf(M4, 1024); sconv("slice5.1", mp, 512, nullptr, 0, B, H4, W4, c6, kActNone);
-    void* fc7 = pbuf(M4, 1024); sconv("slice5.2", c6, 1024, nullptr, 0, B, H4, W4, fc7, kActNone);
-    void* u1a = pbuf(M4, 512); sconv("upconv1.0", fc7, 1024, c52, 512, B, H4, W4, u1a, kActRelu);
-    void* u1b = pbuf(M4, 256); sconv("upconv1.3", u1a, 512, nullptr, 0, B, H4, W4, u1b, kActRelu);
-    void* up1 = pbuf(M3, 256); prof_break(), launch_upsample2x_planes(u1b, up1, B, H4, W4, 256, stream, npl);
-    void* u2a = pbuf(M3, 256); sconv("upconv2.0", up1, 256, c42, 512, B, H3, W3, u2a, kActRelu);
-    void* u2b = pbuf(M3, 128); sconv("upconv2.3", u2a, 256, nullptr, 0, B, H3, W3, u2b, kActRelu);
-    void* up2 = pbuf(M2, 128); prof_break(), launch_upsample2x_planes(u2b, up2, B, H3, W3, 128, stream, npl);
-    void* u3a = pbuf(M2, 128); sconv("upconv3.0", up2, 128, c32, 256, B, H2, W2, u3a, kActRelu);
-    void* u3b = pbuf(M2, 64);  sconv("upconv3.3", u3a, 128, nullptr, 0, B, H2, W2, u3b, kActRelu);
-    void* up3 = pbuf(M1, 64);  prof_break(), launch_upsample2x_planes(u3b, up3, B, H2, W2, 64, stream, npl);
-    void* u4a = pbuf(M1, 64);  sconv("upconv4.0", up3, 64, c22, 128, B, H1, W1, u4a, kActRelu);
-    // 32-channel head: the 3x3 layers on the f16 kernels over planes with 32 zero channels behind the 32 real ones (row = 64 channels);
-    // the two 1x1 layers (16 -> 16 -> 2) on the fp32 MFMA kernel
-    auto zbuf = [&](size_t rows) -> void* { return ws(k++, rows * 64 * 2 * npl, true).p; };
-    void* u4b = zbuf(M1); sconv("upconv4.3", u4a, 64, nullptr, 0, B, H1, W1, u4b, kActRelu, nullptr, nullptr, 0, -1, 64);
-    void* h0 = zbuf(M1);  sconv("conv_cls.0", u4b, 64, nullptr, 0, B, H1, W1, h0, kActRelu, nullptr, nullptr, 0, -1, 64);
-    void* h2 = zbuf(M1);  sconv("conv_cls.2", h0, 64, nullptr, 0, B, H1, W1, h2, kActRelu, nullptr, nullptr, 0, -1, 64);
-    void* h4 = fbuf(M1, 32); sconv("conv_cls.4", h2, 64, nullptr, 0, B, H1, W1, h4, kActRelu, nullptr, nullptr, 0, /*out_planes=*/0);   // fp32, 16 real + 16 zero channels
-    {   // the two 1x1 head layers stay on the fp32 MFMA kernel (restored also when a launch throws)
-      struct Restore { int& v; int keep; ~Restore() { v = keep; } } restore{tn.split_gemm, tn.split_gemm};
-      tn.split_gemm = 0;
-      void* h6 = fbuf(M1, 32);
-      conv("conv_cls.6", h4, 32, nullptr, 0, 0, B, H1, W1, h6, kActRelu);
-      conv("conv_cls.8", h6, 32, nullptr, 0, 0, B, H1, W1, nullptr, kActNone, d_heat);
-    }
-    prof_break();
-  }
-
-  // ---- PARSeq
-  // split-operand linear on planes: in [M][3 K] -> out (planes [M][3 out_ld] or fp32 [M][out_ld]) and / or out_f32 (+ fp32 residual)
-  void sgemm(const Linear& L, const void* in_planes, int M, void* out, int out_ld, int act, int out_planes,
-             float* out_f32 = nullptr, int out_f32_ld = 0, const float* resid = nullptr, int resid_ld = 0, int np = 4, int resid_mod = 0, int out_full_cols = 0,
-             const char* kind = nullptr) {
-    if (!L.ws.p) throw std::runtime_error("split GEMM: the layer has no weight planes");
-    ConvParams p{};
-    p.out_full_cols = out_full_cols;
-    p.in0 = in_planes; p.C0 = L.k; p.B = 1; p.H = 1; p.W = M; p.ks = 1; p.dil = 1;
-    p.wgt = L.ws.p; p.bias = L.b.as<float>(); p.split = np; p.out_scale = L.inv_scale; p.out_planes = out_planes == 1 ? 3 : out_planes;   // (1 = triples)
-    p.out = out; p.out_ld = out_ld; p.out_f32 = out_f32; p.out_f32_ld = out_f32_ld; p.resid = resid; p.resid_ld = resid_ld; p.resid_mod = resid_mod;
-    p.Cout = L.cout; p.M = M; p.act = act;
-    p.skip = cur_skip; p.skip_n = cur_skip_n;
-    if (const char* e = gemm2_check(p)) throw std::runtime_error(e);
-    timed(kind ? kind : (np == 3 ? "split linear (pairs)" : "split linear (triples)"), 2.0 * M * L.cout * L.k, 2.0 * M * L.cout * L.k * np, [&] { launch_gemm2(p, 0, stream); });
-  }
-  // out = L(LayerNorm(x)) for the decoder's per-step rows: the skinny GEMM normalises its own activation rows (bf16, few rows);
-  // otherwise the LayerNorm kernel writes `scratch` and the plain GEMM follows
-  void ln_gemm(const float* x, const std::string& ln_name, float eps, void* scratch, const Linear& L, int M, void* out, int out_ld, int act,
-               float* out_f32 = nullptr, int out_f32_ld = 0) {
-    if (tn.ln_fuse && prec == kBF16 && L.k == 384 && M <= skinny_max_rows()) {
-      ConvParams p{};
-      p.ln_in = x; p.ln_ld = 384; p.ln_gamma = pqf.at(ln_name + ".weight").as<float>(); p.ln_beta = pqf.at(ln_name + ".bias").as<float>(); p.ln_eps = eps;
-      p.C0 = L.k; p.B = 1; p.H = 1; p.W = M; p.ks = 1; p.dil = 1;
-      p.wgt = L.w.p; p.bias = L.b.as<float>();
-      p.out = out; p.out_ld = out_ld; p.out_f32 = out_f32; p.out_f32_ld = out_f32_ld;
-      p.Cout = L.cout; p.M = M; p.act = act;
-      p.skip = cur_skip; p.skip_n = cur_skip_n;
-      igemm(p, 2.0 * M * L.cout * L.k);
-      return;
-    }
-    ln(x, ln_name, eps, scratch, M);
-    gemm(L, scratch, M, out, out_ld, act, out_f32, out_f32_ld);
-  }
-  void gemm(const Linear& L, const void* in, int M, void* out, int out_ld, int act, float* out_f32 = nullptr, int out_f32_ld = 0,
-            const float* resid = nullptr, int resid_ld = 0, int resid_mod = 0) {
-    ConvParams p{};
-    p.in0 = in; p.C0 = L.k; p.B = 1; p.H = 1; p.W = M; p.ks = 1; p.dil = 1;
-    p.wgt = L.w.p; p.bias = L.b.as<float>();
-    p.out = out; p.out_ld = out_ld; p.out_f32 = out_f32; p.out_f32_ld = out_f32_ld;
-    p.resid = resid; p.resid_ld = resid_ld; p.resid_mod = resid_mod;
-    p.Cout = L.cout; p.M = M; p.act = act;
-    p.skip = cur_skip; p.skip_n = cur_skip_n;
-    igemm(p, 2.0 * M * L.cout * L.k);
-  }
-  // AR early exit: while set, the decoder's per-step launches carry the batch's done counter (ConvParams::skip); only the skinny
-  // GEMM and the per-row attention kernels honour it, which are the ones the bf16 AR steps use
-  const int* cur_skip = nullptr; int cur_skip_n = 0;
-  DevBuf ar_done;
-  size_t kvcache_zeroed = 0;
-  void ln(const float* x, const std::string& name, float eps, void* out, int M) {
-    launch_layernorm(prec, x, 384, pqf.at(name + ".weight").as<float>(), pqf.at(name + ".bias").as<float>(), eps, out, 384, M, 384, stream, cur_skip, cur_skip_n);
-  }
-
-  // The decoder tail of the split-operand engines: the same layers as decoder_tail() below, handing each other f16 planes (split.h) instead of
-  // fp32 tensors + split passes - 13 launches per AR step instead of 20.  sa: planes [rows][3 * 384] (self-attention output).
-  void decoder_tail_split(const void* sa, int N, int R, const float* resid_pos, int resid_mod, float* tgt, void* pa, void* pb, void* p1536, float* q384,
-                          void* t384, const void* kvmem, float* logits_out, int logits_ld, const int* done_tok = nullptr, int done_col = 0) {
-    const int rows = N * R;
-    const std::string d = "decoder.layers.0.";
-    auto lnp = [&](const std::string& nm, void* out) {
-      launch_layernorm_planes(tgt, 384, pqf.at(nm + ".weight").as<float>(), pqf.at(nm + ".bias").as<float>(), 1e-5f, out, rows, stream, 3, cur_skip, cur_skip_n);
-    };
-    sgemm(pq.at("self_out"), sa, rows, nullptr, 0, kActNone, 0, tgt, 384, resid_pos, 384, 4, resid_mod);      // tgt = query + self_attn
-    lnp(d + "norm1", pa);
-    sgemm(pq.at("cross_q"), pa, rows, q384, 384, kActNone, 0);                                                   // fp32 queries for the attention kernel
-    launch_dec_cross_attn(kF32, q384, kvmem, pb, N, R, stream, cur_skip, cur_skip_n, done_tok, done_col, 3);    // planes out
-    sgemm(pq.at("cross_out"), pb, rows, nullptr, 0, kActNone, 0, tgt, 384, tgt, 384);                            // tgt += cross_attn
-    lnp(d + "norm2", pa);
-    sgemm(pq.at("ffn1"), pa, rows, p1536, 1536, kActGelu, 3);
-    sgemm(pq.at("ffn2"), p1536, rows, nullptr, 0, kActNone, 0, tgt, 384, tgt, 384);                              // tgt += ffn
-    ln_gemm(tgt, "decoder.norm", 1e-5f, t384, pq.at("head"), rows, nullptr, 0, kActNone, logits_out, logits_ld);
-  }
-
-  // decoder tail shared by the AR steps (R = 1) and the refinement pass (R = 26):
-  // sa T [rows][384] -> logits f32 (row stride logits_ld)
-  void decoder_tail(const void* sa, int N, int R, const float* resid_pos, int resid_mod, float* tgt, void* t384, void* t384b, void* t1536,
-                    const void* kvmem, float* logits_out, int logits_ld, const int* done_tok = nullptr, int done_col = 0) {
-    const int rows = N * R;
-    const std::string d = "decoder.layers.0.";
-    gemm(pq.at("self_out"), sa, rows, nullptr, 0, kActNone, tgt, 384, resid_pos, 384, resid_mod);      // tgt = query + self_attn
-    ln_gemm(tgt, d + "norm1", 1e-5f, t384, pq.at("cross_q"), rows, t384b, 384, kActNone);
-    launch_dec_cross_attn(prec, t384b, kvmem, t384, N, R, stream, cur_skip, cur_skip_n, done_tok, done_col);
-    // (the fused block kernel is one persistent workgroup per CU over 128-row panels: when the panels fill the last round of CUs badly -
-    // 1280 crops x 26 rows = 260 panels on 256 CUs: two rounds for 1.02 - the separate GEMMs are faster: 12.17 vs 12.27 ms per forward)
-    const int dec_panels = (rows + 127) / 128, dec_cus = device_cu_count(256), dec_rounds = (dec_panels + dec_cus - 1) / dec_cus;
-    const bool dec_fill = tn.dec_mlp_fused == 2 || dec_panels * 100 >= 65 * dec_rounds * dec_cus;
-    if (R > 1 && prec == kBF16 && gemm_config() >= 0 && tn.dec_mlp_fused && rows >= tn.dec_mlp_min_rows && dec_fill) {
-      // refinement pass (26 rows per crop): the block behind the cross-attention is an encoder block's second half with other weights —
-      // out projection + residual, norm2, linear1, GELU, linear2, residual, and the final norm as the "next LayerNorm" — one launch
-      MlpParams q{};
-      q.x = tgt; q.x_out = tgt; q.M = rows;
-      q.ln_g = pqf.at(d + "norm2.weight").as<float>(); q.ln_b = pqf.at(d + "norm2.bias").as<float>(); q.ln_eps = 1e-5f;
-      q.w1p = dec_ffn1_packed.as<bf16>(); q.b1 = pq.at("ffn1").b.as<float>();
-      q.w2p = dec_ffn2_packed.as<bf16>(); q.b2 = pq.at("ffn2").b.as<float>();
-      q.nln_g = pqf.at("decoder.norm.weight").as<float>(); q.nln_b = pqf.at("decoder.norm.bias").as<float>(); q.nln_eps = 1e-5f; q.nln_out = (bf16*)t384b;
-      q.att = (const bf16*)t384; q.wpp = dec_co_packed.as<bf16>(); q.bp = pq.at("cross_out").b.as<float>();
-      timed("mlp_fused (refinement block)", 2.0 * rows * 384 * 1536 * 2 + 2.0 * rows * 384 * 384, 2.0 * rows * 384 * 1536 * 2 + 2.0 * rows * 384 * 384, [&] { launch_mlp_fused(q, stream); });
-      gemm(pq.at("head"), t384b, rows, nullptr, 0, kActNone, logits_out, logits_ld);
-      return;
-    }
-    gemm(pq.at("cross_out"), t384, rows, nullptr, 0, kActNone, tgt, 384, tgt, 384, 0);                 // tgt += cross_attn
-    ln_gemm(tgt, d + "norm2", 1e-5f, t384, pq.at("ffn1"), rows, t1536, 1536, kActGelu);
-    gemm(pq.at("ffn2"), t1536, rows, nullptr, 0, kActNone, tgt, 384, tgt, 384, 0);                     // tgt += ffn
-    ln_gemm(tgt, "decoder.norm", 1e-5f, t384, pq.at("head"), rows, nullptr, 0, kActNone, logits_out, logits_ld);
-  }
-
-  // crops u8 [N][32][128][3] (device) -> logits f32 [N][26][95], ids i32 [N][26] (device); d_ar optional
-  void parseq_forward(const uint8_t* d_crops, int N, float* d_logits, float* d_ar, int* d_ids) {
-    if (N <= 0) return;
-    prof_stage = 1;
-    const int M = N * 128, E = 384;
-    const int patch_ld = pq.at("patch").k;   // 96, or 128 in bf16 mode (zero-padded)
-    void* patches = (pq_ws[0].ensure((size_t)M * patch_ld * es), pq_ws[0].p);
-    float* x = (float*)(pq_ws[1].ensure((size_t)M * E * 4), pq_ws[1].p);
-    void* t384 = (pq_ws[2].ensure((size_t)std::max(M, N * 26) * E * es), pq_ws[2].p);
-    void* tbig = (pq_ws[3].ensure((size_t)M * 1536 * es), pq_ws[3].p);
-    void* att = (pq_ws[4].ensure((size_t)std::max(M, N * 26) * E * es), pq_ws[4].p);
-    launch_patchify(prec, d_crops, patches, N, patch_ld, stream);
-    gemm(pq.at("patch"), patches, M, nullptr, 0, kActNone, x, E, pqf.at("encoder.pos_embed").as<float>(), E, 128);
-    const bool enc_split = prec == kSplit && tn.split_gemm && tn.split_planes;
-    if (enc_split) {
-      // split-operand engines: LayerNorm, GEMM epilogues and the attention kernel hand each other planes (split.h); only the residual
-      // stream x is fp32.  Crop groups keep the widest planes tensor (the MLP hidden: 1536 x 6 bytes per row) inside the 2 GiB window.
-      const int CHS = std::max(1, std::min(N, (int)((((size_t)1 << 31) - 1) / ((size_t)128 * 1536 * 6))));
-      void* lnp = (pq_ws[11].ensure((size_t)M * E * 6), pq_ws[11].p);                       // LayerNorm output planes (whole batch: the memory at the end)
-      void* bigp = (pq_ws[12].ensure((size_t)std::min(N, CHS) * 128 * 1536 * 6), pq_ws[12].p);   // qkv / MLP hidden planes
-      void* attp = (pq_ws[13].ensure((size_t)std::min(N, CHS) * 128 * E * 6), pq_ws[13].p);      // attention output planes
-      auto lnp_at = [&](int c0) { return (char*)lnp + (size_t)c0 * 128 * E * 6; };
-      const int lnpl = tn.enc_ln_pairs ? 2 : 3;        // planes of the LayerNorm outputs that feed qkv / fc1 (pairs: three MFMAs per product there)
-      for (int c0 = 0; c0 < N; c0 += CHS) {
-        const int nc = std::min(CHS, N - c0), Mc = nc * 128;
-        float* xc = x + (size_t)c0 * 128 * E;
-        for (int l = 0; l < 12; ++l) {
-          const std::string p = "encoder.blocks." + std::to_string(l) + ".";
-          launch_layernorm_planes(xc, E, pqf.at(p + "norm1.weight").as<float>(), pqf.at(p + "norm1.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream, lnpl);
-          if (tn.qkv_attn_split && lnpl == 2) {   // one launch: the attention of a (crop, head) is the epilogue of its 128 x 192 qkv tile
-            const Linear& L = pq.at(p + "qkv_hm");
-            // executed flops: qkv on pairs (x 3), Q K^T and P V on a triple and a pair (x 4)
-            const double qa = 2.0 * Mc * 3 * E * E, aa = 2.0 * 2 * nc * 6 * 128.0 * 128 * 64;
-            timed("enc.qkv+attention: gemm_sp_kernel<128,192,NP=3,EPI=1>", qa + aa, qa * 3 + aa * 4,
-                  [&] { launch_qkv_attn_split(lnp_at(c0), L.ws.p, L.b.as<float>(), L.inv_scale, attp, nc, stream); });
-          } else {
-          sgemm(pq.at(p + "qkv"), lnp_at(c0), Mc, bigp, 3 * E, kActNone, 1, nullptr, 0, nullptr, 0, lnpl + 1, 0, tn.qkv_kv_pairs ? E : 0, "enc.qkv");   // (K, V: read as pairs)
-          launch_attn_enc_split(bigp, attp, nc, stream);
-          }
-          sgemm(pq.at(p + "proj"), attp, Mc, nullptr, 0, kActNone, 0, xc, E, xc, E, 4, 0, 0, "enc.proj");
-          launch_layernorm_planes(xc, E, pqf.at(p + "norm2.weight").as<float>(), pqf.at(p + "norm2.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream, lnpl);
-          const int hpl = tn.enc_fc2_pairs ? 2 : 3;                                      // planes of the MLP's hidden activation
-          sgemm(pq.at(p + "fc1"), lnp_at(c0), Mc, bigp, 4 * E, kActGelu, hpl, nullptr, 0, nullptr, 0, lnpl + 1, 0, 0, "enc.fc1 + GELU");
-          sgemm(pq.at(p + "fc2"), bigp, Mc, nullptr, 0, kActNone, 0, xc, E, xc, E, hpl + 1, 0, 0, "enc.fc2");
-        }
-        launch_layernorm_planes(xc, E, pqf.at("encoder.norm.weight").as<float>(), pqf.at("encoder.norm.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream);
-      }
-    }
-    // The 12 encoder blocks run over groups of crops so that a group's widest intermediates (qkv, the MLP hidden) are
-    // re-read from the 256 MiB Infinity Cache rather than from HBM (tn.enc_chunk crops per group; 0 = one group).
-    // the fused MLP block needs a panel of 128 rows per CU to fill the chip: below ~2 panels per CU the separate GEMMs win
-    const bool mlp_fused = prec == kBF16 && gemm_config() >= 0 && (tn.mlp_fused == 2 || (tn.mlp_fused == 1 && M >= tn.mlp_min_rows));
-    const int CH = (tn.enc_chunk > 0 && !mlp_fused) ? tn.enc_chunk : N;
-    for (int c0 = 0; c0 < N && !enc_split; c0 += CH) {
-      const int nc = std::min(CH, N - c0), Mc = nc * 128;
-      float* xc = x + (size_t)c0 * 128 * E;
-      if (mlp_fused) ln(xc, "encoder.blocks.0.norm1", 1e-6f, t384, Mc);
-      for (int l = 0; l < 12; ++l) {
-        std::string p = "encoder.blocks." + std::to_string(l) + ".";
-        if (!mlp_fused) ln(xc, p + "norm1", 1e-6f, t384, Mc);
-        if (prec == kBF16 && gemm_config() >= 0 && (tn.qkv_attn == 2 || (tn.qkv_attn == 1 && nc >= tn.qkv_attn_min)) && (size_t)Mc * E * 2 < ((size_t)1 << 31)) {   // (32-bit buffer offsets)
-          const Linear& L = pq.at(p + "qkv");
-          timed("qkv_attn_kernel", 2.0 * Mc * E * 3 * E, 2.0 * Mc * E * 3 * E, [&] { launch_qkv_attn((const bf16*)t384, L.w.as<bf16>(), L.b.as<float>(), (bf16*)att, nc, stream); });
-        } else {
-          gemm(pq.at(p + "qkv"), t384, Mc, tbig, 3 * E, kActNone);
-          launch_attn_enc(prec, tbig, att, nc, stream);
-        }
-        const bool proj_in = mlp_fused && tn.mlp_proj && !tn.mlp_pair;   // the projection runs inside the fused block kernel
-        if (!proj_in) gemm(pq.at(p + "proj"), att, Mc, nullptr, 0, kActNone, xc, E, xc, E, 0);
-        if (mlp_fused) {
-          // norm2 + fc1 + GELU + fc2 + residual in one kernel; it also leaves the next LayerNorm (the next block's norm1, or
-          // the encoder's final norm = the decoder's memory) in t384
-          const std::string nx = l < 11 ? "encoder.blocks." + std::to_string(l + 1) + ".norm1" : std::string("encoder.norm");
-          MlpParams q{};
-          q.x = xc; q.x_out = xc; q.M = Mc;
-          q.ln_g = pqf.at(p + "norm2.weight").as<float>(); q.ln_b = pqf.at(p + "norm2.bias").as<float>(); q.ln_eps = 1e-6f;
-          q.w1p = fc1_packed[l].as<bf16>(); q.b1 = pq.at(p + "fc1").b.as<float>();
-          q.w2p = fc2_packed[l].as<bf16>(); q.b2 = pq.at(p + "fc2").b.as<float>();
-          q.nln_g = pqf.at(nx + ".weight").as<float>(); q.nln_b = pqf.at(nx + ".bias").as<float>(); q.nln_eps = 1e-6f; q.nln_out = (bf16*)t384;
-          if (proj_in) { q.att = (const bf16*)att; q.wpp = proj_packed[l].as<bf16>(); q.bp = pq.at(p + "proj").b.as<float>(); }
-          q.no_x_store = l == 11 && !tn.mlp_pair;   // behind the last block only the final norm (the decoder's memory) is read
-          const double mf = 2.0 * Mc * E * 4 * E * 2 + (proj_in ? 2.0 * Mc * E * E : 0.0);
-          timed("mlp_fused_kernel", mf, mf, [&] { launch_mlp_fused(q, stream); });
-          continue;
-        }
-        ln(xc, p + "norm2", 1e-6f, t384, Mc);
-        gemm(pq.at(p + "fc1"), t384, Mc, tbig, 4 * E, kActGelu);
-        gemm(pq.at(p + "fc2"), tbig, Mc, nullptr, 0, kActNone, xc, E, xc, E, 0);
-      }
-    }
-    if (!mlp_fused && !enc_split) ln(x, "encoder.norm", 1e-6f, t384, M);       // memory
-    void* kvmem = (pq_ws[5].ensure((size_t)M * 768 * es), pq_ws[5].p);
-    if (enc_split) {
-      const int rows_max = (int)((((size_t)1 << 31) - 1) / ((size_t)E * 6));
-      for (int r0 = 0; r0 < M; r0 += rows_max) {
-        const int rr = std::min(rows_max, M - r0);
-        sgemm(pq.at("cross_kv"), (char*)pq_ws[11].p + (size_t)r0 * E * 6, rr, (char*)kvmem + (size_t)r0 * 768 * 4, 768, kActNone, 0);
-      }
-    } else
-    gemm(pq.at("cross_kv"), t384, M, kvmem, 768, kActNone);
-
-    // ---- decoder
-    void* kvcache = (pq_ws[6].ensure((size_t)N * 26 * 768 * es), pq_ws[6].p);
-    if (kvcache_zeroed != pq_ws[6].cap) {   // slots behind an early exit keep older (finite) rows; they are masked, but 0 x NaN is not 0
-      TTR_HIP_CHECK(hipMemsetAsync(kvcache, 0, pq_ws[6].cap, stream));
-      kvcache_zeroed = pq_ws[6].cap;
-    }
-    float* tgt = (float*)(pq_ws[7].ensure((size_t)N * 26 * E * 4), pq_ws[7].p);
-    void* d384b = (pq_ws[8].ensure((size_t)N * 26 * E * es), pq_ws[8].p);
-    void* d1536 = (pq_ws[9].ensure((size_t)N * 26 * 1536 * es), pq_ws[9].p);
-    float* step_logits = (float*)(pq_ws[10].ensure((size_t)N * 26 * 95 * 4), pq_ws[10].p);
-    // split-operand engines: the decoder's layers hand each other planes (decoder_tail_split)
-    const bool dec_split = prec == kSplit && tn.split_gemm && tn.split_planes && tn.dec_planes;
-    void *dpa = nullptr, *dpb = nullptr, *dp1536 = nullptr, *dsa = nullptr;
-    if (dec_split) {
-      dpa = (pq_ws[14].ensure((size_t)N * 26 * E * 6), pq_ws[14].p); dpb = (pq_ws[15].ensure((size_t)N * 26 * E * 6), pq_ws[15].p);
-      dp1536 = (pq_ws[16].ensure((size_t)N * 26 * 1536 * 6), pq_ws[16].p); dsa = (pq_ws[17].ensure((size_t)N * 26 * E * 6), pq_ws[17].p);
-    }
-    tokens.ensure((size_t)N * 26 * 4);
-    int* tk = tokens.as<int>();
-    launch_fill_i32(tk, 96, N * 26, 1, stream);   // PAD
-    launch_fill_i32(tk, 95, N, 26, stream);       // BOS at position 0
-    const float* emb = pqf.at("text_embed.embedding.weight").as<float>();
-    const float* posq = pqf.at("pos_queries").as<float>();
-    const std::string d = "decoder.layers.0.";
-    const float* gc = pqf.at(d + "norm_c.weight").as<float>();
-    const float* bc = pqf.at(d + "norm_c.bias").as<float>();
-    float* ar = d_ar ? d_ar : step_logits;
-    const int nsteps = d_ar ? 26 : 25;  // the 26th AR step only feeds logits the refinement pass discards
-    // Fused persistent AR kernel (dec_fused.hip): ~150 us per step whatever N is (every workgroup is bound by its own
-    // ~12 B/clk fetch rate on the weight and K/V streams).  With the skinny per-step GEMMs (gemm_sk.hip) the kernel-per-op
-    // loop is faster up to ~1200 crops (measured at 40 / 320 / 614 crops), so the fused kernel is only picked beyond that.
-    const bool fused_ar = prec == kBF16 && tn.decoder_mode != 0 && (tn.decoder_mode == 4 || tn.decoder_mode == 8 || tn.decoder_mode == 16 || N > 2048);
-    auto dec_params = [&]() {
-      DecArParams q{};
-      auto W = [&](const char* k) { return pq.at(k).w.as<bf16>(); };
-      auto Bv = [&](const char* k) { return pq.at(k).b.as<float>(); };
-      auto V = [&](const std::string& k) { return pqf.at(k).as<float>(); };
-      q.w_selfkv = W("self_kv"); q.w_selfout = W("self_out"); q.w_crossq = W("cross_q"); q.w_crossout = W("cross_out");
-      q.w_ffn1 = W("ffn1"); q.w_ffn2 = W("ffn2"); q.w_head = W("head");
-      q.b_selfkv = Bv("self_kv"); q.b_selfout = Bv("self_out"); q.b_crossq = Bv("cross_q"); q.b_crossout = Bv("cross_out");
-      q.b_ffn1 = Bv("ffn1"); q.b_ffn2 = Bv("ffn2"); q.b_head = Bv("head");
-      q.emb = emb; q.posq = posq; q.qself = qself.as<float>();
-      q.g_c = gc; q.b_c = bc;
-      q.g_1 = V(d + "norm1.weight"); q.b_1 = V(d + "norm1.bias"); q.g_2 = V(d + "norm2.weight"); q.b_2 = V(d + "norm2.bias");
-      q.g_f = V("decoder.norm.weight"); q.b_f = V("decoder.norm.bias");
-      q.kvmem = (const bf16*)kvmem; q.kvcache = (bf16*)kvcache; q.tokens = tk; q.ar_logits = d_ar;
-      q.gelu_lut = gelu_lut_for_current_device();
-      q.dbg = g_dec_dbg;
-      q.N = N; q.nsteps = nsteps;
-      return q;
-    };
-    if (fused_ar) {
-      DecArParams q = dec_params();
-      int G = tn.decoder_mode;
-      if (G != 4 && G != 8 && G != 16) G = N <= 1024 ? 4 : 8;
-      launch_dec_ar(q, G, stream);
-    } else {
-    prof_stage = 2;
-    const bool tok_fuse = tn.tok_fuse && tn.ln_fuse && prec == kBF16 && N <= skinny_max_rows();
-    // upstream PARSeq leaves its AR loop once every crop of the batch has emitted EOS (system.py): the bf16 engine counts them in the skinny
-    // GEMM's token prologue, the fp32 / f16x4 engines in the argmax kernel; every kernel of a step returns at once when the counter has
-    // reached N, and (ar_crop_exit) the attention kernels skip crops that are done - keys behind a crop's EOS are masked in the
-    // refinement pass, so the refined logits do not depend on it (tests)
-    const bool early = tn.ar_early_exit && (tok_fuse || prec != kBF16);
-    if (early) {
-      ar_done.ensure(64);
-      TTR_HIP_CHECK(hipMemsetAsync(ar_done.p, 0, 4, stream));
-      if (d_ar) TTR_HIP_CHECK(hipMemsetAsync(d_ar, 0, (size_t)N * 26 * 95 * 4, stream));   // steps behind the exit stay zero
-      cur_skip = ar_done.as<int>(); cur_skip_n = N;
-    }
-    // with the early exit, the steps from ar_tail_step on are ONE launch of the fused kernel in its tail form: when every crop
-    // has emitted EOS by then (the usual case: words are short) it returns at once, instead of ~9 returning launches per step
-    const int tail_at = (early && prec == kBF16 && tn.ar_tail_step > 0 && tn.ar_tail_step < nsteps) ? tn.ar_tail_step : 26;
-    struct SkipGuard { Engine& E; ~SkipGuard() { E.cur_skip = nullptr; E.cur_skip_n = 0; } } skip_guard{*this};   // also when a launch throws mid-loop
-    for (int i = 0; i < 26; ++i) {
-      if (i == tail_at) {
-        DecArParams q = dec_params();
-        q.first_step = i; q.prev_logits = ar + (size_t)(i - 1) * 95; q.prev_ld = 26 * 95; q.skip = cur_skip; q.skip_n = cur_skip_n;
-        if (!d_ar) q.ar_logits = nullptr;
-        launch_dec_ar(q, N <= 1024 ? 4 : 8, stream);
-        break;
-      }
-      if (tok_fuse) {   // token of step i = argmax of step i-1's logits, embedded and normalised in the GEMM's loader
-        const Linear& L = pq.at("self_kv");
-        ConvParams p{};
-        p.ln_in = emb; p.ln_ld = 384; p.ln_gamma = gc; p.ln_beta = bc; p.ln_eps = 1e-5f;
-        p.tok = tk; p.tok_ld = 26; p.tok_col = i; p.tok_emb = emb; p.tok_max = 96;
-        if (i > 0) { p.tok_logits = ar + (size_t)(i - 1) * 95; p.tok_logits_ld = 26 * 95; p.tok_C = 95; p.tok_pos = posq + (size_t)(i - 1) * E; }
-        if (early) { p.skip = cur_skip; p.skip_n = cur_skip_n; p.done_count = ar_done.as<int>(); p.tok_eos = 0; }
-        p.C0 = L.k; p.B = 1; p.H = 1; p.W = N; p.ks = 1; p.dil = 1;
-        p.wgt = L.w.p; p.bias = L.b.as<float>();
-        p.out = (char*)kvcache + (size_t)i * 768 * es; p.out_ld = 26 * 768;
-        p.Cout = L.cout; p.M = N; p.act = kActNone;
-        igemm(p, 2.0 * N * L.cout * L.k);
-      } else if (dec_split) {
-        launch_dec_embed_ln(prec, tk, emb, posq, gc, bc, 1e-5f, dpa, N, i, i + 1, stream, cur_skip, cur_skip_n, 3);
-        sgemm(pq.at("self_kv"), dpa, N, (char*)kvcache + (size_t)i * 768 * 4, 26 * 768, kActNone, 0);
-      } else {
-        launch_dec_embed_ln(prec, tk, emb, posq, gc, bc, 1e-5f, t384, N, i, i + 1, stream, cur_skip, cur_skip_n);
-        gemm(pq.at("self_kv"), t384, N, (char*)kvcache + (size_t)i * 768 * es, 26 * 768, kActNone);
-      }
-      if (i >= nsteps) break;
-      const int* crop_done = early && tn.ar_early_exit >= 1 && tn.ar_crop_exit ? tk : nullptr;
-      if (dec_split) {
-        launch_dec_self_attn(prec, qself.as<float>(), kvcache, tk, dsa, N, 1, i, 0, stream, cur_skip, cur_skip_n, 3);
-        decoder_tail_split(dsa, N, 1, posq + (size_t)i * E, 1, tgt, dpa, dpb, dp1536, (float*)d384b, t384, kvmem, ar + (size_t)i * 95, 26 * 95, crop_done, i);
-      } else {
-      launch_dec_self_attn(prec, qself.as<float>(), kvcache, tk, att, N, 1, i, 0, stream, cur_skip, cur_skip_n);
-      decoder_tail(att, N, 1, posq + (size_t)i * E, 1, tgt, t384, d384b, d1536, kvmem, ar + (size_t)i * 95, 26 * 95, crop_done, i);
-      }
-      if (i + 1 < 26 && !tok_fuse) launch_argmax(ar + (size_t)i * 95, 26 * 95, 95, tk, 26, i + 1, N, stream, cur_skip, cur_skip_n, early ? ar_done.as<int>() : nullptr, 0);
-    }
-    cur_skip = nullptr; cur_skip_n = 0;
-    prof_stage = 1;
-    }
-    // ---- refinement pass (cloze mask + EOS key padding), R = 26 query rows per crop
-    if (dec_split) {
-      launch_dec_self_attn(prec, qself.as<float>(), kvcache, tk, dsa, N, 26, 0, 1, stream, nullptr, 0, 3);
-      decoder_tail_split(dsa, N, 26, posq, 26, tgt, dpa, dpb, dp1536, (float*)d384b, t384, kvmem, d_logits, 95);
-    } else {
-    launch_dec_self_attn(prec, qself.as<float>(), kvcache, tk, att, N, 26, 0, 1, stream);
-    decoder_tail(att, N, 26, posq, 26, tgt, t384, d384b, d1536, kvmem, d_logits, 95);
-    }
-    launch_argmax(d_logits, 95, 95, d_ids, 1, 0, N * 26, stream);
-  }
-
-  // ---- post-processing of one page's heat map: GPU CCL + host calipers
-  struct PageBoxes { std::vector<RRect> det; };
-
-  // CCL kernels of pages [p0, p0 + pages) of a batch of `total` pages, then their component counters -> host; group `g`'s event
-  // fires when the counters have landed
-  void ccl_launch(const float* d_heat, int p0, int pages, int total, int g, int H2, int W2) {
-    if (p0 == 0) { ccl.ensure(total, H2 * W2, cfg.max_components); h_counters.ensure((size_t)total * 8); }
-    launch_ccl(d_heat, pages, H2, W2, cfg.text_threshold, cfg.link_threshold, cfg.low_text, cfg.min_area, ccl.view(p0), stream);
-    TTR_HIP_CHECK(hipMemcpyAsync(h_counters.as<int>() + 2 * p0, ccl.counters.as<int>() + 2 * p0, (size_t)pages * 8, hipMemcpyDeviceToHost, stream));
-    while ((int)group_ev.size() <= g) { hipEvent_t e; TTR_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); group_ev.push_back(e); }
-    TTR_HIP_CHECK(hipEventRecord(group_ev[g], stream));
-  }
-  // boxes of pages [p0, p0 + pages): waits for the group's counters, pulls candidates + row extremes over on the copy stream
-  // (the main stream may already be running the next group's CRAFT), then the host calipers
-  void ccl_collect(int p0, int pages, int g, int H2, int W2, std::vector<std::vector<RRect>>& det) {
-    const int* counters = h_counters.as<int>() + 2 * p0;
-    const double tc0 = now_us();
-    spin_event(group_ev[g]);
-    const double tc1 = now_us();
-    // two strided copies bring every page's candidates and row extremes over (width = the busiest page's share)
-    int max_c = 0, max_r = 0;
-    for (int pg = 0; pg < pages; ++pg) {
-      if (counters[2 * pg] > cfg.max_components) throw std::runtime_error("too many text components on a page; raise ttr_config.max_components");
-      max_c = std::max(max_c, counters[2 * pg]); max_r = std::max(max_r, counters[2 * pg + 1]);
-    }
-    const size_t pitch_c = (size_t)max_c * 32, pitch_r = (size_t)max_r * 8;
-    std::vector<size_t> off_c(pages), off_r(pages);
-    for (int pg = 0; pg < pages; ++pg) { off_c[pg] = pg * (pitch_c / 4); off_r[pg] = pg * (pitch_r / 4); }
-    h_cand.ensure(pitch_c * pages + 4); h_rows.ensure(pitch_r * pages + 4);
-    int* cand = h_cand.as<int>();
-    int* rw = h_rows.as<int>();
-    if (max_c > 0) {
-      const CclBuffers v = ccl.view(p0);
-      TTR_HIP_CHECK(hipMemcpy2DAsync(cand, pitch_c, v.cand, (size_t)ccl.max_cand * 32, pitch_c, pages, hipMemcpyDeviceToHost, copy_stream));
-      TTR_HIP_CHECK(hipMemcpy2DAsync(rw, pitch_r, v.rows_packed, (size_t)ccl.npx * 8, pitch_r, pages, hipMemcpyDeviceToHost, copy_stream));
-      TTR_HIP_CHECK(hipEventRecord(copy_ev, copy_stream));
-      spin_event(copy_ev);
-    }
-    const double tc2 = now_us();
-    // the calipers of a page depend on nothing but that page: a few host threads share the group
-    parallel_pages(pages, [&](int pg) {
-      const int n = counters[2 * pg];
-      const int* cd = cand + off_c[pg];
-      std::vector<int> order(n);
-      for (int i = 0; i < n; ++i) order[i] = i;
-      std::sort(order.begin(), order.end(), [&](int a, int b) { return cd[8 * a] < cd[8 * b]; });  // label order = ascending root
-      for (int i : order) {
-        const int* c = &cd[8 * i];
-        Component comp{c[0], c[1], c[2], c[3], c[4], c[5], rw + off_r[pg] + 2 * (size_t)c[6]};
-        RRect r;
-        if (component_to_rect(comp, H2, W2, &r)) det[p0 + pg].push_back(r);
-      }
-    });
-    host_us[1] += (float)(tc1 - tc0); host_us[2] += (float)(tc2 - tc1); host_us[3] += (float)(now_us() - tc2);
-  }
-  // run f(page) for every page on the engine's host threads
-  void parallel_pages(int pages, const std::function<void(int)>& f) { host_pool->run(pages, f); }
-
-  // ---- the hot path over a batch of same-sized device pages, in four phases so that several batches can be in flight:
-  //   detect_enqueue   resize + CRAFT + CCL kernels of a batch on the stream
-  //   detect_collect   host: wait for each CRAFT group's components, calipers -> boxes -> crop rectangles
-  //   recog_enqueue    crop rectangles -> packer -> PARSeq -> token ids back (stream)
-  //   finish           wait, decode the ids per page
-  // run_pages runs them in that order for one batch.  stream_push(j) runs detect_enqueue(j), recog_enqueue(j-1), detect_collect(j),
-  // finish(j-2): the stream holds C(j) P(j-1) behind whatever is running, so the GPU works through the previous batch's recogniser
-  // while the host turns batch j's components into boxes, and still has a whole recogniser queued while the host decodes batch j-2,
-  // returns to the caller and comes back with batch j+1 — no GPU idle at any hand-over; one stream, every kernel still runs alone.
-  // Host staging (crop rectangles, token ids) and the completion events exist twice (slot = batch parity).
-  struct PageBatch {
-    const uint8_t* d_pages = nullptr; int n = 0, h = 0, w = 0;
-    CanvasGeom g{}; int H = 0, W = 0, H2 = 0, W2 = 0; size_t page_bytes = 0;
-    std::vector<std::vector<RRect>> boxes;
-    std::vector<int> rects, page_of;
-    int N = 0, slot = 0, group = 16;
-    bool live = false, enqueued = false;
-    std::vector<int32_t> all_counts;   // with a communicator: crops per page of every rank [world][n]
-    int cap = 0;                       // ... and the largest rank total (rows of the gathered payload per rank)
+void Engine::load_parseq(const std::string& dir) {
+  WeightFile wf(dir + "/parseq.ttrw");
+  auto lin = [&](const std::string& key, const std::string& wname, const std::string& bname, int cout, int k, int row0 = 0, int rows_total = -1) {
+    if (rows_total < 0) rows_total = cout;
+    const auto& w = wf.get(wname, (size_t)rows_total * k);
+    const auto& b = wf.get(bname, (size_t)rows_total);
+    upload_linear(pq[key], w.data.data() + (size_t)row0 * k, cout, k, b.data.data() + row0, cout, k);
   };
-  PageBatch q1, q2;        // streamed batches: q1 = boxes known (recogniser enqueued or not), q2 = older, recogniser enqueued, results not yet returned
-
-  void detect_enqueue(PageBatch& B) {
-    if (B.h <= 0 || B.w <= 0) throw std::runtime_error("Error reading image from file");  // image.empty(), tuatara.cpp:344
-    B.g = canvas_geometry(B.h, B.w, cfg.canvas_size, cfg.mag_ratio);
-    if (B.g.target_h <= 0 || B.g.target_w <= 0) throw std::runtime_error("image too thin to resize");
-    B.H = B.g.h32; B.W = B.g.w32; B.H2 = B.H / 2; B.W2 = B.W / 2;
-    B.page_bytes = (size_t)B.h * B.w * 3;
-    const int n = B.n, H = B.H, W = B.W, H2 = B.H2, W2 = B.W2;
-    canvas.ensure((size_t)n * H * W * 3);
-    heat.ensure((size_t)n * H2 * W2 * 2 * 4);
-    TTR_HIP_CHECK(hipEventRecord(ev[0], stream));
-    launch_resize_pad_u8(B.d_pages, B.h, B.w, B.w * 3, canvas.as<uint8_t>(), B.g.target_h, B.g.target_w, H, W, 1, stream, n, B.page_bytes);
-    // CRAFT in groups of <= 16 pages: bounds the activation workspace (~0.5 GB/page) and keeps every tensor
-    // inside the 2 GiB window gemm2's 32-bit buffer offsets address.  Each group's CCL follows its CRAFT, so the host reads
-    // group g's components back (and runs its calipers) while the GPU is busy with group g + 1.
-    int GP = tn.craft_group;
-    if (prec == kSplit) {   // three f16 planes per value: the widest tensor (64 channels at full resolution) must stay inside the 2 GiB window
-      const size_t per_page = (size_t)H * W * 64 * (tn.craft_products == 4 ? 6 : 4);
-      GP = (int)std::max<size_t>(1, std::min<size_t>(GP, (((size_t)1 << 31) - 1) / per_page));
-      if (GP >= 8 && n % 8 == 0 && tn.craft_group >= 8) GP = 8;   // (even groups: 32 pages = 4 x 8 rather than 10 + 10 + 10 + 2)
-    }
-    B.group = GP;
-    const int groups = (n + GP - 1) / GP;
-    for (int gi = 0; gi < groups; ++gi) {
-      const int p0 = gi * GP, cnt = std::min(GP, n - p0);
-      craft_forward(canvas.as<uint8_t>() + (size_t)p0 * H * W * 3, cnt, H, W, heat.as<float>() + (size_t)p0 * H2 * W2 * 2);
-      if (gi == groups - 1) TTR_HIP_CHECK(hipEventRecord(ev[1], stream));
-      ccl_launch(heat.as<float>() + (size_t)p0 * H2 * W2 * 2, p0, cnt, n, gi, H2, W2);
-    }
-    TTR_HIP_CHECK(hipEventRecord(ev[2], stream));
+  auto vec = [&](const std::string& name, size_t n) { upload_f32(pqf[name], wf.get(name, n).data.data(), n); };
+  const int E = 384;
+  {   // patch embedding: K = 96 (4 x 8 x 3); the bf16 engine pads it to 128 so that the linear runs on gemm2 (K % 64) instead of the
+    // first-generation igemm (104 -> ~60 us at 1280 crops); the pad columns are zero in the patches and in the weights
+    const auto& w = wf.get("encoder.patch_embed.proj.weight", (size_t)E * 96);
+    const auto& b = wf.get("encoder.patch_embed.proj.bias", (size_t)E);
+    upload_linear(pq["patch"], w.data.data(), E, 96, b.data.data(), E, prec != kF32 ? 128 : 96);
   }
-
-  // With a communicator attached a batch is a collective: a {status, pages} header travels before anything whose size depends on the
-  // ranks' inputs, so that a rank that failed in its detector (`pre`: what detect_enqueue threw; or the box extraction below) or passed
-  // another page count makes the call fail on EVERY rank - instead of leaving the others inside a gather that never completes.
-  void detect_collect(PageBatch& B, std::exception_ptr pre = nullptr) {
-    if (!comm) { if (pre) std::rethrow_exception(pre); detect_collect_local(B); return; }
-    std::exception_ptr err = pre;
-    if (!err) { try { detect_collect_local(B); } catch (...) { err = std::current_exception(); } }
-    const int world = comm->world, n = B.n;
-    int32_t hdr[2] = {err ? -1 : 0, n};
-    std::vector<int32_t> all(2 * (size_t)world, 0);
-    allgather_host(hdr, 8, all.data());
-    if (err) std::rethrow_exception(err);
-    for (int r = 0; r < world; ++r) {
-      if (all[2 * r] < 0) throw std::runtime_error("multi-GPU batch: rank " + std::to_string(r) + " failed before the exchange; the batch is dropped on every rank");
-      if (all[2 * r + 1] != n) throw std::runtime_error("multi-GPU batch: rank " + std::to_string(r) + " passed " + std::to_string(all[2 * r + 1]) + " pages, this rank " + std::to_string(n) +
-                                                        ": every rank must push the same number of pages per batch");
+  vec("encoder.pos_embed", 128 * E);
+  for (int i = 0; i < 12; ++i) {
+    std::string p = "encoder.blocks." + std::to_string(i) + ".";
+    vec(p + "norm1.weight", E); vec(p + "norm1.bias", E); vec(p + "norm2.weight", E); vec(p + "norm2.bias", E);
+    lin(p + "qkv", p + "attn.qkv.weight", p + "attn.qkv.bias", 3 * E, E);
+    if (prec == kSplit) {   // the fused qkv + attention launch (gemm_sp.hip, attention epilogue) wants the rows tile by tile: head-major, see qkv_tile_row
+      const auto& w = wf.get(p + "attn.qkv.weight", (size_t)3 * E * E).data;
+      const auto& b = wf.get(p + "attn.qkv.bias", (size_t)3 * E).data;
+      std::vector<float> wp((size_t)3 * E * E), bp((size_t)3 * E);
+      for (int n = 0; n < 3 * E; ++n) {
+        const int src = qkv_tile_row(n);
+        memcpy(&wp[(size_t)n * E], &w[(size_t)src * E], sizeof(float) * E);
+        bp[n] = b[src];
+      }
+      upload_linear(pq[p + "qkv_hm"], wp.data(), 3 * E, E, bp.data(), 3 * E, E);
     }
-    // counts (host-side exchange on the control communicator), so that every rank knows the payload's size
-    std::vector<int32_t> mine(n, 0);
-    for (int pg : B.page_of) mine[pg]++;
-    B.all_counts.assign((size_t)world * n, 0);
-    allgather_host(mine.data(), (size_t)n * 4, B.all_counts.data());
-    B.cap = GatherLayout::from_counts(B.all_counts.data(), world, n).cap;
+    lin(p + "proj", p + "attn.proj.weight", p + "attn.proj.bias", E, E);
+    lin(p + "fc1", p + "mlp.fc1.weight", p + "mlp.fc1.bias", 4 * E, E);
+    lin(p + "fc2", p + "mlp.fc2.weight", p + "mlp.fc2.bias", E, 4 * E);
+    if (prec == kBF16) {   // mlp_fused.hip's operands as LDS images
+      std::vector<uint16_t> h((size_t)E * 4 * E);
+      pack_mlp_w1(wf.get(p + "mlp.fc1.weight", (size_t)4 * E * E).data.data(), h.data());
+      fc1_packed[i].ensure(h.size() * 2);
+      TTR_HIP_CHECK(hipMemcpy(fc1_packed[i].p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+      pack_mlp_w2(wf.get(p + "mlp.fc2.weight", (size_t)E * 4 * E).data.data(), 4 * E, h.data());
+      fc2_packed[i].ensure(h.size() * 2);
+      TTR_HIP_CHECK(hipMemcpy(fc2_packed[i].p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+      std::vector<uint16_t> hp((size_t)E * E);
+      pack_mlp_w2(wf.get(p + "attn.proj.weight", (size_t)E * E).data.data(), E, hp.data());
+      proj_packed[i].ensure(hp.size() * 2);
+      TTR_HIP_CHECK(hipMemcpy(proj_packed[i].p, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
+    }
   }
-  void detect_collect_local(PageBatch& B) {
-    const int n = B.n, GP = B.group, groups = (n + GP - 1) / GP;
-    const float ratio_w = 1.f / B.g.ratio, ratio_h = 1.f / B.g.ratio;   // tuatara.cpp:360-361
-    std::vector<std::vector<RRect>> dets(n);
-    B.boxes.assign(n, std::vector<RRect>());
-    B.rects.clear(); B.page_of.clear();        // x0,y0,x1,y1,page per crop; page index per crop
-    host_us[1] = host_us[2] = host_us[3] = 0.f;
-    for (int gi = 0; gi < groups; ++gi) ccl_collect(gi * GP, std::min(GP, n - gi * GP), gi, B.H2, B.W2, dets);
-    if (tn.detector_only) for (auto& d : dets) d.clear();   // profiling (tools/prof_pages.py): the detector and CCL run, nothing goes to the recogniser
-    if (tn.bench_grid_boxes) {   // benchmark workload control (tuning key "bench_grid_boxes", tuatara_hip_debug.h): the detector's work is done (and timed); 40 fixed boxes per page go on
-      for (int i = 0; i < n; ++i) {
-        dets[i].clear();
-        for (int r = 0; r < 8; ++r)
-          for (int c = 0; c < 5; ++c) {
-            RRect g;
-            g.cx = (c + 0.5f) * (float)B.W2 / 5.f; g.cy = (r + 0.5f) * (float)B.H2 / 8.f; g.w = 75.f * B.g.ratio; g.h = 20.f * B.g.ratio; g.angle = 0.f;
-            dets[i].push_back(g);
-          }
+  vec("encoder.norm.weight", E); vec("encoder.norm.bias", E);
+  const std::string d = "decoder.layers.0.";
+  lin("self_kv", d + "self_attn.in_proj_weight", d + "self_attn.in_proj_bias", 2 * E, E, E, 3 * E);
+  lin("self_out", d + "self_attn.out_proj.weight", d + "self_attn.out_proj.bias", E, E);
+  lin("cross_q", d + "cross_attn.in_proj_weight", d + "cross_attn.in_proj_bias", E, E, 0, 3 * E);
+  lin("cross_kv", d + "cross_attn.in_proj_weight", d + "cross_attn.in_proj_bias", 2 * E, E, E, 3 * E);
+  lin("cross_out", d + "cross_attn.out_proj.weight", d + "cross_attn.out_proj.bias", E, E);
+  lin("ffn1", d + "linear1.weight", d + "linear1.bias", 4 * E, E);
+  lin("ffn2", d + "linear2.weight", d + "linear2.bias", E, 4 * E);
+  if (prec == kBF16) {   // the refinement pass runs cross_out + norm2 + FFN + final norm through mlp_fused.hip
+    std::vector<uint16_t> h((size_t)E * 4 * E), hp((size_t)E * E);
+    pack_mlp_w1(wf.get(d + "linear1.weight", (size_t)4 * E * E).data.data(), h.data());
+    dec_ffn1_packed.ensure(h.size() * 2); TTR_HIP_CHECK(hipMemcpy(dec_ffn1_packed.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    pack_mlp_w2(wf.get(d + "linear2.weight", (size_t)E * 4 * E).data.data(), 4 * E, h.data());
+    dec_ffn2_packed.ensure(h.size() * 2); TTR_HIP_CHECK(hipMemcpy(dec_ffn2_packed.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    pack_mlp_w2(wf.get(d + "cross_attn.out_proj.weight", (size_t)E * E).data.data(), E, hp.data());
+    dec_co_packed.ensure(hp.size() * 2); TTR_HIP_CHECK(hipMemcpy(dec_co_packed.p, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
+  }
+  for (const char* n : {"norm1", "norm2", "norm_q", "norm_c"}) { vec(d + n + ".weight", E); vec(d + n + ".bias", E); }
+  vec("decoder.norm.weight", E); vec("decoder.norm.bias", E);
+  lin("head", "head.weight", "head.bias", 95, E);
+  vec("text_embed.embedding.weight", 97 * E);
+  vec("pos_queries", 26 * E);
+  // Qself[i] = Wq . norm_q(pos_queries[i]) + bq : crop independent, computed once on the host in fp32
+  {
+    const auto& pos = wf.get("pos_queries", 26 * E).data;
+    const auto& g = wf.get(d + "norm_q.weight", E).data;
+    const auto& bt = wf.get(d + "norm_q.bias", E).data;
+    const auto& w = wf.get(d + "self_attn.in_proj_weight", (size_t)3 * E * E).data;
+    const auto& b = wf.get(d + "self_attn.in_proj_bias", 3 * E).data;
+    std::vector<float> q((size_t)26 * E), ln(E);
+    for (int i = 0; i < 26; ++i) {
+      float mean = 0.f;
+      for (int c = 0; c < E; ++c) mean += pos[i * E + c];
+      mean /= E;
+      float var = 0.f;
+      for (int c = 0; c < E; ++c) { float dd = pos[i * E + c] - mean; var += dd * dd; }
+      var /= E;
+      float rstd = 1.0f / std::sqrt(var + 1e-5f);
+      for (int c = 0; c < E; ++c) ln[c] = (pos[i * E + c] - mean) * rstd * g[c] + bt[c];
+      for (int o = 0; o < E; ++o) {
+        float acc = 0.f;
+        for (int c = 0; c < E; ++c) acc += w[(size_t)o * E + c] * ln[c];
+        q[(size_t)i * E + o] = acc + b[o];
       }
     }
-    for (int i = 0; i < n; ++i) {
-      for (const RRect& r : dets[i]) {
-        RRect b = adjust_coordinates(r, ratio_w, ratio_h);            // :406
-        int xywh[4];
-        bounding_rect(b, xywh);                                       // :416
-        int x0 = xywh[0], y0 = xywh[1], x1 = xywh[0] + xywh[2], y1 = xywh[1] + xywh[3];
-        if (cfg.strict_crops) {
-          if (x0 < 0 || y0 < 0 || x1 > B.w || y1 > B.h) throw std::runtime_error("text box leaves the image (cv::Exception in the reference, tuatara.cpp:416)");
-        } else {
-          x0 = std::max(x0, 0); y0 = std::max(y0, 0); x1 = std::min(x1, B.w); y1 = std::min(y1, B.h);
-        }
-        if (x1 <= x0 || y1 <= y0) continue;
-        B.boxes[i].push_back(b);
-        B.rects.insert(B.rects.end(), {x0, y0, x1, y1, i});
-        B.page_of.push_back(i);
-      }
-    }
-    B.N = (int)B.page_of.size();
+    upload_f32(qself, q.data(), q.size());
   }
+}
 
-  void recog_enqueue(PageBatch& B) {
-    const int N = B.N, sl = B.slot;
-    h_ids[sl].ensure((size_t)N * 26 * 4 + 4);
-    TTR_HIP_CHECK(hipEventRecord(evr[sl][0], stream));
-    if (N > 0) {
-      rects_dev.ensure(B.rects.size() * 4);
-      h_rects[sl].ensure(B.rects.size() * 4);
-      memcpy(h_rects[sl].p, B.rects.data(), B.rects.size() * 4);
-      crops.ensure((size_t)N * 32 * 128 * 3);
-      logits.ensure((size_t)N * 26 * 95 * 4);
-      ids_dev.ensure((size_t)std::max(N, B.cap) * 26 * 4);
-      TTR_HIP_CHECK(hipMemcpyAsync(rects_dev.p, h_rects[sl].p, B.rects.size() * 4, hipMemcpyHostToDevice, stream));
-      launch_pack_crops(B.d_pages, B.page_bytes, B.w * 3, rects_dev.as<int>(), crops.as<uint8_t>(), N, stream);
-      TTR_HIP_CHECK(hipEventRecord(evr[sl][1], stream));
-      parseq_forward(crops.as<uint8_t>(), N, logits.as<float>(), nullptr, ids_dev.as<int>());
-      TTR_HIP_CHECK(hipEventRecord(evr[sl][2], stream));
-      TTR_HIP_CHECK(hipMemcpyAsync(h_ids[sl].as<int32_t>(), ids_dev.p, (size_t)N * 26 * 4, hipMemcpyDeviceToHost, stream));
-    } else {
-      TTR_HIP_CHECK(hipEventRecord(evr[sl][1], stream));
-      TTR_HIP_CHECK(hipEventRecord(evr[sl][2], stream));
-    }
-    if (comm && B.cap > 0) {   // the payload: cap rows of 26 ids per rank, straight from the recogniser's device buffer
-      const size_t per = (size_t)B.cap * 26;
-      ids_dev.ensure(per * 4);
-      gath_dev[sl].ensure(per * 4 * comm->world);
-      h_gath[sl].ensure(per * 4 * comm->world);
-      comm->tr->all_gather(ids_dev.p, gath_dev[sl].p, per * 4, false, stream);
-      TTR_HIP_CHECK(hipMemcpyAsync(h_gath[sl].p, gath_dev[sl].p, per * 4 * comm->world, hipMemcpyDeviceToHost, stream));
-    }
-    TTR_HIP_CHECK(hipEventRecord(done_ev[sl], stream));
-    B.enqueued = true;
+Engine::Engine(const std::string& dir, const ttr_config& c) : cfg(c) {
+  { const char* v = getenv("TUATARA_VERBOSE"); verbose = cfg.verbose != 0 || (v && *v && std::string(v) != "0"); }
+  prec = cfg.precision == TTR_PREC_F32 ? kF32 : cfg.precision == TTR_PREC_F16X4 ? kSplit : kBF16;
+  es = prec == kBF16 ? 2 : 4;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) throw std::runtime_error("no HIP device available: the tuatara engine has no CPU fallback");
+  TTR_HIP_CHECK(hipSetDevice(cfg.device));
+  TTR_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  TTR_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+  TTR_HIP_CHECK(hipEventCreateWithFlags(&copy_ev, hipEventDisableTiming));
+  for (auto& x : done_ev) TTR_HIP_CHECK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+  for (auto& sl : evr) for (auto& x : sl) TTR_HIP_CHECK(hipEventCreate(&x));
+  {   // host threads for the per-page calipers / decode: at most 15, and a fair share of the box when several ranks run on it
+    // (torch.distributed.run exports LOCAL_WORLD_SIZE); TUATARA_HOST_THREADS overrides
+    int hw = std::max(1, (int)std::thread::hardware_concurrency());
+    if (const char* lw = getenv("LOCAL_WORLD_SIZE")) { const int n = atoi(lw); if (n > 1) hw = std::max(1, hw / n); }
+    int workers = std::min(15, std::max(1, hw - 1));
+    if (const char* ht = getenv("TUATARA_HOST_THREADS")) { const int n = atoi(ht); if (n >= 1) workers = std::min(64, n); }
+    host_pool.reset(new HostPool(workers));
   }
+  for (auto& x : ev) TTR_HIP_CHECK(hipEventCreate(&x));
+  load_craft(dir);
+  load_parseq(dir);
+}
 
-  void finish(PageBatch& B, std::vector<Result>& results) {
-    const int n = B.n, N = B.N;
-    results.assign(n, Result());
-    const double th2 = now_us();
-    spin_event(done_ev[B.slot]);
-    const double th3 = now_us();
-    // stage times: detector events belong to the latest batch enqueued (complete by now: its components were collected), recogniser events to this one
-    (void)hipEventElapsedTime(&stage_ms[0], ev[0], ev[1]); (void)hipEventElapsedTime(&stage_ms[1], ev[1], ev[2]);
-    (void)hipEventElapsedTime(&stage_ms[2], evr[B.slot][0], evr[B.slot][1]); (void)hipEventElapsedTime(&stage_ms[3], evr[B.slot][1], evr[B.slot][2]);
-    if (profiling) prof_collect();
-    const double th4 = now_us();
-    if (comm) {   // compact the gathered payload: (rank, page, crop) order, no padding
-      const GatherLayout L = GatherLayout::from_counts(B.all_counts.data(), comm->world, n);
-      last_gathered.world = L.world; last_gathered.pages = n; last_gathered.counts = B.all_counts;
-      last_gathered.ids.resize((size_t)L.first.back() * 26);
-      const int32_t* g = h_gath[B.slot].as<int32_t>();
-      for (int r = 0; r < L.world; ++r)
-        if (L.total[r]) memcpy(&last_gathered.ids[(size_t)L.first[(size_t)r * n] * 26], g + (size_t)r * B.cap * 26, (size_t)L.total[r] * 26 * 4);
-    }
-    const int32_t* ids = h_ids[B.slot].as<int32_t>();
-    // crops are ordered by page: page pg owns crops [first[pg], first[pg + 1]); pages decode independently
-    std::vector<int> first(n + 1, 0);
-    for (int c = 0; c < N; ++c) first[B.page_of[c] + 1]++;
-    for (int pg = 0; pg < n; ++pg) first[pg + 1] += first[pg];
-    auto decode_page = [&](int pg) {
-      Result& r = results[pg];
-      const int c0 = first[pg], cnt = first[pg + 1] - c0;
-      r.text.reserve(cnt); r.bbox.reserve((size_t)cnt * 4);
-      r.ids.assign(&ids[(size_t)c0 * 26], &ids[(size_t)(c0 + cnt) * 26]);
-      for (int k = 0; k < cnt; ++k) {
-        r.text.push_back(tok.decode(&ids[(size_t)(c0 + k) * 26], 26));   // :486-505
-        float bb[4];
-        tesseract_bbox(B.boxes[pg][k], bb);                               // :511
-        r.bbox.insert(r.bbox.end(), bb, bb + 4);
-      }
-    };
-    if (N >= 256) parallel_pages(n, decode_page);
-    else for (int pg = 0; pg < n; ++pg) decode_page(pg);
-    host_us[5] = (float)(th3 - th2); host_us[6] = (float)(th4 - th3); host_us[7] = (float)(now_us() - th4);
-    B.live = false; B.enqueued = false;
-  }
+Engine::~Engine() {
+  (void)hipSetDevice(cfg.device);
+  for (auto& x : ev) if (x) (void)hipEventDestroy(x);
+  for (auto& x : prof_pool) (void)hipEventDestroy(x);
+  for (auto& x : group_ev) (void)hipEventDestroy(x);
+  if (copy_ev) (void)hipEventDestroy(copy_ev);
+  for (auto& x : done_ev) if (x) (void)hipEventDestroy(x);
+  for (auto& sl : evr) for (auto& x : sl) if (x) (void)hipEventDestroy(x);
+  if (copy_stream) (void)hipStreamDestroy(copy_stream);
+  if (stream) (void)hipStreamDestroy(stream);
+}
 
-  void run_pages(const uint8_t* d_pages, int n, int h, int w, std::vector<Result>& results) {
-    results.assign(n, Result());
-    if (n <= 0) return;
-    if (q1.live || q2.live) throw std::runtime_error("streamed batches are in flight: call ttr_stream_flush until it returns none");
-    const double th0 = now_us();
-    // the reference's progress lines (tuatara.cpp:328-329, :342, :421, :434: the models are loaded once per engine here, so those
-    // lines report a fact; :386, :488, :509), on request only: callers do not parse stdout
-    if (verbose) std::cout << ttr_version() << " (HIP " << HIP_VERSION_MAJOR << "." << HIP_VERSION_MINOR << ")\ncraft model loaded" << std::endl;
-    PageBatch B;
-    B.d_pages = d_pages; B.n = n; B.h = h; B.w = w; B.slot = 0;
-    std::exception_ptr pre;
-    { RangeScope r("ttr:detect_enqueue"); try { detect_enqueue(B); } catch (...) { if (!comm) throw; pre = std::current_exception(); } }
-    host_us[0] = (float)(now_us() - th0);
-    if (verbose) std::cout << "post processing craft predictions..." << std::endl;
-    { RangeScope r("ttr:detect_collect"); detect_collect(B, pre); }
-    const double th1 = now_us();
-    if (verbose) std::cout << "loading parseq model...\nparseq model loaded" << std::endl;
-    { RangeScope r("ttr:recog_enqueue"); recog_enqueue(B); }
-    host_us[4] = (float)(now_us() - th1);
-    if (verbose) std::cout << "Running tokenizer..." << std::endl;
-    { RangeScope r("ttr:finish"); finish(B, results); }
-    if (verbose) std::cout << "Elapsed time: " << (now_us() - th0) * 1e-6 << " seconds " << std::endl;
-  }
-
-  // Latency mode (the reference's 6-thread fan-out over chunks of the crop batch, tuatara.cpp:450-485, across
-  // GPUs): rank 0 detects and packs the crop batch, the batch is broadcast, rank r recognises the contiguous shard r of
-  // ceil(N / world) crops, the ids are all-gathered, rank 0 decodes and returns the pages' results (the other ranks pass no pages and
-  // return n empty results).  Collective over the engine's communicator.
-  void run_pages_sharded(const uint8_t* d_pages, int n, int h, int w, std::vector<Result>& results) {
-    if (!comm) throw std::runtime_error("latency mode needs a communicator (ttr_engine_attach_comm)");
-    if (q1.live || q2.live) throw std::runtime_error("streamed batches are in flight: call ttr_stream_flush until it returns none");
-    Comm* const c = comm;
-    const int world = c->world, rank = c->rank;
-    PageBatch B;
-    int32_t hdr[2] = {0, 0};                                     // {pages, crops} of rank 0
-    comm = nullptr;                                              // (the detector below is not the throughput mode's: no per-batch gather)
-    try {
-      if (rank == 0) {
-        if (!d_pages || n <= 0) throw std::runtime_error("latency mode: rank 0 passes the pages");
-        B.d_pages = d_pages; B.n = n; B.h = h; B.w = w; B.slot = 0;
-        detect_enqueue(B);
-        detect_collect(B);
-        hdr[0] = n; hdr[1] = B.N;
-      }
-    } catch (...) { comm = c; hdr[0] = -1; std::vector<int32_t> all(2 * world); allgather_host(hdr, 8, all.data()); throw; }
-    comm = c;
-    std::vector<int32_t> all(2 * (size_t)world);
-    allgather_host(hdr, 8, all.data());
-    if (all[0] < 0) throw std::runtime_error("latency mode: rank 0 failed in the detector");
-    const int pages = all[0], N = all[1];
-    results.assign(rank == 0 ? pages : std::max(n, 0), Result());
-    if (N == 0) return;
-    const int per = (N + world - 1) / world;
-    const int lo = std::min(N, rank * per), hi = std::min(N, lo + per);
-    crops.ensure((size_t)world * per * 32 * 128 * 3);           // (the last shard may be ragged: the buffer holds world * per crops)
-    if (rank == 0) {
-      rects_dev.ensure(B.rects.size() * 4);
-      h_rects[0].ensure(B.rects.size() * 4);
-      memcpy(h_rects[0].p, B.rects.data(), B.rects.size() * 4);
-      TTR_HIP_CHECK(hipMemcpyAsync(rects_dev.p, h_rects[0].p, B.rects.size() * 4, hipMemcpyHostToDevice, stream));
-      launch_pack_crops(B.d_pages, B.page_bytes, B.w * 3, rects_dev.as<int>(), crops.as<uint8_t>(), N, stream);
-    }
-    c->tr->broadcast(crops.p, (size_t)N * 32 * 128 * 3, 0, stream);
-    logits.ensure((size_t)per * 26 * 95 * 4);
-    ids_dev.ensure((size_t)per * 26 * 4);
-    if (hi > lo) parseq_forward(crops.as<uint8_t>() + (size_t)lo * 32 * 128 * 3, hi - lo, logits.as<float>(), nullptr, ids_dev.as<int>());
-    gath_dev[0].ensure((size_t)world * per * 26 * 4);
-    h_gath[0].ensure((size_t)world * per * 26 * 4);
-    c->tr->all_gather(ids_dev.p, gath_dev[0].p, (size_t)per * 26 * 4, false, stream);
-    TTR_HIP_CHECK(hipMemcpyAsync(h_gath[0].p, gath_dev[0].p, (size_t)world * per * 26 * 4, hipMemcpyDeviceToHost, stream));
-    TTR_HIP_CHECK(hipEventRecord(done_ev[0], stream));
-    spin_event(done_ev[0]);
-    if (rank != 0) return;
-    const int32_t* ids = h_gath[0].as<int32_t>();                // shard r occupies rows [r * per, r * per + its size): crop k = row k
-    std::vector<int> first(pages + 1, 0);
-    for (int k = 0; k < N; ++k) first[B.page_of[k] + 1]++;
-    for (int pg = 0; pg < pages; ++pg) first[pg + 1] += first[pg];
-    for (int pg = 0; pg < pages; ++pg) {
-      Result& r = results[pg];
-      const int c0 = first[pg], cnt = first[pg + 1] - c0;
-      r.ids.assign(&ids[(size_t)c0 * 26], &ids[(size_t)(c0 + cnt) * 26]);
-      for (int k = 0; k < cnt; ++k) {
-        r.text.push_back(tok.decode(&ids[(size_t)(c0 + k) * 26], 26));
-        float bb[4];
-        tesseract_bbox(B.boxes[pg][k], bb);
-        r.bbox.insert(r.bbox.end(), bb, bb + 4);
-      }
-    }
-  }
-
-  // Streamed form: returns the results of the batch pushed TWO calls earlier (prev_n = its page count, 0 for the first two pushes).
-  // The pages of a batch must stay valid until its results have been returned (the crop packer reads them one push later).
-  void stream_push(const uint8_t* d_pages, int n, int h, int w, std::vector<Result>& prev_results, int& prev_n) {
-    prev_results.clear(); prev_n = 0;
-    if (n <= 0) throw std::runtime_error("stream_push: empty batch");
-    const double th0 = now_us();
-    PageBatch B;
-    B.d_pages = d_pages; B.n = n; B.h = h; B.w = w;
-    B.slot = q1.live ? (q1.slot ^ 1) : 0;     // from the pipeline's state, not a counter: a push that throws leaves q1 / q2 and the slot parity as they were
-    std::exception_ptr pre;      // (with a communicator: a failing rank still takes part in this batch's header exchange, detect_collect)
-    { RangeScope r("ttr:detect_enqueue"); try { detect_enqueue(B); } catch (...) { if (!comm) throw; pre = std::current_exception(); } }
-    host_us[0] = (float)(now_us() - th0);
-    const double th1 = now_us();
-    if (q1.live && !q1.enqueued) { RangeScope r("ttr:recog_enqueue"); recog_enqueue(q1); }
-    host_us[4] = (float)(now_us() - th1);
-    { RangeScope r("ttr:detect_collect"); detect_collect(B, pre); }
-    if (q2.live) { RangeScope r("ttr:finish"); prev_n = q2.n; finish(q2, prev_results); }
-    if (q1.live) q2 = std::move(q1);
-    q1 = std::move(B);
-    q1.live = true; q1.enqueued = false;
-  }
-  // results of the oldest batch in flight (prev_n = 0: none left)
-  void stream_flush(std::vector<Result>& prev_results, int& prev_n) {
-    prev_results.clear(); prev_n = 0;
-    if (q1.live && !q1.enqueued) recog_enqueue(q1);
-    if (q2.live) { prev_n = q2.n; finish(q2, prev_results); return; }
-    if (q1.live) { prev_n = q1.n; finish(q1, prev_results); }
-  }
-};
+DevBuf& Engine::ws(size_t idx, size_t bytes, bool zero_new) {
+  while (craft_ws.size() <= idx) craft_ws.emplace_back(new DevBuf());
+  DevBuf& d = *craft_ws[idx];
+  const size_t cap_before = d.cap;          // (not the pointer: the allocator may hand the grown block the old address)
+  d.ensure(bytes);
+  if (zero_new && d.cap != cap_before) TTR_HIP_CHECK(hipMemsetAsync(d.p, 0, d.cap, stream));   // padding channels are written once, here
+  return d;
+}
 
 }  // namespace ttr
-
-// ====================================================================== C ABI
-using namespace ttr;
-
-struct ttr_engine { std::unique_ptr<Engine> e; };
-struct ttr_result { Result r; };
-
-// Every entry point: the engine's lock, and the engine's device made current for the calling thread (HIP's current device is per
-// thread: allocations, hipFuncSetAttribute and device queries inside the call must hit the device the stream belongs to).
-struct EngineScope {
-  std::lock_guard<std::mutex> lk;
-  explicit EngineScope(Engine& E) : lk(E.mu) { TTR_HIP_CHECK(hipSetDevice(E.cfg.device)); }
-};
-
-#define TTR_GUARD_BEGIN try {
-#define TTR_GUARD_END(rc)                                   \
-  }                                                         \
-  catch (const std::exception& ex) { g_last_error = ex.what(); return rc; } \
-  catch (...) { g_last_error = "unknown error"; return rc; }
-
-extern "C" {
-
-void ttr_config_default(ttr_config* c) {
-  c->precision = TTR_PREC_F16X4; c->device = 0; c->canvas_size = 1024; c->mag_ratio = 1.0f;
-  c->text_threshold = 0.7f; c->link_threshold = 0.4f; c->low_text = 0.4f; c->min_area = 10;
-  c->strict_crops = 0; c->max_components = 4096; c->verbose = 0;
-}
-
-const char* ttr_last_error(void) { return g_last_error.c_str(); }
-const char* ttr_version(void) { return "tuatara-mi355x 0.1 (gfx950)"; }
-
-ttr_engine* ttr_create(const char* weights_dir, const ttr_config* cfg) {
-  TTR_GUARD_BEGIN
-  if (!weights_dir || !*weights_dir) throw std::runtime_error("Please provide a value for weights_dir");  // tuatara.cpp:315-318
-  ttr_config c;
-  if (cfg) c = *cfg; else ttr_config_default(&c);
-  if (c.max_components <= 0) c.max_components = 4096;
-  std::unique_ptr<ttr_engine> h(new ttr_engine());
-  h->e.reset(new Engine(weights_dir, c));
-  return h.release();
-  TTR_GUARD_END(nullptr)
-}
-
-void ttr_destroy(ttr_engine* e) { delete e; }
-
-static void run_locked(ttr_engine* e, const uint8_t* d_pages, int n, int h, int w, ttr_result** out) {
-  std::vector<Result> res;
-  e->e->run_pages(d_pages, n, h, w, res);
-  for (int i = 0; i < n; ++i) { out[i] = new ttr_result(); out[i]->r = std::move(res[i]); }
-}
-
-int ttr_pages_to_data_dev(ttr_engine* e, const uint8_t* d_pages, int n, int h, int w, ttr_result** out) {
-  TTR_GUARD_BEGIN
-  if (!e || !out) throw std::runtime_error("null argument");
-  EngineScope lk(*e->e);
-  run_locked(e, d_pages, n, h, w, out);
-  return 0;
-  TTR_GUARD_END(-1)
-}
-
-struct ttr_comm { std::unique_ptr<Comm> c; };
-
-// rank 0 listens on addr:port and hands its bytes to the world - 1 peers that say hello (rendezvous:: above: each distinct rank once, strays turned away, timeouts)
-static void tcp_share(int rank, int world, const char* addr, int port, void* buf, size_t bytes) {
-  if (world <= 1) return;
-  const double dl = rendezvous::deadline_seconds();
-  if (rank == 0) {
-    std::vector<int> fds = rendezvous::serve(world, addr, port, dl);
-    bool ok = true;
-    for (int r = 1; r < world; ++r) { ok = ok && rendezvous::send_all(fds[r], buf, bytes); }
-    for (int r = 1; r < world; ++r) close(fds[r]);
-    if (!ok) rendezvous::fail("send");
-  } else {
-    const int fd = rendezvous::join(rank, world, addr, port, dl);
-    const bool ok = rendezvous::recv_all(fd, buf, bytes);
-    close(fd);
-    if (!ok) rendezvous::fail("recv");
-  }
-}
-
-static ttr_comm* comm_wrap(ttr_engine* e, int rank, int world, std::unique_ptr<Transport> tr) {
-  Engine& E = *e->e;
-  std::unique_ptr<ttr_comm> h(new ttr_comm());
-  h->c.reset(new Comm());
-  h->c->rank = rank; h->c->world = world; h->c->E = &E;
-  h->c->tr = std::move(tr);
-  return h.release();
-}
-static ttr_comm* comm_create(ttr_engine* e, int rank, int world, const ncclUniqueId ids[2]) {
-  if (!e || world < 1 || rank < 0 || rank >= world) throw std::runtime_error("ttr_comm_create: bad arguments");
-  EngineScope lk(*e->e);
-  return comm_wrap(e, rank, world, std::unique_ptr<Transport>(new RcclTransport(rank, world, ids)));
-}
-
-int ttr_dbg_tcp_share(int rank, int world, const char* addr, int port, void* buf, size_t bytes) {
-  TTR_GUARD_BEGIN
-  if (!buf || world < 1 || rank < 0 || rank >= world) throw std::runtime_error("bad arguments");
-  tcp_share(rank, world, addr, port, buf, bytes);
-  return 0;
-  TTR_GUARD_END(-1)
-}
-
-int ttr_comm_unique_id(void* id256) {
-  TTR_GUARD_BEGIN
-  if (!id256) throw std::runtime_error("null argument");
-  static_assert(sizeof(ncclUniqueId) == 128, "TTR_COMM_ID_BYTES");
-  ncclUniqueId ids[2];
-  TTR_NCCL_CHECK(ncclGetUniqueId(&ids[0]));
-  TTR_NCCL_CHECK(ncclGetUniqueId(&ids[1]));
-  memcpy(id256, ids, sizeof(ids));
-  return 0;
-  TTR_GUARD_END(-1)
-}
-
-ttr_comm* ttr_comm_create(ttr_engine* e, int rank, int world, const void* id256) {
-  TTR_GUARD_BEGIN
-  if (!id256) throw std::runtime_error("null argument");
-  ncclUniqueId ids[2];
-  memcpy(ids, id256, sizeof(ids));
-  return comm_create(e, rank, world, ids);
-  TTR_GUARD_END(nullptr)
-}
-
-ttr_comm* ttr_comm_create_tcp(ttr_engine* e, int rank, int world, const char* addr, int port) {
-  TTR_GUARD_BEGIN
-  ncclUniqueId ids[2];
-  if (rank == 0) { TTR_NCCL_CHECK(ncclGetUniqueId(&ids[0])); TTR_NCCL_CHECK(ncclGetUniqueId(&ids[1])); }
-  tcp_share(rank, world, addr, port, ids, sizeof(ids));
-  return comm_create(e, rank, world, ids);
-  TTR_GUARD_END(nullptr)
-}
-
-// The same communicator over TCP through rank 0 (SocketTransport above): for ranks that share one GPU - RCCL refuses two ranks on a device -
-// and as a fallback; every collective is framed and checked, so a mismatched call sequence raises instead of hanging.
-ttr_comm* ttr_comm_create_socket(ttr_engine* e, int rank, int world, const char* addr, int port) {
-  TTR_GUARD_BEGIN
-  if (!e || world < 1 || rank < 0 || rank >= world) throw std::runtime_error("ttr_comm_create_socket: bad arguments");
-  EngineScope lk(*e->e);
-  return comm_wrap(e, rank, world, std::unique_ptr<Transport>(new SocketTransport(rank, world, addr, port)));
-  TTR_GUARD_END(nullptr)
-}
-const char* ttr_comm_transport(const ttr_comm* c) { return c && c->c && c->c->tr ? c->c->tr->name() : ""; }
-
-void ttr_comm_destroy(ttr_comm* c) {
-  if (!c) return;
-  try {
-    if (c->c && c->c->E) {
-      Engine& E = *c->c->E;
-      EngineScope lk(E);
-      if (E.comm == c->c.get()) E.comm = nullptr;
-      (void)hipStreamSynchronize(E.stream); (void)hipStreamSynchronize(E.copy_stream);
-      c->c.reset();
-    }
-  } catch (...) {}
-  delete c;
-}
-
-int ttr_comm_rank(const ttr_comm* c) { return c && c->c ? c->c->rank : -1; }
-int ttr_comm_world(const ttr_comm* c) { return c && c->c ? c->c->world : -1; }
-
-int ttr_engine_attach_comm(ttr_engine* e, ttr_comm* c) {
-  TTR_GUARD_BEGIN
-  if (!e) throw std::runtime_error("null argument");
-  EngineScope lk(*e->e);
-  if (e->e->q1.live || e->e->q2.live) throw std::runtime_error("streamed batches are in flight");
-  if (c && c->c->E != e->e.get()) throw std::runtime_error("the communicator belongs to another engine");
-  e->e->comm = c ? c->c.get() : nullptr;
-  return 0;
-  TTR_GUARD_END(-1)
-}
-
-int ttr_comm_allgather_host(ttr_comm* c, const void* mine, size_t bytes, void* all) {
-  TTR_GUARD_BEGIN
-  if (!c || !c->c) throw std::runtime_error("null argument");
-  Engine& E = *c->c->E;
-  EngineScope lk(E);
-  Comm* keep = E.comm;
-  E.comm = c->c.get();
-  try { E.allgather_host(mine, bytes, all); } catch (...) { E.comm = keep; throw; }
-  E.comm = keep;
-  return 0;
-  TTR_GUARD_END(-1)
-}
-
-int ttr_last_gathered(ttr_engine* e, int* world, int* pages, int32_t* counts, size_t counts_cap, int32_t* ids, size_t ids_cap, size_t* ids_need) {
-  TTR_GUARD_BEGIN
-  if (!e) throw std::runtime_error("null argument");
-  EngineScope lk(*e->e);
-  const auto& g = e->e->last_gathered;
-  if (world) *world = g.world;
-  if (pages) *pages = g.pages;
-  if (ids_need) *ids_need = g.ids.size();
-  if (counts && counts_cap >= g.counts.size() && !g.counts.empty()) memcpy(counts, g.counts.data(), g.counts.size() * 4);
-  if (ids && ids_cap >= g.ids.size() && !g.ids.empty()) memcpy(ids, g.ids.data(), g.ids.size() * 4);
-  return (int)(g.ids.size() / 26);
-  TTR_GUARD_END(-1)
-}
-
-int ttr_gather_layout(const int32_t* counts, int world, int pages, int* cap, int32_t* total, int64_t* first) {
-  TTR_GUARD_BEGIN
-  if (!counts || world < 1 || pages < 0) throw std::runtime_error("bad arguments");
-  const GatherLayout L = GatherLayout::from_counts(counts, world, pages);
-  if (cap) *cap = L.cap;
-  if (total) memcpy(total, L.total.data(), (size_t)world * 4);
-  if (first) memcpy(first, L.first.data(), L.first.size() * 8);
-  return 0;
-  TTR_GUARD_END(-1)
-}
-
-int ttr_pages_to_data_dev_sharded(ttr_comm* c, const uint8_t* d_pages, int n, int h, int w, ttr_result** out) {
-  TTR_GUARD_BEGIN
-  if (!c || !c->c || !out) throw std::runtime_error("null argument");
-  Engine& E = *c->c->E;
-  EngineScope lk(E);
-  Comm* keep = E.comm;
-  E.comm = c->c.get();
-  std::vector<Result> res;
-  try { E.run_pages_sharded(d_pages, n, h, w, res); } catch (...) { E.comm = keep; throw; }
-  E.comm = keep;
-  for (size_t i = 0; i < res.size(); ++i) { out[i] = new ttr_result(); out[i]->r = std::move(res[i]); }
-  return (int)res.size();
-  TTR_GUARD_END(-1)
-}
-
-int ttr_stream_push(ttr_engine* e, const uint8_t* d_pages, int n, int h, int w, ttr_result** out_prev, int* n_prev) {
-  TTR_GUARD_BEGIN
-  if (!e || !out_prev || !n_prev) throw std::runtime_error("null argument");
-  EngineScope lk(*e->e);
-  std::vector<Result> res;
-  int np = 0;
-  e->e->stream_push(d_pages, n, h, w, res, np);
-  for (int i = 0; i < np; ++i) { out_prev[i] = new ttr_result(); out_prev[i]->r = std::move(res[i]); }
-  *n_prev = np;
-  return 0;
-  TTR_GUARD_END(-1)
-}
-
-int ttr_stream_flush(ttr_engine* e, ttr_result** out_prev, int* n_prev) {
-  TTR_GUARD_BEGIN
-  if (!e || !out_prev || !n_prev) throw std::runtime_error("null argument");
-  EngineScope lk(*e->e);
-  std::vector<Result> res;
-  int np = 0;
-  e->e->stream_flush(res, np);
-  for (int i = 0; i < np; ++i) { out_prev[i] = new ttr_result(); out_prev[i]->r = std::move(res[i]); }
-  *n_prev = np;
-  return 0;
-  TTR_GUARD_END(-1)
-}
-
-int ttr_image_to_data(ttr_engine* e, const uint8_t* img, int h, int w, int row_stride, ttr_result** out) {
-  TTR_GUARD_BEGIN
-  if (!e || !out) throw std::runtime_error("null argument");
-  if (!img || h <= 0 || w <= 0) throw std::runtime_error("Error reading image from file");  // tuatara.cpp:344-347
-  Engine& E = *e->e;
-  EngineScope lk(E);
-  E.staging_img.ensure((size_t)h * w * 3);
-  TTR_HIP_CHECK(hipMemcpy2DAsync(E.staging_img.p, (size_t)w * 3, img, row_stride, (size_t)w * 3, h, hipMemcpyHostToDevice, E.stream));
-  run_locked(e, E.staging_img.as<uint8_t>(), 1, h, w, out);
-  return 0;
-  TTR_GUARD_END(-1)
-}
-
-int ttr_result_count(const ttr_result* r) { return r ? (int)r->r.text.size() : 0; }
-const char* ttr_result_text(const ttr_result* r, int i) { return r->r.text[i].c_str(); }
-const float* ttr_result_bbox(const ttr_result* r, int i) { return &r->r.bbox[4 * (size_t)i]; }
-const int32_t* ttr_result_ids(const ttr_result* r, int i) { return &r->r.ids[26 * (size_t)i]; }
-void ttr_result_free(ttr_result* r) { delete r; }
-const float* ttr_result_bboxes(const ttr_result* r) { return r && !r->r.bbox.empty() ? r->r.bbox.data() : nullptr; }
-const int32_t* ttr_result_ids_all(const ttr_result* r) { return r && !r->r.ids.empty() ? r->r.ids.data() : nullptr; }
-int ttr_results_gather(ttr_result* const* rs, int n, int32_t* counts, float* bboxes, int32_t* ids, char* texts, size_t texts_cap, size_t* texts_need) {
-  if (!rs || n < 0) return -1;
-  size_t total = 0, need = 0;
-  for (int i = 0; i < n; ++i) {
-    const size_t c = rs[i] ? rs[i]->r.text.size() : 0;
-    if (counts) counts[i] = (int32_t)c;
-    total += c;
-    if (rs[i]) for (const auto& t : rs[i]->r.text) need += t.size() + 1;
-  }
-  if (texts_need) *texts_need = need;
-  size_t ob = 0, oi = 0, ot = 0;
-  for (int i = 0; i < n; ++i) {
-    if (!rs[i]) continue;
-    const Result& r = rs[i]->r;
-    if (bboxes && !r.bbox.empty()) { memcpy(bboxes + ob, r.bbox.data(), r.bbox.size() * 4); ob += r.bbox.size(); }
-    if (ids && !r.ids.empty()) { memcpy(ids + oi, r.ids.data(), r.ids.size() * 4); oi += r.ids.size(); }
-    if (texts && texts_cap >= need) for (const auto& t : r.text) { memcpy(texts + ot, t.data(), t.size()); ot += t.size(); texts[ot++] = '\n'; }
-  }
-  return (int)total;
-}
-int ttr_result_texts(const ttr_result* r, char* buf, size_t cap) {
-  if (!r) return 0;
-  size_t need = 0;
-  for (const auto& t : r->r.text) need += t.size() + 1;
-  if (!buf || cap < need) return (int)need;
-  size_t o = 0;
-  for (const auto& t : r->r.text) { memcpy(buf + o, t.data(), t.size()); o += t.size(); buf[o++] = '\n'; }
-  return (int)need;
-}
-
-int ttr_craft_heatmap(ttr_engine* e, const uint8_t* canvas, int H, int W, float* heat_out) {
-  TTR_GUARD_BEGIN
-  Engine& E = *e->e;
-  EngineScope lk(E);
-  E.canvas.ensure((size_t)H * W * 3);
-  E.heat.ensure((size_t)H * W / 4 * 2 * 4);
-  TTR_HIP_CHECK(hipMemcpyAsync(E.canvas.p, canvas, (size_t)H * W * 3, hipMemcpyHostToDevice, E.stream));
-  E.craft_forward(E.canvas.as<uint8_t>(), 1, H, W, E.heat.as<float>());
-  TTR_HIP_CHECK(hipMemcpyAsync(heat_out, E.heat.p, (size_t)H * W / 4 * 2 * 4, hipMemcpyDeviceToHost, E.stream));
-  TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
-  return 0;
-  TTR_GUARD_END(-1)
-}
-
-int ttr_ccl_boxes(ttr_engine* e, const float* heat, int H2, int W2, float* rects5, int max_rects, int* n) {
-  TTR_GUARD_BEGIN
-  Engine& E = *e->e;
-  EngineScope lk(E);
-  E.heat.ensure((size_t)H2 * W2 * 2 * 4);
-  TTR_HIP_CHECK(hipMemcpyAsync(E.heat.p, heat, (size_t)H2 * W2 * 2 * 4, hipMemcpyHostToDevice, E.stream));
-  E.ccl_launch(E.heat.as<float>(), 0, 1, 1, 0, H2, W2);
-  std::vector<std::vector<RRect>> dets;
-  dets.assign(1, std::vector<RRect>());
-  E.ccl_collect(0, 1, 0, H2, W2, dets);
-  const std::vector<RRect>& det = dets[0];
-  *n = (int)det.size();
-  for (int i = 0; i < (int)det.size() && i < max_rects; ++i) {
-    rects5[5 * i] = det[i].cx; rects5[5 * i + 1] = det[i].cy; rects5[5 * i + 2] = det[i].w; rects5[5 * i + 3] = det[i].h; rects5[5 * i + 4] = det[i].angle;
-  }
-  return 0;
-  TTR_GUARD_END(-1)
-}
-
-int ttr_resize_canvas(ttr_engine* e, const uint8_t* img, int h, int w, int row_stride, uint8_t* canvas, size_t cap, int* H, int* W, float* ratio) {
-  TTR_GUARD_BEGIN
-  Engine& E = *e->e;
-  EngineScope lk(E);
-  const CanvasGeom g = canvas_geometry(h, w, E.cfg.canvas_size, E.cfg.mag_ratio);
-  *H = g.h32; *W = g.w32; *ratio = g.ratio;
-  const size_t need = (size_t)g.h32 * g.w32 * 3;
-  if (cap < need) throw std::runtime_error("canvas buffer too small");
-  E.staging_img.ensure((size_t)h * w * 3);
-  E.canvas.ensure(need);
-  TTR_HIP_CHECK(hipMemcpy2DAsync(E.staging_img.p, (size_t)w * 3, img, row_stride, (size_t)w * 3, h, hipMemcpyHostToDevice, E.stream));
-  launch_resize_pad_u8(E.staging_img.as<uint8_t>(), h, w, w * 3, E.canvas.as<uint8_t>(), g.target_h, g.target_w, g.h32, g.w32, 1, E.stream);
-  TTR_HIP_CHECK(hipMemcpyAsync(canvas, E.canvas.p, need, hipMemcpyDeviceToHost, E.stream));
-  TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
-  return 0;
-  TTR_GUARD_END(-1)
-}
-
-int ttr_pack_crops(ttr_engine* e, const uint8_t* img, int h, int w, int row_stride, const float* rects5, int n, float ratio, uint8_t* crops_out,
-                   float* boxes_out) {
-  TTR_GUARD_BEGIN
-  Engine& E = *e->e;
-  EngineScope lk(E);
-  if (n <= 0) return 0;
-  std::vector<int> rects((size_t)n * 5, 0);
-  for (int i = 0; i < n; ++i) {
-    RRect r{rects5[5 * i], rects5[5 * i + 1], rects5[5 * i + 2], rects5[5 * i + 3], rects5[5 * i + 4]};
-    RRect b = adjust_coordinates(r, 1.f / ratio, 1.f / ratio);
-    if (boxes_out) { boxes_out[5 * i] = b.cx; boxes_out[5 * i + 1] = b.cy; boxes_out[5 * i + 2] = b.w; boxes_out[5 * i + 3] = b.h; boxes_out[5 * i + 4] = b.angle; }
-    int xywh[4];
-    bounding_rect(b, xywh);
-    rects[5 * i] = std::max(xywh[0], 0); rects[5 * i + 1] = std::max(xywh[1], 0);
-    rects[5 * i + 2] = std::min(xywh[0] + xywh[2], w); rects[5 * i + 3] = std::min(xywh[1] + xywh[3], h);
-  }
-  E.staging_img.ensure((size_t)h * w * 3);
-  E.rects_dev.ensure(rects.size() * 4);
-  E.crops.ensure((size_t)n * 32 * 128 * 3);
-  TTR_HIP_CHECK(hipMemcpy2DAsync(E.staging_img.p, (size_t)w * 3, img, row_stride, (size_t)w * 3, h, hipMemcpyHostToDevice, E.stream));
-  TTR_HIP_CHECK(hipMemcpyAsync(E.rects_dev.p, rects.data(), rects.size() * 4, hipMemcpyHostToDevice, E.stream));
-  launch_pack_crops(E.staging_img.as<uint8_t>(), 0, w * 3, E.rects_dev.as<int>(), E.crops.as<uint8_t>(), n, E.stream);
-  TTR_HIP_CHECK(hipMemcpyAsync(crops_out, E.crops.p, (size_t)n * 32 * 128 * 3, hipMemcpyDeviceToHost, E.stream));
-  TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
-  return 0;
-  TTR_GUARD_END(-1)
-}
-
-int ttr_parseq_logits(ttr_engine* e, const uint8_t* crops, int n, float* logits, float* ar_logits, int32_t* ids) {
-  TTR_GUARD_BEGIN
-  Engine& E = *e->e;
-  EngineScope lk(E);
-  if (n <= 0) return 0;
-  E.crops.ensure((size_t)n * 32 * 128 * 3);
-  E.logits.ensure((size_t)n * 26 * 95 * 4);
-  E.ids_dev.ensure((size_t)n * 26 * 4);
-  if (ar_logits) E.ar_logits.ensure((size_t)n * 26 * 95 * 4);
-  TTR_HIP_CHECK(hipMemcpyAsync(E.crops.p, crops, (size_t)n * 32 * 128 * 3, hipMemcpyHostToDevice, E.stream));
-  E.parseq_forward(E.crops.as<uint8_t>(), n, E.logits.as<float>(), ar_logits ? E.ar_logits.as<float>() : nullptr, E.ids_dev.as<int>());
-  TTR_HIP_CHECK(hipMemcpyAsync(logits, E.logits.p, (size_t)n * 26 * 95 * 4, hipMemcpyDeviceToHost, E.stream));
-  if (ar_logits) TTR_HIP_CHECK(hipMemcpyAsync(ar_logits, E.ar_logits.p, (size_t)n * 26 * 95 * 4, hipMemcpyDeviceToHost, E.stream));
-  if (ids) TTR_HIP_CHECK(hipMemcpyAsync(ids, E.ids_dev.p, (size_t)n * 26 * 4, hipMemcpyDeviceToHost, E.stream));
-  TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
-  return 0;
-  TTR_GUARD_END(-1)
-}
-
-int ttr_decode_ids(const int32_t* ids, int n, char* buf) {
-  TTR_GUARD_BEGIN
-  static const Tokenizer tok;
-  std::string s = tok.decode(ids, n);
-  memcpy(buf, s.c_str(), s.size() + 1);
-  return (int)s.size();
-  TTR_GUARD_END(-1)
-}
-
-int ttr_dbg_conv(ttr_engine* e, const float* in0, int C0, const float* in1, int C1, int relu0, int relu1, int B, int H, int W, int ks, int dil,
-                 const float* wgt, const float* bias, int Cout, int act, float* out) {
-  TTR_GUARD_BEGIN
-  Engine& E = *e->e;
-  EngineScope lk(E);
-  const size_t M = (size_t)B * H * W;
-  const int K = ks * ks * (C0 + C1);
-  DevBuf d0, d1, dout;
-  Linear L;
-  auto up = [&](DevBuf& d, const float* src, size_t nel) {
-    d.ensure(nel * E.es);
-    if (E.prec == kBF16) {
-      std::vector<uint16_t> hbuf(nel);
-      for (size_t i = 0; i < nel; ++i) hbuf[i] = f32_to_bf16_rne(src[i]);
-      TTR_HIP_CHECK(hipMemcpy(d.p, hbuf.data(), nel * 2, hipMemcpyHostToDevice));
-    } else TTR_HIP_CHECK(hipMemcpy(d.p, src, nel * 4, hipMemcpyHostToDevice));
-  };
-  up(d0, in0, M * C0);
-  if (C1) up(d1, in1, M * C1);
-  E.upload_linear(L, wgt, Cout, K, bias, Cout, K, nullptr, false);
-  dout.ensure(M * Cout * 4);
-  ConvParams p{};
-  p.in0 = d0.p; p.C0 = C0; p.in1 = C1 ? d1.p : nullptr; p.C1 = C1; p.relu0 = relu0; p.relu1 = relu1;
-  p.B = B; p.H = H; p.W = W; p.ks = ks; p.dil = dil; p.wgt = L.w.p; p.bias = bias ? L.b.as<float>() : nullptr;
-  p.out = nullptr; p.out_f32 = dout.as<float>(); p.out_f32_ld = Cout; p.Cout = Cout; p.M = (int)M; p.act = act;
-  const bool bf16_out = E.tn.dbg_bf16_out && E.prec == kBF16;
-  if (bf16_out) { p.out = dout.p; p.out_ld = Cout; p.out_f32 = nullptr; p.out_f32_ld = 0; }
-  launch_igemm(E.prec, p, E.stream);
-  if (bf16_out) {
-    std::vector<uint16_t> hb(M * Cout);
-    TTR_HIP_CHECK(hipMemcpyAsync(hb.data(), dout.p, M * Cout * 2, hipMemcpyDeviceToHost, E.stream));
-    TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
-    for (size_t i = 0; i < hb.size(); ++i) { const uint32_t u = (uint32_t)hb[i] << 16; memcpy(&out[i], &u, 4); }
-    return 0;
-  }
-  TTR_HIP_CHECK(hipMemcpyAsync(out, dout.p, M * Cout * 4, hipMemcpyDeviceToHost, E.stream));
-  TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
-  return 0;
-  TTR_GUARD_END(-1)
-}
-
-// One split-operand linear layer on its own (tests): out[M][N] = act(x w^T + bias (+ resid)) through launch_gemm2's split mode (gemm_sp.hip's kernels
-// where they apply), np = 3 (activation pairs) or 4 (triples); out_planes = 0 (the kernel writes fp32) or 2 / 3 (it writes f16 planes, joined here).
-int ttr_dbg_split_gemm(ttr_engine* e, const float* x, int M, int K, const float* w, const float* bias, int N, int np, int act, int out_planes,
-                       const float* resid, int cfg, float* out) {
-  TTR_GUARD_BEGIN
-  Engine& E = *e->e;
-  EngineScope lk(E);
-  if (E.prec != kSplit) throw std::runtime_error("ttr_dbg_split_gemm: f16x4 engines only");
-  if ((np != 3 && np != 4) || (out_planes != 0 && out_planes != 2 && out_planes != 3)) throw std::runtime_error("ttr_dbg_split_gemm: np must be 3 or 4, out_planes 0, 2 or 3");
-  const int ipl = np == 3 ? 2 : 3;
-  DevBuf dx, dxp, dout, dres;
-  Linear L;
-  dx.ensure((size_t)M * K * 4); TTR_HIP_CHECK(hipMemcpy(dx.p, x, (size_t)M * K * 4, hipMemcpyHostToDevice));
-  dxp.ensure((size_t)M * K * 2 * ipl);
-  launch_split_planes(dx.as<float>(), K, dxp.p, M, K, 0, E.stream, ipl);
-  E.upload_linear(L, w, N, K, bias, N, K, nullptr, false);
-  if (!L.ws.p) throw std::runtime_error("ttr_dbg_split_gemm: the layer has no weight planes");
-  if (resid) { dres.ensure((size_t)M * N * 4); TTR_HIP_CHECK(hipMemcpy(dres.p, resid, (size_t)M * N * 4, hipMemcpyHostToDevice)); }
-  dout.ensure((size_t)M * N * (out_planes ? 2 * out_planes : 4));
-  ConvParams p{};
-  p.in0 = dxp.p; p.C0 = K; p.B = 1; p.H = 1; p.W = M; p.ks = 1; p.dil = 1;
-  p.wgt = L.ws.p; p.bias = bias ? L.b.as<float>() : nullptr; p.split = np; p.out_scale = L.inv_scale; p.out_planes = out_planes;
-  if (out_planes) { p.out = dout.p; p.out_ld = N; } else { p.out_f32 = dout.as<float>(); p.out_f32_ld = N; }
-  p.resid = resid ? dres.as<float>() : nullptr; p.resid_ld = N;
-  p.Cout = N; p.M = M; p.act = act;
-  if (const char* err = gemm2_check(p)) throw std::runtime_error(err);
-  launch_gemm2(p, cfg, E.stream);
-  if (!out_planes) {
-    TTR_HIP_CHECK(hipMemcpyAsync(out, dout.p, (size_t)M * N * 4, hipMemcpyDeviceToHost, E.stream));
-    TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
-    return 0;
-  }
-  std::vector<uint16_t> h((size_t)M * N * out_planes);
-  TTR_HIP_CHECK(hipMemcpyAsync(h.data(), dout.p, h.size() * 2, hipMemcpyDeviceToHost, E.stream));
-  TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
-  auto f16_to_f32 = [](uint16_t v) -> double {
-    const int sgn = v >> 15, ex = (v >> 10) & 31, man = v & 1023;
-    double r = ex == 0 ? std::ldexp((double)man, -24) : ex == 31 ? (man ? NAN : INFINITY) : std::ldexp((double)(man | 1024), ex - 25);
-    return sgn ? -r : r;
-  };
-  for (int m = 0; m < M; ++m)
-    for (int n = 0; n < N; ++n) {
-      const uint16_t* row = h.data() + (size_t)m * out_planes * N;
-      double v = f16_to_f32(row[n]), lo = f16_to_f32(row[N + n]);
-      if (out_planes == 3) lo += f16_to_f32(row[2 * N + n]);
-      out[(size_t)m * N + n] = (float)(v + lo / 2048.0);
-    }
-  return 0;
-  TTR_GUARD_END(-1)
-}
-
-int ttr_dbg_mlp(ttr_engine* e, const float* x, int M, const float* ln_g, const float* ln_b, float eps, const float* w1, const float* b1, const float* w2,
-                const float* b2, const float* nln_g, const float* nln_b, float* x_out, float* nln_out, const float* att, const float* wp, const float* bp) {
-  TTR_GUARD_BEGIN
-  Engine& E = *e->e;
-  EngineScope lk(E);
-  if (E.prec != kBF16) throw std::runtime_error("ttr_dbg_mlp: bf16 engines only");
-  const int D = 384, H = 1536;
-  DevBuf dx, dout, dg, db, dw1, db1, dw2, db2, dng, dnb, dn;
-  auto upf = [&](DevBuf& d, const float* src, size_t n) { d.ensure(n * 4); TTR_HIP_CHECK(hipMemcpy(d.p, src, n * 4, hipMemcpyHostToDevice)); };
-  upf(dx, x, (size_t)M * D); upf(dg, ln_g, D); upf(db, ln_b, D); upf(db1, b1, H); upf(db2, b2, D);
-  if (nln_out) { upf(dng, nln_g, D); upf(dnb, nln_b, D); dn.ensure((size_t)M * D * 2); }
-  std::vector<uint16_t> h((size_t)H * D);
-  pack_mlp_w1(w1, h.data());
-  dw1.ensure(h.size() * 2); TTR_HIP_CHECK(hipMemcpy(dw1.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
-  pack_mlp_w2(w2, H, h.data());
-  dw2.ensure(h.size() * 2); TTR_HIP_CHECK(hipMemcpy(dw2.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
-  dout.ensure((size_t)M * D * 4);
-  MlpParams q{};
-  q.x = dx.as<float>(); q.x_out = dout.as<float>(); q.M = M; q.ln_g = dg.as<float>(); q.ln_b = db.as<float>(); q.ln_eps = eps;
-  q.w1p = dw1.as<bf16>(); q.b1 = db1.as<float>(); q.w2p = dw2.as<bf16>(); q.b2 = db2.as<float>();
-  if (nln_out) { q.nln_g = dng.as<float>(); q.nln_b = dnb.as<float>(); q.nln_eps = eps; q.nln_out = dn.as<bf16>(); }
-  DevBuf datt, dwp, dbp;
-  if (att) {
-    std::vector<uint16_t> ha((size_t)M * D), hw((size_t)D * D);
-    for (size_t i = 0; i < ha.size(); ++i) ha[i] = f32_to_bf16_rne(att[i]);
-    pack_mlp_w2(wp, D, hw.data());
-    datt.ensure(ha.size() * 2); TTR_HIP_CHECK(hipMemcpy(datt.p, ha.data(), ha.size() * 2, hipMemcpyHostToDevice));
-    dwp.ensure(hw.size() * 2); TTR_HIP_CHECK(hipMemcpy(dwp.p, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
-    upf(dbp, bp, D);
-    q.att = datt.as<bf16>(); q.wpp = dwp.as<bf16>(); q.bp = dbp.as<float>();
-  }
-  if (E.tn.mlp_pair && !att) launch_mlp_pair(q, E.stream); else launch_mlp_fused(q, E.stream);
-  TTR_HIP_CHECK(hipMemcpyAsync(x_out, dout.p, (size_t)M * D * 4, hipMemcpyDeviceToHost, E.stream));
-  TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
-  if (nln_out) {
-    std::vector<uint16_t> hb((size_t)M * D);
-    TTR_HIP_CHECK(hipMemcpy(hb.data(), dn.p, hb.size() * 2, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < hb.size(); ++i) { const uint32_t u = (uint32_t)hb[i] << 16; memcpy(&nln_out[i], &u, 4); }
-  }
-  return 0;
-  TTR_GUARD_END(-1)
-}
-
-int ttr_dbg_qkv_attn(ttr_engine* e, const float* x, int N, const float* w, const float* b, float* out) {
-  TTR_GUARD_BEGIN
-  Engine& E = *e->e;
-  EngineScope lk(E);
-  if (E.prec == kSplit) {   // the fused launch of the default precision: x -> pairs, weight rows head-major, output triples joined here
-    const size_t nx = (size_t)N * 128 * 384;
-    DevBuf dx, dxp, dout;
-    Linear L;
-    dx.ensure(nx * 4); TTR_HIP_CHECK(hipMemcpy(dx.p, x, nx * 4, hipMemcpyHostToDevice));
-    dxp.ensure(nx * 4);
-    launch_split_planes(dx.as<float>(), 384, dxp.p, (int64_t)N * 128, 384, 0, E.stream, 2);
-    std::vector<float> wp((size_t)1152 * 384), bp(1152);
-    for (int n = 0; n < 1152; ++n) { const int src = Engine::qkv_tile_row(n); memcpy(&wp[(size_t)n * 384], &w[(size_t)src * 384], 384 * 4); bp[n] = b[src]; }
-    E.upload_linear(L, wp.data(), 1152, 384, bp.data(), 1152, 384, nullptr, false);
-    dout.ensure(nx * 6);
-    launch_qkv_attn_split(dxp.p, L.ws.p, L.b.as<float>(), L.inv_scale, dout.p, N, E.stream);
-    std::vector<_Float16> h(nx * 3);
-    TTR_HIP_CHECK(hipMemcpyAsync(h.data(), dout.p, nx * 6, hipMemcpyDeviceToHost, E.stream));
-    TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
-    for (size_t m = 0; m < (size_t)N * 128; ++m)
-      for (int c = 0; c < 384; ++c) {
-        const _Float16* row = h.data() + m * 1152;
-        out[m * 384 + c] = (float)((double)(float)row[c] + ((double)(float)row[384 + c] + (double)(float)row[768 + c]) / 2048.0);
-      }
-    return 0;
-  }
-  if (E.prec != kBF16) throw std::runtime_error("ttr_dbg_qkv_attn: bf16 and f16x4 engines only");
-  const size_t nx = (size_t)N * 128 * 384, nw = (size_t)1152 * 384;
-  DevBuf dx, dw, db, dout;
-  std::vector<uint16_t> h(std::max(nx, nw));
-  for (size_t i = 0; i < nx; ++i) h[i] = f32_to_bf16_rne(x[i]);
-  dx.ensure(nx * 2); TTR_HIP_CHECK(hipMemcpy(dx.p, h.data(), nx * 2, hipMemcpyHostToDevice));
-  for (size_t i = 0; i < nw; ++i) h[i] = f32_to_bf16_rne(w[i]);
-  dw.ensure(nw * 2); TTR_HIP_CHECK(hipMemcpy(dw.p, h.data(), nw * 2, hipMemcpyHostToDevice));
-  db.ensure(1152 * 4); TTR_HIP_CHECK(hipMemcpy(db.p, b, 1152 * 4, hipMemcpyHostToDevice));
-  dout.ensure(nx * 2);
-  launch_qkv_attn(dx.as<bf16>(), dw.as<bf16>(), db.as<float>(), dout.as<bf16>(), N, E.stream);
-  TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
-  TTR_HIP_CHECK(hipMemcpy(h.data(), dout.p, nx * 2, hipMemcpyDeviceToHost));
-  for (size_t i = 0; i < nx; ++i) { const uint32_t u = (uint32_t)h[i] << 16; memcpy(&out[i], &u, 4); }
-  return 0;
-  TTR_GUARD_END(-1)
-}
-
-int ttr_dbg_attn_enc(ttr_engine* e, const float* qkv, int N, float* out) {
-  TTR_GUARD_BEGIN
-  Engine& E = *e->e;
-  EngineScope lk(E);
-  const size_t nin = (size_t)N * 128 * 1152, nout = (size_t)N * 128 * 384;
-  DevBuf din, dout;
-  din.ensure(nin * E.es); dout.ensure(nout * E.es);
-  if (E.prec == kBF16) {
-    std::vector<uint16_t> h(nin);
-    for (size_t i = 0; i < nin; ++i) h[i] = f32_to_bf16_rne(qkv[i]);
-    TTR_HIP_CHECK(hipMemcpy(din.p, h.data(), nin * 2, hipMemcpyHostToDevice));
-  } else TTR_HIP_CHECK(hipMemcpy(din.p, qkv, nin * 4, hipMemcpyHostToDevice));
-  launch_attn_enc(E.prec, din.p, dout.p, N, E.stream);
-  TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
-  if (E.prec == kBF16) {
-    std::vector<uint16_t> h(nout);
-    TTR_HIP_CHECK(hipMemcpy(h.data(), dout.p, nout * 2, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < nout; ++i) { const uint32_t u = (uint32_t)h[i] << 16; memcpy(&out[i], &u, 4); }
-  } else TTR_HIP_CHECK(hipMemcpy(out, dout.p, nout * 4, hipMemcpyDeviceToHost));
-  return 0;
-  TTR_GUARD_END(-1)
-}
-
-int ttr_dbg_conv_pool(ttr_engine* e, const float* in0, int C0, int B, int H, int W, int ks, const float* wgt, const float* bias, int Cout, int act,
-                      int pool_relu, float* out_full, float* out_pool) {
-  TTR_GUARD_BEGIN
-  Engine& E = *e->e;
-  EngineScope lk(E);
-  if (E.prec != kBF16) throw std::runtime_error("ttr_dbg_conv_pool: bf16 engines only (the fused pool lives in gemm2)");
-  const size_t M = (size_t)B * H * W, Mp = M / 4;
-  const int K = ks * ks * C0;
-  DevBuf d0, dfull, dpool;
-  Linear L;
-  std::vector<uint16_t> hbuf(M * C0);
-  for (size_t i = 0; i < hbuf.size(); ++i) hbuf[i] = f32_to_bf16_rne(in0[i]);
-  d0.ensure(hbuf.size() * 2);
-  TTR_HIP_CHECK(hipMemcpy(d0.p, hbuf.data(), hbuf.size() * 2, hipMemcpyHostToDevice));
-  E.upload_linear(L, wgt, Cout, K, bias, Cout, K, nullptr, false);
-  dfull.ensure(M * Cout * 2); dpool.ensure(Mp * Cout * 2);
-  ConvParams p{};
-  p.in0 = d0.p; p.C0 = C0; p.B = B; p.H = H; p.W = W; p.ks = ks; p.dil = 1; p.wgt = L.w.p; p.bias = bias ? L.b.as<float>() : nullptr;
-  p.out = out_full ? dfull.p : nullptr; p.out_ld = Cout; p.out_pool = dpool.p; p.pool_relu = pool_relu;
-  p.Cout = Cout; p.M = (int)M; p.act = act;
-  launch_igemm(E.prec, p, E.stream);
-  auto down = [&](const DevBuf& d, size_t n, float* dst) {
-    std::vector<uint16_t> h(n);
-    TTR_HIP_CHECK(hipMemcpyAsync(h.data(), d.p, n * 2, hipMemcpyDeviceToHost, E.stream));
-    TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
-    for (size_t i = 0; i < n; ++i) { uint32_t u = (uint32_t)h[i] << 16; memcpy(&dst[i], &u, 4); }
-  };
-  if (out_full) down(dfull, M * Cout, out_full);
-  down(dpool, Mp * Cout, out_pool);
-  return 0;
-  TTR_GUARD_END(-1)
-}
-
-void ttr_set_gemm_config(int cfg) { set_gemm_config(cfg); }
-void ttr_set_decoder_mode(int mode) { g_tuning_default.decoder_mode = mode; }
-void ttr_last_host_us(ttr_engine* e, float out[8]) { for (int i = 0; i < 8; ++i) out[i] = e ? e->e->host_us[i] : 0.f; }
-int ttr_dbg_dec_stamps(unsigned long long* out) { return g_dec_dbg && hipMemcpy(out, g_dec_dbg, 26 * 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
-// process-wide: the kernel files' variant switches and diagnostics; engine-level keys set the default of engines created afterwards
-int ttr_set_tuning(const char* key, int value) {
-  const std::string k = key ? key : "";
-  if (g_tuning_default.set(k, value)) return 0;
-  if (k == "gemm_config") set_gemm_config(value);
-  else if (k == "self_refine") set_dec_self_refine(value);
-  else if (k == "cross_mfma") set_dec_cross_mfma(value);
-  else if (k == "cross_crop") set_dec_cross_crop(value);
-  else if (k == "mlp_store_nt") set_mlp_store_nt(value);
-  else if (k == "pair_ablate") set_mlp_pair_ablate(value);
-  else if (k == "mlp_stagger") set_mlp_stagger(value);
-  else if (k == "c3s_wgs") set_conv3s_wgs_per_cu(value);
-  else if (k == "c3_c32") set_conv3p_c32_tile(value);
-  else if (k == "c3_narrow64") set_conv3p_narrow_bn64(value);
-  else if (k == "upsample_block") set_upsample_block(value);
-  else if (k == "mlp_ablate") set_mlp_ablate(value);
-  else if (k == "attn_impl") set_attn_impl(value);
-  else if (k == "ws_dbg_flags") set_gemm_ws_dbg_flags(value);
-  else if (k == "ws_lean") set_gemm_ws_lean(value);
-  else if (k == "store_policy") set_store_policy(value);
-  else if (k == "g2_x_ring3") set_gemm2_x_ring3(value);
-  else if (k == "g2_split_reuse") set_gemm2_split_reuse(value);
-  else if (k == "g2_split_cfg") set_gemm2_split_cfg(value);
-  else if (k == "g2_split_dbg") set_gemm2_split_dbg(value);
-  else if (k == "g2_split_wreg") set_gemm2_split_wreg(value);
-  else if (k == "g2_split_stream") set_gemm2_split_stream(value);
-  else if (k == "g2_split_stream4") set_gemm2_split_stream4(value);
-  else if (k == "gsp_sched") set_gemm_sp_sched(value);
-  else if (k == "c3_xs1_max_cin") set_conv3p_single_stage_max_cin(value);
-  else if (k == "c3_force_bn128") set_conv3p_force_bn128(value);
-  else if (k == "c3_c64_waves") set_conv3p_c64_waves(value);
-  else if (k == "c3_first_persistent") set_conv3p_first_persistent(value);
-  else if (k == "sk_max_rows") set_skinny_max_rows(value);
-  else if (k == "ws_min_rows") set_gemm_ws_min_rows(value);
-  else if (k == "dec_stamps") {   // value != 0: allocate the stamp buffer; read it back with ttr_dev_download via ttr_dbg_dec_stamps
-    if (value && !g_dec_dbg) { void* d = nullptr; if (hipMalloc(&d, 26 * 16 * 8) != hipSuccess) return -1; (void)hipMemset(d, 0, 26 * 16 * 8); g_dec_dbg = (unsigned long long*)d; }
-    if (!value) g_dec_dbg = nullptr;
-    set_gemm_ws_stamps(value == 2 ? g_dec_dbg : nullptr);
-    set_conv3p_stamps(value == 4 ? g_dec_dbg : nullptr);    // 4: ... or conv3p_first2 stamps
-    set_mlp_stamps(value == 3 ? g_dec_dbg : nullptr);
-    set_mlp_pair_stamps(value == 5 ? g_dec_dbg : nullptr);  // 5: mlp_pair panel stamps       // 3: ... or mlp_fused stamps   // 2: the same buffer takes gemm_ws stamps instead
-  }
-  else return -1;
-  return 0;
-}
-// per engine (under the engine's lock: a batch in flight on another thread keeps the selection it started with)
-int ttr_engine_set_tuning(ttr_engine* e, const char* key, int value) {
-  TTR_GUARD_BEGIN
-  if (!e) return -1;
-  const std::string k = key ? key : "";
-  {
-    std::lock_guard<std::mutex> lk(e->e->mu);
-    if (e->e->tn.set(k, value)) return 0;
-  }
-  return ttr_set_tuning(key, value);   // not an engine key: the process-wide diagnostics setter (documented in tuatara_hip.h)
-  TTR_GUARD_END(-1)
-}
-
-int ttr_bench_conv(ttr_engine* e, int B, int H, int W, int C0, int C1, int ks, int dil, int Cout, int act, int f32_resid, int iters, float* avg_us) {
-  TTR_GUARD_BEGIN
-  Engine& E = *e->e;
-  EngineScope lk(E);
-  const size_t M = (size_t)B * H * W;
-  const int K = ks * ks * (C0 + C1);
-  DevBuf d0, d1, dw, db, dout, dres;
-  d0.ensure(M * C0 * E.es); launch_fill_random(E.prec, d0.p, M * C0, 1u, 1.0f, E.stream);
-  if (C1) { d1.ensure(M * C1 * E.es); launch_fill_random(E.prec, d1.p, M * C1, 2u, 1.0f, E.stream); }
-  dw.ensure((size_t)Cout * K * E.es); launch_fill_random(E.prec, dw.p, (size_t)Cout * K, 3u, 1.0f / std::sqrt((float)K), E.stream);
-  db.ensure((size_t)Cout * 4); launch_fill_random(kF32, db.p, Cout, 4u, 1.0f, E.stream);
-  ConvParams p{};
-  p.in0 = d0.p; p.C0 = C0; p.in1 = C1 ? d1.p : nullptr; p.C1 = C1;
-  p.B = B; p.H = H; p.W = W; p.ks = ks; p.dil = dil; p.wgt = dw.p; p.bias = db.as<float>();
-  p.Cout = Cout; p.M = (int)M; p.act = act;
-  if (f32_resid) {   // the PARSeq residual-stream form: f32 in, f32 out
-    dres.ensure(M * Cout * 4); launch_fill_random(kF32, dres.p, M * Cout, 5u, 1.0f, E.stream);
-    p.out_f32 = dres.as<float>(); p.out_f32_ld = Cout; p.resid = dres.as<float>(); p.resid_ld = Cout;
-  } else {
-    dout.ensure(M * Cout * E.es); p.out = dout.p; p.out_ld = Cout;
-  }
-  for (int i = 0; i < 2; ++i) launch_igemm(E.prec, p, E.stream);
-  hipEvent_t a, b;
-  TTR_HIP_CHECK(hipEventCreate(&a)); TTR_HIP_CHECK(hipEventCreate(&b));
-  TTR_HIP_CHECK(hipEventRecord(a, E.stream));
-  for (int i = 0; i < iters; ++i) launch_igemm(E.prec, p, E.stream);
-  TTR_HIP_CHECK(hipEventRecord(b, E.stream));
-  TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
-  float ms = 0.f;
-  TTR_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
-  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-  *avg_us = ms * 1e3f / iters;
-  return 0;
-  TTR_GUARD_END(-1)
-}
-
-int ttr_dbg_min_area_rect(const float* xy, int n, float* r5) {
-  TTR_GUARD_BEGIN
-  std::vector<Pt2f> p(n);
-  for (int i = 0; i < n; ++i) p[i] = Pt2f{xy[2 * i], xy[2 * i + 1]};
-  RRect r = min_area_rect(p.data(), n);
-  r5[0] = r.cx; r5[1] = r.cy; r5[2] = r.w; r5[3] = r.h; r5[4] = r.angle;
-  return 0;
-  TTR_GUARD_END(-1)
-}
-
-int ttr_dbg_component_rect(int area, int x0, int y0, int x1, int y1, const int32_t* rows, int H, int W, float* r5) {
-  TTR_GUARD_BEGIN
-  Component c{0, area, x0, y0, x1, y1, rows};
-  RRect r;
-  if (!component_to_rect(c, H, W, &r)) return 0;
-  r5[0] = r.cx; r5[1] = r.cy; r5[2] = r.w; r5[3] = r.h; r5[4] = r.angle;
-  return 1;
-  TTR_GUARD_END(-1)
-}
-
-int ttr_dbg_box_geometry(const float* r5, float ratio, float* adj5, int32_t* xywh, float* bbox4) {
-  TTR_GUARD_BEGIN
-  RRect r{r5[0], r5[1], r5[2], r5[3], r5[4]};
-  RRect b = adjust_coordinates(r, 1.f / ratio, 1.f / ratio);
-  adj5[0] = b.cx; adj5[1] = b.cy; adj5[2] = b.w; adj5[3] = b.h; adj5[4] = b.angle;
-  int q[4];
-  bounding_rect(b, q);
-  for (int i = 0; i < 4; ++i) xywh[i] = q[i];
-  tesseract_bbox(b, bbox4);
-  return 0;
-  TTR_GUARD_END(-1)
-}
-
-void* ttr_dev_alloc(size_t bytes) { void* p = nullptr; return hipMalloc(&p, bytes) == hipSuccess ? p : nullptr; }
-void ttr_dev_free(void* p) { if (p) (void)hipFree(p); }
-int ttr_dev_upload(void* dst, const void* src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1; }
-int ttr_dev_download(void* dst, const void* src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
-int ttr_dev_sync(ttr_engine* e) { return hipStreamSynchronize(e->e->stream) == hipSuccess ? 0 : -1; }
-int ttr_set_profiling(ttr_engine* e, int on) {
-  TTR_GUARD_BEGIN
-  if (!e) throw std::runtime_error("null argument");
-  Engine& E = *e->e;
-  EngineScope lk(E);
-  E.profiling = on < 0 ? 0 : (on > 2 ? 2 : on);
-  E.prof_recs.clear();
-  for (int i = 0; i < 3; ++i) { E.prof_ms[i] = 0; E.prof_flops[i] = 0; E.prof_launches[i] = 0; }
-  for (auto& k : E.prof_kinds) { k.ms = 0; k.alg = 0; k.exec = 0; k.launches = 0; }
-  return 0;
-  TTR_GUARD_END(-1)
-}
-// The same records by kernel kind, as JSON text: [{"kind": name, "stage": 0|1|2, "launches": n, "ms": t, "alg_flops": a, "exec_flops": x}, ...]
-// (alg_flops: 2 x MACs of the layers, SURVEY.md section 8(d)'s figure; exec_flops: what the matrix cores execute for them).  Returns the
-// text's length (without the terminator); the text is truncated to cap - 1 characters.
-int ttr_get_profile_kinds(ttr_engine* e, char* buf, size_t cap) {
-  TTR_GUARD_BEGIN
-  if (!e) throw std::runtime_error("null argument");
-  Engine& E = *e->e;
-  EngineScope lk(E);
-  E.prof_collect();
-  std::string s = "[";
-  bool first = true;
-  for (const auto& k : E.prof_kinds) {
-    if (!k.launches) continue;
-    char line[512];
-    snprintf(line, sizeof line, "%s{\"kind\": \"%s\", \"stage\": %d, \"launches\": %ld, \"ms\": %.6f, \"alg_flops\": %.6e, \"exec_flops\": %.6e}", first ? "" : ", ",
-             k.name.c_str(), k.stage, k.launches, k.ms, k.alg, k.exec);
-    s += line; first = false;
-  }
-  s += "]";
-  if (buf && cap) { const size_t n = std::min(s.size(), cap - 1); memcpy(buf, s.data(), n); buf[n] = 0; }
-  return (int)s.size();
-  TTR_GUARD_END(-1)
-}
-int ttr_get_profile(ttr_engine* e, double ms[3], double flops[3], long long launches[3]) {
-  TTR_GUARD_BEGIN
-  if (!e) throw std::runtime_error("null argument");
-  Engine& E = *e->e;
-  EngineScope lk(E);
-  E.prof_collect();          // records whose events completed since the last batch was finished
-  for (int i = 0; i < 3; ++i) { ms[i] = E.prof_ms[i]; flops[i] = E.prof_flops[i]; launches[i] = E.prof_launches[i]; }
-  return 0;
-  TTR_GUARD_END(-1)
-}
-int ttr_last_stage_ms(ttr_engine* e, float ms[4]) { memcpy(ms, e->e->stage_ms, sizeof(float) * 4); return 0; }
-
-}  // extern "C"

@@ -1,0 +1,181 @@
+// Skinny split-operand linear for the recogniser's autoregressive steps of a single page (gfx950 / MI355X):
+//   out[m][n] = act( (sum_k X[m][k] W[n][k]) / S + bias[n] (+ resid[m][n]) ),   M <= 64 rows (the crops of one page), whole K per workgroup.
+//
+// The AR loop of PARSeq (the 26 sequential decoder steps inside the module run at /root/reference/tuatara.cpp:307) issues six linears per step
+// on one row per crop: 40 rows for a page.  gemm_sp.hip's 128-row tiles give such a problem 3 - 12 workgroups that walk K in 6 - 24 dependent
+// ring steps: ~12 us per launch, 170 launches = a quarter of a page's latency (profiles/r03_single_page_kernel_trace.txt).  These problems are
+// bound by one memory round trip, so here
+//   * a workgroup owns 32 output channels and ALL rows: Cout / 32 workgroups (12 - 48), every weight byte is read once by one workgroup;
+//   * its four waves split K (wave w takes the 32-deep k steps w, w + 4, ...), fetch their operand fragments straight from global memory into
+//     registers - the activation planes are a few tens of KB and live in L2, the weight rows are contiguous - three steps ahead of the MFMAs,
+//     and meet once, in LDS, to add the four partial tiles;
+//   * exact triples x weight pairs as everywhere in the decoder (split.h): (w0, x0) (w0 / 2^11, x1) (w0 / 2^11, x2) (w1, x0).
+// Same ConvParams contract as gemm2.hip's split mode (ks = 1, one source, split = 4): fp32 and / or planes outputs, bias, residual
+// (with resid_mod), ReLU / GELU, the AR early exit (`skip`).
+#include <stdexcept>
+
+#include "common.h"
+#include "kernels.h"
+#include "split.h"
+
+namespace ttr {
+
+namespace {
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t skx_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f16x8 skx_load(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+}
+constexpr int SKX_BN = 32, SKX_DEPTH = 3;
+}  // namespace
+
+// RB: 16-row blocks (M <= 16 RB)
+template <int RB>
+__global__ __launch_bounds__(256) void gemm_skx_kernel(ConvParams p) {
+  if (p.skip && __builtin_nontemporal_load(p.skip) >= p.skip_n) return;   // AR early exit: uniform, before the barrier
+  __shared__ __attribute__((aligned(16))) float part[4][2][RB][64][4];    // the four waves' partial tiles
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane & 15, g = lane >> 4;
+  const int K = p.C0, nsteps = K >> 5;                                     // 32-deep k steps
+  const int n0 = blockIdx.x * SKX_BN;
+  const __amdgpu_buffer_rsrc_t rsx = skx_rsrc(p.in0, (unsigned)((size_t)p.M * K * 6));      // rows [x0 | x1 | x2]
+  const __amdgpu_buffer_rsrc_t rsw = skx_rsrc(p.wgt, (unsigned)((size_t)p.Cout * K * 6));   // rows [w0 | w0b | w1]
+  constexpr unsigned OOB = 0x80000000u;
+  // lane-constant byte offsets of the fragments' rows (k = 8 g .. 8 g + 7 of the step); the step and the plane ride in the scalar offset
+  unsigned xo[RB], wo[2];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) { const int m = rb * 16 + q; xo[rb] = m < p.M ? ((unsigned)m * (unsigned)(3 * K) + g * 8) * 2u : OOB; }
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) { const int n = n0 + cb * 16 + q; wo[cb] = n < p.Cout ? ((unsigned)n * (unsigned)(3 * K) + g * 8) * 2u : OOB; }
+
+  struct Frags { f16x8 x[RB][3], w[2][2]; };
+  // (always the same number of loads, so that the compiler's s_waitcnt counts stay exact: a step past the end fetches out of range - zero fill, no traffic)
+  auto fetch = [&](Frags& f, int step) {
+    const unsigned ks = (unsigned)step * 64u;                               // 32 halves
+    const unsigned dead = step < nsteps ? 0u : OOB;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) f.x[rb][pl] = skx_load(rsx, xo[rb] | dead, ks + (unsigned)(pl * K) * 2u);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      f.w[cb][0] = skx_load(rsw, wo[cb] | dead, ks);                        // w0
+      f.w[cb][1] = skx_load(rsw, wo[cb] | dead, ks + (unsigned)(2 * K) * 2u);   // w1
+    }
+  };
+  f32x4 acc[2][RB];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) acc[cb][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const f16 dn = (f16)(1.f / 2048.f);
+  const f16x8 dnv = {dn, dn, dn, dn, dn, dn, dn, dn};
+  auto multiply = [&](const Frags& f) {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const f16x8 w0b = f.w[cb][0] * dnv;
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        f32x4 a = acc[cb][rb];
+        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.w[cb][0], f.x[rb][0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0b, f.x[rb][1], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0b, f.x[rb][2], a, 0, 0, 0);
+        acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.w[cb][1], f.x[rb][0], a, 0, 0, 0);
+      }
+    }
+  };
+  // this wave's steps: wave, wave + 4, ...; SKX_DEPTH of them in flight.  Rounds of SKX_DEPTH steps, every fetch and every multiply
+  // unconditional (steps past the end multiply zeros): straight-line code with static load counts
+  Frags fb[SKX_DEPTH];
+  const int mine = (nsteps - wave + 3) >> 2;                                // steps this wave owns
+  const int rounds = (mine + SKX_DEPTH - 1) / SKX_DEPTH;
+#pragma unroll
+  for (int d = 0; d < SKX_DEPTH; ++d) { fetch(fb[d], wave + 4 * d); __builtin_amdgcn_sched_barrier(0); }   // (in stage order: the loop's first wait must not cover stage 2)
+  for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+    for (int d = 0; d < SKX_DEPTH; ++d) {
+      multiply(fb[d]);
+      __builtin_amdgcn_sched_barrier(0);      // (keeps the refill of a stage behind its MFMAs and in front of the next stage's: the wait counts stay two stages deep)
+      fetch(fb[d], wave + 4 * ((r + 1) * SKX_DEPTH + d));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- meet: partial tiles -> LDS, then pair (cb, rb) number pr goes to wave pr % 4
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) *reinterpret_cast<f32x4*>(&part[wave][cb][rb][lane][0]) = acc[cb][rb];
+  __syncthreads();
+#pragma unroll
+  for (int pr = 0; pr < 2 * RB; ++pr) {
+    if ((pr & 3) != wave) continue;                                         // (wave-uniform)
+    const int cb = pr / RB, rb = pr % RB;
+    f32x4 v = *reinterpret_cast<const f32x4*>(&part[0][cb][rb][lane][0]);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(&part[w][cb][rb][lane][0]);
+    // the lane holds channels n .. n + 3 of row m (C[channel 4 g + r][row q])
+    const int n = n0 + cb * 16 + 4 * g, m = rb * 16 + q;
+    if (n >= p.Cout || m >= p.M) continue;
+    float o[4];
+    const float4 bv = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    o[0] = fmaf(v[0], p.out_scale, bv.x); o[1] = fmaf(v[1], p.out_scale, bv.y); o[2] = fmaf(v[2], p.out_scale, bv.z); o[3] = fmaf(v[3], p.out_scale, bv.w);
+    if (p.resid) {
+      const float4 r = *reinterpret_cast<const float4*>(p.resid + (int64_t)(p.resid_mod ? m % p.resid_mod : m) * p.resid_ld + n);
+      o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+    }
+    if (p.act == kActRelu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+    } else if (p.act == kActGelu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = gelu_exact(o[e]);
+    }
+    if (p.out) {
+      if (p.out_planes == 3) {
+        f16x2 a0, b0, c0, a1, b1, c1;
+        split3_pair(o[0], o[1], a0, b0, c0); split3_pair(o[2], o[3], a1, b1, c1);
+        typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+        f16* d = reinterpret_cast<f16*>(p.out) + (int64_t)m * (3 * (int64_t)p.out_ld) + n;
+        *reinterpret_cast<f16x4*>(d) = f16x4{a0[0], a0[1], a1[0], a1[1]};
+        *reinterpret_cast<f16x4*>(d + p.out_ld) = f16x4{b0[0], b0[1], b1[0], b1[1]};
+        *reinterpret_cast<f16x4*>(d + 2 * p.out_ld) = f16x4{c0[0], c0[1], c1[0], c1[1]};
+      } else if (p.out_planes == 2) {
+        f16x2 a0, b0, a1, b1;
+        split2_pair(o[0], o[1], a0, b0); split2_pair(o[2], o[3], a1, b1);
+        typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+        f16* d = reinterpret_cast<f16*>(p.out) + (int64_t)m * (2 * (int64_t)p.out_ld) + n;
+        *reinterpret_cast<f16x4*>(d) = f16x4{a0[0], a0[1], a1[0], a1[1]};
+        *reinterpret_cast<f16x4*>(d + p.out_ld) = f16x4{b0[0], b0[1], b1[0], b1[1]};
+      } else {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.out_ld + n) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+    if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + (int64_t)m * p.out_f32_ld + n) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// shapes: exact triples (split = 4), ks = 1, one source, M <= 64, K a multiple of 32, Cout a multiple of 4, no pooled / ReLU-copy outputs
+bool gemm_skx_eligible(const ConvParams& p) {
+  if (p.split != 4 || p.ks != 1 || p.C1 != 0 || p.out_pool || p.out_relu || p.M > 64 || p.M <= 0 || p.C0 % 32 != 0 || p.Cout % 4 != 0) return false;
+  if (p.out_full_cols) return false;
+  if ((size_t)p.Cout * p.C0 * 6 >= ((size_t)1 << 31)) return false;
+  if (p.out && (p.out_ld % 4 || ((uintptr_t)p.out & 15))) return false;
+  if (p.out_f32 && (p.out_f32_ld % 4 || ((uintptr_t)p.out_f32 & 15))) return false;
+  if (p.resid && (p.resid_ld % 4 || ((uintptr_t)p.resid & 15))) return false;
+  return !(((uintptr_t)p.in0 | (uintptr_t)p.wgt | (uintptr_t)p.bias) & 15);
+}
+
+void launch_gemm_skx(const ConvParams& p, hipStream_t s) {
+  if (!gemm_skx_eligible(p)) throw std::runtime_error("gemm_skx: shape not supported");
+  const dim3 grid((p.Cout + SKX_BN - 1) / SKX_BN), block(256);
+  const int rb = (p.M + 15) / 16;
+  if (rb == 1) hipLaunchKernelGGL(gemm_skx_kernel<1>, grid, block, 0, s, p);
+  else if (rb == 2) hipLaunchKernelGGL(gemm_skx_kernel<2>, grid, block, 0, s, p);
+  else if (rb == 3) hipLaunchKernelGGL(gemm_skx_kernel<3>, grid, block, 0, s, p);
+  else hipLaunchKernelGGL(gemm_skx_kernel<4>, grid, block, 0, s, p);
+}
+
+}  // namespace ttr

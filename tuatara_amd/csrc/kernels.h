@@ -30,6 +30,9 @@ void set_gemm2_x_ring3(int v);   // 1 (default): activation tiles two K steps ah
 const void* gelu_lut_for_current_device();
 const void* gelu_hermite_lut_for_current_device();   // float4[512]: one cubic of Phi per interval of 1/32, the split mode's GELU (common.h: gelu_hermite)
 // GELU by that table (g = the table, in LDS)
+// ---- gemm_skx.hip (split-operand skinny linear, M <= 64 rows, whole K per workgroup: the AR steps of a single page)
+bool gemm_skx_eligible(const ConvParams& p);
+void launch_gemm_skx(const ConvParams& p, hipStream_t s);
 // ---- gemm_sk.hip (bf16 skinny GEMM, whole K resident: the per-step decoder linears)
 const char* gemm_sk_check(const ConvParams& p);
 void launch_gemm_sk(const ConvParams& p, hipStream_t s);
@@ -153,15 +156,11 @@ struct MlpParams {
   int M;
   int stagger;             // set by the launcher: (groups << 16) | microseconds - workgroup (blockIdx / 8) % groups starts that many steps late, to take the
                            // panels' HBM phases (front loads, epilogue stores) of the groups out of lock-step; 0 = all start together
-  int ablate;              // mlp_pair timing experiments (results are wrong): 1 no weight DMA after the first items, 2 no GELU, 4 no GEMM2, 8 no GEMM1, 16 no epilogue stores
+  int ablate;              // timing experiments of the stamps build (results are wrong): 1 no weight DMA after the first items, 2 no GELU, 4 no GEMM2, 8 no GEMM1, 16 no epilogue stores
 };
 void launch_mlp_fused(const MlpParams& p, hipStream_t s);
 void set_mlp_ablate(int v);    // MlpParams::ablate of the stamps build (tools/mlp_stamps.py)
 void set_mlp_stagger(int v);   // MlpParams::stagger for the following launches
-// ---- mlp_pair.hip: the same block with two waves per SIMD (a pair of waves shares 32 rows and splits hidden units / output channels); no projection
-void launch_mlp_pair(const MlpParams& p, hipStream_t s);
-void set_mlp_pair_stamps(unsigned long long* dev_buf);   // >= 400 u64 or null: panel stamps of workgroup 0
-void set_mlp_pair_ablate(int v);   // timing experiments (MlpParams::ablate)
 // host-side packing of the weight operands into the kernel's LDS images (bf16 bits): w1 f32 [1536][384] -> 48 x 24 KiB;
 // w f32 [384][K] (fc2: K = 1536, attention projection: K = 384) -> K/32 x 24 KiB
 void pack_mlp_w1(const float* w1, uint16_t* out);
