@@ -42,6 +42,18 @@ def _worker(rank, world, port, q, crops_path):
             for p in range(3):
                 for c in range(counts_all[r, p]):
                     assert ids_all[first[r * 3 + p] + c].tolist() == _ids_of(r, p, c)
+        # the {status, pages} header: a rank with another page count, then a rank that failed, fail the batch on BOTH ranks; the next batch works
+        for kind in ("pages", "failed"):
+            try:
+                if kind == "pages":
+                    D.all_gather_var(counts[: 3 - rank], ids[: int(counts[: 3 - rank].sum())])
+                else:
+                    D.all_gather_var(counts, ids, failed=(rank == 1))
+                raise AssertionError(kind + " went through")
+            except RuntimeError as ex:
+                assert "multi-GPU batch" in str(ex)
+        counts_all2, ids_all2 = D.all_gather_var(counts, ids)
+        assert np.array_equal(counts_all2, counts_all) and np.array_equal(ids_all2, ids_all)
         # latency mode: the fp32 oracle PARSeq recognises this rank's shard of real crops; every rank ends with the whole batch's ids
         from oracle import pipeline
         from tuatara_amd import weights as W

@@ -5,10 +5,17 @@ profiler), bytes fetched (KiB x 2: gfx950 tallies 128-B requests at 64 B) and wr
 import csv, json, sys
 
 fetch_csv, write_csv, pages, out, build = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
-CONV = ("conv3p", "gemm2_kernel", "conv1_direct", "igemm_kernel", "conv3s")
+CONV = ("conv3p", "gemm2_kernel", "gemm_sp_kernel", "conv1_direct", "conv1_split", "igemm_kernel", "conv3s")   # (detector-only runs: every such launch is CRAFT's)
 LAYERS = ["slice1.0+slice1.3 +pool", "slice1.7", "slice1.10 (skip relu2_2 + pooled)", "slice2.14", "slice2.17 (skip relu3_2 + relu copy)", "slice3.20 +pool",
           "slice3.24", "slice3.27 (skip relu4_3 + pooled)", "slice4.30", "slice4.34", "slice4.37 (skip relu5_3 + relu copy)", "slice5.1 (dil 6)", "slice5.2",
           "upconv1.0", "upconv1.3", "upconv2.0", "upconv2.3", "upconv3.0", "upconv3.3", "upconv4.0", "upconv4.3", "conv_cls.0", "conv_cls.2", "conv_cls.4+.6+.8"]
+
+
+# the f16x4 engine's 27 launches per group (nothing fused across layers but the pools and the ReLU copies)
+LAYERS_X4 = ["slice1.0 (conv1_split, u8 canvas -> planes)", "slice1.3 +pool", "slice1.7", "slice1.10 (skip relu2_2 + pooled)", "slice2.14", "slice2.17 (skip relu3_2 + relu copy)",
+             "slice3.20 +pool", "slice3.24", "slice3.27 (skip relu4_3 + relu copy)", "slice4.30 +pool", "slice4.34", "slice4.37 (skip relu5_3)", "slice5.1 (dil 6)", "slice5.2",
+             "upconv1.0", "upconv1.3", "upconv2.0", "upconv2.3", "upconv3.0", "upconv3.3", "upconv4.0", "upconv4.3", "conv_cls.0", "conv_cls.2", "conv_cls.4",
+             "conv_cls.6 (fp32)", "conv_cls.8 (fp32)"]
 
 
 def rows(path, counter):
@@ -20,6 +27,8 @@ def rows(path, counter):
 f, w = rows(fetch_csv, "FETCH_SIZE"), rows(write_csv, "WRITE_SIZE")
 n = len(LAYERS)
 per_step = len(f) // 3 if len(f) % 3 == 0 else n
+if per_step == len(LAYERS_X4):
+    LAYERS, n = LAYERS_X4, len(LAYERS_X4)
 f, w = f[-per_step:], w[-per_step:]
 # a 25th launch per step (an igemm fall-back for a thin layer) keeps its kernel name as label
 layers = []

@@ -61,7 +61,7 @@ int ttr_dbg_split_gemm(ttr_engine* e, const float* x, int M, int K, const float*
   dx.ensure((size_t)M * K * 4); TTR_HIP_CHECK(hipMemcpy(dx.p, x, (size_t)M * K * 4, hipMemcpyHostToDevice));
   dxp.ensure((size_t)M * K * 2 * ipl);
   launch_split_planes(dx.as<float>(), K, dxp.p, M, K, 0, E.stream, ipl);
-  E.upload_linear(L, w, N, K, bias, N, K, nullptr, false);
+  E.upload_linear(L, w, N, K, bias, cfg == 7 ? (N + 7) / 8 * 8 : N, K, nullptr, false);   // (the skinny kernel takes any channel count: zero rows pad the planes)
   if (!L.ws.p) throw std::runtime_error("ttr_dbg_split_gemm: the layer has no weight planes");
   if (resid) { dres.ensure((size_t)M * N * 4); TTR_HIP_CHECK(hipMemcpy(dres.p, resid, (size_t)M * N * 4, hipMemcpyHostToDevice)); }
   dout.ensure((size_t)M * N * (out_planes ? 2 * out_planes : 4));
@@ -71,9 +71,11 @@ int ttr_dbg_split_gemm(ttr_engine* e, const float* x, int M, int K, const float*
   if (out_planes) { p.out = dout.p; p.out_ld = N; } else { p.out_f32 = dout.as<float>(); p.out_f32_ld = N; }
   p.resid = resid ? dres.as<float>() : nullptr; p.resid_ld = N;
   p.Cout = N; p.M = M; p.act = act;
-  if (const char* err = gemm2_check(p)) throw std::runtime_error(err);
-  if (cfg == 7) launch_gemm_skx(p, E.stream);       // the skinny whole-K kernel (gemm_skx.hip: M <= 64, triples)
-  else launch_gemm2(p, cfg, E.stream);
+  if (cfg == 7) launch_gemm_skx(p, E.stream);       // the skinny whole-K kernel (gemm_skx.hip: triples; throws for shapes it does not take)
+  else {
+    if (const char* err = gemm2_check(p)) throw std::runtime_error(err);
+    launch_gemm2(p, cfg, E.stream);
+  }
   if (!out_planes) {
     TTR_HIP_CHECK(hipMemcpyAsync(out, dout.p, (size_t)M * N * 4, hipMemcpyDeviceToHost, E.stream));
     TTR_HIP_CHECK(hipStreamSynchronize(E.stream));

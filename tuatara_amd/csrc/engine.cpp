@@ -226,7 +226,12 @@ void Engine::load_parseq(const std::string& dir) {
   }
   for (const char* n : {"norm1", "norm2", "norm_q", "norm_c"}) { vec(d + n + ".weight", E); vec(d + n + ".bias", E); }
   vec("decoder.norm.weight", E); vec("decoder.norm.bias", E);
-  lin("head", "head.weight", "head.bias", 95, E);
+  if (prec == kSplit) {   // 95 classes in 96 weight rows (a zero row): the head gets f16 planes and runs on the skinny split kernel in the AR steps
+    const auto& w = wf.get("head.weight", (size_t)95 * E);
+    const auto& b = wf.get("head.bias", (size_t)95);
+    upload_linear(pq["head"], w.data.data(), 95, E, b.data.data(), 96, E);
+    pq["head"].cout_valid = 95;
+  } else lin("head", "head.weight", "head.bias", 95, E);
   vec("text_embed.embedding.weight", 97 * E);
   vec("pos_queries", 26 * E);
   // Qself[i] = Wq . norm_q(pos_queries[i]) + bq : crop independent, computed once on the host in fp32

@@ -70,7 +70,10 @@ struct Tuning {
   int ln_fuse = 1;            // bf16 decoder steps: LayerNorm computed inside the skinny GEMM's loader (gemm_sk ln_in)
   int fuse_first = 1;         // bf16: CRAFT conv1_1 fused into conv1_2's loader (conv3p FIRST)
   int qkv_attn_split = 1;     // split-operand engines, PARSeq encoder: qkv projection + self-attention as ONE launch (gemm_sp.hip, attention epilogue); needs enc_ln_pairs
-  int skinny_split = 1;       // split-operand engines: linears of <= 64 rows (the AR steps of a single page) on gemm_skx.hip
+  int skinny_split = 1;       // split-operand engines: linears of <= skinny_max_rows rows (the AR steps: one row per crop) on gemm_skx.hip
+  int skinny_max_rows = 2048;
+  int ar_host_check = 10;     // split / fp32 engines, batches of <= 256 crops (the latency regime): from this AR step on the host looks at the done counter every fourth
+                              // step and stops enqueuing steps once every crop has emitted EOS (upstream's loop does that check every step); 0 = never
   int enc_chunk = 0;          // crops per encoder group (0 = all crops at once)
   int enc_ln_pairs = 1;       // split-operand engines, PARSeq encoder: LayerNorm outputs as pairs (qkv and fc1 on three MFMAs per product: their inputs tolerate ~23.5 bits - 3 x 1280 crops: max |dlogit| 7.6e-4 vs 6.9e-4 with triples; proj and fc2 keep exact triples); 0 = triples
   int dec_planes = 1;         // split-operand engines: the decoder's layers hand each other planes (13 launches per AR step instead of 20); 0 = fp32 tensors + split passes
@@ -91,6 +94,8 @@ struct Tuning {
     if (k == "decoder_mode") decoder_mode = value;
     else if (k == "enc_chunk") enc_chunk = value;
     else if (k == "skinny_split") skinny_split = value;
+    else if (k == "skinny_max_rows") skinny_max_rows = value;
+    else if (k == "ar_host_check") ar_host_check = value;
     else if (k == "qkv_attn_split") qkv_attn_split = value;
     else if (k == "fuse_first") fuse_first = value;
     else if (k == "ln_fuse") ln_fuse = value;
@@ -195,6 +200,7 @@ struct PinnedBuf {
 struct Linear {
   DevBuf w, b;
   int cout = 0, k = 0;  // padded sizes as the kernel sees them
+  int cout_valid = 0;   // != 0: the layer's own output count, below `cout` (PARSeq's head: 95 classes in 96 weight rows, so that it has f16 planes); the kernels get this as Cout
   DevBuf ws;            // split-operand engines (split.h): f16 [cout][3][k] = w0 | w0/2^11 | w1 of w S
   float inv_scale = 0;  // 1 / S
 };
@@ -464,6 +470,7 @@ struct Engine {
   // GEMM and the per-row attention kernels honour it, which are the ones the bf16 AR steps use
   const int* cur_skip = nullptr; int cur_skip_n = 0;
   DevBuf ar_done;
+  PinnedBuf h_ar_done;
   size_t kvcache_zeroed = 0;
   void ln(const float* x, const std::string& name, float eps, void* out, int M);
 

@@ -14,11 +14,13 @@ void Engine::sgemm(const Linear& L, const void* in_planes, int M, void* out, int
   p.in0 = in_planes; p.C0 = L.k; p.B = 1; p.H = 1; p.W = M; p.ks = 1; p.dil = 1;
   p.wgt = L.ws.p; p.bias = L.b.as<float>(); p.split = np; p.out_scale = L.inv_scale; p.out_planes = out_planes == 1 ? 3 : out_planes;   // (1 = triples)
   p.out = out; p.out_ld = out_ld; p.out_f32 = out_f32; p.out_f32_ld = out_f32_ld; p.resid = resid; p.resid_ld = resid_ld; p.resid_mod = resid_mod;
-  p.Cout = L.cout; p.M = M; p.act = act;
+  p.Cout = L.cout_valid ? L.cout_valid : L.cout; p.M = M; p.act = act;
   p.skip = cur_skip; p.skip_n = cur_skip_n;
-  if (const char* e = gemm2_check(p)) throw std::runtime_error(e);
-  if (tn.skinny_split && np == 4 && M <= 64 && gemm_skx_eligible(p)) {   // a page's worth of rows: one memory round trip per launch instead of a ring of K steps
-    timed(kind ? kind : "split linear (triples, skinny)", 2.0 * M * L.cout * L.k, 2.0 * M * L.cout * L.k * np, [&] { launch_gemm_skx(p, stream); });
+  const bool skinny = tn.skinny_split && np == 4 && M <= tn.skinny_max_rows && gemm_skx_eligible(p);
+  if (!skinny) { if (const char* e = gemm2_check(p)) throw std::runtime_error(e); }
+  // few rows (the AR steps: one row per crop): one memory round trip per small workgroup instead of a ring of K steps on a handful of 128-row tiles
+  if (skinny) {
+    timed(kind ? kind : "split linear (triples, skinny)", 2.0 * M * p.Cout * L.k, 2.0 * M * p.Cout * L.k * np, [&] { launch_gemm_skx(p, stream); });
     return;
   }
   timed(kind ? kind : (np == 3 ? "split linear (pairs)" : "split linear (triples)"), 2.0 * M * L.cout * L.k, 2.0 * M * L.cout * L.k * np, [&] { launch_gemm2(p, 0, stream); });
@@ -48,9 +50,9 @@ void Engine::gemm(const Linear& L, const void* in, int M, void* out, int out_ld,
   p.wgt = L.w.p; p.bias = L.b.as<float>();
   p.out = out; p.out_ld = out_ld; p.out_f32 = out_f32; p.out_f32_ld = out_f32_ld;
   p.resid = resid; p.resid_ld = resid_ld; p.resid_mod = resid_mod;
-  p.Cout = L.cout; p.M = M; p.act = act;
+  p.Cout = L.cout_valid ? L.cout_valid : L.cout; p.M = M; p.act = act;
   p.skip = cur_skip; p.skip_n = cur_skip_n;
-  igemm(p, 2.0 * M * L.cout * L.k);
+  igemm(p, 2.0 * M * p.Cout * L.k);
 }
 
 void Engine::ln(const float* x, const std::string& name, float eps, void* out, int M) {
@@ -72,7 +74,11 @@ void Engine::decoder_tail_split(const void* sa, int N, int R, const float* resid
   lnp(d + "norm2", pa);
   sgemm(pq.at("ffn1"), pa, rows, p1536, 1536, kActGelu, 3);
   sgemm(pq.at("ffn2"), p1536, rows, nullptr, 0, kActNone, 0, tgt, 384, tgt, 384);                              // tgt += ffn
-  ln_gemm(tgt, "decoder.norm", 1e-5f, t384, pq.at("head"), rows, nullptr, 0, kActNone, logits_out, logits_ld);
+  const Linear& head = pq.at("head");
+  if (head.ws.p && tn.skinny_split && rows <= tn.skinny_max_rows) {   // few rows: the head as a skinny split linear on the final norm's planes
+    lnp("decoder.norm", pa);
+    sgemm(head, pa, rows, nullptr, 0, kActNone, 0, logits_out, logits_ld, nullptr, 0, 4, 0, 0, "dec.head (skinny)");
+  } else ln_gemm(tgt, "decoder.norm", 1e-5f, t384, head, rows, nullptr, 0, kActNone, logits_out, logits_ld);
 }
 
 void Engine::decoder_tail(const void* sa, int N, int R, const float* resid_pos, int resid_mod, float* tgt, void* t384, void* t384b, void* t1536,
@@ -317,6 +323,14 @@ void Engine::parseq_forward(const uint8_t* d_crops, int N, float* d_logits, floa
     decoder_tail(att, N, 1, posq + (size_t)i * E, 1, tgt, t384, d384b, d1536, kvmem, ar + (size_t)i * 95, 26 * 95, crop_done, i);
     }
     if (i + 1 < 26 && !tok_fuse) launch_argmax(ar + (size_t)i * 95, 26 * 95, 95, tk, 26, i + 1, N, stream, cur_skip, cur_skip_n, early ? ar_done.as<int>() : nullptr, 0);
+    // the latency regime (a page or two of crops): every remaining step is ~14 launches that return at once when the batch is done - half a
+    // millisecond of them for ten-character words.  The host looks at the counter (one small synchronous read) and stops enqueuing instead
+    if (early && !tok_fuse && tn.ar_host_check > 0 && N <= 256 && i >= tn.ar_host_check && (i - tn.ar_host_check) % 4 == 0 && i + 1 < nsteps) {
+      h_ar_done.ensure(64);
+      TTR_HIP_CHECK(hipMemcpyAsync(h_ar_done.p, ar_done.p, 4, hipMemcpyDeviceToHost, stream));
+      TTR_HIP_CHECK(hipStreamSynchronize(stream));
+      if (*h_ar_done.as<int>() >= N) break;
+    }
   }
   cur_skip = nullptr; cur_skip_n = 0;
   prof_stage = 1;

@@ -1,11 +1,13 @@
 // Skinny split-operand linear for the recogniser's autoregressive steps of a single page (gfx950 / MI355X):
-//   out[m][n] = act( (sum_k X[m][k] W[n][k]) / S + bias[n] (+ resid[m][n]) ),   M <= 64 rows (the crops of one page), whole K per workgroup.
+//   out[m][n] = act( (sum_k X[m][k] W[n][k]) / S + bias[n] (+ resid[m][n]) ),   a workgroup = 64 rows x 32 channels x the whole K.
 //
 // The AR loop of PARSeq (the 26 sequential decoder steps inside the module run at /root/reference/tuatara.cpp:307) issues six linears per step
 // on one row per crop: 40 rows for a page.  gemm_sp.hip's 128-row tiles give such a problem 3 - 12 workgroups that walk K in 6 - 24 dependent
 // ring steps: ~12 us per launch, 170 launches = a quarter of a page's latency (profiles/r03_single_page_kernel_trace.txt).  These problems are
 // bound by one memory round trip, so here
-//   * a workgroup owns 32 output channels and ALL rows: Cout / 32 workgroups (12 - 48), every weight byte is read once by one workgroup;
+//   * a workgroup owns 32 output channels of a block of <= 64 rows: Cout / 32 workgroups for a page (12 - 48; every weight byte read once),
+//     20 times that for the 1280 rows of a 32-page batch, whose AR steps fill 30 - 120 of gemm_sp.hip's 128 x 128 tiles (15 us per launch
+//     whatever the layer): hundreds of small workgroups finish such a linear in a third of that;
 //   * its four waves split K (wave w takes the 32-deep k steps w, w + 4, ...), fetch their operand fragments straight from global memory into
 //     registers - the activation planes are a few tens of KB and live in L2, the weight rows are contiguous - three steps ahead of the MFMAs,
 //     and meet once, in LDS, to add the four partial tiles;
@@ -31,7 +33,7 @@ __device__ __forceinline__ f16x8 skx_load(__amdgpu_buffer_rsrc_t rs, unsigned vo
 constexpr int SKX_BN = 32, SKX_DEPTH = 3;
 }  // namespace
 
-// RB: 16-row blocks (M <= 16 RB)
+// RB: 16-row blocks per workgroup (blockIdx.y walks the rows in steps of 16 RB)
 template <int RB>
 __global__ __launch_bounds__(256) void gemm_skx_kernel(ConvParams p) {
   if (p.skip && __builtin_nontemporal_load(p.skip) >= p.skip_n) return;   // AR early exit: uniform, before the barrier
@@ -40,14 +42,14 @@ __global__ __launch_bounds__(256) void gemm_skx_kernel(ConvParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane & 15, g = lane >> 4;
   const int K = p.C0, nsteps = K >> 5;                                     // 32-deep k steps
-  const int n0 = blockIdx.x * SKX_BN;
+  const int n0 = blockIdx.x * SKX_BN, m0 = blockIdx.y * (16 * RB);
   const __amdgpu_buffer_rsrc_t rsx = skx_rsrc(p.in0, (unsigned)((size_t)p.M * K * 6));      // rows [x0 | x1 | x2]
   const __amdgpu_buffer_rsrc_t rsw = skx_rsrc(p.wgt, (unsigned)((size_t)p.Cout * K * 6));   // rows [w0 | w0b | w1]
   constexpr unsigned OOB = 0x80000000u;
   // lane-constant byte offsets of the fragments' rows (k = 8 g .. 8 g + 7 of the step); the step and the plane ride in the scalar offset
   unsigned xo[RB], wo[2];
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb) { const int m = rb * 16 + q; xo[rb] = m < p.M ? ((unsigned)m * (unsigned)(3 * K) + g * 8) * 2u : OOB; }
+  for (int rb = 0; rb < RB; ++rb) { const int m = m0 + rb * 16 + q; xo[rb] = m < p.M ? ((unsigned)m * (unsigned)(3 * K) + g * 8) * 2u : OOB; }
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) { const int n = n0 + cb * 16 + q; wo[cb] = n < p.Cout ? ((unsigned)n * (unsigned)(3 * K) + g * 8) * 2u : OOB; }
 
@@ -117,14 +119,23 @@ __global__ __launch_bounds__(256) void gemm_skx_kernel(ConvParams p) {
 #pragma unroll
     for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(&part[w][cb][rb][lane][0]);
     // the lane holds channels n .. n + 3 of row m (C[channel 4 g + r][row q])
-    const int n = n0 + cb * 16 + 4 * g, m = rb * 16 + q;
+    const int n = n0 + cb * 16 + 4 * g, m = m0 + rb * 16 + q;
     if (n >= p.Cout || m >= p.M) continue;
     float o[4];
-    const float4 bv = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-    o[0] = fmaf(v[0], p.out_scale, bv.x); o[1] = fmaf(v[1], p.out_scale, bv.y); o[2] = fmaf(v[2], p.out_scale, bv.z); o[3] = fmaf(v[3], p.out_scale, bv.w);
+    // whole groups of four channels with 16-byte aligned rows take vector accesses; a ragged channel count (PARSeq's head: 95 classes) or an odd
+    // row stride (its logits rows: 95 floats) goes element by element
+    const bool vec = n + 3 < p.Cout;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+      if (vec) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n); bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w; }
+      else { for (int e = 0; e < 4; ++e) if (n + e < p.Cout) bv[e] = p.bias[n + e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = fmaf(v[e], p.out_scale, bv[e]);
     if (p.resid) {
-      const float4 r = *reinterpret_cast<const float4*>(p.resid + (int64_t)(p.resid_mod ? m % p.resid_mod : m) * p.resid_ld + n);
-      o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+      const float* rp = p.resid + (int64_t)(p.resid_mod ? m % p.resid_mod : m) * p.resid_ld + n;
+      if (vec && ((p.resid_ld & 3) | ((uintptr_t)p.resid & 15)) == 0) { const float4 r = *reinterpret_cast<const float4*>(rp); o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w; }
+      else { for (int e = 0; e < 4; ++e) if (n + e < p.Cout) o[e] += rp[e]; }
     }
     if (p.act == kActRelu) {
 #pragma unroll
@@ -133,7 +144,7 @@ __global__ __launch_bounds__(256) void gemm_skx_kernel(ConvParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = gelu_exact(o[e]);
     }
-    if (p.out) {
+    if (p.out) {   // (eligibility: planes outputs have whole groups and aligned rows)
       if (p.out_planes == 3) {
         f16x2 a0, b0, c0, a1, b1, c1;
         split3_pair(o[0], o[1], a0, b0, c0); split3_pair(o[2], o[3], a1, b1, c1);
@@ -150,31 +161,40 @@ __global__ __launch_bounds__(256) void gemm_skx_kernel(ConvParams p) {
         *reinterpret_cast<f16x4*>(d) = f16x4{a0[0], a0[1], a1[0], a1[1]};
         *reinterpret_cast<f16x4*>(d + p.out_ld) = f16x4{b0[0], b0[1], b1[0], b1[1]};
       } else {
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.out_ld + n) = make_float4(o[0], o[1], o[2], o[3]);
+        float* d = reinterpret_cast<float*>(p.out) + (int64_t)m * p.out_ld + n;
+        if (vec && ((p.out_ld & 3) | ((uintptr_t)p.out & 15)) == 0) *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], o[3]);
+        else { for (int e = 0; e < 4; ++e) if (n + e < p.Cout) d[e] = o[e]; }
       }
     }
-    if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + (int64_t)m * p.out_f32_ld + n) = make_float4(o[0], o[1], o[2], o[3]);
+    if (p.out_f32) {
+      float* d = p.out_f32 + (int64_t)m * p.out_f32_ld + n;
+      if (vec && ((p.out_f32_ld & 3) | ((uintptr_t)p.out_f32 & 15)) == 0) *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], o[3]);
+      else { for (int e = 0; e < 4; ++e) if (n + e < p.Cout) d[e] = o[e]; }
+    }
   }
 }
 
-// shapes: exact triples (split = 4), ks = 1, one source, M <= 64, K a multiple of 32, Cout a multiple of 4, no pooled / ReLU-copy outputs
+// shapes: exact triples (split = 4), ks = 1, one source, K a multiple of 32, no pooled / ReLU-copy outputs; planes outputs want whole groups of four
+// channels and aligned rows, fp32 outputs take any channel count and row stride (whether the kernel is the faster one for a shape is the
+// caller's call: it is for a few thousand rows at most)
 bool gemm_skx_eligible(const ConvParams& p) {
-  if (p.split != 4 || p.ks != 1 || p.C1 != 0 || p.out_pool || p.out_relu || p.M > 64 || p.M <= 0 || p.C0 % 32 != 0 || p.Cout % 4 != 0) return false;
-  if (p.out_full_cols) return false;
-  if ((size_t)p.Cout * p.C0 * 6 >= ((size_t)1 << 31)) return false;
-  if (p.out && (p.out_ld % 4 || ((uintptr_t)p.out & 15))) return false;
-  if (p.out_f32 && (p.out_f32_ld % 4 || ((uintptr_t)p.out_f32 & 15))) return false;
-  if (p.resid && (p.resid_ld % 4 || ((uintptr_t)p.resid & 15))) return false;
+  if (p.split != 4 || p.ks != 1 || p.C1 != 0 || p.out_pool || p.out_relu || p.M <= 0 || p.Cout <= 0 || p.C0 % 32 != 0 || p.out_full_cols) return false;
+  if ((size_t)p.M * p.C0 * 6 >= ((size_t)1 << 31) || (p.M + 63) / 64 > 65535) return false;
+  if ((size_t)((p.Cout + 7) / 8 * 8) * p.C0 * 6 >= ((size_t)1 << 31)) return false;
+  if (p.out && p.out_planes && (p.Cout % 4 || p.out_ld % 4 || ((uintptr_t)p.out & 15))) return false;
+  if (((uintptr_t)p.out | (uintptr_t)p.out_f32 | (uintptr_t)p.resid) & 3) return false;   // (fp32 rows: vector accesses where base and stride allow, else scalar)
   return !(((uintptr_t)p.in0 | (uintptr_t)p.wgt | (uintptr_t)p.bias) & 15);
 }
 
 void launch_gemm_skx(const ConvParams& p, hipStream_t s) {
   if (!gemm_skx_eligible(p)) throw std::runtime_error("gemm_skx: shape not supported");
-  const dim3 grid((p.Cout + SKX_BN - 1) / SKX_BN), block(256);
-  const int rb = (p.M + 15) / 16;
-  if (rb == 1) hipLaunchKernelGGL(gemm_skx_kernel<1>, grid, block, 0, s, p);
-  else if (rb == 2) hipLaunchKernelGGL(gemm_skx_kernel<2>, grid, block, 0, s, p);
-  else if (rb == 3) hipLaunchKernelGGL(gemm_skx_kernel<3>, grid, block, 0, s, p);
+  // Rows per workgroup: a workgroup streams its rows' activation planes (6 K bytes per row) and its 32 weight rows (4 K bytes each) at what
+  // one CU takes in (~64 B / clk), so for a page's worth of rows 16-row workgroups (four times as many of them, each weight row read four
+  // times from L2) finish sooner than one 64-row workgroup per 32 channels: K = 1536 at 50 rows 343 KB instead of 786 KB per workgroup;
+  // with a batch's 1280 rows there are workgroups enough and 64-row blocks keep the weight re-reads down.
+  const int rbsel = p.M <= 256 ? 1 : 4;
+  const dim3 grid((p.Cout + SKX_BN - 1) / SKX_BN, (p.M + 16 * rbsel - 1) / (16 * rbsel)), block(256);
+  if (rbsel == 1) hipLaunchKernelGGL(gemm_skx_kernel<1>, grid, block, 0, s, p);
   else hipLaunchKernelGGL(gemm_skx_kernel<4>, grid, block, 0, s, p);
 }
 

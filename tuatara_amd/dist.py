@@ -45,13 +45,25 @@ def gather_layout(counts_all: np.ndarray):
     return int(total.max()) if total.size else 0, total.astype(np.int32), first
 
 
-def all_gather_var(counts: np.ndarray, ids: np.ndarray, device: str = "cpu"):
-    """Every rank's (counts, ids) -> (counts_all [world, pages], ids_all [sum, 26] in (rank, page, crop) order): two collectives,
-    the counts, then the payload padded to the largest rank total."""
+def all_gather_var(counts: np.ndarray, ids: np.ndarray, device: str = "cpu", failed: bool = False):
+    """Every rank's (counts, ids) -> (counts_all [world, pages], ids_all [sum, 26] in (rank, page, crop) order): a {status, pages} header
+    (Engine::detect_collect: a rank that failed before the exchange, or passed another page count, fails the batch on EVERY rank instead of
+    leaving the others in a gather of mismatched sizes), then two collectives - the counts, then the payload padded to the largest rank total."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size()
+    hdr = torch.tensor([-1 if failed else 0, len(counts)], dtype=torch.int32, device=device)
+    hall = torch.empty((world * 2,), dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(hall, hdr)
+    hall = hall.cpu().numpy().reshape(world, 2)
+    if failed:
+        raise RuntimeError("multi-GPU batch: this rank failed before the exchange")
+    for r in range(world):
+        if hall[r, 0] < 0:
+            raise RuntimeError(f"multi-GPU batch: rank {r} failed before the exchange; the batch is dropped on every rank")
+        if hall[r, 1] != len(counts):
+            raise RuntimeError(f"multi-GPU batch: rank {r} passed {hall[r, 1]} pages, this rank {len(counts)}")
     c = torch.from_numpy(np.ascontiguousarray(counts, np.int32)).to(device)
     call = torch.empty((world * c.shape[0],), dtype=c.dtype, device=device)
     dist.all_gather_into_tensor(call, c)
