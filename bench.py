@@ -255,8 +255,11 @@ def main():
     W.make_synthetic_weights(wdir, seed=0, structured=True)
 
     P, H, Wd, R = args.pages, 1024, 768, max(1, args.reps)
+    # TUATARA_BENCH_SHARE_GPU=1 (a pre-flight on a single-GPU box, never a benchmark): every rank on device 0, the exchange over the framed TCP
+    # transport (RCCL refuses two ranks on one device) - launcher, ranks, header / counts / payload gathers and the result line, all but RCCL itself
+    share = os.environ.get("TUATARA_BENCH_SHARE_GPU") == "1"
     with wd.stage("engine set-up (weights to the GPU)", args.stage_deadline):
-        eng = Engine(wdir, precision=args.precision, device=local_rank, bench_grid_boxes=grid)
+        eng = Engine(wdir, precision=args.precision, device=0 if share else local_rank, bench_grid_boxes=grid)
     for kv in args.tune:
         k, v = kv.split("=")
         assert eng.set_tuning(k.encode(), int(v)) == 0, kv
@@ -264,7 +267,7 @@ def main():
     if world > 1:
         port = int(os.environ.get("TUATARA_COMM_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 1))
         with wd.stage("communicator set-up (TCP rendezvous + ncclCommInitRank x 2)", args.stage_deadline):
-            comm = Comm(eng, rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), port)
+            comm = Comm(eng, rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), port, transport="socket" if share else "rccl")
         with wd.stage("first host all-gather (barrier)", args.stage_deadline):
             comm.barrier()
         comm.attach(True)          # from here on every batch all-gathers its token ids on the engine's stream (ncclAllGather)
@@ -425,7 +428,7 @@ def main():
                                               "CRAFT on activation pairs (three; its heat map stays at fp32 noise level); logits within 1e-3 of the CPU fp32 reference, boxes and "
                                               "strings identical (tests/test_gpu_x4_parity.py)",
                                      "bf16": "operands rounded to bf16: NOT output-equivalent (|dlogit| up to ~1e-1..1)", "f32": "fp32 MFMA"}[args.precision],
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}" + (" (ranks SHARE one GPU over the TCP transport: a pre-flight, not a measurement)" if share else "")},
             "gathered_id_rows_last_pass": gathered_rows,
             "stage_ms_last_pass": {k: round(v, 3) for k, v in stage.items()},
             "roofline": roof,

@@ -144,6 +144,31 @@ def test_x4_craft_exact_triples_option(eng_x4_random, weights_random):
     assert np.abs(pairs - triples).max() < 1e-4 * scale
 
 
+def test_x4_craft_head_on_packed_pairs_equals_zero_padded_rows(eng_x4_random, weights_random):
+    """The 32-channel head tensors as 128-byte pixel rows [x0 | x1] with conv_cls.0 / .2 / .4 on packed pairs (conv3p.hip, NP = 2: the default)
+    against the same layers over zero-padded 64-channel rows: the same three products per value (x0 w0 + x1 w0 / 2^11 in one chunk, x0 w1 in
+    the other), so the heat maps agree to the last bits of an fp32 sum taken in another order, and both stay at fp32 noise from the oracle.
+    Switching back and forth re-lays the workspaces out (the zero padding sits elsewhere)."""
+    from oracle import pipeline
+    craft_r, _ = pipeline.load_models(weights_random["craft"], weights_random["parseq"])
+    canvas = np.random.default_rng(77).integers(0, 256, (256, 512, 3), dtype=np.uint8)
+    ref = pipeline.craft_heatmap(craft_r, canvas)
+    eng = eng_x4_random
+    try:
+        a = eng.craft_heatmap(canvas)
+        assert eng.set_tuning(b"head_packed", 0) == 0
+        b = eng.craft_heatmap(canvas)
+        assert eng.set_tuning(b"head_packed", 1) == 0
+        c = eng.craft_heatmap(canvas)
+    finally:
+        eng.set_tuning(b"head_packed", 1)
+    assert np.array_equal(a, c)
+    scale = max(1.0, float(np.abs(ref).max()))
+    print(f"CRAFT 256x512 random weights: packed head {np.abs(a - ref).max():.2e}, zero-padded {np.abs(b - ref).max():.2e}, packed vs padded {np.abs(a - b).max():.2e}")
+    assert np.abs(a - b).max() < 1e-5 * scale, float(np.abs(a - b).max())
+    assert np.abs(a - ref).max() < TOL * scale and np.abs(b - ref).max() < TOL * scale
+
+
 @pytest.mark.parametrize("hw", [(256, 192), (96, 160), (64, 96)])
 def test_x4_craft_small_canvases_random_weights(eng_x4_random, weights_random, hw):
     """Canvases that do not tile into conv3p patches at every level (gemm2's split variant serves those layers)."""

@@ -67,7 +67,12 @@ struct C3 {
 // SP (split-operand mode, split.h): f16 planes.  The input holds [x0 | x1 | x2] per pixel (3 Cin halves), the weight rows
 // [w0 | w0/2^11 | w1] (3 x 9 Cin).  A 64-channel chunk becomes four virtual chunks: x0 with w0, x0 again with w1
 // (the patch stays), x1 with w0/2^11, x2 with w0/2^11 - 36 tap steps into the one accumulator, three patch loads instead of one.
-template <int BN, int WM, int WN, bool FIRST, int XS, int LPW, int NP = 0>   // NP: 0 = bf16, 4 = triples, 3 = pairs (split.h).  XS: patch stages (1 when Cin = 64: a single chunk, and two workgroups fit a CU)
+// NP = 2, PACKED pairs, for layers of 32 input channels (CRAFT's head: upconv4.3's output, conv_cls.0 / .2 / .4's inputs): the pixel's row is
+// [x0 (32 channels) | x1 (32 channels)] - a pairs tensor of 32 channels IS that row - and one patch load serves both virtual chunks: the first
+// multiplies it by weight rows [w0 | w0 / 2^11] (x0 w0 + x1 w0b in ONE chunk), the second by [w1 | 0] (x0 w1).  Two chunks over 128 bytes
+// per pixel instead of three over 256 (32 real channels zero-padded to 64): two thirds of the MFMAs, half the bytes.  The weight planes
+// keep the [plane 0 | plane 1 | plane 2] row layout with plane 1 unused, so the loaders below need no third case.
+template <int BN, int WM, int WN, bool FIRST, int XS, int LPW, int NP = 0>   // NP: 0 = bf16, 4 = triples, 3 = pairs, 2 = packed pairs (split.h).  XS: patch stages (1 when Cin = 64: a single chunk, and two workgroups fit a CU)
 __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM * WN == 4 ? 1 : 1)) void conv3p_kernel(ConvParams p) {
   using C = C3<BN, WM, WN, LPW>;
   using G = Geo<LPW>;
@@ -1079,9 +1084,10 @@ const char* conv3p_check(const ConvParams& p) {
     if (!p.out && !p.out_pool) return "conv3p: no output";
     if ((p.bias && ((uintptr_t)p.bias & 15)) || ((uintptr_t)p.in0 & 15) || ((uintptr_t)p.wgt & 15)) return "conv3p: operand alignment";
     const size_t lim = (size_t)1 << 31;
-    if (p.split != 3 && p.split != 4) return "conv3p: split must be 3 or 4";
+    if (p.split != 2 && p.split != 3 && p.split != 4) return "conv3p: split must be 2 (packed pairs), 3 or 4";
+    if (p.split == 2 && (p.C0 != 64 || p.Cout > 32)) return "conv3p: packed pairs are the 32-channel layers' form (64 halves per pixel, Cout <= 32)";
     if (p.out_planes != 0 && p.out_planes != 2 && p.out_planes != 3) return "conv3p: out_planes must be 0, 2 or 3";
-    if ((size_t)p.M * p.C0 * (p.split == 4 ? 6 : 4) >= lim || (size_t)p.Cout * 27 * p.C0 * 2 >= lim) return "conv3p: tensor too large for 32-bit buffer offsets";
+    if ((size_t)p.M * p.C0 * (p.split == 4 ? 6 : p.split == 3 ? 4 : 2) >= lim || (size_t)p.Cout * 27 * p.C0 * 2 >= lim) return "conv3p: tensor too large for 32-bit buffer offsets";
     if (p.M != p.B * p.H * p.W || p.M <= 0 || !(p.out_scale > 0.f)) return "conv3p: bad shape";
     return nullptr;
   }
@@ -1128,6 +1134,10 @@ void launch_conv3p(const ConvParams& p, hipStream_t s) {
     }                                                                                                   \
     if (!wide) return narrow ? launch_c3<64, 4, 2, false, 1, 4, NPV>(p, s) : launch_c3<128, 4, 2, false, 1, 4, NPV>(p, s);   \
     return launch_c3<128, 4, 2, false, 1, 5, NPV>(p, s);
+    if (p.split == 2) {   // packed pairs (the 32-channel head layers): one 128-byte row [x0 (32) | x1 (32)] per pixel, two virtual chunks
+      if (!wide) return launch_c3<64, 4, 2, false, 1, 4, 2>(p, s);
+      return launch_c3<32, 4, 1, false, 1, 5, 2>(p, s);
+    }
     if (p.split == 3) { TTR_C3_SPLIT(3) }
     TTR_C3_SPLIT(4)
 #undef TTR_C3_SPLIT

@@ -154,6 +154,24 @@ void Engine::load_craft(const std::string& dir) {
     for (int t = 0; t < taps; ++t)
       for (int ci = 0; ci < c.cin; ++ci) kmap[(size_t)t * cin_pad + ci] = t * c.cin + ci;
     upload_linear(L, w.data.data(), c.cout, taps * c.cin, b.data.data(), cout_pad, taps * cin_pad, &kmap);
+    if (head3 && c.cin == 32) {   // the packed pairs form of the same layer (Linear::wsp), same scale S
+      const float S = 1.f / L.inv_scale;
+      const int kp = taps * 64;
+      std::vector<_Float16> h((size_t)cout_pad * 3 * kp, (_Float16)0.f);
+      for (int o = 0; o < c.cout; ++o)
+        for (int t = 0; t < taps; ++t)
+          for (int ci = 0; ci < 32; ++ci) {
+            const float v = w.data[(size_t)o * taps * 32 + t * 32 + ci] * S;   // exact (S a power of two)
+            const _Float16 w0 = (_Float16)v;
+            const _Float16 w1 = (_Float16)(v - (float)w0);
+            _Float16* row = h.data() + (size_t)o * 3 * kp;
+            row[t * 64 + ci] = w0;
+            row[t * 64 + 32 + ci] = (_Float16)((float)w0 * (1.f / 2048.f));
+            row[2 * kp + t * 64 + ci] = w1;
+          }
+      L.wsp.ensure(h.size() * 2);
+      TTR_HIP_CHECK(hipMemcpy(L.wsp.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    }
   }
 }
 

@@ -80,6 +80,8 @@ struct Tuning {
   int qkv_kv_pairs = 1;       // the qkv GEMM leaves the third plane of its K and V columns unwritten (the attention kernel reads them as pairs)
   int enc_fc2_pairs = 1;      // ... and the MLP hidden activation as pairs (fc2 on three MFMAs per product; 3 x 640 crops: max |dlogit| 5.1 - 6.7e-4 vs 5.6 - 7.6e-4 with triples); the attention output - the projection input - stays an exact triple: the one encoder linear whose result moves with the 24th bit (oracle/splitsim.py)
   int craft_products = 3;     // split-operand engines, CRAFT: 3 = activation pairs (~23.5 bits; the heat map stays at fp32 noise level), 4 = exact triples
+  int head_packed = 1;        // ... with pairs: the 32-channel head tensors as 128-byte pixel rows [x0 | x1] and conv_cls.0 / .2 / .4 on packed pairs (two virtual
+                              // chunks instead of three over zero-padded 64-channel rows: two thirds of the MFMAs, half the bytes); 0 = zero-padded rows
   int detector_only = 0;      // profiling: drop every detected box, so that a batch runs the detector + CCL only
   int bench_grid_boxes = 0;   // benchmark workload control (bench.py --boxes=grid40): the detector runs in full, then every page's boxes are replaced by a fixed 5 x 8 grid
   int split_planes = 1;       // split-operand engines: activations stay in planes between the layers (0: fp32 tensors + a split pass in front of every GEMM)
@@ -107,6 +109,7 @@ struct Tuning {
     else if (k == "bench_grid_boxes") bench_grid_boxes = value;
     else if (k == "detector_only") detector_only = value;
     else if (k == "craft_products") craft_products = value == 4 ? 4 : 3;
+    else if (k == "head_packed") head_packed = value;
     else if (k == "enc_ln_pairs") enc_ln_pairs = value;
     else if (k == "enc_fc2_pairs") enc_fc2_pairs = value;
     else if (k == "qkv_kv_pairs") qkv_kv_pairs = value;
@@ -202,6 +205,8 @@ struct Linear {
   int cout = 0, k = 0;  // padded sizes as the kernel sees them
   int cout_valid = 0;   // != 0: the layer's own output count, below `cout` (PARSeq's head: 95 classes in 96 weight rows, so that it has f16 planes); the kernels get this as Cout
   DevBuf ws;            // split-operand engines (split.h): f16 [cout][3][k] = w0 | w0/2^11 | w1 of w S
+  DevBuf wsp;           // ... CRAFT's 3x3 layers of 32 input channels, PACKED pairs form (conv3p.hip, NP = 2): f16 [cout][3][taps * 64], per tap
+                        // plane 0 = [w0 (32) | w0 / 2^11 (32)], plane 1 unused, plane 2 = [w1 (32) | 0]; multiplies pixel rows [x0 (32) | x1 (32)]
   float inv_scale = 0;  // 1 / S
 };
 
@@ -452,7 +457,7 @@ struct Engine {
   // value); the convolutions' epilogues write them (bias, ReLU, ReLU copy, 2x2 max-pool fused), so no fp32 tensor and no separate
   // split pass exists up to the 32-channel head, which stays on the fp32 MFMA kernel (thin layers: 3 % of the FLOPs).
   void sconv(const char* name, const void* in0, int C0, const void* in1, int C1, int B, int H, int W, void* out, int act,
-             void* out_relu = nullptr, void* out_pool = nullptr, int pool_relu = 0, int out_planes = -1, int out_ld = 0);
+             void* out_relu = nullptr, void* out_pool = nullptr, int pool_relu = 0, int out_planes = -1, int out_ld = 0, bool packed = false);
   void craft_forward_split(const uint8_t* d_canvas, int B, int H, int W, float* d_heat);
 
   // ---- PARSeq

@@ -114,10 +114,22 @@ void Engine::craft_forward(const uint8_t* d_canvas, int B, int H, int W, float* 
 }
 
 void Engine::sconv(const char* name, const void* in0, int C0, const void* in1, int C1, int B, int H, int W, void* out, int act,
-           void* out_relu, void* out_pool, int pool_relu, int out_planes, int out_ld) {
+           void* out_relu, void* out_pool, int pool_relu, int out_planes, int out_ld, bool packed) {
   const int np = tn.craft_products == 4 ? 4 : 3;             // products per value: 3 = activation pairs (default), 4 = exact triples
   if (out_planes < 0) out_planes = np - 1;
   const Linear& L = craft.at(name);
+  if (packed) {   // a 32-channel layer on packed pairs: in0 = pixel rows [x0 (32) | x1 (32)] (a pairs tensor of 32 channels), weights Linear::wsp
+    if (np != 3 || C0 != 64 || C1 || !L.wsp.p || L.k != 9 * 64) throw std::runtime_error(std::string("packed split conv: wrong layer ") + name);
+    ConvParams p{};
+    p.in0 = in0; p.C0 = 64; p.B = B; p.H = H; p.W = W; p.ks = 3; p.dil = 1;
+    p.wgt = L.wsp.p; p.bias = L.b.as<float>(); p.split = 2; p.out_scale = L.inv_scale; p.out_planes = out_planes;
+    p.out = out; p.out_ld = out_ld ? out_ld : L.cout; p.Cout = L.cout; p.M = B * H * W; p.act = act;
+    if (const char* e = conv3p_check(p)) throw std::runtime_error(std::string(name) + ": " + e);
+    double flops = 0;
+    for (const auto& c : craft_convs()) if (std::string(c.name) == name) flops = 2.0 * p.M * c.cout * c.ks * c.ks * c.cin;
+    timed("conv3p_kernel<32,NP=2> (packed pairs, 32 input channels)", flops, 2.0 * p.M * L.cout * 9 * 64 * 2, [&] { launch_conv3p(p, stream); });
+    return;
+  }
   ConvParams p{};
   p.in0 = in0; p.C0 = C0; p.in1 = in1; p.C1 = C1; p.B = B; p.H = H; p.W = W;
   const int Ct = C0 + C1;
@@ -145,10 +157,11 @@ void Engine::craft_forward_split(const uint8_t* d_canvas, int B, int H, int W, f
   const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8, H4 = H / 16, W4 = W / 16;
   size_t k = 0;
   const int npl = tn.craft_products == 4 ? 3 : 2;                                       // planes per value
-  if (npl != craft_ws_npl) {   // another plane count: the zero padding channels of the head tensors sit elsewhere - start from fresh buffers
+  const int layout = npl * 2 + (tn.head_packed && npl == 2 ? 1 : 0);   // (plane count and the head tensors' row form: both move the zero padding channels)
+  if (layout != craft_ws_npl) {   // another plane count: the zero padding channels of the head tensors sit elsewhere - start from fresh buffers
     TTR_HIP_CHECK(hipStreamSynchronize(stream));
     craft_ws.clear();
-    craft_ws_npl = npl;
+    craft_ws_npl = layout;
   }
   auto pbuf = [&](size_t rows, int C) -> void* { return ws(k++, rows * C * 2 * npl).p; };   // planes
   auto fbuf = [&](size_t rows, int C) -> void* { return ws(k++, rows * C * 4).p; };   // fp32
@@ -186,11 +199,20 @@ void Engine::craft_forward_split(const uint8_t* d_canvas, int B, int H, int W, f
   void* u4a = pbuf(M1, 64);  sconv("upconv4.0", up3, 64, c22, 128, B, H1, W1, u4a, kActRelu);
   // 32-channel head: the 3x3 layers on the f16 kernels over planes with 32 zero channels behind the 32 real ones (row = 64 channels);
   // the two 1x1 layers (16 -> 16 -> 2) on the fp32 MFMA kernel
+  // (head_packed, pairs only: the 32-channel tensors as 128-byte pixel rows [x0 | x1], their consumers on packed pairs - conv3p.hip, NP = 2)
+  void *u4b, *h0, *h2, *h4 = nullptr;
+  if (tn.head_packed && npl == 2 && H1 % 8 == 0 && W1 % 32 == 0) {
+    u4b = pbuf(M1, 32); sconv("upconv4.3", u4a, 64, nullptr, 0, B, H1, W1, u4b, kActRelu);
+    h0 = pbuf(M1, 32);  sconv("conv_cls.0", u4b, 64, nullptr, 0, B, H1, W1, h0, kActRelu, nullptr, nullptr, 0, -1, 0, true);
+    h2 = pbuf(M1, 32);  sconv("conv_cls.2", h0, 64, nullptr, 0, B, H1, W1, h2, kActRelu, nullptr, nullptr, 0, -1, 0, true);
+    h4 = fbuf(M1, 32);  sconv("conv_cls.4", h2, 64, nullptr, 0, B, H1, W1, h4, kActRelu, nullptr, nullptr, 0, /*out_planes=*/0, 0, true);   // fp32, 16 real + 16 zero channels
+  } else {
   auto zbuf = [&](size_t rows) -> void* { return ws(k++, rows * 64 * 2 * npl, true).p; };
-  void* u4b = zbuf(M1); sconv("upconv4.3", u4a, 64, nullptr, 0, B, H1, W1, u4b, kActRelu, nullptr, nullptr, 0, -1, 64);
-  void* h0 = zbuf(M1);  sconv("conv_cls.0", u4b, 64, nullptr, 0, B, H1, W1, h0, kActRelu, nullptr, nullptr, 0, -1, 64);
-  void* h2 = zbuf(M1);  sconv("conv_cls.2", h0, 64, nullptr, 0, B, H1, W1, h2, kActRelu, nullptr, nullptr, 0, -1, 64);
-  void* h4 = fbuf(M1, 32); sconv("conv_cls.4", h2, 64, nullptr, 0, B, H1, W1, h4, kActRelu, nullptr, nullptr, 0, /*out_planes=*/0);   // fp32, 16 real + 16 zero channels
+  u4b = zbuf(M1); sconv("upconv4.3", u4a, 64, nullptr, 0, B, H1, W1, u4b, kActRelu, nullptr, nullptr, 0, -1, 64);
+  h0 = zbuf(M1);  sconv("conv_cls.0", u4b, 64, nullptr, 0, B, H1, W1, h0, kActRelu, nullptr, nullptr, 0, -1, 64);
+  h2 = zbuf(M1);  sconv("conv_cls.2", h0, 64, nullptr, 0, B, H1, W1, h2, kActRelu, nullptr, nullptr, 0, -1, 64);
+  h4 = fbuf(M1, 32); sconv("conv_cls.4", h2, 64, nullptr, 0, B, H1, W1, h4, kActRelu, nullptr, nullptr, 0, /*out_planes=*/0);   // fp32, 16 real + 16 zero channels
+  }
   {   // the two 1x1 head layers stay on the fp32 MFMA kernel (restored also when a launch throws)
     struct Restore { int& v; int keep; ~Restore() { v = keep; } } restore{tn.split_gemm, tn.split_gemm};
     tn.split_gemm = 0;

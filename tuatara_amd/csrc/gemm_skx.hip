@@ -27,7 +27,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t skx_rsrc(const void* base, uns
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 __device__ __forceinline__ f16x8 skx_load(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
-  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
   return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
 }
 constexpr int SKX_BN = 32, SKX_DEPTH = 3;
