@@ -148,6 +148,7 @@ def test_x4_craft_head_on_packed_pairs_equals_zero_padded_rows(eng_x4_random, we
     """The 32-channel head tensors as 128-byte pixel rows [x0 | x1] with conv_cls.0 / .2 / .4 on packed pairs (conv3p.hip, NP = 2: the default)
     against the same layers over zero-padded 64-channel rows: the same three products per value (x0 w0 + x1 w0 / 2^11 in one chunk, x0 w1 in
     the other), so the heat maps agree to the last bits of an fp32 sum taken in another order, and both stay at fp32 noise from the oracle.
+    Likewise conv_cls.6 / conv_cls.8 as the epilogue of conv_cls.4's tile (pairs x pairs on the matrix cores) against the two fp32 launches.
     Switching back and forth re-lays the workspaces out (the zero padding sits elsewhere)."""
     from oracle import pipeline
     craft_r, _ = pipeline.load_models(weights_random["craft"], weights_random["parseq"])
@@ -155,18 +156,24 @@ def test_x4_craft_head_on_packed_pairs_equals_zero_padded_rows(eng_x4_random, we
     ref = pipeline.craft_heatmap(craft_r, canvas)
     eng = eng_x4_random
     try:
-        a = eng.craft_heatmap(canvas)
+        a = eng.craft_heatmap(canvas)                       # the default: packed pairs, conv_cls.6 / .8 inside conv_cls.4's epilogue
+        assert eng.set_tuning(b"head_tail", 0) == 0
+        t = eng.craft_heatmap(canvas)                       # packed pairs, the two 1x1 layers as fp32 MFMA launches
         assert eng.set_tuning(b"head_packed", 0) == 0
-        b = eng.craft_heatmap(canvas)
-        assert eng.set_tuning(b"head_packed", 1) == 0
+        b = eng.craft_heatmap(canvas)                       # zero-padded rows
+        assert eng.set_tuning(b"head_packed", 1) == 0 and eng.set_tuning(b"head_tail", 1) == 0
         c = eng.craft_heatmap(canvas)
     finally:
         eng.set_tuning(b"head_packed", 1)
+        eng.set_tuning(b"head_tail", 1)
     assert np.array_equal(a, c)
     scale = max(1.0, float(np.abs(ref).max()))
-    print(f"CRAFT 256x512 random weights: packed head {np.abs(a - ref).max():.2e}, zero-padded {np.abs(b - ref).max():.2e}, packed vs padded {np.abs(a - b).max():.2e}")
-    assert np.abs(a - b).max() < 1e-5 * scale, float(np.abs(a - b).max())
-    assert np.abs(a - ref).max() < TOL * scale and np.abs(b - ref).max() < TOL * scale
+    print(f"CRAFT 256x512 random weights: fused tail {np.abs(a - ref).max():.2e}, packed head {np.abs(t - ref).max():.2e}, zero-padded {np.abs(b - ref).max():.2e}; "
+          f"packed vs padded {np.abs(t - b).max():.2e}, fused tail vs fp32 tail {np.abs(a - t).max():.2e}")
+    assert np.abs(t - b).max() < 1e-5 * scale, float(np.abs(t - b).max())
+    assert np.abs(a - t).max() < 1e-5 * scale, float(np.abs(a - t).max())
+    for h in (a, t, b):
+        assert np.isfinite(h).all() and np.abs(h - ref).max() < TOL * scale
 
 
 @pytest.mark.parametrize("hw", [(256, 192), (96, 160), (64, 96)])

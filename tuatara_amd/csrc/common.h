@@ -52,6 +52,10 @@ struct ConvParams {
   // out_planes == 3: columns from out_full_cols on may leave their third plane unwritten (0 = write every plane everywhere).  PARSeq's qkv output:
   // the attention kernel reads K and V as pairs, so only the 384 Q columns need the triple - a fifth of the layer's store traffic
   int out_full_cols;
+  // conv3p.hip, packed pairs (split = 2), CRAFT's conv_cls.4 only: the two 1x1 layers behind it (16 -> 16 ReLU -> 2) as the epilogue of its tile;
+  // nothing but the heat map is written.  tail_w6 / tail_w8: f16 [16 rows][w0 | w1][32 k] (fragment rows; conv_cls.8's k slot 8 g + e holds
+  // channel 4 g + e for e < 4), tail_b6 [16], tail_b8 [2], tail_s6 / tail_s8 = 1 / S of the two tensors, tail_heat f32 [M][2]
+  const void* tail_w6; const void* tail_w8; const float* tail_b6; const float* tail_b8; float tail_s6, tail_s8; float* tail_heat;
 };
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

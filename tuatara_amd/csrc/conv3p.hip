@@ -386,6 +386,35 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
       }
+      if constexpr (NP == 2) {
+        if (p.tail_heat) {
+          // conv_cls.6 + ReLU + conv_cls.8 on this pixel (the reference's last two convolutions, inside CRAFT's module run at tuatara.cpp:376):
+          // the lane's 8 values are channels 8 g + e of pixel fr - an MFMA B fragment (k = channel) as they stand.  conv_cls.6 = W6 (16 x 32 k) times
+          // them: C[channel 4 g + r][pixel]; its 4 values per lane are, with zeros behind them, the B fragment of conv_cls.8, whose weight rows
+          // were laid out for exactly that k order.  Pairs x pairs, three MFMAs per product, as everywhere in CRAFT.
+          const f16 dn = (f16)(1.f / 2048.f);
+          const f16x8 dnv = {dn, dn, dn, dn, dn, dn, dn, dn};
+          const f16* w6 = reinterpret_cast<const f16*>(p.tail_w6) + fr * 64 + fg * 8;
+          const f16* w8 = reinterpret_cast<const f16*>(p.tail_w8) + fr * 64 + fg * 8;
+          const f16x8 a0 = *reinterpret_cast<const f16x8*>(w6), a1 = *reinterpret_cast<const f16x8*>(w6 + 32);
+          const f16x8 c0 = *reinterpret_cast<const f16x8*>(w8), c1 = *reinterpret_cast<const f16x8*>(w8 + 32);
+          f16x8 x0, x1;
+          split2_x8(v, x0, x1);
+          f32x4 t6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          t6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0 * dnv, x1, t6, 0, 0, 0);
+          t6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x0, t6, 0, 0, 0);
+          const float4 b6 = *reinterpret_cast<const float4*>(p.tail_b6 + 4 * fg);
+          float y[8] = {fmaxf(fmaf(t6[0], p.tail_s6, b6.x), 0.f), fmaxf(fmaf(t6[1], p.tail_s6, b6.y), 0.f), fmaxf(fmaf(t6[2], p.tail_s6, b6.z), 0.f),
+                        fmaxf(fmaf(t6[3], p.tail_s6, b6.w), 0.f), 0.f, 0.f, 0.f, 0.f};
+          f16x8 y0, y1;
+          split2_x8(y, y0, y1);
+          f32x4 t8 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c0, y0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          t8 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c0 * dnv, y1, t8, 0, 0, 0);
+          t8 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, y0, t8, 0, 0, 0);
+          if (fg == 0) *reinterpret_cast<float2*>(p.tail_heat + m * 2) = make_float2(fmaf(t8[0], p.tail_s8, p.tail_b8[0]), fmaf(t8[1], p.tail_s8, p.tail_b8[1]));
+          continue;
+        }
+      }
       if constexpr (SP) {
         if (p.out) st_split_n(p.out, m, p.out_ld, n, v, p.out_planes);
         if (p.out_relu) {
@@ -1081,7 +1110,9 @@ const char* conv3p_check(const ConvParams& p) {
     if (p.out && (p.out_ld % ov || ((uintptr_t)p.out & 15))) return "conv3p: output alignment";
     if (p.out_relu && (!p.out || ((uintptr_t)p.out_relu & 15))) return "conv3p: out_relu alignment";
     if (p.out_pool && (p.out_ld % ov || ((uintptr_t)p.out_pool & 15) || (p.H | p.W) & 1)) return "conv3p: out_pool alignment";
-    if (!p.out && !p.out_pool) return "conv3p: no output";
+    if (!p.out && !p.out_pool && !(p.split == 2 && p.tail_heat)) return "conv3p: no output";
+    if (p.tail_heat && (p.split != 2 || p.Cout != 32 || !p.tail_w6 || !p.tail_w8 || !p.tail_b6 || !p.tail_b8 || (((uintptr_t)p.tail_w6 | (uintptr_t)p.tail_w8 | (uintptr_t)p.tail_b6) & 15)))
+      return "conv3p: the fused head tail belongs to conv_cls.4 on packed pairs (32 output channels)";
     if ((p.bias && ((uintptr_t)p.bias & 15)) || ((uintptr_t)p.in0 & 15) || ((uintptr_t)p.wgt & 15)) return "conv3p: operand alignment";
     const size_t lim = (size_t)1 << 31;
     if (p.split != 2 && p.split != 3 && p.split != 4) return "conv3p: split must be 2 (packed pairs), 3 or 4";

@@ -154,6 +154,7 @@ void Engine::load_craft(const std::string& dir) {
     for (int t = 0; t < taps; ++t)
       for (int ci = 0; ci < c.cin; ++ci) kmap[(size_t)t * cin_pad + ci] = t * c.cin + ci;
     upload_linear(L, w.data.data(), c.cout, taps * c.cin, b.data.data(), cout_pad, taps * cin_pad, &kmap);
+    if (prec == kSplit && nm == "conv_cls.8") load_head_tail(wf);
     if (head3 && c.cin == 32) {   // the packed pairs form of the same layer (Linear::wsp), same scale S
       const float S = 1.f / L.inv_scale;
       const int kp = taps * 64;
@@ -173,6 +174,36 @@ void Engine::load_craft(const std::string& dir) {
       TTR_HIP_CHECK(hipMemcpy(L.wsp.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
     }
   }
+}
+
+// conv_cls.6 (16 -> 16) and conv_cls.8 (16 -> 2) as weight pairs in the fragment rows conv3p.hip's fused head tail multiplies from
+void Engine::load_head_tail(WeightFile& wf) {
+  auto planes = [](const std::vector<float>& w, int rows, int cols, bool slot_order, std::vector<_Float16>& out, float& inv_scale) {
+    float mx = 0.f;
+    for (float v : w) mx = std::max(mx, std::fabs(v));
+    int e = 0;
+    if (mx > 0.f) { (void)std::frexp(mx, &e); e = 14 - e; }
+    e = std::max(-24, std::min(40, e));
+    const float S = std::ldexp(1.f, e);
+    inv_scale = std::ldexp(1.f, -e);
+    out.assign((size_t)16 * 64, (_Float16)0.f);                       // [16 rows][w0 (32 k) | w1 (32 k)]
+    for (int r = 0; r < rows; ++r)
+      for (int c = 0; c < cols; ++c) {
+        const float v = w[(size_t)r * cols + c] * S;
+        const _Float16 w0 = (_Float16)v, w1 = (_Float16)(v - (float)w0);
+        const int k = slot_order ? 8 * (c >> 2) + (c & 3) : c;         // conv_cls.8: channel 4 g + e sits in k slot 8 g + e
+        out[(size_t)r * 64 + k] = w0; out[(size_t)r * 64 + 32 + k] = w1;
+      }
+  };
+  const auto& w6 = wf.get("conv_cls.6.w", 16 * 16).data; const auto& b6 = wf.get("conv_cls.6.b", 16).data;
+  const auto& w8 = wf.get("conv_cls.8.w", 2 * 16).data;  const auto& b8 = wf.get("conv_cls.8.b", 2).data;
+  std::vector<_Float16> h;
+  planes(w6, 16, 16, false, h, head_tail.s6);
+  head_tail.w6.ensure(h.size() * 2); TTR_HIP_CHECK(hipMemcpy(head_tail.w6.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  planes(w8, 2, 16, true, h, head_tail.s8);
+  head_tail.w8.ensure(h.size() * 2); TTR_HIP_CHECK(hipMemcpy(head_tail.w8.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  upload_f32(head_tail.b6, b6.data(), 16);
+  upload_f32(head_tail.b8, b8.data(), 2);
 }
 
 void Engine::load_parseq(const std::string& dir) {

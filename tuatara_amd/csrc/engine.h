@@ -80,6 +80,7 @@ struct Tuning {
   int qkv_kv_pairs = 1;       // the qkv GEMM leaves the third plane of its K and V columns unwritten (the attention kernel reads them as pairs)
   int enc_fc2_pairs = 1;      // ... and the MLP hidden activation as pairs (fc2 on three MFMAs per product; 3 x 640 crops: max |dlogit| 5.1 - 6.7e-4 vs 5.6 - 7.6e-4 with triples); the attention output - the projection input - stays an exact triple: the one encoder linear whose result moves with the 24th bit (oracle/splitsim.py)
   int craft_products = 3;     // split-operand engines, CRAFT: 3 = activation pairs (~23.5 bits; the heat map stays at fp32 noise level), 4 = exact triples
+  int head_tail = 1;          // ... and the two 1x1 layers behind conv_cls.4 inside its epilogue (no 16-channel tensors, two launches less); 0 = fp32 MFMA launches
   int head_packed = 1;        // ... with pairs: the 32-channel head tensors as 128-byte pixel rows [x0 | x1] and conv_cls.0 / .2 / .4 on packed pairs (two virtual
                               // chunks instead of three over zero-padded 64-channel rows: two thirds of the MFMAs, half the bytes); 0 = zero-padded rows
   int detector_only = 0;      // profiling: drop every detected box, so that a batch runs the detector + CCL only
@@ -110,6 +111,7 @@ struct Tuning {
     else if (k == "detector_only") detector_only = value;
     else if (k == "craft_products") craft_products = value == 4 ? 4 : 3;
     else if (k == "head_packed") head_packed = value;
+    else if (k == "head_tail") head_tail = value;
     else if (k == "enc_ln_pairs") enc_ln_pairs = value;
     else if (k == "enc_fc2_pairs") enc_fc2_pairs = value;
     else if (k == "qkv_kv_pairs") qkv_kv_pairs = value;
@@ -321,6 +323,8 @@ struct Engine {
 
   // CRAFT
   std::map<std::string, Linear> craft;
+  // split-operand engines: conv_cls.6 / conv_cls.8 as the epilogue of conv_cls.4's packed-pairs tile (ConvParams::tail_*, conv3p.hip)
+  struct HeadTail { DevBuf w6, w8, b6, b8; float s6 = 0, s8 = 0; } head_tail;
   // PARSeq
   std::map<std::string, Linear> pq;               // linears by upstream name
   std::map<std::string, DevBuf> pqf;              // f32 vectors (LayerNorm params, pos embed, ...)
@@ -430,6 +434,7 @@ struct Engine {
     return 384 * t + 64 * h + 32 * wn + dd;
   }
 
+  void load_head_tail(WeightFile& wf);
   void load_parseq(const std::string& dir);
 
   bool verbose = false;
@@ -457,7 +462,7 @@ struct Engine {
   // value); the convolutions' epilogues write them (bias, ReLU, ReLU copy, 2x2 max-pool fused), so no fp32 tensor and no separate
   // split pass exists up to the 32-channel head, which stays on the fp32 MFMA kernel (thin layers: 3 % of the FLOPs).
   void sconv(const char* name, const void* in0, int C0, const void* in1, int C1, int B, int H, int W, void* out, int act,
-             void* out_relu = nullptr, void* out_pool = nullptr, int pool_relu = 0, int out_planes = -1, int out_ld = 0, bool packed = false);
+             void* out_relu = nullptr, void* out_pool = nullptr, int pool_relu = 0, int out_planes = -1, int out_ld = 0, bool packed = false, float* tail_heat = nullptr);
   void craft_forward_split(const uint8_t* d_canvas, int B, int H, int W, float* d_heat);
 
   // ---- PARSeq

@@ -114,7 +114,7 @@ void Engine::craft_forward(const uint8_t* d_canvas, int B, int H, int W, float* 
 }
 
 void Engine::sconv(const char* name, const void* in0, int C0, const void* in1, int C1, int B, int H, int W, void* out, int act,
-           void* out_relu, void* out_pool, int pool_relu, int out_planes, int out_ld, bool packed) {
+           void* out_relu, void* out_pool, int pool_relu, int out_planes, int out_ld, bool packed, float* tail_heat) {
   const int np = tn.craft_products == 4 ? 4 : 3;             // products per value: 3 = activation pairs (default), 4 = exact triples
   if (out_planes < 0) out_planes = np - 1;
   const Linear& L = craft.at(name);
@@ -124,10 +124,17 @@ void Engine::sconv(const char* name, const void* in0, int C0, const void* in1, i
     p.in0 = in0; p.C0 = 64; p.B = B; p.H = H; p.W = W; p.ks = 3; p.dil = 1;
     p.wgt = L.wsp.p; p.bias = L.b.as<float>(); p.split = 2; p.out_scale = L.inv_scale; p.out_planes = out_planes;
     p.out = out; p.out_ld = out_ld ? out_ld : L.cout; p.Cout = L.cout; p.M = B * H * W; p.act = act;
-    if (const char* e = conv3p_check(p)) throw std::runtime_error(std::string(name) + ": " + e);
-    double flops = 0;
+    double flops = 0, tail_flops = 0;
     for (const auto& c : craft_convs()) if (std::string(c.name) == name) flops = 2.0 * p.M * c.cout * c.ks * c.ks * c.cin;
-    timed("conv3p_kernel<32,NP=2> (packed pairs, 32 input channels)", flops, 2.0 * p.M * L.cout * 9 * 64 * 2, [&] { launch_conv3p(p, stream); });
+    if (tail_heat) {   // conv_cls.4 with conv_cls.6 + conv_cls.8 as its epilogue: nothing but the heat map leaves the kernel
+      p.out = nullptr; p.tail_heat = tail_heat;
+      p.tail_w6 = head_tail.w6.p; p.tail_w8 = head_tail.w8.p; p.tail_b6 = head_tail.b6.as<float>(); p.tail_b8 = head_tail.b8.as<float>();
+      p.tail_s6 = head_tail.s6; p.tail_s8 = head_tail.s8;
+      tail_flops = 2.0 * p.M * (16 * 16 + 2 * 16);
+    }
+    if (const char* e = conv3p_check(p)) throw std::runtime_error(std::string(name) + ": " + e);
+    timed(tail_heat ? "conv3p_kernel<32,NP=2> + conv_cls.6 + conv_cls.8 (head tail)" : "conv3p_kernel<32,NP=2> (packed pairs, 32 input channels)", flops + tail_flops,
+          2.0 * p.M * L.cout * 9 * 64 * 2 + (tail_heat ? 2.0 * p.M * 16 * 32 * 6 : 0.0), [&] { launch_conv3p(p, stream); });
     return;
   }
   ConvParams p{};
@@ -205,6 +212,11 @@ void Engine::craft_forward_split(const uint8_t* d_canvas, int B, int H, int W, f
     u4b = pbuf(M1, 32); sconv("upconv4.3", u4a, 64, nullptr, 0, B, H1, W1, u4b, kActRelu);
     h0 = pbuf(M1, 32);  sconv("conv_cls.0", u4b, 64, nullptr, 0, B, H1, W1, h0, kActRelu, nullptr, nullptr, 0, -1, 0, true);
     h2 = pbuf(M1, 32);  sconv("conv_cls.2", h0, 64, nullptr, 0, B, H1, W1, h2, kActRelu, nullptr, nullptr, 0, -1, 0, true);
+    if (tn.head_tail && head_tail.w6.p) {
+      sconv("conv_cls.4", h2, 64, nullptr, 0, B, H1, W1, nullptr, kActRelu, nullptr, nullptr, 0, /*out_planes=*/0, 0, true, d_heat);   // + conv_cls.6 + conv_cls.8
+      prof_break();
+      return;
+    }
     h4 = fbuf(M1, 32);  sconv("conv_cls.4", h2, 64, nullptr, 0, B, H1, W1, h4, kActRelu, nullptr, nullptr, 0, /*out_planes=*/0, 0, true);   // fp32, 16 real + 16 zero channels
   } else {
   auto zbuf = [&](size_t rows) -> void* { return ws(k++, rows * 64 * 2 * npl, true).p; };
