@@ -9,8 +9,14 @@ crop-batch packer -> PARSeq -> token ids), each over one batch of `--pages` synt
 inputs already resident in HBM.  Page-level data parallelism: each rank owns its pages and a
 full weights replica (weak scaling); for N > 1 the decoded token ids of every rank are
 all-gathered with RCCL inside the timed region, device buffer to device buffer, by the engine's C++
-host (include/tuatara_hip.h, "multi-GPU") - the only exchange the path has.  torch.distributed.run is
-only the launcher: this process never imports torch.  Rank 0 prints ONE JSON line.
+host (include/tuatara_hip.h, "multi-GPU") - the only exchange the path has.  `python3 bench.py --gpus N`
+starts its N ranks itself (tuatara_amd/launch.py: one child process per GPU, rank 0's line relayed, non-zero
+exit when a rank fails or hangs); under `python -m torch.distributed.run ... bench.py --gpus N` the launcher's
+ranks are used as they come.  The ranks never import torch.  Rank 0 prints ONE JSON line.
+
+`roofline` follows SURVEY.md section 8(d): the dominant kernel (by time in the timed region), its launches and
+average duration, `achieved` = its ALGORITHMIC flops / its time, `frac` = achieved / the dense f16 MFMA peak;
+what the matrix pipe executes for it (x 3 or x 4 in the split-operand precision) is `mfma_pipe_frac`.
 
 `value` is measured in the engine's DEFAULT precision, f16x4 (fp32-equivalent split-operand f16 MFMA: logits
 within 1e-3 of the CPU fp32 reference, identical boxes and strings - tests/test_gpu_x4_parity.py); the bf16 and

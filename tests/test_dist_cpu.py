@@ -112,7 +112,7 @@ def test_shard_helpers():
 
 
 def test_cpp_gather_layout_matches_the_restatement():
-    """ttr_gather_layout is the framing the C++ host uses for the RCCL gather (GatherLayout, engine.cpp): host logic, runs without a GPU."""
+    """ttr_gather_layout is the framing the C++ host uses for the RCCL gather (GatherLayout, engine.h): host logic, runs without a GPU."""
     from tuatara_amd.build import build_lib
     from tuatara_amd.engine import gather_layout
     build_lib()

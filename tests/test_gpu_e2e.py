@@ -337,7 +337,7 @@ def test_converted_torchscript_archives_end_to_end(tmp_path, oracle_models, funs
 
 
 def test_craft_group_size_does_not_change_results(eng_bf16):
-    """The detector walks a batch in launch groups of `craft_group` pages (default 16; engine.cpp detect_enqueue).  Group size
+    """The detector walks a batch in launch groups of `craft_group` pages (default 16; engine_pages.cpp detect_enqueue).  Group size
     is scheduling only: 40 pages of 1024x768 give the same boxes and strings in groups of 16, 20 and 32 (32 pages put the
     widest activation at 1.6 GB - the 32-bit buffer-offset window is 2 GiB - and the fused first pair past 2^31 virtual input
     bytes, the case conv3p_check sizes by the u8 canvas instead)."""

@@ -14,8 +14,9 @@ LAYERS = ["slice1.0+slice1.3 +pool", "slice1.7", "slice1.10 (skip relu2_2 + pool
 # the f16x4 engine's 27 launches per group (nothing fused across layers but the pools and the ReLU copies)
 LAYERS_X4 = ["slice1.0 (conv1_split, u8 canvas -> planes)", "slice1.3 +pool", "slice1.7", "slice1.10 (skip relu2_2 + pooled)", "slice2.14", "slice2.17 (skip relu3_2 + relu copy)",
              "slice3.20 +pool", "slice3.24", "slice3.27 (skip relu4_3 + relu copy)", "slice4.30 +pool", "slice4.34", "slice4.37 (skip relu5_3)", "slice5.1 (dil 6)", "slice5.2",
-             "upconv1.0", "upconv1.3", "upconv2.0", "upconv2.3", "upconv3.0", "upconv3.3", "upconv4.0", "upconv4.3", "conv_cls.0", "conv_cls.2", "conv_cls.4",
-             "conv_cls.6 (fp32)", "conv_cls.8 (fp32)"]
+             "upconv1.0", "upconv1.3", "upconv2.0", "upconv2.3", "upconv3.0", "upconv3.3", "upconv4.0", "upconv4.3 (-> packed 32-channel rows)", "conv_cls.0 (packed pairs)",
+             "conv_cls.2 (packed pairs)", "conv_cls.4 + .6 + .8 (packed pairs, fused tail)"]
+LAYERS_X4_UNFUSED = LAYERS_X4[:-1] + ["conv_cls.4", "conv_cls.6 (fp32)", "conv_cls.8 (fp32)"]
 
 
 def rows(path, counter):
@@ -27,8 +28,9 @@ def rows(path, counter):
 f, w = rows(fetch_csv, "FETCH_SIZE"), rows(write_csv, "WRITE_SIZE")
 n = len(LAYERS)
 per_step = len(f) // 3 if len(f) % 3 == 0 else n
-if per_step == len(LAYERS_X4):
-    LAYERS, n = LAYERS_X4, len(LAYERS_X4)
+if f and "conv1_split" in f[-per_step]["Kernel_Name"]:       # the f16x4 engine's group (its first launch is conv1_split)
+    LAYERS = LAYERS_X4 if per_step == len(LAYERS_X4) else LAYERS_X4_UNFUSED
+    n = len(LAYERS)
 f, w = f[-per_step:], w[-per_step:]
 # a 25th launch per step (an igemm fall-back for a thin layer) keeps its kernel name as label
 layers = []
@@ -36,7 +38,7 @@ li = 0
 for a, b in zip(f, w):
     us = (int(a["End_Timestamp"]) - int(a["Start_Timestamp"])) * 1e-3
     fb, wb = 2 * 1024 * float(a["Counter_Value"]), 1024 * float(b["Counter_Value"])
-    name = LAYERS[li] if li < n and per_step in (n, n + 1) else a["Kernel_Name"][:40]    # a 25th launch: the igemm fall-back of a thin layer
+    name = LAYERS[li] if li < n and per_step in (n, n + 1) else a["Kernel_Name"][:40]    # (a launch more than the list: the igemm fall-back of a thin layer keeps its kernel name)
     li += 1
     layers.append({"layer": name, "kernel": a["Kernel_Name"][:60], "us_under_profiler": round(us, 1), "fetch_MB": round(fb / 1e6, 1), "write_MB": round(wb / 1e6, 1),
                    "hbm_GB_per_s": round((fb + wb) / us / 1e3, 1), "frac_of_8TBps": round((fb + wb) / us / 1e3 / 8000.0, 3)})

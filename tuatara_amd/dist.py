@@ -5,7 +5,7 @@ tuatara_amd.engine.Comm) - and needs no torch.  What is left here:
   * how work is dealt out: page p -> rank p % G (throughput mode), contiguous crop shards (latency mode);
   * the same record framing and the same latency-mode schedule over torch.distributed, for the CPU tests (backend "gloo",
     world_size 2: tests/test_dist_cpu.py) - counts first, then the payload, nothing truncated - mirroring
-    GatherLayout / Engine::run_pages_sharded of tuatara_amd/csrc/engine.cpp.
+    GatherLayout (engine.h) / Engine::detect_collect and Engine::run_pages_sharded (engine_pages.cpp).
 """
 from __future__ import annotations
 
