@@ -500,6 +500,9 @@ def main():
             eng.pages_to_data_dev(one, 1, H, Wd)
             lat.append((time.perf_counter() - t1) * 1e3)
         out["p50_page_latency_ms"] = float(np.median(lat)) if lat else None
+        hu = eng.last_host_us()          # host wall-clock splits of the last single-page call (microseconds)
+        out["single_page_host_us"] = {"enqueue_detector": hu[0], "wait_for_ccl": hu[1], "copy_components": hu[2], "calipers_and_boxes": hu[3],
+                                      "enqueue_recogniser": hu[4], "wait_for_ids": hu[5], "decode_strings": hu[7]}
         # the same passes with the host -> device copy of every pass's pages inside the span (pageable numpy -> HBM, synchronous
         # hipMemcpy before each push: the un-overlapped upper bound of what a caller holding host buffers pays) -- never `value`
         stacks = [np.stack(host_pages[b]) for b in range(3)]

@@ -182,3 +182,21 @@ def test_world_size_two_on_one_gpu_over_the_socket_transport(weights):
                 p.kill()
     for r, (rc, o, e) in enumerate(outs):
         assert rc == 0 and f"OK rank {r}" in o, (r, rc, o[-800:], e[-3000:])
+
+
+def test_bench_starts_its_own_ranks_two_ranks_on_one_gpu(weights):
+    """`python3 bench.py --gpus 2` as the driver would start it, on a single-GPU box: the launcher's two ranks share device 0 and speak over the
+    framed TCP transport (TUATARA_BENCH_SHARE_GPU=1: a pre-flight, not a measurement) - launcher, rank bodies, stage watchdog, header / counts /
+    payload gathers of every streamed pass, the max-over-ranks time and the single JSON line, all but RCCL itself."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(TUATARA_BENCH_SHARE_GPU="1", TUATARA_PRELOAD_TORCH="0", TUATARA_COMM_TIMEOUT="240")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pages", "8", "--buffers", "3", "--deadline", "800"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, (out.stdout[-500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["gathered_id_rows_last_pass"] == 2 * 8 * 40                      # every page of both ranks: 40 rows of 26 ids
+    assert d["config"]["pages_per_gpu_per_pass"] == 8 and "SHARE one GPU" in d["config"]["parallelism"]
