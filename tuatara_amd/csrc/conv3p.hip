@@ -1143,20 +1143,24 @@ const char* conv3p_check(const ConvParams& p) {
 }
 
 // tile width (output channels per workgroup) launch_conv3p picks for a split-operand layer: 128, 64 or 32 (the profile's kernel kinds)
+static int g_narrow_wide = 1;    // 8 x 32-patch layers too take 64-wide tiles when 128-wide ones would leave workgroup slots empty (0: round 3's rule, 16 x 16-patch layers only)
+static int g_narrow_frac = 8;    // ... "empty" = fewer tiles than g_narrow_frac / 4 per CU (8: two per CU, the kernels' residency)
+void set_conv3p_narrow_wide(int v) { g_narrow_wide = v; }
+void set_conv3p_narrow_frac(int v) { g_narrow_frac = v < 1 ? 1 : v; }
 int conv3p_split_bn(const ConvParams& p) {
   const bool wide = p.H % 8 == 0 && p.W % 32 == 0;
   if (p.Cout <= 64) return (wide && p.Cout <= 32) ? 32 : 64;
-  if (wide) return 128;
-  const int tiles128 = p.B * (p.H / 16) * (p.W / 16) * ((p.Cout + 127) / 128);
-  return tiles128 < 2 * device_cu_count(256) ? 64 : 128;
+  const int tiles128 = p.B * (wide ? (p.H / 8) * (p.W / 32) : (p.H / 16) * (p.W / 16)) * ((p.Cout + 127) / 128);
+  const bool narrow = tiles128 < g_narrow_frac * device_cu_count(256) / 4 && (!wide || g_narrow_wide);
+  return narrow ? 64 : 128;
 }
 
 void launch_conv3p(const ConvParams& p, hipStream_t s) {
   if (const char* e = conv3p_check(p)) throw std::runtime_error(e);
   if (p.split) {   // the one-patch-stage tiles (two workgroups per CU)
     const bool wide = p.H % 8 == 0 && p.W % 32 == 0;
-    const int tiles128 = wide ? 0 : p.B * (p.H / 16) * (p.W / 16) * ((p.Cout + 127) / 128);
-    const bool narrow = !wide && tiles128 < 2 * device_cu_count(256);
+    const int tiles128 = p.B * (wide ? (p.H / 8) * (p.W / 32) : (p.H / 16) * (p.W / 16)) * ((p.Cout + 127) / 128);
+    const bool narrow = tiles128 < g_narrow_frac * device_cu_count(256) / 4 && (!wide || g_narrow_wide);   // fewer 128-wide tiles than workgroup slots: 64-wide tiles fill the chip (a single page)
 #define TTR_C3_SPLIT(NPV)                                                                               \
     if (p.Cout <= 64) {                                                                                 \
       if (!wide) return launch_c3<64, 4, 2, false, 1, 4, NPV>(p, s);                                    \
@@ -1164,7 +1168,7 @@ void launch_conv3p(const ConvParams& p, hipStream_t s) {
       return launch_c3<64, 4, 2, false, 1, 5, NPV>(p, s);                                               \
     }                                                                                                   \
     if (!wide) return narrow ? launch_c3<64, 4, 2, false, 1, 4, NPV>(p, s) : launch_c3<128, 4, 2, false, 1, 4, NPV>(p, s);   \
-    return launch_c3<128, 4, 2, false, 1, 5, NPV>(p, s);
+    return narrow ? launch_c3<64, 4, 2, false, 1, 5, NPV>(p, s) : launch_c3<128, 4, 2, false, 1, 5, NPV>(p, s);
     if (p.split == 2) {   // packed pairs (the 32-channel head layers): one 128-byte row [x0 (32) | x1 (32)] per pixel, two virtual chunks
       if (!wide) return launch_c3<64, 4, 2, false, 1, 4, 2>(p, s);
       return launch_c3<32, 4, 1, false, 1, 5, 2>(p, s);
