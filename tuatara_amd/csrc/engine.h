@@ -481,6 +481,7 @@ struct Engine {
   const int* cur_skip = nullptr; int cur_skip_n = 0;
   DevBuf ar_done;
   PinnedBuf h_ar_done;
+  bool streaming_recog = false;   // set around the recogniser of a STREAMED batch: no host-side wait there (the stream holds the next batch's detector)
   size_t kvcache_zeroed = 0;
   void ln(const float* x, const std::string& name, float eps, void* out, int M);
 

@@ -331,7 +331,12 @@ void Engine::stream_push(const uint8_t* d_pages, int n, int h, int w, std::vecto
   { RangeScope r("ttr:detect_enqueue"); try { detect_enqueue(B); } catch (...) { if (!comm) throw; pre = std::current_exception(); } }
   host_us[0] = (float)(now_us() - th0);
   const double th1 = now_us();
-  if (q1.live && !q1.enqueued) { RangeScope r("ttr:recog_enqueue"); recog_enqueue(q1); }
+  if (q1.live && !q1.enqueued) {
+    RangeScope r("ttr:recog_enqueue");
+    struct Flag { bool& f; ~Flag() { f = false; } } flag{streaming_recog};
+    streaming_recog = true;
+    recog_enqueue(q1);
+  }
   host_us[4] = (float)(now_us() - th1);
   { RangeScope r("ttr:detect_collect"); detect_collect(B, pre); }
   if (q2.live) { RangeScope r("ttr:finish"); prev_n = q2.n; finish(q2, prev_results); }

@@ -326,7 +326,7 @@ void Engine::parseq_forward(const uint8_t* d_crops, int N, float* d_logits, floa
     if (i + 1 < 26 && !tok_fuse) launch_argmax(ar + (size_t)i * 95, 26 * 95, 95, tk, 26, i + 1, N, stream, cur_skip, cur_skip_n, early ? ar_done.as<int>() : nullptr, 0);
     // the latency regime (a page or two of crops): every remaining step is ~14 launches that return at once when the batch is done - half a
     // millisecond of them for ten-character words.  The host looks at the counter (one small synchronous read) and stops enqueuing instead
-    if (early && !tok_fuse && tn.ar_host_check > 0 && N <= 256 && i >= tn.ar_host_check && (i - tn.ar_host_check) % 4 == 0 && i + 1 < nsteps) {
+    if (early && !tok_fuse && !streaming_recog && tn.ar_host_check > 0 && N <= 256 && i >= tn.ar_host_check && (i - tn.ar_host_check) % 4 == 0 && i + 1 < nsteps) {
       h_ar_done.ensure(64);
       TTR_HIP_CHECK(hipMemcpyAsync(h_ar_done.p, ar_done.p, 4, hipMemcpyDeviceToHost, stream));
       TTR_HIP_CHECK(hipStreamSynchronize(stream));
