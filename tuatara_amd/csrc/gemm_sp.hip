@@ -36,6 +36,15 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t sp_rsrc(const void* bas
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
+// fp32 output stores are streaming (nt): a launch writes 0.25 GB that nothing reads before the next launch, through an L2 of 4 MB per XCD that also
+// holds the weight planes every tile re-reads; a lane's 32 bytes and its three neighbours' make whole 128-byte lines (fc2 -3 %, proj -2 % at 1280
+// crops).  The f16 plane outputs keep the default policy: a row block contributes 64-byte pieces that only meet their other half in L2, and
+// streamed they reach the memory as partial writes (fc1 +5 %, qkv + attention +2 %; HBM fetch of fc1 848 -> 337 MB per launch all the same).
+static __device__ __forceinline__ void sp_store_f32x8(float* o, const float (&v)[8]) {
+  __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(o));
+  __builtin_nontemporal_store(f32x4{v[4], v[5], v[6], v[7]}, reinterpret_cast<f32x4*>(o + 4));
+}
+
 template <int BM, int BN, int WM, int WN, int XST, int WST>
 struct SpCfg {
   static constexpr int NW = WM * WN, NT = NW * 64;
@@ -376,7 +385,6 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
       constexpr int KV = 16384;                                   // one plane of K or V: 128 rows x 128 B
       unsigned char* const sQ = smem + C::LDS;                    // [4 wm][2 reader wn][3 planes][64 lanes][16 B]
       unsigned char* const sK = sQ + 24576;                       // [2 planes][128 rows][128 B]; V afterwards
-      __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0): the prefetched tiles have landed (they were requested >= a phase ago)
       const float osc = p.out_scale;
       // lane-constant LDS offsets (few, so that they stay in registers across the K loop): everything else is an immediate
       const int kR0 = wm * 32 + (((fr >> 2) & 1) << 4) + ((fr >> 3) << 2) + (fr & 3);   // LDS row of key 32 wm + q (key + 16: row + 8)
@@ -520,6 +528,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
 #undef TTR_SPA_TR
       }
       // out planes [M][3][384]: oacc[2u], oacc[2u+1] hold d = 32 u + 8 g + 0..7 of query q
+      __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0), in front of the first store: the prefetched tiles have landed (requested an epilogue ago)
       {
         f16* const op = reinterpret_cast<f16*>(p.out) + (int64_t)(m0c + wm * 32 + wn * 16 + fr) * (3 * 384) + (n0c / 192) * 64 + fg * 8;
 #pragma unroll
@@ -540,31 +549,67 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
       read_x(fx0); read_w(fw0);
       continue;
     }
-    // ---- epilogue: lane holds channels n = nb + 32t + (lane>>4)*8 + 0..7 of row m = mb + 16i + (lane&15)
-#pragma unroll
-    for (int t = 0; t < C::NJ / 2; ++t) {
-      const int n = n0c + wn * C::TN + t * 32 + fg * 8;
-      if (n >= p.Cout) continue;
-      float bv[8];
-      if (p.bias) {
-        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
-        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = 0.f;
-      }
+    // ---- epilogue: lane holds channels n = nb + 32t + (lane>>4)*8 + 0..7 of row m = mb + 16i + (lane&15).  Two passes.  Pass 1 issues EVERY
+    // vector-memory load of the epilogue (bias, residual rows: buffer loads, out-of-range lanes read zeros, no branches) and folds them into the
+    // accumulators in place; pass 2 (activation, planes, stores) loads nothing.  Mixed, a load behind a store costs a full drain of the stores:
+    // the counter counts both, they complete out of order with respect to each other, so the compiler can only wait for vmcnt(0) - the
+    // one-pass form did that once per 16-row block, eight write round trips per tile.
+    {
+      const __amdgpu_buffer_rsrc_t rsb = sp_rsrc(p.bias, p.bias ? (unsigned)p.Cout * 4u : 0u);
+      const int64_t rrows = p.resid_mod ? p.resid_mod : p.M;
+      const __amdgpu_buffer_rsrc_t rsr = sp_rsrc(p.resid, p.resid ? (unsigned)(rrows * p.resid_ld * 4) : 0u);
+      unsigned rrow[C::MI];
 #pragma unroll
       for (int i = 0; i < C::MI; ++i) {
         const int m = m0c + wm * C::TM + i * 16 + fr;
-        if (m >= p.M) continue;
+        rrow[i] = m < p.M ? (unsigned)(p.resid_mod ? m % p.resid_mod : m) * (unsigned)p.resid_ld * 4u : OOB;
+      }
+      const float osc = p.out_scale;
+#pragma unroll
+      for (int t = 0; t < C::NJ / 2; ++t) {   // per 32-channel block: its loads in flight together, then the sums
+        const int n = n0c + wn * C::TN + t * 32 + fg * 8;
+        const unsigned ncol = n < p.Cout ? (unsigned)n * 4u : OOB;
+        const f32x4 b0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsb, ncol, 0, 0));
+        const f32x4 b1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsb, ncol, 16, 0));
+        if (p.resid) {
+          f32x4 rv[C::MI][2];
+#pragma unroll
+          for (int i = 0; i < C::MI; ++i) {
+            const unsigned ro = (ncol != OOB && rrow[i] != OOB) ? rrow[i] + ncol : OOB;
+            rv[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsr, ro, 0, 0));
+            rv[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsr, ro, 16, 0));
+          }
+#pragma unroll
+          for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              acc[2 * t][i][e] = fmaf(acc[2 * t][i][e], osc, b0[e]) + rv[i][0][e];
+              acc[2 * t + 1][i][e] = fmaf(acc[2 * t + 1][i][e], osc, b1[e]) + rv[i][1][e];
+            }
+        } else {
+#pragma unroll
+          for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              acc[2 * t][i][e] = fmaf(acc[2 * t][i][e], osc, b0[e]);
+              acc[2 * t + 1][i][e] = fmaf(acc[2 * t + 1][i][e], osc, b1[e]);
+            }
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the loads above (and the K loop's prefetch, requested a phase and more ago); no store is out yet
+    // (rows outside, channel blocks inside: the 64-byte pieces a row's blocks contribute to one 128-byte line leave back to back)
+#pragma unroll
+    for (int i = 0; i < C::MI; ++i) {
+      const int m = m0c + wm * C::TM + i * 16 + fr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int t = 0; t < C::NJ / 2; ++t) {
+        const int n = n0c + wn * C::TN + t * 32 + fg * 8;
+        if (n >= p.Cout) continue;
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = fmaf(acc[2 * t][i][e], p.out_scale, bv[e]); v[4 + e] = fmaf(acc[2 * t + 1][i][e], p.out_scale, bv[4 + e]); }
-        if (p.resid) {
-          const float* rp = p.resid + (int64_t)(p.resid_mod ? m % p.resid_mod : m) * p.resid_ld + n;
-          const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
-          v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-        }
+        for (int e = 0; e < 4; ++e) { v[e] = acc[2 * t][i][e]; v[4 + e] = acc[2 * t + 1][i][e]; }
         if (p.act == kActRelu) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -579,20 +624,15 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
             split3_x8(v, a, b, c);
             f16* o = reinterpret_cast<f16*>(p.out) + (int64_t)m * (3 * (int64_t)p.out_ld) + n;
             *reinterpret_cast<f16x8*>(o) = a; *reinterpret_cast<f16x8*>(o + p.out_ld) = b;
-          } else st_split_n(p.out, (int64_t)m, p.out_ld, n, v, p.out_planes);
+          } else if (p.out_planes) st_split_n(p.out, (int64_t)m, p.out_ld, n, v, p.out_planes);
+          else sp_store_f32x8(reinterpret_cast<float*>(p.out) + (int64_t)m * p.out_ld + n, v);
         }
-        if (p.out_f32) {
-          float* op = p.out_f32 + (int64_t)m * p.out_f32_ld + n;
-          *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        }
+        if (p.out_f32) sp_store_f32x8(p.out_f32 + (int64_t)m * p.out_f32_ld + n, v);
       }
     }
-    // Every vector-memory load has landed, in the compiler's book-keeping too: an epilogue load it still counts as pending here (the bias of
-    // a channel block whose rows were all skipped) would make it put its own s_waitcnt vmcnt(0) INSIDE the K loop, in front of the first
-    // MFMA that reuses that load's registers - a wait for every prefetch in flight, every k0.  The youngest prefetch was requested a phase
-    // and an epilogue ago: this wait is free.
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) (gfx9 encoding: expcnt 7, lgkmcnt 15 = no wait)
+    // The stores drain here (gfx9 encoding: expcnt 7, lgkmcnt 15 = no wait): the K loop's counted waits would take them for loads in flight.  (Leaving them
+    // in flight under the next tile's first k0 - what that k0 reads was requested before the epilogue - was measured: no gain, profiles/r03_pmc_stall_parseq.txt §3.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     if (!has_next) break;
   }   // (the streams' trailing out-of-range loads, which target this workgroup's LDS, have landed: the wait above)
 }
@@ -623,6 +663,7 @@ void set_gemm_sp_sched(int v) { g_sp_sched = v; }
 bool gemm_sp_eligible(const ConvParams& p) {
   if ((p.split != 3 && p.split != 4) || p.ks != 1 || p.C1 != 0 || p.out_pool || p.out_relu || p.C0 % 64 != 0 || p.Cout % 8 != 0) return false;
   if (p.split == 3 ? p.C0 < 192 : (p.C0 < 128 || (p.C0 >> 6) % 2 != 0)) return false;
+  if (p.resid && (size_t)(p.resid_mod ? p.resid_mod : p.M) * p.resid_ld * 4 >= ((size_t)1 << 31)) return false;   // the epilogue reads the residual through a buffer descriptor
   return (size_t)p.M * p.C0 * (p.split == 3 ? 4 : 6) < ((size_t)1 << 31) && (size_t)p.Cout * p.C0 * 6 < ((size_t)1 << 31);
 }
 

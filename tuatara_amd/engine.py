@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
-_LIBPATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtuatara_hip.so")
+_LIBPATH = os.environ.get("TUATARA_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtuatara_hip.so")   # (TUATARA_LIB: another build of the same ABI, for same-box A/B timing)
 _lib = None
 
 PREC_BF16, PREC_F32, PREC_F16X4 = 0, 1, 2
