@@ -1147,8 +1147,16 @@ static int g_narrow_wide = 1;    // 8 x 32-patch layers too take 64-wide tiles w
 static int g_narrow_frac = 8;    // ... "empty" = fewer tiles than g_narrow_frac / 4 per CU (8: two per CU, the kernels' residency)
 void set_conv3p_narrow_wide(int v) { g_narrow_wide = v; }
 void set_conv3p_narrow_frac(int v) { g_narrow_frac = v < 1 ? 1 : v; }
+static int g_narrowest_frac = 4; // 32-wide tiles (four waves) when even the 64-wide ones number fewer than g_narrowest_frac / 4 per CU: the deep layers of a single page
+void set_conv3p_narrowest_frac(int v) { g_narrowest_frac = v < 0 ? 0 : v; }
+// (the K loop, and with it every sum's order, is the same on every tile width: a page's result does not depend on the batch it came in)
+static bool c3_narrowest(const ConvParams& p, bool wide) {
+  const int tiles64 = p.B * (wide ? (p.H / 8) * (p.W / 32) : (p.H / 16) * (p.W / 16)) * ((p.Cout + 63) / 64);
+  return p.Cout > 32 && tiles64 < g_narrowest_frac * device_cu_count(256) / 4;
+}
 int conv3p_split_bn(const ConvParams& p) {
   const bool wide = p.H % 8 == 0 && p.W % 32 == 0;
+  if (c3_narrowest(p, wide)) return 32;
   if (p.Cout <= 64) return (wide && p.Cout <= 32) ? 32 : 64;
   const int tiles128 = p.B * (wide ? (p.H / 8) * (p.W / 32) : (p.H / 16) * (p.W / 16)) * ((p.Cout + 127) / 128);
   const bool narrow = tiles128 < g_narrow_frac * device_cu_count(256) / 4 && (!wide || g_narrow_wide);
@@ -1161,7 +1169,9 @@ void launch_conv3p(const ConvParams& p, hipStream_t s) {
     const bool wide = p.H % 8 == 0 && p.W % 32 == 0;
     const int tiles128 = p.B * (wide ? (p.H / 8) * (p.W / 32) : (p.H / 16) * (p.W / 16)) * ((p.Cout + 127) / 128);
     const bool narrow = tiles128 < g_narrow_frac * device_cu_count(256) / 4 && (!wide || g_narrow_wide);   // fewer 128-wide tiles than workgroup slots: 64-wide tiles fill the chip (a single page)
+    const bool narrowest = c3_narrowest(p, wide);
 #define TTR_C3_SPLIT(NPV)                                                                               \
+    if (narrowest) return wide ? launch_c3<32, 4, 1, false, 1, 5, NPV>(p, s) : launch_c3<32, 4, 1, false, 1, 4, NPV>(p, s);   \
     if (p.Cout <= 64) {                                                                                 \
       if (!wide) return launch_c3<64, 4, 2, false, 1, 4, NPV>(p, s);                                    \
       if (p.Cout <= 32) return launch_c3<32, 4, 1, false, 1, 5, NPV>(p, s);                             \

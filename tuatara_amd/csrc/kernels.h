@@ -71,9 +71,10 @@ void set_conv3s_wgs_per_cu(int v);   // persistent grid: workgroups per CU (defa
 // ---- conv3p.hip (bf16 3x3 conv with a patch-stationary input tile)
 const char* conv3p_check(const ConvParams& p);   // nullptr when conv3p can run the layer
 void launch_conv3p(const ConvParams& p, hipStream_t s);
-int conv3p_split_bn(const ConvParams& p);
+int conv3p_split_bn(const ConvParams& p);   // split-operand layers: the tile width launch_conv3p picks (128 / 64 / 32)
 void set_conv3p_narrow_wide(int v);   // split-operand layers on 8 x 32 patches: 64-wide tiles when 128-wide ones would not fill the workgroup slots (1, default)
-void set_conv3p_narrow_frac(int v);   // ... fewer than v / 4 tiles per CU (default 8)   // split-operand layers: the tile width launch_conv3p picks (128 / 64 / 32)
+void set_conv3p_narrow_frac(int v);   // ... fewer than v / 4 tiles per CU (default 8)
+void set_conv3p_narrowest_frac(int v);   // 32-wide tiles when the 64-wide ones number fewer than v / 4 per CU (default 4; 0 = never)
 void set_conv3p_single_stage_max_cin(int c);
 void set_conv3p_force_bn128(int v);
 void set_conv3p_c64_waves(int w);
