@@ -131,3 +131,25 @@ def test_skinny_and_ring_kernels_agree_and_the_engine_picks_the_skinny_one(eng):
     finally:
         eng.set_tuning("skinny_split", 1)
     assert np.array_equal(i0, i1) and np.abs(l0 - l1).max() < 6e-4      # (two fp32-equivalent paths: each within ~5e-4 of the oracle at |logit| ~ 32)
+
+
+def test_skinny_layernorm_prologue_changes_nothing(eng):
+    """The decoder's LayerNorm + linear pairs as ONE skinny launch (gemm_skx.hip, LayerNorm prologue; tuning key "skx_ln_fuse") against the
+    LayerNorm kernel followed by the skinny linear: the same arithmetic in the same order, so the AR logits, the refined logits and the ids
+    are identical bit for bit - at a page's crop count (three 16-row blocks, the last one ragged), for a single crop, and for 17."""
+    rng = np.random.default_rng(77)
+    for n in (40, 1, 17):
+        crops = rng.integers(0, 256, (n, 32, 128, 3), dtype=np.uint8)
+        try:
+            assert eng.set_tuning("skx_ln_fuse", 0) == 0
+            l0, a0, i0 = eng.parseq_logits(crops, want_ar=True)
+            assert eng.set_tuning("skx_ln_fuse", 1) == 0
+            l1, a1, i1 = eng.parseq_logits(crops, want_ar=True)
+        finally:
+            eng.set_tuning("skx_ln_fuse", 1)
+        assert np.isfinite(l1).all() and np.array_equal(i0, i1) and np.array_equal(l0, l1), n
+        # AR logits: up to each crop's EOS step (behind it the attention kernels skip the crop and its rows hold whatever the buffers held)
+        for c in range(n):
+            eos = np.flatnonzero(i0[c] == 0)
+            upto = int(eos[0]) + 1 if len(eos) else 26
+            assert np.array_equal(a0[c, :upto], a1[c, :upto]), (n, c)

@@ -66,19 +66,33 @@ void Engine::decoder_tail_split(const void* sa, int N, int R, const float* resid
   auto lnp = [&](const std::string& nm, void* out) {
     launch_layernorm_planes(tgt, 384, pqf.at(nm + ".weight").as<float>(), pqf.at(nm + ".bias").as<float>(), 1e-5f, out, rows, stream, 3, cur_skip, cur_skip_n);
   };
+  // LayerNorm + linear: two launches, or - a page's worth of rows (the AR steps of the latency regime) - the skinny kernel with the LayerNorm
+  // as its prologue (gemm_skx.hip, LNP): the same arithmetic, one dependent launch less
+  auto ln_lin = [&](const std::string& nm, const Linear& L, void* out, int out_ld, int act, int out_planes, float* out_f32, int out_f32_ld, const char* kind) {
+    ConvParams p{};
+    p.ln_in = tgt; p.ln_ld = 384; p.ln_gamma = pqf.at(nm + ".weight").as<float>(); p.ln_beta = pqf.at(nm + ".bias").as<float>(); p.ln_eps = 1e-5f;
+    p.C0 = L.k; p.B = 1; p.H = 1; p.W = rows; p.ks = 1; p.dil = 1;
+    p.wgt = L.ws.p; p.bias = L.b.as<float>(); p.split = 4; p.out_scale = L.inv_scale; p.out_planes = out_planes == 1 ? 3 : out_planes;
+    p.out = out; p.out_ld = out_ld; p.out_f32 = out_f32; p.out_f32_ld = out_f32_ld;
+    p.Cout = L.cout_valid ? L.cout_valid : L.cout; p.M = rows; p.act = act;
+    p.skip = cur_skip; p.skip_n = cur_skip_n;
+    if (tn.skx_ln_fuse && tn.skinny_split && L.ws.p && gemm_skx_ln_eligible(p)) {
+      timed(kind, 2.0 * rows * p.Cout * L.k, 2.0 * rows * p.Cout * L.k * 4, [&] { launch_gemm_skx(p, stream); });
+      return;
+    }
+    lnp(nm, pa);
+    sgemm(L, pa, rows, out, out_ld, act, out_planes, out_f32, out_f32_ld, nullptr, 0, 4, 0, 0, kind);
+  };
   sgemm(pq.at("self_out"), sa, rows, nullptr, 0, kActNone, 0, tgt, 384, resid_pos, 384, 4, resid_mod);      // tgt = query + self_attn
-  lnp(d + "norm1", pa);
-  sgemm(pq.at("cross_q"), pa, rows, q384, 384, kActNone, 0);                                                   // fp32 queries for the attention kernel
+  ln_lin(d + "norm1", pq.at("cross_q"), q384, 384, kActNone, 0, nullptr, 0, "dec.norm1 + cross_q");           // fp32 queries for the attention kernel
   launch_dec_cross_attn(kF32, q384, kvmem, pb, N, R, stream, cur_skip, cur_skip_n, done_tok, done_col, 3);    // planes out
   sgemm(pq.at("cross_out"), pb, rows, nullptr, 0, kActNone, 0, tgt, 384, tgt, 384);                            // tgt += cross_attn
-  lnp(d + "norm2", pa);
-  sgemm(pq.at("ffn1"), pa, rows, p1536, 1536, kActGelu, 3);
+  ln_lin(d + "norm2", pq.at("ffn1"), p1536, 1536, kActGelu, 3, nullptr, 0, "dec.norm2 + ffn1");
   sgemm(pq.at("ffn2"), p1536, rows, nullptr, 0, kActNone, 0, tgt, 384, tgt, 384);                              // tgt += ffn
   const Linear& head = pq.at("head");
-  if (head.ws.p && tn.skinny_split && rows <= tn.skinny_max_rows) {   // few rows: the head as a skinny split linear on the final norm's planes
-    lnp("decoder.norm", pa);
-    sgemm(head, pa, rows, nullptr, 0, kActNone, 0, logits_out, logits_ld, nullptr, 0, 4, 0, 0, "dec.head (skinny)");
-  } else ln_gemm(tgt, "decoder.norm", 1e-5f, t384, head, rows, nullptr, 0, kActNone, logits_out, logits_ld);
+  if (head.ws.p && tn.skinny_split && rows <= tn.skinny_max_rows)   // few rows: the head as a skinny split linear on the final norm's planes
+    ln_lin("decoder.norm", head, nullptr, 0, kActNone, 0, logits_out, logits_ld, "dec.norm + head (skinny)");
+  else ln_gemm(tgt, "decoder.norm", 1e-5f, t384, head, rows, nullptr, 0, kActNone, logits_out, logits_ld);
 }
 
 void Engine::decoder_tail(const void* sa, int N, int R, const float* resid_pos, int resid_mod, float* tgt, void* t384, void* t384b, void* t1536,

@@ -32,11 +32,18 @@ __device__ __forceinline__ f16x8 skx_load(__amdgpu_buffer_rsrc_t rs, unsigned vo
 constexpr int SKX_BN = 32, SKX_DEPTH = 3;
 }  // namespace
 
-// RB: 16-row blocks per workgroup (blockIdx.y walks the rows in steps of 16 RB)
-template <int RB>
+// RB: 16-row blocks per workgroup (blockIdx.y walks the rows in steps of 16 RB).
+// LNP (RB = 1, K = 384): the activation rows are LayerNorm(ln_in rows) - fp32 [M][384], ConvParams::ln_* - normalised, split into exact triples and
+// parked in LDS by the workgroup itself (its 16 rows: 24 KB of reads, the arithmetic of layernorm_planes_kernel to the operation), while its first
+// weight fragments are on their way.  An AR step's three LayerNorms (norm1 -> cross-attention query, norm2 -> ffn1, the final norm -> head) lose
+// their launches - three of fourteen dependent launches per step, each a kernel of ~5 us and a hand-over of ~4.
+template <int RB, bool LNP = false>
 __global__ __launch_bounds__(256) void gemm_skx_kernel(ConvParams p) {
+  static_assert(!LNP || RB == 1, "the LayerNorm prologue is the 16-row form's");
   if (p.skip && __builtin_nontemporal_load(p.skip) >= p.skip_n) return;   // AR early exit: uniform, before the barrier
   __shared__ __attribute__((aligned(16))) float part[4][2][RB][64][4];    // the four waves' partial tiles
+  constexpr int XROW = 3 * 384 + 8;                                       // halves per parked row: three planes + 16 bytes (rows 16 bytes apart modulo the banks)
+  __shared__ __attribute__((aligned(16))) f16 xs[LNP ? 16 * XROW : 8];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane & 15, g = lane >> 4;
@@ -57,10 +64,12 @@ __global__ __launch_bounds__(256) void gemm_skx_kernel(ConvParams p) {
   auto fetch = [&](Frags& f, int step) {
     const unsigned ks = (unsigned)step * 64u;                               // 32 halves
     const unsigned dead = step < nsteps ? 0u : OOB;
+    if constexpr (!LNP) {
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
+      for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) f.x[rb][pl] = skx_load(rsx, xo[rb] | dead, ks + (unsigned)(pl * K) * 2u);
+        for (int pl = 0; pl < 3; ++pl) f.x[rb][pl] = skx_load(rsx, xo[rb] | dead, ks + (unsigned)(pl * K) * 2u);
+    }
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
       f.w[cb][0] = skx_load(rsw, wo[cb] | dead, ks);                        // w0
@@ -95,6 +104,38 @@ __global__ __launch_bounds__(256) void gemm_skx_kernel(ConvParams p) {
   const int rounds = (mine + SKX_DEPTH - 1) / SKX_DEPTH;
 #pragma unroll
   for (int d = 0; d < SKX_DEPTH; ++d) { fetch(fb[d], wave + 4 * d); __builtin_amdgcn_sched_barrier(0); }   // (in stage order: the loop's first wait must not cover stage 2)
+  if constexpr (LNP) {
+    // wave w normalises rows w, w + 4, w + 8, w + 12 of the block: 48 lanes x 8 values, as layernorm_planes_kernel
+    constexpr int D = 384;
+    const bool act = lane < 48;
+    const int c = (act ? lane : 0) * 8;
+#pragma unroll 1
+    for (int rr = 0; rr < 4; ++rr) {
+      const int rl = wave + 4 * rr, m = m0 + rl;
+      f16x8 o0 = {0, 0, 0, 0, 0, 0, 0, 0}, o1 = o0, o2 = o0;
+      if (m < p.M) {                                                        // (wave-uniform)
+        const float* x = p.ln_in + (int64_t)m * p.ln_ld + c;
+        float v[8];
+        {
+          const float4 a = *reinterpret_cast<const float4*>(x), b = *reinterpret_cast<const float4*>(x + 4);
+          v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        }
+        float y[8];
+        ln384_row8(v, act, p.ln_gamma + c, p.ln_beta + c, p.ln_eps, y);
+        split3_x8(y, o0, o1, o2);
+      }
+      if (act) {
+        f16* d = xs + rl * XROW + c;
+        *reinterpret_cast<f16x8*>(d) = o0; *reinterpret_cast<f16x8*>(d + D) = o1; *reinterpret_cast<f16x8*>(d + 2 * D) = o2;
+      }
+    }
+    __syncthreads();
+    // K = 384: twelve steps, this wave's are wave, wave + 4, wave + 8 = stages 0, 1, 2 of the one round
+#pragma unroll
+    for (int d = 0; d < SKX_DEPTH; ++d)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) fb[d].x[0][pl] = *reinterpret_cast<const f16x8*>(xs + q * XROW + pl * D + (wave + 4 * d) * 32 + g * 8);
+  }
   for (int r = 0; r < rounds; ++r) {
 #pragma unroll
     for (int d = 0; d < SKX_DEPTH; ++d) {
@@ -176,6 +217,15 @@ __global__ __launch_bounds__(256) void gemm_skx_kernel(ConvParams p) {
 // shapes: exact triples (split = 4), ks = 1, one source, K a multiple of 32, no pooled / ReLU-copy outputs; planes outputs want whole groups of four
 // channels and aligned rows, fp32 outputs take any channel count and row stride (whether the kernel is the faster one for a shape is the
 // caller's call: it is for a few thousand rows at most)
+// the LayerNorm-prologue form: fp32 rows of 384 in, a page's worth of them (the 16-row workgroups)
+bool gemm_skx_ln_eligible(const ConvParams& p) {
+  if (!p.ln_in || !p.ln_gamma || !p.ln_beta || p.C0 != 384 || p.M > 256 || p.ln_ld % 4) return false;
+  if (((uintptr_t)p.ln_in | (uintptr_t)p.ln_gamma | (uintptr_t)p.ln_beta) & 15) return false;
+  ConvParams q = p;
+  q.in0 = p.wgt;   // (any aligned pointer: the planes operand is not read)
+  return gemm_skx_eligible(q);
+}
+
 bool gemm_skx_eligible(const ConvParams& p) {
   if (p.split != 4 || p.ks != 1 || p.C1 != 0 || p.out_pool || p.out_relu || p.M <= 0 || p.Cout <= 0 || p.C0 % 32 != 0 || p.out_full_cols) return false;
   if ((size_t)p.M * p.C0 * 6 >= ((size_t)1 << 31) || (p.M + 63) / 64 > 65535) return false;
@@ -186,6 +236,11 @@ bool gemm_skx_eligible(const ConvParams& p) {
 }
 
 void launch_gemm_skx(const ConvParams& p, hipStream_t s) {
+  if (p.ln_in) {
+    if (!gemm_skx_ln_eligible(p)) throw std::runtime_error("gemm_skx: LayerNorm prologue: shape not supported");
+    hipLaunchKernelGGL((gemm_skx_kernel<1, true>), dim3((p.Cout + SKX_BN - 1) / SKX_BN, (p.M + 15) / 16), dim3(256), 0, s, p);
+    return;
+  }
   if (!gemm_skx_eligible(p)) throw std::runtime_error("gemm_skx: shape not supported");
   // Rows per workgroup: a workgroup streams its rows' activation planes (6 K bytes per row) and its 32 weight rows (4 K bytes each) at what
   // one CU takes in (~64 B / clk), so for a page's worth of rows 16-row workgroups (four times as many of them, each weight row read four

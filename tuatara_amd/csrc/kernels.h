@@ -32,6 +32,7 @@ const void* gelu_hermite_lut_for_current_device();   // float4[512]: one cubic o
 // GELU by that table (g = the table, in LDS)
 // ---- gemm_skx.hip (split-operand skinny linear, M <= 64 rows, whole K per workgroup: the AR steps of a single page)
 bool gemm_skx_eligible(const ConvParams& p);
+bool gemm_skx_ln_eligible(const ConvParams& p);   // ... with the LayerNorm prologue (ConvParams::ln_in: fp32 rows of 384, <= 256 of them)
 void launch_gemm_skx(const ConvParams& p, hipStream_t s);
 // ---- gemm_sk.hip (bf16 skinny GEMM, whole K resident: the per-step decoder linears)
 const char* gemm_sk_check(const ConvParams& p);

@@ -101,4 +101,28 @@ __device__ __forceinline__ void st_split_one(void* out, int64_t row, int ld, int
 __host__ __device__ __forceinline__ constexpr int split_xplane(int q) { return q == 3 ? 0 : q; }
 __host__ __device__ __forceinline__ constexpr int split_wplane(int q) { return q == 0 ? 0 : q == 3 ? 2 : 1; }
 
+// LayerNorm of one 384-wide row held by a wavefront as 48 lanes x 8 consecutive values (lanes 48 - 63 idle, `act` false): y = (v - mean) rstd gamma + beta,
+// two passes over the registers, every multiply-add spelled out so that the kernels which share this (layernorm_planes_kernel, gemm_skx.hip's
+// LayerNorm prologue) round identically whatever the compiler would contract on its own.  All 64 lanes must call it (wave reductions).
+__device__ __forceinline__ void ln384_row8(const float (&v)[8], bool act, const float* gamma8, const float* beta8, float eps, float (&y)[8]) {
+  constexpr int D = 384;
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s += act ? v[e] : 0.f;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s * (1.0f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { const float d = act ? v[e] - mean : 0.f; q = fmaf(d, d, q); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = rsqrtf(fmaf(q, 1.0f / D, eps));
+  const float4 g0 = *reinterpret_cast<const float4*>(gamma8), g1 = *reinterpret_cast<const float4*>(gamma8 + 4);
+  const float4 b0 = *reinterpret_cast<const float4*>(beta8), b1 = *reinterpret_cast<const float4*>(beta8 + 4);
+  const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) y[e] = fmaf(__fmul_rn(v[e] - mean, rstd), gg[e], bb[e]);
+}
+
 }  // namespace ttr

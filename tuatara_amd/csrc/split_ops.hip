@@ -262,25 +262,9 @@ __global__ __launch_bounds__(256) void layernorm_planes_kernel(const float* __re
     const float4 a = *reinterpret_cast<const float4*>(x), b = *reinterpret_cast<const float4*>(x + 4);
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
   }
-  float s = 0.f;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) s += act ? v[e] : 0.f;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  const float mean = s * (1.0f / D);
-  float q = 0.f;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; q += act ? d * d : 0.f; }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-  const float rstd = rsqrtf(q * (1.0f / D) + eps);
-  if (!act) return;
-  const float4 g0 = *reinterpret_cast<const float4*>(gamma + c), g1 = *reinterpret_cast<const float4*>(gamma + c + 4);
-  const float4 b0 = *reinterpret_cast<const float4*>(beta + c), b1 = *reinterpret_cast<const float4*>(beta + c + 4);
-  const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
   V8 o;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) o.v[e] = (v[e] - mean) * rstd * gg[e] + bb[e];
+  ln384_row8(v, act, gamma + c, beta + c, eps, o.v);
+  if (!act) return;
   st_planes<NPL>(out + (int64_t)row * (NPL * D) + c, D, o);
 }
 }  // namespace
