@@ -137,16 +137,29 @@ def test_skinny_layernorm_prologue_changes_nothing(eng):
     """The decoder's LayerNorm + linear pairs as ONE skinny launch (gemm_skx.hip, LayerNorm prologue; tuning key "skx_ln_fuse") against the
     LayerNorm kernel followed by the skinny linear: the same arithmetic in the same order, so the AR logits, the refined logits and the ids
     are identical bit for bit - at a page's crop count (three 16-row blocks, the last one ragged), for a single crop, and for 17."""
+    _fold_check(eng, "skx_ln_fuse", (40, 1, 17))
+
+
+def test_argmax_inside_the_next_steps_embedding_kernel_changes_nothing(eng):
+    """An AR step's argmax (token, first-EOS count) found by the next step's embedding + LayerNorm kernel (tuning key "argmax_fold") instead of by
+    its own launch: same ids, same logits, bit for bit - a page's crops (where the host also looks at the done counter every fourth step
+    and the argmax keeps its own launch there), a single crop, and 300 crops (no host checks: every step folded)."""
+    _fold_check(eng, "argmax_fold", (40, 1, 300))
+
+
+def _fold_check(eng, key, counts):
     rng = np.random.default_rng(77)
-    for n in (40, 1, 17):
+    for n in counts:
         crops = rng.integers(0, 256, (n, 32, 128, 3), dtype=np.uint8)
+        if n >= 8:
+            crops[: n // 2, :, 40:] = 255          # short words too: half the crops are blank behind a third of their width
         try:
-            assert eng.set_tuning("skx_ln_fuse", 0) == 0
+            assert eng.set_tuning(key, 0) == 0
             l0, a0, i0 = eng.parseq_logits(crops, want_ar=True)
-            assert eng.set_tuning("skx_ln_fuse", 1) == 0
+            assert eng.set_tuning(key, 1) == 0
             l1, a1, i1 = eng.parseq_logits(crops, want_ar=True)
         finally:
-            eng.set_tuning("skx_ln_fuse", 1)
+            eng.set_tuning(key, 1)
         assert np.isfinite(l1).all() and np.array_equal(i0, i1) and np.array_equal(l0, l1), n
         # AR logits: up to each crop's EOS step (behind it the attention kernels skip the crop and its rows hold whatever the buffers held)
         for c in range(n):

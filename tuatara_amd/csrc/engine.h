@@ -73,6 +73,7 @@ struct Tuning {
   int skinny_split = 1;       // split-operand engines: linears of <= skinny_max_rows rows (the AR steps: one row per crop) on gemm_skx.hip
   int skinny_max_rows = 2048;
   int skx_ln_fuse = 1;        // split engines, <= 256 rows: the decoder's LayerNorm + linear pairs as one skinny launch (gemm_skx.hip, LayerNorm prologue)
+  int argmax_fold = 1;        // split engines: an AR step's argmax inside the next step's embedding kernel (one dependent launch less per step)
   int ar_host_check = 10;     // split / fp32 engines, batches of <= 256 crops (the latency regime): from this AR step on the host looks at the done counter every fourth
                               // step and stops enqueuing steps once every crop has emitted EOS (upstream's loop does that check every step); 0 = never
   int enc_chunk = 0;          // crops per encoder group (0 = all crops at once)
@@ -100,6 +101,7 @@ struct Tuning {
     else if (k == "skinny_split") skinny_split = value;
     else if (k == "skinny_max_rows") skinny_max_rows = value;
     else if (k == "ar_host_check") ar_host_check = value;
+    else if (k == "argmax_fold") argmax_fold = value;
     else if (k == "skx_ln_fuse") skx_ln_fuse = value;
     else if (k == "qkv_attn_split") qkv_attn_split = value;
     else if (k == "fuse_first") fuse_first = value;

@@ -301,6 +301,7 @@ void Engine::parseq_forward(const uint8_t* d_crops, int N, float* d_logits, floa
   // has emitted EOS by then (the usual case: words are short) it returns at once, instead of ~9 returning launches per step
   const int tail_at = (early && prec == kBF16 && tn.ar_tail_step > 0 && tn.ar_tail_step < nsteps) ? tn.ar_tail_step : 26;
   struct SkipGuard { Engine& E; ~SkipGuard() { E.cur_skip = nullptr; E.cur_skip_n = 0; } } skip_guard{*this};   // also when a launch throws mid-loop
+  int pend_argmax = -1;   // AR step whose logits still await their argmax (dec_embed_ln of the next step takes it)
   for (int i = 0; i < 26; ++i) {
     if (i == tail_at) {
       DecArParams q = dec_params();
@@ -322,7 +323,11 @@ void Engine::parseq_forward(const uint8_t* d_crops, int N, float* d_logits, floa
       p.Cout = L.cout; p.M = N; p.act = kActNone;
       igemm(p, 2.0 * N * L.cout * L.k);
     } else if (dec_split) {
-      launch_dec_embed_ln(prec, tk, emb, posq, gc, bc, 1e-5f, dpa, N, i, i + 1, stream, cur_skip, cur_skip_n, 3);
+      if (pend_argmax >= 0) {   // column i's token = argmax of step i - 1's logits, found by this kernel's waves (one launch less per step)
+        launch_dec_embed_ln(prec, tk, emb, posq, gc, bc, 1e-5f, dpa, N, i, i + 1, stream, cur_skip, cur_skip_n, 3,
+                            ar + (size_t)pend_argmax * 95, 26 * 95, 95, early ? ar_done.as<int>() : nullptr, 0);
+        pend_argmax = -1;
+      } else launch_dec_embed_ln(prec, tk, emb, posq, gc, bc, 1e-5f, dpa, N, i, i + 1, stream, cur_skip, cur_skip_n, 3);
       sgemm(pq.at("self_kv"), dpa, N, (char*)kvcache + (size_t)i * 768 * 4, 26 * 768, kActNone, 0);
     } else {
       launch_dec_embed_ln(prec, tk, emb, posq, gc, bc, 1e-5f, t384, N, i, i + 1, stream, cur_skip, cur_skip_n);
@@ -337,10 +342,15 @@ void Engine::parseq_forward(const uint8_t* d_crops, int N, float* d_logits, floa
     launch_dec_self_attn(prec, qself.as<float>(), kvcache, tk, att, N, 1, i, 0, stream, cur_skip, cur_skip_n);
     decoder_tail(att, N, 1, posq + (size_t)i * E, 1, tgt, t384, d384b, d1536, kvmem, ar + (size_t)i * 95, 26 * 95, crop_done, i);
     }
-    if (i + 1 < 26 && !tok_fuse) launch_argmax(ar + (size_t)i * 95, 26 * 95, 95, tk, 26, i + 1, N, stream, cur_skip, cur_skip_n, early ? ar_done.as<int>() : nullptr, 0);
-    // the latency regime (a page or two of crops): every remaining step is ~14 launches that return at once when the batch is done - half a
+    // the latency regime (a page or two of crops): every remaining step is ~11 launches that return at once when the batch is done - half a
     // millisecond of them for ten-character words.  The host looks at the counter (one small synchronous read) and stops enqueuing instead
-    if (early && !tok_fuse && !streaming_recog && tn.ar_host_check > 0 && N <= 256 && i >= tn.ar_host_check && (i - tn.ar_host_check) % 4 == 0 && i + 1 < nsteps) {
+    const bool host_check = early && !tok_fuse && !streaming_recog && tn.ar_host_check > 0 && N <= 256 && i >= tn.ar_host_check && (i - tn.ar_host_check) % 4 == 0 && i + 1 < nsteps;
+    if (i + 1 < 26 && !tok_fuse) {
+      // the step's argmax: its own launch where the host is about to look at the counter (or nothing follows), else left to the next step's first kernel
+      if (dec_split && tn.argmax_fold && !host_check) pend_argmax = i;
+      else launch_argmax(ar + (size_t)i * 95, 26 * 95, 95, tk, 26, i + 1, N, stream, cur_skip, cur_skip_n, early ? ar_done.as<int>() : nullptr, 0);
+    }
+    if (host_check) {
       h_ar_done.ensure(64);
       TTR_HIP_CHECK(hipMemcpyAsync(h_ar_done.p, ar_done.p, 4, hipMemcpyDeviceToHost, stream));
       TTR_HIP_CHECK(hipStreamSynchronize(stream));

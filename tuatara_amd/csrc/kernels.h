@@ -128,8 +128,9 @@ void launch_attn_enc2(const bf16* qkv, bf16* out, int N, hipStream_t s);        
 void launch_qkv_attn(const bf16* x, const bf16* w, const float* bias, bf16* out, int N, hipStream_t s);
 void set_attn_impl(int v);                                                               // 0: bf16 also uses the first generation
 // content token embedding + norm_c.  rows (n, i) for i in [i0,i1): out row n*(i1-i0)+(i-i0)
-void launch_dec_embed_ln(Precision prec, const int* tokens, const float* emb, const float* pos_q, const float* gamma, const float* beta, float eps,
-                         void* out, int N, int i0, int i1, hipStream_t s, const int* skip = nullptr, int skip_n = 0, int planes = 0);   // planes = 3 (fp32 engines): f16 triple planes out
+void launch_dec_embed_ln(Precision prec, int* tokens, const float* emb, const float* pos_q, const float* gamma, const float* beta, float eps,
+                         void* out, int N, int i0, int i1, hipStream_t s, const int* skip = nullptr, int skip_n = 0, int planes = 0,
+                         const float* prev_logits = nullptr, int prev_ld = 0, int C = 0, int* done_count = nullptr, int eos = 0);   // prev_logits: column i0's token = argmax of these rows first (an AR step)   // planes = 3 (fp32 engines): f16 triple planes out
 // self attention of R query rows per crop against the K/V cache [N][26][768].
 // mode 0 (AR): R == 1, query index qi0, keys 0..qi0.  mode 1 (refine): R == 26, cloze mask + EOS key padding.
 // skip / skip_n: the kernel returns at once when *skip >= skip_n (AR early exit, ConvParams::skip); bf16 per-row kernels only

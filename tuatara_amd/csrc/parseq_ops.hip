@@ -214,16 +214,38 @@ void launch_attn_enc(Precision prec, const void* qkv, void* out, int N, hipStrea
 // ------------------------------------------------------------------ decoder: content embedding + norm_c
 // token i of crop n: i == 0 -> emb[tok] (null context, no position), else pos_q[i-1] + emb[tok].
 // emb is pre-scaled by sqrt(384) at export.  One wave per row.
+// prev_logits (an AR step, i1 == i0 + 1 >= 2): the token of column i0 is not there yet - it is the first maximal index of the previous step's
+// logits row (argmax_kernel's rule), which the row's wave finds first, writes to tokens[n][i0] and counts (done_count: crops whose FIRST EOS
+// this is): the argmax launch between two AR steps folded into the next step's first kernel.
 template <typename T>
-__global__ void dec_embed_ln_kernel(const int* __restrict__ tokens, const float* __restrict__ emb, const float* __restrict__ pos_q,
+__global__ void dec_embed_ln_kernel(int* __restrict__ tokens, const float* __restrict__ emb, const float* __restrict__ pos_q,
                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, T* __restrict__ out, int N, int i0, int i1,
-                                    const int* skip, int skip_n, int planes) {
+                                    const int* skip, int skip_n, int planes, const float* __restrict__ prev_logits, int prev_ld, int C, int* done_count, int eos) {
   if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;   // AR early exit (see ConvParams::skip)
   const int R = i1 - i0;
   int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= N * R) return;
   int n = row / R, i = i0 + row % R;
-  int tok = tokens[n * 26 + i];
+  int tok;
+  if (prev_logits) {
+    const float* x = prev_logits + (int64_t)n * prev_ld;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) { float v = x[c]; if (v > best) { best = v; bi = c; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      float ov = __shfl_xor(best, o); int oi = __shfl_xor(bi, o);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    tok = bi;
+    if (lane == 0) {
+      tokens[n * 26 + i] = bi;
+      if (done_count && bi == eos) {
+        bool first = true;
+        for (int c = 1; c < i; ++c) first = first && tokens[n * 26 + c] != eos;
+        if (first) atomicAdd(done_count, 1);
+      }
+    }
+  } else tok = tokens[n * 26 + i];
   tok = tok < 0 ? 0 : (tok > 96 ? 96 : tok);
   float v[6], s = 0.f;
 #pragma unroll
@@ -246,13 +268,15 @@ __global__ void dec_embed_ln_kernel(const int* __restrict__ tokens, const float*
   }
 }
 
-void launch_dec_embed_ln(Precision prec, const int* tokens, const float* emb, const float* pos_q, const float* gamma, const float* beta, float eps,
-                         void* out, int N, int i0, int i1, hipStream_t s, const int* skip, int skip_n, int planes) {
+void launch_dec_embed_ln(Precision prec, int* tokens, const float* emb, const float* pos_q, const float* gamma, const float* beta, float eps,
+                         void* out, int N, int i0, int i1, hipStream_t s, const int* skip, int skip_n, int planes,
+                         const float* prev_logits, int prev_ld, int C, int* done_count, int eos) {
   int rows = N * (i1 - i0);
   if (rows <= 0) return;
+  if (prev_logits && (i1 != i0 + 1 || i0 < 1)) throw std::runtime_error("dec_embed_ln: the folded argmax belongs to one AR step's column");
   dim3 grid((rows + 3) / 4);
-  if (prec == kBF16) hipLaunchKernelGGL(dec_embed_ln_kernel<bf16>, grid, dim3(256), 0, s, tokens, emb, pos_q, gamma, beta, eps, (bf16*)out, N, i0, i1, skip, skip_n, 0);
-  else hipLaunchKernelGGL(dec_embed_ln_kernel<float>, grid, dim3(256), 0, s, tokens, emb, pos_q, gamma, beta, eps, (float*)out, N, i0, i1, skip, skip_n, planes);
+  if (prec == kBF16) hipLaunchKernelGGL(dec_embed_ln_kernel<bf16>, grid, dim3(256), 0, s, tokens, emb, pos_q, gamma, beta, eps, (bf16*)out, N, i0, i1, skip, skip_n, 0, prev_logits, prev_ld, C, done_count, eos);
+  else hipLaunchKernelGGL(dec_embed_ln_kernel<float>, grid, dim3(256), 0, s, tokens, emb, pos_q, gamma, beta, eps, (float*)out, N, i0, i1, skip, skip_n, planes, prev_logits, prev_ld, C, done_count, eos);
 }
 
 // ------------------------------------------------------------------ decoder self attention
