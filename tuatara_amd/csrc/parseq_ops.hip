@@ -484,6 +484,8 @@ __global__ __launch_bounds__(384) void dec_cross_attn_kernel(const T* __restrict
 // are read once instead of 26 times (1.16 ms -> the read time at 1280 crops).  Head by head: K_h and V_h (128 x 32 floats each) go to LDS, then
 // the 26 x 128 scores, the row softmaxes and P V, every sum in the order dec_cross_attn_kernel uses (d, lanes and j ascending, the same
 // shuffles); the two agree like two fp32 evaluations (tests/test_gpu_x4_parity.py).
+// blockIdx.y: head group (12 / gridDim.y heads each) - a page's few crops spread over the chip (40 crops: 480 workgroups of one head instead of 40 of
+// twelve, 94 -> ~15 us); heads are independent, the sums inside a head keep their order.
 __global__ __launch_bounds__(384) void dec_cross_attn_crop_kernel(const float* __restrict__ q, const float* __restrict__ kvmem, float* __restrict__ out,
                                                                   int R, const int* skip, int skip_n, int planes) {
   if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;
@@ -499,7 +501,8 @@ __global__ __launch_bounds__(384) void dec_cross_attn_crop_kernel(const float* _
     sq[r][c * 4] = v.x; sq[r][c * 4 + 1] = v.y; sq[r][c * 4 + 2] = v.z; sq[r][c * 4 + 3] = v.w;
   }
   const float* kvn = kvmem + (int64_t)n * 128 * 768;
-  for (int h = 0; h < 12; ++h) {
+  const int hper = 12 / (int)gridDim.y, h0 = (int)blockIdx.y * hper;
+  for (int h = h0; h < h0 + hper; ++h) {
     __syncthreads();                       // sq written (first head); the previous head's sk / sv / sp no longer read
     for (int i = t; i < 128 * 8; i += 384) {
       const int j = i >> 3, c = i & 7;
@@ -646,7 +649,8 @@ void launch_dec_cross_attn(Precision prec, const void* q, const void* kvmem, voi
   if (N <= 0) return;
   if (prec == kBF16 && g_cross_mfma && (R == 26 || g_cross_mfma == 2)) return launch_dec_cross_attn_mfma((const bf16*)q, (const bf16*)kvmem, (bf16*)out, N, R, s);   // refinement pass (attn_dec2.hip); 2: the AR steps' single row too
   if (prec != kBF16 && g_cross_crop && R > 1 && R <= 26) {
-    hipLaunchKernelGGL(dec_cross_attn_crop_kernel, dim3(N), dim3(384), 0, s, (const float*)q, (const float*)kvmem, (float*)out, R, skip, skip_n, planes);
+    const int hsplit = N <= 64 ? 12 : N <= 256 ? 4 : N <= 512 ? 2 : 1;   // head groups: enough workgroups for the chip when the crops are few
+    hipLaunchKernelGGL(dec_cross_attn_crop_kernel, dim3(N, hsplit), dim3(384), 0, s, (const float*)q, (const float*)kvmem, (float*)out, R, skip, skip_n, planes);
     return;
   }
   dim3 grid(N * R);
