@@ -67,7 +67,9 @@ int ttr_dbg_split_gemm(ttr_engine* e, const float* x, int M, int K, const float*
   dout.ensure((size_t)M * N * (out_planes ? 2 * out_planes : 4));
   ConvParams p{};
   p.in0 = dxp.p; p.C0 = K; p.B = 1; p.H = 1; p.W = M; p.ks = 1; p.dil = 1;
+  if (E.tn.sp_tiled_w) E.tile_planes(L);                       // (what the engine's own layers hand gemm_sp.hip)
   p.wgt = L.ws.p; p.bias = bias ? L.b.as<float>() : nullptr; p.split = np; p.out_scale = L.inv_scale; p.out_planes = out_planes;
+  p.wgt_tiled = E.tn.sp_tiled_w ? L.wst.p : nullptr;
   if (out_planes) { p.out = dout.p; p.out_ld = N; } else { p.out_f32 = dout.as<float>(); p.out_f32_ld = N; }
   p.resid = resid ? dres.as<float>() : nullptr; p.resid_ld = N;
   p.Cout = N; p.M = M; p.act = act;
@@ -158,7 +160,8 @@ int ttr_dbg_qkv_attn(ttr_engine* e, const float* x, int N, const float* w, const
     for (int n = 0; n < 1152; ++n) { const int src = Engine::qkv_tile_row(n); memcpy(&wp[(size_t)n * 384], &w[(size_t)src * 384], 384 * 4); bp[n] = b[src]; }
     E.upload_linear(L, wp.data(), 1152, 384, bp.data(), 1152, 384, nullptr, false);
     dout.ensure(nx * 6);
-    launch_qkv_attn_split(dxp.p, L.ws.p, L.b.as<float>(), L.inv_scale, dout.p, N, E.stream);
+    if (E.tn.sp_tiled_w) E.tile_planes(L);
+    launch_qkv_attn_split(dxp.p, L.ws.p, L.b.as<float>(), L.inv_scale, dout.p, N, E.stream, E.tn.sp_tiled_w ? L.wst.p : nullptr);
     std::vector<_Float16> h(nx * 3);
     TTR_HIP_CHECK(hipMemcpyAsync(h.data(), dout.p, nx * 6, hipMemcpyDeviceToHost, E.stream));
     TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
@@ -278,6 +281,7 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "g2_split_stream") set_gemm2_split_stream(value);
   else if (k == "g2_split_stream4") set_gemm2_split_stream4(value);
   else if (k == "gsp_sched") set_gemm_sp_sched(value);
+  else if (k == "gsp_few") set_gemm_sp_few(value);
   else if (k == "c3_xs1_max_cin") set_conv3p_single_stage_max_cin(value);
   else if (k == "c3_force_bn128") set_conv3p_force_bn128(value);
   else if (k == "c3_c64_waves") set_conv3p_c64_waves(value);

@@ -24,6 +24,7 @@ struct ConvParams {
   int B, H, W;               // spatial size (stride 1, "same" padding)
   int ks, dil;               // kernel size 1 or 3; dilation
   const void* wgt;           // T [Cout][ks*ks*(C0+C1)]
+  const void* wgt_tiled;     // gemm_sp.hip only, optional: the split weight planes as contiguous 1-KiB loader pieces (Engine::tile_planes); `wgt` stays valid
   const float* bias;         // f32 [Cout] or null
   void* out; int out_ld;     // T output, row stride in elements (may be null)
   float* out_f32; int out_f32_ld;  // optional f32 output

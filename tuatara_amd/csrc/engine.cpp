@@ -125,6 +125,28 @@ void Engine::upload_linear(Linear& L, const float* w, int cout, int k, const flo
   TTR_HIP_CHECK(hipMemcpy(L.b.p, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
 }
 
+// The weight planes of a linear layer once more, as the 1-KiB pieces gemm_sp.hip's loader fetches (ConvParams::wgt_tiled): piece P = 8 rows x 64 halves
+// of one plane and one 64-deep k step, contiguous; [P][plane][k / 64][8][64] with P counting eight-row groups IN THE ORDER OF THE LDS IMAGE - within
+// every 32 output channels, image row lr (0 .. 31) holds channel ((lr & 15) >> 2) * 8 + ((lr >> 4) & 1) * 4 + (lr & 3), the permutation that leaves a
+// lane of the MFMA result 8 consecutive channels (gemm_sp.hip: tile_offsets).  Channels past cout are zero rows.
+void Engine::tile_planes(Linear& L) {
+  if (!L.ws.p || L.k % 64 != 0 || L.cout % 8 != 0) return;
+  const int K = L.k, k64 = K / 64, groups = (L.cout + 31) / 32;
+  std::vector<uint16_t> h((size_t)L.cout * 3 * K), t((size_t)groups * 32 * 3 * K, 0);
+  TTR_HIP_CHECK(hipMemcpy(h.data(), L.ws.p, h.size() * 2, hipMemcpyDeviceToHost));
+  for (int P = 0; P < groups * 4; ++P)
+    for (int j = 0; j < 8; ++j) {
+      const int lr = 8 * (P & 3) + j;
+      const int n = 32 * (P >> 2) + ((lr & 15) >> 2) * 8 + ((lr >> 4) & 1) * 4 + (lr & 3);
+      if (n >= L.cout) continue;
+      for (int pl = 0; pl < 3; ++pl)
+        for (int kb = 0; kb < k64; ++kb)
+          memcpy(&t[((((size_t)P * 3 + pl) * k64 + kb) * 8 + j) * 64], &h[((size_t)n * 3 + pl) * K + (size_t)kb * 64], 128);
+    }
+  L.wst.ensure(t.size() * 2);
+  TTR_HIP_CHECK(hipMemcpy(L.wst.p, t.data(), t.size() * 2, hipMemcpyHostToDevice));
+}
+
 void Engine::upload_f32(DevBuf& d, const float* p, size_t n) {
   d.ensure(n * 4);
   TTR_HIP_CHECK(hipMemcpy(d.p, p, n * 4, hipMemcpyHostToDevice));
@@ -281,6 +303,8 @@ void Engine::load_parseq(const std::string& dir) {
     upload_linear(pq["head"], w.data.data(), 95, E, b.data.data(), 96, E);
     pq["head"].cout_valid = 95;
   } else lin("head", "head.weight", "head.bias", 95, E);
+  if (prec == kSplit)   // gemm_sp.hip's loader pieces of every recogniser linear it may run
+    for (auto& kv : pq) tile_planes(kv.second);
   vec("text_embed.embedding.weight", 97 * E);
   vec("pos_queries", 26 * E);
   // Qself[i] = Wq . norm_q(pos_queries[i]) + bq : crop independent, computed once on the host in fp32

@@ -74,6 +74,7 @@ struct Tuning {
   int skinny_max_rows = 2048;
   int skx_ln_fuse = 1;        // split engines, <= 256 rows: the decoder's LayerNorm + linear pairs as one skinny launch (gemm_skx.hip, LayerNorm prologue)
   int argmax_fold = 1;        // split engines: an AR step's argmax inside the next step's embedding kernel (one dependent launch less per step)
+  int sp_tiled_w = 1;         // split engines: gemm_sp.hip reads the recogniser's weight planes as contiguous 1-KiB pieces (Linear::wst)
   int ar_host_check = 10;     // split / fp32 engines, batches of <= 256 crops (the latency regime): from this AR step on the host looks at the done counter every fourth
                               // step and stops enqueuing steps once every crop has emitted EOS (upstream's loop does that check every step); 0 = never
   int enc_chunk = 0;          // crops per encoder group (0 = all crops at once)
@@ -101,6 +102,7 @@ struct Tuning {
     else if (k == "skinny_split") skinny_split = value;
     else if (k == "skinny_max_rows") skinny_max_rows = value;
     else if (k == "ar_host_check") ar_host_check = value;
+    else if (k == "sp_tiled_w") sp_tiled_w = value;
     else if (k == "argmax_fold") argmax_fold = value;
     else if (k == "skx_ln_fuse") skx_ln_fuse = value;
     else if (k == "qkv_attn_split") qkv_attn_split = value;
@@ -211,6 +213,7 @@ struct Linear {
   int cout = 0, k = 0;  // padded sizes as the kernel sees them
   int cout_valid = 0;   // != 0: the layer's own output count, below `cout` (PARSeq's head: 95 classes in 96 weight rows, so that it has f16 planes); the kernels get this as Cout
   DevBuf ws;            // split-operand engines (split.h): f16 [cout][3][k] = w0 | w0/2^11 | w1 of w S
+  DevBuf wst;           // ... the same planes as the loader pieces of gemm_sp.hip (Engine::tile_planes): f16 [ceil(cout / 32) * 4][3][k / 64][8 rows][64]
   DevBuf wsp;           // ... CRAFT's 3x3 layers of 32 input channels, PACKED pairs form (conv3p.hip, NP = 2): f16 [cout][3][taps * 64], per tap
                         // plane 0 = [w0 (32) | w0 / 2^11 (32)], plane 1 unused, plane 2 = [w1 (32) | 0]; multiplies pixel rows [x0 (32) | x1 (32)]
   float inv_scale = 0;  // 1 / S
@@ -414,6 +417,7 @@ struct Engine {
   // ---- construction
   void upload_linear(Linear& L, const float* w, int cout, int k, const float* bias, int cout_pad, int k_pad,
                      const std::vector<int>* kmap = nullptr, bool own = true);
+  void tile_planes(Linear& L);   // L.ws -> L.wst (gemm_sp.hip's contiguous loader pieces)
   void upload_f32(DevBuf& d, const float* p, size_t n);
 
   static const std::vector<CraftConv>& craft_convs() {

@@ -13,6 +13,7 @@ void Engine::sgemm(const Linear& L, const void* in_planes, int M, void* out, int
   p.out_full_cols = out_full_cols;
   p.in0 = in_planes; p.C0 = L.k; p.B = 1; p.H = 1; p.W = M; p.ks = 1; p.dil = 1;
   p.wgt = L.ws.p; p.bias = L.b.as<float>(); p.split = np; p.out_scale = L.inv_scale; p.out_planes = out_planes == 1 ? 3 : out_planes;   // (1 = triples)
+  p.wgt_tiled = tn.sp_tiled_w ? L.wst.p : nullptr;
   p.out = out; p.out_ld = out_ld; p.out_f32 = out_f32; p.out_f32_ld = out_f32_ld; p.resid = resid; p.resid_ld = resid_ld; p.resid_mod = resid_mod;
   p.Cout = L.cout_valid ? L.cout_valid : L.cout; p.M = M; p.act = act;
   p.skip = cur_skip; p.skip_n = cur_skip_n;
@@ -160,7 +161,7 @@ void Engine::parseq_forward(const uint8_t* d_crops, int N, float* d_logits, floa
           // executed flops: qkv on pairs (x 3), Q K^T and P V on a triple and a pair (x 4)
           const double qa = 2.0 * Mc * 3 * E * E, aa = 2.0 * 2 * nc * 6 * 128.0 * 128 * 64;
           timed("enc.qkv+attention: gemm_sp_kernel<128,192,NP=3,EPI=1>", qa + aa, qa * 3 + aa * 4,
-                [&] { launch_qkv_attn_split(lnp_at(c0), L.ws.p, L.b.as<float>(), L.inv_scale, attp, nc, stream); });
+                [&] { launch_qkv_attn_split(lnp_at(c0), L.ws.p, L.b.as<float>(), L.inv_scale, attp, nc, stream, tn.sp_tiled_w ? L.wst.p : nullptr); });
         } else {
         sgemm(pq.at(p + "qkv"), lnp_at(c0), Mc, bigp, 3 * E, kActNone, 1, nullptr, 0, nullptr, 0, lnpl + 1, 0, tn.qkv_kv_pairs ? E : 0, "enc.qkv");   // (K, V: read as pairs)
         launch_attn_enc_split(bigp, attp, nc, stream);

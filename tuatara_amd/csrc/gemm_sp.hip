@@ -98,7 +98,12 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
 
   const int K = p.C0, nk0 = K >> 6;
   const __amdgpu_buffer_rsrc_t rsx = sp_rsrc(p.in0, (unsigned)((size_t)p.M * K * 2 * PLX));   // rows [x0 | x1 (| x2)]
-  const __amdgpu_buffer_rsrc_t rsw = sp_rsrc(p.wgt, (unsigned)((size_t)p.Cout * K * 6));   // rows [w0 | w0b | w1]
+  // weights: rows [w0 | w0b | w1], or (wgt_tiled) the same halves as 1-KiB pieces [Cout / 8][plane][K / 64][8 rows][64]: what one wave instruction of the
+  // loader fetches is then one contiguous KiB instead of eight 128-byte runs 6 K bytes apart (LDS-DMA from L2: 55 - 65 against 36 - 40 B / clk per CU,
+  // profiles/r03_pmc_stall_parseq.txt section 4), the rows of a piece in the order the LDS image wants them
+  const bool wtiled = p.wgt_tiled != nullptr;
+  const __amdgpu_buffer_rsrc_t rsw = sp_rsrc(wtiled ? p.wgt_tiled : p.wgt, (unsigned)((size_t)((p.Cout + 31) / 32 * 32) * K * 6));
+  const unsigned w_pl1 = wtiled ? (unsigned)(2 * (K >> 6)) * 1024u : (unsigned)K * 4u, w_kstep = wtiled ? 1024u : 128u;   // byte offsets of plane w1 and of one k0
   constexpr unsigned OOB = 0x80000000u;
 
   unsigned char* const xring = smem;
@@ -123,7 +128,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
       const int q16 = row & 15;
       const int nl = (row & ~31) + (q16 >> 2) * 8 + ((row >> 4) & 1) * 4 + (q16 & 3);   // channel held by that LDS row
       const int n = n0 + nl;
-      wo[j] = (live && n < p.Cout) ? ((unsigned)n * (unsigned)(3 * K) + g * 8) * 2u : OOB;
+      if (wtiled) wo[j] = (live && n < p.Cout) ? (unsigned)((n0 + (row & ~7)) >> 3) * (unsigned)(3 * (K >> 6)) * 1024u + (unsigned)((row & 7) * 128 + g * 16) : OOB;
+      else wo[j] = (live && n < p.Cout) ? ((unsigned)n * (unsigned)(3 * K) + g * 8) * 2u : OOB;
     }
   };
 
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
     for (int i = 0; i < C::XPW; ++i) xvo[i] += xdl[i] & mask;
   };
   auto issue_w = [&]() {
-    const unsigned soff = (unsigned)((ws_pl ? 2 * K : 0) + (ws_k << 6)) * 2u;
+    const unsigned soff = (ws_pl ? w_pl1 : 0u) + (unsigned)ws_k * w_kstep;
     unsigned char* sb = wring + ws_slot * C::WBYTES + wave * 1024;
 #pragma unroll
     for (int j = 0; j < C::WPW; ++j) {
@@ -655,6 +661,8 @@ static void launch_sp(const ConvParams& p_in, hipStream_t s) {
   hipLaunchKernelGGL((gemm_sp_kernel<BM, BN, WM, WN, XST, WST, MINB, SCHED, NP, EPI>), dim3(grid), dim3(C::NT), lds, s, p);
 }
 
+static int g_sp_few = 1;   // the few-tile rules of launch_gemm_sp (a page's worth of rows)
+void set_gemm_sp_few(int v) { g_sp_few = v; }
 static int g_sp_sched = 1;   // 1: fragment reads and requests interleaved with the first MFMAs of a phase; 0: in front of them
 void set_gemm_sp_sched(int v) { g_sp_sched = v; }
 
@@ -674,12 +682,22 @@ void launch_gemm_sp(const ConvParams& p, int cfg, hipStream_t s) {
   if (!gemm_sp_eligible(p)) throw std::runtime_error("gemm_sp: shape not supported");
   const bool sched = g_sp_sched != 0;
   const bool table = p.act == kActGelu && p.gelu_lut;
+  const int cus = device_cu_count(256);
+  const int tiles128 = ((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+  // A page's worth of rows: fewer 128 x 128 tiles than half the CUs.  A workgroup alone on its CU walks K at the rate its tiles arrive (~40 B / clk
+  // per CU for these 8-row pieces: 32 KB per phase against 512 cycles of MFMAs), so 64-row tiles on twice as many CUs shorten every phase of the
+  // chain: fc2 at 40 crops (K = 1536, 120 tiles) 44 -> 31 us.  (Deeper rings alone - 3 + 3 on the 128-row tile - changed nothing: not a latency.)
+  const bool few = cfg == 3 && g_sp_few && 2 * tiles128 <= cus;
   if (p.split == 4) {
+    if (few) { launch_sp<64, 128, 2, 2, 3, 2, 2, true, 4>(p, s); return; }
     if (cfg == 6) launch_sp<128, 256, 2, 4, 3, 2, 1, true, 4>(p, s);
     else if (cfg == 2) launch_sp<256, 128, 4, 2, 3, 2, 1, true, 4>(p, s);
     else launch_sp<128, 128, 2, 2, 3, 2, 2, true, 4>(p, s);
     return;
   }
+  // (64 x 64 tiles, two per CU: the same 31 us - the CU's fill rate, not the workgroup's)
+  if (few) { launch_sp<64, 128, 2, 2, 3, 3, 1, true>(p, s); return; }
+  // (a wide layer on one round of 128 x 256 tiles instead - fc1 at 40 crops: 240 - is no faster: 31 -> 32 - 37 us)
   if (cfg == 6) { if (sched) launch_sp<128, 256, 2, 4, 3, 3, 1, true>(p, s); else launch_sp<128, 256, 2, 4, 3, 3, 1, false>(p, s); }
   else if (cfg == 2) { if (sched) launch_sp<256, 128, 4, 2, 3, 3, 1, true>(p, s); else launch_sp<256, 128, 4, 2, 3, 3, 1, false>(p, s); }
   else if (table) { if (sched) launch_sp<128, 128, 2, 2, 2, 2, 2, true>(p, s); else launch_sp<128, 128, 2, 2, 2, 2, 2, false>(p, s); }
@@ -689,13 +707,13 @@ void launch_gemm_sp(const ConvParams& p, int cfg, hipStream_t s) {
 // The encoder's qkv projection + self-attention as ONE launch (EPI = 1 above).  x_pairs: LayerNorm output as f16 pairs [N * 128][2][384];
 // w_planes: the qkv weight planes [1152][3][384] with the rows in HEAD-MAJOR order (row 192 h + 64 c + d = upstream row 384 c + 64 h + d,
 // c = 0 / 1 / 2 for Q / K / V), bias likewise; out: attention output as exact triples [N * 128][3][384] (the projection GEMM's input).
-void launch_qkv_attn_split(const void* x_pairs, const void* w_planes, const float* bias, float inv_scale, void* out_planes, int N, hipStream_t s) {
+void launch_qkv_attn_split(const void* x_pairs, const void* w_planes, const float* bias, float inv_scale, void* out_planes, int N, hipStream_t s, const void* w_tiled) {
   if (N <= 0) return;
   if (((uintptr_t)x_pairs | (uintptr_t)w_planes | (uintptr_t)bias | (uintptr_t)out_planes) & 15) throw std::runtime_error("qkv_attn_split: operands must be 16-byte aligned");
   if ((size_t)N * 128 * 384 * 6 >= ((size_t)1 << 31)) throw std::runtime_error("qkv_attn_split: too many crops for 32-bit buffer offsets (the caller groups them)");
   ConvParams p{};
   p.in0 = x_pairs; p.C0 = 384; p.B = 1; p.H = 1; p.W = N * 128; p.ks = 1; p.dil = 1;
-  p.wgt = w_planes; p.bias = bias; p.split = 3; p.out_scale = inv_scale; p.out_planes = 3;
+  p.wgt = w_planes; p.wgt_tiled = w_tiled; p.bias = bias; p.split = 3; p.out_scale = inv_scale; p.out_planes = 3;
   p.out = out_planes; p.out_ld = 384; p.Cout = 1152; p.M = N * 128; p.act = kActNone;
   launch_sp<128, 192, 4, 2, 3, 2, 1, true, 3, 1>(p, s);
 }

@@ -22,6 +22,7 @@ void set_gemm2_split_stream(int v);   // split mode, pairs, plain GEMM shapes: g
 void set_gemm2_split_stream4(int v);  // the same for activation triples (1, default)
 bool gemm_sp_eligible(const ConvParams& p);
 void set_gemm_sp_sched(int v);
+void set_gemm_sp_few(int v);
 void launch_gemm_sp(const ConvParams& p, int cfg, hipStream_t s);   // gemm_sp.hip: streamlined split-pairs GEMM (cfg 2 = 256 x 128 tiles, 6 = 128 x 256)
 void set_gemm2_split_cfg(int v);     // split mode: force gemm2 tile configuration 1..6 (0 = automatic)
 void set_gemm2_split_reuse(int v);   // split mode: 1 (default) reuse-order K loop, 0 plane-major order (A/B)
@@ -98,7 +99,8 @@ void launch_layernorm_planes(const float* in, int in_ld, const float* gamma, con
 void launch_attn_enc_split(const void* qkv_planes, void* out_planes, int N, hipStream_t s);
 // gemm_sp.hip: qkv projection + self-attention of the ViT encoder as one launch.  x_pairs [N*128][2][384] (LayerNorm output as pairs), weight planes
 // [1152][3][384] and bias [1152] with the rows in head-major order (192 h + 64 c + d <- upstream 384 c + 64 h + d) -> out triples [N*128][3][384]
-void launch_qkv_attn_split(const void* x_pairs, const void* w_planes, const float* bias, float inv_scale, void* out_planes, int N, hipStream_t s);
+void launch_qkv_attn_split(const void* x_pairs, const void* w_planes, const float* bias, float inv_scale, void* out_planes, int N, hipStream_t s,
+                           const void* w_tiled = nullptr);   // w_tiled: the same planes as loader pieces (Engine::tile_planes), optional
 // CRAFT's conv1_1 + bias + ReLU from the u8 canvas into planes [M][3 * 64]; wgt_planes f16 [64][3][32] (k = (ky*3+kx)*3+c, 27 used)
 void launch_conv1_split(const uint8_t* canvas, const void* wgt_planes, const float* bias, float out_scale, void* out, int B, int H, int W, hipStream_t s, int planes = 3);
 
