@@ -288,6 +288,8 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "c3_narrow_wide") set_conv3p_narrow_wide(value);
   else if (k == "c3_narrow_frac") set_conv3p_narrow_frac(value);
   else if (k == "c3_narrowest_frac") set_conv3p_narrowest_frac(value);
+  else if (k == "c3_deep_w") set_conv3p_deep_w(value);
+  else if (k == "c3_deep_w64") set_conv3p_deep_w64(value);
   else if (k == "c3_first_persistent") set_conv3p_first_persistent(value);
   else if (k == "sk_max_rows") set_skinny_max_rows(value);
   else if (k == "ws_min_rows") set_gemm_ws_min_rows(value);

@@ -72,8 +72,12 @@ struct C3 {
 // multiplies it by weight rows [w0 | w0 / 2^11] (x0 w0 + x1 w0b in ONE chunk), the second by [w1 | 0] (x0 w1).  Two chunks over 128 bytes
 // per pixel instead of three over 256 (32 real channels zero-padded to 64): two thirds of the MFMAs, half the bytes.  The weight planes
 // keep the [plane 0 | plane 1 | plane 2] row layout with plane 1 unused, so the loaders below need no third case.
-template <int BN, int WM, int WN, bool FIRST, int XS, int LPW, int NP = 0>   // NP: 0 = bf16, 4 = triples, 3 = pairs, 2 = packed pairs (split.h).  XS: patch stages (1 when Cin = 64: a single chunk, and two workgroups fit a CU)
+// NWS: weight stages (2, 4 or 8; the static-address loop only).  A tap's weights are requested NWS - 1 taps ahead.  Two stages - one tap ahead - is what the
+// batch regime wants (the CU's other workgroups cover the wait, the LDS buys residency); a workgroup ALONE on its CU (the deep layers of a single page: 48 - 192
+// workgroups on 256 CUs) waits out one L2 / Infinity-Cache round trip per tap with them, ~0.65 us x 216 taps for 512 input channels, and takes four (eight: no further gain).
+template <int BN, int WM, int WN, bool FIRST, int XS, int LPW, int NP = 0, int NWS = 2>   // NP: 0 = bf16, 4 = triples, 3 = pairs, 2 = packed pairs (split.h).  XS: patch stages (1 when Cin = 64: a single chunk, and two workgroups fit a CU)
 __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM * WN == 4 ? 1 : 1)) void conv3p_kernel(ConvParams p) {
+  static_assert(NWS == 2 || ((NWS == 4 || NWS == 8) && XS == 1 && BN <= 64 && !FIRST), "more than two weight stages: the static-address loop's");
   using C = C3<BN, WM, WN, LPW>;
   using G = Geo<LPW>;
   constexpr bool SP = NP != 0;
@@ -148,14 +152,14 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
   };
   // weights of K step (chunk, tap) -> W stage `parity`; [Cout][tap][Cin].  The K offset rides in the instruction's scalar offset (no
   // per-lane arithmetic; the range check sees the lane offset only, so rows past Cout stay out of range)
-  auto stage_w = [&](int chunk, int tap, int parity) {
+  auto stage_w = [&](int chunk, int tap, int parity, bool dead = false) {   // dead: a step past the end - out-of-range loads (zero fill, no traffic) keep the wait counts static
     unsigned char* sb = ws + parity * C::WSTAGE;
     unsigned ko = (unsigned)((tap * Cin + chunk * 64) * 2);
     if constexpr (SP) { const int q = chunk % VC, pl = q == 0 ? 0 : q == 1 ? 2 : 1; ko = (unsigned)((pl * K + tap * Cin + (chunk / VC) * 64) * 2); }
 #pragma unroll
     for (int j = 0; j < C::WPW; ++j) {
-      const unsigned vo = wb[j];   // (a local copy: with the array element as the builtin's argument hipcc's host pass drops the kernel's stub without a word)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sb + (j * C::NW + wave) * 1024), 16, vo, ko, 0, 0);
+      const unsigned vo = dead ? OOB : wb[j];   // (a local copy: with the array element as the builtin's argument hipcc's host pass drops the kernel's stub without a word)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sb + (j * C::NW + wave) * 1024), 16, vo, dead ? 0u : ko, 0, 0);
     }
   };
 
@@ -178,9 +182,13 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
   stage_w(0, 0, 0);
   if constexpr (!FIRST) {
     stage_x(0);
+    if constexpr (NWS > 2) {   // taps 1 .. NWS - 2 of chunk 0 (NWS - 1 <= 7 < 9 taps)
+#pragma unroll
+      for (int t = 1; t < NWS - 1; ++t) stage_w(0, t, t);
+    }
   } else {
     // ---- conv1_1 on the halo patch -> xs stage 0 (the LDS behind the operand stages holds the u8 canvas patch and a u8/255 table)
-    unsigned char* cv = smem + XS * XSTAGE + 2 * C::WSTAGE;  // [12][36*3] canvas bytes around the halo (zero outside the image)
+    unsigned char* cv = smem + XS * XSTAGE + NWS * C::WSTAGE;  // [12][36*3] canvas bytes around the halo (zero outside the image)
     bf16* lut = reinterpret_cast<bf16*>(cv + 1536);    // bf16(v / 255.0f), v = 0..255
     const uint8_t* canvas = reinterpret_cast<const uint8_t*>(p.in0);
     for (int q = tid; q < 12 * 108; q += C::NT) {
@@ -250,8 +258,8 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        const int par = (chunk + tap) & 1;                 // (chunk * 9 + tap) & 1
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int par = (chunk + tap) & (NWS - 1);         // (chunk * 9 + tap) % NWS: 9 = 1 modulo 2, 4 and 8
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NWS - 2) * C::WPW) : "memory");   // the taps requested after this one may still be on their way
         __builtin_amdgcn_s_barrier();
         if (tap == 0 && chunk > 0 && (!SP || chunk % VC != 1)) {   // single patch stage: the next chunk's patch can only be fetched now
           stage_x(chunk);
@@ -270,8 +278,14 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
           const int off = ((i * 16) >> LPW) * HW2 + ((i * 16) & (PW - 1)) + tapoff;
           fx[i] = *reinterpret_cast<const frag_t*>(smem + xbase[off & 7] + off * 128);
         }
-        if (tap < 8) stage_w(chunk, tap + 1, par ^ 1);
-        else if (chunk + 1 < nchunks) stage_w(chunk + 1, 0, par ^ 1);
+        if constexpr (NWS == 2) {
+          if (tap < 8) stage_w(chunk, tap + 1, par ^ 1);
+          else if (chunk + 1 < nchunks) stage_w(chunk + 1, 0, par ^ 1);
+        } else {   // tap + NWS - 1 of this chunk or the next, into the stage the previous tap has left; every step issues (past the end: dead loads)
+          constexpr int AH = NWS - 1;
+          const int t2 = tap + AH >= 9 ? tap + AH - 9 : tap + AH, c2 = tap + AH >= 9 ? chunk + 1 : chunk;
+          stage_w(c2, t2, (par + AH) & (NWS - 1), c2 >= nchunks);
+        }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           if (kk) {
@@ -293,6 +307,7 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
         }
       }
     }
+    if constexpr (NWS > 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing dead requests target this workgroup's LDS
   } else {
   int chunk = 0, tap = 0;
   for (int s = 0; s < nsteps; ++s) {
@@ -1076,15 +1091,15 @@ static void launch_first2(const ConvParams& p_in, hipStream_t s) {
   hipLaunchKernelGGL(conv3p_first2_kernel, dim3(std::min(npatch, cus)), dim3(512), lds, s, p);
 }
 
-template <int BN, int WM, int WN, bool FIRST = false, int XS = 2, int LPW = 5, int NP = 0>
+template <int BN, int WM, int WN, bool FIRST = false, int XS = 2, int LPW = 5, int NP = 0, int NWS = 2>
 static void launch_c3(const ConvParams& p, hipStream_t s) {
   using C = C3<BN, WM, WN, LPW>;
   using G = Geo<LPW>;
   const int tilesM = p.B * (p.H / G::PH) * (p.W / G::PW), tilesN = (p.Cout + BN - 1) / BN;
-  constexpr int lds = XS * G::XSTAGE + 2 * C::WSTAGE + (FIRST ? 2048 : 0);
+  constexpr int lds = XS * G::XSTAGE + NWS * C::WSTAGE + (FIRST ? 2048 : 0);
   static PerDeviceOnce once;
-  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_kernel<BN, WM, WN, FIRST, XS, LPW, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); });
-  hipLaunchKernelGGL((conv3p_kernel<BN, WM, WN, FIRST, XS, LPW, NP>), dim3(tilesM * tilesN), dim3(C::NT), lds, s, p);
+  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_kernel<BN, WM, WN, FIRST, XS, LPW, NP, NWS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); });
+  hipLaunchKernelGGL((conv3p_kernel<BN, WM, WN, FIRST, XS, LPW, NP, NWS>), dim3(tilesM * tilesN), dim3(C::NT), lds, s, p);
 }
 
 void set_conv3p_first_persistent(int v) { g_first_persistent = v; }
@@ -1147,6 +1162,11 @@ static int g_narrow_wide = 1;    // 8 x 32-patch layers too take 64-wide tiles w
 static int g_narrow_frac = 8;    // ... "empty" = fewer tiles than g_narrow_frac / 4 per CU (8: two per CU, the kernels' residency)
 void set_conv3p_narrow_wide(int v) { g_narrow_wide = v; }
 void set_conv3p_narrow_frac(int v) { g_narrow_frac = v < 1 ? 1 : v; }
+static int g_deep_w = 1;         // the 32-wide tiles of a single page's deep layers on four weight stages (conv3p_kernel: NWS)
+void set_conv3p_deep_w(int v) { g_deep_w = v; }
+static int g_deep_w64 = 1 << 20; // ... and the 64-wide tiles while they number fewer than this many per CU (0 = never; default: always - the same two workgroups per CU,
+                                 // the deep layers of an 8-page group 262 -> 235 us, a single page's 64-wide layers -7 %, the full-resolution ones unchanged)
+void set_conv3p_deep_w64(int v) { g_deep_w64 = v; }
 static int g_narrowest_frac = 4; // 32-wide tiles (four waves) when even the 64-wide ones number fewer than g_narrowest_frac / 4 per CU: the deep layers of a single page
 void set_conv3p_narrowest_frac(int v) { g_narrowest_frac = v < 0 ? 0 : v; }
 // (the K loop, and with it every sum's order, is the same on every tile width: a page's result does not depend on the batch it came in)
@@ -1183,7 +1203,14 @@ void launch_conv3p(const ConvParams& p, hipStream_t s) {
       if (!wide) return launch_c3<64, 4, 2, false, 1, 4, 2>(p, s);
       return launch_c3<32, 4, 1, false, 1, 5, 2>(p, s);
     }
-    if (p.split == 3) { TTR_C3_SPLIT(3) }
+    if (p.split == 3) {
+      // pairs (the default): the tiles of a page or two - workgroups (nearly) alone on their CUs - request their weights further ahead (NWS)
+      const int tiles64 = p.B * (wide ? (p.H / 8) * (p.W / 32) : (p.H / 16) * (p.W / 16)) * ((p.Cout + 63) / 64);
+      if (narrowest && g_deep_w) return wide ? launch_c3<32, 4, 1, false, 1, 5, 3, 4>(p, s) : launch_c3<32, 4, 1, false, 1, 4, 3, 4>(p, s);
+      if (!narrowest && g_deep_w64 && p.Cout >= 64 && (p.Cout <= 64 || narrow) && tiles64 < g_deep_w64 * device_cu_count(256))
+        return wide ? launch_c3<64, 4, 2, false, 1, 5, 3, 4>(p, s) : launch_c3<64, 4, 2, false, 1, 4, 3, 4>(p, s);
+      TTR_C3_SPLIT(3)
+    }
     TTR_C3_SPLIT(4)
 #undef TTR_C3_SPLIT
   }

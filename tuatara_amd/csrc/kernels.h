@@ -76,7 +76,9 @@ void launch_conv3p(const ConvParams& p, hipStream_t s);
 int conv3p_split_bn(const ConvParams& p);   // split-operand layers: the tile width launch_conv3p picks (128 / 64 / 32)
 void set_conv3p_narrow_wide(int v);   // split-operand layers on 8 x 32 patches: 64-wide tiles when 128-wide ones would not fill the workgroup slots (1, default)
 void set_conv3p_narrow_frac(int v);   // ... fewer than v / 4 tiles per CU (default 8)
-void set_conv3p_narrowest_frac(int v);   // 32-wide tiles when the 64-wide ones number fewer than v / 4 per CU (default 4; 0 = never)
+void set_conv3p_deep_w(int v);           // 1 (default): those 32-wide tiles request a tap's weights three taps ahead (four weight stages)
+void set_conv3p_deep_w64(int v);         // ... and the 64-wide tiles while fewer than v per CU (default: always; 0 = never)
+void set_conv3p_narrowest_frac(int v);   // 32-wide tiles when the 64-wide ones number fewer than v / 4 per CU (default: always; 0 = never)
 void set_conv3p_single_stage_max_cin(int c);
 void set_conv3p_force_bn128(int v);
 void set_conv3p_c64_waves(int w);
