@@ -147,6 +147,14 @@ def test_argmax_inside_the_next_steps_embedding_kernel_changes_nothing(eng):
     _fold_check(eng, "argmax_fold", (40, 1, 300))
 
 
+def test_tiled_planes_change_nothing(eng):
+    """The encoder's activation planes and the recogniser's weight planes laid out as gemm_sp.hip's loader pieces (tuning keys "sp_tiled_x",
+    "sp_tiled_w": 1-KiB blocks of 8 rows x 64 halves instead of row-major rows) against the row-major tensors: a layout, not an arithmetic -
+    logits and ids identical bit for bit, at 1 (a group small enough for the skinny projection keeps its rows), 17, 40 and 300 crops."""
+    _fold_check(eng, "sp_tiled_x", (40, 1, 17, 300))
+    _fold_check(eng, "sp_tiled_w", (40, 300))
+
+
 def _fold_check(eng, key, counts):
     rng = np.random.default_rng(77)
     for n in counts:

@@ -24,6 +24,9 @@ struct ConvParams {
   int B, H, W;               // spatial size (stride 1, "same" padding)
   int ks, dil;               // kernel size 1 or 3; dilation
   const void* wgt;           // T [Cout][ks*ks*(C0+C1)]
+  // gemm_sp.hip only: the activation planes in0 (x_tiled) / the planes output `out` (out_tiled) are laid out as the loader's 1-KiB pieces,
+  // [rows / 8][plane][channels / 64][8 rows][64 halves], instead of row-major [row][plane][channels] (the recogniser's encoder, rows a multiple of 8)
+  int x_tiled, out_tiled;
   const void* wgt_tiled;     // gemm_sp.hip only, optional: the split weight planes as contiguous 1-KiB loader pieces (Engine::tile_planes); `wgt` stays valid
   const float* bias;         // f32 [Cout] or null
   void* out; int out_ld;     // T output, row stride in elements (may be null)

@@ -74,6 +74,7 @@ struct Tuning {
   int skinny_max_rows = 2048;
   int skx_ln_fuse = 1;        // split engines, <= 256 rows: the decoder's LayerNorm + linear pairs as one skinny launch (gemm_skx.hip, LayerNorm prologue)
   int argmax_fold = 1;        // split engines: an AR step's argmax inside the next step's embedding kernel (one dependent launch less per step)
+  int sp_tiled_x = 1;         // ... and the encoder's activation planes (LayerNorm outputs, attention output, MLP hidden) are written and read as such pieces
   int sp_tiled_w = 1;         // split engines: gemm_sp.hip reads the recogniser's weight planes as contiguous 1-KiB pieces (Linear::wst)
   int ar_host_check = 10;     // split / fp32 engines, batches of <= 256 crops (the latency regime): from this AR step on the host looks at the done counter every fourth
                               // step and stops enqueuing steps once every crop has emitted EOS (upstream's loop does that check every step); 0 = never
@@ -103,6 +104,7 @@ struct Tuning {
     else if (k == "skinny_max_rows") skinny_max_rows = value;
     else if (k == "ar_host_check") ar_host_check = value;
     else if (k == "sp_tiled_w") sp_tiled_w = value;
+    else if (k == "sp_tiled_x") sp_tiled_x = value;
     else if (k == "argmax_fold") argmax_fold = value;
     else if (k == "skx_ln_fuse") skx_ln_fuse = value;
     else if (k == "qkv_attn_split") qkv_attn_split = value;
@@ -477,7 +479,7 @@ struct Engine {
   // split-operand linear on planes: in [M][3 K] -> out (planes [M][3 out_ld] or fp32 [M][out_ld]) and / or out_f32 (+ fp32 residual)
   void sgemm(const Linear& L, const void* in_planes, int M, void* out, int out_ld, int act, int out_planes,
              float* out_f32 = nullptr, int out_f32_ld = 0, const float* resid = nullptr, int resid_ld = 0, int np = 4, int resid_mod = 0, int out_full_cols = 0,
-             const char* kind = nullptr);
+             const char* kind = nullptr, int x_tiled = 0, int out_tiled = 0);
   // out = L(LayerNorm(x)) for the decoder's per-step rows: the skinny GEMM normalises its own activation rows (bf16, few rows);
   // otherwise the LayerNorm kernel writes `scratch` and the plain GEMM follows
   void ln_gemm(const float* x, const std::string& ln_name, float eps, void* scratch, const Linear& L, int M, void* out, int out_ld, int act,

@@ -7,17 +7,18 @@ unsigned long long* g_dec_dbg = nullptr;
 
 void Engine::sgemm(const Linear& L, const void* in_planes, int M, void* out, int out_ld, int act, int out_planes,
            float* out_f32, int out_f32_ld, const float* resid, int resid_ld, int np, int resid_mod, int out_full_cols,
-           const char* kind) {
+           const char* kind, int x_tiled, int out_tiled) {
   if (!L.ws.p) throw std::runtime_error("split GEMM: the layer has no weight planes");
   ConvParams p{};
   p.out_full_cols = out_full_cols;
   p.in0 = in_planes; p.C0 = L.k; p.B = 1; p.H = 1; p.W = M; p.ks = 1; p.dil = 1;
   p.wgt = L.ws.p; p.bias = L.b.as<float>(); p.split = np; p.out_scale = L.inv_scale; p.out_planes = out_planes == 1 ? 3 : out_planes;   // (1 = triples)
   p.wgt_tiled = tn.sp_tiled_w ? L.wst.p : nullptr;
+  p.x_tiled = x_tiled; p.out_tiled = out_tiled;
   p.out = out; p.out_ld = out_ld; p.out_f32 = out_f32; p.out_f32_ld = out_f32_ld; p.resid = resid; p.resid_ld = resid_ld; p.resid_mod = resid_mod;
   p.Cout = L.cout_valid ? L.cout_valid : L.cout; p.M = M; p.act = act;
   p.skip = cur_skip; p.skip_n = cur_skip_n;
-  const bool skinny = tn.skinny_split && np == 4 && M <= tn.skinny_max_rows && gemm_skx_eligible(p);
+  const bool skinny = tn.skinny_split && np == 4 && M <= tn.skinny_max_rows && !x_tiled && !out_tiled && gemm_skx_eligible(p);
   if (!skinny) { if (const char* e = gemm2_check(p)) throw std::runtime_error(e); }
   // few rows (the AR steps: one row per crop): one memory round trip per small workgroup instead of a ring of K steps on a handful of 128-row tiles
   if (skinny) {
@@ -150,27 +151,31 @@ void Engine::parseq_forward(const uint8_t* d_crops, int N, float* d_logits, floa
     void* attp = (pq_ws[13].ensure((size_t)std::min(N, CHS) * 128 * E * 6), pq_ws[13].p);      // attention output planes
     auto lnp_at = [&](int c0) { return (char*)lnp + (size_t)c0 * 128 * E * 6; };
     const int lnpl = tn.enc_ln_pairs ? 2 : 3;        // planes of the LayerNorm outputs that feed qkv / fc1 (pairs: three MFMAs per product there)
+    // the planes the encoder's GEMMs hand each other as their loaders' 1-KiB pieces (ConvParams::x_tiled): a wave instruction of the LDS-DMA fetches one
+    // contiguous KiB instead of eight 128-byte rows 1.5 - 6 KB apart - 71 against 31 GB/s per CU for a lone four-wave workgroup (tools/micro/dma_depth.hip)
+    // (measured: the recogniser pass at 1280 crops 34.96 -> 34.22 ms; a single page's 40 crops unchanged.  Groups small enough for the skinny projection keep the rows.)
+    const int xt = tn.sp_tiled_x && tn.qkv_attn_split && lnpl == 2 && tn.enc_fc2_pairs && std::min(CHS, N) * 128 > tn.skinny_max_rows ? 1 : 0;
     for (int c0 = 0; c0 < N; c0 += CHS) {
       const int nc = std::min(CHS, N - c0), Mc = nc * 128;
       float* xc = x + (size_t)c0 * 128 * E;
       for (int l = 0; l < 12; ++l) {
         const std::string p = "encoder.blocks." + std::to_string(l) + ".";
-        launch_layernorm_planes(xc, E, pqf.at(p + "norm1.weight").as<float>(), pqf.at(p + "norm1.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream, lnpl);
+        launch_layernorm_planes(xc, E, pqf.at(p + "norm1.weight").as<float>(), pqf.at(p + "norm1.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream, lnpl, nullptr, 0, xt);
         if (tn.qkv_attn_split && lnpl == 2) {   // one launch: the attention of a (crop, head) is the epilogue of its 128 x 192 qkv tile
           const Linear& L = pq.at(p + "qkv_hm");
           // executed flops: qkv on pairs (x 3), Q K^T and P V on a triple and a pair (x 4)
           const double qa = 2.0 * Mc * 3 * E * E, aa = 2.0 * 2 * nc * 6 * 128.0 * 128 * 64;
           timed("enc.qkv+attention: gemm_sp_kernel<128,192,NP=3,EPI=1>", qa + aa, qa * 3 + aa * 4,
-                [&] { launch_qkv_attn_split(lnp_at(c0), L.ws.p, L.b.as<float>(), L.inv_scale, attp, nc, stream, tn.sp_tiled_w ? L.wst.p : nullptr); });
+                [&] { launch_qkv_attn_split(lnp_at(c0), L.ws.p, L.b.as<float>(), L.inv_scale, attp, nc, stream, tn.sp_tiled_w ? L.wst.p : nullptr, xt, xt); });
         } else {
         sgemm(pq.at(p + "qkv"), lnp_at(c0), Mc, bigp, 3 * E, kActNone, 1, nullptr, 0, nullptr, 0, lnpl + 1, 0, tn.qkv_kv_pairs ? E : 0, "enc.qkv");   // (K, V: read as pairs)
         launch_attn_enc_split(bigp, attp, nc, stream);
         }
-        sgemm(pq.at(p + "proj"), attp, Mc, nullptr, 0, kActNone, 0, xc, E, xc, E, 4, 0, 0, "enc.proj");
-        launch_layernorm_planes(xc, E, pqf.at(p + "norm2.weight").as<float>(), pqf.at(p + "norm2.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream, lnpl);
+        sgemm(pq.at(p + "proj"), attp, Mc, nullptr, 0, kActNone, 0, xc, E, xc, E, 4, 0, 0, "enc.proj", xt, 0);
+        launch_layernorm_planes(xc, E, pqf.at(p + "norm2.weight").as<float>(), pqf.at(p + "norm2.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream, lnpl, nullptr, 0, xt);
         const int hpl = tn.enc_fc2_pairs ? 2 : 3;                                      // planes of the MLP's hidden activation
-        sgemm(pq.at(p + "fc1"), lnp_at(c0), Mc, bigp, 4 * E, kActGelu, hpl, nullptr, 0, nullptr, 0, lnpl + 1, 0, 0, "enc.fc1 + GELU");
-        sgemm(pq.at(p + "fc2"), bigp, Mc, nullptr, 0, kActNone, 0, xc, E, xc, E, hpl + 1, 0, 0, "enc.fc2");
+        sgemm(pq.at(p + "fc1"), lnp_at(c0), Mc, bigp, 4 * E, kActGelu, hpl, nullptr, 0, nullptr, 0, lnpl + 1, 0, 0, "enc.fc1 + GELU", xt, xt);
+        sgemm(pq.at(p + "fc2"), bigp, Mc, nullptr, 0, kActNone, 0, xc, E, xc, E, hpl + 1, 0, 0, "enc.fc2", xt, 0);
       }
       launch_layernorm_planes(xc, E, pqf.at("encoder.norm.weight").as<float>(), pqf.at("encoder.norm.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream);
     }

@@ -651,6 +651,7 @@ void launch_gemm2(const ConvParams& p_in, int cfg, hipStream_t s) {
     if (g_split_stream == 1 || (p.Cout < 512 && Ctot >= 1024)) sc = 3;
     return launch_gemm_sp(p, sc, s);
   }
+  if (p.x_tiled || p.out_tiled) throw std::runtime_error("gemm2: tiled planes are gemm_sp.hip's (this shape did not qualify for it)");
   if (p.split) {   // three-slot X ring everywhere: the reuse-order K loop
     const bool ru = g_split_reuse != 0 || p.split == 3;
     if (p.split == 3) {

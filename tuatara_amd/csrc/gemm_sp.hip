@@ -103,6 +103,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
   // profiles/r03_pmc_stall_parseq.txt section 4), the rows of a piece in the order the LDS image wants them
   const bool wtiled = p.wgt_tiled != nullptr;
   const __amdgpu_buffer_rsrc_t rsw = sp_rsrc(wtiled ? p.wgt_tiled : p.wgt, (unsigned)((size_t)((p.Cout + 31) / 32 * 32) * K * 6));
+  const unsigned x_plstep = p.x_tiled ? (unsigned)(K >> 6) * 1024u : (unsigned)K * 2u, x_kstep = p.x_tiled ? 1024u : 128u;   // byte offsets of one activation plane and of one k0
   const unsigned w_pl1 = wtiled ? (unsigned)(2 * (K >> 6)) * 1024u : (unsigned)K * 4u, w_kstep = wtiled ? 1024u : 128u;   // byte offsets of plane w1 and of one k0
   constexpr unsigned OOB = 0x80000000u;
 
@@ -119,7 +120,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
       const int row = (i * C::NW + wave) * 8 + (lane >> 3);
       const int g = (lane & 7) ^ ((row >> 1) & 7);
       const int m = m0 + row;
-      xo[i] = (live && m < p.M) ? ((unsigned)m * (unsigned)(PLX * K) + g * 8) * 2u : OOB;
+      if (p.x_tiled) xo[i] = (live && m < p.M) ? (unsigned)(m >> 3) * (unsigned)(PLX * (K >> 6)) * 1024u + (unsigned)((m & 7) * 128 + g * 16) : OOB;
+      else xo[i] = (live && m < p.M) ? ((unsigned)m * (unsigned)(PLX * K) + g * 8) * 2u : OOB;
     }
 #pragma unroll
     for (int j = 0; j < C::WPW; ++j) {
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
   int xs_k = 0, xs_pl = 0, xs_slot = 0;
   int ws_k = 0, ws_pl = 0, ws_slot = 0;
   auto issue_x = [&]() {
-    const unsigned soff = (unsigned)(xs_pl * K + (xs_k << 6)) * 2u;
+    const unsigned soff = (unsigned)xs_pl * x_plstep + (unsigned)xs_k * x_kstep;
     unsigned char* sb = xring + xs_slot * C::XBYTES + wave * 1024;
 #pragma unroll
     for (int i = 0; i < C::XPW; ++i) {
@@ -536,7 +538,11 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
       // out planes [M][3][384]: oacc[2u], oacc[2u+1] hold d = 32 u + 8 g + 0..7 of query q
       __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0), in front of the first store: the prefetched tiles have landed (requested an epilogue ago)
       {
-        f16* const op = reinterpret_cast<f16*>(p.out) + (int64_t)(m0c + wm * 32 + wn * 16 + fr) * (3 * 384) + (n0c / 192) * 64 + fg * 8;
+        const int orow = m0c + wm * 32 + wn * 16 + fr, ohead = n0c / 192;
+        // (out_tiled: the projection GEMM's loader pieces - a head's 64 channels are one 64-deep k step; planes 6 KiB apart instead of 384 halves)
+        f16* const op = p.out_tiled ? reinterpret_cast<f16*>(p.out) + ((int64_t)(orow >> 3) * 18 + ohead) * 512 + (orow & 7) * 64 + fg * 8
+                                    : reinterpret_cast<f16*>(p.out) + (int64_t)orow * (3 * 384) + ohead * 64 + fg * 8;
+        const int opl = p.out_tiled ? 6 * 512 : 384;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           float v[8];
@@ -544,7 +550,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
           for (int e = 0; e < 4; ++e) { v[e] = oacc[2 * u][e] * rinv; v[4 + e] = oacc[2 * u + 1][e] * rinv; }
           f16x8 a, b, c;
           split3_x8(v, a, b, c);
-          *reinterpret_cast<f16x8*>(op + u * 32) = a; *reinterpret_cast<f16x8*>(op + 384 + u * 32) = b; *reinterpret_cast<f16x8*>(op + 768 + u * 32) = c;
+          *reinterpret_cast<f16x8*>(op + u * 32) = a; *reinterpret_cast<f16x8*>(op + opl + u * 32) = b; *reinterpret_cast<f16x8*>(op + 2 * opl + u * 32) = c;
         }
       }
       __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -630,6 +636,13 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
             split3_x8(v, a, b, c);
             f16* o = reinterpret_cast<f16*>(p.out) + (int64_t)m * (3 * (int64_t)p.out_ld) + n;
             *reinterpret_cast<f16x8*>(o) = a; *reinterpret_cast<f16x8*>(o + p.out_ld) = b;
+          } else if (p.out_planes && p.out_tiled) {   // the next GEMM's loader pieces
+            const int kb = p.out_ld >> 6;
+            f16* o = reinterpret_cast<f16*>(p.out) + ((int64_t)(m >> 3) * (p.out_planes * kb) + (n >> 6)) * 512 + (m & 7) * 64 + (n & 63);
+            f16x8 a, b, c;
+            if (p.out_planes == 3) { split3_x8(v, a, b, c); *reinterpret_cast<f16x8*>(o + 2 * kb * 512) = c; }
+            else split2_x8(v, a, b);
+            *reinterpret_cast<f16x8*>(o) = a; *reinterpret_cast<f16x8*>(o + kb * 512) = b;
           } else if (p.out_planes) st_split_n(p.out, (int64_t)m, p.out_ld, n, v, p.out_planes);
           else sp_store_f32x8(reinterpret_cast<float*>(p.out) + (int64_t)m * p.out_ld + n, v);
         }
@@ -669,6 +682,7 @@ void set_gemm_sp_sched(int v) { g_sp_sched = v; }
 // shapes these kernels take (gemm2.hip's split mode keeps the rest): ks = 1, one source, no pooled / ReLU-copy outputs, K a multiple of 64;
 // pairs: K >= 192; triples: K >= 128 and K / 64 even (the K loop runs in pairs of k0)
 bool gemm_sp_eligible(const ConvParams& p) {
+  if (p.out_tiled && (!p.out_planes || p.out_ld % 64 != 0 || p.out_full_cols)) return false;   // (tiled planes: whole 64-channel blocks, every plane)
   if ((p.split != 3 && p.split != 4) || p.ks != 1 || p.C1 != 0 || p.out_pool || p.out_relu || p.C0 % 64 != 0 || p.Cout % 8 != 0) return false;
   if (p.split == 3 ? p.C0 < 192 : (p.C0 < 128 || (p.C0 >> 6) % 2 != 0)) return false;
   if (p.resid && (size_t)(p.resid_mod ? p.resid_mod : p.M) * p.resid_ld * 4 >= ((size_t)1 << 31)) return false;   // the epilogue reads the residual through a buffer descriptor
@@ -707,13 +721,15 @@ void launch_gemm_sp(const ConvParams& p, int cfg, hipStream_t s) {
 // The encoder's qkv projection + self-attention as ONE launch (EPI = 1 above).  x_pairs: LayerNorm output as f16 pairs [N * 128][2][384];
 // w_planes: the qkv weight planes [1152][3][384] with the rows in HEAD-MAJOR order (row 192 h + 64 c + d = upstream row 384 c + 64 h + d,
 // c = 0 / 1 / 2 for Q / K / V), bias likewise; out: attention output as exact triples [N * 128][3][384] (the projection GEMM's input).
-void launch_qkv_attn_split(const void* x_pairs, const void* w_planes, const float* bias, float inv_scale, void* out_planes, int N, hipStream_t s, const void* w_tiled) {
+void launch_qkv_attn_split(const void* x_pairs, const void* w_planes, const float* bias, float inv_scale, void* out_planes, int N, hipStream_t s, const void* w_tiled,
+                           int x_tiled, int out_tiled) {
   if (N <= 0) return;
   if (((uintptr_t)x_pairs | (uintptr_t)w_planes | (uintptr_t)bias | (uintptr_t)out_planes) & 15) throw std::runtime_error("qkv_attn_split: operands must be 16-byte aligned");
   if ((size_t)N * 128 * 384 * 6 >= ((size_t)1 << 31)) throw std::runtime_error("qkv_attn_split: too many crops for 32-bit buffer offsets (the caller groups them)");
   ConvParams p{};
   p.in0 = x_pairs; p.C0 = 384; p.B = 1; p.H = 1; p.W = N * 128; p.ks = 1; p.dil = 1;
   p.wgt = w_planes; p.wgt_tiled = w_tiled; p.bias = bias; p.split = 3; p.out_scale = inv_scale; p.out_planes = 3;
+  p.x_tiled = x_tiled; p.out_tiled = out_tiled;
   p.out = out_planes; p.out_ld = 384; p.Cout = 1152; p.M = N * 128; p.act = kActNone;
   launch_sp<128, 192, 4, 2, 3, 2, 1, true, 3, 1>(p, s);
 }

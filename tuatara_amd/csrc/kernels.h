@@ -96,13 +96,13 @@ void launch_maxpool3x3s1_planes(const void* in, void* out, int B, int H, int W, 
 void launch_upsample2x_planes(const void* in, void* out, int B, int H, int W, int C, hipStream_t s, int planes = 3);
 // LayerNorm over 384 columns of fp32 rows (stride in_ld) -> planes [M][3 * 384]
 void launch_layernorm_planes(const float* in, int in_ld, const float* gamma, const float* beta, float eps, void* out, int M, hipStream_t s, int planes = 3,
-                             const int* skip = nullptr, int skip_n = 0);
+                             const int* skip = nullptr, int skip_n = 0, int tiled = 0);   // tiled: the planes as gemm_sp.hip's loader pieces (ConvParams::x_tiled)
 // attn_split.hip: ViT encoder self-attention, qkv planes [N*128][3][1152] -> planes [N*128][3][384]
 void launch_attn_enc_split(const void* qkv_planes, void* out_planes, int N, hipStream_t s);
 // gemm_sp.hip: qkv projection + self-attention of the ViT encoder as one launch.  x_pairs [N*128][2][384] (LayerNorm output as pairs), weight planes
 // [1152][3][384] and bias [1152] with the rows in head-major order (192 h + 64 c + d <- upstream 384 c + 64 h + d) -> out triples [N*128][3][384]
 void launch_qkv_attn_split(const void* x_pairs, const void* w_planes, const float* bias, float inv_scale, void* out_planes, int N, hipStream_t s,
-                           const void* w_tiled = nullptr);   // w_tiled: the same planes as loader pieces (Engine::tile_planes), optional
+                           const void* w_tiled = nullptr, int x_tiled = 0, int out_tiled = 0);   // w_tiled: the same planes as loader pieces (Engine::tile_planes), optional
 // CRAFT's conv1_1 + bias + ReLU from the u8 canvas into planes [M][3 * 64]; wgt_planes f16 [64][3][32] (k = (ky*3+kx)*3+c, 27 used)
 void launch_conv1_split(const uint8_t* canvas, const void* wgt_planes, const float* bias, float out_scale, void* out, int B, int H, int W, hipStream_t s, int planes = 3);
 

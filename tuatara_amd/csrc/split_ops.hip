@@ -249,7 +249,7 @@ namespace ttr {
 namespace {
 template <int NPL>
 __global__ __launch_bounds__(256) void layernorm_planes_kernel(const float* __restrict__ in, int in_ld, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              float eps, f16* __restrict__ out, int M, const int* skip, int skip_n) {
+                                                              float eps, f16* __restrict__ out, int M, const int* skip, int skip_n, int tiled) {
   if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;   // AR early exit (see ConvParams::skip)
   constexpr int D = 384;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -265,15 +265,18 @@ __global__ __launch_bounds__(256) void layernorm_planes_kernel(const float* __re
   V8 o;
   ln384_row8(v, act, gamma + c, beta + c, eps, o.v);
   if (!act) return;
-  st_planes<NPL>(out + (int64_t)row * (NPL * D) + c, D, o);
+  // tiled: gemm_sp.hip's loader pieces [rows / 8][plane][6 blocks of 64 channels][8 rows][64] (ConvParams::x_tiled) - planes 6 x 512 halves apart
+  if (tiled) st_planes<NPL>(out + ((int64_t)(row >> 3) * (NPL * 6) + (c >> 6)) * 512 + (row & 7) * 64 + (c & 63), 6 * 512, o);
+  else st_planes<NPL>(out + (int64_t)row * (NPL * D) + c, D, o);
 }
 }  // namespace
 
 void launch_layernorm_planes(const float* in, int in_ld, const float* gamma, const float* beta, float eps, void* out, int M, hipStream_t s, int planes,
-                             const int* skip, int skip_n) {
+                             const int* skip, int skip_n, int tiled) {
   if (M <= 0) return;
   if (in_ld % 4 || (((uintptr_t)in | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15)) throw std::runtime_error("layernorm (planes): 16-byte alignment");
-  if (planes == 2) hipLaunchKernelGGL(layernorm_planes_kernel<2>, dim3((M + 3) / 4), dim3(256), 0, s, in, in_ld, gamma, beta, eps, (f16*)out, M, skip, skip_n);
-  else hipLaunchKernelGGL(layernorm_planes_kernel<3>, dim3((M + 3) / 4), dim3(256), 0, s, in, in_ld, gamma, beta, eps, (f16*)out, M, skip, skip_n);
+  if (tiled && M % 8) throw std::runtime_error("layernorm (planes): the tiled layout wants a multiple of 8 rows");
+  if (planes == 2) hipLaunchKernelGGL(layernorm_planes_kernel<2>, dim3((M + 3) / 4), dim3(256), 0, s, in, in_ld, gamma, beta, eps, (f16*)out, M, skip, skip_n, tiled);
+  else hipLaunchKernelGGL(layernorm_planes_kernel<3>, dim3((M + 3) / 4), dim3(256), 0, s, in, in_ld, gamma, beta, eps, (f16*)out, M, skip, skip_n, tiled);
 }
 }  // namespace ttr
