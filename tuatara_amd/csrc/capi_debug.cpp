@@ -276,6 +276,7 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "g2_x_ring3") set_gemm2_x_ring3(value);
   else if (k == "g2_split_reuse") set_gemm2_split_reuse(value);
   else if (k == "g2_split_cfg") set_gemm2_split_cfg(value);
+  else if (k == "g2_split_few") set_gemm2_split_few(value);
   else if (k == "g2_split_dbg") set_gemm2_split_dbg(value);
   else if (k == "g2_split_wreg") set_gemm2_split_wreg(value);
   else if (k == "g2_split_stream") set_gemm2_split_stream(value);

@@ -578,6 +578,8 @@ static int g_split_stream4 = 1; // ... and for activation triples (proj, the dec
 void set_gemm2_split_stream4(int v) { g_split_stream4 = v; }
 static int g_split_dbg = 0;     // split mode timing experiments (results are wrong): 1 = no output stores
 void set_gemm2_split_dbg(int v) { g_split_dbg = v; }
+static int g_split_few = 1;     // split mode, gemm2's own loop: 128 x 64 tiles when the 128 x 128 ones number no more than the CUs
+void set_gemm2_split_few(int v) { g_split_few = v; }
 static int g_split_cfg = 0;     // split mode: force a tile configuration (0 = automatic)
 void set_gemm2_split_cfg(int v) { g_split_cfg = v; }
 static int g_split_reuse = 1;   // split mode: 1 = reuse-order K loop (X0 and W0b staged once per k0), 0 = plane-major order with a two-slot X ring
@@ -652,6 +654,9 @@ void launch_gemm2(const ConvParams& p_in, int cfg, hipStream_t s) {
     return launch_gemm_sp(p, sc, s);
   }
   if (p.x_tiled || p.out_tiled) throw std::runtime_error("gemm2: tiled planes are gemm_sp.hip's (this shape did not qualify for it)");
+  // a page's worth of pixels on this loop (CRAFT's dilated 3x3 and two-source 1x1 layers): no more 128 x 128 tiles than CUs - 128 x 64 tiles on twice
+  // as many workgroups move three quarters of the bytes per K step each (slice5.1 at one page 182 -> 157 us, upconv1.0 65 -> 52, upconv2.0 41 -> 33)
+  if (p.split && cfg == 3 && g_split_few && (int64_t)((p.M + 127) / 128) * ((p.Cout + 127) / 128) <= num_cus()) cfg = 5;
   if (p.split) {   // three-slot X ring everywhere: the reuse-order K loop
     const bool ru = g_split_reuse != 0 || p.split == 3;
     if (p.split == 3) {

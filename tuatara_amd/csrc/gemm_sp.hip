@@ -700,17 +700,18 @@ void launch_gemm_sp(const ConvParams& p, int cfg, hipStream_t s) {
   const int tiles128 = ((p.M + 127) / 128) * ((p.Cout + 127) / 128);
   // A page's worth of rows: fewer 128 x 128 tiles than half the CUs.  A workgroup alone on its CU walks K at the rate its tiles arrive (~40 B / clk
   // per CU for these 8-row pieces: 32 KB per phase against 512 cycles of MFMAs), so 64-row tiles on twice as many CUs shorten every phase of the
-  // chain: fc2 at 40 crops (K = 1536, 120 tiles) 44 -> 31 us.  (Deeper rings alone - 3 + 3 on the 128-row tile - changed nothing: not a latency.)
+  // chain: fc2 at 40 crops (K = 1536, 120 tiles) 44 -> 31 us, and eight waves (wave tiles of 32 x 32) issue the loader's pieces at 1.4 - 1.6 x the rate of
+  // four (tools/micro/dma_depth.hip): a page's recogniser -70 us more.  (Deeper rings alone - 3 + 3 on the 128-row tile - changed nothing: not a latency.)
   const bool few = cfg == 3 && g_sp_few && 2 * tiles128 <= cus;
   if (p.split == 4) {
-    if (few) { launch_sp<64, 128, 2, 2, 3, 2, 2, true, 4>(p, s); return; }
+    if (few) { launch_sp<64, 128, 2, 4, 3, 2, 1, true, 4>(p, s); return; }
     if (cfg == 6) launch_sp<128, 256, 2, 4, 3, 2, 1, true, 4>(p, s);
     else if (cfg == 2) launch_sp<256, 128, 4, 2, 3, 2, 1, true, 4>(p, s);
     else launch_sp<128, 128, 2, 2, 3, 2, 2, true, 4>(p, s);
     return;
   }
   // (64 x 64 tiles, two per CU: the same 31 us - the CU's fill rate, not the workgroup's)
-  if (few) { launch_sp<64, 128, 2, 2, 3, 3, 1, true>(p, s); return; }
+  if (few) { launch_sp<64, 128, 2, 4, 3, 3, 1, true>(p, s); return; }
   // (a wide layer on one round of 128 x 256 tiles instead - fc1 at 40 crops: 240 - is no faster: 31 -> 32 - 37 us)
   if (cfg == 6) { if (sched) launch_sp<128, 256, 2, 4, 3, 3, 1, true>(p, s); else launch_sp<128, 256, 2, 4, 3, 3, 1, false>(p, s); }
   else if (cfg == 2) { if (sched) launch_sp<256, 128, 4, 2, 3, 3, 1, true>(p, s); else launch_sp<256, 128, 4, 2, 3, 3, 1, false>(p, s); }

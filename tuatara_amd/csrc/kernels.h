@@ -24,7 +24,8 @@ bool gemm_sp_eligible(const ConvParams& p);
 void set_gemm_sp_sched(int v);
 void set_gemm_sp_few(int v);
 void launch_gemm_sp(const ConvParams& p, int cfg, hipStream_t s);   // gemm_sp.hip: streamlined split-pairs GEMM (cfg 2 = 256 x 128 tiles, 6 = 128 x 256)
-void set_gemm2_split_cfg(int v);     // split mode: force gemm2 tile configuration 1..6 (0 = automatic)
+void set_gemm2_split_cfg(int v);
+void set_gemm2_split_few(int v);     // split mode: force gemm2 tile configuration 1..6 (0 = automatic)
 void set_gemm2_split_reuse(int v);   // split mode: 1 (default) reuse-order K loop, 0 plane-major order (A/B)
 void set_gemm2_x_ring3(int v);   // 1 (default): activation tiles two K steps ahead where LDS allows; 0: one step (measurement)
 // device table float2[1024] {Phi(x_i), Phi(x_i + 1/64) - Phi(x_i)}, x_i = -8 + i/64, of the GELU epilogues (built on first use)
