@@ -147,6 +147,18 @@ def test_argmax_inside_the_next_steps_embedding_kernel_changes_nothing(eng):
     _fold_check(eng, "argmax_fold", (40, 1, 300))
 
 
+def test_embedding_inside_the_self_kv_linear_changes_nothing(eng):
+    """An AR step's token -> embedding -> norm_c -> self_kv projection as one skinny launch (tuning key "embed_fold"; gemm_skx.hip's token prologue,
+    which also takes the pending argmax) against dec_embed_ln_planes_kernel + the skinny linear: identical bit for bit, with and without the
+    folded argmax."""
+    _fold_check(eng, "embed_fold", (40, 1, 17))
+    try:
+        assert eng.set_tuning("argmax_fold", 0) == 0
+        _fold_check(eng, "embed_fold", (40,))
+    finally:
+        eng.set_tuning("argmax_fold", 1)
+
+
 def test_tiled_planes_change_nothing(eng):
     """The encoder's activation planes and the recogniser's weight planes laid out as gemm_sp.hip's loader pieces (tuning keys "sp_tiled_x",
     "sp_tiled_w": 1-KiB blocks of 8 rows x 64 halves instead of row-major rows) against the row-major tensors: a layout, not an arithmetic -

@@ -73,6 +73,7 @@ struct Tuning {
   int skinny_split = 1;       // split-operand engines: linears of <= skinny_max_rows rows (the AR steps: one row per crop) on gemm_skx.hip
   int skinny_max_rows = 2048;
   int skx_ln_fuse = 1;        // split engines, <= 256 rows: the decoder's LayerNorm + linear pairs as one skinny launch (gemm_skx.hip, LayerNorm prologue)
+  int embed_fold = 1;         // split engines, <= 256 crops: an AR step's embedding + norm_c inside its self_kv linear (gemm_skx.hip, token prologue)
   int argmax_fold = 1;        // split engines: an AR step's argmax inside the next step's embedding kernel (one dependent launch less per step)
   int sp_tiled_x = 1;         // ... and the encoder's activation planes (LayerNorm outputs, attention output, MLP hidden) are written and read as such pieces
   int sp_tiled_w = 1;         // split engines: gemm_sp.hip reads the recogniser's weight planes as contiguous 1-KiB pieces (Linear::wst)
@@ -106,6 +107,7 @@ struct Tuning {
     else if (k == "sp_tiled_w") sp_tiled_w = value;
     else if (k == "sp_tiled_x") sp_tiled_x = value;
     else if (k == "argmax_fold") argmax_fold = value;
+    else if (k == "embed_fold") embed_fold = value;
     else if (k == "skx_ln_fuse") skx_ln_fuse = value;
     else if (k == "qkv_attn_split") qkv_attn_split = value;
     else if (k == "fuse_first") fuse_first = value;

@@ -328,6 +328,23 @@ void Engine::parseq_forward(const uint8_t* d_crops, int N, float* d_logits, floa
       p.out = (char*)kvcache + (size_t)i * 768 * es; p.out_ld = 26 * 768;
       p.Cout = L.cout; p.M = N; p.act = kActNone;
       igemm(p, 2.0 * N * L.cout * L.k);
+    } else if (dec_split && tn.embed_fold && tn.skinny_split && N <= 256) {
+      // a page's worth of crops: token (or the pending argmax) -> embedding -> norm_c -> self_kv as ONE skinny launch (gemm_skx.hip, token prologue)
+      const Linear& L = pq.at("self_kv");
+      ConvParams p{};
+      p.tok = tk; p.tok_ld = 26; p.tok_col = i; p.tok_emb = emb; p.tok_max = 96; p.tok_pos = i > 0 ? posq + (size_t)(i - 1) * E : nullptr;
+      if (pend_argmax >= 0) {
+        p.tok_logits = ar + (size_t)pend_argmax * 95; p.tok_logits_ld = 26 * 95; p.tok_C = 95; p.done_count = early ? ar_done.as<int>() : nullptr; p.tok_eos = 0;
+        pend_argmax = -1;
+      }
+      p.ln_gamma = gc; p.ln_beta = bc; p.ln_eps = 1e-5f;
+      p.C0 = L.k; p.B = 1; p.H = 1; p.W = N; p.ks = 1; p.dil = 1;
+      p.wgt = L.ws.p; p.bias = L.b.as<float>(); p.split = 4; p.out_scale = L.inv_scale;
+      p.out = (char*)kvcache + (size_t)i * 768 * 4; p.out_ld = 26 * 768;
+      p.Cout = L.cout; p.M = N; p.act = kActNone;
+      p.skip = cur_skip; p.skip_n = cur_skip_n;
+      if (!gemm_skx_ln_eligible(p)) throw std::runtime_error("AR step: the token prologue does not take this shape");
+      timed("dec.embed + norm_c + self_kv (skinny)", 2.0 * N * L.cout * L.k, 2.0 * N * L.cout * L.k * 4, [&] { launch_gemm_skx(p, stream); });
     } else if (dec_split) {
       if (pend_argmax >= 0) {   // column i's token = argmax of step i - 1's logits, found by this kernel's waves (one launch less per step)
         launch_dec_embed_ln(prec, tk, emb, posq, gc, bc, 1e-5f, dpa, N, i, i + 1, stream, cur_skip, cur_skip_n, 3,

@@ -114,9 +114,41 @@ __global__ __launch_bounds__(256) void gemm_skx_kernel(ConvParams p) {
       const int rl = wave + 4 * rr, m = m0 + rl;
       f16x8 o0 = {0, 0, 0, 0, 0, 0, 0, 0}, o1 = o0, o2 = o0;
       if (m < p.M) {                                                        // (wave-uniform)
-        const float* x = p.ln_in + (int64_t)m * p.ln_ld + c;
         float v[8];
-        {
+        if (p.tok) {
+          // an AR step's content row (ConvParams::tok*, as gemm_sk.hip's token prologue; dec_embed_ln_planes_kernel is the stand-alone form): the row to
+          // normalise is emb[token] (+ the position query), token = tok[m][tok_col] or - tok_logits - the first maximal index of the previous step's
+          // logits row, which the first column tile also writes back and counts (first EOS of the crop: done_count).  embed + LayerNorm + self_kv: one launch.
+          int token;
+          if (p.tok_logits) {
+            const float* lg = p.tok_logits + (int64_t)m * p.tok_logits_ld;
+            float best = -INFINITY; int bi = 0x7fffffff;
+            for (int cc = lane; cc < p.tok_C; cc += 64) { const float t = lg[cc]; if (t > best) { best = t; bi = cc; } }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+              const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+              if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            }
+            token = bi;
+            if (blockIdx.x == 0 && lane == 0) {
+              p.tok[m * p.tok_ld + p.tok_col] = bi;
+              if (p.done_count && bi == p.tok_eos) {
+                bool first = true;
+                for (int cc = 1; cc < p.tok_col; ++cc) first = first && p.tok[m * p.tok_ld + cc] != p.tok_eos;
+                if (first) atomicAdd(p.done_count, 1);
+              }
+            }
+          } else token = p.tok[m * p.tok_ld + p.tok_col];
+          token = token < 0 ? 0 : (token > p.tok_max ? p.tok_max : token);
+          const float* x = p.tok_emb + (int64_t)token * D + c;
+          const float4 a = *reinterpret_cast<const float4*>(x), b = *reinterpret_cast<const float4*>(x + 4);
+          v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+          if (p.tok_pos) {
+            const float4 pa = *reinterpret_cast<const float4*>(p.tok_pos + c), pb = *reinterpret_cast<const float4*>(p.tok_pos + c + 4);
+            v[0] = pa.x + v[0]; v[1] = pa.y + v[1]; v[2] = pa.z + v[2]; v[3] = pa.w + v[3]; v[4] = pb.x + v[4]; v[5] = pb.y + v[5]; v[6] = pb.z + v[6]; v[7] = pb.w + v[7];
+          }
+        } else {
+          const float* x = p.ln_in + (int64_t)m * p.ln_ld + c;
           const float4 a = *reinterpret_cast<const float4*>(x), b = *reinterpret_cast<const float4*>(x + 4);
           v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
         }
@@ -219,8 +251,9 @@ __global__ __launch_bounds__(256) void gemm_skx_kernel(ConvParams p) {
 // caller's call: it is for a few thousand rows at most)
 // the LayerNorm-prologue form: fp32 rows of 384 in, a page's worth of them (the 16-row workgroups)
 bool gemm_skx_ln_eligible(const ConvParams& p) {
-  if (!p.ln_in || !p.ln_gamma || !p.ln_beta || p.C0 != 384 || p.M > 256 || p.ln_ld % 4) return false;
-  if (((uintptr_t)p.ln_in | (uintptr_t)p.ln_gamma | (uintptr_t)p.ln_beta) & 15) return false;
+  if ((!p.ln_in && !p.tok) || !p.ln_gamma || !p.ln_beta || p.C0 != 384 || p.M > 256) return false;
+  if (p.tok ? (!p.tok_emb || (((uintptr_t)p.tok_emb | (uintptr_t)p.tok_pos) & 15)) : (p.ln_ld % 4 != 0 || ((uintptr_t)p.ln_in & 15))) return false;
+  if (((uintptr_t)p.ln_gamma | (uintptr_t)p.ln_beta) & 15) return false;
   ConvParams q = p;
   q.in0 = p.wgt;   // (any aligned pointer: the planes operand is not read)
   return gemm_skx_eligible(q);
@@ -236,7 +269,7 @@ bool gemm_skx_eligible(const ConvParams& p) {
 }
 
 void launch_gemm_skx(const ConvParams& p, hipStream_t s) {
-  if (p.ln_in) {
+  if (p.ln_in || p.tok) {
     if (!gemm_skx_ln_eligible(p)) throw std::runtime_error("gemm_skx: LayerNorm prologue: shape not supported");
     hipLaunchKernelGGL((gemm_skx_kernel<1, true>), dim3((p.Cout + SKX_BN - 1) / SKX_BN, (p.M + 15) / 16), dim3(256), 0, s, p);
     return;

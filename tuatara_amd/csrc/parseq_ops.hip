@@ -268,6 +268,62 @@ __global__ void dec_embed_ln_kernel(int* __restrict__ tokens, const float* __res
   }
 }
 
+// split engines (planes out): the same rows in the 48 lanes x 8 values form, the LayerNorm through ln384_row8 - what gemm_skx.hip's token prologue
+// does inside the self_kv linear of an AR step of few rows, operation for operation (the two forms give identical planes)
+template <int NPL>
+__global__ __launch_bounds__(256) void dec_embed_ln_planes_kernel(int* __restrict__ tokens, const float* __restrict__ emb, const float* __restrict__ pos_q,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps, f16* __restrict__ out, int N,
+                                                                  int i0, int i1, const int* skip, int skip_n, const float* __restrict__ prev_logits, int prev_ld, int C,
+                                                                  int* done_count, int eos) {
+  if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;
+  const int R = i1 - i0;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= N * R) return;
+  const int n = row / R, i = i0 + row % R;
+  int tok;
+  if (prev_logits) {
+    const float* x = prev_logits + (int64_t)n * prev_ld;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) { float v = x[c]; if (v > best) { best = v; bi = c; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      float ov = __shfl_xor(best, o); int oi = __shfl_xor(bi, o);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    tok = bi;
+    if (lane == 0) {
+      tokens[n * 26 + i] = bi;
+      if (done_count && bi == eos) {
+        bool first = true;
+        for (int c = 1; c < i; ++c) first = first && tokens[n * 26 + c] != eos;
+        if (first) atomicAdd(done_count, 1);
+      }
+    }
+  } else tok = tokens[n * 26 + i];
+  tok = tok < 0 ? 0 : (tok > 96 ? 96 : tok);
+  const bool act = lane < 48;
+  const int c = (act ? lane : 0) * 8;
+  float v[8];
+  {
+    const float* x = emb + (int64_t)tok * 384 + c;
+    const float4 a = *reinterpret_cast<const float4*>(x), b = *reinterpret_cast<const float4*>(x + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  if (i > 0) {
+    const float* pp = pos_q + (int64_t)(i - 1) * 384 + c;
+    const float4 pa = *reinterpret_cast<const float4*>(pp), pb = *reinterpret_cast<const float4*>(pp + 4);
+    v[0] = pa.x + v[0]; v[1] = pa.y + v[1]; v[2] = pa.z + v[2]; v[3] = pa.w + v[3]; v[4] = pb.x + v[4]; v[5] = pb.y + v[5]; v[6] = pb.z + v[6]; v[7] = pb.w + v[7];
+  }
+  float y[8];
+  ln384_row8(v, act, gamma + c, beta + c, eps, y);
+  if (!act) return;
+  f16* d = out + (int64_t)row * (NPL * 384) + c;
+  f16x8 o0, o1, o2;
+  if (NPL == 3) { split3_x8(y, o0, o1, o2); *reinterpret_cast<f16x8*>(d + 768) = o2; }
+  else split2_x8(y, o0, o1);
+  *reinterpret_cast<f16x8*>(d) = o0; *reinterpret_cast<f16x8*>(d + 384) = o1;
+}
+
 void launch_dec_embed_ln(Precision prec, int* tokens, const float* emb, const float* pos_q, const float* gamma, const float* beta, float eps,
                          void* out, int N, int i0, int i1, hipStream_t s, const int* skip, int skip_n, int planes,
                          const float* prev_logits, int prev_ld, int C, int* done_count, int eos) {
@@ -275,7 +331,9 @@ void launch_dec_embed_ln(Precision prec, int* tokens, const float* emb, const fl
   if (rows <= 0) return;
   if (prev_logits && (i1 != i0 + 1 || i0 < 1)) throw std::runtime_error("dec_embed_ln: the folded argmax belongs to one AR step's column");
   dim3 grid((rows + 3) / 4);
-  if (prec == kBF16) hipLaunchKernelGGL(dec_embed_ln_kernel<bf16>, grid, dim3(256), 0, s, tokens, emb, pos_q, gamma, beta, eps, (bf16*)out, N, i0, i1, skip, skip_n, 0, prev_logits, prev_ld, C, done_count, eos);
+  if (prec != kBF16 && planes == 3 && !(((uintptr_t)emb | (uintptr_t)pos_q | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out) & 15))
+    hipLaunchKernelGGL(dec_embed_ln_planes_kernel<3>, grid, dim3(256), 0, s, tokens, emb, pos_q, gamma, beta, eps, (f16*)out, N, i0, i1, skip, skip_n, prev_logits, prev_ld, C, done_count, eos);
+  else if (prec == kBF16) hipLaunchKernelGGL(dec_embed_ln_kernel<bf16>, grid, dim3(256), 0, s, tokens, emb, pos_q, gamma, beta, eps, (bf16*)out, N, i0, i1, skip, skip_n, 0, prev_logits, prev_ld, C, done_count, eos);
   else hipLaunchKernelGGL(dec_embed_ln_kernel<float>, grid, dim3(256), 0, s, tokens, emb, pos_q, gamma, beta, eps, (float*)out, N, i0, i1, skip, skip_n, planes, prev_logits, prev_ld, C, done_count, eos);
 }
 
