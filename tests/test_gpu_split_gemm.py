@@ -167,7 +167,15 @@ def test_tiled_planes_change_nothing(eng):
     _fold_check(eng, "sp_tiled_w", (40, 300))
 
 
-def _fold_check(eng, key, counts):
+def test_fixed_epilogue_kernels_change_nothing(eng):
+    """gemm_sp.hip's recurring epilogue cases on kernels of their own (tuning key "gsp_epi": fc1's GELU + tiled pairs, the residual linears' bias +
+    residual + fp32 rows, as compile-time cases of the same code) against the general kernel that tests ConvParams' flags per 8-value block: the same
+    arithmetic in the same order - logits and ids identical bit for bit, at a page's crops (64-row and 128-row tiles), 17, 300 (256 x 128 tiles) and
+    640 crops (fc1 on 128 x 256 tiles)."""
+    _fold_check(eng, "gsp_epi", (40, 17, 300, 640), on=15, restore=3)
+
+
+def _fold_check(eng, key, counts, on=1, restore=None):
     rng = np.random.default_rng(77)
     for n in counts:
         crops = rng.integers(0, 256, (n, 32, 128, 3), dtype=np.uint8)
@@ -176,10 +184,10 @@ def _fold_check(eng, key, counts):
         try:
             assert eng.set_tuning(key, 0) == 0
             l0, a0, i0 = eng.parseq_logits(crops, want_ar=True)
-            assert eng.set_tuning(key, 1) == 0
+            assert eng.set_tuning(key, on) == 0
             l1, a1, i1 = eng.parseq_logits(crops, want_ar=True)
         finally:
-            eng.set_tuning(key, 1)
+            eng.set_tuning(key, on if restore is None else restore)
         assert np.isfinite(l1).all() and np.array_equal(i0, i1) and np.array_equal(l0, l1), n
         # AR logits: up to each crop's EOS step (behind it the attention kernels skip the crop and its rows hold whatever the buffers held)
         for c in range(n):

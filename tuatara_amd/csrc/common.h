@@ -92,6 +92,23 @@ __device__ __forceinline__ float gelu_hermite(float x, const float2* lut) {
   return x * fmaf(fmaf(fmaf(c.w, t, c.z), t, c.y), t, c.x);
 }
 
+// The same for 8 values: every table read issued before the first polynomial (one LDS round trip per 8 values instead of one per value);
+// bit-identical to eight gelu_hermite calls.
+__device__ __forceinline__ void gelu_hermite8(float (&v)[8], const float2* lut) {
+  float u[8];
+  float4 c[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    u[e] = fmaf(__builtin_amdgcn_fmed3f(v[e], -8.0f, 7.96875f), 32.0f, 256.0f);
+    c[e] = reinterpret_cast<const float4*>(lut)[(int)u[e]];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float t = __builtin_amdgcn_fractf(u[e]);
+    v[e] = v[e] * fmaf(fmaf(fmaf(c[e].w, t, c[e].z), t, c[e].y), t, c[e].x);
+  }
+}
+
 // GELU of 8 values with the table in LDS at byte address lut_lds.  The table reads are inline asm: hipcc orders every LDS
 // read it can see behind all in-flight LDS-DMA loads AND stores of the wave (s_waitcnt vmcnt(0) — it cannot prove that the
 // DMA does not write the table), which drains the activation prefetch and waits for write acknowledgements 4x per epilogue.

@@ -66,7 +66,10 @@ struct SpCfg {
 //     ph3: MFMA X2(k) w0s     reads X0(k+1), W0(k+1)    requests X2(k+1)
 // EPI = 1: the encoder's qkv projection with the self-attention of a (crop, head) as its epilogue (below, "attention epilogue"): tiles of
 // 128 rows (one crop) x 192 channels (Q | K | V of one head: the caller passes the weight rows in head-major order), eight waves as 4 x 2.
-template <int BM, int BN, int WM, int WN, int XST, int WST, int MINB, bool SCHED, int NP, int EPI = 0>
+// EM: the plain epilogue's case fixed at compile time (0 = by ConvParams' flags at run time, every case in one kernel).  1 = the encoder's fc1: GELU by the
+// table, the hidden activation out as tiled pairs; 2 = the residual linears (proj, fc2, the decoder's): bias + residual, fp32 rows out.  With the flags
+// tested per 8-value block hipcc serialised the GELU table reads (one LDS round trip and two branches per VALUE) and spilled scalars into lanes.
+template <int BM, int BN, int WM, int WN, int XST, int WST, int MINB, bool SCHED, int NP, int EPI = 0, int EM = 0>
 __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams p) {
   using C = SpCfg<BM, BN, WM, WN, XST, WST>;
   static_assert(NP == 3 || (NP == 4 && XST == 3 && WST == 2), "pairs, or triples on rings 3 + 2");
@@ -78,8 +81,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
 
+  static_assert(EM == 0 || EPI == 0, "fixed epilogue cases are the plain epilogue's");
   float2* const glut = reinterpret_cast<float2*>(smem + C::LDS);          // Hermite GELU table behind the rings (common.h: gelu_hermite)
-  if (p.act == kActGelu && p.gelu_lut) {
+  if (EM == 1 || (EM == 0 && p.act == kActGelu && p.gelu_lut)) {
     for (int i = tid; i < 512; i += C::NT) reinterpret_cast<uint4*>(glut)[i] = reinterpret_cast<const uint4*>(p.gelu_lut)[i];
   }   // visible after the first barrier
 
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
     const bool has_next = idx < xcd_count;
     TTR_SP_NEXT_DELTAS(idx)                 // the streams are inside tile idx now (nk0 >= 3: they run at most two k0 ahead)
 
-    if (p.dbg_flags & 2) {   // timing experiment: no epilogue at all
+    if (EM == 0 && (p.dbg_flags & 2)) {   // timing experiment: no epilogue at all
       float sum = 0.f;
 #pragma unroll
       for (int j = 0; j < C::NJ; ++j)
@@ -566,10 +570,13 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
     // accumulators in place; pass 2 (activation, planes, stores) loads nothing.  Mixed, a load behind a store costs a full drain of the stores:
     // the counter counts both, they complete out of order with respect to each other, so the compiler can only wait for vmcnt(0) - the
     // one-pass form did that once per 16-row block, eight write round trips per tile.
+    const int e_act = EM == 1 ? (int)kActGelu : EM == 2 ? (int)kActNone : p.act;
+    const bool e_lut = EM == 1 ? true : EM == 2 ? false : p.gelu_lut != nullptr;
+    const bool e_resid = EM == 1 ? false : EM == 2 ? true : p.resid != nullptr;
     {
       const __amdgpu_buffer_rsrc_t rsb = sp_rsrc(p.bias, p.bias ? (unsigned)p.Cout * 4u : 0u);
       const int64_t rrows = p.resid_mod ? p.resid_mod : p.M;
-      const __amdgpu_buffer_rsrc_t rsr = sp_rsrc(p.resid, p.resid ? (unsigned)(rrows * p.resid_ld * 4) : 0u);
+      const __amdgpu_buffer_rsrc_t rsr = sp_rsrc(p.resid, e_resid ? (unsigned)(rrows * p.resid_ld * 4) : 0u);
       unsigned rrow[C::MI];
 #pragma unroll
       for (int i = 0; i < C::MI; ++i) {
@@ -583,7 +590,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
         const unsigned ncol = n < p.Cout ? (unsigned)n * 4u : OOB;
         const f32x4 b0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsb, ncol, 0, 0));
         const f32x4 b1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsb, ncol, 16, 0));
-        if (p.resid) {
+        if (e_resid) {
           f32x4 rv[C::MI][2];
 #pragma unroll
           for (int i = 0; i < C::MI; ++i) {
@@ -622,12 +629,28 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
         float v[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] = acc[2 * t][i][e]; v[4 + e] = acc[2 * t + 1][i][e]; }
-        if (p.act == kActRelu) {
+        if constexpr (EM == 1) {          // GELU (the block's eight table reads in flight together), then tiled pairs: the next GEMM's loader pieces
+          gelu_hermite8(v, glut);
+          const int kb = p.out_ld >> 6;
+          f16* o = reinterpret_cast<f16*>(p.out) + ((int64_t)(m >> 3) * (2 * kb) + (n >> 6)) * 512 + (m & 7) * 64 + (n & 63);
+          f16x8 a, b;
+          split2_x8(v, a, b);
+          *reinterpret_cast<f16x8*>(o) = a; *reinterpret_cast<f16x8*>(o + kb * 512) = b;
+          __builtin_amdgcn_sched_barrier(0);   // block by block: hoisting every block's table reads to the top costs 256 registers (spills)
+          continue;
+        } else if constexpr (EM == 2) {   // fp32 rows
+          sp_store_f32x8(p.out_f32 + (int64_t)m * p.out_f32_ld + n, v);
+          continue;
+        }
+        if (e_act == kActRelu) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        } else if (p.act == kActGelu) {
+        } else if (e_act == kActGelu) {
+          if (e_lut) gelu_hermite8(v, glut);
+          else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = p.gelu_lut ? gelu_hermite(v[e], glut) : gelu_exact(v[e]);
+            for (int e = 0; e < 8; ++e) v[e] = gelu_exact(v[e]);
+          }
         }
         if (p.dbg_flags & 1) { if (v[0] == 1.2345e30f) reinterpret_cast<float*>(p.out)[0] = v[1]; continue; }   // timing experiment: no output stores
         if (p.out) {
@@ -658,7 +681,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
 
 #undef TTR_SP_NEXT_DELTAS
 
-template <int BM, int BN, int WM, int WN, int XST, int WST, int MINB, bool SCHED, int NP = 3, int EPI = 0>
+template <int BM, int BN, int WM, int WN, int XST, int WST, int MINB, bool SCHED, int NP = 3, int EPI = 0, int EM = 0>
 static void launch_sp(const ConvParams& p_in, hipStream_t s) {
   using C = SpCfg<BM, BN, WM, WN, XST, WST>;
   constexpr int TABLE = EPI == 1 ? 57344 : 8208;   // behind the rings: the GELU table, or the attention epilogue's Q / K / V images
@@ -666,16 +689,18 @@ static void launch_sp(const ConvParams& p_in, hipStream_t s) {
   if ((size_t)(C::LDS + TABLE) * MINB > 160 * 1024) p.gelu_lut = nullptr;   // no room for the table beside these rings: erf
   static PerDeviceOnce once;
   static_assert(EPI == 0 || C::LDS + TABLE <= 160 * 1024, "attention epilogue: rings + images must fit the LDS");
-  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_sp_kernel<BM, BN, WM, WN, XST, WST, MINB, SCHED, NP, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, std::min(C::LDS + TABLE, 160 * 1024))); });
+  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_sp_kernel<BM, BN, WM, WN, XST, WST, MINB, SCHED, NP, EPI, EM>, hipFuncAttributeMaxDynamicSharedMemorySize, std::min(C::LDS + TABLE, 160 * 1024))); });
   const size_t lds = C::LDS + (EPI == 1 || (p.act == kActGelu && p.gelu_lut) ? TABLE : 0);
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
   const int cap = device_cu_count(256) * MINB / 8 * 8;
   const int grid = std::min((tilesM * tilesN + 7) / 8 * 8, std::max(cap, 8));
-  hipLaunchKernelGGL((gemm_sp_kernel<BM, BN, WM, WN, XST, WST, MINB, SCHED, NP, EPI>), dim3(grid), dim3(C::NT), lds, s, p);
+  hipLaunchKernelGGL((gemm_sp_kernel<BM, BN, WM, WN, XST, WST, MINB, SCHED, NP, EPI, EM>), dim3(grid), dim3(C::NT), lds, s, p);
 }
 
 static int g_sp_few = 1;   // the few-tile rules of launch_gemm_sp (a page's worth of rows)
 void set_gemm_sp_few(int v) { g_sp_few = v; }
+static int g_sp_epi = 3;     // bits: 1 = fc1's case on its own kernels (EM = 1), 2 = the residual linears' (EM = 2) on the 256 x 128 triples tile (proj), 8 = on the other 128- / 256-row tiles, 4 = on the 64-row tiles; 0: the general kernel everywhere
+void set_gemm_sp_epi(int v) { g_sp_epi = v; }
 static int g_sp_sched = 1;   // 1: fragment reads and requests interleaved with the first MFMAs of a phase; 0: in front of them
 void set_gemm_sp_sched(int v) { g_sp_sched = v; }
 
@@ -703,20 +728,28 @@ void launch_gemm_sp(const ConvParams& p, int cfg, hipStream_t s) {
   // chain: fc2 at 40 crops (K = 1536, 120 tiles) 44 -> 31 us, and eight waves (wave tiles of 32 x 32) issue the loader's pieces at 1.4 - 1.6 x the rate of
   // four (tools/micro/dma_depth.hip): a page's recogniser -70 us more.  (Deeper rings alone - 3 + 3 on the 128-row tile - changed nothing: not a latency.)
   const bool few = cfg == 3 && g_sp_few && 2 * tiles128 <= cus;
+  // the encoder's and the decoder's recurring epilogue cases as kernels of their own (gemm_sp_kernel's EM): fc1 (GELU table, tiled pairs out) and the residual
+  // linears (bias + residual, fp32 rows out).  Same arithmetic, same order: bit-identical to the general kernel (tests/test_gpu_split_gemm.py; g_sp_epi = 0 turns them off)
+  const bool plain = sched && p.dbg_flags == 0;
+  const bool em_fc1 = plain && (g_sp_epi & 1) && table && !p.resid && p.out && p.out_planes == 2 && p.out_tiled && !p.out_full_cols && !p.out_f32;
+  // (measured at 1280 crops, same box, twice: fc1 770 -> 670 us per layer; proj on the 256 x 128 triples tile 255 -> 242; fc2 on two 128 x 128 workgroups per CU
+  // 555 -> 572 - its fixed case keeps 15 registers in scratch where the general kernel parks scalars in lanes - so that one stays on the general kernel; a page's
+  // 64-row tiles: no difference)
+  const bool em_res = plain && (g_sp_epi & (few ? 4 : (p.split == 4 && cfg == 2) ? 2 : 8)) && p.act == kActNone && p.resid && !p.out && p.out_f32;
   if (p.split == 4) {
-    if (few) { launch_sp<64, 128, 2, 4, 3, 2, 1, true, 4>(p, s); return; }
+    if (few) { if (em_res) launch_sp<64, 128, 2, 4, 3, 2, 1, true, 4, 0, 2>(p, s); else launch_sp<64, 128, 2, 4, 3, 2, 1, true, 4>(p, s); return; }
     if (cfg == 6) launch_sp<128, 256, 2, 4, 3, 2, 1, true, 4>(p, s);
-    else if (cfg == 2) launch_sp<256, 128, 4, 2, 3, 2, 1, true, 4>(p, s);
-    else launch_sp<128, 128, 2, 2, 3, 2, 2, true, 4>(p, s);
+    else if (cfg == 2) { if (em_res) launch_sp<256, 128, 4, 2, 3, 2, 1, true, 4, 0, 2>(p, s); else launch_sp<256, 128, 4, 2, 3, 2, 1, true, 4>(p, s); }
+    else { if (em_res) launch_sp<128, 128, 2, 2, 3, 2, 2, true, 4, 0, 2>(p, s); else launch_sp<128, 128, 2, 2, 3, 2, 2, true, 4>(p, s); }
     return;
   }
   // (64 x 64 tiles, two per CU: the same 31 us - the CU's fill rate, not the workgroup's)
-  if (few) { launch_sp<64, 128, 2, 4, 3, 3, 1, true>(p, s); return; }
+  if (few) { if (em_res) launch_sp<64, 128, 2, 4, 3, 3, 1, true, 3, 0, 2>(p, s); else launch_sp<64, 128, 2, 4, 3, 3, 1, true>(p, s); return; }
   // (a wide layer on one round of 128 x 256 tiles instead - fc1 at 40 crops: 240 - is no faster: 31 -> 32 - 37 us)
-  if (cfg == 6) { if (sched) launch_sp<128, 256, 2, 4, 3, 3, 1, true>(p, s); else launch_sp<128, 256, 2, 4, 3, 3, 1, false>(p, s); }
-  else if (cfg == 2) { if (sched) launch_sp<256, 128, 4, 2, 3, 3, 1, true>(p, s); else launch_sp<256, 128, 4, 2, 3, 3, 1, false>(p, s); }
-  else if (table) { if (sched) launch_sp<128, 128, 2, 2, 2, 2, 2, true>(p, s); else launch_sp<128, 128, 2, 2, 2, 2, 2, false>(p, s); }
-  else { if (sched) launch_sp<128, 128, 2, 2, 3, 2, 2, true>(p, s); else launch_sp<128, 128, 2, 2, 3, 2, 2, false>(p, s); }
+  if (cfg == 6) { if (em_fc1) launch_sp<128, 256, 2, 4, 3, 3, 1, true, 3, 0, 1>(p, s); else if (sched) launch_sp<128, 256, 2, 4, 3, 3, 1, true>(p, s); else launch_sp<128, 256, 2, 4, 3, 3, 1, false>(p, s); }
+  else if (cfg == 2) { if (em_fc1) launch_sp<256, 128, 4, 2, 3, 3, 1, true, 3, 0, 1>(p, s); else if (sched) launch_sp<256, 128, 4, 2, 3, 3, 1, true>(p, s); else launch_sp<256, 128, 4, 2, 3, 3, 1, false>(p, s); }
+  else if (table) { if (em_fc1) launch_sp<128, 128, 2, 2, 2, 2, 2, true, 3, 0, 1>(p, s); else if (sched) launch_sp<128, 128, 2, 2, 2, 2, 2, true>(p, s); else launch_sp<128, 128, 2, 2, 2, 2, 2, false>(p, s); }
+  else { if (em_res) launch_sp<128, 128, 2, 2, 3, 2, 2, true, 3, 0, 2>(p, s); else if (sched) launch_sp<128, 128, 2, 2, 3, 2, 2, true>(p, s); else launch_sp<128, 128, 2, 2, 3, 2, 2, false>(p, s); }
 }
 
 // The encoder's qkv projection + self-attention as ONE launch (EPI = 1 above).  x_pairs: LayerNorm output as f16 pairs [N * 128][2][384];
