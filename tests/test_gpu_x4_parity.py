@@ -144,6 +144,28 @@ def test_x4_craft_exact_triples_option(eng_x4_random, weights_random):
     assert np.abs(pairs - triples).max() < 1e-4 * scale
 
 
+@pytest.mark.parametrize("hw", [(1024, 768), (576, 1024), (96, 160)])
+def test_x4_craft_commuted_upconvolutions(eng_x4_random, weights_random, hw):
+    """upconv2.0 / 3.0 / 4.0 as W_up . y at the low resolution + the skip half's 1x1 with the bilinear upsample of that product in its epilogue (the default,
+    tuning key "up_commute": no upsampled tensor is written) against the upsample kernel + two-source 1x1: the same sums in another order - both within the
+    bar of the fp32 oracle on fully random weights, and within fp32 noise of each other; a full page, a ragged canvas (546 x 1024 padded to 576 x 1024:
+    odd tile edges at every level) and a small one."""
+    from oracle import pipeline
+    craft_r, _ = pipeline.load_models(weights_random["craft"], weights_random["parseq"])
+    canvas = np.random.default_rng(21).integers(0, 256, (hw[0], hw[1], 3), dtype=np.uint8)
+    ref = pipeline.craft_heatmap(craft_r, canvas)
+    new = eng_x4_random.craft_heatmap(canvas)
+    assert eng_x4_random.set_tuning(b"up_commute", 0) == 0
+    try:
+        old = eng_x4_random.craft_heatmap(canvas)
+    finally:
+        eng_x4_random.set_tuning(b"up_commute", 1)
+    scale = max(1.0, float(np.abs(ref).max()))
+    print(f"CRAFT {hw} random weights: commuted {np.abs(new - ref).max():.2e}, two-source {np.abs(old - ref).max():.2e}, apart {np.abs(new - old).max():.2e} (max |heat| {scale:.2f})")
+    assert np.isfinite(new).all() and np.abs(new - ref).max() < TOL * scale and np.abs(old - ref).max() < TOL * scale
+    assert np.abs(new - old).max() < 1e-4 * scale
+
+
 def test_x4_craft_head_on_packed_pairs_equals_zero_padded_rows(eng_x4_random, weights_random):
     """The 32-channel head tensors as 128-byte pixel rows [x0 | x1] with conv_cls.0 / .2 / .4 on packed pairs (conv3p.hip, NP = 2: the default)
     against the same layers over zero-padded 64-channel rows: the same three products per value (x0 w0 + x1 w0 / 2^11 in one chunk, x0 w1 in

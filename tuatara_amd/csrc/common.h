@@ -60,6 +60,11 @@ struct ConvParams {
   // nothing but the heat map is written.  tail_w6 / tail_w8: f16 [16 rows][w0 | w1][32 k] (fragment rows; conv_cls.8's k slot 8 g + e holds
   // channel 4 g + e for e < 4), tail_b6 [16], tail_b8 [2], tail_s6 / tail_s8 = 1 / S of the two tensors, tail_heat f32 [M][2]
   const void* tail_w6; const void* tail_w8; const float* tail_b6; const float* tail_b8; float tail_s6, tail_s8; float* tail_heat;
+  // gemm2.hip, split mode, ks = 1: up_z = fp32 [B][H / 2][W / 2][up_ld] - a tensor at half the resolution whose 2x bilinear upsample (align_corners = false,
+  // upsample2x_planes_kernel's arithmetic) at the row's pixel is added before the activation.  CRAFT's upconvN.0 layers are 1x1 convolutions over
+  // cat(upsample(y), skip): a 1x1 convolution commutes with the upsample, so W_up . y runs at the low resolution (a quarter of the rows) and arrives here,
+  // and the upsampled tensor is never written (engine_craft.cpp: upconv_commuted)
+  const float* up_z; int up_ld;
 };
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

@@ -177,6 +177,15 @@ void Engine::load_craft(const std::string& dir) {
       for (int ci = 0; ci < c.cin; ++ci) kmap[(size_t)t * cin_pad + ci] = t * c.cin + ci;
     upload_linear(L, w.data.data(), c.cout, taps * c.cin, b.data.data(), cout_pad, taps * cin_pad, &kmap);
     if (prec == kSplit && nm == "conv_cls.8") load_head_tail(wf);
+    if (prec == kSplit && (nm == "upconv2.0" || nm == "upconv3.0" || nm == "upconv4.0")) {
+      // the layer's two column blocks as linears of their own (tn.up_commute): [0, C0) multiplies the upsampled tensor, [C0, cin) the skip tensor (+ the bias)
+      const int c0 = nm == "upconv2.0" ? 256 : nm == "upconv3.0" ? 128 : 64, c1 = c.cin - c0;
+      std::vector<int> ka(c0), kb(c1);
+      for (int i = 0; i < c0; ++i) ka[i] = i;
+      for (int i = 0; i < c1; ++i) kb[i] = c0 + i;
+      upload_linear(craft[nm + ".up"], w.data.data(), c.cout, c.cin, nullptr, c.cout, c0, &ka);
+      upload_linear(craft[nm + ".skip"], w.data.data(), c.cout, c.cin, b.data.data(), c.cout, c1, &kb);
+    }
     if (head3 && c.cin == 32) {   // the packed pairs form of the same layer (Linear::wsp), same scale S
       const float S = 1.f / L.inv_scale;
       const int kp = taps * 64;

@@ -85,6 +85,8 @@ struct Tuning {
   int qkv_kv_pairs = 1;       // the qkv GEMM leaves the third plane of its K and V columns unwritten (the attention kernel reads them as pairs)
   int enc_fc2_pairs = 1;      // ... and the MLP hidden activation as pairs (fc2 on three MFMAs per product; 3 x 640 crops: max |dlogit| 5.1 - 6.7e-4 vs 5.6 - 7.6e-4 with triples); the attention output - the projection input - stays an exact triple: the one encoder linear whose result moves with the 24th bit (oracle/splitsim.py)
   int craft_products = 3;     // split-operand engines, CRAFT: 3 = activation pairs (~23.5 bits; the heat map stays at fp32 noise level), 4 = exact triples
+  int up_commute = 1;         // split engines, CRAFT's upconv2.0 / 3.0 / 4.0 (1x1 over cat(upsample(y), skip)): W_up . y at the low resolution, its bilinear upsample added in the
+                              // epilogue of the skip half's 1x1 (gemm2.hip, ConvParams::up_z) - the upsampled tensors are never written; 0 = upsample kernel + two-source 1x1
   int head_tail = 1;          // ... and the two 1x1 layers behind conv_cls.4 inside its epilogue (no 16-channel tensors, two launches less); 0 = fp32 MFMA launches
   int head_packed = 1;        // ... with pairs: the 32-channel head tensors as 128-byte pixel rows [x0 | x1] and conv_cls.0 / .2 / .4 on packed pairs (two virtual
                               // chunks instead of three over zero-padded 64-channel rows: two thirds of the MFMAs, half the bytes); 0 = zero-padded rows
@@ -101,6 +103,7 @@ struct Tuning {
   bool set(const std::string& k, int value) {
     if (k == "decoder_mode") decoder_mode = value;
     else if (k == "enc_chunk") enc_chunk = value;
+    else if (k == "up_commute") up_commute = value;
     else if (k == "skinny_split") skinny_split = value;
     else if (k == "skinny_max_rows") skinny_max_rows = value;
     else if (k == "ar_host_check") ar_host_check = value;
@@ -473,6 +476,7 @@ struct Engine {
   // ---- CRAFT, split-operand engines: every tensor between the convolutions lives as f16 planes ([pixel][x0 | x1 | x2], 6 bytes per
   // value); the convolutions' epilogues write them (bias, ReLU, ReLU copy, 2x2 max-pool fused), so no fp32 tensor and no separate
   // split pass exists up to the 32-channel head, which stays on the fp32 MFMA kernel (thin layers: 3 % of the FLOPs).
+  void upconv_commuted(const char* name, const void* y_lo, int C0, const void* skip, int C1, int B, int H, int W, float* z, void* out);
   void sconv(const char* name, const void* in0, int C0, const void* in1, int C1, int B, int H, int W, void* out, int act,
              void* out_relu = nullptr, void* out_pool = nullptr, int pool_relu = 0, int out_planes = -1, int out_ld = 0, bool packed = false, float* tail_heat = nullptr);
   void craft_forward_split(const uint8_t* d_canvas, int B, int H, int W, float* d_heat);

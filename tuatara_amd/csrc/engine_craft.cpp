@@ -158,6 +158,33 @@ void Engine::sconv(const char* name, const void* in0, int C0, const void* in1, i
   timed(kind, flops, flops * np, [&] { if (c3) launch_conv3p(p, stream); else launch_gemm2(p, 0, stream); });
 }
 
+// upconvN.0 = ReLU(W . cat(upsample2x(y), skip) + b), a 1x1 convolution (inside CRAFT's TorchScript module run at tuatara.cpp:376).  The bilinear upsample is a fixed
+// linear map over pixels, the 1x1 convolution one over channels: they commute.  z = W_up . y at the LOW resolution (a quarter of the rows, fp32 out, no bias),
+// then ReLU(W_skip . skip + b + upsample2x(z)) with the four-tap interpolation in the second launch's epilogue (ConvParams::up_z).  The upsampled tensor - as wide
+// as y and four times as long - is neither written nor read; the arithmetic differs from the two-source form at fp32 rounding level only (sums in another order).
+void Engine::upconv_commuted(const char* name, const void* y_lo, int C0, const void* skip, int C1, int B, int H, int W, float* z, void* out) {
+  const Linear& La = craft.at(std::string(name) + ".up");
+  const Linear& Lb = craft.at(std::string(name) + ".skip");
+  if (La.k != C0 || Lb.k != C1 || !La.ws.p || !Lb.ws.p || La.cout != Lb.cout || (H & 1) || (W & 1)) throw std::runtime_error(std::string("commuted up-convolution: shape mismatch at ") + name);
+  const int np = tn.craft_products == 4 ? 4 : 3, Cout = La.cout;
+  const int64_t Mhi = (int64_t)B * H * W, Mlo = Mhi / 4;
+  ConvParams a{};
+  a.in0 = y_lo; a.C0 = C0; a.B = B; a.H = H / 2; a.W = W / 2; a.ks = 1; a.dil = 1;
+  a.wgt = La.ws.p; a.bias = La.b.as<float>(); a.split = np; a.out_scale = La.inv_scale; a.out_planes = 0;
+  a.out = z; a.out_ld = Cout; a.Cout = Cout; a.M = (int)Mlo; a.act = kActNone;
+  if (const char* e = gemm2_check(a)) throw std::runtime_error(std::string(name) + " (low-resolution half): " + e);
+  ConvParams b{};
+  b.in0 = skip; b.C0 = C1; b.B = B; b.H = H; b.W = W; b.ks = 1; b.dil = 1;
+  b.wgt = Lb.ws.p; b.bias = Lb.b.as<float>(); b.split = np; b.out_scale = Lb.inv_scale; b.out_planes = np - 1;
+  b.out = out; b.out_ld = Cout; b.Cout = Cout; b.M = (int)Mhi; b.act = kActRelu;
+  b.up_z = z; b.up_ld = Cout;
+  if (const char* e = gemm2_check(b)) throw std::runtime_error(std::string(name) + " (skip half): " + e);
+  const char* kind = np == 3 ? "gemm2_kernel<SP,NP=3> (CRAFT 1x1 / dilated)" : "gemm2_kernel<SP,NP=4> (CRAFT 1x1 / dilated)";
+  // algorithmic flops: the layer's own (SURVEY.md section 8(d) counts the convolution as the reference runs it); executed: what the two launches multiply
+  timed(kind, 2.0 * Mhi * Cout * C0, 2.0 * Mlo * Cout * C0 * np, [&] { launch_gemm2(a, 0, stream); });
+  timed(kind, 2.0 * Mhi * Cout * C1, 2.0 * Mhi * Cout * C1 * np, [&] { launch_gemm2(b, 0, stream); });
+}
+
 void Engine::craft_forward_split(const uint8_t* d_canvas, int B, int H, int W, float* d_heat) {
   prof_stage = 0;
   const size_t M0 = (size_t)B * H * W, M1 = M0 / 4, M2 = M1 / 4, M3 = M2 / 4, M4 = M3 / 4;
@@ -196,14 +223,23 @@ void Engine::craft_forward_split(const uint8_t* d_canvas, int B, int H, int W, f
   void* fc7 = pbuf(M4, 1024); sconv("slice5.2", c6, 1024, nullptr, 0, B, H4, W4, fc7, kActNone);
   void* u1a = pbuf(M4, 512); sconv("upconv1.0", fc7, 1024, c52, 512, B, H4, W4, u1a, kActRelu);
   void* u1b = pbuf(M4, 256); sconv("upconv1.3", u1a, 512, nullptr, 0, B, H4, W4, u1b, kActRelu);
-  void* up1 = pbuf(M3, 256); prof_break(), launch_upsample2x_planes(u1b, up1, B, H4, W4, 256, stream, npl);
-  void* u2a = pbuf(M3, 256); sconv("upconv2.0", up1, 256, c42, 512, B, H3, W3, u2a, kActRelu);
+  // upconvN.0 over cat(upsample(y), skip): the upsample kernel + a two-source 1x1, or (tn.up_commute) the commuted form that never writes the upsampled tensor
+  auto upconv = [&](const char* name, const void* y_lo, int C0, const void* skip, int C1, int Cout, size_t Mhi, int Hh, int Wh) -> void* {
+    if (tn.up_commute && craft.count(std::string(name) + ".up") && Hh % 2 == 0 && Wh % 2 == 0) {
+      float* z = (float*)fbuf(Mhi / 4, Cout);
+      void* o = pbuf(Mhi, Cout);
+      upconv_commuted(name, y_lo, C0, skip, C1, B, Hh, Wh, z, o);
+      return o;
+    }
+    void* up = pbuf(Mhi, C0); prof_break(), launch_upsample2x_planes(y_lo, up, B, Hh / 2, Wh / 2, C0, stream, npl);
+    void* o = pbuf(Mhi, Cout); sconv(name, up, C0, skip, C1, B, Hh, Wh, o, kActRelu);
+    return o;
+  };
+  void* u2a = upconv("upconv2.0", u1b, 256, c42, 512, 256, M3, H3, W3);
   void* u2b = pbuf(M3, 128); sconv("upconv2.3", u2a, 256, nullptr, 0, B, H3, W3, u2b, kActRelu);
-  void* up2 = pbuf(M2, 128); prof_break(), launch_upsample2x_planes(u2b, up2, B, H3, W3, 128, stream, npl);
-  void* u3a = pbuf(M2, 128); sconv("upconv3.0", up2, 128, c32, 256, B, H2, W2, u3a, kActRelu);
+  void* u3a = upconv("upconv3.0", u2b, 128, c32, 256, 128, M2, H2, W2);
   void* u3b = pbuf(M2, 64);  sconv("upconv3.3", u3a, 128, nullptr, 0, B, H2, W2, u3b, kActRelu);
-  void* up3 = pbuf(M1, 64);  prof_break(), launch_upsample2x_planes(u3b, up3, B, H2, W2, 64, stream, npl);
-  void* u4a = pbuf(M1, 64);  sconv("upconv4.0", up3, 64, c22, 128, B, H1, W1, u4a, kActRelu);
+  void* u4a = upconv("upconv4.0", u3b, 64, c22, 128, 64, M1, H1, W1);
   // 32-channel head: the 3x3 layers on the f16 kernels over planes with 32 zero channels behind the 32 real ones (row = 64 channels);
   // the two 1x1 layers (16 -> 16 -> 2) on the fp32 MFMA kernel
   // (head_packed, pairs only: the 32-channel tensors as 128-byte pixel rows [x0 | x1], their consumers on packed pairs - conv3p.hip, NP = 2)

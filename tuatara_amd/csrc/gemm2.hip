@@ -441,6 +441,30 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
           const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
           v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
         }
+        if constexpr (SP && !(BM == 256 && BN == 256)) {   // (the 256 x 256 tile is not one these layers run on: launch_gemm2)
+          if (p.up_z && valid) {   // + bilinear 2x upsample of the half-resolution tensor at this pixel (ConvParams::up_z)
+            const int Hl = p.H >> 1, Wl = p.W >> 1;
+            const int xo = m % p.W, tq = m / p.W, yo = tq % p.H, bq = tq / p.H;
+            const float sy = fmaxf(0.5f * ((float)yo + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * ((float)xo + 0.5f) - 0.5f, 0.f);
+            const int y0 = (int)sy, x0 = (int)sx;
+            const int y1 = y0 + (y0 < Hl - 1 ? 1 : 0), x1 = x0 + (x0 < Wl - 1 ? 1 : 0);
+            const float ly1 = sy - (float)y0, ly0 = 1.f - ly1, lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+            const float* zb = p.up_z + (int64_t)bq * Hl * Wl * p.up_ld + n;
+            const float* z00 = zb + ((int64_t)y0 * Wl + x0) * p.up_ld; const float* z01 = zb + ((int64_t)y0 * Wl + x1) * p.up_ld;
+            const float* z10 = zb + ((int64_t)y1 * Wl + x0) * p.up_ld; const float* z11 = zb + ((int64_t)y1 * Wl + x1) * p.up_ld;
+  #pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const float4 a = *reinterpret_cast<const float4*>(z00 + 4 * h), b = *reinterpret_cast<const float4*>(z01 + 4 * h);
+              const float4 c = *reinterpret_cast<const float4*>(z10 + 4 * h), d = *reinterpret_cast<const float4*>(z11 + 4 * h);
+              const float aa[4] = {a.x, a.y, a.z, a.w}, bb[4] = {b.x, b.y, b.z, b.w}, cc[4] = {c.x, c.y, c.z, c.w}, dd[4] = {d.x, d.y, d.z, d.w};
+  #pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float top = fmaf(lx1, bb[e], lx0 * aa[e]), bot = fmaf(lx1, dd[e], lx0 * cc[e]);
+                v[4 * h + e] += fmaf(ly1, bot, ly0 * top);
+              }
+            }
+          }
+        }
         if (p.act == kActRelu) {
   #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -608,6 +632,8 @@ const char* gemm2_check(const ConvParams& p) {
   if ((size_t)p.M * p.C0 * es_in >= lim || (size_t)p.M * p.C1 * es_in >= lim || (size_t)p.Cout * K * 2 >= lim) return "gemm2: tensor too large for 32-bit buffer offsets";
   if (p.M != p.B * p.H * p.W || p.M <= 0 || p.Cout <= 0) return "gemm2: bad shape";
   if (p.split && !(p.out_scale > 0.f)) return "gemm2: split mode needs out_scale";
+  if (p.up_z && (!p.split || p.ks != 1 || p.C1 || (p.H & 1) || (p.W & 1) || p.up_ld % 4 || p.up_ld < p.Cout || ((uintptr_t)p.up_z & 15) || p.out_pool || p.resid))
+    return "gemm2: the half-resolution addend (up_z) is the split mode's, on a single-source 1x1 layer over even H and W";
   return nullptr;
 }
 
@@ -644,6 +670,7 @@ void launch_gemm2(const ConvParams& p_in, int cfg, hipStream_t s) {
   // the GELU table (8 KiB) pushes the 256x256 and 128x128 tiles back to 2
   const bool deep = g_x_ring3 && p.act != kActGelu;
   if (p.split) p.dbg_flags = g_split_dbg;
+  if (p.up_z && cfg == 1) cfg = 2;                 // (the half-resolution addend's epilogue is not compiled into the 256 x 256 tile)
   if (p.split && cfg == 1) p.gelu_lut = nullptr;   // 256 x 256 tiles fill the LDS: erf instead of the table
   if (p.split == 4 && (cfg == 2 || cfg == 3 || cfg == 6) && g_split_stream && g_split_stream4 && gemm_sp_eligible(p)) return launch_gemm_sp(p, cfg, s);   // triples
   if (p.split == 3 && (cfg == 2 || cfg == 3 || cfg == 6) && g_split_stream && gemm_sp_eligible(p)) {

@@ -707,6 +707,7 @@ void set_gemm_sp_sched(int v) { g_sp_sched = v; }
 // shapes these kernels take (gemm2.hip's split mode keeps the rest): ks = 1, one source, no pooled / ReLU-copy outputs, K a multiple of 64;
 // pairs: K >= 192; triples: K >= 128 and K / 64 even (the K loop runs in pairs of k0)
 bool gemm_sp_eligible(const ConvParams& p) {
+  if (p.up_z) return false;   // (the half-resolution addend is an epilogue of gemm2.hip's split loop)
   if (p.out_tiled && (!p.out_planes || p.out_ld % 64 != 0 || p.out_full_cols)) return false;   // (tiled planes: whole 64-channel blocks, every plane)
   if ((p.split != 3 && p.split != 4) || p.ks != 1 || p.C1 != 0 || p.out_pool || p.out_relu || p.C0 % 64 != 0 || p.Cout % 8 != 0) return false;
   if (p.split == 3 ? p.C0 < 192 : (p.C0 < 128 || (p.C0 >> 6) % 2 != 0)) return false;
