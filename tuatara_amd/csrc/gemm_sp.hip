@@ -407,6 +407,10 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
       const float* const bp = p.bias + n0c + wn * 96 + fg * 8;
       f16x8 fq[2][3];                                             // [own d half, other d half][plane]
       f16x8 vp[2][2];                                             // V pairs [plane][i]
+      const f16 dn = (f16)(1.f / 2048.f);
+      const f16x8 dnv = {dn, dn, dn, dn, dn, dn, dn, dn};
+      // (K's and V's second planes go to LDS already scaled by 2^-11 - the factor their MFMA operand carries: one multiply per element where it is written
+      // instead of one per reading wave and product, the same f16 product either way)
       auto tile_values = [&](int t, int i, float (&v)[8]) {       // bias + scale of the lane's 8 channels of block t, row half i
         const float4 b0 = *reinterpret_cast<const float4*>(bp + t * 32), b1 = *reinterpret_cast<const float4*>(bp + t * 32 + 4);
         const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
@@ -431,19 +435,18 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
         f16x8 a, b;
         split2_x8(v, a, b);
         unsigned char* d = sK + (kwr + i * 1024 ^ i * 64);
-        *reinterpret_cast<f16x8*>(d) = a; *reinterpret_cast<f16x8*>(d + KV) = b;
+        *reinterpret_cast<f16x8*>(d) = a; *reinterpret_cast<f16x8*>(d + KV) = b * dnv;
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {   // V: kept until every wave is through with K
         float v[8];
         tile_values(2, i, v);
         split2_x8(v, vp[0][i], vp[1][i]);
+        vp[1][i] = vp[1][i] * dnv;
       }
       __syncthreads();
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) fq[1][pl] = *reinterpret_cast<const f16x8*>(sQ + qrd + pl * 1024);
-      const f16 dn = (f16)(1.f / 2048.f);
-      const f16x8 dnv = {dn, dn, dn, dn, dn, dn, dn, dn};
       // S^T = K Q^T: sacc[kt], lane = query q, LDS key rows 16 kt + 4 g + r = keys 32 (kt >> 1) + 8 g + 4 (kt & 1) + r
       f32x4 sacc[8];
       {
@@ -453,8 +456,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
           f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int hf = 0; hf < 2; ++hf) {
-            const f16x8 k0 = *reinterpret_cast<const f16x8*>(kb[hf] + kt * 2048), x1 = *reinterpret_cast<const f16x8*>(kb[hf] + KV + kt * 2048);
-            const f16x8 k0b = k0 * dnv, k1 = x1 * dnv;
+            const f16x8 k0 = *reinterpret_cast<const f16x8*>(kb[hf] + kt * 2048), k1 = *reinterpret_cast<const f16x8*>(kb[hf] + KV + kt * 2048);
+            const f16x8 k0b = k0 * dnv;
             a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, fq[hf][0], a, 0, 0, 0);
             a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0b, fq[hf][1], a, 0, 0, 0);
             a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0b, fq[hf][2], a, 0, 0, 0);
@@ -523,8 +526,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
                        "+v"(lo[1][0]), "+v"(lo[1][1]), "+v"(lo[1][2]), "+v"(lo[1][3]), "+v"(hi[1][0]), "+v"(hi[1][1]), "+v"(hi[1][2]), "+v"(hi[1][3])); \
           _Pragma("unroll") for (int dt = 0; dt < 4; ++dt) {                                                   \
             const f16x8 v0 = __builtin_shufflevector(lo[0][dt], hi[0][dt], 0, 1, 2, 3, 4, 5, 6, 7);            \
-            const f16x8 x1 = __builtin_shufflevector(lo[1][dt], hi[1][dt], 0, 1, 2, 3, 4, 5, 6, 7);            \
-            const f16x8 v0b = v0 * dnv, v1 = x1 * dnv;                                                         \
+            const f16x8 v1 = __builtin_shufflevector(lo[1][dt], hi[1][dt], 0, 1, 2, 3, 4, 5, 6, 7);            \
+            const f16x8 v0b = v0 * dnv;                                                                        \
             f32x4 a = oacc[dt];                                                                                \
             a = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0, fp[0][s], a, 0, 0, 0);                              \
             a = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0b, fp[1][s], a, 0, 0, 0);                             \
