@@ -17,6 +17,13 @@ LAYERS_X4 = ["slice1.0 (conv1_split, u8 canvas -> planes)", "slice1.3 +pool", "s
              "upconv1.0", "upconv1.3", "upconv2.0", "upconv2.3", "upconv3.0", "upconv3.3", "upconv4.0", "upconv4.3 (-> packed 32-channel rows)", "conv_cls.0 (packed pairs)",
              "conv_cls.2 (packed pairs)", "conv_cls.4 + .6 + .8 (packed pairs, fused tail)"]
 LAYERS_X4_UNFUSED = LAYERS_X4[:-1] + ["conv_cls.4", "conv_cls.6 (fp32)", "conv_cls.8 (fp32)"]
+# ... with upconv2.0 / 3.0 / 4.0 commuted with their upsamples (tuning key up_commute, the default): two launches each, no upsample kernels
+LAYERS_X4_COMMUTED = []
+for _l in LAYERS_X4:
+    if _l in ("upconv2.0", "upconv3.0", "upconv4.0"):
+        LAYERS_X4_COMMUTED += [_l + " (W_up . y at the low resolution -> fp32 z)", _l + " (skip half + upsample(z) in the epilogue)"]
+    else:
+        LAYERS_X4_COMMUTED.append(_l)
 
 
 def rows(path, counter):
@@ -29,7 +36,7 @@ f, w = rows(fetch_csv, "FETCH_SIZE"), rows(write_csv, "WRITE_SIZE")
 n = len(LAYERS)
 per_step = len(f) // 3 if len(f) % 3 == 0 else n
 if f and "conv1_split" in f[-per_step]["Kernel_Name"]:       # the f16x4 engine's group (its first launch is conv1_split)
-    LAYERS = LAYERS_X4 if per_step == len(LAYERS_X4) else LAYERS_X4_UNFUSED
+    LAYERS = LAYERS_X4_COMMUTED if per_step == len(LAYERS_X4_COMMUTED) else LAYERS_X4 if per_step == len(LAYERS_X4) else LAYERS_X4_UNFUSED
     n = len(LAYERS)
 f, w = f[-per_step:], w[-per_step:]
 # a 25th launch per step (an igemm fall-back for a thin layer) keeps its kernel name as label

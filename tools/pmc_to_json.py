@@ -33,11 +33,18 @@ conv = {k: v for k, v in kernels.items() if any(c in k for c in CONV) and not an
 tot_f = sum(v["fetch_bytes_per_launch"] * v["launches_per_step"] for v in conv.values())
 tot_w = sum(v["write_bytes_per_launch"] * v["launches_per_step"] for v in conv.values())
 n = sum(v["launches_per_step"] for v in conv.values())
+# every kernel of the detector-only step but the copies and the CCL: the convolutions plus the elementwise kernels between them (pools, upsamples)
+DET_EXC = ("copyBuffer", "fillBuffer", "ccl_", "rowext", "binarize", "candidates", "minmax")
+det = {k: v for k, v in kernels.items() if not any(x in k for x in DET_EXC) and not any(x in k for x in EXC)}
+det_f = sum(v["fetch_bytes_per_launch"] * v["launches_per_step"] for v in det.values())
+det_w = sum(v["write_bytes_per_launch"] * v["launches_per_step"] for v in det.values())
 json.dump({
     "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 tools/prof_pages.py %d %d 0  (second pass: --pmc WRITE_SIZE)" % (pages, steps),
     "corrections": "counter values are KiB; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE as is",
     "pages_per_step": pages, "pages": pages, "steps": steps, "kernels": kernels,
     "craft_conv_kernels": {"launches_per_step": n, "fetch_bytes_per_step": tot_f, "write_bytes_per_step": tot_w,
                                "hbm_bytes_per_launch": (tot_f + tot_w) / max(1, n)},
+    "detector_all_kernels": {"launches_per_step": sum(v["launches_per_step"] for v in det.values()), "fetch_bytes_per_step": det_f, "write_bytes_per_step": det_w,
+                             "hbm_GB_per_page": (det_f + det_w) / 1e9 / pages, "note": "resize + every CRAFT launch (convolutions, pools, upsamples); CCL and copies excluded"},
 }, open(out, "w"), indent=1)
-print(out, "conv+gemm2 launches/step", n, "GB/step", (tot_f + tot_w) / 1e9)
+print(out, "conv+gemm2 launches/step", n, "GB/step", (tot_f + tot_w) / 1e9, "| all detector kernels GB/page", (det_f + det_w) / 1e9 / pages)

@@ -413,6 +413,60 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
     const bool has_next = idx < xcd_count;
 
   // ---- epilogue: lane holds channels n = nb + 32t + (lane>>4)*8 + 0..7 of pixel m = mb + 16i + (lane&15)
+    // ConvParams::up_z (CRAFT's commuted up-convolutions): a pass of its own in front, loads only - bias + the bilinear 2x upsample of the half-resolution
+    // tensor at each row's pixel, folded into the accumulators in place.  Inside the loop below every block's four-tap gather sat behind the previous
+    // block's stores (vmcnt counts both: a write round trip and a read round trip per 16-row block; gemm_sp.hip's two-pass epilogue has the account).
+    bool folded = false;
+    if constexpr (SP && !(BM == 256 && BN == 256)) {   // (the 256 x 256 tile is not one these layers run on: launch_gemm2)
+      if (p.up_z) {
+        folded = true;
+        const int Hl = p.H >> 1, Wl = p.W >> 1;
+        int64_t o00[C::MI], o01[C::MI], o10[C::MI], o11[C::MI];
+        float wx[C::MI], wy[C::MI];
+  #pragma unroll
+        for (int i = 0; i < C::MI; ++i) {
+          const int grow = m0c + wm * C::TM + i * 16 + fr;
+          const int m = grow < p.M ? grow : 0;
+          const int xo = m % p.W, tq = m / p.W, yo = tq % p.H, bq = tq / p.H;
+          const float sy = fmaxf(0.5f * ((float)yo + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * ((float)xo + 0.5f) - 0.5f, 0.f);
+          const int y0 = (int)sy, x0 = (int)sx;
+          const int y1 = y0 + (y0 < Hl - 1 ? 1 : 0), x1 = x0 + (x0 < Wl - 1 ? 1 : 0);
+          wy[i] = sy - (float)y0; wx[i] = sx - (float)x0;
+          const int64_t pb = (int64_t)bq * Hl * Wl;
+          o00[i] = (pb + (int64_t)y0 * Wl + x0) * p.up_ld; o01[i] = (pb + (int64_t)y0 * Wl + x1) * p.up_ld;
+          o10[i] = (pb + (int64_t)y1 * Wl + x0) * p.up_ld; o11[i] = (pb + (int64_t)y1 * Wl + x1) * p.up_ld;
+        }
+  #pragma unroll
+        for (int t = 0; t < C::NJ / 2; ++t) {
+          const int n = n0c + wn * C::TN + t * 32 + fg * 8;
+          if (n >= p.Cout) continue;
+          float bv[8];
+          if (p.bias) {
+            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+            bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+          } else {
+  #pragma unroll
+            for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+          }
+  #pragma unroll
+          for (int i = 0; i < C::MI; ++i) {
+            const float lx1 = wx[i], lx0 = 1.f - lx1, ly1 = wy[i], ly0 = 1.f - ly1;
+            const float* zb = p.up_z + n;
+  #pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const float4 a = *reinterpret_cast<const float4*>(zb + o00[i] + 4 * h), b = *reinterpret_cast<const float4*>(zb + o01[i] + 4 * h);
+              const float4 c = *reinterpret_cast<const float4*>(zb + o10[i] + 4 * h), d = *reinterpret_cast<const float4*>(zb + o11[i] + 4 * h);
+              const float aa[4] = {a.x, a.y, a.z, a.w}, bb[4] = {b.x, b.y, b.z, b.w}, cc[4] = {c.x, c.y, c.z, c.w}, dd[4] = {d.x, d.y, d.z, d.w};
+  #pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float top = fmaf(lx1, bb[e], lx0 * aa[e]), bot = fmaf(lx1, dd[e], lx0 * cc[e]);
+                acc[2 * t + h][i][e] = fmaf(acc[2 * t + h][i][e], p.out_scale, bv[4 * h + e]) + fmaf(ly1, bot, ly0 * top);
+              }
+            }
+          }
+        }
+      }
+    }
   #pragma unroll
     for (int t = 0; t < C::NJ / 2; ++t) {
       const int n = n0c + wn * C::TN + t * 32 + fg * 8;
@@ -433,37 +487,16 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
         float v[8];
   #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if constexpr (SP) { v[e] = fmaf(acc[2 * t][i][e], p.out_scale, bv[e]); v[4 + e] = fmaf(acc[2 * t + 1][i][e], p.out_scale, bv[4 + e]); }
+          if constexpr (SP) {
+            v[e] = folded ? acc[2 * t][i][e] : fmaf(acc[2 * t][i][e], p.out_scale, bv[e]);
+            v[4 + e] = folded ? acc[2 * t + 1][i][e] : fmaf(acc[2 * t + 1][i][e], p.out_scale, bv[4 + e]);
+          }
           else { v[e] = acc[2 * t][i][e] + bv[e]; v[4 + e] = acc[2 * t + 1][i][e] + bv[4 + e]; }
         }
         if (p.resid && valid) {
           const float* rp = p.resid + (int64_t)(p.resid_mod ? m % p.resid_mod : m) * p.resid_ld + n;
           const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
           v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-        }
-        if constexpr (SP && !(BM == 256 && BN == 256)) {   // (the 256 x 256 tile is not one these layers run on: launch_gemm2)
-          if (p.up_z && valid) {   // + bilinear 2x upsample of the half-resolution tensor at this pixel (ConvParams::up_z)
-            const int Hl = p.H >> 1, Wl = p.W >> 1;
-            const int xo = m % p.W, tq = m / p.W, yo = tq % p.H, bq = tq / p.H;
-            const float sy = fmaxf(0.5f * ((float)yo + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * ((float)xo + 0.5f) - 0.5f, 0.f);
-            const int y0 = (int)sy, x0 = (int)sx;
-            const int y1 = y0 + (y0 < Hl - 1 ? 1 : 0), x1 = x0 + (x0 < Wl - 1 ? 1 : 0);
-            const float ly1 = sy - (float)y0, ly0 = 1.f - ly1, lx1 = sx - (float)x0, lx0 = 1.f - lx1;
-            const float* zb = p.up_z + (int64_t)bq * Hl * Wl * p.up_ld + n;
-            const float* z00 = zb + ((int64_t)y0 * Wl + x0) * p.up_ld; const float* z01 = zb + ((int64_t)y0 * Wl + x1) * p.up_ld;
-            const float* z10 = zb + ((int64_t)y1 * Wl + x0) * p.up_ld; const float* z11 = zb + ((int64_t)y1 * Wl + x1) * p.up_ld;
-  #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const float4 a = *reinterpret_cast<const float4*>(z00 + 4 * h), b = *reinterpret_cast<const float4*>(z01 + 4 * h);
-              const float4 c = *reinterpret_cast<const float4*>(z10 + 4 * h), d = *reinterpret_cast<const float4*>(z11 + 4 * h);
-              const float aa[4] = {a.x, a.y, a.z, a.w}, bb[4] = {b.x, b.y, b.z, b.w}, cc[4] = {c.x, c.y, c.z, c.w}, dd[4] = {d.x, d.y, d.z, d.w};
-  #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float top = fmaf(lx1, bb[e], lx0 * aa[e]), bot = fmaf(lx1, dd[e], lx0 * cc[e]);
-                v[4 * h + e] += fmaf(ly1, bot, ly0 * top);
-              }
-            }
-          }
         }
         if (p.act == kActRelu) {
   #pragma unroll
