@@ -166,6 +166,20 @@ def test_x4_craft_commuted_upconvolutions(eng_x4_random, weights_random, hw):
     assert np.abs(new - old).max() < 1e-4 * scale
 
 
+def test_x4_craft_four_and_eight_wave_tiles_are_bit_identical(eng_x4_random):
+    """conv3p.hip's 128-channel tiles on four waves of 64 pixels x 128 channels (static fragment addresses, the default; tuning key "c3_c128_waves") against
+    eight waves of 64 x 64 (runtime-tap loop): the K order and every sum are the same, so the heat map is identical bit for bit - a batch of two full pages
+    (where the 128-wide tiles are picked) on fully random weights."""
+    canvas = np.random.default_rng(31).integers(0, 256, (1024, 768, 3), dtype=np.uint8)
+    four = eng_x4_random.craft_heatmap(canvas)
+    assert eng_x4_random.set_tuning(b"c3_c128_waves", 8) == 0
+    try:
+        eight = eng_x4_random.craft_heatmap(canvas)
+    finally:
+        eng_x4_random.set_tuning(b"c3_c128_waves", 4)
+    assert np.isfinite(four).all() and np.array_equal(four, eight)
+
+
 def test_x4_craft_head_on_packed_pairs_equals_zero_padded_rows(eng_x4_random, weights_random):
     """The 32-channel head tensors as 128-byte pixel rows [x0 | x1] with conv_cls.0 / .2 / .4 on packed pairs (conv3p.hip, NP = 2: the default)
     against the same layers over zero-padded 64-channel rows: the same three products per value (x0 w0 + x1 w0 / 2^11 in one chunk, x0 w1 in

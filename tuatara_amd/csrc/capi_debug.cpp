@@ -287,6 +287,7 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "c3_xs1_max_cin") set_conv3p_single_stage_max_cin(value);
   else if (k == "c3_force_bn128") set_conv3p_force_bn128(value);
   else if (k == "c3_c64_waves") set_conv3p_c64_waves(value);
+  else if (k == "c3_c128_waves") set_conv3p_c128_waves(value);
   else if (k == "c3_narrow_wide") set_conv3p_narrow_wide(value);
   else if (k == "c3_narrow_frac") set_conv3p_narrow_frac(value);
   else if (k == "c3_narrowest_frac") set_conv3p_narrowest_frac(value);

@@ -76,7 +76,7 @@ struct C3 {
 // batch regime wants (the CU's other workgroups cover the wait, the LDS buys residency); a workgroup ALONE on its CU (the deep layers of a single page: 48 - 192
 // workgroups on 256 CUs) waits out one L2 / Infinity-Cache round trip per tap with them, ~0.65 us x 216 taps for 512 input channels, and takes four (eight: no further gain).
 template <int BN, int WM, int WN, bool FIRST, int XS, int LPW, int NP = 0, int NWS = 2>   // NP: 0 = bf16, 4 = triples, 3 = pairs, 2 = packed pairs (split.h).  XS: patch stages (1 when Cin = 64: a single chunk, and two workgroups fit a CU)
-__global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM * WN == 4 ? 1 : 1)) void conv3p_kernel(ConvParams p) {
+__global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 && !(BN == 128 && WN == 1) ? 4 : 2)) void conv3p_kernel(ConvParams p) {   // (second number: waves per SIMD the register budget allows)
   static_assert(NWS == 2 || ((NWS == 4 || NWS == 8) && XS == 1 && BN <= 64 && !FIRST), "more than two weight stages: the static-address loop's");
   using C = C3<BN, WM, WN, LPW>;
   using G = Geo<LPW>;
@@ -248,7 +248,9 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 ? 4 : 2) * (WM 
   // Measured per layer (16 pages): the 64-wide tiles gain 6-17 % (upconv2.3 98 -> 91, upconv3.3 136 -> 112, upconv4.3 258 -> 220 us); the
   // 128-wide ones do not (3.27 -3.5 %, 1.7 +11 %: they sit at the 128-register limit and the extra live addresses spill), so those keep
   // the runtime-tap loop below.
-  constexpr bool STATIC_ADDR = XS == 1 && BN <= 64 && C::TM == 64 && !FIRST;
+  // BN = 128 on FOUR waves (WN = 1: wave tiles of 64 pixels x all 128 channels, 64 MFMAs per tap and wave, 24 fragment reads instead of 32 per 64 MFMAs; two
+  // workgroups per CU = two waves per SIMD with 256 registers each) takes this loop too: the experiment behind the tuning key c3_c128_waves.
+  constexpr bool STATIC_ADDR = XS == 1 && (BN <= 64 || (BN == 128 && WN == 1)) && C::TM == 64 && !FIRST;
   if constexpr (STATIC_ADDR) {
     const int pib = ((wm * C::TM) >> LPW) * HW2 + fr;
     int xbase[8];                                          // byte offsets from smem (32-bit LDS arithmetic)
@@ -1107,6 +1109,13 @@ static int g_c32_tile = 1;          // Cout <= 32: 32-wide tiles, 4 waves of 64 
 void set_conv3p_c32_tile(int v) { g_c32_tile = v; }
 static int g_narrow_bn64 = 2;       // 16 x 16-patch maps with Cout > 64 on 64-wide tiles: 0 never, 1 always, 2 when the 128-wide tiles do not fill the chip once
 void set_conv3p_narrow_bn64(int v) { g_narrow_bn64 = v; }
+// split pairs, Cout > 64 tiles on 8 x 32 patches: 4 waves (wave tile 64 x 128, static addresses, 256 registers: the default) or 8 (wave tile 64 x 64, runtime-tap loop, 128
+// registers).  Same K order, same sums: bit-identical heat maps.  Measured per 8-page group (the eight layers on these tiles, same box, twice): 7.94 / 8.00 -> 7.47 / 7.54 ms.
+// The eight-wave loop spends ~33 vector and ~40 scalar instructions per tap on fragment addresses, in all four waves of a SIMD, and vector instructions and MFMAs of a
+// SIMD do not overlap (conv3p_first2s_kernel's stamps): 16 / (16 + 2.2 x 4) = 0.65 is the MFMA-busy fraction the counters showed.  The four-wave loop has 52 vector
+// instructions per NINE taps (576 MFMAs).  Requesting each pixel fragment one block of eight MFMAs ahead changes nothing on top (7.47 / 7.54): not a latency.
+static int g_c128_waves = 4;
+void set_conv3p_c128_waves(int w) { g_c128_waves = w; }
 static int g_c64_waves = 8;        // Cout <= 64 tiles: 8 waves (wave tile 64x32) or 4 waves (wave tile 64x64, fewer LDS fragment reads per MFMA)
 void set_conv3p_c64_waves(int w) { g_c64_waves = w; }
 static int g_force_bn128 = 1;     // BN = 128 single-stage tiles, two workgroups per CU, for every Cout > 64 (0: BN = 256, one per CU, for Cout % 256 == 0):
@@ -1207,8 +1216,10 @@ void launch_conv3p(const ConvParams& p, hipStream_t s) {
       // pairs (the default): the tiles of a page or two - workgroups (nearly) alone on their CUs - request their weights further ahead (NWS)
       const int tiles64 = p.B * (wide ? (p.H / 8) * (p.W / 32) : (p.H / 16) * (p.W / 16)) * ((p.Cout + 63) / 64);
       if (narrowest && g_deep_w) return wide ? launch_c3<32, 4, 1, false, 1, 5, 3, 4>(p, s) : launch_c3<32, 4, 1, false, 1, 4, 3, 4>(p, s);
+      // (the 64-wide tiles on four waves of 64 x 64 instead of eight of 64 x 32 - both on static addresses: 1525 against 1457 us per 8-page group: eight stay)
       if (!narrowest && g_deep_w64 && p.Cout >= 64 && (p.Cout <= 64 || narrow) && tiles64 < g_deep_w64 * device_cu_count(256))
         return wide ? launch_c3<64, 4, 2, false, 1, 5, 3, 4>(p, s) : launch_c3<64, 4, 2, false, 1, 4, 3, 4>(p, s);
+      if (g_c128_waves == 4 && wide && p.Cout > 64 && !narrow) return launch_c3<128, 4, 1, false, 1, 5, 3>(p, s);
       TTR_C3_SPLIT(3)
     }
     TTR_C3_SPLIT(4)

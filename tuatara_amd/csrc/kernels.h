@@ -84,6 +84,7 @@ void set_conv3p_narrowest_frac(int v);   // 32-wide tiles when the 64-wide ones 
 void set_conv3p_single_stage_max_cin(int c);
 void set_conv3p_force_bn128(int v);
 void set_conv3p_c64_waves(int w);
+void set_conv3p_c128_waves(int w);
 void set_conv3p_first_persistent(int v);
 void set_conv3p_narrow_bn64(int v);
 void set_conv3p_c32_tile(int v);   // Cout <= 32 on 32-wide tiles (default 1)
