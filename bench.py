@@ -392,12 +392,13 @@ def main():
         fam_ms = sum(k["ms"] for k in craft_kinds)
         fam_alg, fam_exec = sum(k["alg_flops"] for k in craft_kinds), sum(k["exec_flops"] for k in craft_kinds)
         # HBM bytes per launch of the dominant kernel: the two --pmc passes (FETCH_SIZE doubled, WRITE_SIZE) committed under profiles/
-        traffic = traffic_src = fam_traffic = None
+        traffic = traffic_src = fam_traffic = det_gb_page = None
         for name in (("r04_pmc_craft_x4.json", "r03_pmc_craft_x4.json") if args.precision == "f16x4" else ("r02_pmc_craft_b16_v2.json",)):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     tj = json.load(f)
                 fam_traffic = tj["craft_conv_kernels"]["hbm_bytes_per_launch"]
+                det_gb_page = (tj.get("detector_all_kernels") or {}).get("hbm_GB_per_page")
                 tag = dom["kind"].split("<")[0] if dom else ""
                 width = dom["kind"].split("<")[1].split(",")[0] if dom and "<" in dom["kind"] else ""
                 for kn, kv in tj["kernels"].items():
@@ -444,6 +445,7 @@ def main():
                                       "mfma_pipe_frac": fam_exec / (fam_ms * 1e-3) / 1e12 / peak if fam_ms else None,
                                       "ms_per_pass": fam_ms / max(1, n_pass), "algorithmic_gflop_per_page": fam_alg / max(1, P * n_pass) / 1e9,
                                       "survey_gflop_per_page": CRAFT_GFLOP_PER_PAGE, "traffic_bytes_per_launch_all_kinds": fam_traffic,
+                                      "hbm_GB_per_page_every_detector_kernel": det_gb_page,   # (convolutions + pools + resize: the same two --pmc passes)
                                       "by_kernel": sorted((line(k) for k in craft_kinds), key=lambda d: -d["avg_launch_us"] * d["launches_per_pass"])},
         }
 
