@@ -137,7 +137,7 @@ def test_skinny_layernorm_prologue_changes_nothing(eng):
     """The decoder's LayerNorm + linear pairs as ONE skinny launch (gemm_skx.hip, LayerNorm prologue; tuning key "skx_ln_fuse") against the
     LayerNorm kernel followed by the skinny linear: the same arithmetic in the same order, so the AR logits, the refined logits and the ids
     are identical bit for bit - at a page's crop count (three 16-row blocks, the last one ragged), for a single crop, and for 17."""
-    _fold_check(eng, "skx_ln_fuse", (40, 1, 17))
+    _fold_check(eng, "skx_ln_fuse", (40, 1, 17, 300))      # (300 crops: the prologue form is offered up to 2048 rows)
 
 
 def test_argmax_inside_the_next_steps_embedding_kernel_changes_nothing(eng):

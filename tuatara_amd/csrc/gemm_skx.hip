@@ -250,8 +250,12 @@ __global__ __launch_bounds__(256) void gemm_skx_kernel(ConvParams p) {
 // channels and aligned rows, fp32 outputs take any channel count and row stride (whether the kernel is the faster one for a shape is the
 // caller's call: it is for a few thousand rows at most)
 // the LayerNorm-prologue form: fp32 rows of 384 in, a page's worth of them (the 16-row workgroups)
+// rows up to which the LayerNorm-prologue form is offered (16-row workgroups: every one of them re-reads its 32 weight rows).  At a batch's 1280 rows the three LayerNorm + linear
+// pairs of an AR step still win as one launch each: 25 steps 2.39 -> 2.17 ms of kernel time, 75 launches fewer (the token prologue keeps its 256: one crop per row there)
+static int g_skx_ln_max_rows = 2048;
+void set_gemm_skx_ln_max_rows(int v) { g_skx_ln_max_rows = v; }
 bool gemm_skx_ln_eligible(const ConvParams& p) {
-  if ((!p.ln_in && !p.tok) || !p.ln_gamma || !p.ln_beta || p.C0 != 384 || p.M > 256) return false;
+  if ((!p.ln_in && !p.tok) || !p.ln_gamma || !p.ln_beta || p.C0 != 384 || p.M > (p.tok ? 256 : g_skx_ln_max_rows)) return false;
   if (p.tok ? (!p.tok_emb || (((uintptr_t)p.tok_emb | (uintptr_t)p.tok_pos) & 15)) : (p.ln_ld % 4 != 0 || ((uintptr_t)p.ln_in & 15))) return false;
   if (((uintptr_t)p.ln_gamma | (uintptr_t)p.ln_beta) & 15) return false;
   ConvParams q = p;
