@@ -180,6 +180,23 @@ def test_x4_craft_four_and_eight_wave_tiles_are_bit_identical(eng_x4_random):
     assert np.isfinite(four).all() and np.array_equal(four, eight)
 
 
+@pytest.mark.parametrize("hw", [(1024, 768), (576, 1024), (96, 160)])
+def test_x4_craft_dilated_layer_on_the_streamlined_loop_is_bit_identical(eng_x4_random, hw):
+    """slice5.1 (3x3, dilation 6) on gemm_sp.hip's loop with per-tap row offsets (the default, tuning key "gsp_ks3": 256 x 128 tiles for a batch, 64- or
+    128-row tiles for a page) against gemm2.hip's loop: the same products in the same order - identical heat maps bit for bit, on fully random weights; a full
+    page, a ragged canvas (taps leaving the image at odd places) and a small one (a map narrower than the dilated footprint: most taps out of range)."""
+    canvas = np.random.default_rng(41).integers(0, 256, (hw[0], hw[1], 3), dtype=np.uint8)
+    new = eng_x4_random.craft_heatmap(canvas)
+    outs = []
+    for k in (0, 3):
+        assert eng_x4_random.set_tuning(b"gsp_ks3", k) == 0
+        try:
+            outs.append(eng_x4_random.craft_heatmap(canvas))
+        finally:
+            eng_x4_random.set_tuning(b"gsp_ks3", 1)
+    assert np.isfinite(new).all() and np.array_equal(new, outs[0]) and np.array_equal(new, outs[1])
+
+
 def test_x4_craft_head_on_packed_pairs_equals_zero_padded_rows(eng_x4_random, weights_random):
     """The 32-channel head tensors as 128-byte pixel rows [x0 | x1] with conv_cls.0 / .2 / .4 on packed pairs (conv3p.hip, NP = 2: the default)
     against the same layers over zero-padded 64-channel rows: the same three products per value (x0 w0 + x1 w0 / 2^11 in one chunk, x0 w1 in

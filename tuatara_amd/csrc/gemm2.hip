@@ -713,6 +713,9 @@ void launch_gemm2(const ConvParams& p_in, int cfg, hipStream_t s) {
     if (g_split_stream == 1 || (p.Cout < 512 && Ctot >= 1024)) sc = 3;
     return launch_gemm_sp(p, sc, s);
   }
+  // a dilated 3x3 layer of a batch (CRAFT's slice5.1: 1.06 PFLOP/s executed on this file's loop, whose tap arithmetic runs per load) on gemm_sp.hip's loop
+  if (p.split == 3 && p.ks == 3 && (cfg == 2 || cfg == 3) && g_split_stream && gemm_sp_ks3_eligible(p))
+    return launch_gemm_sp_ks3(p, cfg, s);
   if (p.x_tiled || p.out_tiled) throw std::runtime_error("gemm2: tiled planes are gemm_sp.hip's (this shape did not qualify for it)");
   // a page's worth of pixels on this loop (CRAFT's dilated 3x3 and two-source 1x1 layers): no more 128 x 128 tiles than CUs - 128 x 64 tiles on twice
   // as many workgroups move three quarters of the bytes per K step each (slice5.1 at one page 182 -> 157 us, upconv1.0 65 -> 52, upconv2.0 41 -> 33)

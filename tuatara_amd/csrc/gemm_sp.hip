@@ -69,7 +69,11 @@ struct SpCfg {
 // EM: the plain epilogue's case fixed at compile time (0 = by ConvParams' flags at run time, every case in one kernel).  1 = the encoder's fc1: GELU by the
 // table, the hidden activation out as tiled pairs; 2 = the residual linears (proj, fc2, the decoder's): bias + residual, fp32 rows out.  With the flags
 // tested per 8-value block hipcc serialised the GELU table reads (one LDS round trip and two branches per VALUE) and spilled scalars into lanes.
-template <int BM, int BN, int WM, int WN, int XST, int WST, int MINB, bool SCHED, int NP, int EPI = 0, int EM = 0>
+// KS3: a 3x3 convolution of any dilation (CRAFT's slice5.1: dilation 6 on the 1/16-resolution map, which conv3p.hip's patches do not take) as this GEMM with
+// K = 9 taps x Cin: the weight stream is unchanged (its rows are [tap][Cin] already); the activation stream re-forms its lanes' row offsets at every tap
+// change - pixel + (dy W + dx) dil, out of range (zero fill) where the tap leaves the image - from two registers per piece kept per tile (offset of the
+// centre pixel, its (y, x)): ~8 vector instructions per piece and tap, every Cin / 64 k steps.  gemm2.hip's loop did that arithmetic per load.
+template <int BM, int BN, int WM, int WN, int XST, int WST, int MINB, bool SCHED, int NP, int EPI = 0, int EM = 0, bool KS3 = false>
 __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams p) {
   using C = SpCfg<BM, BN, WM, WN, XST, WST>;
   static_assert(NP == 3 || (NP == 4 && XST == 3 && WST == 2), "pairs, or triples on rings 3 + 2");
@@ -82,6 +86,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
   const int wm = wave / WN, wn = wave % WN;
 
   static_assert(EM == 0 || EPI == 0, "fixed epilogue cases are the plain epilogue's");
+  static_assert(!KS3 || (NP == 3 && EPI == 0), "3x3 taps: the pairs loop");
   float2* const glut = reinterpret_cast<float2*>(smem + C::LDS);          // Hermite GELU table behind the rings (common.h: gelu_hermite)
   if (EM == 1 || (EM == 0 && p.act == kActGelu && p.gelu_lut)) {
     for (int i = tid; i < 512; i += C::NT) reinterpret_cast<uint4*>(glut)[i] = reinterpret_cast<const uint4*>(p.gelu_lut)[i];
@@ -100,15 +105,16 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
   int idx = blockIdx.x >> 3;
   if (idx >= xcd_count) return;
 
-  const int K = p.C0, nk0 = K >> 6;
+  const int K = p.C0, nkt = K >> 6, nk0 = KS3 ? 9 * nkt : nkt;   // (KS3: k steps per tap, per tile)
+  const int Kw = KS3 ? 9 * K : K;                                  // halves per weight plane
   const __amdgpu_buffer_rsrc_t rsx = sp_rsrc(p.in0, (unsigned)((size_t)p.M * K * 2 * PLX));   // rows [x0 | x1 (| x2)]
   // weights: rows [w0 | w0b | w1], or (wgt_tiled) the same halves as 1-KiB pieces [Cout / 8][plane][K / 64][8 rows][64]: what one wave instruction of the
   // loader fetches is then one contiguous KiB instead of eight 128-byte runs 6 K bytes apart (LDS-DMA from L2: 55 - 65 against 36 - 40 B / clk per CU,
   // profiles/r03_pmc_stall_parseq.txt section 4), the rows of a piece in the order the LDS image wants them
   const bool wtiled = p.wgt_tiled != nullptr;
-  const __amdgpu_buffer_rsrc_t rsw = sp_rsrc(wtiled ? p.wgt_tiled : p.wgt, (unsigned)((size_t)((p.Cout + 31) / 32 * 32) * K * 6));
+  const __amdgpu_buffer_rsrc_t rsw = sp_rsrc(wtiled ? p.wgt_tiled : p.wgt, (unsigned)((size_t)((p.Cout + 31) / 32 * 32) * Kw * 6));
   const unsigned x_plstep = p.x_tiled ? (unsigned)(K >> 6) * 1024u : (unsigned)K * 2u, x_kstep = p.x_tiled ? 1024u : 128u;   // byte offsets of one activation plane and of one k0
-  const unsigned w_pl1 = wtiled ? (unsigned)(2 * (K >> 6)) * 1024u : (unsigned)K * 4u, w_kstep = wtiled ? 1024u : 128u;   // byte offsets of plane w1 and of one k0
+  const unsigned w_pl1 = wtiled ? (unsigned)(2 * (K >> 6)) * 1024u : (unsigned)Kw * 4u, w_kstep = wtiled ? 1024u : 128u;   // byte offsets of plane w1 and of one k0
   constexpr unsigned OOB = 0x80000000u;
 
   unsigned char* const xring = smem;
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
       const int nl = (row & ~31) + (q16 >> 2) * 8 + ((row >> 4) & 1) * 4 + (q16 & 3);   // channel held by that LDS row
       const int n = n0 + nl;
       if (wtiled) wo[j] = (live && n < p.Cout) ? (unsigned)((n0 + (row & ~7)) >> 3) * (unsigned)(3 * (K >> 6)) * 1024u + (unsigned)((row & 7) * 128 + g * 16) : OOB;
-      else wo[j] = (live && n < p.Cout) ? ((unsigned)n * (unsigned)(3 * K) + g * 8) * 2u : OOB;
+      else wo[j] = (live && n < p.Cout) ? ((unsigned)n * (unsigned)(3 * Kw) + g * 8) * 2u : OOB;
     }
   };
 
@@ -144,6 +150,34 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
   unsigned xvo[C::XPW], wvo[C::WPW], xdl[C::XPW], wdl[C::WPW];
   int xs_k = 0, xs_pl = 0, xs_slot = 0;
   int ws_k = 0, ws_pl = 0, ws_slot = 0;
+  // KS3: the X stream's own tile and tap; per piece the centre pixel's row offset (OOB past M or past the workgroup's tiles) and its (y << 16 | x)
+  unsigned xcen[KS3 ? C::XPW : 1];
+  int xyq[KS3 ? C::XPW : 1];
+  int xs_tap = 0, xs_li = idx;
+  auto x_set_tile = [&](int li) {
+    const bool live = li < xcd_count;
+    const int tile = xcd_first + li, tm = tile / tilesN, m0 = tm * BM;
+#pragma unroll
+    for (int i = 0; i < C::XPW; ++i) {
+      const int row = (i * C::NW + wave) * 8 + (lane >> 3);
+      const int g = (lane & 7) ^ ((row >> 1) & 7);
+      const int m = m0 + row;
+      const int mm = m < p.M ? m : 0;
+      const int xq = mm % p.W, yq = (mm / p.W) % p.H;
+      xyq[KS3 ? i : 0] = (yq << 16) | xq;
+      xcen[KS3 ? i : 0] = (live && m < p.M) ? ((unsigned)m * (unsigned)(PLX * K) + g * 8) * 2u : OOB;
+    }
+  };
+  auto x_set_tap = [&](int tap) {
+    const int ty = tap / 3, dy = (ty - 1) * p.dil, dx = (tap - 3 * ty - 1) * p.dil;
+    const unsigned shift = (unsigned)((dy * p.W + dx) * (PLX * K * 2));
+#pragma unroll
+    for (int i = 0; i < C::XPW; ++i) {
+      const int y = (xyq[KS3 ? i : 0] >> 16) + dy, x = (xyq[KS3 ? i : 0] & 0xffff) + dx;
+      const bool ok = xcen[KS3 ? i : 0] != OOB && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+      xvo[i] = ok ? xcen[KS3 ? i : 0] + shift : OOB;
+    }
+  };
   auto issue_x = [&]() {
     const unsigned soff = (unsigned)xs_pl * x_plstep + (unsigned)xs_k * x_kstep;
     unsigned char* sb = xring + xs_slot * C::XBYTES + wave * 1024;
@@ -156,11 +190,21 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
     const bool lastpl = xs_pl == PLX - 1;              // the last plane -> next k0
     const int k1 = xs_k + (lastpl ? 1 : 0);
     xs_pl = lastpl ? 0 : xs_pl + 1;
+    if constexpr (KS3) {                               // xs_k counts the k steps inside a tap
+      const bool tapwrap = k1 == nkt;
+      xs_k = tapwrap ? 0 : k1;
+      if (tapwrap) {                                   // (scalar: uniform over the workgroup)
+        xs_tap = xs_tap == 8 ? 0 : xs_tap + 1;
+        if (xs_tap == 0) { xs_li += J; x_set_tile(xs_li); }
+        x_set_tap(xs_tap);
+      }
+    } else {
     const bool wrap = k1 == nk0;
     xs_k = wrap ? 0 : k1;
     const unsigned mask = wrap ? 0xFFFFFFFFu : 0u;
 #pragma unroll
     for (int i = 0; i < C::XPW; ++i) xvo[i] += xdl[i] & mask;
+    }
   };
   auto issue_w = [&]() {
     const unsigned soff = (ws_pl ? w_pl1 : 0u) + (unsigned)ws_k * w_kstep;
@@ -216,6 +260,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
   // ---- prologue: the loads the steady state would have issued before ph0 of the first k0, in its order
   tile_offsets(idx, xvo, wvo);
   TTR_SP_NEXT_DELTAS(idx)
+  if constexpr (KS3) { x_set_tile(idx); x_set_tap(0); }
   // Requests per phase in steady state, by ring depth (a tile is requested as soon as the slot it takes has been read):
   //   X ring 3:  ph0 X1(k+1)   ph2 X0(k+2)        X ring 2:  ph0 X0(k+1)   ph2 X1(k+1)
   //   W ring 3:  ph0 W1(k+1)   ph1 W0(k+2)        W ring 2:  ph0 W0(k+1)   ph1 W1(k+1)
@@ -684,7 +729,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
 
 #undef TTR_SP_NEXT_DELTAS
 
-template <int BM, int BN, int WM, int WN, int XST, int WST, int MINB, bool SCHED, int NP = 3, int EPI = 0, int EM = 0>
+template <int BM, int BN, int WM, int WN, int XST, int WST, int MINB, bool SCHED, int NP = 3, int EPI = 0, int EM = 0, bool KS3 = false>
 static void launch_sp(const ConvParams& p_in, hipStream_t s) {
   using C = SpCfg<BM, BN, WM, WN, XST, WST>;
   constexpr int TABLE = EPI == 1 ? 57344 : 8208;   // behind the rings: the GELU table, or the attention epilogue's Q / K / V images
@@ -692,12 +737,12 @@ static void launch_sp(const ConvParams& p_in, hipStream_t s) {
   if ((size_t)(C::LDS + TABLE) * MINB > 160 * 1024) p.gelu_lut = nullptr;   // no room for the table beside these rings: erf
   static PerDeviceOnce once;
   static_assert(EPI == 0 || C::LDS + TABLE <= 160 * 1024, "attention epilogue: rings + images must fit the LDS");
-  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_sp_kernel<BM, BN, WM, WN, XST, WST, MINB, SCHED, NP, EPI, EM>, hipFuncAttributeMaxDynamicSharedMemorySize, std::min(C::LDS + TABLE, 160 * 1024))); });
+  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_sp_kernel<BM, BN, WM, WN, XST, WST, MINB, SCHED, NP, EPI, EM, KS3>, hipFuncAttributeMaxDynamicSharedMemorySize, std::min(C::LDS + TABLE, 160 * 1024))); });
   const size_t lds = C::LDS + (EPI == 1 || (p.act == kActGelu && p.gelu_lut) ? TABLE : 0);
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
   const int cap = device_cu_count(256) * MINB / 8 * 8;
   const int grid = std::min((tilesM * tilesN + 7) / 8 * 8, std::max(cap, 8));
-  hipLaunchKernelGGL((gemm_sp_kernel<BM, BN, WM, WN, XST, WST, MINB, SCHED, NP, EPI, EM>), dim3(grid), dim3(C::NT), lds, s, p);
+  hipLaunchKernelGGL((gemm_sp_kernel<BM, BN, WM, WN, XST, WST, MINB, SCHED, NP, EPI, EM, KS3>), dim3(grid), dim3(C::NT), lds, s, p);
 }
 
 static int g_sp_few = 1;   // the few-tile rules of launch_gemm_sp (a page's worth of rows)
@@ -716,6 +761,24 @@ bool gemm_sp_eligible(const ConvParams& p) {
   if (p.split == 3 ? p.C0 < 192 : (p.C0 < 128 || (p.C0 >> 6) % 2 != 0)) return false;
   if (p.resid && (size_t)(p.resid_mod ? p.resid_mod : p.M) * p.resid_ld * 4 >= ((size_t)1 << 31)) return false;   // the epilogue reads the residual through a buffer descriptor
   return (size_t)p.M * p.C0 * (p.split == 3 ? 4 : 6) < ((size_t)1 << 31) && (size_t)p.Cout * p.C0 * 6 < ((size_t)1 << 31);
+}
+
+// 3x3 taps (any dilation) on the pairs loop (gemm_sp_kernel's KS3): row-major planes in, single source, no pooled / ReLU-copy / tiled outputs
+static int g_sp_ks3 = 1;   // 0: gemm2.hip's loop; 1: this file's (tile by launch_gemm_sp_ks3); 3: ... never the 64-row tile
+void set_gemm_sp_ks3(int v) { g_sp_ks3 = v; }
+bool gemm_sp_ks3_eligible(const ConvParams& p) {
+  if (!g_sp_ks3 || p.split != 3 || p.ks != 3 || p.dil < 1 || p.C1 != 0 || p.out_pool || p.out_relu || p.C0 % 64 != 0 || p.Cout % 8 != 0) return false;
+  if (p.x_tiled || p.out_tiled || p.wgt_tiled || p.up_z || p.resid || p.out_full_cols || p.skip) return false;
+  if (p.M != p.B * p.H * p.W || p.H >= 32768 || p.W >= 65536) return false;
+  return (size_t)p.M * p.C0 * 4 < ((size_t)1 << 31) && (size_t)((p.Cout + 31) / 32 * 32) * 9 * p.C0 * 6 < ((size_t)1 << 31);
+}
+void launch_gemm_sp_ks3(const ConvParams& p, int cfg, hipStream_t s) {
+  if (!gemm_sp_ks3_eligible(p)) throw std::runtime_error("gemm_sp (3x3 taps): shape not supported");
+  const int tiles128 = ((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+  if (cfg == 2) launch_sp<256, 128, 4, 2, 3, 3, 1, true, 3, 0, 0, true>(p, s);
+  // (a page - no more 128 x 128 tiles than CUs -: 64-row tiles on eight waves, as the 1x1 layers'; slice5.1 of one page 157 -> ~105 us.  g_sp_ks3 = 3 keeps the 128-row tile)
+  else if (g_sp_few && g_sp_ks3 != 3 && tiles128 <= device_cu_count(256)) launch_sp<64, 128, 2, 4, 3, 3, 1, true, 3, 0, 0, true>(p, s);
+  else launch_sp<128, 128, 2, 2, 3, 2, 2, true, 3, 0, 0, true>(p, s);
 }
 
 // cfg: 2 = 256 x 128 tiles, 6 = 128 x 256 (one workgroup of 8 waves per CU), 3 = 128 x 128 (two workgroups of 4 waves per CU: one's epilogue -

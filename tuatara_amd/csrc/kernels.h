@@ -24,6 +24,9 @@ bool gemm_sp_eligible(const ConvParams& p);
 void set_gemm_sp_sched(int v);
 void set_gemm_sp_few(int v);
 void set_gemm_sp_epi(int v);
+void set_gemm_sp_ks3(int v);
+bool gemm_sp_ks3_eligible(const ConvParams& p);
+void launch_gemm_sp_ks3(const ConvParams& p, int cfg, hipStream_t s);
 void set_gemm_skx_ln_max_rows(int v);
 void launch_gemm_sp(const ConvParams& p, int cfg, hipStream_t s);   // gemm_sp.hip: streamlined split-pairs GEMM (cfg 2 = 256 x 128 tiles, 6 = 128 x 256)
 void set_gemm2_split_cfg(int v);
