@@ -7,7 +7,7 @@ from tuatara_amd import synth, weights as W
 from tuatara_amd.engine import DeviceBuffer, Engine
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 d = tempfile.mkdtemp(); W.make_synthetic_weights(d, seed=0, structured=True)
-eng = Engine(d, precision="bf16")
+eng = Engine(d, precision=os.environ.get("TTR_PREC", "bf16"))
 P = 32
 pages = np.stack([synth.synthetic_page(200 + i, 1024, 768, n_words=40) for i in range(P)])
 buf = DeviceBuffer(pages.nbytes); buf.upload(pages)
