@@ -1111,9 +1111,10 @@ static int g_narrow_bn64 = 2;       // 16 x 16-patch maps with Cout > 64 on 64-w
 void set_conv3p_narrow_bn64(int v) { g_narrow_bn64 = v; }
 // split pairs, Cout > 64 tiles on 8 x 32 patches: 4 waves (wave tile 64 x 128, static addresses, 256 registers: the default) or 8 (wave tile 64 x 64, runtime-tap loop, 128
 // registers).  Same K order, same sums: bit-identical heat maps.  Measured per 8-page group (the eight layers on these tiles, same box, twice): 7.94 / 8.00 -> 7.47 / 7.54 ms.
-// The eight-wave loop spends ~33 vector and ~40 scalar instructions per tap on fragment addresses, in all four waves of a SIMD, and vector instructions and MFMAs of a
-// SIMD do not overlap (conv3p_first2s_kernel's stamps): 16 / (16 + 2.2 x 4) = 0.65 is the MFMA-busy fraction the counters showed.  The four-wave loop has 52 vector
-// instructions per NINE taps (576 MFMAs).  Requesting each pixel fragment one block of eight MFMAs ahead changes nothing on top (7.47 / 7.54): not a latency.
+// The eight-wave loop spends ~33 vector and ~40 scalar instructions per tap on fragment addresses, in all four waves of a SIMD (vector instructions and MFMAs of a
+// SIMD share an issue port: conv3p_first2s_kernel's stamps); the four-wave loop has 47 vector instructions per NINE taps (576 MFMAs).  Counters per MFMA, whole
+// kernel (profiles/r04_pmc_stall_craft.txt): vector 1.23 -> 0.49, scalar 2.03 -> 0.38, LDS 0.51 -> 0.385; MFMA busy 0.65 at 1.68 GHz -> 0.69 at 1.63.
+// Requesting each pixel fragment one block of eight MFMAs ahead changes nothing on top (7.47 / 7.54): not a latency.
 static int g_c128_waves = 4;
 void set_conv3p_c128_waves(int w) { g_c128_waves = w; }
 static int g_c64_waves = 8;        // Cout <= 64 tiles: 8 waves (wave tile 64x32) or 4 waves (wave tile 64x64, fewer LDS fragment reads per MFMA)
