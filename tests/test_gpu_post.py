@@ -106,3 +106,29 @@ def test_ccl_statistics_paths(eng_f32, hw):
     got = eng_f32.ccl_boxes(heat)
     ref, _, _ = post.get_detected_boxes(heat[..., 0], heat[..., 1])
     assert len(ref) >= 3 and np.array_equal(got, ref)
+
+
+def test_gpu_side_min_area_rect_equals_the_hosts(eng_f32):
+    """get_detected_boxes' per-component tail on the GPU (post_ops.hip: ccl_rects_kernel, one lane per candidate running geometry.cpp's arithmetic; the default,
+    tuning key "gpu_calipers") against the host's calipers, and against the path that falls back to the host when the hulls' scratch pool is too small
+    (gpu_calipers = 2: a 2 KB pool): the same float32 rectangles in the same order, bit for bit - on the synthetic heat maps of the golden set (40 anisotropic
+    blobs, bridges, edge-touching and tiny components) and on a full-size map with a page-wide component."""
+    from oracle import post
+    from tests.golden.make_golden import synthetic_heatmap
+    maps = [synthetic_heatmap(seed) for seed in (0, 1, 2, 3)]
+    big = np.zeros((512, 384, 2), np.float32)
+    big[40:470, 30:350, 0] = 1.0                      # one component of 430 rows: ~900 hull candidates
+    big[10:14, 10:60, 0] = 0.9
+    maps.append(big)
+    for hm in maps:
+        ref = eng_f32.ccl_boxes(hm)
+        outs = []
+        for k in (0, 2):
+            assert eng_f32.set_tuning(b"gpu_calipers", k) == 0
+            try:
+                outs.append(eng_f32.ccl_boxes(hm))
+            finally:
+                eng_f32.set_tuning(b"gpu_calipers", 1)
+        assert len(ref) > 0 and np.array_equal(ref, outs[0]) and np.array_equal(ref, outs[1])
+        oracle_rects, _, _ = post.get_detected_boxes(hm[..., 0], hm[..., 1])
+        assert np.array_equal(ref, oracle_rects)

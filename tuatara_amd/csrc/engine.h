@@ -85,6 +85,8 @@ struct Tuning {
   int qkv_kv_pairs = 1;       // the qkv GEMM leaves the third plane of its K and V columns unwritten (the attention kernel reads them as pairs)
   int enc_fc2_pairs = 1;      // ... and the MLP hidden activation as pairs (fc2 on three MFMAs per product; 3 x 640 crops: max |dlogit| 5.1 - 6.7e-4 vs 5.6 - 7.6e-4 with triples); the attention output - the projection input - stays an exact triple: the one encoder linear whose result moves with the 24th bit (oracle/splitsim.py)
   int craft_products = 3;     // split-operand engines, CRAFT: 3 = activation pairs (~23.5 bits; the heat map stays at fp32 noise level), 4 = exact triples
+  int gpu_calipers = 1;       // get_detected_boxes' per-component tail (dilated extremes -> hull -> minAreaRect, tuatara.cpp:162-179) on the GPU (post_ops.hip: ccl_rects_kernel);
+                              // the host then reads 24 bytes per candidate instead of its row extremes and runs no calipers; 0 = geometry.cpp on the host
   int up_commute = 1;         // split engines, CRAFT's upconv2.0 / 3.0 / 4.0 (1x1 over cat(upsample(y), skip)): W_up . y at the low resolution, its bilinear upsample added in the
                               // epilogue of the skip half's 1x1 (gemm2.hip, ConvParams::up_z) - the upsampled tensors are never written; 0 = upsample kernel + two-source 1x1
   int head_tail = 1;          // ... and the two 1x1 layers behind conv_cls.4 inside its epilogue (no 16-channel tensors, two launches less); 0 = fp32 MFMA launches
@@ -104,6 +106,7 @@ struct Tuning {
     if (k == "decoder_mode") decoder_mode = value;
     else if (k == "enc_chunk") enc_chunk = value;
     else if (k == "up_commute") up_commute = value;
+    else if (k == "gpu_calipers") gpu_calipers = value;
     else if (k == "skinny_split") skinny_split = value;
     else if (k == "skinny_max_rows") skinny_max_rows = value;
     else if (k == "ar_host_check") ar_host_check = value;
@@ -237,7 +240,10 @@ struct Result {
 
 struct CclBatch {   // device workspaces of the CCL stage for a batch of equally sized pages
   DevBuf tnorm, flags, parent, mm, area, bbox, maxt, cand_slot, cand, counters, rows;
+  DevBuf rects, cal_pool, cal_ctr;   // GPU-side minAreaRect: per-candidate results, the hulls' scratch pool and its bump counter
+  static constexpr int kCalCap = 4 << 20;   // floats (16 MB: ~230 k hull points per CRAFT group; a group that needs more falls back to the host's calipers)
   int pages = 0, npx = 0, max_cand = 0;
+  int cal_cap_now = kCalCap;          // (tuning key gpu_calipers = 2 shrinks it to 512 floats: the host-fallback path under test)
   CclBuffers view(int p0 = 0) {   // the slices of pages p0.. (every array is strided by the page)
     CclBuffers b;
     const size_t o = (size_t)p0 * npx;
@@ -245,6 +251,7 @@ struct CclBatch {   // device workspaces of the CCL stage for a batch of equally
     b.area = area.as<int>() + o; b.bbox = bbox.as<int>() + o * 4; b.maxt = maxt.as<unsigned>() + o; b.cand_slot = cand_slot.as<int>() + o;
     b.cand = cand.as<int>() + (size_t)p0 * max_cand * 8; b.counters = counters.as<int>() + (size_t)p0 * 2; b.rows_packed = rows.as<int>() + o * 2;
     b.max_cand = max_cand;
+    b.rects = rects.as<float>() + (size_t)p0 * max_cand * 6; b.cal_pool = cal_pool.as<float>(); b.cal_ctr = cal_ctr.as<int>(); b.cal_cap = cal_cap_now;
     return b;
   }
   void ensure(int pages_, int npx_, int max_cand_) {
@@ -253,6 +260,7 @@ struct CclBatch {   // device workspaces of the CCL stage for a batch of equally
     tnorm.ensure(n * 4); flags.ensure(n); parent.ensure(n * 4); mm.ensure((size_t)pages * 16);
     area.ensure(n * 4); bbox.ensure(n * 16); maxt.ensure(n * 4); cand_slot.ensure(n * 4);
     cand.ensure((size_t)pages * max_cand * 32); counters.ensure((size_t)pages * 8); rows.ensure(n * 8);
+    rects.ensure((size_t)pages * max_cand * 24); cal_pool.ensure((size_t)kCalCap * 4); cal_ctr.ensure(64);
   }
 };
 
@@ -354,7 +362,7 @@ struct Engine {
   DevBuf pq_ws[24];
   DevBuf canvas, heat, staging_img, crops, rects_dev, logits, ar_logits, ids_dev, tokens;
   CclBatch ccl;
-  PinnedBuf h_counters, h_cand, h_rows, h_rects[2], h_ids[2];   // pinned staging of the small host <-> device transfers
+  PinnedBuf h_counters, h_cand, h_rows, h_rects_f, h_rects[2], h_ids[2];   // pinned staging of the small host <-> device transfers
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   float stage_ms[4] = {0, 0, 0, 0};
   float host_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // host wall-clock splits of the last run_pages (ttr_last_host_us)

@@ -19,6 +19,11 @@ void Engine::allgather_host(const void* mine, size_t bytes, void* all) {
 void Engine::ccl_launch(const float* d_heat, int p0, int pages, int total, int g, int H2, int W2) {
   if (p0 == 0) { ccl.ensure(total, H2 * W2, cfg.max_components); h_counters.ensure((size_t)total * 8); }
   launch_ccl(d_heat, pages, H2, W2, cfg.text_threshold, cfg.link_threshold, cfg.low_text, cfg.min_area, ccl.view(p0), stream);
+  ccl.cal_cap_now = tn.gpu_calipers == 2 ? 512 : CclBatch::kCalCap;
+  if (tn.gpu_calipers) {   // minAreaRect of every candidate, on the stream right behind its row extremes
+    TTR_HIP_CHECK(hipMemsetAsync(ccl.cal_ctr.p, 0, 4, stream));
+    launch_ccl_rects(ccl.view(p0), pages, H2, W2, stream);
+  }
   TTR_HIP_CHECK(hipMemcpyAsync(h_counters.as<int>() + 2 * p0, ccl.counters.as<int>() + 2 * p0, (size_t)pages * 8, hipMemcpyDeviceToHost, stream));
   while ((int)group_ev.size() <= g) { hipEvent_t e; TTR_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); group_ev.push_back(e); }
   TTR_HIP_CHECK(hipEventRecord(group_ev[g], stream));
@@ -41,8 +46,42 @@ void Engine::ccl_collect(int p0, int pages, int g, int H2, int W2, std::vector<s
   h_cand.ensure(pitch_c * pages + 4); h_rows.ensure(pitch_r * pages + 4);
   int* cand = h_cand.as<int>();
   int* rw = h_rows.as<int>();
+  const CclBuffers v = ccl.view(p0);
+  if (tn.gpu_calipers && max_c > 0) {
+    // the rectangles were computed on the GPU (ccl_rects_kernel): candidates (for the label order) + 24 bytes of result each
+    const size_t pitch_q = (size_t)max_c * 24;
+    h_rects_f.ensure(pitch_q * pages + 4);
+    float* rq = h_rects_f.as<float>();
+    TTR_HIP_CHECK(hipMemcpy2DAsync(cand, pitch_c, v.cand, (size_t)ccl.max_cand * 32, pitch_c, pages, hipMemcpyDeviceToHost, copy_stream));
+    TTR_HIP_CHECK(hipMemcpy2DAsync(rq, pitch_q, v.rects, (size_t)ccl.max_cand * 24, pitch_q, pages, hipMemcpyDeviceToHost, copy_stream));
+    TTR_HIP_CHECK(hipEventRecord(copy_ev, copy_stream));
+    spin_event(copy_ev);
+    const double tc2g = now_us();
+    bool pool_full = false;
+    for (int pg = 0; pg < pages && !pool_full; ++pg)
+      for (int i = 0; i < counters[2 * pg]; ++i)
+        if (reinterpret_cast<const int*>(rq + (size_t)pg * (pitch_q / 4) + 6 * (size_t)i)[0] == 2) { pool_full = true; break; }
+    if (!pool_full) {
+      for (int pg = 0; pg < pages; ++pg) {
+        const int n = counters[2 * pg];
+        const int* cd = cand + off_c[pg];
+        const float* q = rq + (size_t)pg * (pitch_q / 4);
+        std::vector<int> order(n);
+        for (int i = 0; i < n; ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return cd[8 * a] < cd[8 * b]; });  // label order = ascending root
+        for (int i : order) {
+          if (reinterpret_cast<const int*>(q + 6 * (size_t)i)[0] != 1) continue;
+          RRect r;
+          r.cx = q[6 * i + 1]; r.cy = q[6 * i + 2]; r.w = q[6 * i + 3]; r.h = q[6 * i + 4]; r.angle = q[6 * i + 5];
+          det[p0 + pg].push_back(r);
+        }
+      }
+      host_us[1] += (float)(tc1 - tc0); host_us[2] += (float)(tc2g - tc1); host_us[3] += (float)(now_us() - tc2g);
+      return;
+    }
+    // (the scratch pool was too small for this group's hulls: the host's calipers below, as without gpu_calipers)
+  }
   if (max_c > 0) {
-    const CclBuffers v = ccl.view(p0);
     TTR_HIP_CHECK(hipMemcpy2DAsync(cand, pitch_c, v.cand, (size_t)ccl.max_cand * 32, pitch_c, pages, hipMemcpyDeviceToHost, copy_stream));
     TTR_HIP_CHECK(hipMemcpy2DAsync(rw, pitch_r, v.rows_packed, (size_t)ccl.npx * 8, pitch_r, pages, hipMemcpyDeviceToHost, copy_stream));
     TTR_HIP_CHECK(hipEventRecord(copy_ev, copy_stream));

@@ -214,11 +214,18 @@ struct CclBuffers {
   int* counters;          // [pages][2]: n_cand, total_rows
   int* rows_packed;       // [pages][npx][2]: per candidate row {min x, max x} of the link-masked pixels
   int max_cand;
+  // GPU-side minAreaRect (rects_kernel): per candidate {status, cx, cy, w, h, angle} (status as int bits: 0 nothing left, 1 a rectangle, 2 the scratch pool was
+  // full - the host's calipers take that group); scratch for the hulls: one pool per batch, bump-allocated
+  float* rects;           // [pages][max_cand][6]
+  float* cal_pool; int* cal_ctr; int cal_cap;   // pool of cal_cap floats, *cal_ctr = floats handed out (zeroed by ccl_init_kernel of page 0)
 };
 void launch_ccl(const float* heat /*[pages][H][W][2]*/, int pages, int H, int W, float text_threshold, float link_threshold, float low_text, int min_area,
                 const CclBuffers& b, hipStream_t s);
 // crops: rects5[n] = {x0,y0,x1,y1,page} (clamped, x1/y1 exclusive) of images u8 [pages][h,w,3] (page stride page_bytes)
 // -> out u8 [N][32][128][3]; one launch for the crops of every page of a batch
 void launch_pack_crops(const uint8_t* images, size_t page_bytes, int stride, const int* rects5, uint8_t* out, int N, hipStream_t s);
+// get_detected_boxes' per-component tail on the GPU (tuatara.cpp:162-179: niter, ROI, dilation, findNonZero + minAreaRect): one lane per candidate, geometry.cpp's
+// arithmetic step for step (float32 calipers, double where OpenCV is double) -> CclBuffers::rects.  After launch_ccl on the same stream.
+void launch_ccl_rects(const CclBuffers& b, int pages, int H, int W, hipStream_t s);
 
 }  // namespace ttr

@@ -251,6 +251,243 @@ void launch_ccl(const float* heat, int pages, int H, int W, float text_threshold
   hipLaunchKernelGGL(rowext_kernel, grid, blk, 0, s, b, H, W);
 }
 
+// ------------------------------------------------------------------ minAreaRect on the GPU
+// One lane per candidate runs geometry.cpp's component_to_rect / min_area_rect as they stand (same operations in the same order and precision, no
+// contraction): dilated row extremes -> points -> sort (x, y) + unique -> monotone-chain hull (double cross products) -> rotating calipers (float32) ->
+// centre, sides (double sqrt), angle (double atan2).  Scratch per candidate (points, hull, edge vectors, inverse lengths: 9 floats per point) comes from
+// one pool by atomic bump; a candidate that does not get its share reports status 2 and the host computes the group as before.
+namespace {
+struct DPt { float x, y; };
+#pragma clang fp contract(off)
+__device__ inline double d_cross(const DPt& o, const DPt& a, const DPt& b) {
+  return ((double)a.x - o.x) * ((double)b.y - o.y) - ((double)a.y - o.y) * ((double)b.x - o.x);
+}
+__device__ inline bool d_less(const DPt& a, const DPt& b) { return a.x < b.x || (a.x == b.x && a.y < b.y); }
+// sort (unless the caller has: `sorted`) + unique in place, hull into h (capacity 2 n); returns the hull's size (n < 3 after unique: the points themselves)
+__device__ int d_convex_hull(DPt* p, int n, DPt* h, bool sorted) {
+  if (!sorted)
+  for (int gap = n >> 1; gap > 0; gap = gap == 2 ? 1 : (int)(gap * 5 / 11)) {   // shell sort (any correct sort gives std::sort's sequence: duplicates are removed below)
+    for (int i = gap; i < n; ++i) {
+      const DPt v = p[i];
+      int j = i;
+      for (; j >= gap && d_less(v, p[j - gap]); j -= gap) p[j] = p[j - gap];
+      p[j] = v;
+    }
+  }
+  int m = 0;
+  for (int i = 0; i < n; ++i)
+    if (m == 0 || p[i].x != p[m - 1].x || p[i].y != p[m - 1].y) p[m++] = p[i];
+  n = m;
+  if (n < 3) { for (int i = 0; i < n; ++i) h[i] = p[i]; return n; }
+  int k = 0;
+  for (int i = 0; i < n; ++i) { while (k >= 2 && d_cross(h[k - 2], h[k - 1], p[i]) <= 0) --k; h[k++] = p[i]; }
+  for (int i = n - 2, t = k + 1; i >= 0; --i) { while (k >= t && d_cross(h[k - 2], h[k - 1], p[i]) <= 0) --k; h[k++] = p[i]; }
+  return k - 1;
+}
+__device__ void d_calipers(const DPt* points, int n, DPt* vect, float* inv_len, float out[6]) {
+  float minarea = 3.402823466e+38f;
+  int left = 0, bottom = 0, right = 0, top = 0;
+  int seq[4];
+  float orientation = 0.f, base_a, base_b = 0.f;
+  DPt pt0 = points[0];
+  float left_x = pt0.x, right_x = pt0.x, top_y = pt0.y, bottom_y = pt0.y;
+  for (int i = 0; i < n; ++i) {
+    if (pt0.x < left_x) left_x = pt0.x, left = i;
+    if (pt0.x > right_x) right_x = pt0.x, right = i;
+    if (pt0.y > top_y) top_y = pt0.y, top = i;
+    if (pt0.y < bottom_y) bottom_y = pt0.y, bottom = i;
+    const DPt pt = points[i + 1 < n ? i + 1 : 0];
+    const double dx = pt.x - pt0.x, dy = pt.y - pt0.y;
+    vect[i].x = (float)dx; vect[i].y = (float)dy;
+    inv_len[i] = (float)(1. / sqrt(dx * dx + dy * dy));
+    pt0 = pt;
+  }
+  {
+    double ax = vect[n - 1].x, ay = vect[n - 1].y;
+    for (int i = 0; i < n; ++i) {
+      const double bx = vect[i].x, by = vect[i].y;
+      const double convexity = ax * by - ay * bx;
+      if (convexity != 0) { orientation = convexity > 0 ? 1.f : -1.f; break; }
+      ax = bx; ay = by;
+    }
+  }
+  base_a = orientation;
+  seq[0] = bottom; seq[1] = right; seq[2] = top; seq[3] = left;
+  int best_left = 0, best_bottom = 0;
+  float best_a = 1.f, best_b = 0.f, best_w = 0.f, best_h = 0.f;
+  for (int k = 0; k < n; ++k) {
+    const float dp0 = +base_a * vect[seq[0]].x + base_b * vect[seq[0]].y;
+    const float dp1 = -base_b * vect[seq[1]].x + base_a * vect[seq[1]].y;
+    const float dp2 = -base_a * vect[seq[2]].x - base_b * vect[seq[2]].y;
+    const float dp3 = +base_b * vect[seq[3]].x - base_a * vect[seq[3]].y;
+    float maxcos = dp0 * inv_len[seq[0]];
+    int main_element = 0;
+    { const float c = dp1 * inv_len[seq[1]]; if (c > maxcos) { main_element = 1; maxcos = c; } }
+    { const float c = dp2 * inv_len[seq[2]]; if (c > maxcos) { main_element = 2; maxcos = c; } }
+    { const float c = dp3 * inv_len[seq[3]]; if (c > maxcos) { main_element = 3; maxcos = c; } }
+    {
+      const int pindex = main_element == 0 ? seq[0] : main_element == 1 ? seq[1] : main_element == 2 ? seq[2] : seq[3];
+      const float lead_x = vect[pindex].x * inv_len[pindex], lead_y = vect[pindex].y * inv_len[pindex];
+      if (main_element == 0) { base_a = lead_x; base_b = lead_y; }
+      else if (main_element == 1) { base_a = lead_y; base_b = -lead_x; }
+      else if (main_element == 2) { base_a = -lead_x; base_b = -lead_y; }
+      else { base_a = -lead_y; base_b = lead_x; }
+    }
+    if (main_element == 0) { if (++seq[0] == n) seq[0] = 0; }
+    else if (main_element == 1) { if (++seq[1] == n) seq[1] = 0; }
+    else if (main_element == 2) { if (++seq[2] == n) seq[2] = 0; }
+    else { if (++seq[3] == n) seq[3] = 0; }
+    float dx = points[seq[1]].x - points[seq[3]].x, dy = points[seq[1]].y - points[seq[3]].y;
+    const float width = dx * base_a + dy * base_b;
+    dx = points[seq[2]].x - points[seq[0]].x; dy = points[seq[2]].y - points[seq[0]].y;
+    const float height = -dx * base_b + dy * base_a;
+    const float area = width * height;
+    if (area <= minarea) {
+      minarea = area;
+      best_left = seq[3]; best_bottom = seq[0];
+      best_a = base_a; best_b = base_b; best_w = width; best_h = height;
+    }
+  }
+  const float A1 = best_a, B1 = best_b, A2 = -best_b, B2 = best_a;
+  const float C1 = A1 * points[best_left].x + points[best_left].y * B1;
+  const float C2 = A2 * points[best_bottom].x + points[best_bottom].y * B2;
+  const float idet = 1.f / (A1 * B2 - A2 * B1);
+  out[0] = (C1 * B2 - C2 * B1) * idet;
+  out[1] = (A1 * C2 - A2 * C1) * idet;
+  out[2] = A1 * best_w; out[3] = B1 * best_w;
+  out[4] = A2 * best_h; out[5] = B2 * best_h;
+}
+// geometry.cpp: min_area_rect on n points (pts is sorted in place); rr = {cx, cy, w, h, angle in degrees}
+__device__ void d_min_area_rect(DPt* pts, int n, DPt* hull, DPt* vect, float* inv_len, float rr[5], bool sorted) {
+  const double kPi = 3.1415926535897932384626433832795;
+  const int hn = d_convex_hull(pts, n, hull, sorted);
+  float cx = 0.f, cy = 0.f, w = 0.f, h = 0.f, angle = 0.f;
+  if (hn > 2) {
+    float out[6];
+    d_calipers(hull, hn, vect, inv_len, out);
+    cx = out[0] + (out[2] + out[4]) * 0.5f;
+    cy = out[1] + (out[3] + out[5]) * 0.5f;
+    w = (float)sqrt((double)out[2] * out[2] + (double)out[3] * out[3]);
+    h = (float)sqrt((double)out[4] * out[4] + (double)out[5] * out[5]);
+    angle = (float)atan2((double)out[3], (double)out[2]);
+  } else if (hn == 2) {
+    cx = (hull[0].x + hull[1].x) * 0.5f;
+    cy = (hull[0].y + hull[1].y) * 0.5f;
+    const double dx = hull[1].x - hull[0].x, dy = hull[1].y - hull[0].y;
+    w = (float)sqrt(dx * dx + dy * dy);
+    h = 0;
+    angle = (float)atan2(dy, dx);
+  } else if (hn == 1) {
+    cx = hull[0].x; cy = hull[0].y;
+  }
+  angle = (float)((angle * 180) / kPi);
+  rr[0] = cx; rr[1] = cy; rr[2] = w; rr[3] = h; rr[4] = angle;
+}
+}  // namespace
+
+// One wave per candidate, lane 0 at work: the hull's scratch lives in the workgroup's LDS (a dependent access costs an LDS round trip instead of an L2 one:
+// the sort, the hull and the calipers are chains of them) when the candidate has at most kRectLds points, else in the global pool.
+constexpr int kRectLds = 448;   // points: 9 x 448 floats = 16 KB
+__global__ __launch_bounds__(64) void ccl_rects_kernel(CclBuffers b, int H, int W) {
+  __shared__ float lds_scratch[9 * kRectLds];
+  __shared__ int lds_rows[2 * 1024];
+  const size_t pg = blockIdx.y;
+  const int slot = blockIdx.x;
+  const int* counters = b.counters + pg * 2;
+  if (slot >= counters[0] || slot >= b.max_cand) return;      // (uniform over the workgroup)
+  const int* c = b.cand + (pg * b.max_cand + slot) * 8;
+  float* rr = b.rects + (pg * b.max_cand + slot) * 6;
+  const int* rows = b.rows_packed + pg * (size_t)H * W * 2 + 2 * (size_t)c[6];
+  {   // the candidate's row extremes into LDS, all lanes (lane 0 alone would wait out an L2 round trip per row)
+    const int hrows = c[5] - c[3] + 1;
+    if (hrows <= 1024) {
+      for (int i = threadIdx.x; i < 2 * hrows; i += 64) lds_rows[i] = rows[i];
+      __syncthreads();
+      rows = lds_rows;
+    }
+  }
+  __shared__ int lds_n;
+  // geometry.cpp: component_to_rect
+  const int x = c[2], y = c[3], w = c[4] - c[2] + 1, h = c[5] - c[3] + 1, size = c[1];
+  const int niter = (int)sqrt((double)(size * min(w, h) / (w * h) * 2));   // tuatara.cpp:166, integer inside the sqrt
+  const int sx = max(0, x - niter), sy = max(0, y - niter);
+  const int ex = min(W, x + w + niter + 1), ey = min(H, y + h + niter + 1);
+  const int k = 1 + niter, a = k / 2, back = k - 1 - a;
+  const int oy0 = max(sy, y - back), oy1 = min(ey - 1, y + h - 1 + a);
+  const int nmax = 2 * max(oy1 - oy0 + 1, 0);
+  if (nmax == 0) { if (threadIdx.x == 0) reinterpret_cast<int*>(rr)[0] = 0; return; }
+  const bool in_lds = !(nmax > kRectLds || b.cal_cap < 9 * kRectLds);   // (a pool smaller than the LDS share: the fallback path under test)
+  if (!in_lds && threadIdx.x != 0) return;                               // the pool path is lane 0's alone
+  float* scratch = lds_scratch;
+  if (!in_lds) {
+    const int need = 9 * nmax;
+    const int off = atomicAdd(b.cal_ctr, need);
+    if (off < 0 || off + need > b.cal_cap) { reinterpret_cast<int*>(rr)[0] = 2; return; }
+    scratch = b.cal_pool + off;
+  }
+  DPt* pts = reinterpret_cast<DPt*>(scratch);                 // nmax points
+  DPt* hull = pts + nmax;                                      // 2 nmax
+  DPt* vect = hull + 2 * nmax;                                 // nmax
+  float* inv_len = reinterpret_cast<float*>(vect + nmax);      // nmax
+  int n = 0;
+  if (in_lds) {   // a row per lane; the points land in any order (they are sorted below, and equal points are equal)
+    if (threadIdx.x == 0) lds_n = 0;
+    __syncthreads();
+    for (int oy = oy0 + (int)threadIdx.x; oy <= oy1; oy += 64) {
+      int mn = 0x7fffffff, mx = -1;
+      for (int s = max(y, oy - a); s <= min(y + h - 1, oy + back); ++s) {
+        const int* r = rows + 2 * (s - y);
+        if (r[1] < 0) continue;
+        mn = min(mn, r[0]); mx = max(mx, r[1]);
+      }
+      if (mx < 0) continue;
+      mn = max(mn - back, sx); mx = min(mx + a, ex - 1);
+      const int cnt = mx != mn ? 2 : 1;
+      const int at = atomicAdd(&lds_n, cnt);
+      pts[at] = DPt{(float)mn, (float)oy};
+      if (cnt == 2) pts[at + 1] = DPt{(float)mx, (float)oy};
+    }
+  } else
+  for (int oy = oy0; oy <= oy1; ++oy) {
+    int mn = 0x7fffffff, mx = -1;
+    for (int s = max(y, oy - a); s <= min(y + h - 1, oy + back); ++s) {
+      const int* r = rows + 2 * (s - y);
+      if (r[1] < 0) continue;
+      mn = min(mn, r[0]); mx = max(mx, r[1]);
+    }
+    if (mx < 0) continue;
+    mn = max(mn - back, sx); mx = min(mx + a, ex - 1);
+    pts[n++] = DPt{(float)mn, (float)oy};
+    if (mx != mn) pts[n++] = DPt{(float)mx, (float)oy};
+  }
+  bool sorted = false;
+  if (in_lds) {   // the sort on all lanes: a point's place = the number of points before it in (x, y, index) order; through the hull's space and back
+    __syncthreads();
+    n = lds_n;
+    for (int i = threadIdx.x; i < n; i += 64) {
+      const DPt v = pts[i];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) { const DPt u = pts[j]; rank += (d_less(u, v) || (u.x == v.x && u.y == v.y && j < i)) ? 1 : 0; }
+      hull[rank] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 64) pts[i] = hull[i];
+    __syncthreads();
+    sorted = true;
+    if (threadIdx.x != 0) return;
+  }
+  if (n == 0) { reinterpret_cast<int*>(rr)[0] = 0; return; }
+  float out5[5];
+  d_min_area_rect(pts, n, hull, vect, inv_len, out5, sorted);
+  reinterpret_cast<int*>(rr)[0] = 1;
+  rr[1] = out5[0]; rr[2] = out5[1]; rr[3] = out5[2]; rr[4] = out5[3]; rr[5] = out5[4];
+}
+
+void launch_ccl_rects(const CclBuffers& b, int pages, int H, int W, hipStream_t s) {
+  if (!b.rects || !b.cal_pool || !b.cal_ctr) throw std::runtime_error("ccl_rects: no buffers");
+  hipLaunchKernelGGL(ccl_rects_kernel, dim3(b.max_cand, pages), dim3(64), 0, s, b, H, W);
+}
+
 // ------------------------------------------------------------------ crop-batch packer
 // One workgroup per crop: OpenCV fixed-point bilinear resample of image[y0:y1, x0:x1] to 32x128.
 // The reference swaps channels before cropping (:349) and again after the resize (:441); the
