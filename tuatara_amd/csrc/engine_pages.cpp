@@ -20,10 +20,7 @@ void Engine::ccl_launch(const float* d_heat, int p0, int pages, int total, int g
   if (p0 == 0) { ccl.ensure(total, H2 * W2, cfg.max_components); h_counters.ensure((size_t)total * 8); }
   launch_ccl(d_heat, pages, H2, W2, cfg.text_threshold, cfg.link_threshold, cfg.low_text, cfg.min_area, ccl.view(p0), stream);
   ccl.cal_cap_now = tn.gpu_calipers == 2 ? 512 : CclBatch::kCalCap;
-  if (tn.gpu_calipers) {   // minAreaRect of every candidate, on the stream right behind its row extremes
-    TTR_HIP_CHECK(hipMemsetAsync(ccl.cal_ctr.p, 0, 4, stream));
-    launch_ccl_rects(ccl.view(p0), pages, H2, W2, stream);
-  }
+  if (tn.gpu_calipers) launch_ccl_rects(ccl.view(p0), pages, H2, W2, stream);   // minAreaRect of every candidate, on the stream right behind its row extremes
   TTR_HIP_CHECK(hipMemcpyAsync(h_counters.as<int>() + 2 * p0, ccl.counters.as<int>() + 2 * p0, (size_t)pages * 8, hipMemcpyDeviceToHost, stream));
   while ((int)group_ev.size() <= g) { hipEvent_t e; TTR_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); group_ev.push_back(e); }
   TTR_HIP_CHECK(hipEventRecord(group_ev[g], stream));

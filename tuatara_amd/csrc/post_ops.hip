@@ -43,6 +43,7 @@ __global__ void ccl_init_kernel(CclBuffers b, int pages) {
   if (pg >= pages) return;
   unsigned* mm = b.mm + pg * 4; int* counters = b.counters + pg * 2;
   mm[0] = 0xFFFFFFFFu; mm[1] = 0u; mm[2] = 0xFFFFFFFFu; mm[3] = 0u; counters[0] = 0; counters[1] = 0;
+  if (pg == 0 && b.cal_ctr) *b.cal_ctr = 0;   // the hulls' scratch pool starts empty for this group (ccl_rects_kernel)
 }
 
 // one workgroup reduction, then 4 atomics per workgroup (the per-wave form spent 48 us per page serialising on 4 words)
