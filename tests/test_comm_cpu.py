@@ -50,3 +50,40 @@ def test_rendezvous_reports_a_dead_address():
     assert "rendezvous" in lib.ttr_last_error().decode()
     assert lib.ttr_dbg_tcp_share(0, 1, b"127.0.0.1", 1, buf, 16) == 0          # world 1: nothing to share
     assert lib.ttr_dbg_tcp_share(5, 2, b"127.0.0.1", 1, buf, 16) == -1         # rank out of range
+
+
+def _rank_cfg(rank, world, port, q, delay, timeout_s):
+    import os
+    import time
+    os.environ["TUATARA_COMM_TIMEOUT"] = str(timeout_s)
+    from tuatara_amd.build import build_lib
+    from tuatara_amd.engine import load
+    build_lib()
+    lib = load()
+    time.sleep(delay)
+    buf = C.create_string_buffer(b"\x07" * 16 if rank == 0 else b"\0" * 16, 16)
+    rc = lib.ttr_dbg_tcp_share(rank, world, b"127.0.0.1", port, buf, 16)
+    q.put((rank, world, rc, lib.ttr_last_error().decode() if rc else ""))
+
+
+def test_rendezvous_tells_a_refused_rank_why():
+    """rank 0 (world 2) is joined by a rank started with world 3 and by two ranks numbered 1: the odd ones are told the reason before
+    their socket closes (they used to see a bare 'recv' failure), the good one gets the bytes."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_cfg, args=(0, 2, port, q, 0.0, 60)),
+             ctx.Process(target=_rank_cfg, args=(1, 3, port, q, 1.0, 60)),          # wrong world size: turned away
+             ctx.Process(target=_rank_cfg, args=(1, 2, port, q, 3.0, 60)),          # the real rank 1
+             ctx.Process(target=_rank_cfg, args=(1, 2, port, q, 6.0, 5))]           # a duplicate after the meeting: nobody listens any more
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    by = {}
+    for rank, world, rc, err in got:
+        by.setdefault((rank, world, rc == 0), []).append(err)
+    assert (0, 2, True) in by and (1, 2, True) in by, got
+    assert any("another world size" in e for e in by.get((1, 3, False), [])), got
+    assert len(by.get((1, 2, False), [])) == 1, got                                   # the late duplicate: connect fails, rank 0 has left

@@ -43,6 +43,11 @@ def _assert_logits(ref, ref_ar, got, got_ar, ids, label):
     assert np.isfinite(got).all() and np.isfinite(got_ar).all()
     assert err[mask].max() < TOL, err[mask].max()
     assert err_ar[mask].max() < TOL, err_ar[mask].max()
+    # the REFINED logits are defined at all 26 positions (keys at and behind a crop's EOS are padded out of the refinement pass, so the junk the AR loop
+    # produces behind EOS - or does not produce: the early exit - never reaches them): the bar holds there as well.  The AR logits behind EOS are not
+    # compared: the engine leaves its loop like upstream PARSeq, the oracle (early_exit = False) runs on over tokens nobody reads.
+    assert err.max() < TOL, ("a refined position behind EOS", err.max())
+    assert np.array_equal(np.asarray(ids).reshape(ref.shape[0], 26), ref.argmax(-1))
     ids = np.asarray(ids).reshape(ref.shape[0], 26)
     assert np.array_equal(ids[mask], ref.argmax(-1)[mask])
     assert np.array_equal(got_ar.argmax(-1)[mask], ref_ar.argmax(-1)[mask])
@@ -58,6 +63,113 @@ def test_x4_parseq_logits_within_1e3(eng_x4, oracle_models, n):
     ref, ref_ar = _oracle_logits(parseq, crops)
     got, got_ar, ids = eng_x4.parseq_logits(crops, want_ar=True)
     _assert_logits(ref, ref_ar, got, got_ar, ids, f"f16x4 PARSeq, {n} crops vs oracle")
+
+
+def test_x4_parseq_seed_sweep(eng_x4, oracle_models):
+    """Config 2's comparison over eight seeds of 96 crops each (noise crops and text-like ones), the distribution of max |dlogit| printed: the 1e-3 bar is
+    met on every seed, at every refined position, not on a lucky one."""
+    _, parseq = oracle_models
+    worst = []
+    for seed in range(100, 108):
+        rng = np.random.default_rng(seed)
+        crops = rng.integers(0, 256, (96, 32, 128, 3), dtype=np.uint8)
+        for i in range(48, 96):                                   # half of them: dark strokes on light paper (longer strings than noise gives)
+            img = np.full((32, 128, 3), int(rng.integers(200, 256)), np.uint8)
+            for _ in range(int(rng.integers(2, 10))):
+                x, w, y, h = int(rng.integers(2, 118)), int(rng.integers(2, 9)), int(rng.integers(3, 14)), int(rng.integers(8, 18))
+                img[y:y + h, x:x + w] = rng.integers(0, 90, (1, 1, 3), dtype=np.uint8)
+            crops[i] = img
+        ref, ref_ar = _oracle_logits(parseq, crops)
+        got, got_ar, ids = eng_x4.parseq_logits(crops, want_ar=True)
+        err = np.abs(got - ref)
+        up = R.upto_eos(ref.argmax(-1))
+        mask = np.arange(26)[None, :] < up[:, None]
+        worst.append((seed, float(err.max()), float(err[mask].max()), float(np.abs(got_ar - ref_ar)[mask].max()), float(np.percentile(err, 99.99)), int(up.max()) - 1))
+        assert np.array_equal(np.asarray(ids).reshape(-1, 26), ref.argmax(-1)), seed
+    print("seed: max |dlogit| all refined positions / up to EOS / AR up to EOS / p99.99 / longest string")
+    for w in worst:
+        print(f"  {w[0]}: {w[1]:.2e} / {w[2]:.2e} / {w[3]:.2e} / {w[4]:.2e} / {w[5]}")
+    allmax = np.array([w[1] for w in worst])
+    print(f"over 8 seeds x 96 crops: max {allmax.max():.2e}, median of the seeds' maxima {np.median(allmax):.2e}, min {allmax.min():.2e}")
+    assert allmax.max() < TOL and max(w[3] for w in worst) < TOL
+
+
+def _fp64(model):
+    import copy
+    return copy.deepcopy(model).double()
+
+
+def test_x4_error_budget_against_fp64_parseq(eng_x4, oracle_models):
+    """What "fp32-equivalent" means, measured: the engine's logits and the fp32 oracle's are both compared with an fp64 evaluation of the same network on
+    128 crops.  The engine's error must stay within 1.5 x the fp32 evaluation's own - in the maximum and at the 99.99th percentile - i.e. the split-operand
+    mode behaves like one more fp32 implementation (another summation order), not like a lower precision.  Crops whose fp64 greedy path differs from
+    the fp32 one (a near-tie decided the other way: every later logit then belongs to another sentence) are left out and counted."""
+    import torch
+    _, parseq = oracle_models
+    p64 = _fp64(parseq)
+    rng = np.random.default_rng(64)
+    crops = rng.integers(0, 256, (128, 32, 128, 3), dtype=np.uint8)
+    ref32, ar32 = _oracle_logits(parseq, crops)
+    with torch.no_grad():
+        r64, a64 = p64(torch.from_numpy(crops).permute(0, 3, 1, 2).double().div(255.0), return_ar=True)
+    r64, a64 = r64.numpy(), a64.numpy()
+    got, got_ar, ids = eng_x4.parseq_logits(crops, want_ar=True)
+    up = R.upto_eos(r64.argmax(-1))
+    mask = np.arange(26)[None, :] < up[:, None]
+    same = ((ar32.argmax(-1) == a64.argmax(-1)) | ~mask).all(1) & (ref32.argmax(-1) == r64.argmax(-1)).all(1)
+    print(f"{int(same.sum())} of {len(same)} crops follow the fp64 greedy path in fp32")
+    assert same.sum() >= 120
+    e_eng, e_f32 = np.abs(got.astype(np.float64) - r64)[same], np.abs(ref32.astype(np.float64) - r64)[same]
+    e_eng_ar, e_f32_ar = np.abs(got_ar.astype(np.float64) - a64)[same][mask[same]], np.abs(ar32.astype(np.float64) - a64)[same][mask[same]]
+    for name, a, b in (("refined, all 26 positions", e_eng, e_f32), ("AR up to EOS", e_eng_ar, e_f32_ar)):
+        print(f"{name}: |engine - fp64| max {a.max():.2e} p99.99 {np.percentile(a, 99.99):.2e} mean {a.mean():.2e}   |fp32 oracle - fp64| max {b.max():.2e} "
+              f"p99.99 {np.percentile(b, 99.99):.2e} mean {b.mean():.2e}   ratio max {a.max() / b.max():.2f} p99.99 {np.percentile(a, 99.99) / np.percentile(b, 99.99):.2f}")
+        assert a.max() <= 1.5 * b.max(), (name, a.max(), b.max())
+        assert np.percentile(a, 99.99) <= 1.5 * np.percentile(b, 99.99), (name, np.percentile(a, 99.99), np.percentile(b, 99.99))
+    assert np.array_equal(np.asarray(ids).reshape(-1, 26)[same], r64.argmax(-1)[same])
+
+
+def test_x4_error_budget_against_fp64_craft(eng_x4_random, weights_random):
+    """The same budget for the detector: a 256 x 192 canvas through all 27 convolutions with FULLY RANDOM weights, engine and fp32 oracle against the fp64
+    evaluation: |engine - fp64| <= 1.5 x |fp32 - fp64| in the maximum and at the 99.99th percentile of the heat map's pixels."""
+    import torch
+    from oracle import pipeline
+    craft_r, _ = pipeline.load_models(weights_random["craft"], weights_random["parseq"])
+    c64 = _fp64(craft_r)
+    canvas = np.random.default_rng(65).integers(0, 256, (256, 192, 3), dtype=np.uint8)
+    ref32 = pipeline.craft_heatmap(craft_r, canvas)
+    with torch.no_grad():                                         # pipeline.craft_heatmap's steps (tuatara.cpp:363-394) in fp64
+        x = torch.from_numpy(np.ascontiguousarray(canvas)).unsqueeze(0).permute(0, 3, 1, 2).to(torch.float64).div(255.0)
+        y64 = c64(x)[0][0].contiguous().numpy()
+    got = eng_x4_random.craft_heatmap(canvas)
+    assert y64.shape == ref32.shape == got.shape, (y64.shape, ref32.shape, got.shape)
+    chk = np.abs(ref32 - y64).max()
+    assert chk < 1e-3 * max(1.0, np.abs(y64).max()), f"the fp64 path does not restate pipeline.craft_heatmap ({chk})"
+    a, b = np.abs(got.astype(np.float64) - y64), np.abs(ref32.astype(np.float64) - y64)
+    print(f"CRAFT 256x192 random weights, max |heat| {np.abs(y64).max():.2f}: |engine - fp64| max {a.max():.2e} p99.99 {np.percentile(a, 99.99):.2e} mean {a.mean():.2e}   "
+          f"|fp32 oracle - fp64| max {b.max():.2e} p99.99 {np.percentile(b, 99.99):.2e} mean {b.mean():.2e}")
+    assert a.max() <= 1.5 * b.max(), (a.max(), b.max())
+    assert np.percentile(a, 99.99) <= 1.5 * np.percentile(b, 99.99)
+
+
+def test_x4_matches_reference_compiled_infer(eng_x4):
+    """tests/golden/g8_ref_infer.npz holds what the REFERENCE's own compiled code - infer() (tuatara.cpp:289-312: the queue of 4-crop chunks, six
+    threads on one module) and class Tokenizer (:25-117), built unmodified against LibTorch by oracle/build_ref_infer.py - produced for 22 crops on the
+    exported TorchScript archive of the seed-0 PARSeq.  The engine in its default precision: logits within 1e-3 at all 26 positions, the same ids, the
+    same strings."""
+    import json
+    import os
+    from tests.conftest import GOLDEN
+    from tuatara_amd.engine import decode_ids
+    g = np.load(os.path.join(GOLDEN, "g8_ref_infer.npz"))
+    crops, ref = g["crops"], g["logits"]
+    texts = [bytes(t).decode("latin1") for t in json.loads(bytes(g["texts"]).decode())]
+    got, ids = eng_x4.parseq_logits(crops)
+    err = np.abs(got - ref)
+    print(f"f16x4 vs the reference-compiled infer(): max |dlogit| {err.max():.2e} over all 26 positions of {len(crops)} crops; strings {texts}")
+    assert err.max() < TOL
+    assert np.array_equal(np.asarray(ids).reshape(-1, 26), ref.argmax(-1))
+    assert [decode_ids(r) for r in np.asarray(ids).reshape(-1, 26)] == texts
 
 
 def test_x4_ar_early_exit_is_invisible_in_the_refined_logits(eng_x4):

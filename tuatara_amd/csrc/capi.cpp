@@ -277,10 +277,16 @@ int ttr_get_profile_kinds(ttr_engine* e, char* buf, size_t cap) {
   bool first = true;
   for (const auto& k : E.prof_kinds) {
     if (!k.launches) continue;
-    char line[512];
-    snprintf(line, sizeof line, "%s{\"kind\": \"%s\", \"stage\": %d, \"launches\": %ld, \"ms\": %.6f, \"alg_flops\": %.6e, \"exec_flops\": %.6e}", first ? "" : ", ",
-             k.name.c_str(), k.stage, k.launches, k.ms, k.alg, k.exec);
-    s += line; first = false;
+    std::string name;            // JSON string: quotes, backslashes and control characters escaped
+    for (const char ch : k.name) {
+      if (ch == '"' || ch == '\\') { name += '\\'; name += ch; }
+      else if ((unsigned char)ch < 0x20) { char u[8]; snprintf(u, sizeof u, "\\u%04x", (unsigned)(unsigned char)ch); name += u; }
+      else name += ch;
+    }
+    char line[256];
+    snprintf(line, sizeof line, "\", \"stage\": %d, \"launches\": %lld, \"ms\": %.6f, \"alg_flops\": %.6e, \"exec_flops\": %.6e}", k.stage, (long long)k.launches, k.ms, k.alg, k.exec);
+    s += first ? "{\"kind\": \"" : ", {\"kind\": \"";
+    s += name; s += line; first = false;
   }
   s += "]";
   if (buf && cap) { const size_t n = std::min(s.size(), cap - 1); memcpy(buf, s.data(), n); buf[n] = 0; }

@@ -27,6 +27,7 @@ struct RcclTransport : Transport {
 namespace rendezvous {
 constexpr uint32_t kMagic = 0x54545243u;   // "TTRC"
 struct Hello { uint32_t magic; int32_t rank, world; };
+enum : uint32_t { kWelcome = 0, kWrongWorld = 1, kBadRank = 2, kDuplicate = 3 };   // rank 0's answer to a hello
 inline void fail(const std::string& m) { throw std::runtime_error("comm rendezvous: " + m + (errno ? std::string(": ") + strerror(errno) : std::string())); }
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 inline void set_timeouts(int fd, double seconds) {
@@ -49,10 +50,13 @@ inline sockaddr_in resolve(const char* addr, int port) {
   sockaddr_in sa{};
   sa.sin_family = AF_INET; sa.sin_port = htons((uint16_t)port);
   const char* a = (addr && *addr) ? addr : "127.0.0.1";
-  if (inet_pton(AF_INET, a, &sa.sin_addr) != 1) {
-    hostent* he = gethostbyname(a);
-    if (!he) { errno = 0; fail(std::string("cannot resolve ") + a); }
-    memcpy(&sa.sin_addr, he->h_addr_list[0], sizeof(sa.sin_addr));
+  if (inet_pton(AF_INET, a, &sa.sin_addr) != 1) {   // a name: getaddrinfo (thread-safe: two engines may set up their communicators from two threads)
+    addrinfo hints{}, *res = nullptr;
+    hints.ai_family = AF_INET; hints.ai_socktype = SOCK_STREAM;
+    const int rc = getaddrinfo(a, nullptr, &hints, &res);
+    if (rc != 0 || !res) { errno = 0; fail(std::string("cannot resolve ") + a + (rc ? std::string(": ") + gai_strerror(rc) : std::string())); }
+    sa.sin_addr = reinterpret_cast<const sockaddr_in*>(res->ai_addr)->sin_addr;
+    freeaddrinfo(res);
   }
   return sa;
 }
@@ -81,7 +85,10 @@ inline std::vector<int> serve(int world, const char* addr, int port, double dead
     if (cs < 0) { if (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR) continue; const int e = errno; close_all(); errno = e; fail("accept"); }
     set_timeouts(cs, 5.0);
     Hello h{};
-    if (!recv_all(cs, &h, sizeof h) || h.magic != kMagic || h.world != world || h.rank <= 0 || h.rank >= world || fds[h.rank] >= 0) { close(cs); continue; }   // a stray, a stranger or a duplicate
+    if (!recv_all(cs, &h, sizeof h) || h.magic != kMagic) { close(cs); continue; }   // a stray or a stranger: no answer
+    // one of ours: it is told why it is turned away (kWelcome or a reason word) before the socket closes
+    const uint32_t why = h.world != world ? kWrongWorld : (h.rank <= 0 || h.rank >= world) ? kBadRank : fds[h.rank] >= 0 ? kDuplicate : kWelcome;
+    if (!send_all(cs, &why, 4) || why != kWelcome) { close(cs); continue; }
     set_timeouts(cs, deadline_s);
     fds[h.rank] = cs; ++have;
   }
@@ -98,6 +105,13 @@ inline int join(int rank, int world, const char* addr, int port, double deadline
       set_timeouts(cs, deadline_s);
       const Hello h{kMagic, rank, world};
       if (!send_all(cs, &h, sizeof h)) { const int e = errno; close(cs); errno = e; fail("hello"); }
+      uint32_t why = kWelcome;
+      if (!recv_all(cs, &why, 4)) { const int e = errno; close(cs); errno = e; fail("no answer to rank " + std::to_string(rank) + "'s hello from " + std::string(addr ? addr : "") + ":" + std::to_string(port) + " (not this job's rank 0?)"); }
+      if (why != kWelcome) {
+        close(cs); errno = 0;
+        fail("rank 0 turned rank " + std::to_string(rank) + " away: " + (why == kWrongWorld ? "it was started with another world size than " + std::to_string(world)
+             : why == kBadRank ? "rank out of range for world size " + std::to_string(world) : why == kDuplicate ? "a rank with this number has already joined" : "unknown reason"));
+      }
       return cs;
     }
     close(cs);
@@ -246,6 +260,7 @@ ttr_comm* ttr_comm_create(ttr_engine* e, int rank, int world, const void* id256)
 
 ttr_comm* ttr_comm_create_tcp(ttr_engine* e, int rank, int world, const char* addr, int port) {
   TTR_GUARD_BEGIN
+  if (!e || world < 1 || rank < 0 || rank >= world) throw std::runtime_error("ttr_comm_create_tcp: bad arguments");   // before the (blocking) rendezvous
   ncclUniqueId ids[2];
   if (rank == 0) { TTR_NCCL_CHECK(ncclGetUniqueId(&ids[0])); TTR_NCCL_CHECK(ncclGetUniqueId(&ids[1])); }
   tcp_share(rank, world, addr, port, ids, sizeof(ids));

@@ -251,7 +251,7 @@ struct CclBatch {   // device workspaces of the CCL stage for a batch of equally
     b.area = area.as<int>() + o; b.bbox = bbox.as<int>() + o * 4; b.maxt = maxt.as<unsigned>() + o; b.cand_slot = cand_slot.as<int>() + o;
     b.cand = cand.as<int>() + (size_t)p0 * max_cand * 8; b.counters = counters.as<int>() + (size_t)p0 * 2; b.rows_packed = rows.as<int>() + o * 2;
     b.max_cand = max_cand;
-    b.rects = rects.as<float>() + (size_t)p0 * max_cand * 6; b.cal_pool = cal_pool.as<float>(); b.cal_ctr = cal_ctr.as<int>(); b.cal_cap = cal_cap_now;
+    b.rects = rects.as<float>() + (size_t)p0 * max_cand * 8; b.cal_pool = cal_pool.as<float>(); b.cal_ctr = cal_ctr.as<int>(); b.cal_cap = cal_cap_now;
     return b;
   }
   void ensure(int pages_, int npx_, int max_cand_) {
@@ -260,7 +260,7 @@ struct CclBatch {   // device workspaces of the CCL stage for a batch of equally
     tnorm.ensure(n * 4); flags.ensure(n); parent.ensure(n * 4); mm.ensure((size_t)pages * 16);
     area.ensure(n * 4); bbox.ensure(n * 16); maxt.ensure(n * 4); cand_slot.ensure(n * 4);
     cand.ensure((size_t)pages * max_cand * 32); counters.ensure((size_t)pages * 8); rows.ensure(n * 8);
-    rects.ensure((size_t)pages * max_cand * 24); cal_pool.ensure((size_t)kCalCap * 4); cal_ctr.ensure(64);
+    rects.ensure((size_t)pages * max_cand * 32); cal_pool.ensure((size_t)kCalCap * 4); cal_ctr.ensure(64);
   }
 };
 

@@ -45,19 +45,19 @@ void Engine::ccl_collect(int p0, int pages, int g, int H2, int W2, std::vector<s
   int* rw = h_rows.as<int>();
   const CclBuffers v = ccl.view(p0);
   if (tn.gpu_calipers && max_c > 0) {
-    // the rectangles were computed on the GPU (ccl_rects_kernel): candidates (for the label order) + 24 bytes of result each
-    const size_t pitch_q = (size_t)max_c * 24;
+    // the calipers ran on the GPU (ccl_rects_kernel): candidates (for the label order) + 32 bytes of raw result each; sides and angle here (the host's libm)
+    const size_t pitch_q = (size_t)max_c * 32;
     h_rects_f.ensure(pitch_q * pages + 4);
     float* rq = h_rects_f.as<float>();
     TTR_HIP_CHECK(hipMemcpy2DAsync(cand, pitch_c, v.cand, (size_t)ccl.max_cand * 32, pitch_c, pages, hipMemcpyDeviceToHost, copy_stream));
-    TTR_HIP_CHECK(hipMemcpy2DAsync(rq, pitch_q, v.rects, (size_t)ccl.max_cand * 24, pitch_q, pages, hipMemcpyDeviceToHost, copy_stream));
+    TTR_HIP_CHECK(hipMemcpy2DAsync(rq, pitch_q, v.rects, (size_t)ccl.max_cand * 32, pitch_q, pages, hipMemcpyDeviceToHost, copy_stream));
     TTR_HIP_CHECK(hipEventRecord(copy_ev, copy_stream));
     spin_event(copy_ev);
     const double tc2g = now_us();
     bool pool_full = false;
     for (int pg = 0; pg < pages && !pool_full; ++pg)
       for (int i = 0; i < counters[2 * pg]; ++i)
-        if (reinterpret_cast<const int*>(rq + (size_t)pg * (pitch_q / 4) + 6 * (size_t)i)[0] == 2) { pool_full = true; break; }
+        if (reinterpret_cast<const int*>(rq + (size_t)pg * (pitch_q / 4) + 8 * (size_t)i)[0] == 2) { pool_full = true; break; }
     if (!pool_full) {
       for (int pg = 0; pg < pages; ++pg) {
         const int n = counters[2 * pg];
@@ -67,10 +67,9 @@ void Engine::ccl_collect(int p0, int pages, int g, int H2, int W2, std::vector<s
         for (int i = 0; i < n; ++i) order[i] = i;
         std::sort(order.begin(), order.end(), [&](int a, int b) { return cd[8 * a] < cd[8 * b]; });  // label order = ascending root
         for (int i : order) {
-          if (reinterpret_cast<const int*>(q + 6 * (size_t)i)[0] != 1) continue;
-          RRect r;
-          r.cx = q[6 * i + 1]; r.cy = q[6 * i + 2]; r.w = q[6 * i + 3]; r.h = q[6 * i + 4]; r.angle = q[6 * i + 5];
-          det[p0 + pg].push_back(r);
+          const int kind = reinterpret_cast<const int*>(q + 8 * (size_t)i)[0];
+          if (kind != 1 && kind != 3 && kind != 4) continue;
+          det[p0 + pg].push_back(finish_min_area_rect(kind, q + 8 * (size_t)i + 1));
         }
       }
       host_us[1] += (float)(tc1 - tc0); host_us[2] += (float)(tc2g - tc1); host_us[3] += (float)(now_us() - tc2g);

@@ -40,8 +40,17 @@ constexpr int SKX_BN = 32, SKX_DEPTH = 3;
 template <int RB, bool LNP = false>
 __global__ __launch_bounds__(256) void gemm_skx_kernel(ConvParams p) {
   static_assert(!LNP || RB == 1, "the LayerNorm prologue is the 16-row form's");
-  if (p.skip && __builtin_nontemporal_load(p.skip) >= p.skip_n) return;   // AR early exit: uniform, before the barrier
   __shared__ __attribute__((aligned(16))) float part[4][2][RB][64][4];    // the four waves' partial tiles
+  __shared__ int skip_now;
+  if (p.skip) {   // AR early exit, decided once per WORKGROUP, before the barriers
+    if (LNP && p.done_count) {
+      // the token prologue's launch bumps the very counter it is asked to honour (its blockIdx.x == 0 workgroups, below): waves that each read it
+      // could disagree mid-launch - one returns, the others wait for rows it never parks.  One read per workgroup, handed on through LDS
+      if (threadIdx.x == 0) skip_now = __builtin_nontemporal_load(p.skip) >= p.skip_n;
+      __syncthreads();
+      if (skip_now) return;
+    } else if (__builtin_nontemporal_load(p.skip) >= p.skip_n) return;      // (nobody writes the counter during this launch: every wave reads the same value)
+  }
   constexpr int XROW = 3 * 384 + 8;                                       // halves per parked row: three planes + 16 bytes (rows 16 bytes apart modulo the banks)
   __shared__ __attribute__((aligned(16))) f16 xs[LNP ? 16 * XROW : 8];
   const int tid = threadIdx.x, lane = tid & 63;

@@ -154,30 +154,36 @@ static void rotating_calipers_min_area(const Pt2f* points, int n, float out[6]) 
   out[4] = A2 * best_h; out[5] = B2 * best_h;
 }
 
-RRect min_area_rect(const Pt2f* pts, int n) {
-  std::vector<Pt2f> hull = convex_hull(std::vector<Pt2f>(pts, pts + n));
+RRect finish_min_area_rect(int kind, const float v[6]) {
   RRect box;
-  const int hn = (int)hull.size();
-  if (hn > 2) {
-    float out[6];
-    rotating_calipers_min_area(hull.data(), hn, out);
-    box.cx = out[0] + (out[2] + out[4]) * 0.5f;
-    box.cy = out[1] + (out[3] + out[5]) * 0.5f;
-    box.w = (float)std::sqrt((double)out[2] * out[2] + (double)out[3] * out[3]);
-    box.h = (float)std::sqrt((double)out[4] * out[4] + (double)out[5] * out[5]);
-    box.angle = (float)std::atan2((double)out[3], (double)out[2]);
-  } else if (hn == 2) {
-    box.cx = (hull[0].x + hull[1].x) * 0.5f;
-    box.cy = (hull[0].y + hull[1].y) * 0.5f;
-    double dx = hull[1].x - hull[0].x, dy = hull[1].y - hull[0].y;
+  if (kind == 1) {
+    box.cx = v[0] + (v[2] + v[4]) * 0.5f;
+    box.cy = v[1] + (v[3] + v[5]) * 0.5f;
+    box.w = (float)std::sqrt((double)v[2] * v[2] + (double)v[3] * v[3]);
+    box.h = (float)std::sqrt((double)v[4] * v[4] + (double)v[5] * v[5]);
+    box.angle = (float)std::atan2((double)v[3], (double)v[2]);
+  } else if (kind == 3) {
+    box.cx = (v[0] + v[2]) * 0.5f;
+    box.cy = (v[1] + v[3]) * 0.5f;
+    double dx = v[2] - v[0], dy = v[3] - v[1];
     box.w = (float)std::sqrt(dx * dx + dy * dy);
     box.h = 0;
     box.angle = (float)std::atan2(dy, dx);
-  } else if (hn == 1) {
-    box.cx = hull[0].x; box.cy = hull[0].y;
+  } else if (kind == 4) {
+    box.cx = v[0]; box.cy = v[1];
   }
   box.angle = (float)(box.angle * 180 / kPi);
   return box;
+}
+
+RRect min_area_rect(const Pt2f* pts, int n) {
+  std::vector<Pt2f> hull = convex_hull(std::vector<Pt2f>(pts, pts + n));
+  const int hn = (int)hull.size();
+  float v[6] = {0, 0, 0, 0, 0, 0};
+  if (hn > 2) { rotating_calipers_min_area(hull.data(), hn, v); return finish_min_area_rect(1, v); }
+  if (hn == 2) { v[0] = hull[0].x; v[1] = hull[0].y; v[2] = hull[1].x; v[3] = hull[1].y; return finish_min_area_rect(3, v); }
+  if (hn == 1) { v[0] = hull[0].x; v[1] = hull[0].y; return finish_min_area_rect(4, v); }
+  return finish_min_area_rect(0, v);
 }
 
 RRect adjust_coordinates(const RRect& r, float ratio_w, float ratio_h, float ratio_net) {

@@ -14,6 +14,10 @@ void rect_points(const RRect& r, Pt2f pt[4]);                 // cv::RotatedRect
 void bounding_rect(const RRect& r, int xywh[4]);              // cv::RotatedRect::boundingRect (tuatara.cpp:416)
 void tesseract_bbox(const RRect& r, float bbox[4]);           // rotated_rect_to_tesseract_format (tuatara.cpp:256-274)
 RRect min_area_rect(const Pt2f* pts, int n);                  // cv::minAreaRect              (tuatara.cpp:179,:248)
+// the tail of cv::minAreaRect behind the hull: kind 1 = the rotating calipers' raw result out[6] (corner + two side vectors), 3 = a two-point hull
+// (x0, y0, x1, y1), 4 = one point -> centre, sides (double sqrt), angle (double atan2, degrees).  min_area_rect ends in it; the GPU calipers
+// (post_ops.hip: ccl_rects_kernel) hand their raw result to it, so that sqrt / atan2 are the host's libm on both paths
+RRect finish_min_area_rect(int kind, const float v[6]);
 RRect adjust_coordinates(const RRect& r, float ratio_w, float ratio_h, float ratio_net = 2.f);  // tuatara.cpp:236-253
 
 // One CCL candidate as the GPU reports it (post_ops.hip): stats of the combined-map

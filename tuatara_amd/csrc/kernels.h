@@ -214,9 +214,10 @@ struct CclBuffers {
   int* counters;          // [pages][2]: n_cand, total_rows
   int* rows_packed;       // [pages][npx][2]: per candidate row {min x, max x} of the link-masked pixels
   int max_cand;
-  // GPU-side minAreaRect (rects_kernel): per candidate {status, cx, cy, w, h, angle} (status as int bits: 0 nothing left, 1 a rectangle, 2 the scratch pool was
-  // full - the host's calipers take that group); scratch for the hulls: one pool per batch, bump-allocated
-  float* rects;           // [pages][max_cand][6]
+  // GPU-side minAreaRect (rects_kernel): per candidate 8 floats {kind, v[0..5], -} (kind as int bits: 0 nothing left, 1 the calipers' raw result, 2 the scratch
+  // pool was full - the host's calipers take that group -, 3 a segment, 4 a point; geometry.cpp: finish_min_area_rect turns 1 / 3 / 4 into the RotatedRect with
+  // the host's sqrt / atan2); scratch for the hulls: one pool per batch, bump-allocated
+  float* rects;           // [pages][max_cand][8]
   float* cal_pool; int* cal_ctr; int cal_cap;   // pool of cal_cap floats, *cal_ctr = floats handed out (zeroed by ccl_init_kernel of page 0)
 };
 void launch_ccl(const float* heat /*[pages][H][W][2]*/, int pages, int H, int W, float text_threshold, float link_threshold, float low_text, int min_area,

@@ -392,7 +392,8 @@ __global__ __launch_bounds__(384) void dec_self_attn_kernel(const float* __restr
   {
     int h = t >> 5;
     float acc = 0.f;
-    for (int j = 0; j < nkeys; ++j) acc += sp[h][j] * (float)kvn[j * 768 + 384 + t];
+    for (int j = 0; j < nkeys; ++j)
+      if (visible[j]) acc += sp[h][j] * (float)kvn[j * 768 + 384 + t];      // (a masked key's V row is not read: its weight is 0, but 0 x NaN would not be)
     if (planes) st_split_one(out, row, 384, t, acc, planes); else out[(int64_t)row * 384 + t] = (T)acc;
   }
 }

@@ -358,46 +358,28 @@ __device__ void d_calipers(const DPt* points, int n, DPt* vect, float* inv_len, 
   out[2] = A1 * best_w; out[3] = B1 * best_w;
   out[4] = A2 * best_h; out[5] = B2 * best_h;
 }
-// geometry.cpp: min_area_rect on n points (pts is sorted in place); rr = {cx, cy, w, h, angle in degrees}
-__device__ void d_min_area_rect(DPt* pts, int n, DPt* hull, DPt* vect, float* inv_len, float rr[5], bool sorted) {
-  const double kPi = 3.1415926535897932384626433832795;
+// geometry.cpp: min_area_rect on n points (pts is sorted in place) up to the calipers; the sides and the angle (double sqrt / atan2: the device's libm is
+// not the host's, and one ulp there can move boundingRect's integer rounding) are left to the host (geometry.cpp: finish_min_area_rect).
+// Returns the record's kind: 1 = calipers' out[6], 3 = a segment (v = x0, y0, x1, y1), 4 = a point (v = x, y)
+__device__ int d_min_area_rect_raw(DPt* pts, int n, DPt* hull, DPt* vect, float* inv_len, float v[6], bool sorted) {
   const int hn = d_convex_hull(pts, n, hull, sorted);
-  float cx = 0.f, cy = 0.f, w = 0.f, h = 0.f, angle = 0.f;
-  if (hn > 2) {
-    float out[6];
-    d_calipers(hull, hn, vect, inv_len, out);
-    cx = out[0] + (out[2] + out[4]) * 0.5f;
-    cy = out[1] + (out[3] + out[5]) * 0.5f;
-    w = (float)sqrt((double)out[2] * out[2] + (double)out[3] * out[3]);
-    h = (float)sqrt((double)out[4] * out[4] + (double)out[5] * out[5]);
-    angle = (float)atan2((double)out[3], (double)out[2]);
-  } else if (hn == 2) {
-    cx = (hull[0].x + hull[1].x) * 0.5f;
-    cy = (hull[0].y + hull[1].y) * 0.5f;
-    const double dx = hull[1].x - hull[0].x, dy = hull[1].y - hull[0].y;
-    w = (float)sqrt(dx * dx + dy * dy);
-    h = 0;
-    angle = (float)atan2(dy, dx);
-  } else if (hn == 1) {
-    cx = hull[0].x; cy = hull[0].y;
-  }
-  angle = (float)((angle * 180) / kPi);
-  rr[0] = cx; rr[1] = cy; rr[2] = w; rr[3] = h; rr[4] = angle;
+  for (int i = 0; i < 6; ++i) v[i] = 0.f;
+  if (hn > 2) { d_calipers(hull, hn, vect, inv_len, v); return 1; }
+  if (hn == 2) { v[0] = hull[0].x; v[1] = hull[0].y; v[2] = hull[1].x; v[3] = hull[1].y; return 3; }
+  v[0] = hull[0].x; v[1] = hull[0].y;
+  return 4;
 }
 }  // namespace
 
 // One wave per candidate, lane 0 at work: the hull's scratch lives in the workgroup's LDS (a dependent access costs an LDS round trip instead of an L2 one:
 // the sort, the hull and the calipers are chains of them) when the candidate has at most kRectLds points, else in the global pool.
+// Record per candidate: 8 floats {kind, v[0..5], -}: kind (int bits) 0 nothing left, 1 calipers' raw result, 2 the scratch pool was exhausted, 3 segment, 4 point.
 constexpr int kRectLds = 448;   // points: 9 x 448 floats = 16 KB
-__global__ __launch_bounds__(64) void ccl_rects_kernel(CclBuffers b, int H, int W) {
-  __shared__ float lds_scratch[9 * kRectLds];
-  __shared__ int lds_rows[2 * 1024];
-  const size_t pg = blockIdx.y;
-  const int slot = blockIdx.x;
-  const int* counters = b.counters + pg * 2;
-  if (slot >= counters[0] || slot >= b.max_cand) return;      // (uniform over the workgroup)
+constexpr int kRectGridX = 256; // workgroups per page: a workgroup walks the candidates slot, slot + 256, ... (a page has tens to hundreds; max_cand is 4096)
+namespace {
+__device__ void rect_of_candidate(const CclBuffers& b, int H, int W, size_t pg, int slot, float* lds_scratch, int* lds_rows, int* lds_n) {
   const int* c = b.cand + (pg * b.max_cand + slot) * 8;
-  float* rr = b.rects + (pg * b.max_cand + slot) * 6;
+  float* rr = b.rects + (pg * b.max_cand + slot) * 8;
   const int* rows = b.rows_packed + pg * (size_t)H * W * 2 + 2 * (size_t)c[6];
   {   // the candidate's row extremes into LDS, all lanes (lane 0 alone would wait out an L2 round trip per row)
     const int hrows = c[5] - c[3] + 1;
@@ -407,7 +389,6 @@ __global__ __launch_bounds__(64) void ccl_rects_kernel(CclBuffers b, int H, int 
       rows = lds_rows;
     }
   }
-  __shared__ int lds_n;
   // geometry.cpp: component_to_rect
   const int x = c[2], y = c[3], w = c[4] - c[2] + 1, h = c[5] - c[3] + 1, size = c[1];
   const int niter = (int)sqrt((double)(size * min(w, h) / (w * h) * 2));   // tuatara.cpp:166, integer inside the sqrt
@@ -432,7 +413,7 @@ __global__ __launch_bounds__(64) void ccl_rects_kernel(CclBuffers b, int H, int 
   float* inv_len = reinterpret_cast<float*>(vect + nmax);      // nmax
   int n = 0;
   if (in_lds) {   // a row per lane; the points land in any order (they are sorted below, and equal points are equal)
-    if (threadIdx.x == 0) lds_n = 0;
+    if (threadIdx.x == 0) *lds_n = 0;
     __syncthreads();
     for (int oy = oy0 + (int)threadIdx.x; oy <= oy1; oy += 64) {
       int mn = 0x7fffffff, mx = -1;
@@ -444,7 +425,7 @@ __global__ __launch_bounds__(64) void ccl_rects_kernel(CclBuffers b, int H, int 
       if (mx < 0) continue;
       mn = max(mn - back, sx); mx = min(mx + a, ex - 1);
       const int cnt = mx != mn ? 2 : 1;
-      const int at = atomicAdd(&lds_n, cnt);
+      const int at = atomicAdd(lds_n, cnt);
       pts[at] = DPt{(float)mn, (float)oy};
       if (cnt == 2) pts[at + 1] = DPt{(float)mx, (float)oy};
     }
@@ -464,7 +445,7 @@ __global__ __launch_bounds__(64) void ccl_rects_kernel(CclBuffers b, int H, int 
   bool sorted = false;
   if (in_lds) {   // the sort on all lanes: a point's place = the number of points before it in (x, y, index) order; through the hull's space and back
     __syncthreads();
-    n = lds_n;
+    n = *lds_n;
     for (int i = threadIdx.x; i < n; i += 64) {
       const DPt v = pts[i];
       int rank = 0;
@@ -478,15 +459,28 @@ __global__ __launch_bounds__(64) void ccl_rects_kernel(CclBuffers b, int H, int 
     if (threadIdx.x != 0) return;
   }
   if (n == 0) { reinterpret_cast<int*>(rr)[0] = 0; return; }
-  float out5[5];
-  d_min_area_rect(pts, n, hull, vect, inv_len, out5, sorted);
-  reinterpret_cast<int*>(rr)[0] = 1;
-  rr[1] = out5[0]; rr[2] = out5[1]; rr[3] = out5[2]; rr[4] = out5[3]; rr[5] = out5[4];
+  float v6[6];
+  const int kind = d_min_area_rect_raw(pts, n, hull, vect, inv_len, v6, sorted);
+  reinterpret_cast<int*>(rr)[0] = kind;
+  for (int i = 0; i < 6; ++i) rr[1 + i] = v6[i];
+}
+}  // namespace
+
+__global__ __launch_bounds__(64) void ccl_rects_kernel(CclBuffers b, int H, int W) {
+  __shared__ float lds_scratch[9 * kRectLds];
+  __shared__ int lds_rows[2 * 1024];
+  __shared__ int lds_n;
+  const size_t pg = blockIdx.y;
+  const int count = min(b.counters[pg * 2], b.max_cand);        // (uniform over the workgroup - one wave, so the barriers below order its lanes' LDS accesses only)
+  for (int slot = blockIdx.x; slot < count; slot += gridDim.x) {
+    rect_of_candidate(b, H, W, pg, slot, lds_scratch, lds_rows, &lds_n);
+    __syncthreads();                                             // the next candidate reuses the LDS
+  }
 }
 
 void launch_ccl_rects(const CclBuffers& b, int pages, int H, int W, hipStream_t s) {
   if (!b.rects || !b.cal_pool || !b.cal_ctr) throw std::runtime_error("ccl_rects: no buffers");
-  hipLaunchKernelGGL(ccl_rects_kernel, dim3(b.max_cand, pages), dim3(64), 0, s, b, H, W);
+  hipLaunchKernelGGL(ccl_rects_kernel, dim3(std::min(b.max_cand, kRectGridX), pages), dim3(64), 0, s, b, H, W);
 }
 
 // ------------------------------------------------------------------ crop-batch packer

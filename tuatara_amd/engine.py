@@ -409,6 +409,9 @@ class Engine:
         import json
         buf = C.create_string_buffer(1 << 16)
         n = self.lib.ttr_get_profile_kinds(self.h, buf, len(buf))
+        if n >= len(buf):                                   # the call returns the full length: come back with room for it
+            buf = C.create_string_buffer(n + 1)
+            n = self.lib.ttr_get_profile_kinds(self.h, buf, len(buf))
         if n < 0:
             raise EngineError(self.lib.ttr_last_error().decode())
         return json.loads(buf.value.decode())

@@ -62,6 +62,9 @@ def run_ranks(script: str, argv: Sequence[str], world: int, deadline_s: float = 
     out = out or sys.stdout
     err = err or sys.stderr
     port = port or free_port(addr)
+    # the ranks' own rendezvous (comm.cpp: RCCL unique id / the framed-TCP transport) listens on TUATARA_COMM_PORT; its default MASTER_PORT + 1 was
+    # never probed, so another listener there (a concurrent launch) left rank 0 spinning in bind().  Reserve a second free port unless the caller chose one
+    comm_port = os.environ.get("TUATARA_COMM_PORT") or str(free_port(addr))
     procs: List[subprocess.Popen] = []
     lines0: List[str] = []
 
@@ -79,7 +82,7 @@ def run_ranks(script: str, argv: Sequence[str], world: int, deadline_s: float = 
         for r in range(world):
             env = dict(os.environ)
             env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world), "MASTER_ADDR": addr,
-                        "MASTER_PORT": str(port), CHILD_ENV: "1", "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+                        "MASTER_PORT": str(port), "TUATARA_COMM_PORT": comm_port, CHILD_ENV: "1", "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
             if extra_env:
                 env.update(extra_env)
             p = subprocess.Popen([sys.executable, script, *argv], env=env, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1)
