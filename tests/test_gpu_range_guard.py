@@ -1,0 +1,110 @@
+"""-m gpu: the range guard of the default precision (tuatara_amd/csrc/split.h: RangeWatch).
+
+f16x4 writes every activation as f16 planes: exact for |x| < 65504, silently saturated beyond.  Synthetic weights never get near the limit; the archives
+the reference loads (/root/reference/tuatara.cpp:333, :423) are unknown.  Every kernel that writes planes therefore watches the values it splits, and a
+batch whose activations left the range FAILS, naming the layer - instead of returning finite, wrong boxes and strings.  Here one layer's weights are
+scaled until it trips, on CRAFT and on PARSeq; the other modes of the knob (warn, off) and the untripped engine are checked beside it."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(d):
+    from tests.conftest import _engine as E
+    return E(d, "f16x4")
+
+
+@pytest.fixture(scope="module")
+def scaled_dirs(tmp_path_factory):
+    """Two weight directories: CRAFT's slice2.14 scaled by 3e5 (its ReLU outputs pass 65504), PARSeq's encoder.blocks.3 fc1 scaled by 4e4."""
+    from tuatara_amd import weights as W
+    c, p = W.synth_craft(0, False), W.synth_parseq(0)
+    dc = str(tmp_path_factory.mktemp("w_craft_hot"))
+    c2 = dict(c)
+    name = [conv for nm, conv, bn, cin, cout, k in W.craft_layers() if nm == "slice2.14"][0]
+    c2[name + ".weight"] = c[name + ".weight"] * np.float32(3e5)
+    W.export_craft(c2, dc)
+    W.export_parseq(p, dc)
+    dp = str(tmp_path_factory.mktemp("w_parseq_hot"))
+    p2 = dict(p)
+    for k in ("weight", "bias"):
+        p2[f"encoder.blocks.3.mlp.fc1.{k}"] = p[f"encoder.blocks.3.mlp.fc1.{k}"] * np.float32(4e4)
+    W.export_craft(c, dp)
+    W.export_parseq(p2, dp)
+    return {"craft": dc, "parseq": dp}
+
+
+def test_craft_layer_out_of_range_fails_the_call_and_names_the_layer(scaled_dirs):
+    from tuatara_amd.engine import EngineError
+    eng = _engine(scaled_dirs["craft"])
+    canvas = np.random.default_rng(0).integers(0, 256, (256, 192, 3), dtype=np.uint8)
+    with pytest.raises(EngineError) as ei:
+        eng.craft_heatmap(canvas)
+    msg = str(ei.value)
+    print(msg)
+    assert "range guard" in msg and "craft.slice2.14" in msg and "65504" in msg
+    # the word is cleared when it is reported: the next call reports again (same weights), it does not inherit
+    with pytest.raises(EngineError):
+        eng.craft_heatmap(canvas)
+    # through the whole path: image_to_data fails too (the reference's convention one level up: the shim prints and returns [])
+    page = np.random.default_rng(1).integers(0, 256, (200, 180, 3), dtype=np.uint8)
+    with pytest.raises(EngineError) as ei:
+        eng.image_to_data(page)
+    assert "craft.slice2.14" in str(ei.value)
+    # warn only: the (saturated) result comes back; off: silent
+    assert eng.set_tuning(b"range_guard", 2) == 0
+    h = eng.craft_heatmap(canvas)
+    assert h.shape == (128, 96, 2)
+    assert eng.set_tuning(b"range_guard", 0) == 0
+    eng.craft_heatmap(canvas)
+    assert eng.set_tuning(b"range_guard", 1) == 0
+    with pytest.raises(EngineError):
+        eng.craft_heatmap(canvas)
+
+
+def test_parseq_layer_out_of_range_fails_the_call_and_names_the_layer(scaled_dirs):
+    from tuatara_amd.engine import EngineError
+    eng = _engine(scaled_dirs["parseq"])
+    crops = np.random.default_rng(2).integers(0, 256, (40, 32, 128, 3), dtype=np.uint8)
+    with pytest.raises(EngineError) as ei:
+        eng.parseq_logits(crops)
+    msg = str(ei.value)
+    print(msg)
+    assert "range guard" in msg and "encoder.blocks.3." in msg and "fc1" in msg
+    # the detector of this directory is healthy: it does not trip
+    canvas = np.random.default_rng(0).integers(0, 256, (256, 192, 3), dtype=np.uint8)
+    assert np.isfinite(eng.craft_heatmap(canvas)).all()
+    # a large batch goes through the 128-row tiles (other kernels than a page's 64-row ones): same verdict
+    crops = np.random.default_rng(3).integers(0, 256, (300, 32, 128, 3), dtype=np.uint8)
+    with pytest.raises(EngineError) as ei:
+        eng.parseq_logits(crops)
+    assert "encoder.blocks.3." in str(ei.value)
+
+
+def test_healthy_weights_do_not_trip_and_cost_nothing_visible(eng_x4):
+    """The shipped engine on the benchmark's weights: no trip on a page and on a crop batch; results identical with the guard on and off (it only watches)."""
+    crops = np.random.default_rng(5).integers(0, 256, (64, 32, 128, 3), dtype=np.uint8)
+    a, ida = eng_x4.parseq_logits(crops)
+    assert eng_x4.set_tuning(b"range_guard", 0) == 0
+    try:
+        b, idb = eng_x4.parseq_logits(crops)
+    finally:
+        eng_x4.set_tuning(b"range_guard", 1)
+    assert np.array_equal(a, b) and np.array_equal(ida, idb)
+
+
+def test_non_finite_weights_are_refused_at_load(tmp_path):
+    """The guard sees magnitudes (a maximum): a NaN slips under it.  A NaN can only come from an infinity (caught) or from the file - refused by name."""
+    from tuatara_amd import weights as W
+    from tuatara_amd.engine import Engine, EngineError
+    c, p = W.synth_craft(0, True), W.synth_parseq(0)
+    p2 = dict(p)
+    w = p["decoder.layers.0.linear1.weight"].copy()
+    w[7, 9] = np.nan
+    p2["decoder.layers.0.linear1.weight"] = w
+    W.export_craft(c, str(tmp_path))
+    W.export_parseq(p2, str(tmp_path))
+    with pytest.raises(EngineError) as ei:
+        Engine(str(tmp_path))
+    assert "non-finite" in str(ei.value) and "linear1" in str(ei.value)

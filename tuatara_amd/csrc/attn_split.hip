@@ -33,7 +33,8 @@ __device__ __forceinline__ f16x8 scale_down(f16x8 v) {   // v / 2^11 (exact unle
 }
 }  // namespace
 
-__global__ __launch_bounds__(256, 2) void attn_enc_split_kernel(const f16* __restrict__ qkv, f16* __restrict__ out, int N) {
+__global__ __launch_bounds__(256, 2) void attn_enc_split_kernel(const f16* __restrict__ qkv, f16* __restrict__ out, int N, unsigned* range_flag, unsigned range_tag) {
+  RangeWatch rw;   // (split.h)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * TILE];
   unsigned char* const sK = smem;               // [2 planes][128 keys (permuted)][128 B]
   unsigned char* const sV = smem + 2 * TILE;    // [2 planes][128 keys][128 B]
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void attn_enc_split_kernel(const f16* __res
         ev[e] = __expf((sacc[qt][2 * s + (e >> 2)][e & 3] - mx) * 0.125f);
         sum += ev[e];
       }
-      split3_x8(ev, fp[0][qt][s], fp[1][qt][s], fp[2][qt][s]);
+      split3_x8(ev, fp[0][qt][s], fp[1][qt][s], fp[2][qt][s], rw);
     }
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
@@ -171,8 +172,8 @@ __global__ __launch_bounds__(256, 2) void attn_enc_split_kernel(const f16* __res
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       f16x2 a0, b0, c0, a1, b1, c1;
-      split3_pair(oacc[qt][dt][0] * rinv[qt], oacc[qt][dt][1] * rinv[qt], a0, b0, c0);
-      split3_pair(oacc[qt][dt][2] * rinv[qt], oacc[qt][dt][3] * rinv[qt], a1, b1, c1);
+      split3_pair(oacc[qt][dt][0] * rinv[qt], oacc[qt][dt][1] * rinv[qt], a0, b0, c0, rw);
+      split3_pair(oacc[qt][dt][2] * rinv[qt], oacc[qt][dt][3] * rinv[qt], a1, b1, c1, rw);
       unsigned char* d = so + (qt * 16 + q) * 128 + (dt * 16 + 4 * g) * 2;
       *reinterpret_cast<f16x4*>(d) = f16x4{a0[0], a0[1], a1[0], a1[1]};
       *reinterpret_cast<f16x4*>(d + 32 * 128) = f16x4{b0[0], b0[1], b1[0], b1[1]};
@@ -188,12 +189,13 @@ __global__ __launch_bounds__(256, 2) void attn_enc_split_kernel(const f16* __res
       const f16x8 v = *reinterpret_cast<const f16x8*>(so + pl * 32 * 128 + row * 128 + c * 16);
       *reinterpret_cast<f16x8*>(op + (size_t)row * (3 * EO) + pl * EO + c * 8) = v;
     }
+  rw.flush(range_flag, range_tag);
 }
 
 void launch_attn_enc_split(const void* qkv_planes, void* out_planes, int N, hipStream_t s) {
   if (N <= 0) return;
   if (((uintptr_t)qkv_planes | (uintptr_t)out_planes) & 15) throw std::runtime_error("attn_enc_split: operands must be 16-byte aligned");
-  hipLaunchKernelGGL(attn_enc_split_kernel, dim3(N * 6), dim3(256), 0, s, (const f16*)qkv_planes, (f16*)out_planes, N);
+  hipLaunchKernelGGL(attn_enc_split_kernel, dim3(N * 6), dim3(256), 0, s, (const f16*)qkv_planes, (f16*)out_planes, N, range_ctx().flag, range_ctx().tag);
 }
 
 }  // namespace ttr

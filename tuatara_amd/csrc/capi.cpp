@@ -143,7 +143,9 @@ int ttr_craft_heatmap(ttr_engine* e, const uint8_t* canvas, int H, int W, float*
   TTR_HIP_CHECK(hipMemcpyAsync(E.canvas.p, canvas, (size_t)H * W * 3, hipMemcpyHostToDevice, E.stream));
   E.craft_forward(E.canvas.as<uint8_t>(), 1, H, W, E.heat.as<float>());
   TTR_HIP_CHECK(hipMemcpyAsync(heat_out, E.heat.p, (size_t)H * W / 4 * 2 * 4, hipMemcpyDeviceToHost, E.stream));
+  E.range_fetch(2);
   TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
+  E.range_verify(2, "ttr_craft_heatmap");
   return 0;
   TTR_GUARD_END(-1)
 }
@@ -227,7 +229,9 @@ int ttr_parseq_logits(ttr_engine* e, const uint8_t* crops, int n, float* logits,
   TTR_HIP_CHECK(hipMemcpyAsync(logits, E.logits.p, (size_t)n * 26 * 95 * 4, hipMemcpyDeviceToHost, E.stream));
   if (ar_logits) TTR_HIP_CHECK(hipMemcpyAsync(ar_logits, E.ar_logits.p, (size_t)n * 26 * 95 * 4, hipMemcpyDeviceToHost, E.stream));
   if (ids) TTR_HIP_CHECK(hipMemcpyAsync(ids, E.ids_dev.p, (size_t)n * 26 * 4, hipMemcpyDeviceToHost, E.stream));
+  E.range_fetch(2);
   TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
+  E.range_verify(2, "ttr_parseq_logits");
   return 0;
   TTR_GUARD_END(-1)
 }

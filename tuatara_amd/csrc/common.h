@@ -65,6 +65,9 @@ struct ConvParams {
   // cat(upsample(y), skip): a 1x1 convolution commutes with the upsample, so W_up . y runs at the low resolution (a quarter of the rows) and arrives here,
   // and the upsampled tensor is never written (engine_craft.cpp: upconv_commuted)
   const float* up_z; int up_ld;
+  // split-operand mode: the engine's sticky range word and this layer's tag (split.h: RangeWatch); null = not watched.  The launchers fill them from
+  // range_ctx() (kernels.h) when the caller left them empty
+  unsigned* range_flag; unsigned range_tag;
 };
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

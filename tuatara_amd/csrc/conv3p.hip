@@ -375,6 +375,7 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 && !(BN == 128 
   }
 
   // ---- epilogue: lane holds channels n..n+7 of patch pixel (py, px) for every i; i^2 is the pixel below / above
+  RangeWatch rw;   // (split.h: the running maximum of |x| over the values this lane writes as planes)
 #pragma unroll
   for (int t = 0; t < C::NJ / 2; ++t) {
     const int n = n0 + wn * C::TN + t * 32 + fg * 8;
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 && !(BN == 128 
           const f16x8 a0 = *reinterpret_cast<const f16x8*>(w6), a1 = *reinterpret_cast<const f16x8*>(w6 + 32);
           const f16x8 c0 = *reinterpret_cast<const f16x8*>(w8), c1 = *reinterpret_cast<const f16x8*>(w8 + 32);
           f16x8 x0, x1;
-          split2_x8(v, x0, x1);
+          split2_x8(v, x0, x1, rw);
           f32x4 t6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
           t6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0 * dnv, x1, t6, 0, 0, 0);
           t6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x0, t6, 0, 0, 0);
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 && !(BN == 128 
           float y[8] = {fmaxf(fmaf(t6[0], p.tail_s6, b6.x), 0.f), fmaxf(fmaf(t6[1], p.tail_s6, b6.y), 0.f), fmaxf(fmaf(t6[2], p.tail_s6, b6.z), 0.f),
                         fmaxf(fmaf(t6[3], p.tail_s6, b6.w), 0.f), 0.f, 0.f, 0.f, 0.f};
           f16x8 y0, y1;
-          split2_x8(y, y0, y1);
+          split2_x8(y, y0, y1, rw);
           f32x4 t8 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c0, y0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
           t8 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c0 * dnv, y1, t8, 0, 0, 0);
           t8 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, y0, t8, 0, 0, 0);
@@ -433,12 +434,12 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 && !(BN == 128 
         }
       }
       if constexpr (SP) {
-        if (p.out) st_split_n(p.out, m, p.out_ld, n, v, p.out_planes);
+        if (p.out) st_split_n(p.out, m, p.out_ld, n, v, p.out_planes, rw);
         if (p.out_relu) {
           float w[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) w[e] = fmaxf(v[e], 0.f);
-          st_split_n(p.out_relu, m, p.out_ld, n, w, p.out_planes);
+          st_split_n(p.out_relu, m, p.out_ld, n, w, p.out_planes, rw);
         }
       } else {
       if (p.out) {
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 && !(BN == 128 
             float w[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) w[e] = fmaxf(pooled[i][e], pooled[i + PD][e]);
-            if ((fr & 1) == 0) st_split_n(p.out_pool, ((int64_t)b * (p.H >> 1) + yo) * (p.W >> 1) + xo2, p.out_ld, n, w, p.out_planes);
+            if ((fr & 1) == 0) st_split_n(p.out_pool, ((int64_t)b * (p.H >> 1) + yo) * (p.W >> 1) + xo2, p.out_ld, n, w, p.out_planes, rw);
           } else {
           bf16x8 o;
 #pragma unroll
@@ -486,6 +487,7 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 && !(BN == 128 
       }
     }
   }
+  if constexpr (SP) rw.flush(p.range_flag, p.range_tag);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1094,7 +1096,8 @@ static void launch_first2(const ConvParams& p_in, hipStream_t s) {
 }
 
 template <int BN, int WM, int WN, bool FIRST = false, int XS = 2, int LPW = 5, int NP = 0, int NWS = 2>
-static void launch_c3(const ConvParams& p, hipStream_t s) {
+static void launch_c3(const ConvParams& p_in, hipStream_t s) {
+  const ConvParams p = with_range_ctx(p_in);
   using C = C3<BN, WM, WN, LPW>;
   using G = Geo<LPW>;
   const int tilesM = p.B * (p.H / G::PH) * (p.W / G::PW), tilesN = (p.Cout + BN - 1) / BN;

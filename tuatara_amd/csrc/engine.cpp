@@ -11,6 +11,33 @@ void hip_fail(const char* what, hipError_t e, const char* file, int line) {
 
 Tuning g_tuning_default;
 
+RangeCtx& range_ctx() { static thread_local RangeCtx c; return c; }
+
+void Engine::range_tag(const std::string& layer) {
+  if (prec != kSplit) return;
+  auto it = range_ids.find(layer);
+  if (it == range_ids.end()) { range_names.push_back(layer); it = range_ids.emplace(layer, (unsigned)range_names.size()).first; }
+  range_ctx().tag = it->second;
+}
+
+void Engine::range_fetch(int slot) {
+  if (!range_flag_ptr()) return;
+  TTR_HIP_CHECK(hipMemcpyAsync(h_range.as<unsigned>() + slot, range_word.p, 4, hipMemcpyDeviceToHost, stream));
+}
+
+void Engine::range_verify(int slot, const char* where) {
+  if (!range_flag_ptr()) return;
+  unsigned& w = h_range.as<unsigned>()[slot];
+  if (!w) return;
+  const std::string layer = w <= range_names.size() ? range_names[w - 1] : std::string("(untagged kernel)");
+  w = 0;
+  TTR_HIP_CHECK(hipMemsetAsync(range_word.p, 0, 4, stream));       // sticky until reported; the next batch starts clean
+  const std::string msg = std::string("f16x4 range guard (") + where + "): an activation of layer '" + layer + "' reached |x| >= 65504 (or an infinity): the split-operand "
+                          "precision cannot represent it and has saturated - these weights need TTR_PREC_F32 (tuatara_amd/csrc/split.h)";
+  if (tn.range_guard == 2) { std::cerr << "warning: " << msg << std::endl; return; }
+  throw std::runtime_error(msg);
+}
+
 // mlp_fused.hip's weight operands are stored as the LDS images the kernel multiplies from (see the layout notes there)
 void pack_mlp_w1(const float* w1, uint16_t* out) {               // w1 [1536][384] -> [48 chunks][3 segments][32 rows][16 positions][8]
   for (int c = 0; c < 48; ++c)
@@ -365,6 +392,8 @@ Engine::Engine(const std::string& dir, const ttr_config& c) : cfg(c) {
     host_pool.reset(new HostPool(workers));
   }
   for (auto& x : ev) TTR_HIP_CHECK(hipEventCreate(&x));
+  range_word.ensure(64); h_range.ensure(64);
+  TTR_HIP_CHECK(hipMemset(range_word.p, 0, 64)); memset(h_range.p, 0, 64);
   load_craft(dir);
   load_parseq(dir);
 }

@@ -102,9 +102,12 @@ struct Tuning {
   int ar_crop_exit = 1;       // ... and, per crop, the two attention kernels of a step return for crops that have emitted EOS
   int ar_early_exit = 1;      // bf16 kernel-per-op AR loop: the steps' kernels return at once when every crop of the batch has emitted EOS (upstream's break)
   int decoder_mode = 1;       // 0 = kernel-per-op AR loop, 4/8/16 = fused kernel with that many crops per workgroup, else automatic
+  int range_guard = 1;        // split engines: every kernel that writes planes watches |x| < 65504 (split.h: RangeWatch); a tripped batch 1 = fails the call naming the
+                              // layer, 2 = warns on stderr and returns the (saturated) result, 0 = not watched
   bool set(const std::string& k, int value) {
     if (k == "decoder_mode") decoder_mode = value;
     else if (k == "enc_chunk") enc_chunk = value;
+    else if (k == "range_guard") range_guard = value;
     else if (k == "up_commute") up_commute = value;
     else if (k == "gpu_calipers") gpu_calipers = value;
     else if (k == "skinny_split") skinny_split = value;
@@ -461,6 +464,16 @@ struct Engine {
   void load_parseq(const std::string& dir);
 
   bool verbose = false;
+  // ---- range guard of the split-operand mode (split.h: RangeWatch; kernels.h: range_ctx)
+  DevBuf range_word;                               // the sticky flag word: 0, or the tag of the first layer whose planes left the f16 range
+  PinnedBuf h_range;                               // [3] copies of it: streamed slots 0 / 1, stage entry points 2
+  std::vector<std::string> range_names;            // tag - 1 -> layer name
+  std::map<std::string, unsigned> range_ids;
+  std::string range_scope;                         // prefix of the tags sgemm() forms from its profile kinds ("encoder.blocks.3.", "decoder.")
+  unsigned* range_flag_ptr() { return prec == kSplit && tn.range_guard ? range_word.as<unsigned>() : nullptr; }
+  void range_tag(const std::string& layer);        // names the layer whose launches follow (this thread's range_ctx().tag)
+  void range_fetch(int slot);                      // enqueue the word's copy to the host behind a batch's kernels
+  void range_verify(int slot, const char* where);  // after the batch's sync: a tripped word fails the call (or warns), then is cleared
   // ---- multi-GPU (ttr_engine_attach_comm): every batch's token ids are all-gathered on the stream, device buffer to device buffer
   Comm* comm = nullptr;
   DevBuf gath_dev[2];
@@ -593,7 +606,11 @@ struct ttr_result { ttr::Result r; };
 // thread: allocations, hipFuncSetAttribute and device queries inside the call must hit the device the stream belongs to).
 struct EngineScope {
   std::lock_guard<std::mutex> lk;
-  explicit EngineScope(ttr::Engine& E) : lk(E.mu) { TTR_HIP_CHECK(hipSetDevice(E.cfg.device)); }
+  explicit EngineScope(ttr::Engine& E) : lk(E.mu) {
+    TTR_HIP_CHECK(hipSetDevice(E.cfg.device));
+    ttr::range_ctx().flag = E.range_flag_ptr(); ttr::range_ctx().tag = 0;   // this thread's launches belong to this engine until the scope ends
+  }
+  ~EngineScope() { ttr::range_ctx().flag = nullptr; ttr::range_ctx().tag = 0; }
 };
 
 #define TTR_GUARD_BEGIN try {

@@ -117,6 +117,7 @@ void Engine::sconv(const char* name, const void* in0, int C0, const void* in1, i
            void* out_relu, void* out_pool, int pool_relu, int out_planes, int out_ld, bool packed, float* tail_heat) {
   const int np = tn.craft_products == 4 ? 4 : 3;             // products per value: 3 = activation pairs (default), 4 = exact triples
   if (out_planes < 0) out_planes = np - 1;
+  range_tag(std::string("craft.") + name);
   const Linear& L = craft.at(name);
   if (packed) {   // a 32-channel layer on packed pairs: in0 = pixel rows [x0 (32) | x1 (32)] (a pairs tensor of 32 channels), weights Linear::wsp
     if (np != 3 || C0 != 64 || C1 || !L.wsp.p || L.k != 9 * 64) throw std::runtime_error(std::string("packed split conv: wrong layer ") + name);
@@ -163,6 +164,7 @@ void Engine::sconv(const char* name, const void* in0, int C0, const void* in1, i
 // then ReLU(W_skip . skip + b + upsample2x(z)) with the four-tap interpolation in the second launch's epilogue (ConvParams::up_z).  The upsampled tensor - as wide
 // as y and four times as long - is neither written nor read; the arithmetic differs from the two-source form at fp32 rounding level only (sums in another order).
 void Engine::upconv_commuted(const char* name, const void* y_lo, int C0, const void* skip, int C1, int B, int H, int W, float* z, void* out) {
+  range_tag(std::string("craft.") + name);
   const Linear& La = craft.at(std::string(name) + ".up");
   const Linear& Lb = craft.at(std::string(name) + ".skip");
   if (La.k != C0 || Lb.k != C1 || !La.ws.p || !Lb.ws.p || La.cout != Lb.cout || (H & 1) || (W & 1)) throw std::runtime_error(std::string("commuted up-convolution: shape mismatch at ") + name);
@@ -202,6 +204,7 @@ void Engine::craft_forward_split(const uint8_t* d_canvas, int B, int H, int W, f
   void* c11 = pbuf(M0, 64);
   {
     const Linear& L0 = craft.at("slice1.0");
+    range_tag("craft.slice1.0");
     timed("conv1_split_kernel", 2.0 * M0 * 64 * 27, 2.0 * M0 * 64 * 27 * (npl + 1), [&] { launch_conv1_split(d_canvas, L0.ws.p, L0.b.as<float>(), L0.inv_scale, c11, B, H, W, stream, npl); });
   }
   void* p1 = pbuf(M1, 64);   sconv("slice1.3", c11, 64, nullptr, 0, B, H, W, nullptr, kActRelu, nullptr, p1, 0);

@@ -223,6 +223,7 @@ void Engine::recog_enqueue(PageBatch& B) {
     comm->tr->all_gather(ids_dev.p, gath_dev[sl].p, per * 4, false, stream);
     TTR_HIP_CHECK(hipMemcpyAsync(h_gath[sl].p, gath_dev[sl].p, per * 4 * comm->world, hipMemcpyDeviceToHost, stream));
   }
+  range_fetch(sl);
   TTR_HIP_CHECK(hipEventRecord(done_ev[sl], stream));
   B.enqueued = true;
 }
@@ -232,6 +233,7 @@ void Engine::finish(PageBatch& B, std::vector<Result>& results) {
   results.assign(n, Result());
   const double th2 = now_us();
   spin_event(done_ev[B.slot]);
+  range_verify(B.slot, "a batch of pages");
   const double th3 = now_us();
   // stage times: detector events belong to the latest batch enqueued (complete by now: its components were collected), recogniser events to this one
   (void)hipEventElapsedTime(&stage_ms[0], ev[0], ev[1]); (void)hipEventElapsedTime(&stage_ms[1], ev[1], ev[2]);
@@ -335,8 +337,10 @@ void Engine::run_pages_sharded(const uint8_t* d_pages, int n, int h, int w, std:
   h_gath[0].ensure((size_t)world * per * 26 * 4);
   c->tr->all_gather(ids_dev.p, gath_dev[0].p, (size_t)per * 26 * 4, false, stream);
   TTR_HIP_CHECK(hipMemcpyAsync(h_gath[0].p, gath_dev[0].p, (size_t)world * per * 26 * 4, hipMemcpyDeviceToHost, stream));
+  range_fetch(0);
   TTR_HIP_CHECK(hipEventRecord(done_ev[0], stream));
   spin_event(done_ev[0]);
+  range_verify(0, "a sharded page");
   if (rank != 0) return;
   const int32_t* ids = h_gath[0].as<int32_t>();                // shard r occupies rows [r * per, r * per + its size): crop k = row k
   std::vector<int> first(pages + 1, 0);

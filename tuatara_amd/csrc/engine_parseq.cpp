@@ -9,6 +9,7 @@ void Engine::sgemm(const Linear& L, const void* in_planes, int M, void* out, int
            float* out_f32, int out_f32_ld, const float* resid, int resid_ld, int np, int resid_mod, int out_full_cols,
            const char* kind, int x_tiled, int out_tiled) {
   if (!L.ws.p) throw std::runtime_error("split GEMM: the layer has no weight planes");
+  range_tag("parseq." + range_scope + (kind ? kind : "linear"));
   ConvParams p{};
   p.out_full_cols = out_full_cols;
   p.in0 = in_planes; p.C0 = L.k; p.B = 1; p.H = 1; p.W = M; p.ks = 1; p.dil = 1;
@@ -66,11 +67,13 @@ void Engine::decoder_tail_split(const void* sa, int N, int R, const float* resid
   const int rows = N * R;
   const std::string d = "decoder.layers.0.";
   auto lnp = [&](const std::string& nm, void* out) {
+    range_tag("parseq." + nm);
     launch_layernorm_planes(tgt, 384, pqf.at(nm + ".weight").as<float>(), pqf.at(nm + ".bias").as<float>(), 1e-5f, out, rows, stream, 3, cur_skip, cur_skip_n);
   };
   // LayerNorm + linear: two launches, or - a page's worth of rows (the AR steps of the latency regime) - the skinny kernel with the LayerNorm
   // as its prologue (gemm_skx.hip, LNP): the same arithmetic, one dependent launch less
   auto ln_lin = [&](const std::string& nm, const Linear& L, void* out, int out_ld, int act, int out_planes, float* out_f32, int out_f32_ld, const char* kind) {
+    range_tag("parseq." + range_scope + kind);
     ConvParams p{};
     p.ln_in = tgt; p.ln_ld = 384; p.ln_gamma = pqf.at(nm + ".weight").as<float>(); p.ln_beta = pqf.at(nm + ".bias").as<float>(); p.ln_eps = 1e-5f;
     p.C0 = L.k; p.B = 1; p.H = 1; p.W = rows; p.ks = 1; p.dil = 1;
@@ -85,8 +88,10 @@ void Engine::decoder_tail_split(const void* sa, int N, int R, const float* resid
     lnp(nm, pa);
     sgemm(L, pa, rows, out, out_ld, act, out_planes, out_f32, out_f32_ld, nullptr, 0, 4, 0, 0, kind);
   };
+  range_tag("parseq.decoder.self_attn.out_proj");
   sgemm(pq.at("self_out"), sa, rows, nullptr, 0, kActNone, 0, tgt, 384, resid_pos, 384, 4, resid_mod);      // tgt = query + self_attn
   ln_lin(d + "norm1", pq.at("cross_q"), q384, 384, kActNone, 0, nullptr, 0, "dec.norm1 + cross_q");           // fp32 queries for the attention kernel
+  range_tag("parseq.decoder.cross_attn");
   launch_dec_cross_attn(kF32, q384, kvmem, pb, N, R, stream, cur_skip, cur_skip_n, done_tok, done_col, 3);    // planes out
   sgemm(pq.at("cross_out"), pb, rows, nullptr, 0, kActNone, 0, tgt, 384, tgt, 384);                            // tgt += cross_attn
   ln_lin(d + "norm2", pq.at("ffn1"), p1536, 1536, kActGelu, 3, nullptr, 0, "dec.norm2 + ffn1");
@@ -133,6 +138,7 @@ void Engine::parseq_forward(const uint8_t* d_crops, int N, float* d_logits, floa
   prof_stage = 1;
   const int M = N * 128, E = 384;
   const int patch_ld = pq.at("patch").k;   // 96, or 128 in bf16 mode (zero-padded)
+  range_tag("parseq.encoder.patch_embed");
   void* patches = (pq_ws[0].ensure((size_t)M * patch_ld * es), pq_ws[0].p);
   float* x = (float*)(pq_ws[1].ensure((size_t)M * E * 4), pq_ws[1].p);
   void* t384 = (pq_ws[2].ensure((size_t)std::max(M, N * 26) * E * es), pq_ws[2].p);
@@ -160,23 +166,29 @@ void Engine::parseq_forward(const uint8_t* d_crops, int N, float* d_logits, floa
       float* xc = x + (size_t)c0 * 128 * E;
       for (int l = 0; l < 12; ++l) {
         const std::string p = "encoder.blocks." + std::to_string(l) + ".";
+        range_scope = p;
+        range_tag("parseq." + p + "norm1");
         launch_layernorm_planes(xc, E, pqf.at(p + "norm1.weight").as<float>(), pqf.at(p + "norm1.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream, lnpl, nullptr, 0, xt);
         if (tn.qkv_attn_split && lnpl == 2) {   // one launch: the attention of a (crop, head) is the epilogue of its 128 x 192 qkv tile
           const Linear& L = pq.at(p + "qkv_hm");
+          range_tag("parseq." + p + "attn (qkv + attention)");
           // executed flops: qkv on pairs (x 3), Q K^T and P V on a triple and a pair (x 4)
           const double qa = 2.0 * Mc * 3 * E * E, aa = 2.0 * 2 * nc * 6 * 128.0 * 128 * 64;
           timed("enc.qkv+attention: gemm_sp_kernel<128,192,NP=3,EPI=1>", qa + aa, qa * 3 + aa * 4,
                 [&] { launch_qkv_attn_split(lnp_at(c0), L.ws.p, L.b.as<float>(), L.inv_scale, attp, nc, stream, tn.sp_tiled_w ? L.wst.p : nullptr, xt, xt); });
         } else {
         sgemm(pq.at(p + "qkv"), lnp_at(c0), Mc, bigp, 3 * E, kActNone, 1, nullptr, 0, nullptr, 0, lnpl + 1, 0, tn.qkv_kv_pairs ? E : 0, "enc.qkv");   // (K, V: read as pairs)
-        launch_attn_enc_split(bigp, attp, nc, stream);
+        range_tag("parseq." + p + "attn.qkv"), launch_attn_enc_split(bigp, attp, nc, stream);
         }
         sgemm(pq.at(p + "proj"), attp, Mc, nullptr, 0, kActNone, 0, xc, E, xc, E, 4, 0, 0, "enc.proj", xt, 0);
+        range_tag("parseq." + p + "norm2");
         launch_layernorm_planes(xc, E, pqf.at(p + "norm2.weight").as<float>(), pqf.at(p + "norm2.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream, lnpl, nullptr, 0, xt);
         const int hpl = tn.enc_fc2_pairs ? 2 : 3;                                      // planes of the MLP's hidden activation
         sgemm(pq.at(p + "fc1"), lnp_at(c0), Mc, bigp, 4 * E, kActGelu, hpl, nullptr, 0, nullptr, 0, lnpl + 1, 0, 0, "enc.fc1 + GELU", xt, xt);
         sgemm(pq.at(p + "fc2"), bigp, Mc, nullptr, 0, kActNone, 0, xc, E, xc, E, hpl + 1, 0, 0, "enc.fc2", xt, 0);
       }
+      range_scope.clear();
+      range_tag("parseq.encoder.norm");
       launch_layernorm_planes(xc, E, pqf.at("encoder.norm.weight").as<float>(), pqf.at("encoder.norm.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream);
     }
   }
@@ -234,6 +246,8 @@ void Engine::parseq_forward(const uint8_t* d_crops, int N, float* d_logits, floa
   gemm(pq.at("cross_kv"), t384, M, kvmem, 768, kActNone);
 
   // ---- decoder
+  range_scope = "decoder.";
+  struct ScopeReset { std::string& s; ~ScopeReset() { s.clear(); } } scope_reset{range_scope};
   void* kvcache = (pq_ws[6].ensure((size_t)N * 26 * 768 * es), pq_ws[6].p);
   if (kvcache_zeroed != pq_ws[6].cap) {   // slots behind an early exit keep older (finite) rows; they are masked, but 0 x NaN is not 0
     TTR_HIP_CHECK(hipMemsetAsync(kvcache, 0, pq_ws[6].cap, stream));

@@ -411,6 +411,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
     }
     idx += J;
     const bool has_next = idx < xcd_count;
+    RangeWatch rw;   // (split.h: the maximum of |x| over the values this lane writes as planes; per tile, so that nothing lives across the K loop)
 
   // ---- epilogue: lane holds channels n = nb + 32t + (lane>>4)*8 + 0..7 of pixel m = mb + 16i + (lane&15)
     // ConvParams::up_z (CRAFT's commuted up-convolutions): a pass of its own in front, loads only - bias + the bilinear 2x upsample of the half-resolution
@@ -507,12 +508,12 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
         }
         if constexpr (SP) {
           if (p.dbg_flags & 1) { if (v[0] == 1.2345e30f) reinterpret_cast<float*>(p.out)[0] = v[1]; continue; }   // timing experiment: no output stores
-          if (p.out && valid) st_split_n(p.out, (int64_t)m, p.out_ld, n, v, p.out_planes);
+          if (p.out && valid) st_split_n(p.out, (int64_t)m, p.out_ld, n, v, p.out_planes, rw);
           if (p.out_relu && valid) {
             float w[8];
   #pragma unroll
             for (int e = 0; e < 8; ++e) w[e] = fmaxf(v[e], 0.f);
-            st_split_n(p.out_relu, (int64_t)m, p.out_ld, n, w, p.out_planes);
+            st_split_n(p.out_relu, (int64_t)m, p.out_ld, n, w, p.out_planes, rw);
           }
         } else {
         if (p.out && valid) {
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
             w[e] = x;
           }
           if constexpr (SP) {
-            if (valid && (fr & 3) == 0) st_split_n(p.out_pool, (int64_t)(grow >> 2), p.out_ld, n, w, p.out_planes);
+            if (valid && (fr & 3) == 0) st_split_n(p.out_pool, (int64_t)(grow >> 2), p.out_ld, n, w, p.out_planes, rw);
           } else {
             bf16x8 o;
   #pragma unroll
@@ -553,6 +554,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
         }
       }
     }
+    if constexpr (SP) rw.flush(p.range_flag, p.range_tag);
     if (!has_next) break;
   }
 }
@@ -560,7 +562,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
 static int num_cus() { return device_cu_count(256); }   // (per device: a process may drive several)
 
 template <int BM, int BN, int WM, int WN, int MINB, int XST, int NP = 0, int WST = 2>
-static void launch_g2(const ConvParams& p, hipStream_t s) {
+static void launch_g2(const ConvParams& p_in, hipStream_t s) {
+  const ConvParams p = with_range_ctx(p_in);
   constexpr bool SP = NP != 0;
   using C = G2Cfg<BM, BN, WM, WN, XST, WST>;
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;

@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256) void gemm_skx_kernel(ConvParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane & 15, g = lane >> 4;
+  RangeWatch rw;                                                            // (split.h: maximum of |x| over the values this lane writes as planes)
   const int K = p.C0, nsteps = K >> 5;                                     // 32-deep k steps
   const int n0 = blockIdx.x * SKX_BN, m0 = blockIdx.y * (16 * RB);
   const __amdgpu_buffer_rsrc_t rsx = skx_rsrc(p.in0, (unsigned)((size_t)p.M * K * 6));      // rows [x0 | x1 | x2]
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void gemm_skx_kernel(ConvParams p) {
         }
         float y[8];
         ln384_row8(v, act, p.ln_gamma + c, p.ln_beta + c, p.ln_eps, y);
-        split3_x8(y, o0, o1, o2);
+        split3_x8(y, o0, o1, o2, rw);
       }
       if (act) {
         f16* d = xs + rl * XROW + c;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256) void gemm_skx_kernel(ConvParams p) {
     if (p.out) {   // (eligibility: planes outputs have whole groups and aligned rows)
       if (p.out_planes == 3) {
         f16x2 a0, b0, c0, a1, b1, c1;
-        split3_pair(o[0], o[1], a0, b0, c0); split3_pair(o[2], o[3], a1, b1, c1);
+        split3_pair(o[0], o[1], a0, b0, c0, rw); split3_pair(o[2], o[3], a1, b1, c1, rw);
         typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
         f16* d = reinterpret_cast<f16*>(p.out) + (int64_t)m * (3 * (int64_t)p.out_ld) + n;
         *reinterpret_cast<f16x4*>(d) = f16x4{a0[0], a0[1], a1[0], a1[1]};
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256) void gemm_skx_kernel(ConvParams p) {
         *reinterpret_cast<f16x4*>(d + 2 * p.out_ld) = f16x4{c0[0], c0[1], c1[0], c1[1]};
       } else if (p.out_planes == 2) {
         f16x2 a0, b0, a1, b1;
-        split2_pair(o[0], o[1], a0, b0); split2_pair(o[2], o[3], a1, b1);
+        split2_pair(o[0], o[1], a0, b0, rw); split2_pair(o[2], o[3], a1, b1, rw);
         typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
         f16* d = reinterpret_cast<f16*>(p.out) + (int64_t)m * (2 * (int64_t)p.out_ld) + n;
         *reinterpret_cast<f16x4*>(d) = f16x4{a0[0], a0[1], a1[0], a1[1]};
@@ -253,6 +254,7 @@ __global__ __launch_bounds__(256) void gemm_skx_kernel(ConvParams p) {
       else { for (int e = 0; e < 4; ++e) if (n + e < p.Cout) d[e] = o[e]; }
     }
   }
+  rw.flush(p.range_flag, p.range_tag);
 }
 
 // shapes: exact triples (split = 4), ks = 1, one source, K a multiple of 32, no pooled / ReLU-copy outputs; planes outputs want whole groups of four
@@ -281,7 +283,8 @@ bool gemm_skx_eligible(const ConvParams& p) {
   return !(((uintptr_t)p.in0 | (uintptr_t)p.wgt | (uintptr_t)p.bias) & 15);
 }
 
-void launch_gemm_skx(const ConvParams& p, hipStream_t s) {
+void launch_gemm_skx(const ConvParams& p_in, hipStream_t s) {
+  const ConvParams p = with_range_ctx(p_in);
   if (p.ln_in || p.tok) {
     if (!gemm_skx_ln_eligible(p)) throw std::runtime_error("gemm_skx: LayerNorm prologue: shape not supported");
     hipLaunchKernelGGL((gemm_skx_kernel<1, true>), dim3((p.Cout + SKX_BN - 1) / SKX_BN, (p.M + 15) / 16), dim3(256), 0, s, p);

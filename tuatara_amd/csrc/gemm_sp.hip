@@ -413,6 +413,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
     idx += J;
     const bool has_next = idx < xcd_count;
     TTR_SP_NEXT_DELTAS(idx)                 // the streams are inside tile idx now (nk0 >= 3: they run at most two k0 ahead)
+    RangeWatch rw;                          // (split.h: the maximum of |x| over the values this lane writes as planes; per tile, so that nothing lives across the K loop)
 
     if (EM == 0 && (p.dbg_flags & 2)) {   // timing experiment: no epilogue at all
       float sum = 0.f;
@@ -467,9 +468,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
         tile_values(0, 0, v0); tile_values(0, 1, v1);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { keep[e] = wn ? v1[e] : v0[e]; send[e] = wn ? v0[e] : v1[e]; }
-        split3_x8(keep, fq[0][0], fq[0][1], fq[0][2]);
+        split3_x8(keep, fq[0][0], fq[0][1], fq[0][2], rw);
         f16x8 a, b, c;
-        split3_x8(send, a, b, c);
+        split3_x8(send, a, b, c, rw);
         unsigned char* d = sQ + qwr;
         *reinterpret_cast<f16x8*>(d) = a; *reinterpret_cast<f16x8*>(d + 1024) = b; *reinterpret_cast<f16x8*>(d + 2048) = c;
       }
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
         float v[8];
         tile_values(1, i, v);
         f16x8 a, b;
-        split2_x8(v, a, b);
+        split2_x8(v, a, b, rw);
         unsigned char* d = sK + (kwr + i * 1024 ^ i * 64);
         *reinterpret_cast<f16x8*>(d) = a; *reinterpret_cast<f16x8*>(d + KV) = b * dnv;
       }
@@ -486,9 +487,10 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
       for (int i = 0; i < 2; ++i) {   // V: kept until every wave is through with K
         float v[8];
         tile_values(2, i, v);
-        split2_x8(v, vp[0][i], vp[1][i]);
+        split2_x8(v, vp[0][i], vp[1][i], rw);
         vp[1][i] = vp[1][i] * dnv;
       }
+      rw.flush(p.range_flag, p.range_tag);   // (here, not behind the tile: the watch would cost a register across the attention; the output rows are convex combinations of the V rows just watched)
       __syncthreads();
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) fq[1][pl] = *reinterpret_cast<const f16x8*>(sQ + qrd + pl * 1024);
@@ -523,6 +525,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         float sum = 0.f;
+        RangeWatch rp;                      // (dead: the probabilities are <= 1)
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
           float ev[8];
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
             ev[e] = __expf((sacc[2 * s4 + (e >> 2)][e & 3] - mx) * 0.125f);
             sum += ev[e];
           }
-          split3_x8(ev, fp[0][s4], fp[1][s4], fp[2][s4]);
+          split3_x8(ev, fp[0][s4], fp[1][s4], fp[2][s4], rp);
         }
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
@@ -601,7 +604,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
 #pragma unroll
           for (int e = 0; e < 4; ++e) { v[e] = oacc[2 * u][e] * rinv; v[4 + e] = oacc[2 * u + 1][e] * rinv; }
           f16x8 a, b, c;
-          split3_x8(v, a, b, c);
+          RangeWatch ro;                     // (dead)
+          split3_x8(v, a, b, c, ro);
           *reinterpret_cast<f16x8*>(op + u * 32) = a; *reinterpret_cast<f16x8*>(op + opl + u * 32) = b; *reinterpret_cast<f16x8*>(op + 2 * opl + u * 32) = c;
         }
       }
@@ -682,7 +686,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
           const int kb = p.out_ld >> 6;
           f16* o = reinterpret_cast<f16*>(p.out) + ((int64_t)(m >> 3) * (2 * kb) + (n >> 6)) * 512 + (m & 7) * 64 + (n & 63);
           f16x8 a, b;
-          split2_x8(v, a, b);
+          split2_x8(v, a, b, rw);
           *reinterpret_cast<f16x8*>(o) = a; *reinterpret_cast<f16x8*>(o + kb * 512) = b;
           __builtin_amdgcn_sched_barrier(0);   // block by block: hoisting every block's table reads to the top costs 256 registers (spills)
           continue;
@@ -704,17 +708,17 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
         if (p.out) {
           if (p.out_planes == 3 && p.out_full_cols > 0 && n >= p.out_full_cols) {   // a triple whose third plane nobody reads (ConvParams::out_full_cols)
             f16x8 a, b, c;
-            split3_x8(v, a, b, c);
+            split3_x8(v, a, b, c, rw);
             f16* o = reinterpret_cast<f16*>(p.out) + (int64_t)m * (3 * (int64_t)p.out_ld) + n;
             *reinterpret_cast<f16x8*>(o) = a; *reinterpret_cast<f16x8*>(o + p.out_ld) = b;
           } else if (p.out_planes && p.out_tiled) {   // the next GEMM's loader pieces
             const int kb = p.out_ld >> 6;
             f16* o = reinterpret_cast<f16*>(p.out) + ((int64_t)(m >> 3) * (p.out_planes * kb) + (n >> 6)) * 512 + (m & 7) * 64 + (n & 63);
             f16x8 a, b, c;
-            if (p.out_planes == 3) { split3_x8(v, a, b, c); *reinterpret_cast<f16x8*>(o + 2 * kb * 512) = c; }
-            else split2_x8(v, a, b);
+            if (p.out_planes == 3) { split3_x8(v, a, b, c, rw); *reinterpret_cast<f16x8*>(o + 2 * kb * 512) = c; }
+            else split2_x8(v, a, b, rw);
             *reinterpret_cast<f16x8*>(o) = a; *reinterpret_cast<f16x8*>(o + kb * 512) = b;
-          } else if (p.out_planes) st_split_n(p.out, (int64_t)m, p.out_ld, n, v, p.out_planes);
+          } else if (p.out_planes) st_split_n(p.out, (int64_t)m, p.out_ld, n, v, p.out_planes, rw);
           else sp_store_f32x8(reinterpret_cast<float*>(p.out) + (int64_t)m * p.out_ld + n, v);
         }
         if (p.out_f32) sp_store_f32x8(p.out_f32 + (int64_t)m * p.out_f32_ld + n, v);
@@ -723,6 +727,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
     // The stores drain here (gfx9 encoding: expcnt 7, lgkmcnt 15 = no wait): the K loop's counted waits would take them for loads in flight.  (Leaving them
     // in flight under the next tile's first k0 - what that k0 reads was requested before the epilogue - was measured: no gain, profiles/r03_pmc_stall_parseq.txt §3.)
     __builtin_amdgcn_s_waitcnt(0x0F70);
+    rw.flush(p.range_flag, p.range_tag);
     if (!has_next) break;
   }   // (the streams' trailing out-of-range loads, which target this workgroup's LDS, have landed: the wait above)
 }
@@ -733,7 +738,7 @@ template <int BM, int BN, int WM, int WN, int XST, int WST, int MINB, bool SCHED
 static void launch_sp(const ConvParams& p_in, hipStream_t s) {
   using C = SpCfg<BM, BN, WM, WN, XST, WST>;
   constexpr int TABLE = EPI == 1 ? 57344 : 8208;   // behind the rings: the GELU table, or the attention epilogue's Q / K / V images
-  ConvParams p = p_in;
+  ConvParams p = with_range_ctx(p_in);
   if ((size_t)(C::LDS + TABLE) * MINB > 160 * 1024) p.gelu_lut = nullptr;   // no room for the table beside these rings: erf
   static PerDeviceOnce once;
   static_assert(EPI == 0 || C::LDS + TABLE <= 160 * 1024, "attention epilogue: rings + images must fit the LDS");

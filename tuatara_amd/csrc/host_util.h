@@ -3,6 +3,7 @@
 // AddressSanitizer / UBSan / ThreadSanitizer (tests/native/host_san.cpp, tests/test_sanitizers_cpu.py): the weight file and the PNG
 // reader parse bytes a caller hands over, and the pool replaces the reference's ad-hoc thread fan-out (tuatara.cpp:461-475).
 #pragma once
+#include <cmath>
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
@@ -53,6 +54,9 @@ struct WeightFile {
       if (e.off > room || e.nb > room - e.off) throw std::runtime_error("tensor out of range in " + path);   // overflow-safe
       HostTensor ht; ht.dims = e.dims; ht.data.resize(e.nb / 4);
       memcpy(ht.data.data(), buf.data() + data0 + e.off, e.nb);
+      // a NaN or an infinity in a weight poisons every product it meets, and the split-operand mode's range guard (split.h) only sees magnitudes:
+      // such a file is refused here, by name
+      for (const float v : ht.data) if (!std::isfinite(v)) throw std::runtime_error("non-finite value in weight tensor " + e.name + " of " + path);
       t[e.name] = std::move(ht);
     }
   }

@@ -5,6 +5,18 @@
 
 namespace ttr {
 
+// ---- split-operand range guard (split.h: RangeWatch).  The engine points the calling thread's context at its sticky flag word and names the layer it is about
+// to launch (a tag = index into its table of names); every launcher of a kernel that writes planes hands both to the kernel.  Thread-local: an engine runs
+// under its own lock on one thread at a time, two engines on two threads do not see each other's context.  flag == nullptr: not watched.
+struct RangeCtx { unsigned* flag = nullptr; unsigned tag = 0; };
+RangeCtx& range_ctx();                                   // engine.cpp
+inline ConvParams with_range_ctx(const ConvParams& p) {  // a launcher's copy of its parameters, the guard filled in unless the caller set it
+  ConvParams q = p;
+  if (!q.range_flag) { q.range_flag = range_ctx().flag; q.range_tag = range_ctx().tag; }
+  return q;
+}
+
+
 // ---- igemm.hip
 const char* igemm_check(const ConvParams& p);
 void launch_igemm(Precision prec, const ConvParams& p, hipStream_t s);

@@ -220,7 +220,8 @@ void launch_attn_enc(Precision prec, const void* qkv, void* out, int N, hipStrea
 template <typename T>
 __global__ void dec_embed_ln_kernel(int* __restrict__ tokens, const float* __restrict__ emb, const float* __restrict__ pos_q,
                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, T* __restrict__ out, int N, int i0, int i1,
-                                    const int* skip, int skip_n, int planes, const float* __restrict__ prev_logits, int prev_ld, int C, int* done_count, int eos) {
+                                    const int* skip, int skip_n, int planes, const float* __restrict__ prev_logits, int prev_ld, int C, int* done_count, int eos, unsigned* range_flag, unsigned range_tag) {
+  RangeWatch rw;   // (split.h)
   if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;   // AR early exit (see ConvParams::skip)
   const int R = i1 - i0;
   int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -264,8 +265,9 @@ __global__ void dec_embed_ln_kernel(int* __restrict__ tokens, const float* __res
   for (int k = 0; k < 6; ++k) {
     int c = lane + 64 * k;
     const float y = (v[k] - mean) * rstd * gamma[c] + beta[c];
-    if (planes) st_split_one(out, row, 384, c, y, planes); else out[(int64_t)row * 384 + c] = (T)y;
+    if (planes) st_split_one(out, row, 384, c, y, planes, rw); else out[(int64_t)row * 384 + c] = (T)y;
   }
+  rw.flush(range_flag, range_tag);
 }
 
 // split engines (planes out): the same rows in the 48 lanes x 8 values form, the LayerNorm through ln384_row8 - what gemm_skx.hip's token prologue
@@ -274,7 +276,8 @@ template <int NPL>
 __global__ __launch_bounds__(256) void dec_embed_ln_planes_kernel(int* __restrict__ tokens, const float* __restrict__ emb, const float* __restrict__ pos_q,
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps, f16* __restrict__ out, int N,
                                                                   int i0, int i1, const int* skip, int skip_n, const float* __restrict__ prev_logits, int prev_ld, int C,
-                                                                  int* done_count, int eos) {
+                                                                  int* done_count, int eos, unsigned* range_flag, unsigned range_tag) {
+  RangeWatch rw;   // (split.h)
   if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;
   const int R = i1 - i0;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -319,9 +322,10 @@ __global__ __launch_bounds__(256) void dec_embed_ln_planes_kernel(int* __restric
   if (!act) return;
   f16* d = out + (int64_t)row * (NPL * 384) + c;
   f16x8 o0, o1, o2;
-  if (NPL == 3) { split3_x8(y, o0, o1, o2); *reinterpret_cast<f16x8*>(d + 768) = o2; }
-  else split2_x8(y, o0, o1);
+  if (NPL == 3) { split3_x8(y, o0, o1, o2, rw); *reinterpret_cast<f16x8*>(d + 768) = o2; }
+  else split2_x8(y, o0, o1, rw);
   *reinterpret_cast<f16x8*>(d) = o0; *reinterpret_cast<f16x8*>(d + 384) = o1;
+  rw.flush(range_flag, range_tag);
 }
 
 void launch_dec_embed_ln(Precision prec, int* tokens, const float* emb, const float* pos_q, const float* gamma, const float* beta, float eps,
@@ -332,9 +336,9 @@ void launch_dec_embed_ln(Precision prec, int* tokens, const float* emb, const fl
   if (prev_logits && (i1 != i0 + 1 || i0 < 1)) throw std::runtime_error("dec_embed_ln: the folded argmax belongs to one AR step's column");
   dim3 grid((rows + 3) / 4);
   if (prec != kBF16 && planes == 3 && !(((uintptr_t)emb | (uintptr_t)pos_q | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out) & 15))
-    hipLaunchKernelGGL(dec_embed_ln_planes_kernel<3>, grid, dim3(256), 0, s, tokens, emb, pos_q, gamma, beta, eps, (f16*)out, N, i0, i1, skip, skip_n, prev_logits, prev_ld, C, done_count, eos);
-  else if (prec == kBF16) hipLaunchKernelGGL(dec_embed_ln_kernel<bf16>, grid, dim3(256), 0, s, tokens, emb, pos_q, gamma, beta, eps, (bf16*)out, N, i0, i1, skip, skip_n, 0, prev_logits, prev_ld, C, done_count, eos);
-  else hipLaunchKernelGGL(dec_embed_ln_kernel<float>, grid, dim3(256), 0, s, tokens, emb, pos_q, gamma, beta, eps, (float*)out, N, i0, i1, skip, skip_n, planes, prev_logits, prev_ld, C, done_count, eos);
+    hipLaunchKernelGGL(dec_embed_ln_planes_kernel<3>, grid, dim3(256), 0, s, tokens, emb, pos_q, gamma, beta, eps, (f16*)out, N, i0, i1, skip, skip_n, prev_logits, prev_ld, C, done_count, eos, range_ctx().flag, range_ctx().tag);
+  else if (prec == kBF16) hipLaunchKernelGGL(dec_embed_ln_kernel<bf16>, grid, dim3(256), 0, s, tokens, emb, pos_q, gamma, beta, eps, (bf16*)out, N, i0, i1, skip, skip_n, 0, prev_logits, prev_ld, C, done_count, eos, range_ctx().flag, range_ctx().tag);
+  else hipLaunchKernelGGL(dec_embed_ln_kernel<float>, grid, dim3(256), 0, s, tokens, emb, pos_q, gamma, beta, eps, (float*)out, N, i0, i1, skip, skip_n, planes, prev_logits, prev_ld, C, done_count, eos, range_ctx().flag, range_ctx().tag);
 }
 
 // ------------------------------------------------------------------ decoder self attention
@@ -345,7 +349,8 @@ void launch_dec_embed_ln(Precision prec, int* tokens, const float* emb, const fl
 //   mode 1 (refine): key j hidden iff j == qi+1 (cloze) or tokens[n][0..j] contains EOS (key padding).
 template <typename T>
 __global__ __launch_bounds__(384) void dec_self_attn_kernel(const float* __restrict__ q, const T* __restrict__ kv, const int* __restrict__ tokens,
-                                                            T* __restrict__ out, int R, int qi0, int mode, const int* skip, int skip_n, int planes) {
+                                                            T* __restrict__ out, int R, int qi0, int mode, const int* skip, int skip_n, int planes, unsigned* range_flag, unsigned range_tag) {
+  RangeWatch rw;   // (split.h)
   if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;   // AR early exit (see ConvParams::skip)
   __shared__ float sq[384];
   __shared__ float sp[12][28];
@@ -394,8 +399,9 @@ __global__ __launch_bounds__(384) void dec_self_attn_kernel(const float* __restr
     float acc = 0.f;
     for (int j = 0; j < nkeys; ++j)
       if (visible[j]) acc += sp[h][j] * (float)kvn[j * 768 + 384 + t];      // (a masked key's V row is not read: its weight is 0, but 0 x NaN would not be)
-    if (planes) st_split_one(out, row, 384, t, acc, planes); else out[(int64_t)row * 384 + t] = (T)acc;
+    if (planes) st_split_one(out, row, 384, t, acc, planes, rw); else out[(int64_t)row * 384 + t] = (T)acc;
   }
+  rw.flush(range_flag, range_tag);
 }
 
 // Refinement pass (mode 1, R = 26 query rows per crop), bf16: ONE workgroup per crop does all 26 rows — the crop's K/V cache
@@ -486,15 +492,16 @@ void launch_dec_self_attn(Precision prec, const float* q, const void* kvcache, c
     return;
   }
   dim3 grid(N * R);
-  if (prec == kBF16) hipLaunchKernelGGL(dec_self_attn_kernel<bf16>, grid, dim3(384), 0, s, q, (const bf16*)kvcache, tokens, (bf16*)out, R, qi0, mode, skip, skip_n, 0);
-  else hipLaunchKernelGGL(dec_self_attn_kernel<float>, grid, dim3(384), 0, s, q, (const float*)kvcache, tokens, (float*)out, R, qi0, mode, skip, skip_n, planes);
+  if (prec == kBF16) hipLaunchKernelGGL(dec_self_attn_kernel<bf16>, grid, dim3(384), 0, s, q, (const bf16*)kvcache, tokens, (bf16*)out, R, qi0, mode, skip, skip_n, 0, range_ctx().flag, range_ctx().tag);
+  else hipLaunchKernelGGL(dec_self_attn_kernel<float>, grid, dim3(384), 0, s, q, (const float*)kvcache, tokens, (float*)out, R, qi0, mode, skip, skip_n, planes, range_ctx().flag, range_ctx().tag);
 }
 
 // ------------------------------------------------------------------ decoder cross attention
 // one 384-thread workgroup per query row; 12 heads x 32 dims against the crop's 128 memory tokens.
 template <typename T>
 __global__ __launch_bounds__(384) void dec_cross_attn_kernel(const T* __restrict__ q, const T* __restrict__ kvmem, T* __restrict__ out, int R,
-                                                             const int* skip, int skip_n, const int* done_tok, int done_col, int planes) {
+                                                             const int* skip, int skip_n, const int* done_tok, int done_col, int planes, unsigned* range_flag, unsigned range_tag) {
+  RangeWatch rw;   // (split.h)
   if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;   // AR early exit (see ConvParams::skip)
   __shared__ float sq[384];
   __shared__ float sp[12][128];
@@ -535,8 +542,9 @@ __global__ __launch_bounds__(384) void dec_cross_attn_kernel(const T* __restrict
     int h = t >> 5;
     float acc = 0.f;
     for (int j = 0; j < 128; ++j) acc += sp[h][j] * (float)kvn[j * 768 + 384 + t];
-    if (planes) st_split_one(out, row, 384, t, acc, planes); else out[(int64_t)row * 384 + t] = (T)acc;
+    if (planes) st_split_one(out, row, 384, t, acc, planes, rw); else out[(int64_t)row * 384 + t] = (T)acc;
   }
+  rw.flush(range_flag, range_tag);
 }
 
 // fp32 / f16x4 engines, refinement pass (R = 26 query rows per crop): ONE workgroup per crop instead of one per row, so the crop's 393 KB of K / V
@@ -546,7 +554,8 @@ __global__ __launch_bounds__(384) void dec_cross_attn_kernel(const T* __restrict
 // blockIdx.y: head group (12 / gridDim.y heads each) - a page's few crops spread over the chip (40 crops: 480 workgroups of one head instead of 40 of
 // twelve, 94 -> ~15 us); heads are independent, the sums inside a head keep their order.
 __global__ __launch_bounds__(384) void dec_cross_attn_crop_kernel(const float* __restrict__ q, const float* __restrict__ kvmem, float* __restrict__ out,
-                                                                  int R, const int* skip, int skip_n, int planes) {
+                                                                  int R, const int* skip, int skip_n, int planes, unsigned* range_flag, unsigned range_tag) {
+  RangeWatch rw;   // (split.h)
   if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;
   constexpr int RMAX = 26;
   __shared__ float sq[RMAX][384];
@@ -607,10 +616,11 @@ __global__ __launch_bounds__(384) void dec_cross_attn_crop_kernel(const float* _
         float acc = 0.f;
         for (int j = 0; j < 128; ++j) acc += sp[r][j] * sv[j][d];
         const int64_t row = (int64_t)n * R + r;
-        if (planes) st_split_one(out, row, 384, h * 32 + d, acc, planes); else out[row * 384 + h * 32 + d] = acc;
+        if (planes) st_split_one(out, row, 384, h * 32 + d, acc, planes, rw); else out[row * 384 + h * 32 + d] = acc;
       }
     }
   }
+  rw.flush(range_flag, range_tag);
 }
 
 // bf16 fast path: a K (or V) row of the crop's memory is 768 bytes = 48 lanes x 16 bytes, so one wave instruction fetches one
@@ -709,12 +719,12 @@ void launch_dec_cross_attn(Precision prec, const void* q, const void* kvmem, voi
   if (prec == kBF16 && g_cross_mfma && (R == 26 || g_cross_mfma == 2)) return launch_dec_cross_attn_mfma((const bf16*)q, (const bf16*)kvmem, (bf16*)out, N, R, s);   // refinement pass (attn_dec2.hip); 2: the AR steps' single row too
   if (prec != kBF16 && g_cross_crop && R > 1 && R <= 26) {
     const int hsplit = N <= 64 ? 12 : N <= 256 ? 4 : N <= 512 ? 2 : 1;   // head groups: enough workgroups for the chip when the crops are few
-    hipLaunchKernelGGL(dec_cross_attn_crop_kernel, dim3(N, hsplit), dim3(384), 0, s, (const float*)q, (const float*)kvmem, (float*)out, R, skip, skip_n, planes);
+    hipLaunchKernelGGL(dec_cross_attn_crop_kernel, dim3(N, hsplit), dim3(384), 0, s, (const float*)q, (const float*)kvmem, (float*)out, R, skip, skip_n, planes, range_ctx().flag, range_ctx().tag);
     return;
   }
   dim3 grid(N * R);
   if (prec == kBF16) hipLaunchKernelGGL(dec_cross_attn_rows_kernel, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)kvmem, (bf16*)out, R, skip, skip_n, R == 1 ? done_tok : nullptr, done_col);
-  else hipLaunchKernelGGL(dec_cross_attn_kernel<float>, grid, dim3(384), 0, s, (const float*)q, (const float*)kvmem, (float*)out, R, skip, skip_n, R == 1 ? done_tok : nullptr, done_col, planes);
+  else hipLaunchKernelGGL(dec_cross_attn_kernel<float>, grid, dim3(384), 0, s, (const float*)q, (const float*)kvmem, (float*)out, R, skip, skip_n, R == 1 ? done_tok : nullptr, done_col, planes, range_ctx().flag, range_ctx().tag);
 }
 
 // ------------------------------------------------------------------ argmax (first maximal index, like torch.argmax on CPU)

@@ -27,8 +27,27 @@ typedef _Float16 f16;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
+// ---- the mode's one range condition, watched: |x| < 65504 for every value that is written as planes.  The conversions below saturate silently (a triple's
+// round-toward-zero planes stop at the largest finite f16, a pair is clamped), so a network whose activations leave the f16 range would come out finite and
+// WRONG.  Every kernel that writes planes keeps the running maximum of |x| over the values it splits - one v_max3_f32 per two values, no branch - and, if
+// that maximum is not below 65504 (an infinity included), leaves its layer's tag in the engine's sticky flag word: one predicated atomic per thread, at
+// the end of the kernel.  The engine reads the word with a batch's results and fails the call naming the layer (ttr_config / tuning key "range_guard").
+// A NaN alone does not move a maximum; one can only come from an infinity earlier on (caught) or from the weight file (checked at load).
+struct RangeWatch {
+  float m = 0.f;
+  __device__ __forceinline__ void note(float a, float b) { m = fmaxf(m, fmaxf(fabsf(a), fabsf(b))); }
+  __device__ __forceinline__ void note8(const float (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) note(v[e], v[e + 1]);
+  }
+  __device__ __forceinline__ void flush(unsigned* flag, unsigned tag) const {
+    if (flag && !(m < 65504.f)) atomicCAS(flag, 0u, tag);       // the first layer that trips keeps the word (launches are stream-ordered)
+  }
+};
+
 // ---- the exact TRIPLE: two values -> their three planes (packed pairs)
-__device__ __forceinline__ void split3_pair(float a, float b, f16x2& p0, f16x2& p1, f16x2& p2) {
+__device__ __forceinline__ void split3_pair(float a, float b, f16x2& p0, f16x2& p1, f16x2& p2, RangeWatch& rw) {
+  rw.note(a, b);
   p0 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
   const float ra = fmaf((float)p0[0], -2048.f, a * 2048.f), rb = fmaf((float)p0[1], -2048.f, b * 2048.f);   // exact
   p1 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(ra, rb));
@@ -36,11 +55,11 @@ __device__ __forceinline__ void split3_pair(float a, float b, f16x2& p0, f16x2& 
   p2 = f16x2{(f16)sa, (f16)sb};
 }
 // eight values -> three 16-byte plane vectors
-__device__ __forceinline__ void split3_x8(const float (&v)[8], f16x8& o0, f16x8& o1, f16x8& o2) {
+__device__ __forceinline__ void split3_x8(const float (&v)[8], f16x8& o0, f16x8& o1, f16x8& o2, RangeWatch& rw) {
 #pragma unroll
   for (int e = 0; e < 8; e += 2) {
     f16x2 a, b, c;
-    split3_pair(v[e], v[e + 1], a, b, c);
+    split3_pair(v[e], v[e + 1], a, b, c, rw);
     o0[e] = a[0]; o0[e + 1] = a[1]; o1[e] = b[0]; o1[e + 1] = b[1]; o2[e] = c[0]; o2[e + 1] = c[1];
   }
 }
@@ -49,17 +68,18 @@ __device__ __forceinline__ float join3(f16 a, f16 b, f16 c) { return (float)a + 
 // ---- the PAIR (x0, x1), for layers whose result tolerates ~23.5-bit activations (CRAFT: its heat map stays at fp32 noise level
 // with it): x0 = rn_f16(x), x1 = rn_f16((x - x0) 2^11) - round to nearest both times (unbiased; 3 of 4 values are exact,
 // the rest off by one fp32 ulp), |x| clamped to the f16 range first.  THREE MFMAs per product: x0 w0 + x0 w1 + x1 w0b.
-__device__ __forceinline__ void split2_pair(float a, float b, f16x2& p0, f16x2& p1) {
+__device__ __forceinline__ void split2_pair(float a, float b, f16x2& p0, f16x2& p1, RangeWatch& rw) {
+  rw.note(a, b);
   a = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f); b = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
   p0 = f16x2{(f16)a, (f16)b};
   const float ra = fmaf((float)p0[0], -2048.f, a * 2048.f), rb = fmaf((float)p0[1], -2048.f, b * 2048.f);   // exact
   p1 = f16x2{(f16)ra, (f16)rb};
 }
-__device__ __forceinline__ void split2_x8(const float (&v)[8], f16x8& o0, f16x8& o1) {
+__device__ __forceinline__ void split2_x8(const float (&v)[8], f16x8& o0, f16x8& o1, RangeWatch& rw) {
 #pragma unroll
   for (int e = 0; e < 8; e += 2) {
     f16x2 a, b;
-    split2_pair(v[e], v[e + 1], a, b);
+    split2_pair(v[e], v[e + 1], a, b, rw);
     o0[e] = a[0]; o0[e + 1] = a[1]; o1[e] = b[0]; o1[e + 1] = b[1];
   }
 }
@@ -67,15 +87,15 @@ __device__ __forceinline__ float join2(f16 a, f16 b) { return (float)a + (float)
 
 // 8 consecutive channels n.. of pixel m -> a tensor of `planes` f16 planes (row = planes * ld halves: 3 = triple, 2 = pair), or plain
 // fp32 [m][ld] when planes == 0
-__device__ __forceinline__ void st_split_n(void* out, int64_t m, int ld, int n, const float (&v)[8], int planes) {
+__device__ __forceinline__ void st_split_n(void* out, int64_t m, int ld, int n, const float (&v)[8], int planes, RangeWatch& rw) {
   if (planes == 3) {
     f16x8 a, b, c;
-    split3_x8(v, a, b, c);
+    split3_x8(v, a, b, c, rw);
     f16* o = reinterpret_cast<f16*>(out) + m * (3 * (int64_t)ld) + n;
     *reinterpret_cast<f16x8*>(o) = a; *reinterpret_cast<f16x8*>(o + ld) = b; *reinterpret_cast<f16x8*>(o + 2 * ld) = c;
   } else if (planes == 2) {
     f16x8 a, b;
-    split2_x8(v, a, b);
+    split2_x8(v, a, b, rw);
     f16* o = reinterpret_cast<f16*>(out) + m * (2 * (int64_t)ld) + n;
     *reinterpret_cast<f16x8*>(o) = a; *reinterpret_cast<f16x8*>(o + ld) = b;
   } else {
@@ -86,10 +106,10 @@ __device__ __forceinline__ void st_split_n(void* out, int64_t m, int ld, int n, 
 }
 
 // one value -> element c of row `row` of a tensor with `planes` planes (3 = triple; 0 = plain fp32 [row][ld]): for the thread-per-element kernels
-__device__ __forceinline__ void st_split_one(void* out, int64_t row, int ld, int c, float v, int planes) {
+__device__ __forceinline__ void st_split_one(void* out, int64_t row, int ld, int c, float v, int planes, RangeWatch& rw) {
   if (planes == 3) {
     f16x2 a, b, d;
-    split3_pair(v, 0.f, a, b, d);
+    split3_pair(v, 0.f, a, b, d, rw);
     f16* o = reinterpret_cast<f16*>(out) + row * (3 * (int64_t)ld) + c;
     o[0] = a[0]; o[ld] = b[0]; o[2 * ld] = d[0];
   } else {

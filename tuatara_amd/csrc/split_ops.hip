@@ -11,8 +11,10 @@
 namespace ttr {
 
 template <int NPL>
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ in, int ld, f16* __restrict__ out, int64_t M, int C, int relu, const int* skip, int skip_n) {
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ in, int ld, f16* __restrict__ out, int64_t M, int C, int relu, const int* skip, int skip_n,
+                                                          unsigned* range_flag, unsigned range_tag) {
   if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;   // AR early exit (see ConvParams::skip)
+  RangeWatch rw;
   const int cv = C >> 3;                                   // 8-channel groups per row
   const int64_t total = M * cv;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -25,8 +27,9 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
     }
-    st_split_n(out, m, C, c, v, NPL);
+    st_split_n(out, m, C, c, v, NPL, rw);
   }
+  rw.flush(range_flag, range_tag);
 }
 
 void launch_split_planes(const float* in, int ld, void* out, int64_t M, int C, int relu, hipStream_t s, int planes, const int* skip, int skip_n) {
@@ -34,8 +37,8 @@ void launch_split_planes(const float* in, int ld, void* out, int64_t M, int C, i
   if (C % 8 || ld % 4 || ((uintptr_t)in & 15) || ((uintptr_t)out & 15)) throw std::runtime_error("split_planes: C must be a multiple of 8 and the tensors 16-byte aligned");
   const int64_t total = M * (C >> 3);
   const int grid = (int)std::min<int64_t>((total + 255) / 256, 256 * 32);
-  if (planes == 2) hipLaunchKernelGGL(split_planes_kernel<2>, dim3(grid), dim3(256), 0, s, in, ld, (f16*)out, M, C, relu, skip, skip_n);
-  else hipLaunchKernelGGL(split_planes_kernel<3>, dim3(grid), dim3(256), 0, s, in, ld, (f16*)out, M, C, relu, skip, skip_n);
+  if (planes == 2) hipLaunchKernelGGL(split_planes_kernel<2>, dim3(grid), dim3(256), 0, s, in, ld, (f16*)out, M, C, relu, skip, skip_n, range_ctx().flag, range_ctx().tag);
+  else hipLaunchKernelGGL(split_planes_kernel<3>, dim3(grid), dim3(256), 0, s, in, ld, (f16*)out, M, C, relu, skip, skip_n, range_ctx().flag, range_ctx().tag);
 }
 
 }  // namespace ttr
@@ -61,14 +64,14 @@ template <int NPL> __device__ __forceinline__ V8 ld_planes(const f16* p, int C) 
   }
   return r;
 }
-template <int NPL> __device__ __forceinline__ void st_planes(f16* p, int C, const V8& r) {
+template <int NPL> __device__ __forceinline__ void st_planes(f16* p, int C, const V8& r, RangeWatch& rw) {
   if constexpr (NPL == 3) {
     f16x8 a, b, c;
-    split3_x8(r.v, a, b, c);
+    split3_x8(r.v, a, b, c, rw);
     *reinterpret_cast<f16x8*>(p) = a; *reinterpret_cast<f16x8*>(p + C) = b; *reinterpret_cast<f16x8*>(p + 2 * C) = c;
   } else {
     f16x8 a, b;
-    split2_x8(r.v, a, b);
+    split2_x8(r.v, a, b, rw);
     *reinterpret_cast<f16x8*>(p) = a; *reinterpret_cast<f16x8*>(p + C) = b;
   }
 }
@@ -92,7 +95,8 @@ __global__ __launch_bounds__(256) void maxpool3x3s1_planes_kernel(const f16* __r
 #pragma unroll
       for (int e = 0; e < 8; ++e) m.v[e] = fmaxf(m.v[e], v.v[e]);
     }
-  st_planes<NPL>(out + (((int64_t)b * H + y) * W + x) * (NPL * (int64_t)C) + cc * 8, C, m);
+  RangeWatch rw;   // (not flushed: a maximum of values their producer has watched)
+  st_planes<NPL>(out + (((int64_t)b * H + y) * W + x) * (NPL * (int64_t)C) + cc * 8, C, m, rw);
 }
 
 // F.interpolate(mode='bilinear', align_corners=False), exact x2: the expression of craft_ops.hip's bilerp()
@@ -119,7 +123,8 @@ __global__ __launch_bounds__(256) void upsample2x_planes_kernel(const f16* __res
   V8 o;
 #pragma unroll
   for (int e = 0; e < 8; ++e) o.v[e] = bilerp_s(v00.v[e], v01.v[e], v10.v[e], v11.v[e], lx0, lx1, ly0, ly1);
-  st_planes<NPL>(out + (((int64_t)b * Ho + yo) * Wo + xo) * ps + cc * 8, C, o);
+  RangeWatch rw;   // (not flushed: a convex combination of values their producer has watched)
+  st_planes<NPL>(out + (((int64_t)b * Ho + yo) * Wo + xo) * ps + cc * 8, C, o, rw);
 }
 
 // CRAFT's conv1_1 (3 -> 64, 3x3, ReLU) from the u8 canvas straight into planes: conv1_direct_kernel's structure (craft_ops.hip)
@@ -127,17 +132,18 @@ __global__ __launch_bounds__(256) void upsample2x_planes_kernel(const f16* __res
 // come from three 256-entry tables built once per workgroup; the weights are the layer's three planes [64][3][32].
 template <int NPL>
 __global__ __launch_bounds__(256) void conv1_split_kernel(const uint8_t* __restrict__ canvas, const f16* __restrict__ wgt /*[64][3][32]*/, const float* __restrict__ bias,
-                                                         float out_scale, f16* __restrict__ out /*[M][3*64]*/, int B, int H, int W) {
+                                                         float out_scale, f16* __restrict__ out /*[M][3*64]*/, int B, int H, int W, unsigned* range_flag, unsigned range_tag) {
   // A wave takes 64 consecutive pixels of one row (W % 32 == 0: the last segment of a row may hold 32).  The three canvas rows around them come
   // in as 51 aligned dwords each (row bytes 3 x0 - 4 .. 3 x0 + 199: one pixel of halo either side; 3 W and 3 x0 - 4 are multiples of 4) into the
   // wave's own LDS strip, zero outside the image, and the 27 taps of a pixel are byte reads from there: byte 1 + 3 px + (k % 9) of row k / 9.
   // (The earlier form fetched every tap with its own global byte load: 32 per lane and 64 pixels instead of 3 dwords.)
   __shared__ f16 lut[3][256];
   __shared__ __attribute__((aligned(16))) uint8_t strip[4][3][208];
+  RangeWatch rw;
   {
     f16x2 a, b, c = f16x2{(f16)0.f, (f16)0.f};
-    if constexpr (NPL == 3) split3_pair((float)threadIdx.x / 255.0f, 0.f, a, b, c);
-    else split2_pair((float)threadIdx.x / 255.0f, 0.f, a, b);
+    if constexpr (NPL == 3) split3_pair((float)threadIdx.x / 255.0f, 0.f, a, b, c, rw);
+    else split2_pair((float)threadIdx.x / 255.0f, 0.f, a, b, rw);
     lut[0][threadIdx.x] = a[0]; lut[1][threadIdx.x] = b[0]; lut[2][threadIdx.x] = c[0];
   }
   __syncthreads();
@@ -210,10 +216,11 @@ __global__ __launch_bounds__(256) void conv1_split_kernel(const uint8_t* __restr
           o.v[e] = fmaxf(fmaf(acc[2 * t][i][e], out_scale, bv[t][e]), 0.f);
           o.v[4 + e] = fmaxf(fmaf(acc[2 * t + 1][i][e], out_scale, bv[t][4 + e]), 0.f);
         }
-        st_planes<NPL>(out + (m0 + px) * (NPL * 64) + 32 * t + fg * 8, 64, o);
+        st_planes<NPL>(out + (m0 + px) * (NPL * 64) + 32 * t + fg * 8, 64, o, rw);
       }
     }
   }
+  rw.flush(range_flag, range_tag);
 }
 
 }  // namespace
@@ -236,8 +243,8 @@ void launch_conv1_split(const uint8_t* canvas, const void* wgt_planes, const flo
   if (W % 32) throw std::runtime_error("conv1_split: the canvas width must be a multiple of 32");
   const int64_t tasks = (int64_t)B * H * ((W + 63) / 64);
   const int grid = (int)std::min<int64_t>((tasks + 3) / 4, 256 * 16);
-  if (planes == 2) hipLaunchKernelGGL(conv1_split_kernel<2>, dim3(grid), dim3(256), 0, s, canvas, (const f16*)wgt_planes, bias, out_scale, (f16*)out, B, H, W);
-  else hipLaunchKernelGGL(conv1_split_kernel<3>, dim3(grid), dim3(256), 0, s, canvas, (const f16*)wgt_planes, bias, out_scale, (f16*)out, B, H, W);
+  if (planes == 2) hipLaunchKernelGGL(conv1_split_kernel<2>, dim3(grid), dim3(256), 0, s, canvas, (const f16*)wgt_planes, bias, out_scale, (f16*)out, B, H, W, range_ctx().flag, range_ctx().tag);
+  else hipLaunchKernelGGL(conv1_split_kernel<3>, dim3(grid), dim3(256), 0, s, canvas, (const f16*)wgt_planes, bias, out_scale, (f16*)out, B, H, W, range_ctx().flag, range_ctx().tag);
 }
 
 }  // namespace ttr
@@ -249,7 +256,8 @@ namespace ttr {
 namespace {
 template <int NPL>
 __global__ __launch_bounds__(256) void layernorm_planes_kernel(const float* __restrict__ in, int in_ld, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              float eps, f16* __restrict__ out, int M, const int* skip, int skip_n, int tiled) {
+                                                              float eps, f16* __restrict__ out, int M, const int* skip, int skip_n, int tiled,
+                                                              unsigned* range_flag, unsigned range_tag) {
   if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;   // AR early exit (see ConvParams::skip)
   constexpr int D = 384;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -266,8 +274,10 @@ __global__ __launch_bounds__(256) void layernorm_planes_kernel(const float* __re
   ln384_row8(v, act, gamma + c, beta + c, eps, o.v);
   if (!act) return;
   // tiled: gemm_sp.hip's loader pieces [rows / 8][plane][6 blocks of 64 channels][8 rows][64] (ConvParams::x_tiled) - planes 6 x 512 halves apart
-  if (tiled) st_planes<NPL>(out + ((int64_t)(row >> 3) * (NPL * 6) + (c >> 6)) * 512 + (row & 7) * 64 + (c & 63), 6 * 512, o);
-  else st_planes<NPL>(out + (int64_t)row * (NPL * D) + c, D, o);
+  RangeWatch rw;
+  if (tiled) st_planes<NPL>(out + ((int64_t)(row >> 3) * (NPL * 6) + (c >> 6)) * 512 + (row & 7) * 64 + (c & 63), 6 * 512, o, rw);
+  else st_planes<NPL>(out + (int64_t)row * (NPL * D) + c, D, o, rw);
+  rw.flush(range_flag, range_tag);
 }
 }  // namespace
 
@@ -276,7 +286,7 @@ void launch_layernorm_planes(const float* in, int in_ld, const float* gamma, con
   if (M <= 0) return;
   if (in_ld % 4 || (((uintptr_t)in | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15)) throw std::runtime_error("layernorm (planes): 16-byte alignment");
   if (tiled && M % 8) throw std::runtime_error("layernorm (planes): the tiled layout wants a multiple of 8 rows");
-  if (planes == 2) hipLaunchKernelGGL(layernorm_planes_kernel<2>, dim3((M + 3) / 4), dim3(256), 0, s, in, in_ld, gamma, beta, eps, (f16*)out, M, skip, skip_n, tiled);
-  else hipLaunchKernelGGL(layernorm_planes_kernel<3>, dim3((M + 3) / 4), dim3(256), 0, s, in, in_ld, gamma, beta, eps, (f16*)out, M, skip, skip_n, tiled);
+  if (planes == 2) hipLaunchKernelGGL(layernorm_planes_kernel<2>, dim3((M + 3) / 4), dim3(256), 0, s, in, in_ld, gamma, beta, eps, (f16*)out, M, skip, skip_n, tiled, range_ctx().flag, range_ctx().tag);
+  else hipLaunchKernelGGL(layernorm_planes_kernel<3>, dim3((M + 3) / 4), dim3(256), 0, s, in, in_ld, gamma, beta, eps, (f16*)out, M, skip, skip_n, tiled, range_ctx().flag, range_ctx().tag);
 }
 }  // namespace ttr
