@@ -24,12 +24,23 @@ struct OutputItem {
 std::vector<OutputItem> image_to_data(const uint8_t* image, int rows, int cols, std::ptrdiff_t row_stride, std::string weights_dir,
                                       std::string outputs_dir);
 
+// The same over a list of images of any sizes: one entry of the result per image, in input order (what a caller of the reference writes as a loop over
+// image_to_data; here the list shares one engine, same-sized images travel as batches and the host-to-device copies run beside the GPU's work).
+// An error (see above) prints its message and returns an empty list.
+struct ImageView { const uint8_t* data; int rows, cols; std::ptrdiff_t row_stride; };   // row_stride 0 = tightly packed
+std::vector<std::vector<OutputItem>> images_to_data(const std::vector<ImageView>& images, std::string weights_dir, std::string outputs_dir);
+
 #if defined(__has_include)
 #if __has_include(<opencv2/core.hpp>)
 #include <opencv2/core.hpp>
 inline std::vector<OutputItem> image_to_data(cv::Mat image, std::string weights_dir, std::string outputs_dir) {
   if (image.empty() || image.type() != CV_8UC3) return image_to_data(nullptr, 0, 0, 0, weights_dir, outputs_dir);
   return image_to_data(image.data, image.rows, image.cols, (std::ptrdiff_t)image.step, weights_dir, outputs_dir);
+}
+inline std::vector<std::vector<OutputItem>> images_to_data(const std::vector<cv::Mat>& images, std::string weights_dir, std::string outputs_dir) {
+  std::vector<ImageView> v;
+  for (const cv::Mat& m : images) v.push_back(m.empty() || m.type() != CV_8UC3 ? ImageView{nullptr, 0, 0, 0} : ImageView{m.data, m.rows, m.cols, (std::ptrdiff_t)m.step});
+  return images_to_data(v, weights_dir, outputs_dir);
 }
 #endif
 #endif

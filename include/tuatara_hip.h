@@ -70,6 +70,12 @@ int ttr_pages_to_data_dev(ttr_engine* e, const uint8_t* d_pages, int n, int h, i
  * entries as the largest batch.  The synchronous calls refuse to run while streamed batches are in flight. */
 int ttr_stream_push(ttr_engine* e, const uint8_t* d_pages, int n, int h, int w, ttr_result** out_prev, int* n_prev);
 int ttr_stream_flush(ttr_engine* e, ttr_result** out_prev, int* n_prev);
+/* image_to_data over a LIST of host images of any sizes (u8 HWC, 3 channels each; hs[i] x ws[i]; row_strides in bytes, NULL = tightly packed):
+ * what a caller of the reference writes as a loop over image_to_data (/root/reference/bindings/run_ocr.py:92, examples/resume.cpp:11), with the models
+ * loaded once (the reference reloads both per call, tuatara.cpp:336, :428).  Images of equal size travel together as batches through the streamed path
+ * above; their rows are gathered into pinned staging buffers and copied to the device on an upload stream of their own while the previous batch is on the
+ * GPU.  out[i] receives image i's result - input order, whatever the batching.  Every result equals what ttr_image_to_data returns for that image. */
+int ttr_images_to_data(ttr_engine* e, const uint8_t* const* images, const int* hs, const int* ws, const int* row_strides, int n, ttr_result** out);
 
 int ttr_result_count(const ttr_result* r);
 const char* ttr_result_text(const ttr_result* r, int i);

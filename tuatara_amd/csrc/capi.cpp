@@ -89,6 +89,20 @@ int ttr_image_to_data(ttr_engine* e, const uint8_t* img, int h, int w, int row_s
   TTR_GUARD_END(-1)
 }
 
+int ttr_images_to_data(ttr_engine* e, const uint8_t* const* images, const int* hs, const int* ws, const int* row_strides, int n, ttr_result** out) {
+  TTR_GUARD_BEGIN
+  if (!e || !out || n < 0 || (n > 0 && (!images || !hs || !ws))) throw std::runtime_error("null argument");
+  Engine& E = *e->e;
+  EngineScope lk(E);
+  std::vector<Engine::HostImage> imgs((size_t)n);
+  for (int i = 0; i < n; ++i) imgs[i] = Engine::HostImage{images[i], hs[i], ws[i], row_strides ? (std::ptrdiff_t)row_strides[i] : (std::ptrdiff_t)ws[i] * 3};
+  std::vector<Result> res;
+  E.run_images(imgs, res);
+  for (int i = 0; i < n; ++i) { out[i] = new ttr_result(); out[i]->r = std::move(res[i]); }
+  return 0;
+  TTR_GUARD_END(-1)
+}
+
 int ttr_result_count(const ttr_result* r) { return r ? (int)r->r.text.size() : 0; }
 
 const char* ttr_result_text(const ttr_result* r, int i) { return r->r.text[i].c_str(); }

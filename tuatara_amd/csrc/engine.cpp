@@ -406,6 +406,8 @@ Engine::~Engine() {
   if (copy_ev) (void)hipEventDestroy(copy_ev);
   for (auto& x : done_ev) if (x) (void)hipEventDestroy(x);
   for (auto& sl : evr) for (auto& x : sl) if (x) (void)hipEventDestroy(x);
+  for (auto& x : up_ev) if (x) (void)hipEventDestroy(x);
+  if (up_stream) (void)hipStreamDestroy(up_stream);
   if (copy_stream) (void)hipStreamDestroy(copy_stream);
   if (stream) (void)hipStreamDestroy(stream);
 }

@@ -102,12 +102,14 @@ struct Tuning {
   int ar_crop_exit = 1;       // ... and, per crop, the two attention kernels of a step return for crops that have emitted EOS
   int ar_early_exit = 1;      // bf16 kernel-per-op AR loop: the steps' kernels return at once when every crop of the batch has emitted EOS (upstream's break)
   int decoder_mode = 1;       // 0 = kernel-per-op AR loop, 4/8/16 = fused kernel with that many crops per workgroup, else automatic
+  int images_batch = 32;      // ttr_images_to_data: pages per streamed batch (same-sized images travel together)
   int range_guard = 1;        // split engines: every kernel that writes planes watches |x| < 65504 (split.h: RangeWatch); a tripped batch 1 = fails the call naming the
                               // layer, 2 = warns on stderr and returns the (saturated) result, 0 = not watched
   bool set(const std::string& k, int value) {
     if (k == "decoder_mode") decoder_mode = value;
     else if (k == "enc_chunk") enc_chunk = value;
     else if (k == "range_guard") range_guard = value;
+    else if (k == "images_batch") images_batch = value < 1 ? 1 : (value > 256 ? 256 : value);
     else if (k == "up_commute") up_commute = value;
     else if (k == "gpu_calipers") gpu_calipers = value;
     else if (k == "skinny_split") skinny_split = value;
@@ -594,6 +596,18 @@ struct Engine {
   void stream_push(const uint8_t* d_pages, int n, int h, int w, std::vector<Result>& prev_results, int& prev_n);
   // results of the oldest batch in flight (prev_n = 0: none left)
   void stream_flush(std::vector<Result>& prev_results, int& prev_n);
+
+  // ---- image_to_data over a LIST of host images of any sizes (the reference loads both models per call, tuatara.cpp:336, :428, and
+  // takes one image per call): images of equal size travel together as batches of <= images_batch pages through the streamed path above.  Staging: four
+  // pinned host buffers + four device buffers; a helper thread gathers batch j + 1's rows into its pinned buffer and starts its host-to-device copy on the
+  // upload stream while the caller's thread is inside stream_push(j) - the detector of a batch waits for its pages' copy event, nothing else does.
+  struct HostImage { const uint8_t* data; int h, w; std::ptrdiff_t row_stride; };
+  static constexpr int kStageSlots = 4;   // a batch's pages must outlive its recogniser (two pushes later) while the helper fills the next slot
+  PinnedBuf stage_host[kStageSlots];
+  DevBuf stage_dev[kStageSlots];
+  hipStream_t up_stream = nullptr;
+  hipEvent_t up_ev[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
+  void run_images(const std::vector<HostImage>& imgs, std::vector<Result>& results);
 };
 
 }  // namespace ttr

@@ -391,4 +391,90 @@ void Engine::stream_flush(std::vector<Result>& prev_results, int& prev_n) {
   if (q1.live) { prev_n = q1.n; finish(q1, prev_results); }
 }
 
+// ---- image_to_data over a list of host images (engine.h: run_images)
+void Engine::run_images(const std::vector<HostImage>& imgs, std::vector<Result>& results) {
+  const int n = (int)imgs.size();
+  results.assign(n, Result());
+  if (n == 0) return;
+  if (q1.live || q2.live) throw std::runtime_error("streamed batches are in flight: call ttr_stream_flush until it returns none");
+  if (comm) throw std::runtime_error("ttr_images_to_data runs on one engine: detach the communicator (every rank takes its own list)");
+  for (const HostImage& im : imgs)
+    if (!im.data || im.h <= 0 || im.w <= 0 || (im.row_stride >= 0 && im.row_stride < (std::ptrdiff_t)im.w * 3)) throw std::runtime_error("Error reading image from file");  // tuatara.cpp:344-347
+  // buckets of equal (h, w), the largest canvases first (the engine's grow-only workspaces then grow once), cut into batches
+  std::map<std::pair<int, int>, std::vector<int>> by_size;
+  for (int i = 0; i < n; ++i) by_size[{imgs[i].h, imgs[i].w}].push_back(i);
+  std::vector<std::pair<std::pair<int, int>, std::vector<int>>> buckets(by_size.begin(), by_size.end());
+  std::stable_sort(buckets.begin(), buckets.end(), [&](const auto& a, const auto& b) {
+    const CanvasGeom ga = canvas_geometry(a.first.first, a.first.second, cfg.canvas_size, cfg.mag_ratio), gb = canvas_geometry(b.first.first, b.first.second, cfg.canvas_size, cfg.mag_ratio);
+    return (size_t)ga.h32 * ga.w32 > (size_t)gb.h32 * gb.w32;
+  });
+  struct Batch { int h, w; std::vector<int> idx; };
+  std::vector<Batch> batches;
+  size_t max_bytes = 0;
+  const int cap = std::max(1, tn.images_batch);
+  for (auto& b : buckets)
+    for (size_t o = 0; o < b.second.size(); o += cap) {
+      Batch t{b.first.first, b.first.second, std::vector<int>(b.second.begin() + o, b.second.begin() + std::min(b.second.size(), o + cap))};
+      max_bytes = std::max(max_bytes, t.idx.size() * (size_t)t.h * t.w * 3);
+      batches.push_back(std::move(t));
+    }
+  if (!up_stream) {
+    TTR_HIP_CHECK(hipStreamCreateWithFlags(&up_stream, hipStreamNonBlocking));
+    for (auto& x : up_ev) TTR_HIP_CHECK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+  }
+  for (int s = 0; s < kStageSlots && s < (int)batches.size(); ++s) { stage_host[s].ensure(max_bytes); stage_dev[s].ensure(max_bytes); }
+  // stage(j): the rows of batch j's images, tightly packed, into pinned slot j % 4; one copy to the device on the upload stream; an event behind it
+  std::exception_ptr stage_err;
+  auto stage = [&](int j) {
+    try {
+      TTR_HIP_CHECK(hipSetDevice(cfg.device));
+      const Batch& b = batches[j];
+      const int sl = j % kStageSlots;
+      const size_t page = (size_t)b.h * b.w * 3, row = (size_t)b.w * 3;
+      uint8_t* dst = stage_host[sl].as<uint8_t>();
+      for (size_t k = 0; k < b.idx.size(); ++k) {
+        const HostImage& im = imgs[b.idx[k]];
+        if (im.row_stride == (std::ptrdiff_t)row) memcpy(dst + k * page, im.data, page);
+        else for (int y = 0; y < b.h; ++y) memcpy(dst + k * page + (size_t)y * row, im.data + (std::ptrdiff_t)y * im.row_stride, row);
+      }
+      TTR_HIP_CHECK(hipMemcpyAsync(stage_dev[sl].p, dst, b.idx.size() * page, hipMemcpyHostToDevice, up_stream));
+      TTR_HIP_CHECK(hipEventRecord(up_ev[sl], up_stream));
+    } catch (...) { stage_err = std::current_exception(); }
+  };
+  const int nb = (int)batches.size();
+  std::thread helper;
+  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{helper};
+  auto deliver = [&](int j, std::vector<Result>& res, int cnt) {       // batch j's results go to its images' places in the caller's order
+    if (cnt != (int)batches[j].idx.size()) throw std::runtime_error("ttr_images_to_data: a batch came back with another page count");
+    for (int k = 0; k < cnt; ++k) results[batches[j].idx[k]] = std::move(res[k]);
+  };
+  auto drain = [&]() {                                                 // an error mid-list: nothing stays in flight behind it
+    std::vector<Result> r; int c = 0;
+    for (int guard = 0; guard < 3 && (q1.live || q2.live); ++guard) { try { stream_flush(r, c); } catch (...) { q1 = PageBatch(); q2 = PageBatch(); } }
+  };
+  stage(0);
+  if (stage_err) std::rethrow_exception(stage_err);
+  try {
+    for (int j = 0; j < nb; ++j) {
+      if (helper.joinable()) helper.join();
+      if (stage_err) std::rethrow_exception(stage_err);
+      if (j + 1 < nb) helper = std::thread(stage, j + 1);               // (slot (j + 1) % 4 last held batch j - 3: returned one push ago)
+      TTR_HIP_CHECK(hipStreamWaitEvent(stream, up_ev[j % kStageSlots], 0));
+      std::vector<Result> prev; int np = 0;
+      stream_push(stage_dev[j % kStageSlots].as<uint8_t>(), (int)batches[j].idx.size(), batches[j].h, batches[j].w, prev, np);
+      if (np) deliver(j - 2, prev, np);
+    }
+    if (helper.joinable()) helper.join();
+    for (int j = std::max(0, nb - 2); j < nb; ++j) {
+      std::vector<Result> prev; int np = 0;
+      stream_flush(prev, np);
+      if (np) deliver(j, prev, np);
+    }
+  } catch (...) {
+    if (helper.joinable()) helper.join();
+    drain();
+    throw;
+  }
+}
+
 }  // namespace ttr

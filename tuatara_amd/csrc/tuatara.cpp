@@ -64,3 +64,34 @@ std::vector<OutputItem> image_to_data(const uint8_t* image, int rows, int cols, 
   ttr_result_free(r);
   return out;
 }
+
+std::vector<std::vector<OutputItem>> images_to_data(const std::vector<ImageView>& images, std::string weights_dir, std::string outputs_dir) {
+  if (weights_dir.empty()) { std::cerr << "Please provide a value for weights_dir" << std::endl; return {}; }   // tuatara.cpp:315-318
+  if (outputs_dir.empty()) { std::cerr << "Please provide a value for outputs_dir" << std::endl; return {}; }   // tuatara.cpp:320-323
+  ttr_engine* e = engine_for(weights_dir);
+  if (!e) { std::cerr << "error loading craft/parseq model: " << ttr_last_error() << std::endl; return {}; }     // tuatara.cpp:337-340, :429-432
+  const int n = (int)images.size();
+  std::vector<const uint8_t*> ptr(n);
+  std::vector<int> hs(n), ws(n), st(n);
+  for (int i = 0; i < n; ++i) {
+    if (!images[i].data || images[i].rows <= 0 || images[i].cols <= 0) { std::cerr << "Error reading image from file"; return {}; }   // tuatara.cpp:344-347
+    ptr[i] = images[i].data; hs[i] = images[i].rows; ws[i] = images[i].cols;
+    st[i] = images[i].row_stride ? (int)images[i].row_stride : images[i].cols * 3;
+  }
+  std::vector<ttr_result*> rs(n, nullptr);
+  if (n && ttr_images_to_data(e, ptr.data(), hs.data(), ws.data(), st.data(), n, rs.data()) != 0) {
+    std::cerr << "tuatara: " << ttr_last_error() << std::endl;
+    return {};
+  }
+  std::vector<std::vector<OutputItem>> out(n);
+  for (int i = 0; i < n; ++i) {
+    out[i].resize(ttr_result_count(rs[i]));
+    for (size_t k = 0; k < out[i].size(); ++k) {
+      out[i][k].text = ttr_result_text(rs[i], (int)k);
+      const float* b = ttr_result_bbox(rs[i], (int)k);
+      out[i][k].bbox.assign(b, b + 4);
+    }
+    ttr_result_free(rs[i]);
+  }
+  return out;
+}

@@ -39,6 +39,7 @@ SYMBOLS = [
     ("ttr_pages_to_data_dev", _I, [_VP, _VP, _I, _I, _I, C.POINTER(_VP)]),
     ("ttr_stream_push", _I, [_VP, _VP, _I, _I, _I, C.POINTER(_VP), C.POINTER(C.c_int)]),
     ("ttr_stream_flush", _I, [_VP, C.POINTER(_VP), C.POINTER(C.c_int)]),
+    ("ttr_images_to_data", _I, [_VP, C.POINTER(_VP), _PI, _PI, _PI, _I, C.POINTER(_VP)]),
     ("ttr_result_count", _I, [_VP]),
     ("ttr_result_text", C.c_char_p, [_VP, _I]),
     ("ttr_result_bbox", _PF, [_VP, _I]),
@@ -316,6 +317,30 @@ class Engine:
         r = C.c_void_p()
         self._check(self.lib.ttr_image_to_data(self.h, _u8(image), image.shape[0], image.shape[1], image.shape[1] * 3, C.byref(r)))
         return self._take(r)
+
+    def images_to_data(self, images, keep: bool = True):
+        """image_to_data over a list of host images [H, W, 3] u8 of any sizes (ttr_images_to_data): one result list per image, input order."""
+        arrs = []
+        for im in images:
+            a = np.asarray(im)
+            if a.ndim != 3 or a.shape[2] != 3:
+                raise EngineError("Input array should have 3 dimensions")
+            arrs.append(np.ascontiguousarray(a, dtype=np.uint8))
+        n = len(arrs)
+        if n == 0:
+            return []
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        hs = (C.c_int32 * n)(*[a.shape[0] for a in arrs])
+        ws = (C.c_int32 * n)(*[a.shape[1] for a in arrs])
+        out = (C.c_void_p * n)()
+        self._check(self.lib.ttr_images_to_data(self.h, ptrs, hs, ws, None, n, out))
+        if keep:
+            return self._take_many(out, n)
+        counts = []
+        for i in range(n):
+            counts.append(self.lib.ttr_result_count(out[i]))
+            self.lib.ttr_result_free(out[i])
+        return counts
 
     def pages_to_data_dev(self, d_pages, n: int, h: int, w: int, keep: bool = True):
         """d_pages: DeviceBuffer or raw device pointer holding [n][h][w][3] u8."""
