@@ -111,6 +111,9 @@ ttr_comm* ttr_comm_create_tcp(ttr_engine* e, int rank, int world, const char* ad
  * Rendezvous (both forms): rank 0 listens on addr:port for TUATARA_COMM_TIMEOUT seconds (default 120). */
 ttr_comm* ttr_comm_create_socket(ttr_engine* e, int rank, int world, const char* addr, int port);
 const char* ttr_comm_transport(const ttr_comm* c);   /* "rccl" or "socket" */
+/* one JSON object about this rank's end of the communicator: {"rank", "world", "transport", "rccl_version" (ncclGetVersion), "device" (HIP ordinal),
+ * "pci_bus_id", "gpu" (gcnArchName), "pid"} - what a scaling run prints so that its rank -> GPU map can be read afterwards.  Returns the length. */
+int ttr_comm_describe(const ttr_comm* c, char* buf, size_t cap);
 void ttr_comm_destroy(ttr_comm* c);
 int ttr_comm_rank(const ttr_comm* c);
 int ttr_comm_world(const ttr_comm* c);

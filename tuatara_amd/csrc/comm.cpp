@@ -280,6 +280,25 @@ ttr_comm* ttr_comm_create_socket(ttr_engine* e, int rank, int world, const char*
 
 const char* ttr_comm_transport(const ttr_comm* c) { return c && c->c && c->c->tr ? c->c->tr->name() : ""; }
 
+int ttr_comm_describe(const ttr_comm* c, char* buf, size_t cap) {
+  TTR_GUARD_BEGIN
+  if (!c || !c->c || !c->c->E || !buf || cap < 2) throw std::runtime_error("null argument");
+  const Engine& E = *c->c->E;
+  int ver = 0;
+  (void)ncclGetVersion(&ver);
+  char bus[64] = "";
+  (void)hipDeviceGetPCIBusId(bus, (int)sizeof bus, E.cfg.device);
+  hipDeviceProp_t prop{};
+  (void)hipGetDeviceProperties(&prop, E.cfg.device);
+  char line[512];
+  const int n = snprintf(line, sizeof line, "{\"rank\": %d, \"world\": %d, \"transport\": \"%s\", \"rccl_version\": %d, \"device\": %d, \"pci_bus_id\": \"%s\", \"gpu\": \"%s\", \"pid\": %d}",
+                         c->c->rank, c->c->world, c->c->tr ? c->c->tr->name() : "", ver, E.cfg.device, bus, prop.gcnArchName, (int)getpid());
+  const size_t m = std::min((size_t)std::max(n, 0), cap - 1);
+  memcpy(buf, line, m); buf[m] = 0;
+  return n;
+  TTR_GUARD_END(-1)
+}
+
 void ttr_comm_destroy(ttr_comm* c) {
   if (!c) return;
   try {

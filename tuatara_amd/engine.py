@@ -86,6 +86,7 @@ SYMBOLS = [
     ("ttr_comm_create_tcp", _VP, [_VP, _I, _I, C.c_char_p, _I]),
     ("ttr_comm_create_socket", _VP, [_VP, _I, _I, C.c_char_p, _I]),
     ("ttr_comm_transport", C.c_char_p, [_VP]),
+    ("ttr_comm_describe", _I, [_VP, C.c_char_p, C.c_size_t]),
     ("ttr_comm_destroy", None, [_VP]),
     ("ttr_comm_rank", _I, [_VP]),
     ("ttr_comm_world", _I, [_VP]),
@@ -583,6 +584,22 @@ class Comm:
 
     def barrier(self):
         self.allgather_host(np.zeros(1, np.int32))
+
+    def describe(self) -> dict:
+        """this rank's end of the communicator (ttr_comm_describe): rank, world, transport, RCCL version, HIP device, PCI bus id"""
+        import json
+        buf = C.create_string_buffer(512)
+        if self.lib.ttr_comm_describe(self.h, buf, len(buf)) < 0:
+            raise EngineError(self.lib.ttr_last_error().decode())
+        return json.loads(buf.value.decode())
+
+    def describe_all(self) -> list:
+        """every rank's describe(), by rank (collective)"""
+        import json
+        mine = np.zeros(512, np.uint8)
+        raw = json.dumps(self.describe()).encode()[:511]
+        mine[:len(raw)] = np.frombuffer(raw, np.uint8)
+        return [json.loads(bytes(r).split(b"\0", 1)[0].decode()) for r in self.allgather_host(mine)]
 
     def last_gathered(self):
         """(counts int32 [world, pages], ids int32 [rows, 26]) of the batch whose results the engine returned last."""
