@@ -249,16 +249,17 @@ def test_stream_survives_a_failed_push(eng_x4, eng_bf16, funsd, prec):
         assert [x["bbox"] for x in g[0]] == [x["bbox"] for x in w] and [x["text"] for x in g[0]] == [x["text"] for x in w]
 
 
-def test_engine_called_from_another_thread(weights, funsd):
+@pytest.mark.parametrize("prec", ["f16x4", "bf16"])
+def test_engine_called_from_another_thread(weights, funsd, prec):
     """HIP's current device is per thread: every C ABI entry point makes the engine's device current itself, so an engine may be
-    created in one thread and driven from others."""
+    created in one thread and driven from others - the default precision (whose range-guard context is per thread too) and bf16."""
     import threading
     from tuatara_amd.engine import Engine
     page = np.ascontiguousarray(funsd[:512, :384])
     box = {}
 
     def make():
-        box["eng"] = Engine(weights["dir"], precision="bf16")
+        box["eng"] = Engine(weights["dir"], precision=prec)
         box["a"] = box["eng"].image_to_data(page)
 
     def use():
@@ -301,11 +302,13 @@ def test_malformed_inputs_are_rejected_loudly(weights, eng_f32, tmp_path):
             Engine(str(d), precision="f32")
 
 
-def test_converted_torchscript_archives_end_to_end(tmp_path, oracle_models, funsd):
+@pytest.mark.parametrize("prec", ["f16x4", "f32"])
+def test_converted_torchscript_archives_end_to_end(tmp_path, oracle_models, funsd, prec):
     """SURVEY 8f-1 end to end: the reference loads two TorchScript archives (tuatara.cpp:333-336, :423-428).  Archives of that
     layout are traced from the oracle models, saved under the reference's file names, converted by tools/convert_weights.py, and
     the engine on the converted directory must give what the ARCHIVES give when run the reference's way (torch.jit.load ->
-    forward) through the oracle's post-processing: identical boxes and strings (f32 parity mode)."""
+    forward) through the oracle's post-processing: identical boxes and strings - in the engine's DEFAULT precision (what a user of the converter gets) and
+    in the fp32-MFMA mode."""
     import subprocess
     import torch
     from oracle import pipeline, post
@@ -329,7 +332,7 @@ def test_converted_torchscript_archives_end_to_end(tmp_path, oracle_models, funs
         logits = tp(torch.from_numpy(crops).permute(0, 3, 1, 2).float().div(255.0)).numpy()
     texts, _ = post.decode_logits(logits)
     ref = [{"text": t, "bbox": post.tesseract_bbox(b)} for t, b in zip(texts, da["boxes"])]
-    eng = Engine(wd, precision="f32")
+    eng = Engine(wd, precision=prec)
     got = eng.image_to_data(funsd)
     eng.close()
     assert [g["bbox"] for g in got] == [r["bbox"] for r in ref] and len(got) >= 40
