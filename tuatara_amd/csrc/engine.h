@@ -102,6 +102,9 @@ struct Tuning {
   int ar_crop_exit = 1;       // ... and, per crop, the two attention kernels of a step return for crops that have emitted EOS
   int ar_early_exit = 1;      // bf16 kernel-per-op AR loop: the steps' kernels return at once when every crop of the batch has emitted EOS (upstream's break)
   int decoder_mode = 1;       // 0 = kernel-per-op AR loop, 4/8/16 = fused kernel with that many crops per workgroup, else automatic
+  int sp_hidden16 = 2;        // split engines, encoder MLP: the hidden activation (fc1 -> fc2, 1 GB per layer at 1280 crops) as 16-row pieces in the producing epilogue's lane
+                              // order - a store instruction writes one contiguous KiB (gemm_sp.hip, x_tiled / out_tiled = 2); 2 = and those stores stream (nt) past the
+                              // weights and activation rows the tiles re-read from L2; 0 = the loader's 8-row pieces
   int images_batch = 32;      // ttr_images_to_data: pages per streamed batch (same-sized images travel together)
   int range_guard = 1;        // split engines: every kernel that writes planes watches |x| < 65504 (split.h: RangeWatch); a tripped batch 1 = fails the call naming the
                               // layer, 2 = warns on stderr and returns the (saturated) result, 0 = not watched
@@ -109,6 +112,7 @@ struct Tuning {
     if (k == "decoder_mode") decoder_mode = value;
     else if (k == "enc_chunk") enc_chunk = value;
     else if (k == "range_guard") range_guard = value;
+    else if (k == "sp_hidden16") sp_hidden16 = value;
     else if (k == "images_batch") images_batch = value < 1 ? 1 : (value > 256 ? 256 : value);
     else if (k == "up_commute") up_commute = value;
     else if (k == "gpu_calipers") gpu_calipers = value;

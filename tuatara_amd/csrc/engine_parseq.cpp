@@ -16,6 +16,7 @@ void Engine::sgemm(const Linear& L, const void* in_planes, int M, void* out, int
   p.wgt = L.ws.p; p.bias = L.b.as<float>(); p.split = np; p.out_scale = L.inv_scale; p.out_planes = out_planes == 1 ? 3 : out_planes;   // (1 = triples)
   p.wgt_tiled = tn.sp_tiled_w ? L.wst.p : nullptr;
   p.x_tiled = x_tiled; p.out_tiled = out_tiled;
+  p.store_policy = out_tiled == 2 && tn.sp_hidden16 == 2 ? 1 : 0;      // (16-row pieces: whole lines per store instruction, so the plane stores may stream)
   p.out = out; p.out_ld = out_ld; p.out_f32 = out_f32; p.out_f32_ld = out_f32_ld; p.resid = resid; p.resid_ld = resid_ld; p.resid_mod = resid_mod;
   p.Cout = L.cout_valid ? L.cout_valid : L.cout; p.M = M; p.act = act;
   p.skip = cur_skip; p.skip_n = cur_skip_n;
@@ -184,8 +185,9 @@ void Engine::parseq_forward(const uint8_t* d_crops, int N, float* d_logits, floa
         range_tag("parseq." + p + "norm2");
         launch_layernorm_planes(xc, E, pqf.at(p + "norm2.weight").as<float>(), pqf.at(p + "norm2.bias").as<float>(), 1e-6f, lnp_at(c0), Mc, stream, lnpl, nullptr, 0, xt);
         const int hpl = tn.enc_fc2_pairs ? 2 : 3;                                      // planes of the MLP's hidden activation
-        sgemm(pq.at(p + "fc1"), lnp_at(c0), Mc, bigp, 4 * E, kActGelu, hpl, nullptr, 0, nullptr, 0, lnpl + 1, 0, 0, "enc.fc1 + GELU", xt, xt);
-        sgemm(pq.at(p + "fc2"), bigp, Mc, nullptr, 0, kActNone, 0, xc, E, xc, E, hpl + 1, 0, 0, "enc.fc2", xt, 0);
+        const int hx = xt && tn.sp_hidden16 && hpl == 2 ? 2 : xt;                       // layout of the hidden planes (ConvParams::out_tiled / x_tiled)
+        sgemm(pq.at(p + "fc1"), lnp_at(c0), Mc, bigp, 4 * E, kActGelu, hpl, nullptr, 0, nullptr, 0, lnpl + 1, 0, 0, "enc.fc1 + GELU", xt, hx);
+        sgemm(pq.at(p + "fc2"), bigp, Mc, nullptr, 0, kActNone, 0, xc, E, xc, E, hpl + 1, 0, 0, "enc.fc2", hx, 0);
       }
       range_scope.clear();
       range_tag("parseq.encoder.norm");

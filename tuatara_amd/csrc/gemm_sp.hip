@@ -113,7 +113,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
   // profiles/r03_pmc_stall_parseq.txt section 4), the rows of a piece in the order the LDS image wants them
   const bool wtiled = p.wgt_tiled != nullptr;
   const __amdgpu_buffer_rsrc_t rsw = sp_rsrc(wtiled ? p.wgt_tiled : p.wgt, (unsigned)((size_t)((p.Cout + 31) / 32 * 32) * Kw * 6));
-  const unsigned x_plstep = p.x_tiled ? (unsigned)(K >> 6) * 1024u : (unsigned)K * 2u, x_kstep = p.x_tiled ? 1024u : 128u;   // byte offsets of one activation plane and of one k0
+  // byte offsets of one activation plane and of one k0: row-major rows; the loader's 8-row pieces (x_tiled = 1); the producer's 16-row pieces (x_tiled = 2, below)
+  const unsigned x_plstep = p.x_tiled == 2 ? (unsigned)(K >> 5) * 1024u : p.x_tiled ? (unsigned)(K >> 6) * 1024u : (unsigned)K * 2u;
+  const unsigned x_kstep = p.x_tiled == 2 ? 2048u : p.x_tiled ? 1024u : 128u;
   const unsigned w_pl1 = wtiled ? (unsigned)(2 * (K >> 6)) * 1024u : (unsigned)Kw * 4u, w_kstep = wtiled ? 1024u : 128u;   // byte offsets of plane w1 and of one k0
   constexpr unsigned OOB = 0x80000000u;
 
@@ -130,7 +132,11 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
       const int row = (i * C::NW + wave) * 8 + (lane >> 3);
       const int g = (lane & 7) ^ ((row >> 1) & 7);
       const int m = m0 + row;
-      if (p.x_tiled) xo[i] = (live && m < p.M) ? (unsigned)(m >> 3) * (unsigned)(PLX * (K >> 6)) * 1024u + (unsigned)((m & 7) * 128 + g * 16) : OOB;
+      // x_tiled = 2: [rows / 16][plane][channels / 32][4 chunks][16 rows][8 halves] - a KiB is what ONE store instruction of the producing epilogue writes, its 64
+      // lanes in lane order (lane = row + 16 chunk: the MFMA accumulator layout as it stands), i.e. eight whole 128-byte lines per instruction with nothing to merge
+      // in L2, so the stores can stream (nt) past the weights the tiles re-read.  This loader gathers its 8 rows x 8 chunks from two such KiB (eight 128-byte runs).
+      if (p.x_tiled == 2) xo[i] = (live && m < p.M) ? ((unsigned)(m >> 4) * (unsigned)(PLX * (K >> 5)) + (unsigned)(g >> 2)) * 1024u + (unsigned)(((g & 3) * 16 + (m & 15)) * 16) : OOB;
+      else if (p.x_tiled) xo[i] = (live && m < p.M) ? (unsigned)(m >> 3) * (unsigned)(PLX * (K >> 6)) * 1024u + (unsigned)((m & 7) * 128 + g * 16) : OOB;
       else xo[i] = (live && m < p.M) ? ((unsigned)m * (unsigned)(PLX * K) + g * 8) * 2u : OOB;
     }
 #pragma unroll
@@ -683,11 +689,18 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
         for (int e = 0; e < 4; ++e) { v[e] = acc[2 * t][i][e]; v[4 + e] = acc[2 * t + 1][i][e]; }
         if constexpr (EM == 1) {          // GELU (the block's eight table reads in flight together), then tiled pairs: the next GEMM's loader pieces
           gelu_hermite8(v, glut);
-          const int kb = p.out_ld >> 6;
-          f16* o = reinterpret_cast<f16*>(p.out) + ((int64_t)(m >> 3) * (2 * kb) + (n >> 6)) * 512 + (m & 7) * 64 + (n & 63);
           f16x8 a, b;
           split2_x8(v, a, b, rw);
+          if (p.out_tiled == 2) {         // 16-row pieces in lane order (see the loader): this instruction's 64 lanes write one contiguous KiB
+            const int kb = p.out_ld >> 5;
+            f16* o = reinterpret_cast<f16*>(p.out) + ((int64_t)(m >> 4) * (2 * kb) + (n >> 5)) * 512 + ((n >> 3) & 3) * 128 + (m & 15) * 8;
+            if (p.store_policy == 1) { __builtin_nontemporal_store(a, reinterpret_cast<f16x8*>(o)); __builtin_nontemporal_store(b, reinterpret_cast<f16x8*>(o + kb * 512)); }
+            else { *reinterpret_cast<f16x8*>(o) = a; *reinterpret_cast<f16x8*>(o + kb * 512) = b; }
+          } else {
+          const int kb = p.out_ld >> 6;
+          f16* o = reinterpret_cast<f16*>(p.out) + ((int64_t)(m >> 3) * (2 * kb) + (n >> 6)) * 512 + (m & 7) * 64 + (n & 63);
           *reinterpret_cast<f16x8*>(o) = a; *reinterpret_cast<f16x8*>(o + kb * 512) = b;
+          }
           __builtin_amdgcn_sched_barrier(0);   // block by block: hoisting every block's table reads to the top costs 256 registers (spills)
           continue;
         } else if constexpr (EM == 2) {   // fp32 rows
@@ -711,9 +724,10 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
             split3_x8(v, a, b, c, rw);
             f16* o = reinterpret_cast<f16*>(p.out) + (int64_t)m * (3 * (int64_t)p.out_ld) + n;
             *reinterpret_cast<f16x8*>(o) = a; *reinterpret_cast<f16x8*>(o + p.out_ld) = b;
-          } else if (p.out_planes && p.out_tiled) {   // the next GEMM's loader pieces
-            const int kb = p.out_ld >> 6;
-            f16* o = reinterpret_cast<f16*>(p.out) + ((int64_t)(m >> 3) * (p.out_planes * kb) + (n >> 6)) * 512 + (m & 7) * 64 + (n & 63);
+          } else if (p.out_planes && p.out_tiled) {   // the next GEMM's loader pieces (8-row pieces; out_tiled = 2: 16-row pieces in lane order)
+            const int kb = p.out_tiled == 2 ? p.out_ld >> 5 : p.out_ld >> 6;
+            f16* o = p.out_tiled == 2 ? reinterpret_cast<f16*>(p.out) + ((int64_t)(m >> 4) * (p.out_planes * kb) + (n >> 5)) * 512 + ((n >> 3) & 3) * 128 + (m & 15) * 8
+                                      : reinterpret_cast<f16*>(p.out) + ((int64_t)(m >> 3) * (p.out_planes * kb) + (n >> 6)) * 512 + (m & 7) * 64 + (n & 63);
             f16x8 a, b, c;
             if (p.out_planes == 3) { split3_x8(v, a, b, c, rw); *reinterpret_cast<f16x8*>(o + 2 * kb * 512) = c; }
             else split2_x8(v, a, b, rw);
@@ -762,6 +776,7 @@ void set_gemm_sp_sched(int v) { g_sp_sched = v; }
 bool gemm_sp_eligible(const ConvParams& p) {
   if (p.up_z) return false;   // (the half-resolution addend is an epilogue of gemm2.hip's split loop)
   if (p.out_tiled && (!p.out_planes || p.out_ld % 64 != 0 || p.out_full_cols)) return false;   // (tiled planes: whole 64-channel blocks, every plane)
+  if ((p.out_tiled == 2 || p.x_tiled == 2) && p.M % 16 != 0) return false;                     // (16-row pieces)
   if ((p.split != 3 && p.split != 4) || p.ks != 1 || p.C1 != 0 || p.out_pool || p.out_relu || p.C0 % 64 != 0 || p.Cout % 8 != 0) return false;
   if (p.split == 3 ? p.C0 < 192 : (p.C0 < 128 || (p.C0 >> 6) % 2 != 0)) return false;
   if (p.resid && (size_t)(p.resid_mod ? p.resid_mod : p.M) * p.resid_ld * 4 >= ((size_t)1 << 31)) return false;   // the epilogue reads the residual through a buffer descriptor
