@@ -132,14 +132,26 @@ def test_batch_of_pages_matches_single_pages_bf16(eng_bf16, funsd):
     assert len(batch[0]) > 5
 
 
-@pytest.mark.parametrize("prec", ["f16x4", "f32", "bf16"])
+@pytest.mark.parametrize("prec", ["f16x4", "f32", "bf16", "f16x4+overlap"])
 def test_streamed_batches_equal_synchronous_calls(eng_x4, eng_f32, eng_bf16, funsd, prec):
     """ttr_stream_push / ttr_stream_flush: batch j's detector and batch j-1's recogniser are enqueued before batch j-2's results are
     awaited, and results come back two calls later — same kernels over the same batches, so boxes and strings must equal the
     synchronous call's exactly.  Five batches of different sizes (one of a single page, one of blank pages) and a refusal of synchronous
     calls mid-stream."""
     from tuatara_amd.engine import DeviceBuffer, EngineError
+    overlap = prec.endswith("+overlap")       # tuning key "recog_overlap": the recogniser of batch j - 1 on its own stream beside the detector of batch j
+    prec = prec.split("+")[0]
     eng = {"f16x4": eng_x4, "f32": eng_f32, "bf16": eng_bf16}[prec]
+    if overlap:
+        assert eng.set_tuning(b"recog_overlap", 1) == 0
+    try:
+        _streamed_equal_synchronous(eng, funsd)
+    finally:
+        eng.set_tuning(b"recog_overlap", 0)
+
+
+def _streamed_equal_synchronous(eng, funsd):
+    from tuatara_amd.engine import DeviceBuffer, EngineError
     crops3 = [funsd[:512, :384].copy(), np.ascontiguousarray(funsd[300:812, 200:584]), np.ascontiguousarray(funsd[100:612, 300:684])]
     batches = [crops3, [crops3[1]], [np.full((512, 384, 3), 255, np.uint8)] * 2, crops3[::-1] + crops3, [crops3[2], crops3[0]]]
     bufs = []

@@ -139,7 +139,7 @@ void Engine::upload_linear(Linear& L, const float* w, int cout, int k, const flo
         _Float16* row = h.data() + (size_t)o * 3 * k_pad;
         row[kk] = w0;
         row[k_pad + kk] = (_Float16)((float)w0 * (1.f / 2048.f));
-        row[2 * k_pad + kk] = w1;
+        row[2 * k_pad + kk] = drop_w1 ? (_Float16)0.f : w1;
       }
     L.ws.ensure(h.size() * 2);
     TTR_HIP_CHECK(hipMemcpy(L.ws.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
@@ -202,6 +202,10 @@ void Engine::load_craft(const std::string& dir) {
     std::vector<int> kmap((size_t)taps * cin_pad, -1);
     for (int t = 0; t < taps; ++t)
       for (int ci = 0; ci < c.cin; ++ci) kmap[(size_t)t * cin_pad + ci] = t * c.cin + ci;
+    // EXPERIMENT (TUATARA_CRAFT_PRODUCTS=2, DESIGN_APPENDIX.md "CRAFT on two products"): the layers of >= 64 input channels with their weights' low parts
+    // dropped (w1 = 0: x0 w0 + x1 w0 / 2^11 only) - the arithmetic a two-MFMA-per-product CRAFT would have, on the three-product kernels
+    struct DropScope { bool& f; ~DropScope() { f = false; } } drop_scope{drop_w1};
+    { const char* ev = getenv("TUATARA_CRAFT_PRODUCTS"); drop_w1 = ev && std::string(ev) == "2" && c.cin >= 64 && nm.rfind("conv_cls", 0) != 0; }
     upload_linear(L, w.data.data(), c.cout, taps * c.cin, b.data.data(), cout_pad, taps * cin_pad, &kmap);
     if (prec == kSplit && nm == "conv_cls.8") load_head_tail(wf);
     if (prec == kSplit && (nm == "upconv2.0" || nm == "upconv3.0" || nm == "upconv4.0")) {
@@ -380,6 +384,7 @@ Engine::Engine(const std::string& dir, const ttr_config& c) : cfg(c) {
   TTR_HIP_CHECK(hipSetDevice(cfg.device));
   TTR_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   TTR_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+  TTR_HIP_CHECK(hipStreamCreateWithFlags(&recog_stream, hipStreamNonBlocking));
   TTR_HIP_CHECK(hipEventCreateWithFlags(&copy_ev, hipEventDisableTiming));
   for (auto& x : done_ev) TTR_HIP_CHECK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
   for (auto& sl : evr) for (auto& x : sl) TTR_HIP_CHECK(hipEventCreate(&x));
@@ -409,6 +414,7 @@ Engine::~Engine() {
   for (auto& x : up_ev) if (x) (void)hipEventDestroy(x);
   if (up_stream) (void)hipStreamDestroy(up_stream);
   if (copy_stream) (void)hipStreamDestroy(copy_stream);
+  if (recog_stream) (void)hipStreamDestroy(recog_stream);
   if (stream) (void)hipStreamDestroy(stream);
 }
 

@@ -102,9 +102,11 @@ struct Tuning {
   int ar_crop_exit = 1;       // ... and, per crop, the two attention kernels of a step return for crops that have emitted EOS
   int ar_early_exit = 1;      // bf16 kernel-per-op AR loop: the steps' kernels return at once when every crop of the batch has emitted EOS (upstream's break)
   int decoder_mode = 1;       // 0 = kernel-per-op AR loop, 4/8/16 = fused kernel with that many crops per workgroup, else automatic
-  int sp_hidden16 = 2;        // split engines, encoder MLP: the hidden activation (fc1 -> fc2, 1 GB per layer at 1280 crops) as 16-row pieces in the producing epilogue's lane
+  int sp_hidden16 = 0;        // split engines, encoder MLP: the hidden activation (fc1 -> fc2, 1 GB per layer at 1280 crops) as 16-row pieces in the producing epilogue's lane
                               // order - a store instruction writes one contiguous KiB (gemm_sp.hip, x_tiled / out_tiled = 2); 2 = and those stores stream (nt) past the
                               // weights and activation rows the tiles re-read from L2; 0 = the loader's 8-row pieces
+  int recog_overlap = 0;      // streamed batches: the recogniser of batch j - 1 on a stream of its own, beside the detector of batch j (they share no buffer): the
+                              // HBM-bound kernels and tile tails of one run under the other's matrix work.  Per-kernel times then include the neighbour's share of the chip
   int images_batch = 32;      // ttr_images_to_data: pages per streamed batch (same-sized images travel together)
   int range_guard = 1;        // split engines: every kernel that writes planes watches |x| < 65504 (split.h: RangeWatch); a tripped batch 1 = fails the call naming the
                               // layer, 2 = warns on stderr and returns the (saturated) result, 0 = not watched
@@ -112,6 +114,7 @@ struct Tuning {
     if (k == "decoder_mode") decoder_mode = value;
     else if (k == "enc_chunk") enc_chunk = value;
     else if (k == "range_guard") range_guard = value;
+    else if (k == "recog_overlap") recog_overlap = value;
     else if (k == "sp_hidden16") sp_hidden16 = value;
     else if (k == "images_batch") images_batch = value < 1 ? 1 : (value > 256 ? 256 : value);
     else if (k == "up_commute") up_commute = value;
@@ -337,6 +340,7 @@ struct Engine {
   size_t es;  // element size of T
   hipStream_t stream = nullptr;
   std::unique_ptr<HostPool> host_pool;
+  hipStream_t recog_stream = nullptr;             // tn.recog_overlap: the recogniser of a streamed batch runs here
   hipStream_t copy_stream = nullptr;              // device -> host copies of one page group's components while the next group's CRAFT runs
   hipEvent_t copy_ev = nullptr, done_ev[2] = {nullptr, nullptr};   // done_ev[slot]: a batch's token ids have landed
   hipEvent_t evr[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};   // per slot: before the packer, after it, after PARSeq
@@ -442,6 +446,7 @@ struct Engine {
   void upload_linear(Linear& L, const float* w, int cout, int k, const float* bias, int cout_pad, int k_pad,
                      const std::vector<int>* kmap = nullptr, bool own = true);
   void tile_planes(Linear& L);   // L.ws -> L.wst (gemm_sp.hip's contiguous loader pieces)
+  bool drop_w1 = false;          // (experiment, load_craft: the weight planes' low parts as zeros)
   void upload_f32(DevBuf& d, const float* p, size_t n);
 
   static const std::vector<CraftConv>& craft_convs() {

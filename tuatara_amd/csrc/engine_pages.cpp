@@ -374,6 +374,9 @@ void Engine::stream_push(const uint8_t* d_pages, int n, int h, int w, std::vecto
     RangeScope r("ttr:recog_enqueue");
     struct Flag { bool& f; ~Flag() { f = false; } } flag{streaming_recog};
     streaming_recog = true;
+    // (recog_overlap: everything recog_enqueue puts on "the stream" - packer, recogniser, id copy, completion event - goes to the recogniser's own stream)
+    struct StreamSwap { Engine& E; bool on; StreamSwap(Engine& e, bool o) : E(e), on(o) { if (on) std::swap(E.stream, E.recog_stream); } ~StreamSwap() { if (on) std::swap(E.stream, E.recog_stream); } }
+        swap_guard{*this, tn.recog_overlap != 0 && !comm};
     recog_enqueue(q1);
   }
   host_us[4] = (float)(now_us() - th1);
@@ -386,7 +389,12 @@ void Engine::stream_push(const uint8_t* d_pages, int n, int h, int w, std::vecto
 
 void Engine::stream_flush(std::vector<Result>& prev_results, int& prev_n) {
   prev_results.clear(); prev_n = 0;
-  if (q1.live && !q1.enqueued) recog_enqueue(q1);
+  if (q1.live && !q1.enqueued) {
+    const bool sw = tn.recog_overlap != 0 && !comm;
+    if (sw) std::swap(stream, recog_stream);
+    try { recog_enqueue(q1); } catch (...) { if (sw) std::swap(stream, recog_stream); throw; }
+    if (sw) std::swap(stream, recog_stream);
+  }
   if (q2.live) { prev_n = q2.n; finish(q2, prev_results); return; }
   if (q1.live) { prev_n = q1.n; finish(q1, prev_results); }
 }
