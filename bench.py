@@ -415,6 +415,28 @@ def main():
     kinds = eng.get_profile_kinds()
     eng.set_profiling(0)
     stage = eng.last_stage_ms()
+    # In the timed region a batch's recogniser runs on its own stream beside the next batch's detector (tuning key "recog_overlap", the engine's default: +3 % pages/s):
+    # the dominant kernel's launches then share the chip with the recogniser's, and their durations say so.  The same kernel ALONE on the chip: a few passes
+    # with the overlap off, outside the timed region -> roofline.exclusive
+    kinds_excl = None
+    overlap_on = not any(kv.startswith("recog_overlap=0") for kv in args.tune) and stream
+    if overlap_on and not args.no_extras and world == 1:
+        eng.set_tuning(b"recog_overlap", 0)
+        run_passes(eng, 1)
+        eng.lib.ttr_dev_sync(eng.h)
+        eng.get_profile_kinds()
+        eng.set_profiling(1)
+        before = {(k["kind"], k["stage"]): dict(k) for k in eng.get_profile_kinds()}
+        run_passes(eng, 4)
+        eng.lib.ttr_dev_sync(eng.h)
+        after = eng.get_profile_kinds()
+        eng.set_profiling(0)
+        eng.set_tuning(b"recog_overlap", 1)
+        kinds_excl = []
+        for k in after:
+            b = before.get((k["kind"], k["stage"]), {"ms": 0.0, "launches": 0, "alg_flops": 0.0, "exec_flops": 0.0})
+            kinds_excl.append({"kind": k["kind"], "stage": k["stage"], "ms": k["ms"] - b["ms"], "launches": k["launches"] - b["launches"],
+                               "alg_flops": k["alg_flops"] - b["alg_flops"], "exec_flops": k["exec_flops"] - b["exec_flops"]})
     gathered_rows = None
     if comm:
         cts, gids = comm.last_gathered()
@@ -472,6 +494,16 @@ def main():
                                    "dispatch gaps inside a run are charged to it.  mfma_pipe_* = the flops the matrix cores execute for them (three f16 MFMAs per product "
                                    "on activation pairs, four on exact triples: tuatara_amd/csrc/split.h)")
             roof["share_of_craft_time"] = dom["ms"] / fam_ms if fam_ms else None
+            if overlap_on:
+                roof["shares_the_chip"] = ("in the timed region this kernel's launches run while the previous batch's recogniser is on the chip too (engine default \"recog_overlap\": "
+                                           "the recogniser on its own stream, +3 % pages/s): avg_launch_us / achieved / frac are what the kernel gets of a shared machine; "
+                                           "`exclusive` = the same launches alone on the chip (overlap off, passes behind the timed region)")
+            if kinds_excl:
+                ke = [k for k in kinds_excl if k["kind"] == dom["kind"] and k["stage"] == 0 and k["ms"] > 0 and k["launches"] > 0]
+                if ke:
+                    e = line(ke[0])
+                    e["launches_per_pass"] = ke[0]["launches"] / 4.0          # (four passes were measured)
+                    roof["exclusive"] = {kk: e[kk] for kk in ("launches_per_pass", "avg_launch_us", "algorithmic_gflop_per_launch", "achieved", "frac", "mfma_pipe_tflops", "mfma_pipe_frac")}
         roof.update({"traffic": traffic, "traffic_unit": "HBM bytes per launch of this kernel (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes over one CRAFT group)",
                      "traffic_source": traffic_src})
         out = {

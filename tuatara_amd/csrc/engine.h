@@ -105,7 +105,7 @@ struct Tuning {
   int sp_hidden16 = 0;        // split engines, encoder MLP: the hidden activation (fc1 -> fc2, 1 GB per layer at 1280 crops) as 16-row pieces in the producing epilogue's lane
                               // order - a store instruction writes one contiguous KiB (gemm_sp.hip, x_tiled / out_tiled = 2); 2 = and those stores stream (nt) past the
                               // weights and activation rows the tiles re-read from L2; 0 = the loader's 8-row pieces
-  int recog_overlap = 0;      // streamed batches: the recogniser of batch j - 1 on a stream of its own, beside the detector of batch j (they share no buffer): the
+  int recog_overlap = 1;      // streamed batches: the recogniser of batch j - 1 on a stream of its own, beside the detector of batch j (they share no buffer): the
                               // HBM-bound kernels and tile tails of one run under the other's matrix work.  Per-kernel times then include the neighbour's share of the chip
   int images_batch = 32;      // ttr_images_to_data: pages per streamed batch (same-sized images travel together)
   int range_guard = 1;        // split engines: every kernel that writes planes watches |x| < 65504 (split.h: RangeWatch); a tripped batch 1 = fails the call naming the

@@ -376,7 +376,7 @@ void Engine::stream_push(const uint8_t* d_pages, int n, int h, int w, std::vecto
     streaming_recog = true;
     // (recog_overlap: everything recog_enqueue puts on "the stream" - packer, recogniser, id copy, completion event - goes to the recogniser's own stream)
     struct StreamSwap { Engine& E; bool on; StreamSwap(Engine& e, bool o) : E(e), on(o) { if (on) std::swap(E.stream, E.recog_stream); } ~StreamSwap() { if (on) std::swap(E.stream, E.recog_stream); } }
-        swap_guard{*this, tn.recog_overlap != 0 && !comm};
+        swap_guard{*this, tn.recog_overlap != 0};
     recog_enqueue(q1);
   }
   host_us[4] = (float)(now_us() - th1);
@@ -390,7 +390,7 @@ void Engine::stream_push(const uint8_t* d_pages, int n, int h, int w, std::vecto
 void Engine::stream_flush(std::vector<Result>& prev_results, int& prev_n) {
   prev_results.clear(); prev_n = 0;
   if (q1.live && !q1.enqueued) {
-    const bool sw = tn.recog_overlap != 0 && !comm;
+    const bool sw = tn.recog_overlap != 0;
     if (sw) std::swap(stream, recog_stream);
     try { recog_enqueue(q1); } catch (...) { if (sw) std::swap(stream, recog_stream); throw; }
     if (sw) std::swap(stream, recog_stream);
