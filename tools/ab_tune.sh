@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for cfg in "$@"; do
   args=""; for kv in $cfg; do args="$args --tune $kv"; done
-  python3 $R/bench.py --no-cpu-baseline --no-extras ${STEPS:+--steps $STEPS} $args 2>/dev/null | python3 -c "
+  python3 $R/bench.py --no-cpu-baseline --no-extras ${STEPS:+--steps $STEPS} $BENCH_ARGS $args 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('$cfg:', round(d['value'], 1), 'pages/s; dominant kernel', round(d['roofline']['avg_launch_us'], 1), 'us; stages', d['stage_ms_last_pass'])"

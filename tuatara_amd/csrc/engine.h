@@ -186,14 +186,19 @@ struct RangeScope {
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  size_t cap_seen = 0;   // the last capacity this buffer had (survives the window in which cap is 0 during a re-allocation)
   void ensure(size_t bytes) {
     if (bytes <= cap) return;
     void* old = p;
     p = nullptr; cap = 0;                       // a throwing hipFree must not leave a dangling pointer for the destructor
     if (old) TTR_HIP_CHECK(hipFree(old));
-    size_t want = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+    // a buffer that grows again grows by a quarter at least: batches of slightly different crop counts must not re-allocate (hipFree waits for the whole
+    // device) pass after pass - 288 GB of HBM make the slack free
+    const size_t old_cap = cap_seen;
+    size_t want = std::max(bytes, old_cap ? old_cap + old_cap / 4 : (size_t)0);
+    want = (want + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
     TTR_HIP_CHECK(hipMalloc(&p, want));
-    cap = want;
+    cap = want; cap_seen = want;
   }
   template <typename U> U* as() const { return reinterpret_cast<U*>(p); }
   ~DevBuf() { if (p) (void)hipFree(p); }
