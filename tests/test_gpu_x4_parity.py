@@ -369,6 +369,33 @@ def test_x4_batch_of_pages_equals_single_pages(eng_x4):
         assert [g["text"] for g in one] == [g["text"] for g in res[k]], k
 
 
+def test_x4_two_detector_lanes_change_nothing(eng_x4):
+    """A batch's CRAFT launch groups on two staggered streams with their own workspaces (tuning key "craft_lanes" = 2, the default) against one group after
+    the other (1): scheduling only - 20 pages (three groups: 8 + 8 + 4, so both lanes and a second round of the first) give identical boxes, ids and strings,
+    also with a large component whose hull goes through the lanes' halves of the calipers pool."""
+    from tuatara_amd import synth
+    from tuatara_amd.engine import DeviceBuffer
+    pages = [synth.synthetic_page(300 + i, 1024, 768, n_words=24) for i in range(20)]
+    pages[9][100:900, 40:60] = 0                    # a tall bar: a component of ~400 rows (more hull points than the LDS path takes)
+    pages[12][500:520, 30:740] = 0
+    buf = DeviceBuffer(20 * 1024 * 768 * 3)
+    buf.upload(np.stack(pages))
+    two = eng_x4.pages_to_data_dev(buf, 20, 1024, 768)
+    assert eng_x4.set_tuning(b"craft_lanes", 1) == 0
+    try:
+        one = eng_x4.pages_to_data_dev(buf, 20, 1024, 768)
+    finally:
+        eng_x4.set_tuning(b"craft_lanes", 2)
+    again = eng_x4.pages_to_data_dev(buf, 20, 1024, 768)
+    buf.free()
+    for k in range(20):
+        for other in (one, again):
+            assert np.array_equal(np.array([g["bbox"] for g in two[k]]), np.array([g["bbox"] for g in other[k]])), k
+            assert [g["text"] for g in two[k]] == [g["text"] for g in other[k]], k
+            assert np.array_equal(np.array([g["ids"] for g in two[k]]), np.array([g["ids"] for g in other[k]])), k
+    assert sum(len(r) for r in two) > 300
+
+
 def test_x4_funsd_end_to_end_identical(eng_x4, oracle_models, funsd):
     """Config 4: FUNSD page through the whole path: boxes (np.array_equal, order included) and strings identical to the oracle."""
     from oracle import pipeline

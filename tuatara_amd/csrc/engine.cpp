@@ -385,6 +385,8 @@ Engine::Engine(const std::string& dir, const ttr_config& c) : cfg(c) {
   TTR_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   TTR_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
   TTR_HIP_CHECK(hipStreamCreateWithFlags(&recog_stream, hipStreamNonBlocking));
+  TTR_HIP_CHECK(hipStreamCreateWithFlags(&lane_stream, hipStreamNonBlocking));
+  for (hipEvent_t* e : {&lane_go, &lane_done, &resize_done}) TTR_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
   TTR_HIP_CHECK(hipEventCreateWithFlags(&copy_ev, hipEventDisableTiming));
   for (auto& x : done_ev) TTR_HIP_CHECK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
   for (auto& sl : evr) for (auto& x : sl) TTR_HIP_CHECK(hipEventCreate(&x));
@@ -415,10 +417,13 @@ Engine::~Engine() {
   if (up_stream) (void)hipStreamDestroy(up_stream);
   if (copy_stream) (void)hipStreamDestroy(copy_stream);
   if (recog_stream) (void)hipStreamDestroy(recog_stream);
+  for (hipEvent_t e : {lane_go, lane_done, resize_done}) if (e) (void)hipEventDestroy(e);
+  if (lane_stream) (void)hipStreamDestroy(lane_stream);
   if (stream) (void)hipStreamDestroy(stream);
 }
 
 DevBuf& Engine::ws(size_t idx, size_t bytes, bool zero_new) {
+  auto& craft_ws = craft_ws_cur();
   while (craft_ws.size() <= idx) craft_ws.emplace_back(new DevBuf());
   DevBuf& d = *craft_ws[idx];
   const size_t cap_before = d.cap;          // (not the pointer: the allocator may hand the grown block the old address)

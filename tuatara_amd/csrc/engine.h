@@ -105,6 +105,7 @@ struct Tuning {
   int sp_hidden16 = 0;        // split engines, encoder MLP: the hidden activation (fc1 -> fc2, 1 GB per layer at 1280 crops) as 16-row pieces in the producing epilogue's lane
                               // order - a store instruction writes one contiguous KiB (gemm_sp.hip, x_tiled / out_tiled = 2); 2 = and those stores stream (nt) past the
                               // weights and activation rows the tiles re-read from L2; 0 = the loader's 8-row pieces
+  int craft_lanes = 2;        // split engines, batches of >= 2 CRAFT launch groups: the groups on two staggered streams (Engine::lane_stream); 1 = one after the other
   int recog_overlap = 1;      // streamed batches: the recogniser of batch j - 1 on a stream of its own, beside the detector of batch j (they share no buffer): the
                               // HBM-bound kernels and tile tails of one run under the other's matrix work.  Per-kernel times then include the neighbour's share of the chip
   int images_batch = 32;      // ttr_images_to_data: pages per streamed batch (same-sized images travel together)
@@ -115,6 +116,7 @@ struct Tuning {
     else if (k == "enc_chunk") enc_chunk = value;
     else if (k == "range_guard") range_guard = value;
     else if (k == "recog_overlap") recog_overlap = value;
+    else if (k == "craft_lanes") craft_lanes = value == 2 ? 2 : 1;
     else if (k == "sp_hidden16") sp_hidden16 = value;
     else if (k == "images_batch") images_batch = value < 1 ? 1 : (value > 256 ? 256 : value);
     else if (k == "up_commute") up_commute = value;
@@ -261,14 +263,15 @@ struct CclBatch {   // device workspaces of the CCL stage for a batch of equally
   static constexpr int kCalCap = 4 << 20;   // floats (16 MB: ~230 k hull points per CRAFT group; a group that needs more falls back to the host's calipers)
   int pages = 0, npx = 0, max_cand = 0;
   int cal_cap_now = kCalCap;          // (tuning key gpu_calipers = 2 shrinks it to 512 floats: the host-fallback path under test)
-  CclBuffers view(int p0 = 0) {   // the slices of pages p0.. (every array is strided by the page)
+  CclBuffers view(int p0 = 0, int lane = 0) {   // the slices of pages p0.. (every array is strided by the page); lane: which half of the hulls' pool (two detector lanes)
     CclBuffers b;
     const size_t o = (size_t)p0 * npx;
     b.tnorm = tnorm.as<float>() + o; b.flags = flags.as<uint8_t>() + o; b.parent = parent.as<int>() + o; b.mm = mm.as<unsigned>() + (size_t)p0 * 4;
     b.area = area.as<int>() + o; b.bbox = bbox.as<int>() + o * 4; b.maxt = maxt.as<unsigned>() + o; b.cand_slot = cand_slot.as<int>() + o;
     b.cand = cand.as<int>() + (size_t)p0 * max_cand * 8; b.counters = counters.as<int>() + (size_t)p0 * 2; b.rows_packed = rows.as<int>() + o * 2;
     b.max_cand = max_cand;
-    b.rects = rects.as<float>() + (size_t)p0 * max_cand * 8; b.cal_pool = cal_pool.as<float>(); b.cal_ctr = cal_ctr.as<int>(); b.cal_cap = cal_cap_now;
+    b.rects = rects.as<float>() + (size_t)p0 * max_cand * 8;
+    b.cal_pool = cal_pool.as<float>() + (size_t)lane * (kCalCap / 2); b.cal_ctr = cal_ctr.as<int>() + lane; b.cal_cap = std::min(cal_cap_now, kCalCap / 2);
     return b;
   }
   void ensure(int pages_, int npx_, int max_cand_) {
@@ -375,7 +378,15 @@ struct Engine {
   DevBuf qself;                                   // f32 [26][384]
 
   // workspaces
-  std::vector<std::unique_ptr<DevBuf>> craft_ws;  // per-layer activations
+  std::vector<std::unique_ptr<DevBuf>> craft_ws_set[2];   // per-layer activations; [1]: the second detector lane's (tn.craft_lanes)
+  int ws_sel = 0;                                 // which set ws() hands out
+  std::vector<std::unique_ptr<DevBuf>>& craft_ws_cur() { return craft_ws_set[ws_sel]; }
+  // tn.craft_lanes = 2: a batch's CRAFT launch groups alternate between the main stream and lane_stream, the second lane half a group behind the first
+  // (lane_go: recorded by the first group once its full-resolution layers are through), so that one lane's matrix-bound first half runs beside the other's
+  // HBM-bound U-Net tail; lane_done: the second lane's last CCL is enqueued (the main stream waits for it before the batch's closing events)
+  hipStream_t lane_stream = nullptr;
+  hipEvent_t lane_go = nullptr, lane_done = nullptr, resize_done = nullptr;
+  bool lane_go_pending = false;                   // craft_forward_split records lane_go behind slice3.20 when set
   int craft_ws_npl = 0;                           // planes per value the split CRAFT workspaces were laid out for
   DevBuf pq_ws[24];
   DevBuf canvas, heat, staging_img, crops, rects_dev, logits, ar_logits, ids_dev, tokens;
@@ -556,7 +567,7 @@ struct Engine {
 
   // CCL kernels of pages [p0, p0 + pages) of a batch of `total` pages, then their component counters -> host; group `g`'s event
   // fires when the counters have landed
-  void ccl_launch(const float* d_heat, int p0, int pages, int total, int g, int H2, int W2);
+  void ccl_launch(const float* d_heat, int p0, int pages, int total, int g, int H2, int W2, int lane = 0);
   // boxes of pages [p0, p0 + pages): waits for the group's counters, pulls candidates + row extremes over on the copy stream
   // (the main stream may already be running the next group's CRAFT), then the host calipers
   void ccl_collect(int p0, int pages, int g, int H2, int W2, std::vector<std::vector<RRect>>& det);

@@ -195,8 +195,8 @@ void Engine::craft_forward_split(const uint8_t* d_canvas, int B, int H, int W, f
   const int npl = tn.craft_products == 4 ? 3 : 2;                                       // planes per value
   const int layout = npl * 2 + (tn.head_packed && npl == 2 ? 1 : 0);   // (plane count and the head tensors' row form: both move the zero padding channels)
   if (layout != craft_ws_npl) {   // another plane count: the zero padding channels of the head tensors sit elsewhere - start from fresh buffers
-    TTR_HIP_CHECK(hipStreamSynchronize(stream));
-    craft_ws.clear();
+    TTR_HIP_CHECK(hipStreamSynchronize(stream)); TTR_HIP_CHECK(hipStreamSynchronize(lane_stream));
+    craft_ws_set[0].clear(); craft_ws_set[1].clear();
     craft_ws_npl = layout;
   }
   auto pbuf = [&](size_t rows, int C) -> void* { return ws(k++, rows * C * 2 * npl).p; };   // planes
@@ -215,6 +215,7 @@ void Engine::craft_forward_split(const uint8_t* d_canvas, int B, int H, int W, f
   void* c32 = pbuf(M2, 256); void* c32r = pbuf(M2, 256);
   sconv("slice2.17", c31, 256, nullptr, 0, B, H2, W2, c32, kActNone, c32r);                               // relu3_2 skip + its ReLU
   void* p3 = pbuf(M3, 256);  sconv("slice3.20", c32r, 256, nullptr, 0, B, H2, W2, nullptr, kActRelu, nullptr, p3, 0);
+  if (lane_go_pending) { prof_break(); TTR_HIP_CHECK(hipEventRecord(lane_go, stream)); lane_go_pending = false; }   // (half a group in: the second lane may start)
   void* c41 = pbuf(M3, 512); sconv("slice3.24", p3, 256, nullptr, 0, B, H3, W3, c41, kActRelu);
   void* c42 = pbuf(M3, 512); void* c42r = pbuf(M3, 512);
   sconv("slice3.27", c41, 512, nullptr, 0, B, H3, W3, c42, kActNone, c42r);                               // relu4_3 skip + its ReLU

@@ -16,11 +16,11 @@ void Engine::allgather_host(const void* mine, size_t bytes, void* all) {
   if (bytes && all) memcpy(all, c.h_out.p, bytes * c.world);
 }
 
-void Engine::ccl_launch(const float* d_heat, int p0, int pages, int total, int g, int H2, int W2) {
+void Engine::ccl_launch(const float* d_heat, int p0, int pages, int total, int g, int H2, int W2, int lane) {
   if (p0 == 0) { ccl.ensure(total, H2 * W2, cfg.max_components); h_counters.ensure((size_t)total * 8); }
-  launch_ccl(d_heat, pages, H2, W2, cfg.text_threshold, cfg.link_threshold, cfg.low_text, cfg.min_area, ccl.view(p0), stream);
   ccl.cal_cap_now = tn.gpu_calipers == 2 ? 512 : CclBatch::kCalCap;
-  if (tn.gpu_calipers) launch_ccl_rects(ccl.view(p0), pages, H2, W2, stream);   // minAreaRect of every candidate, on the stream right behind its row extremes
+  launch_ccl(d_heat, pages, H2, W2, cfg.text_threshold, cfg.link_threshold, cfg.low_text, cfg.min_area, ccl.view(p0, lane), stream);
+  if (tn.gpu_calipers) launch_ccl_rects(ccl.view(p0, lane), pages, H2, W2, stream);   // minAreaRect of every candidate, on the stream right behind its row extremes
   TTR_HIP_CHECK(hipMemcpyAsync(h_counters.as<int>() + 2 * p0, ccl.counters.as<int>() + 2 * p0, (size_t)pages * 8, hipMemcpyDeviceToHost, stream));
   while ((int)group_ev.size() <= g) { hipEvent_t e; TTR_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); group_ev.push_back(e); }
   TTR_HIP_CHECK(hipEventRecord(group_ev[g], stream));
@@ -123,12 +123,36 @@ void Engine::detect_enqueue(PageBatch& B) {
   }
   B.group = GP;
   const int groups = (n + GP - 1) / GP;
+  // Two detector lanes (tn.craft_lanes, engine.h): odd groups on lane_stream with their own workspaces, half a group behind the even ones, so that a lane's
+  // matrix-bound full-resolution layers run beside the other lane's HBM-bound U-Net tail and head (a group alone: 9.7 ms of the one, 2.8 of the other)
+  const bool two = prec == kSplit && tn.craft_lanes == 2 && groups >= 2;
+  if (two) {
+    TTR_HIP_CHECK(hipEventRecord(resize_done, stream));
+    TTR_HIP_CHECK(hipStreamWaitEvent(lane_stream, resize_done, 0));     // (the canvas; and everything the main stream held before it: the previous batch's detector)
+    lane_go_pending = true;
+  }
+  struct LaneGuard {   // the odd groups borrow the engine's `stream` and workspace selector; restored also when a launch throws
+    Engine& E; bool on = false;
+    void enter() { E.prof_break(); std::swap(E.stream, E.lane_stream); E.ws_sel = 1; on = true; }
+    void leave() { if (on) { E.prof_break(); std::swap(E.stream, E.lane_stream); E.ws_sel = 0; on = false; } }
+    ~LaneGuard() { if (on) { std::swap(E.stream, E.lane_stream); E.ws_sel = 0; } E.lane_go_pending = false; }
+  } lane_guard{*this};
   for (int gi = 0; gi < groups; ++gi) {
     const int p0 = gi * GP, cnt = std::min(GP, n - p0);
+    const int lane = two ? (gi & 1) : 0;
+    if (lane) {
+      lane_guard.enter();
+      if (gi == 1) TTR_HIP_CHECK(hipStreamWaitEvent(stream, lane_go, 0));   // (recorded inside group 0's forward pass, behind slice3.20)
+    }
     craft_forward(canvas.as<uint8_t>() + (size_t)p0 * H * W * 3, cnt, H, W, heat.as<float>() + (size_t)p0 * H2 * W2 * 2);
     if (gi == groups - 1) TTR_HIP_CHECK(hipEventRecord(ev[1], stream));
-    ccl_launch(heat.as<float>() + (size_t)p0 * H2 * W2 * 2, p0, cnt, n, gi, H2, W2);
+    ccl_launch(heat.as<float>() + (size_t)p0 * H2 * W2 * 2, p0, cnt, n, gi, H2, W2, lane);
+    if (lane) {
+      if (gi + 2 >= groups) TTR_HIP_CHECK(hipEventRecord(lane_done, stream));   // this lane's last group
+      lane_guard.leave();
+    }
   }
+  if (two) TTR_HIP_CHECK(hipStreamWaitEvent(stream, lane_done, 0));       // the batch's detector is complete when the main stream gets here
   TTR_HIP_CHECK(hipEventRecord(ev[2], stream));
 }
 
