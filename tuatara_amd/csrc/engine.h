@@ -105,7 +105,8 @@ struct Tuning {
   int sp_hidden16 = 0;        // split engines, encoder MLP: the hidden activation (fc1 -> fc2, 1 GB per layer at 1280 crops) as 16-row pieces in the producing epilogue's lane
                               // order - a store instruction writes one contiguous KiB (gemm_sp.hip, x_tiled / out_tiled = 2); 2 = and those stores stream (nt) past the
                               // weights and activation rows the tiles re-read from L2; 0 = the loader's 8-row pieces
-  int craft_lanes = 2;        // split engines, batches of >= 2 CRAFT launch groups: the groups on two staggered streams (Engine::lane_stream); 1 = one after the other
+  int craft_lanes = 1;        // split engines, batches of >= 2 CRAFT launch groups: 2 = the groups on two staggered streams (Engine::lane_stream) - measured: no gain
+                              // (403.0 / 403.3 against 403.7 / 404.3 pages/s: both lanes want the matrix pipe and the power budget); 1 = one after the other
   int recog_overlap = 1;      // streamed batches: the recogniser of batch j - 1 on a stream of its own, beside the detector of batch j (they share no buffer): the
                               // HBM-bound kernels and tile tails of one run under the other's matrix work.  Per-kernel times then include the neighbour's share of the chip
   int images_batch = 32;      // ttr_images_to_data: pages per streamed batch (same-sized images travel together)
