@@ -470,7 +470,7 @@ def main():
         fam_alg, fam_exec = sum(k["alg_flops"] for k in craft_kinds), sum(k["exec_flops"] for k in craft_kinds)
         # HBM bytes per launch of the dominant kernel: the two --pmc passes (FETCH_SIZE doubled, WRITE_SIZE) committed under profiles/
         traffic = traffic_src = fam_traffic = det_gb_page = None
-        for name in (("r04_pmc_craft_x4.json", "r03_pmc_craft_x4.json") if args.precision == "f16x4" else ("r02_pmc_craft_b16_v2.json",)):
+        for name in (("r05_pmc_craft_x4.json", "r04_pmc_craft_x4.json", "r03_pmc_craft_x4.json") if args.precision == "f16x4" else ("r02_pmc_craft_b16_v2.json",)):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     tj = json.load(f)
