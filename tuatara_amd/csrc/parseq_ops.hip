@@ -558,20 +558,21 @@ __global__ __launch_bounds__(384) void dec_cross_attn_crop_kernel(const float* _
   RangeWatch rw;   // (split.h)
   if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;
   constexpr int RMAX = 26;
-  __shared__ float sq[RMAX][384];
+  // (the queries per head: 26 x 32 floats instead of the crop's 26 x 384 - 49 KB of LDS per workgroup instead of 86, three workgroups per CU instead of one;
+  // the kernel is a chain of barriers, and at 1280 crops it ran at 0.9 TB/s of its 0.5 GB)
+  __shared__ float sq[RMAX][32];
   __shared__ float sk[128][33];          // (+1: lanes of a wave read 64 different rows at one d)
   __shared__ float sv[128][32];
   __shared__ float sp[RMAX][128];
   const int n = blockIdx.x, t = threadIdx.x;
-  for (int i = t; i < R * 96; i += 384) {
-    const int r = i / 96, c = i - r * 96;
-    const float4 v = *reinterpret_cast<const float4*>(q + ((int64_t)n * R + r) * 384 + c * 4);
-    sq[r][c * 4] = v.x; sq[r][c * 4 + 1] = v.y; sq[r][c * 4 + 2] = v.z; sq[r][c * 4 + 3] = v.w;
-  }
   const float* kvn = kvmem + (int64_t)n * 128 * 768;
   const int hper = 12 / (int)gridDim.y, h0 = (int)blockIdx.y * hper;
   for (int h = h0; h < h0 + hper; ++h) {
-    __syncthreads();                       // sq written (first head); the previous head's sk / sv / sp no longer read
+    __syncthreads();                       // the previous head's sq / sk / sv / sp no longer read
+    for (int i = t; i < R * 8; i += 384) {
+      const int r = i >> 3, c = i & 7;
+      *reinterpret_cast<float4*>(&sq[r][c * 4]) = *reinterpret_cast<const float4*>(q + ((int64_t)n * R + r) * 384 + h * 32 + c * 4);
+    }
     for (int i = t; i < 128 * 8; i += 384) {
       const int j = i >> 3, c = i & 7;
       const float4 kk = *reinterpret_cast<const float4*>(kvn + j * 768 + h * 32 + c * 4);
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(384) void dec_cross_attn_crop_kernel(const float* _
       for (int r = rg; r < R; r += 3) {
         float sc = 0.f;
 #pragma unroll
-        for (int d = 0; d < 32; ++d) sc += sq[r][h * 32 + d] * kr[d];
+        for (int d = 0; d < 32; ++d) sc += sq[r][d] * kr[d];
         sp[r][j] = sc * 0.17677669529663687f;
       }
     }
