@@ -267,7 +267,13 @@ int ttr_dev_upload(void* dst, const void* src, size_t bytes) { return hipMemcpy(
 
 int ttr_dev_download(void* dst, const void* src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
 
-int ttr_dev_sync(ttr_engine* e) { return hipStreamSynchronize(e->e->stream) == hipSuccess ? 0 : -1; }
+int ttr_dev_sync(ttr_engine* e) {   // every stream the engine enqueues work on (the recogniser of a streamed batch and the second detector lane have their own)
+  if (!e) return -1;
+  bool ok = hipStreamSynchronize(e->e->stream) == hipSuccess;
+  ok = (hipStreamSynchronize(e->e->recog_stream) == hipSuccess) && ok;
+  ok = (hipStreamSynchronize(e->e->lane_stream) == hipSuccess) && ok;
+  return ok ? 0 : -1;
+}
 
 int ttr_set_profiling(ttr_engine* e, int on) {
   TTR_GUARD_BEGIN

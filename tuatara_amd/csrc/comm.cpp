@@ -306,7 +306,7 @@ void ttr_comm_destroy(ttr_comm* c) {
       Engine& E = *c->c->E;
       EngineScope lk(E);
       if (E.comm == c->c.get()) E.comm = nullptr;
-      (void)hipStreamSynchronize(E.stream); (void)hipStreamSynchronize(E.copy_stream);
+      (void)hipStreamSynchronize(E.stream); (void)hipStreamSynchronize(E.recog_stream); (void)hipStreamSynchronize(E.copy_stream);
       c->c.reset();
     }
   } catch (...) {}

@@ -407,6 +407,7 @@ Engine::Engine(const std::string& dir, const ttr_config& c) : cfg(c) {
 
 Engine::~Engine() {
   (void)hipSetDevice(cfg.device);
+  for (hipStream_t st : {stream, recog_stream, lane_stream, copy_stream, up_stream}) if (st) (void)hipStreamSynchronize(st);   // nothing in flight when the buffers go
   for (auto& x : ev) if (x) (void)hipEventDestroy(x);
   for (auto& x : prof_pool) (void)hipEventDestroy(x);
   for (auto& x : group_ev) (void)hipEventDestroy(x);
