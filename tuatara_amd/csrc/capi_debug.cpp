@@ -285,6 +285,7 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "gsp_few") set_gemm_sp_few(value);
   else if (k == "gsp_epi") set_gemm_sp_epi(value);
   else if (k == "gsp_ks3") set_gemm_sp_ks3(value);
+  else if (k == "qkv_attn_dbg") set_qkv_attn_dbg(value);
   else if (k == "skx_ln_max_rows") set_gemm_skx_ln_max_rows(value);
   else if (k == "c3_xs1_max_cin") set_conv3p_single_stage_max_cin(value);
   else if (k == "c3_force_bn128") set_conv3p_force_bn128(value);

@@ -433,6 +433,16 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
       continue;
     }
     if constexpr (EPI == 1) {
+      if (p.dbg_flags & 4) {   // timing experiment (results are wrong): the K loop alone - no attention, one predicated store keeps the accumulators alive
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < C::NJ; ++j)
+#pragma unroll
+          for (int i = 0; i < C::MI; ++i) sum += acc[j][i][0] + acc[j][i][1] + acc[j][i][2] + acc[j][i][3];
+        if (sum == 1.2345e30f) reinterpret_cast<float*>(p.out)[0] = sum;
+        if (!has_next) break;
+        continue;
+      }
       // ---- attention epilogue (timm Attention.forward inside the TorchScript module run at tuatara.cpp:307; attn_split.hip is the stand-alone
       // form): the tile is Q | K | V [128 rows][64] of one (crop, head), its 192 channels ordered so that BOTH waves of a row block hold the
       // same kinds: tile channel 96 wn + 32 t + dd is Q (t = 0), K (t = 1) or V (t = 2), d = 32 wn + dd.  A lane holds, of row 32 wm + 16 i + q,
@@ -764,6 +774,8 @@ static void launch_sp(const ConvParams& p_in, hipStream_t s) {
   hipLaunchKernelGGL((gemm_sp_kernel<BM, BN, WM, WN, XST, WST, MINB, SCHED, NP, EPI, EM, KS3>), dim3(grid), dim3(C::NT), lds, s, p);
 }
 
+static int g_qkv_attn_dbg = 0;   // timing experiments on the fused qkv + attention launch (results are wrong): 4 = the K loop alone
+void set_qkv_attn_dbg(int v) { g_qkv_attn_dbg = v; }
 static int g_sp_few = 1;   // the few-tile rules of launch_gemm_sp (a page's worth of rows)
 void set_gemm_sp_few(int v) { g_sp_few = v; }
 static int g_sp_epi = 3;     // bits: 1 = fc1's case on its own kernels (EM = 1), 2 = the residual linears' (EM = 2) on the 256 x 128 triples tile (proj), 8 = on the other 128- / 256-row tiles, 4 = on the 64-row tiles; 0: the general kernel everywhere
@@ -852,6 +864,7 @@ void launch_qkv_attn_split(const void* x_pairs, const void* w_planes, const floa
   p.wgt = w_planes; p.wgt_tiled = w_tiled; p.bias = bias; p.split = 3; p.out_scale = inv_scale; p.out_planes = 3;
   p.x_tiled = x_tiled; p.out_tiled = out_tiled;
   p.out = out_planes; p.out_ld = 384; p.Cout = 1152; p.M = N * 128; p.act = kActNone;
+  p.dbg_flags = g_qkv_attn_dbg;
   launch_sp<128, 192, 4, 2, 3, 2, 1, true, 3, 1>(p, s);
 }
 

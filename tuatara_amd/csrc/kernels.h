@@ -37,6 +37,7 @@ void set_gemm_sp_sched(int v);
 void set_gemm_sp_few(int v);
 void set_gemm_sp_epi(int v);
 void set_gemm_sp_ks3(int v);
+void set_qkv_attn_dbg(int v);
 bool gemm_sp_ks3_eligible(const ConvParams& p);
 void launch_gemm_sp_ks3(const ConvParams& p, int cfg, hipStream_t s);
 void set_gemm_skx_ln_max_rows(int v);
