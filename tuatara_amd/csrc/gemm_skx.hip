@@ -119,51 +119,97 @@ __global__ __launch_bounds__(256) void gemm_skx_kernel(ConvParams p) {
     constexpr int D = 384;
     const bool act = lane < 48;
     const int c = (act ? lane : 0) * 8;
-#pragma unroll 1
-    for (int rr = 0; rr < 4; ++rr) {
-      const int rl = wave + 4 * rr, m = m0 + rl;
-      f16x8 o0 = {0, 0, 0, 0, 0, 0, 0, 0}, o1 = o0, o2 = o0;
-      if (m < p.M) {                                                        // (wave-uniform)
-        float v[8];
-        if (p.tok) {
-          // an AR step's content row (ConvParams::tok*, as gemm_sk.hip's token prologue; dec_embed_ln_planes_kernel is the stand-alone form): the row to
-          // normalise is emb[token] (+ the position query), token = tok[m][tok_col] or - tok_logits - the first maximal index of the previous step's
-          // logits row, which the first column tile also writes back and counts (first EOS of the crop: done_count).  embed + LayerNorm + self_kv: one launch.
-          int token;
-          if (p.tok_logits) {
-            const float* lg = p.tok_logits + (int64_t)m * p.tok_logits_ld;
-            float best = -INFINITY; int bi = 0x7fffffff;
-            for (int cc = lane; cc < p.tok_C; cc += 64) { const float t = lg[cc]; if (t > best) { best = t; bi = cc; } }
+    // The wave's four rows TOGETHER, stage by stage - every row's chain is two or three dependent memory round trips (its logits or token, the embedding row,
+    // then the arithmetic): one row after the other that was up to twelve round trips in front of the first MFMA, the bulk of this launch's ~11 us at a page's
+    // 40 rows.  Same operations per row in the same order: the planes are bit-identical to the row-by-row form (tests).
+    int mrow[4]; bool live[4];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-              const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
-              if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-            }
-            token = bi;
-            if (blockIdx.x == 0 && lane == 0) {
-              p.tok[m * p.tok_ld + p.tok_col] = bi;
-              if (p.done_count && bi == p.tok_eos) {
-                bool first = true;
-                for (int cc = 1; cc < p.tok_col; ++cc) first = first && p.tok[m * p.tok_ld + cc] != p.tok_eos;
-                if (first) atomicAdd(p.done_count, 1);
-              }
-            }
-          } else token = p.tok[m * p.tok_ld + p.tok_col];
-          token = token < 0 ? 0 : (token > p.tok_max ? p.tok_max : token);
-          const float* x = p.tok_emb + (int64_t)token * D + c;
-          const float4 a = *reinterpret_cast<const float4*>(x), b = *reinterpret_cast<const float4*>(x + 4);
-          v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-          if (p.tok_pos) {
-            const float4 pa = *reinterpret_cast<const float4*>(p.tok_pos + c), pb = *reinterpret_cast<const float4*>(p.tok_pos + c + 4);
-            v[0] = pa.x + v[0]; v[1] = pa.y + v[1]; v[2] = pa.z + v[2]; v[3] = pa.w + v[3]; v[4] = pb.x + v[4]; v[5] = pb.y + v[5]; v[6] = pb.z + v[6]; v[7] = pb.w + v[7];
+    for (int rr = 0; rr < 4; ++rr) { mrow[rr] = m0 + wave + 4 * rr; live[rr] = mrow[rr] < p.M; }              // (wave-uniform)
+    float v[4][8];
+    if (p.tok) {
+      // an AR step's content rows (ConvParams::tok*, as gemm_sk.hip's token prologue; dec_embed_ln_planes_kernel is the stand-alone form): the row to
+      // normalise is emb[token] (+ the position query), token = tok[m][tok_col] or - tok_logits - the first maximal index of the previous step's
+      // logits row, which the first column tile also writes back and counts (first EOS of the crop: done_count).  embed + LayerNorm + self_kv: one launch.
+      int token[4] = {0, 0, 0, 0};
+      if (p.tok_logits) {
+        float best[4]; int bi[4];
+        if (p.tok_C <= 128) {                                                // (PARSeq: 95 classes) two values per lane, the four rows' loads in flight together
+          float t0[4], t1[4];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const float* lg = p.tok_logits + (int64_t)(live[rr] ? mrow[rr] : m0) * p.tok_logits_ld;
+            t0[rr] = lane < p.tok_C ? lg[lane] : -INFINITY;
+            t1[rr] = lane + 64 < p.tok_C ? lg[lane + 64] : -INFINITY;
+          }
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {                                   // (the loop's order: cc = lane, then lane + 64; strict > keeps the first maximum)
+            best[rr] = -INFINITY; bi[rr] = 0x7fffffff;
+            if (lane < p.tok_C && t0[rr] > best[rr]) { best[rr] = t0[rr]; bi[rr] = lane; }
+            if (lane + 64 < p.tok_C && t1[rr] > best[rr]) { best[rr] = t1[rr]; bi[rr] = lane + 64; }
           }
         } else {
-          const float* x = p.ln_in + (int64_t)m * p.ln_ld + c;
-          const float4 a = *reinterpret_cast<const float4*>(x), b = *reinterpret_cast<const float4*>(x + 4);
-          v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const float* lg = p.tok_logits + (int64_t)(live[rr] ? mrow[rr] : m0) * p.tok_logits_ld;
+            best[rr] = -INFINITY; bi[rr] = 0x7fffffff;
+            for (int cc = lane; cc < p.tok_C; cc += 64) { const float t = lg[cc]; if (t > best[rr]) { best[rr] = t; bi[rr] = cc; } }
+          }
         }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best[rr], o); const int oi = __shfl_xor(bi[rr], o);
+            if (ov > best[rr] || (ov == best[rr] && oi < bi[rr])) { best[rr] = ov; bi[rr] = oi; }
+          }
+          token[rr] = bi[rr];
+        }
+        if (blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            if (!live[rr]) continue;
+            const int m = mrow[rr];
+            p.tok[m * p.tok_ld + p.tok_col] = bi[rr];
+            if (p.done_count && bi[rr] == p.tok_eos) {
+              bool first = true;
+              for (int cc = 1; cc < p.tok_col; ++cc) first = first && p.tok[m * p.tok_ld + cc] != p.tok_eos;
+              if (first) atomicAdd(p.done_count, 1);
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) token[rr] = live[rr] ? p.tok[mrow[rr] * p.tok_ld + p.tok_col] : 0;
+      }
+      float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
+      if (p.tok_pos) { pa = *reinterpret_cast<const float4*>(p.tok_pos + c); pb = *reinterpret_cast<const float4*>(p.tok_pos + c + 4); }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        int tk = token[rr];
+        tk = tk < 0 ? 0 : (tk > p.tok_max ? p.tok_max : tk);
+        const float* x = p.tok_emb + (int64_t)tk * D + c;
+        const float4 a = *reinterpret_cast<const float4*>(x), b = *reinterpret_cast<const float4*>(x + 4);
+        v[rr][0] = a.x; v[rr][1] = a.y; v[rr][2] = a.z; v[rr][3] = a.w; v[rr][4] = b.x; v[rr][5] = b.y; v[rr][6] = b.z; v[rr][7] = b.w;
+        if (p.tok_pos) {
+          v[rr][0] = pa.x + v[rr][0]; v[rr][1] = pa.y + v[rr][1]; v[rr][2] = pa.z + v[rr][2]; v[rr][3] = pa.w + v[rr][3];
+          v[rr][4] = pb.x + v[rr][4]; v[rr][5] = pb.y + v[rr][5]; v[rr][6] = pb.z + v[rr][6]; v[rr][7] = pb.w + v[rr][7];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const float* x = p.ln_in + (int64_t)(live[rr] ? mrow[rr] : m0) * p.ln_ld + c;
+        const float4 a = *reinterpret_cast<const float4*>(x), b = *reinterpret_cast<const float4*>(x + 4);
+        v[rr][0] = a.x; v[rr][1] = a.y; v[rr][2] = a.z; v[rr][3] = a.w; v[rr][4] = b.x; v[rr][5] = b.y; v[rr][6] = b.z; v[rr][7] = b.w;
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int rl = wave + 4 * rr;
+      f16x8 o0 = {0, 0, 0, 0, 0, 0, 0, 0}, o1 = o0, o2 = o0;
+      if (live[rr]) {                                                       // (wave-uniform)
         float y[8];
-        ln384_row8(v, act, p.ln_gamma + c, p.ln_beta + c, p.ln_eps, y);
+        ln384_row8(v[rr], act, p.ln_gamma + c, p.ln_beta + c, p.ln_eps, y);
         split3_x8(y, o0, o1, o2, rw);
       }
       if (act) {
