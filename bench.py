@@ -4,7 +4,7 @@
 
   python bench.py --gpus N --steps K --warmup W
 
-A *step* is `--reps` passes of the hot path (resize/pad -> CRAFT -> union-find CCL -> calipers ->
+A *step* is `--reps` (1) passes of the hot path (resize/pad -> CRAFT -> union-find CCL -> calipers ->
 crop-batch packer -> PARSeq -> token ids), each over one batch of `--pages` synthetic pages per GPU,
 inputs already resident in HBM.  Page-level data parallelism: each rank owns its pages and a
 full weights replica (weak scaling); for N > 1 the decoded token ids of every rank are
@@ -241,8 +241,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pages", type=int, default=32, help="pages per GPU per pass (PARSeq runs over all crops of a pass)")
-    ap.add_argument("--reps", type=int, default=2, help="passes of --pages pages per step (a step carries >= 250 ms of GPU work)")
+    ap.add_argument("--pages", type=int, default=64, help="pages per GPU per pass (PARSeq runs over all crops of a pass, in even groups of <= 1820 crops); 64 per pass "
+                    "instead of round 4's 32: +1.3-1.5 %% pages/s on the same box (half as many hand-overs between the host and the two streams)")
+    ap.add_argument("--reps", type=int, default=1, help="passes of --pages pages per step (a step carries >= 150 ms of GPU work)")
     ap.add_argument("--words", type=int, default=40, help="words drawn per synthetic page (SURVEY.md section 8d: ~40 random words)")
     ap.add_argument("--boxes", default="grid40", choices=["grid40", "detected"], help="grid40 (SURVEY.md section 8d): CRAFT + CCL + box extraction run in full (timed), then every page's "
                     "boxes are replaced by a fixed 5 x 8 grid of 150 x 40 px boxes so that PARSeq sees exactly 40 crops per page; detected: the synthetic detector's own boxes")

@@ -153,6 +153,7 @@ void Engine::parseq_forward(const uint8_t* d_crops, int N, float* d_logits, floa
     // stream x is fp32.  Crop groups keep the widest planes tensor (the MLP hidden: 1536 x 6 bytes per row) inside the 2 GiB window.
     int CHS = std::max(1, std::min(N, (int)((((size_t)1 << 31) - 1) / ((size_t)128 * 1536 * 6))));
     if (tn.enc_chunk > 0) CHS = std::min(CHS, tn.enc_chunk);   // (experiment knob: crop groups whose residual stream and LayerNorm planes stay in the Infinity Cache)
+    if (N > CHS) { const int groups = (N + CHS - 1) / CHS; CHS = (N + groups - 1) / groups; }   // even groups: 2560 crops = 1280 + 1280, not 1820 + 740
     void* lnp = (pq_ws[11].ensure((size_t)M * E * 6), pq_ws[11].p);                       // LayerNorm output planes (whole batch: the memory at the end)
     void* bigp = (pq_ws[12].ensure((size_t)std::min(N, CHS) * 128 * 1536 * 6), pq_ws[12].p);   // qkv / MLP hidden planes
     void* attp = (pq_ws[13].ensure((size_t)std::min(N, CHS) * 128 * E * 6), pq_ws[13].p);      // attention output planes
