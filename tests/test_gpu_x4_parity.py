@@ -210,6 +210,22 @@ def test_x4_refinement_cross_attention_per_crop_matches_per_row(eng_x4):
     assert d[mask].max() < 1e-3 and np.array_equal(ida.reshape(-1, 26)[mask], idb.reshape(-1, 26)[mask])
 
 
+def test_x4_parseq_very_large_crop_batch_runs_in_even_groups(eng_x4):
+    """9100 crops in one call (64 pages of ~140 boxes): beyond 8962 crops the refinement pass's widest planes tensor would leave the 2 GiB window of the
+    kernels' 32-bit buffer offsets - the engine takes such a batch in even groups of <= 4096 crops (here 3 x 3034 / 3034 / 3032).  Crops are independent: the
+    result is bit for bit what the groups give as calls of their own."""
+    rng = np.random.default_rng(41)
+    base = rng.integers(0, 256, (700, 32, 128, 3), dtype=np.uint8)
+    crops = np.concatenate([base] * 13)                               # 9100 crops, 112 MB
+    crops[:, 0, 0, 0] = (np.arange(len(crops)) % 251).astype(np.uint8)   # every crop differs
+    got, ids = eng_x4.parseq_logits(crops)
+    assert np.isfinite(got).all()
+    per = (len(crops) + 2) // 3
+    for g0 in range(0, len(crops), per):
+        part, pid = eng_x4.parseq_logits(crops[g0:g0 + per])
+        assert np.array_equal(part, got[g0:g0 + per]) and np.array_equal(np.asarray(pid).reshape(-1, 26), np.asarray(ids).reshape(-1, 26)[g0:g0 + per]), g0
+
+
 def test_x4_parseq_batch_invariance(eng_x4):
     crops = np.random.default_rng(3).integers(0, 256, (9, 32, 128, 3), dtype=np.uint8)
     a, _ = eng_x4.parseq_logits(crops)

@@ -136,6 +136,18 @@ void Engine::decoder_tail(const void* sa, int N, int R, const float* resid_pos, 
 
 void Engine::parseq_forward(const uint8_t* d_crops, int N, float* d_logits, float* d_ar, int* d_ids) {
   if (N <= 0) return;
+  // A very large crop batch (64 pages of ~150 boxes) goes through in even groups: the refinement pass's widest planes tensor (26 rows per crop x 1536 x 6 bytes)
+  // must stay inside the 2 GiB window of 32-bit buffer offsets (8962 crops), and the workspaces stay bounded.  Crops are independent (batch-invariant logits,
+  // tests): grouping changes nothing but the kernels' shapes; the AR loop's early exit then applies per group.
+  constexpr int kMaxCrops = 4096;
+  if (N > kMaxCrops) {
+    const int groups = (N + kMaxCrops - 1) / kMaxCrops, per = (N + groups - 1) / groups;
+    for (int g0 = 0; g0 < N; g0 += per) {
+      const int n = std::min(per, N - g0);
+      parseq_forward(d_crops + (size_t)g0 * 32 * 128 * 3, n, d_logits + (size_t)g0 * 26 * 95, d_ar ? d_ar + (size_t)g0 * 26 * 95 : nullptr, d_ids + (size_t)g0 * 26);
+    }
+    return;
+  }
   prof_stage = 1;
   const int M = N * 128, E = 384;
   const int patch_ld = pq.at("patch").k;   // 96, or 128 in bf16 mode (zero-padded)
