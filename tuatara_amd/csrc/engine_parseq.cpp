@@ -186,9 +186,9 @@ void Engine::parseq_forward(const uint8_t* d_crops, int N, float* d_logits, floa
         if (tn.qkv_attn_split && lnpl == 2) {   // one launch: the attention of a (crop, head) is the epilogue of its 128 x 192 qkv tile
           const Linear& L = pq.at(p + "qkv_hm");
           range_tag("parseq." + p + "attn (qkv + attention)");
-          // executed flops: qkv on pairs (x 3), Q K^T and P V on a triple and a pair (x 4)
+          // executed flops: qkv on pairs (x 3), Q K^T on a triple and a pair (x 4), P V on pairs (x 3)
           const double qa = 2.0 * Mc * 3 * E * E, aa = 2.0 * 2 * nc * 6 * 128.0 * 128 * 64;
-          timed("enc.qkv+attention: gemm_sp_kernel<128,192,NP=3,EPI=1>", qa + aa, qa * 3 + aa * 4,
+          timed("enc.qkv+attention: gemm_sp_kernel<128,192,NP=3,EPI=1>", qa + aa, qa * 3 + aa * 3.5,
                 [&] { launch_qkv_attn_split(lnp_at(c0), L.ws.p, L.b.as<float>(), L.inv_scale, attp, nc, stream, tn.sp_tiled_w ? L.wst.p : nullptr, xt, xt); });
         } else {
         sgemm(pq.at(p + "qkv"), lnp_at(c0), Mc, bigp, 3 * E, kActNone, 1, nullptr, 0, nullptr, 0, lnpl + 1, 0, tn.qkv_kv_pairs ? E : 0, "enc.qkv");   // (K, V: read as pairs)

@@ -530,7 +530,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
         }
       }
       // softmax over the 128 keys of a query: 32 values here, the rest in lanes q + 16 g'
-      f16x8 fp[3][4];                                             // [plane][32-key step]: keys 32 s + 8 g + e
+      // (the probabilities as PAIRS: p in [0, 1] on 22+ bits is fp32's own resolution of it - three MFMAs per product in P V and a split of half the
+      // instructions; the queries stay exact triples: a score's error is |q||k| times the operand's, and it goes through an exponential)
+      f16x8 fp[2][4];                                             // [plane][32-key step]: keys 32 s + 8 g + e
       float rinv;
       {
         float mx = -INFINITY;
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
             ev[e] = __expf((sacc[2 * s4 + (e >> 2)][e & 3] - mx) * 0.125f);
             sum += ev[e];
           }
-          split3_x8(ev, fp[0][s4], fp[1][s4], fp[2][s4], rp);
+          split2_x8(ev, fp[0][s4], fp[1][s4], rp);
         }
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
@@ -595,7 +597,6 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
             f32x4 a = oacc[dt];                                                                                \
             a = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0, fp[0][s], a, 0, 0, 0);                              \
             a = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0b, fp[1][s], a, 0, 0, 0);                             \
-            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0b, fp[2][s], a, 0, 0, 0);                             \
             oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1, fp[0][s], a, 0, 0, 0);                       \
           }                                                                                                    \
         }
