@@ -305,6 +305,7 @@ int ttr_set_tuning(const char* key, int value) {
     set_gemm_ws_stamps(value == 2 ? g_dec_dbg : nullptr);
     set_conv3p_stamps(value == 4 ? g_dec_dbg : nullptr);    // 4: ... or conv3p_first2 stamps
     set_mlp_stamps(value == 3 ? g_dec_dbg : nullptr);
+    set_qkv_attn_stamps(value == 5 ? g_dec_dbg : nullptr);   // 5: ... or the fused qkv + attention launch's
     // 3: ... or mlp_fused stamps   // 2: the same buffer takes gemm_ws stamps instead
   }
   else return -1;

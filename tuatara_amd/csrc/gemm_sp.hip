@@ -308,7 +308,10 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
   asm volatile("" ::: "memory");
   read_x(fx0); read_w(fw0);
 
+  int stamp_tile = 0;   // (diagnostics: phase stamps of workgroup 0, wave 0 over its first 24 tiles, ConvParams::dbg)
+#define TTR_SP_STAMP(ph) do { if (EPI == 1 && p.dbg && blockIdx.x == 0 && tid == 0 && stamp_tile < 24) p.dbg[stamp_tile * 16 + (ph)] = __builtin_readcyclecounter(); } while (0)
   while (true) {
+    TTR_SP_STAMP(0);
     f32x4 acc[C::NJ][C::MI];
 #pragma unroll
     for (int j = 0; j < C::NJ; ++j)
@@ -416,6 +419,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
     }
     }
     __builtin_amdgcn_sched_barrier(0);
+    TTR_SP_STAMP(1);                        // K loop done
     idx += J;
     const bool has_next = idx < xcd_count;
     TTR_SP_NEXT_DELTAS(idx)                 // the streams are inside tile idx now (nk0 >= 3: they run at most two k0 ahead)
@@ -507,7 +511,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
         vp[1][i] = vp[1][i] * dnv;
       }
       rw.flush(p.range_flag, p.range_tag);   // (here, not behind the tile: the watch would cost a register across the attention; the output rows are convex combinations of the V rows just watched)
+      TTR_SP_STAMP(2);                      // Q / K / V converted, Q and K written
       __syncthreads();
+      TTR_SP_STAMP(3);
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) fq[1][pl] = *reinterpret_cast<const f16x8*>(sQ + qrd + pl * 1024);
       // S^T = K Q^T: sacc[kt], lane = query q, LDS key rows 16 kt + 4 g + r = keys 32 (kt >> 1) + 8 g + 4 (kt & 1) + r
@@ -529,6 +535,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
           sacc[kt] = a;
         }
       }
+      TTR_SP_STAMP(4);                      // S = Q K^T done
       // softmax over the 128 keys of a query: 32 values here, the rest in lanes q + 16 g'
       // (the probabilities as PAIRS: p in [0, 1] on 22+ bits is fp32's own resolution of it - three MFMAs per product in P V and a split of half the
       // instructions; the queries stay exact triples: a score's error is |q||k| times the operand's, and it goes through an exponential)
@@ -558,7 +565,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
         sum += __shfl_xor(sum, 32);
         rinv = 1.0f / sum;
       }
+      TTR_SP_STAMP(5);                      // softmax + probability planes done
       __syncthreads();                                            // every wave has read K
+      TTR_SP_STAMP(6);
       // V: row = key, the 8 values d = 32 wn + 8 g + e go to column positions 32 wn + 4 g + e (e < 4) and 32 wn + 16 + 4 g + e - 4
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl)
@@ -570,6 +579,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
           *reinterpret_cast<f16x4*>(d + 32) = f16x4{v[4], v[5], v[6], v[7]};
         }
       __syncthreads();
+      TTR_SP_STAMP(7);                      // V written + barrier
       // O^T = V^T P^T: A = V^T fragment (16 column positions x 32 keys) by transposed reads of the row-major planes (attn_split.hip)
       f32x4 oacc[4];
 #pragma unroll
@@ -607,8 +617,10 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
 #undef TTR_SPA_STEP
 #undef TTR_SPA_TR
       }
+      TTR_SP_STAMP(8);                      // P V done
       // out planes [M][3][384]: oacc[2u], oacc[2u+1] hold d = 32 u + 8 g + 0..7 of query q
       __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0), in front of the first store: the prefetched tiles have landed (requested an epilogue ago)
+      TTR_SP_STAMP(9);
       {
         const int orow = m0c + wm * 32 + wn * 16 + fr, ohead = n0c / 192;
         // (out_tiled: the projection GEMM's loader pieces - a head's 64 channels are one 64-deep k step; planes 6 KiB apart instead of 384 halves)
@@ -627,6 +639,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
         }
       }
       __builtin_amdgcn_s_waitcnt(0x0F70);
+      TTR_SP_STAMP(10);                     // output planes stored and drained
+      ++stamp_tile;
       if (!has_next) break;
       // The next tile's first fragments were read in the last phase above, like every k0's; this epilogue needs their 64 registers, so they are
       // read AGAIN here (their ring slots are untouched: nothing was requested meanwhile) and the first copies die at the top of the epilogue.
@@ -758,6 +772,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
 }
 
 #undef TTR_SP_NEXT_DELTAS
+#undef TTR_SP_STAMP
 
 template <int BM, int BN, int WM, int WN, int XST, int WST, int MINB, bool SCHED, int NP = 3, int EPI = 0, int EM = 0, bool KS3 = false>
 static void launch_sp(const ConvParams& p_in, hipStream_t s) {
@@ -777,6 +792,8 @@ static void launch_sp(const ConvParams& p_in, hipStream_t s) {
 
 static int g_qkv_attn_dbg = 0;   // timing experiments on the fused qkv + attention launch (results are wrong): 4 = the K loop alone
 void set_qkv_attn_dbg(int v) { g_qkv_attn_dbg = v; }
+static unsigned long long* g_qkv_attn_stamps = nullptr;
+void set_qkv_attn_stamps(unsigned long long* d) { g_qkv_attn_stamps = d; }
 static int g_sp_few = 1;   // the few-tile rules of launch_gemm_sp (a page's worth of rows)
 void set_gemm_sp_few(int v) { g_sp_few = v; }
 static int g_sp_epi = 3;     // bits: 1 = fc1's case on its own kernels (EM = 1), 2 = the residual linears' (EM = 2) on the 256 x 128 triples tile (proj), 8 = on the other 128- / 256-row tiles, 4 = on the 64-row tiles; 0: the general kernel everywhere
@@ -865,7 +882,7 @@ void launch_qkv_attn_split(const void* x_pairs, const void* w_planes, const floa
   p.wgt = w_planes; p.wgt_tiled = w_tiled; p.bias = bias; p.split = 3; p.out_scale = inv_scale; p.out_planes = 3;
   p.x_tiled = x_tiled; p.out_tiled = out_tiled;
   p.out = out_planes; p.out_ld = 384; p.Cout = 1152; p.M = N * 128; p.act = kActNone;
-  p.dbg_flags = g_qkv_attn_dbg;
+  p.dbg_flags = g_qkv_attn_dbg; p.dbg = g_qkv_attn_stamps;
   launch_sp<128, 192, 4, 2, 3, 2, 1, true, 3, 1>(p, s);
 }
 

@@ -38,6 +38,7 @@ void set_gemm_sp_few(int v);
 void set_gemm_sp_epi(int v);
 void set_gemm_sp_ks3(int v);
 void set_qkv_attn_dbg(int v);
+void set_qkv_attn_stamps(unsigned long long* dev_buf);   // >= 24 * 16 u64, or null: phase stamps of the fused qkv + attention launch's workgroup 0
 bool gemm_sp_ks3_eligible(const ConvParams& p);
 void launch_gemm_sp_ks3(const ConvParams& p, int cfg, hipStream_t s);
 void set_gemm_skx_ln_max_rows(int v);
