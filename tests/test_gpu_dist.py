@@ -53,6 +53,9 @@ lat = comm.pages_to_data_sharded(one, 1, 1024, 768)                           # 
 plain = eng.image_to_data(small[0])
 assert len(plain) > 5 and [x["text"] for x in lat[0]] == [x["text"] for x in plain] and [x["bbox"] for x in lat[0]] == [x["bbox"] for x in plain]
 assert comm.allgather_host(np.arange(5, dtype=np.int32)).tolist() == [[0, 1, 2, 3, 4]]
+info = comm.describe_all()                                                     # what a scaling run prints: rank -> device / bus id / RCCL version
+assert len(info) == 1 and info[0]["rank"] == 0 and info[0]["world"] == 1 and info[0]["transport"] == "rccl" and info[0]["rccl_version"] > 20000, info
+assert info[0]["device"] == 0 and info[0]["pci_bus_id"] and info[0]["gpu"].startswith("gfx950") and info[0]["pid"] == os.getpid(), info
 comm.close()
 after = eng.image_to_data(small[0])
 assert [x["text"] for x in after] == [x["text"] for x in plain]
