@@ -67,23 +67,26 @@ def _rank_cfg(rank, world, port, q, delay, timeout_s):
 
 
 def test_rendezvous_tells_a_refused_rank_why():
-    """rank 0 (world 2) is joined by a rank started with world 3 and by two ranks numbered 1: the odd ones are told the reason before
-    their socket closes (they used to see a bare 'recv' failure), the good one gets the bytes."""
+    """rank 0 (world 2) is joined by a rank started with world 3, then by the real rank 1, then - the meeting over - by a second rank 1: the odd ones are told
+    the reason before their socket closes (they used to see a bare 'recv' failure) or find nobody listening, the good one gets the bytes.  The three joiners are
+    started one after the other's verdict, so the order does not depend on how fast a process comes up."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_cfg, args=(0, 2, port, q, 0.0, 60)),
-             ctx.Process(target=_rank_cfg, args=(1, 3, port, q, 1.0, 60)),          # wrong world size: turned away
-             ctx.Process(target=_rank_cfg, args=(1, 2, port, q, 3.0, 60)),          # the real rank 1
-             ctx.Process(target=_rank_cfg, args=(1, 2, port, q, 6.0, 5))]           # a duplicate after the meeting: nobody listens any more
-    for p in procs:
-        p.start()
-    got = [q.get(timeout=120) for _ in procs]
+    procs = [ctx.Process(target=_rank_cfg, args=(0, 2, port, q, 0.0, 120))]
+    procs[0].start()
+    got = []
+    procs.append(ctx.Process(target=_rank_cfg, args=(1, 3, port, q, 0.5, 60)))          # wrong world size: turned away while rank 0 keeps listening
+    procs[-1].start()
+    got.append(q.get(timeout=120))
+    assert got[0][:2] == (1, 3) and got[0][2] != 0 and "another world size" in got[0][3], got
+    procs.append(ctx.Process(target=_rank_cfg, args=(1, 2, port, q, 0.0, 60)))          # the real rank 1
+    procs[-1].start()
+    got += [q.get(timeout=120), q.get(timeout=120)]                                     # rank 0 and rank 1, in either order
+    assert sorted(g[:3] for g in got[1:]) == [(0, 2, 0), (1, 2, 0)], got
+    procs.append(ctx.Process(target=_rank_cfg, args=(1, 2, port, q, 0.0, 3)))           # a duplicate after the meeting: nobody listens any more
+    procs[-1].start()
+    late = q.get(timeout=120)
+    assert late[:2] == (1, 2) and late[2] != 0 and "rendezvous" in late[3], late
     for p in procs:
         p.join(timeout=30)
-    by = {}
-    for rank, world, rc, err in got:
-        by.setdefault((rank, world, rc == 0), []).append(err)
-    assert (0, 2, True) in by and (1, 2, True) in by, got
-    assert any("another world size" in e for e in by.get((1, 3, False), [])), got
-    assert len(by.get((1, 2, False), [])) == 1, got                                   # the late duplicate: connect fails, rank 0 has left
