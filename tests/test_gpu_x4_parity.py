@@ -192,22 +192,29 @@ def test_x4_ar_early_exit_is_invisible_in_the_refined_logits(eng_x4):
     assert steps_run < 26
 
 
-def test_x4_refinement_cross_attention_per_crop_matches_per_row(eng_x4):
-    """The refinement pass reads a crop's K / V once for its 26 query rows (dec_cross_attn_crop_kernel) instead of once per row.  Same sums in
-    the same order; the compiled code differs in the last bit here and there, which this network turns into ~1e-4 on a logit (the fp32 oracle
-    itself sits 8e-4 from an fp64 evaluation): the two agree like two fp32 evaluations, ids identical."""
-    crops = np.random.default_rng(11).integers(0, 256, (45, 32, 128, 3), dtype=np.uint8)
-    a, ida = eng_x4.parseq_logits(crops)
-    assert eng_x4.set_tuning(b"cross_crop", 0) == 0
-    try:
-        b, idb = eng_x4.parseq_logits(crops)
-    finally:
-        eng_x4.set_tuning(b"cross_crop", 1)
-    up = R.upto_eos(idb.reshape(-1, 26))
-    mask = np.arange(26)[None, :] < up[:, None]
-    d = np.abs(a - b).max(-1)
-    print(f"per-crop vs per-row cross-attention: max |dlogit| up to EOS {d[mask].max():.2e}")
-    assert d[mask].max() < 1e-3 and np.array_equal(ida.reshape(-1, 26)[mask], idb.reshape(-1, 26)[mask])
+def test_x4_refinement_cross_attention_three_kernels_agree(eng_x4):
+    """The refinement pass's cross-attention has three forms: on the matrix cores in split-operand arithmetic, one wave per crop and head
+    (attn_cross_split.hip, the default), one workgroup per crop on the vector ALU (dec_cross_attn_crop_kernel: a crop's K / V read once for its 26 rows)
+    and one workgroup per row.  The sums are the same, their order and the compiled code are not: this network turns a last-bit difference into ~1e-4 on a
+    logit (the fp32 oracle itself sits 8e-4 from an fp64 evaluation) - the three agree like fp32 evaluations, ids identical.  Sizes: a ragged 45 crops and
+    a single crop."""
+    for ncrop, seed in ((45, 11), (1, 12)):
+        crops = np.random.default_rng(seed).integers(0, 256, (ncrop, 32, 128, 3), dtype=np.uint8)
+        a, ida = eng_x4.parseq_logits(crops)
+        got = {}
+        for name, knob in (("per-crop", b"cross_split"), ("per-row", b"cross_crop")):
+            assert eng_x4.set_tuning(knob, 0) == 0
+            try:
+                got[name] = eng_x4.parseq_logits(crops)
+            finally:
+                eng_x4.set_tuning(knob, 1)
+        assert not np.array_equal(a, got["per-crop"][0]) or ncrop == 1      # (the knob did select another kernel)
+        for name, (b, idb) in got.items():
+            up = R.upto_eos(idb.reshape(-1, 26))
+            mask = np.arange(26)[None, :] < up[:, None]
+            d = np.abs(a - b).max(-1)
+            print(f"{ncrop} crops, matrix-core vs {name} cross-attention: max |dlogit| up to EOS {d[mask].max():.2e}")
+            assert d[mask].max() < 1e-3 and np.array_equal(ida.reshape(-1, 26)[mask], idb.reshape(-1, 26)[mask])
 
 
 def test_x4_parseq_very_large_crop_batch_runs_in_even_groups(eng_x4):

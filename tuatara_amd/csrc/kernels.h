@@ -62,6 +62,8 @@ void set_skinny_max_rows(int m);   // problems with M <= m rows go to gemm_sk (0
 void set_mlp_store_nt(int v);
 void set_mlp_stamps(unsigned long long* dev_buf);       // >= 48*8 u64 or null
 void launch_dec_cross_attn_mfma(const bf16* q, const bf16* kvmem, bf16* out, int N, int R, hipStream_t s);   // attn_dec2.hip: R <= 32 query rows per crop
+void launch_dec_cross_attn_split(const float* q, const float* kvmem, void* out_planes, int N, int R, hipStream_t s);   // attn_cross_split.hip: f16x4 refinement pass, triples out
+void set_dec_cross_split(int v);                         // 1 (default): that kernel; 0: dec_cross_attn_crop_kernel
 void set_dec_cross_crop(int v);                          // 1 (default): fp32 / f16x4 refinement-pass cross-attention with one workgroup per crop
 void set_dec_cross_mfma(int v);                          // 1 (default): refinement-pass cross-attention on the matrix cores
 void set_dec_self_refine(int v);                         // 1 (default): refinement-pass self-attention as one workgroup per crop

@@ -713,11 +713,15 @@ static int g_cross_mfma = 1;
 void set_dec_cross_mfma(int v) { g_cross_mfma = v; }
 static int g_cross_crop = 1;    // fp32 / f16x4 engines, refinement pass: one workgroup per crop (dec_cross_attn_crop_kernel); 0 = one per row
 void set_dec_cross_crop(int v) { g_cross_crop = v; }
+static int g_cross_split = 1;   // f16x4 engine, refinement pass: the matrix-core kernel of attn_cross_split.hip (one wave per crop and head); 0 = the per-crop vector kernel
+void set_dec_cross_split(int v) { g_cross_split = v; }
 
 void launch_dec_cross_attn(Precision prec, const void* q, const void* kvmem, void* out, int N, int R, hipStream_t s, const int* skip, int skip_n,
                            const int* done_tok, int done_col, int planes) {
   if (N <= 0) return;
   if (prec == kBF16 && g_cross_mfma && (R == 26 || g_cross_mfma == 2)) return launch_dec_cross_attn_mfma((const bf16*)q, (const bf16*)kvmem, (bf16*)out, N, R, s);   // refinement pass (attn_dec2.hip); 2: the AR steps' single row too
+  if (prec != kBF16 && planes == 3 && g_cross_split && g_cross_crop && R > 1 && R <= 32 && !skip)
+    return launch_dec_cross_attn_split((const float*)q, (const float*)kvmem, out, N, R, s);
   if (prec != kBF16 && g_cross_crop && R > 1 && R <= 26) {
     const int hsplit = N <= 64 ? 12 : N <= 256 ? 4 : N <= 512 ? 2 : 1;   // head groups: enough workgroups for the chip when the crops are few
     hipLaunchKernelGGL(dec_cross_attn_crop_kernel, dim3(N, hsplit), dim3(384), 0, s, (const float*)q, (const float*)kvmem, (float*)out, R, skip, skip_n, planes, range_ctx().flag, range_ctx().tag);
