@@ -217,6 +217,23 @@ def test_x4_refinement_cross_attention_three_kernels_agree(eng_x4):
             assert d[mask].max() < 1e-3 and np.array_equal(ida.reshape(-1, 26)[mask], idb.reshape(-1, 26)[mask])
 
 
+def test_x4_ar_cross_attention_head_groups_change_nothing(eng_x4):
+    """An AR step of a page's crops (<= 128 rows) runs its cross-attention with the 12 heads in four workgroups per row instead of one (a workgroup pulls a
+    quarter of the crop's K / V through its CU): per head the same sums in the same order - refined logits, ids and the AR logits up to each crop's EOS are
+    bit for bit those of the one-workgroup form."""
+    crops = np.random.default_rng(23).integers(0, 256, (52, 32, 128, 3), dtype=np.uint8)
+    a, a_ar, ida = eng_x4.parseq_logits(crops, want_ar=True)
+    assert eng_x4.set_tuning(b"cross_rows_hsplit", 1) == 0
+    try:
+        b, b_ar, idb = eng_x4.parseq_logits(crops, want_ar=True)
+    finally:
+        eng_x4.set_tuning(b"cross_rows_hsplit", 4)
+    assert np.array_equal(a, b) and np.array_equal(ida, idb)
+    up = R.upto_eos(b_ar.argmax(-1))
+    mask = np.arange(26)[None, :] < up[:, None]
+    assert np.array_equal(a_ar[mask], b_ar[mask])
+
+
 def test_x4_parseq_very_large_crop_batch_runs_in_even_groups(eng_x4):
     """9100 crops in one call (64 pages of ~140 boxes): beyond 8962 crops the refinement pass's widest planes tensor would leave the 2 GiB window of the
     kernels' 32-bit buffer offsets - the engine takes such a batch in even groups of <= 4096 crops (here 3 x 3034 / 3034 / 3032).  Crops are independent: the

@@ -263,6 +263,7 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "cross_mfma") set_dec_cross_mfma(value);
   else if (k == "cross_crop") set_dec_cross_crop(value);
   else if (k == "cross_split") set_dec_cross_split(value);
+  else if (k == "cross_rows_hsplit") set_dec_cross_rows_hsplit(value);
   else if (k == "mlp_store_nt") set_mlp_store_nt(value);
   else if (k == "mlp_stagger") set_mlp_stagger(value);
   else if (k == "c3s_wgs") set_conv3s_wgs_per_cu(value);

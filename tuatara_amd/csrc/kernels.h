@@ -63,6 +63,7 @@ void set_mlp_store_nt(int v);
 void set_mlp_stamps(unsigned long long* dev_buf);       // >= 48*8 u64 or null
 void launch_dec_cross_attn_mfma(const bf16* q, const bf16* kvmem, bf16* out, int N, int R, hipStream_t s);   // attn_dec2.hip: R <= 32 query rows per crop
 void launch_dec_cross_attn_split(const float* q, const float* kvmem, void* out_planes, int N, int R, hipStream_t s);   // attn_cross_split.hip: f16x4 refinement pass, triples out
+void set_dec_cross_rows_hsplit(int v);                   // head groups (workgroups) per row of the per-row cross-attention at <= 128 rows: 4 (default); 1: all 12 heads in one
 void set_dec_cross_split(int v);                         // 1 (default): that kernel; 0: dec_cross_attn_crop_kernel
 void set_dec_cross_crop(int v);                          // 1 (default): fp32 / f16x4 refinement-pass cross-attention with one workgroup per crop
 void set_dec_cross_mfma(int v);                          // 1 (default): refinement-pass cross-attention on the matrix cores

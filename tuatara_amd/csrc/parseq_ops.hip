@@ -497,7 +497,8 @@ void launch_dec_self_attn(Precision prec, const float* q, const void* kvcache, c
 }
 
 // ------------------------------------------------------------------ decoder cross attention
-// one 384-thread workgroup per query row; 12 heads x 32 dims against the crop's 128 memory tokens.
+// one workgroup per query row and head group (blockDim.x = 32 x its heads; gridDim.y groups: 1 = all 12 heads in 384 threads); 32 dims per head against the
+// crop's 128 memory tokens.  A page's few rows spread their heads over workgroups (launch_dec_cross_attn): per head the sums are the same in the same order.
 template <typename T>
 __global__ __launch_bounds__(384) void dec_cross_attn_kernel(const T* __restrict__ q, const T* __restrict__ kvmem, T* __restrict__ out, int R,
                                                              const int* skip, int skip_n, const int* done_tok, int done_col, int planes, unsigned* range_flag, unsigned range_tag) {
@@ -506,13 +507,14 @@ __global__ __launch_bounds__(384) void dec_cross_attn_kernel(const T* __restrict
   __shared__ float sq[384];
   __shared__ float sp[12][128];
   const int row = blockIdx.x, n = row / R, t = threadIdx.x;
+  const int NT = blockDim.x, c0 = blockIdx.y * NT, nh = NT >> 5;   // this workgroup's columns c0 .. c0 + NT - 1 = heads c0 / 32 .. + nh - 1
   if (done_tok) {   // ... and per crop: it has emitted EOS in token columns 1 .. done_col; what this row would produce is never read
     for (int c = 1; c <= done_col; ++c) if (done_tok[n * 26 + c] == 0) return;
   }
-  sq[t] = (float)q[(int64_t)row * 384 + t];
+  sq[t] = (float)q[(int64_t)row * 384 + c0 + t];
   __syncthreads();
-  const T* kvn = kvmem + (int64_t)n * 128 * 768;
-  for (int idx = t; idx < 12 * 128; idx += 384) {
+  const T* kvn = kvmem + (int64_t)n * 128 * 768 + c0;
+  for (int idx = t; idx < nh * 128; idx += NT) {
     int h = idx >> 7, j = idx & 127;
     const T* k = kvn + j * 768 + h * 32;
     float s = 0.f;
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(384) void dec_cross_attn_kernel(const T* __restrict
     sp[h][j] = s * 0.17677669529663687f;
   }
   __syncthreads();
-  {  // softmax: 32 lanes per head row (12 heads = 384 threads)
+  {  // softmax: 32 lanes per head row
     int h = t >> 5, l = t & 31;
     float v[4], mx = -INFINITY;
 #pragma unroll
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(384) void dec_cross_attn_kernel(const T* __restrict
     int h = t >> 5;
     float acc = 0.f;
     for (int j = 0; j < 128; ++j) acc += sp[h][j] * (float)kvn[j * 768 + 384 + t];
-    if (planes) st_split_one(out, row, 384, t, acc, planes, rw); else out[(int64_t)row * 384 + t] = (T)acc;
+    if (planes) st_split_one(out, row, 384, c0 + t, acc, planes, rw); else out[(int64_t)row * 384 + c0 + t] = (T)acc;
   }
   rw.flush(range_flag, range_tag);
 }
@@ -713,6 +715,8 @@ static int g_cross_mfma = 1;
 void set_dec_cross_mfma(int v) { g_cross_mfma = v; }
 static int g_cross_crop = 1;    // fp32 / f16x4 engines, refinement pass: one workgroup per crop (dec_cross_attn_crop_kernel); 0 = one per row
 void set_dec_cross_crop(int v) { g_cross_crop = v; }
+static int g_cross_rows_hsplit = 4;   // the per-row kernel at <= 128 rows: head groups per row (a divisor of 12; 0 / 1: one workgroup per row)
+void set_dec_cross_rows_hsplit(int v) { g_cross_rows_hsplit = (v >= 1 && v <= 12 && 12 % v == 0) ? v : 1; }
 static int g_cross_split = 1;   // f16x4 engine, refinement pass: the matrix-core kernel of attn_cross_split.hip (one wave per crop and head); 0 = the per-crop vector kernel
 void set_dec_cross_split(int v) { g_cross_split = v; }
 
@@ -728,8 +732,11 @@ void launch_dec_cross_attn(Precision prec, const void* q, const void* kvmem, voi
     return;
   }
   dim3 grid(N * R);
-  if (prec == kBF16) hipLaunchKernelGGL(dec_cross_attn_rows_kernel, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)kvmem, (bf16*)out, R, skip, skip_n, R == 1 ? done_tok : nullptr, done_col);
-  else hipLaunchKernelGGL(dec_cross_attn_kernel<float>, grid, dim3(384), 0, s, (const float*)q, (const float*)kvmem, (float*)out, R, skip, skip_n, R == 1 ? done_tok : nullptr, done_col, planes, range_ctx().flag, range_ctx().tag);
+  if (prec == kBF16) { hipLaunchKernelGGL(dec_cross_attn_rows_kernel, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)kvmem, (bf16*)out, R, skip, skip_n, R == 1 ? done_tok : nullptr, done_col); return; }
+  // a page's few rows (an AR step of <= 128 crops): three heads per workgroup, four times the workgroups - each pulls 98 KB of K / V through its CU instead of 393
+  const int hgroups = N * R <= 128 ? g_cross_rows_hsplit : 1;
+  grid.y = hgroups;
+  hipLaunchKernelGGL(dec_cross_attn_kernel<float>, grid, dim3(384 / hgroups), 0, s, (const float*)q, (const float*)kvmem, (float*)out, R, skip, skip_n, R == 1 ? done_tok : nullptr, done_col, planes, range_ctx().flag, range_ctx().tag);
 }
 
 // ------------------------------------------------------------------ argmax (first maximal index, like torch.argmax on CPU)
