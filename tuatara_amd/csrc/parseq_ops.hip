@@ -497,17 +497,18 @@ void launch_dec_self_attn(Precision prec, const float* q, const void* kvcache, c
 }
 
 // ------------------------------------------------------------------ decoder cross attention
-// one workgroup per query row and head group (blockDim.x = 32 x its heads; gridDim.y groups: 1 = all 12 heads in 384 threads); 32 dims per head against the
+// one workgroup per query row and head group (NH heads in 32 NH threads; gridDim.y = 12 / NH groups: 1 = all 12 heads in 384 threads); 32 dims per head against the
 // crop's 128 memory tokens.  A page's few rows spread their heads over workgroups (launch_dec_cross_attn): per head the sums are the same in the same order.
-template <typename T>
-__global__ __launch_bounds__(384) void dec_cross_attn_kernel(const T* __restrict__ q, const T* __restrict__ kvmem, T* __restrict__ out, int R,
+template <typename T, int NH = 12>   // NH: heads per workgroup (12 / gridDim.y)
+__global__ __launch_bounds__(NH * 32) void dec_cross_attn_kernel(const T* __restrict__ q, const T* __restrict__ kvmem, T* __restrict__ out, int R,
                                                              const int* skip, int skip_n, const int* done_tok, int done_col, int planes, unsigned* range_flag, unsigned range_tag) {
   RangeWatch rw;   // (split.h)
   if (skip && __builtin_nontemporal_load(skip) >= skip_n) return;   // AR early exit (see ConvParams::skip)
-  __shared__ float sq[384];
-  __shared__ float sp[12][128];
+  __shared__ float sq[NH * 32];
+  __shared__ float sp[NH][128];
   const int row = blockIdx.x, n = row / R, t = threadIdx.x;
-  const int NT = blockDim.x, c0 = blockIdx.y * NT, nh = NT >> 5;   // this workgroup's columns c0 .. c0 + NT - 1 = heads c0 / 32 .. + nh - 1
+  constexpr int NT = NH * 32, nh = NH;
+  const int c0 = blockIdx.y * NT;   // this workgroup's columns c0 .. c0 + NT - 1 = heads c0 / 32 .. + NH - 1
   if (done_tok) {   // ... and per crop: it has emitted EOS in token columns 1 .. done_col; what this row would produce is never read
     for (int c = 1; c <= done_col; ++c) if (done_tok[n * 26 + c] == 0) return;
   }
@@ -736,7 +737,16 @@ void launch_dec_cross_attn(Precision prec, const void* q, const void* kvmem, voi
   // a page's few rows (an AR step of <= 128 crops): three heads per workgroup, four times the workgroups - each pulls 98 KB of K / V through its CU instead of 393
   const int hgroups = N * R <= 128 ? g_cross_rows_hsplit : 1;
   grid.y = hgroups;
-  hipLaunchKernelGGL(dec_cross_attn_kernel<float>, grid, dim3(384 / hgroups), 0, s, (const float*)q, (const float*)kvmem, (float*)out, R, skip, skip_n, R == 1 ? done_tok : nullptr, done_col, planes, range_ctx().flag, range_ctx().tag);
+#define TTR_CROSS_ROWS(NH) hipLaunchKernelGGL((dec_cross_attn_kernel<float, NH>), grid, dim3(NH * 32), 0, s, (const float*)q, (const float*)kvmem, (float*)out, R, skip, skip_n, R == 1 ? done_tok : nullptr, done_col, planes, range_ctx().flag, range_ctx().tag)
+  switch (hgroups) {
+    case 2: TTR_CROSS_ROWS(6); break;
+    case 3: TTR_CROSS_ROWS(4); break;
+    case 4: TTR_CROSS_ROWS(3); break;
+    case 6: TTR_CROSS_ROWS(2); break;
+    case 12: TTR_CROSS_ROWS(1); break;
+    default: TTR_CROSS_ROWS(12);
+  }
+#undef TTR_CROSS_ROWS
 }
 
 // ------------------------------------------------------------------ argmax (first maximal index, like torch.argmax on CPU)
