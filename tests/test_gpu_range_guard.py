@@ -32,7 +32,15 @@ def scaled_dirs(tmp_path_factory):
         p2[f"encoder.blocks.3.mlp.fc1.{k}"] = p[f"encoder.blocks.3.mlp.fc1.{k}"] * np.float32(4e4)
     W.export_craft(c, dp)
     W.export_parseq(p2, dp)
-    return {"craft": dc, "parseq": dp}
+    dk = str(tmp_path_factory.mktemp("w_parseq_hot_keys"))   # the decoder's cross-attention keys (rows 384 .. 767 of its in_proj) scaled by 1e5
+    p3 = dict(p)
+    for k in ("in_proj_weight", "in_proj_bias"):
+        a = p[f"decoder.layers.0.cross_attn.{k}"].copy()
+        a[384:768] *= np.float32(1e5)
+        p3[f"decoder.layers.0.cross_attn.{k}"] = a
+    W.export_craft(c, dk)
+    W.export_parseq(p3, dk)
+    return {"craft": dc, "parseq": dp, "parseq_keys": dk}
 
 
 def test_craft_layer_out_of_range_fails_the_call_and_names_the_layer(scaled_dirs):
@@ -80,6 +88,26 @@ def test_parseq_layer_out_of_range_fails_the_call_and_names_the_layer(scaled_dir
     with pytest.raises(EngineError) as ei:
         eng.parseq_logits(crops)
     assert "encoder.blocks.3." in str(ei.value)
+
+
+def test_cross_attention_keys_out_of_range_trip_where_they_become_f16(scaled_dirs):
+    """The memory's K / V leave the cross_kv linear as fp32 rows; the AR steps' per-row cross-attention multiplies them in fp32, the refinement pass's
+    matrix-core kernel (attn_cross_split.hip) splits them into f16 planes - and watches them there.  Keys of ~1e6: the call fails naming the decoder's
+    cross-attention; with that kernel switched off (the vector form keeps K in fp32) the same weights go through."""
+    from tuatara_amd.engine import EngineError
+    eng = _engine(scaled_dirs["parseq_keys"])
+    crops = np.random.default_rng(4).integers(0, 256, (24, 32, 128, 3), dtype=np.uint8)
+    with pytest.raises(EngineError) as ei:
+        eng.parseq_logits(crops)
+    msg = str(ei.value)
+    print(msg)
+    assert "range guard" in msg and "decoder.cross_attn" in msg
+    assert eng.set_tuning(b"cross_split", 0) == 0
+    try:
+        got, ids = eng.parseq_logits(crops)
+    finally:
+        eng.set_tuning(b"cross_split", 1)
+    assert np.isfinite(got).all()
 
 
 def test_healthy_weights_do_not_trip_and_cost_nothing_visible(eng_x4):

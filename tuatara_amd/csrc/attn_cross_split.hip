@@ -50,13 +50,13 @@ __global__ __launch_bounds__(128) void dec_cross_attn_split_kernel(const float* 
   // ---- K_h: fp32 -> pairs -> LDS.  A wave instruction fetches 8 key rows x 128 bytes; this lane: key 8 it + (lane >> 3), d = 4 (lane & 7) .. + 3
   const float* const kv = kvmem + (int64_t)n * XS_KEYS * 768 + h * XS_DH + (lane & 7) * 4;
   const int c4 = lane & 7;
-  RangeWatch rk;                                                  // (the memory's K / V were watched where the cross_kv linear wrote them: they are fp32 there)
+  // (K, V and Q arrive as fp32 - the cross_kv / cross_q linears' rows - and become f16 planes HERE: they are watched with the output)
 #pragma unroll 8
   for (int it = 0; it < 16; ++it) {
     const int key = it * 8 + (lane >> 3);
     const float4 kf = *reinterpret_cast<const float4*>(kv + (int64_t)key * 768);
     f16x2 a0, b0, a1, b1;
-    split2_pair(kf.x, kf.y, a0, b0, rk); split2_pair(kf.z, kf.w, a1, b1, rk);
+    split2_pair(kf.x, kf.y, a0, b0, rw); split2_pair(kf.z, kf.w, a1, b1, rw);
     // LDS row of key k = 32 s + 8 g' + 4 a + b:  R = 32 s + 16 a + 4 g' + b   (so that S^T's accumulators hold 8 consecutive keys per lane)
     const int Rk = (key & ~31) + ((key >> 2) & 1) * 16 + ((key >> 3) & 3) * 4 + (key & 3);
     const int posk = (((c4 >> 1) ^ ((Rk >> 2) & 3)) << 4) + (c4 & 1) * 8;
@@ -74,8 +74,7 @@ __global__ __launch_bounds__(128) void dec_cross_attn_split_kernel(const float* 
       const float4 a = *reinterpret_cast<const float4*>(qp), b = *reinterpret_cast<const float4*>(qp + 4);
       v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     }
-    RangeWatch rq;                                                // (the queries are the cross_q linear's fp32 output)
-    split3_x8(v, fq[0][qt], fq[1][qt], fq[2][qt], rq);
+    split3_x8(v, fq[0][qt], fq[1][qt], fq[2][qt], rw);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // this wave's LDS writes are done (a wave's LDS operations complete in order; the compiler must not move reads above)
   __builtin_amdgcn_wave_barrier();
@@ -106,7 +105,7 @@ __global__ __launch_bounds__(128) void dec_cross_attn_split_kernel(const float* 
     const int key = it * 8 + (lane >> 3);
     const float4 vf = *reinterpret_cast<const float4*>(kv + (int64_t)key * 768 + 384);
     f16x2 a0, b0, a1, b1;
-    split2_pair(vf.x, vf.y, a0, b0, rk); split2_pair(vf.z, vf.w, a1, b1, rk);
+    split2_pair(vf.x, vf.y, a0, b0, rw); split2_pair(vf.z, vf.w, a1, b1, rw);
     *reinterpret_cast<f16x4*>(sV + key * XS_ROWB + c4 * 8) = f16x4{a0[0], a0[1], a1[0], a1[1]};
     *reinterpret_cast<f16x4*>(sV + XS_PLANE + key * XS_ROWB + c4 * 8) = f16x4{b0[0], b0[1], b1[0], b1[1]};
   }
