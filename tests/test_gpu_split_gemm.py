@@ -189,14 +189,21 @@ def test_fixed_epilogue_kernels_change_nothing(eng):
     _fold_check(eng, "gsp_epi", (40, 17, 300, 640), on=15, restore=3)
 
 
-def _fold_check(eng, key, counts, on=1, restore=None):
+def test_ninety_six_row_tiles_change_nothing(eng):
+    """A page of 43 - 128 crops: the encoder's proj / fc2 (129 - 384 tiles of 128 x 128 on 256 CUs) take 96-row tiles where those need no extra round
+    (tuning key "gsp_few": 1 = with them, 2 = without): the same k order per output - logits and ids identical bit for bit at 43, 52, 60, 64 crops (one round),
+    100 and 127 (two), and at 70 and 160, where the rule does not fire."""
+    _fold_check(eng, "gsp_few", (43, 52, 60, 64, 70, 100, 127, 160), on=1, restore=1, off=2)
+
+
+def _fold_check(eng, key, counts, on=1, restore=None, off=0):
     rng = np.random.default_rng(77)
     for n in counts:
         crops = rng.integers(0, 256, (n, 32, 128, 3), dtype=np.uint8)
         if n >= 8:
             crops[: n // 2, :, 40:] = 255          # short words too: half the crops are blank behind a third of their width
         try:
-            assert eng.set_tuning(key, 0) == 0
+            assert eng.set_tuning(key, off) == 0
             l0, a0, i0 = eng.parseq_logits(crops, want_ar=True)
             assert eng.set_tuning(key, on) == 0
             l1, a1, i1 = eng.parseq_logits(crops, want_ar=True)

@@ -845,6 +845,12 @@ void launch_gemm_sp(const ConvParams& p, int cfg, hipStream_t s) {
   // chain: fc2 at 40 crops (K = 1536, 120 tiles) 44 -> 31 us, and eight waves (wave tiles of 32 x 32) issue the loader's pieces at 1.4 - 1.6 x the rate of
   // four (tools/micro/dma_depth.hip): a page's recogniser -70 us more.  (Deeper rings alone - 3 + 3 on the 128-row tile - changed nothing: not a latency.)
   const bool few = cfg == 3 && g_sp_few && 2 * tiles128 <= cus;
+  // Beyond that, up to two rounds of 128-row tiles (a page of 43 - 128 crops: proj / fc2 on 129 - 384 tiles): a lone workgroup's time is the operand rows its CU
+  // pulls in, rounds x (BM + BN) per k step, so 96-row tiles win where a quarter more workgroups need no extra round - 60 crops: 180 -> 240 tiles, one round of
+  // 224 rows instead of 256 (fc2 46.8 -> 41.4 us, proj 24.5 -> 20.6); 100 crops: 300 -> 402 tiles, two rounds either way.  (g_sp_few = 2: without this rule.)
+  const int tiles96 = ((p.M + 95) / 96) * ((p.Cout + 127) / 128);
+  const int rounds128 = (tiles128 + cus - 1) / cus, rounds96 = (tiles96 + cus - 1) / cus;
+  const bool mid = cfg == 3 && g_sp_few == 1 && !few && tiles128 <= 4 * cus && rounds96 * 224 < rounds128 * 256 && !(p.act == kActGelu && p.gelu_lut);
   // the encoder's and the decoder's recurring epilogue cases as kernels of their own (gemm_sp_kernel's EM): fc1 (GELU table, tiled pairs out) and the residual
   // linears (bias + residual, fp32 rows out).  Same arithmetic, same order: bit-identical to the general kernel (tests/test_gpu_split_gemm.py; g_sp_epi = 0 turns them off)
   const bool plain = sched && p.dbg_flags == 0;
@@ -855,6 +861,7 @@ void launch_gemm_sp(const ConvParams& p, int cfg, hipStream_t s) {
   const bool em_res = plain && (g_sp_epi & (few ? 4 : (p.split == 4 && cfg == 2) ? 2 : 8)) && p.act == kActNone && p.resid && !p.out && p.out_f32;
   if (p.split == 4) {
     if (few) { if (em_res) launch_sp<64, 128, 2, 4, 3, 2, 1, true, 4, 0, 2>(p, s); else launch_sp<64, 128, 2, 4, 3, 2, 1, true, 4>(p, s); return; }
+    if (mid) { launch_sp<96, 128, 2, 2, 3, 2, 2, true, 4>(p, s); return; }
     if (cfg == 6) launch_sp<128, 256, 2, 4, 3, 2, 1, true, 4>(p, s);
     else if (cfg == 2) { if (em_res) launch_sp<256, 128, 4, 2, 3, 2, 1, true, 4, 0, 2>(p, s); else launch_sp<256, 128, 4, 2, 3, 2, 1, true, 4>(p, s); }
     else { if (em_res) launch_sp<128, 128, 2, 2, 3, 2, 2, true, 4, 0, 2>(p, s); else launch_sp<128, 128, 2, 2, 3, 2, 2, true, 4>(p, s); }
@@ -862,6 +869,7 @@ void launch_gemm_sp(const ConvParams& p, int cfg, hipStream_t s) {
   }
   // (64 x 64 tiles, two per CU: the same 31 us - the CU's fill rate, not the workgroup's)
   if (few) { if (em_res) launch_sp<64, 128, 2, 4, 3, 3, 1, true, 3, 0, 2>(p, s); else launch_sp<64, 128, 2, 4, 3, 3, 1, true>(p, s); return; }
+  if (mid) { launch_sp<96, 128, 2, 2, 3, 2, 2, true>(p, s); return; }
   // (a wide layer on one round of 128 x 256 tiles instead - fc1 at 40 crops: 240 - is no faster: 31 -> 32 - 37 us)
   if (cfg == 6) { if (em_fc1) launch_sp<128, 256, 2, 4, 3, 3, 1, true, 3, 0, 1>(p, s); else if (sched) launch_sp<128, 256, 2, 4, 3, 3, 1, true>(p, s); else launch_sp<128, 256, 2, 4, 3, 3, 1, false>(p, s); }
   else if (cfg == 2) { if (em_fc1) launch_sp<256, 128, 4, 2, 3, 3, 1, true, 3, 0, 1>(p, s); else if (sched) launch_sp<256, 128, 4, 2, 3, 3, 1, true>(p, s); else launch_sp<256, 128, 4, 2, 3, 3, 1, false>(p, s); }
