@@ -52,6 +52,10 @@ int ttr_set_tuning(const char* key, int value);
 void ttr_last_host_us(ttr_engine* e, float out[8]);
 /* test hook for the ViT encoder self-attention kernels: qkv f32 [N][128][1152] (rounded to the engine's type) -> out [N][128][384] */
 int ttr_dbg_attn_enc(ttr_engine* e, const float* qkv, int N, float* out);
+/* test hook for the decoder's cross-attention kernels of the split-operand / fp32 engines (parseq_ops.hip, attn_cross_split.hip; which one runs follows the
+ * tuning keys "cross_split", "cross_crop", "cross_rows_hsplit"): q f32 [N * R][384] (R query rows per crop), kvmem f32 [N * 128][768] (K | V of a crop's 128
+ * memory tokens) -> out f32 [N * R][384], joined from the exact triples the kernels write */
+int ttr_dbg_cross_attn(ttr_engine* e, const float* q, const float* kvmem, int N, int R, float* out);
 /* test hook for qkv_attn.hip (bf16 engines): x f32 [N][128][384], w [1152][384], b [1152] -> self-attention output [N][128][384] */
 int ttr_dbg_qkv_attn(ttr_engine* e, const float* x, int N, const float* w, const float* b, float* out);
 /* test hook for mlp_fused.hip (bf16 engines): x_out = x + fc2(GELU(fc1(LayerNorm(x)))) over f32 rows [M][384] with weights

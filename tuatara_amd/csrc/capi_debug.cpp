@@ -213,6 +213,28 @@ int ttr_dbg_attn_enc(ttr_engine* e, const float* qkv, int N, float* out) {
   TTR_GUARD_END(-1)
 }
 
+int ttr_dbg_cross_attn(ttr_engine* e, const float* q, const float* kvmem, int N, int R, float* out) {
+  TTR_GUARD_BEGIN
+  Engine& E = *e->e;
+  EngineScope lk(E);
+  if (E.prec == kBF16) throw std::runtime_error("ttr_dbg_cross_attn: split-operand / fp32 engines");
+  if (N <= 0 || R <= 0) throw std::runtime_error("ttr_dbg_cross_attn: N, R >= 1");
+  const size_t nq = (size_t)N * R * 384, nkv = (size_t)N * 128 * 768;
+  DevBuf dq, dkv, dout;
+  dq.ensure(nq * 4); dkv.ensure(nkv * 4); dout.ensure(nq * 6);
+  TTR_HIP_CHECK(hipMemcpy(dq.p, q, nq * 4, hipMemcpyHostToDevice));
+  TTR_HIP_CHECK(hipMemcpy(dkv.p, kvmem, nkv * 4, hipMemcpyHostToDevice));
+  launch_dec_cross_attn(kF32, dq.p, dkv.p, dout.p, N, R, E.stream, nullptr, 0, nullptr, 0, 3);   // exact triples [N * R][3][384]
+  TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
+  std::vector<_Float16> h(nq * 3);
+  TTR_HIP_CHECK(hipMemcpy(h.data(), dout.p, nq * 6, hipMemcpyDeviceToHost));
+  for (size_t r = 0; r < (size_t)N * R; ++r)
+    for (int c = 0; c < 384; ++c)
+      out[r * 384 + c] = (float)h[r * 1152 + c] + ((float)h[r * 1152 + 384 + c] + (float)h[r * 1152 + 768 + c]) * (1.f / 2048.f);
+  return 0;
+  TTR_GUARD_END(-1)
+}
+
 int ttr_dbg_conv_pool(ttr_engine* e, const float* in0, int C0, int B, int H, int W, int ks, const float* wgt, const float* bias, int Cout, int act,
                       int pool_relu, float* out_full, float* out_pool) {
   TTR_GUARD_BEGIN

@@ -75,6 +75,7 @@ SYMBOLS = [
     ("ttr_set_tuning", _I, [C.c_char_p, _I]),
     ("ttr_last_host_us", None, [_VP, _PF]),
     ("ttr_dbg_attn_enc", _I, [_VP, _PF, _I, _PF]),
+    ("ttr_dbg_cross_attn", _I, [_VP, _PF, _PF, _I, _I, _PF]),
     ("ttr_dbg_qkv_attn", _I, [_VP, _PF, _I, _PF, _PF, _PF]),
     ("ttr_dbg_mlp", _I, [_VP, _PF, _I, _PF, _PF, C.c_float, _PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF]),
     ("ttr_dbg_dec_stamps", _I, [C.POINTER(C.c_ulonglong)]),
@@ -392,6 +393,14 @@ class Engine:
         N = qkv.shape[0]
         out = np.zeros((N, 128, 384), np.float32)
         self._check(self.lib.ttr_dbg_attn_enc(self.h, _f(qkv), N, _f(out)))
+        return out
+
+    def dbg_cross_attn(self, q, kvmem):
+        """The decoder's cross-attention kernels on their own: q [N, R, 384], kvmem [N, 128, 768] (K | V) -> [N, R, 384] (split / fp32 engines)."""
+        q = np.ascontiguousarray(q, np.float32); kvmem = np.ascontiguousarray(kvmem, np.float32)
+        N, R = q.shape[0], q.shape[1]
+        out = np.zeros((N, R, 384), np.float32)
+        self._check(self.lib.ttr_dbg_cross_attn(self.h, _f(q), _f(kvmem), N, R, _f(out)))
         return out
 
     def dbg_qkv_attn(self, x, w, b):
