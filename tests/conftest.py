@@ -54,6 +54,13 @@ def funsd():
     return np.array(Image.open(os.path.join(DATA, "funsd_0001129658.png")).convert("RGB"))
 
 
+@pytest.fixture(scope="session")
+def funsd_oracle(oracle_models, funsd):
+    """The CPU oracle on the FUNSD page (config 1 / 4), once per session: detect()'s fields + crops, logits, result (oracle/pipeline.py, debug=True)."""
+    from oracle import pipeline
+    return pipeline.image_to_data(oracle_models[0], oracle_models[1], funsd, debug=True)
+
+
 def _engine(weights_dir, precision):
     from tuatara_amd.build import build_lib
     from tuatara_amd.engine import Engine

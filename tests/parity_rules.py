@@ -92,3 +92,25 @@ def heatmap_flips(h_ref: np.ndarray, h_got: np.ndarray, low_text: float = 0.4, l
     flips = ((tr > low_text) != (tg > low_text)) | ((lr > link_threshold) != (lg > link_threshold))
     err = max(float(np.abs(tr - tg).max()), float(np.abs(lr - lg).max()))
     return flips, err, int(((tr > low_text) | (lr > link_threshold)).sum())
+
+
+# ---- the CPU oracle's PARSeq logits, memoised per (model, crops): several GPU tests compare different engines with the oracle on the SAME seeded crop batches
+# (config 2's 256 crops, the 448-crop batch); the oracle runs all 26 AR steps on the host - seconds per hundred crops - once per batch and test session
+_oracle_memo = {}
+
+
+def oracle_logits(parseq, crops, batch=64):
+    import hashlib
+    import torch
+    key = (id(parseq), batch, crops.shape, hashlib.sha1(np.ascontiguousarray(crops).tobytes()).hexdigest())
+    if key not in _oracle_memo:
+        refs, ars = [], []
+        with torch.no_grad():
+            for i in range(0, len(crops), batch):
+                x = torch.from_numpy(crops[i:i + batch]).permute(0, 3, 1, 2).float().div(255.0)
+                r, a = parseq(x, return_ar=True)
+                refs.append(r.numpy())
+                ars.append(a.numpy())
+        _oracle_memo[key] = (np.concatenate(refs), np.concatenate(ars))
+    r, a = _oracle_memo[key]
+    return r.copy(), a.copy()

@@ -11,15 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _oracle_logits(parseq, crops, batch=64):
-    import torch
-    refs, ars = [], []
-    with torch.no_grad():
-        for i in range(0, len(crops), batch):
-            x = torch.from_numpy(crops[i:i + batch]).permute(0, 3, 1, 2).float().div(255.0)
-            r, a = parseq(x, return_ar=True)
-            refs.append(r.numpy())
-            ars.append(a.numpy())
-    return np.concatenate(refs), np.concatenate(ars)
+    return R.oracle_logits(parseq, crops, batch)      # (memoised: tests/parity_rules.py)
 
 
 @pytest.mark.parametrize("n", [256, 448])

@@ -203,3 +203,5 @@ def test_bench_starts_its_own_ranks_two_ranks_on_one_gpu(weights):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["gathered_id_rows_last_pass"] == 2 * 8 * 40                      # every page of both ranks: 40 rows of 26 ids
     assert d["config"]["pages_per_gpu_per_pass"] == 8 and "SHARE one GPU" in d["config"]["parallelism"]
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1      # an N > 1 line carries the CPU leg too (rank 0, behind the timed region)
+    assert len(d["ranks"]) == 2

@@ -22,10 +22,9 @@ def _iou(a, b):
     return inter / ua
 
 
-def test_funsd_f32_identical_to_oracle(eng_f32, oracle_models, funsd):
-    from oracle import pipeline
+def test_funsd_f32_identical_to_oracle(eng_f32, funsd_oracle, funsd):
     got = eng_f32.image_to_data(funsd)
-    ref = pipeline.image_to_data(oracle_models[0], oracle_models[1], funsd)
+    ref = funsd_oracle["result"]
     assert len(got) == len(ref) >= 40
     assert [g["bbox"] for g in got] == [r["bbox"] for r in ref]          # same boxes, same order
     assert [g["text"] for g in got] == [r["text"] for r in ref]          # identical strings
@@ -34,7 +33,7 @@ def test_funsd_f32_identical_to_oracle(eng_f32, oracle_models, funsd):
     assert sum(g["text"] == r["text"] for g, r in zip(got, G["funsd"])) >= len(got) - 2
 
 
-def test_funsd_bf16_margin_aware_equivalence(eng_bf16, oracle_models, funsd):
+def test_funsd_bf16_margin_aware_equivalence(eng_bf16, oracle_models, funsd, funsd_oracle):
     """Config 4 in the bf16 throughput mode.  bf16 rounding moves the heat map by ~1e-2 at a few pixels, so a pixel whose fp32
     value sits on a threshold (tuatara.cpp:131-132) can flip and move a blob outline by one pixel.  Required:
       * the heat map stays within a bounded error of the oracle's and the flipped pixels are a small share of the set ones;
@@ -47,7 +46,7 @@ def test_funsd_bf16_margin_aware_equivalence(eng_bf16, oracle_models, funsd):
     from tests import parity_rules as R
     from tuatara_amd.engine import decode_ids
     got = eng_bf16.image_to_data(funsd)
-    d = pipeline.image_to_data(oracle_models[0], oracle_models[1], funsd, debug=True)
+    d = funsd_oracle
     ref = d["result"]
     heat = eng_bf16.craft_heatmap(d["canvas"])
     flips, err, nset = R.heatmap_flips(d["heat"], heat)
@@ -76,7 +75,7 @@ def test_funsd_bf16_margin_aware_equivalence(eng_bf16, oracle_models, funsd):
     assert n_pair >= 0.6 * len(ref) and n_eq == n_pair
 
 
-def test_pytuatara_run_ocr_counterpart(weights, oracle_models, funsd, monkeypatch):
+def test_pytuatara_run_ocr_counterpart(weights, oracle_models, funsd, funsd_oracle, monkeypatch):
     """bindings/run_ocr.py:88-93: PIL -> RGB numpy -> pytuatara.image_to_data(img, weights, outputs) -> list of dicts.  What a user of the
     drop-in gets - the shim's DEFAULT precision (f16x4; no TUATARA_PRECISION in the environment) - against the CPU oracle: same boxes,
     same order, same strings."""
@@ -87,7 +86,7 @@ def test_pytuatara_run_ocr_counterpart(weights, oracle_models, funsd, monkeypatc
     import pytuatara
     monkeypatch.delenv("TUATARA_PRECISION", raising=False)
     res = pytuatara.image_to_data(funsd, weights["dir"], "../outputs")
-    ref = pipeline.image_to_data(*oracle_models, funsd)
+    ref = funsd_oracle["result"]
     assert isinstance(res, list) and set(res[0].keys()) == {"text", "bbox"}
     assert len(res) == len(ref) > 20
     assert [r["text"] for r in res] == [r["text"] for r in ref]
@@ -314,21 +313,17 @@ def test_malformed_inputs_are_rejected_loudly(weights, eng_f32, tmp_path):
             Engine(str(d), precision="f32")
 
 
-@pytest.mark.parametrize("prec", ["f16x4", "f32"])
-def test_converted_torchscript_archives_end_to_end(tmp_path, oracle_models, funsd, prec):
-    """SURVEY 8f-1 end to end: the reference loads two TorchScript archives (tuatara.cpp:333-336, :423-428).  Archives of that
-    layout are traced from the oracle models, saved under the reference's file names, converted by tools/convert_weights.py, and
-    the engine on the converted directory must give what the ARCHIVES give when run the reference's way (torch.jit.load ->
-    forward) through the oracle's post-processing: identical boxes and strings - in the engine's DEFAULT precision (what a user of the converter gets) and
-    in the fp32-MFMA mode."""
+@pytest.fixture(scope="module")
+def converted_archives(tmp_path_factory, oracle_models, funsd, funsd_oracle):
+    """Archives of the reference's layout traced from the oracle models, saved under the reference's file names and converted by tools/convert_weights.py
+    (once per session); and what the ARCHIVES give on the FUNSD page when run the reference's way (torch.jit.load -> forward) through the oracle's post-processing."""
     import subprocess
     import torch
     from oracle import pipeline, post
-    from tuatara_amd.engine import Engine
     craft, parseq = oracle_models
-    d = pipeline.image_to_data(craft, parseq, funsd, debug=True)
+    d = funsd_oracle
     n = len(d["crops"])
-    wd = str(tmp_path)
+    wd = str(tmp_path_factory.mktemp("converted"))
     cpath, ppath = os.path.join(wd, "craft_traced_torchscript_model.pt"), os.path.join(wd, "parseq_torchscript.bin")
     with torch.no_grad():
         torch.jit.trace(craft, torch.zeros(1, 3, d["canvas"].shape[0], d["canvas"].shape[1]), check_trace=False).save(cpath)
@@ -343,7 +338,18 @@ def test_converted_torchscript_archives_end_to_end(tmp_path, oracle_models, funs
     with torch.no_grad():
         logits = tp(torch.from_numpy(crops).permute(0, 3, 1, 2).float().div(255.0)).numpy()
     texts, _ = post.decode_logits(logits)
-    ref = [{"text": t, "bbox": post.tesseract_bbox(b)} for t, b in zip(texts, da["boxes"])]
+    return wd, [{"text": t, "bbox": post.tesseract_bbox(b)} for t, b in zip(texts, da["boxes"])]
+
+
+@pytest.mark.parametrize("prec", ["f16x4", "f32"])
+def test_converted_torchscript_archives_end_to_end(converted_archives, funsd, prec):
+    """SURVEY 8f-1 end to end: the reference loads two TorchScript archives (tuatara.cpp:333-336, :423-428).  Archives of that
+    layout are traced from the oracle models, saved under the reference's file names, converted by tools/convert_weights.py, and
+    the engine on the converted directory must give what the ARCHIVES give when run the reference's way (torch.jit.load ->
+    forward) through the oracle's post-processing: identical boxes and strings - in the engine's DEFAULT precision (what a user of the converter gets) and
+    in the fp32-MFMA mode."""
+    from tuatara_amd.engine import Engine
+    wd, ref = converted_archives
     eng = Engine(wd, precision=prec)
     got = eng.image_to_data(funsd)
     eng.close()

@@ -19,15 +19,7 @@ def eng_x4_random(weights_random):
 
 
 def _oracle_logits(parseq, crops, batch=64):
-    import torch
-    refs, ars = [], []
-    with torch.no_grad():
-        for i in range(0, len(crops), batch):
-            x = torch.from_numpy(crops[i:i + batch]).permute(0, 3, 1, 2).float().div(255.0)
-            r, a = parseq(x, return_ar=True)
-            refs.append(r.numpy())
-            ars.append(a.numpy())
-    return np.concatenate(refs), np.concatenate(ars)
+    return R.oracle_logits(parseq, crops, batch)      # (memoised: tests/parity_rules.py)
 
 
 def _assert_logits(ref, ref_ar, got, got_ar, ids, label):
@@ -436,11 +428,9 @@ def test_x4_two_detector_lanes_change_nothing(eng_x4):
     assert sum(len(r) for r in two) > 300
 
 
-def test_x4_funsd_end_to_end_identical(eng_x4, oracle_models, funsd):
+def test_x4_funsd_end_to_end_identical(eng_x4, funsd_oracle, funsd):
     """Config 4: FUNSD page through the whole path: boxes (np.array_equal, order included) and strings identical to the oracle."""
-    from oracle import pipeline
-    craft, parseq = oracle_models
-    ref = pipeline.image_to_data(craft, parseq, funsd)
+    ref = funsd_oracle["result"]
     got = eng_x4.image_to_data(funsd)
     assert len(got) == len(ref) and len(ref) > 50
     assert np.array_equal(np.array([g["bbox"] for g in got]), np.array([r["bbox"] for r in ref]))
