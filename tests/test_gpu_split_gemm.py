@@ -189,6 +189,22 @@ def test_fixed_epilogue_kernels_change_nothing(eng):
     _fold_check(eng, "gsp_epi", (40, 17, 300, 640), on=15, restore=3)
 
 
+def test_whole_line_stores_change_nothing(eng):
+    """The encoder GEMMs' epilogues with every store instruction writing whole 128-byte lines (tuning key "gsp_epi" bits 16: fc1's tiled pairs as contiguous
+    KiB pieces, 32: the residual linears' fp32 rows; lanes fr and fr ^ 8 exchange one 16-byte piece by DPP, gemm_sp.hip EM = 3 / 4) against the accumulator-layout
+    stores (sixteen half lines per instruction; profiles/r06_store_rate.txt): pure data movement - logits and ids identical bit for bit at 17, 300 and 640 crops
+    (128 x 128, 256 x 128 and 128 x 256 tiles) and at a page's 40 (64-row tiles: unchanged kernels)."""
+    _fold_check(eng, "gsp_epi", (40, 17, 300, 640), on=51, restore=3, off=3)
+    _fold_check(eng, "gsp_epi", (300,), on=3 + 16, restore=3, off=3)
+    _fold_check(eng, "gsp_epi", (300,), on=3 + 32, restore=3, off=3)
+
+
+def test_staggered_wave_halves_change_nothing(eng):
+    """The eight-wave pairs tiles with waves 4 - 7 half a phase behind waves 0 - 3 (gemm_sp_kernel's STAG, tuning key "gsp_stag"): the same requests in the same
+    barrier intervals, the same accumulation order per accumulator - logits and ids identical bit for bit at 300 and 640 crops.  (Measured slower: off by default.)"""
+    _fold_check(eng, "gsp_stag", (300, 640), on=1, restore=0, off=0)
+
+
 def test_ninety_six_row_tiles_change_nothing(eng):
     """A page of 43 - 128 crops: the encoder's proj / fc2 (129 - 384 tiles of 128 x 128 on 256 CUs) take 96-row tiles where those need no extra round
     (tuning key "gsp_few": 1 = with them, 2 = without): the same k order per output - logits and ids identical bit for bit at 43, 52, 60, 64 crops (one round),

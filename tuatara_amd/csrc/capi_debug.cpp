@@ -309,6 +309,10 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "gsp_few") set_gemm_sp_few(value);
   else if (k == "gsp_epi") set_gemm_sp_epi(value);
   else if (k == "gsp_ks3") set_gemm_sp_ks3(value);
+  else if (k == "gsp_stagger") set_gemm_sp_stagger(value);
+  else if (k == "gsp_dbg") set_gemm_sp_dbg(value);
+  else if (k == "gsp_stag") set_gemm_sp_stag(value);
+  else if (k == "gsp_stagger_groups") set_gemm_sp_stagger_groups(value);
   else if (k == "qkv_attn_dbg") set_qkv_attn_dbg(value);
   else if (k == "skx_ln_max_rows") set_gemm_skx_ln_max_rows(value);
   else if (k == "c3_xs1_max_cin") set_conv3p_single_stage_max_cin(value);

@@ -68,6 +68,9 @@ struct ConvParams {
   // split-operand mode: the engine's sticky range word and this layer's tag (split.h: RangeWatch); null = not watched.  The launchers fill them from
   // range_ctx() (kernels.h) when the caller left them empty
   unsigned* range_flag; unsigned range_tag;
+  // gemm_sp.hip: workgroup (blockIdx.x >> 3) % cu_stagger_groups waits that many cu_stagger_groups-ths of cu_stagger ticks (s_memrealtime, 10 ns) before its first
+  // tile, so that the CUs do not reach their epilogues - every CU's store burst - together (0 = off; set by the launcher from the tuning keys)
+  int cu_stagger, cu_stagger_groups;
 };
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

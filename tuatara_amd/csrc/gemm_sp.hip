@@ -73,7 +73,13 @@ struct SpCfg {
 // K = 9 taps x Cin: the weight stream is unchanged (its rows are [tap][Cin] already); the activation stream re-forms its lanes' row offsets at every tap
 // change - pixel + (dy W + dx) dil, out of range (zero fill) where the tap leaves the image - from two registers per piece kept per tile (offset of the
 // centre pixel, its (y, x)): ~8 vector instructions per piece and tap, every Cin / 64 k steps.  gemm2.hip's loop did that arithmetic per load.
-template <int BM, int BN, int WM, int WN, int XST, int WST, int MINB, bool SCHED, int NP, int EPI = 0, int EM = 0, bool KS3 = false>
+// DBG (timing experiments, results are wrong): bit 0 = the loader streams request nothing, bit 1 = no fragment reads from LDS (the MFMAs run on what the registers hold)
+// STAG (pairs loop, eight waves): the second-dispatched half of the workgroup (waves 4 - 7: the SIMD partners of waves 0 - 3) runs half a phase behind - it
+// defers the second 32-deep half of every phase's MFMAs to the far side of the next barrier, so that behind a barrier one wave of a SIMD issues matrix
+// instructions back to back while its partner issues the phase's LDS-DMA requests (60 - 185 cycles each, during which that wave issues nothing else) and
+// fragment reads, and the other way round in the second half of the interval (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  Same requests in the same
+// intervals, same accumulation order per accumulator: results are bit-identical.
+template <int BM, int BN, int WM, int WN, int XST, int WST, int MINB, bool SCHED, int NP, int EPI = 0, int EM = 0, bool KS3 = false, int DBG = 0, bool STAG = false>
 __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams p) {
   using C = SpCfg<BM, BN, WM, WN, XST, WST>;
   static_assert(NP == 3 || (NP == 4 && XST == 3 && WST == 2), "pairs, or triples on rings 3 + 2");
@@ -87,8 +93,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
 
   static_assert(EM == 0 || EPI == 0, "fixed epilogue cases are the plain epilogue's");
   static_assert(!KS3 || (NP == 3 && EPI == 0), "3x3 taps: the pairs loop");
+  static_assert(!STAG || (NP == 3 && WM * WN == 8 && SCHED), "staggered halves: the pairs loop on eight waves");
   float2* const glut = reinterpret_cast<float2*>(smem + C::LDS);          // Hermite GELU table behind the rings (common.h: gelu_hermite)
-  if (EM == 1 || (EM == 0 && p.act == kActGelu && p.gelu_lut)) {
+  if (EM == 1 || EM == 3 || (EM == 0 && p.act == kActGelu && p.gelu_lut)) {
     for (int i = tid; i < 512; i += C::NT) reinterpret_cast<uint4*>(glut)[i] = reinterpret_cast<const uint4*>(p.gelu_lut)[i];
   }   // visible after the first barrier
 
@@ -104,6 +111,11 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
   }
   int idx = blockIdx.x >> 3;
   if (idx >= xcd_count) return;
+  if (p.cu_stagger > 0) {   // ConvParams::cu_stagger: a start delay by workgroup, uniform over the workgroup, before anything is requested
+    const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) % p.cu_stagger_groups) * (unsigned)p.cu_stagger / (unsigned)p.cu_stagger_groups;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+  }
 
   const int K = p.C0, nkt = K >> 6, nk0 = KS3 ? 9 * nkt : nkt;   // (KS3: k steps per tap, per tile)
   const int Kw = KS3 ? 9 * K : K;                                  // halves per weight plane
@@ -189,8 +201,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
     unsigned char* sb = xring + xs_slot * C::XBYTES + wave * 1024;
 #pragma unroll
     for (int i = 0; i < C::XPW; ++i) {
-      const unsigned vo = xvo[i];   // (a local copy: hipcc's host pass fails to instantiate the kernel when the array element is passed directly)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(sb + i * C::NW * 1024), 16, vo, soff, 0, 0);
+      const unsigned vo = (DBG & 4) ? OOB : (DBG & 8) ? xvo[i] - (xvo[i] != OOB ? xvo[i] / (1u << 20) * (1u << 20) : 0u) : xvo[i];   // (a local copy: hipcc's host pass fails to instantiate the kernel when the array element is passed directly; DBG 4: every request out of range, 8: every request inside the first MiB)
+      if constexpr (!(DBG & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr)(sb + i * C::NW * 1024), 16, vo, soff, 0, 0);
     }
     xs_slot = xs_slot == XST - 1 ? 0 : xs_slot + 1;
     const bool lastpl = xs_pl == PLX - 1;              // the last plane -> next k0
@@ -217,8 +229,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
     unsigned char* sb = wring + ws_slot * C::WBYTES + wave * 1024;
 #pragma unroll
     for (int j = 0; j < C::WPW; ++j) {
-      const unsigned vo = wvo[j];
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sb + j * C::NW * 1024), 16, vo, soff, 0, 0);
+      const unsigned vo = (DBG & 4) ? OOB : wvo[j];
+      if constexpr (!(DBG & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sb + j * C::NW * 1024), 16, vo, soff, 0, 0);
     }
     ws_slot = ws_slot == WST - 1 ? 0 : ws_slot + 1;
     const int k1 = ws_k + ws_pl;
@@ -246,7 +258,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
   const int fg = lane >> 4, fr = lane & 15;
   int xr = 0, wr = 0;                     // ring slots the next fragment reads take
   f16x8 fx0[2][C::MI], fx1[2][C::MI], fw0[2][C::NJ], fw1[2][C::NJ];
+  bool dbg_first = true;   // (DBG & 2: the first call of each reader still reads, so that the registers hold something)
   auto read_x = [&](f16x8 (&f)[2][C::MI]) {
+    if constexpr ((DBG & 2) != 0) { if (!dbg_first) { asm volatile("" : "+v"(f[0][0]), "+v"(f[1][0])); return; } }
     const unsigned char* b = xring + xr * C::XBYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
@@ -255,6 +269,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
     xr = xr == XST - 1 ? 0 : xr + 1;
   };
   auto read_w = [&](f16x8 (&f)[2][C::NJ]) {
+    if constexpr ((DBG & 2) != 0) { if (!dbg_first) { asm volatile("" : "+v"(f[0][0]), "+v"(f[1][0])); return; } }
     const unsigned char* b = wring + wr * C::WBYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
@@ -307,6 +322,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   read_x(fx0); read_w(fw0);
+  if constexpr ((DBG & 2) != 0) { read_x(fx1); read_w(fw1); dbg_first = false; }
 
   int stamp_tile = 0;   // (diagnostics: phase stamps of workgroup 0, wave 0 over its first 24 tiles, ConvParams::dbg)
 #define TTR_SP_STAMP(ph) do { if (EPI == 1 && p.dbg && blockIdx.x == 0 && tid == 0 && stamp_tile < 24) p.dbg[stamp_tile * 16 + (ph)] = __builtin_readcyclecounter(); } while (0)
@@ -382,6 +398,64 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
         if constexpr (SCHED) interleave(std::integral_constant<int, 2 * C::MI + 2 * C::NJ>{}, std::integral_constant<int, C::XPW>{});
       };
       for (int k0 = 0; k0 < nk0; k0 += 2) { k_step(fx0, fx1); k_step(fx1, fx0); }
+    } else if constexpr (STAG) {
+      // one code path for both halves: per barrier interval the early half (waves 0 - 3) runs [head of phase x: requests, reads, first 32-deep half of its MFMAs]
+      // [second half of phase x], the late half [second half of phase x - 1] [head of phase x]
+      const bool late = wave >= 4;
+      auto mfmas_kk = [&](const f16x8 (&fw)[2][C::NJ], const f16x8 (&fx)[2][C::MI], int kk) {
+#pragma unroll
+        for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+          for (int j = 0; j < C::NJ; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[kk][j], fx[kk][i], acc[j][i], 0, 0, 0);
+      };
+      auto scale_w0_kk = [&](int kk) {
+        const f16 sc = (f16)(1.f / 2048.f);
+        const f16x8 scv = {sc, sc, sc, sc, sc, sc, sc, sc};
+#pragma unroll
+        for (int j = 0; j < C::NJ; ++j) fw1[kk][j] = fw0[kk][j] * scv;
+      };
+      auto head = [&](auto allow_c) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(decltype(allow_c)::value) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      for (int k0 = 0; k0 < nk0; ++k0) {
+        // ph0 interval
+        head(std::integral_constant<int, PH0>{});
+        if (late && k0 > 0) mfmas_kk(fw1, fx1, 1);      // (w0s X1 of the previous k0, second half)
+        __builtin_amdgcn_sched_barrier(0);
+        issue_x(); issue_w();
+        read_w(fw1);                         // W1(k)
+        mfmas_kk(fw0, fx0, 0);
+        interleave(std::integral_constant<int, 2 * C::NJ>{}, std::integral_constant<int, XW>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (!late) mfmas_kk(fw0, fx0, 1);
+        // ph1 interval
+        head(std::integral_constant<int, PH1>{});
+        if (late) mfmas_kk(fw0, fx0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_w();
+        read_x(fx1);                         // X1(k)
+        mfmas_kk(fw1, fx0, 0);
+        interleave(std::integral_constant<int, 2 * C::MI>{}, std::integral_constant<int, C::WPW>{});
+        __builtin_amdgcn_sched_barrier(0);
+        scale_w0_kk(0);
+        if (!late) { mfmas_kk(fw1, fx0, 1); __builtin_amdgcn_sched_barrier(0); scale_w0_kk(1); }
+        // ph2 interval
+        head(std::integral_constant<int, PH2>{});
+        if (late) { mfmas_kk(fw1, fx0, 1); __builtin_amdgcn_sched_barrier(0); scale_w0_kk(1); }
+        __builtin_amdgcn_sched_barrier(0);
+        issue_x();
+        read_x(fx0); read_w(fw0);            // X0(k+1), W0(k+1)
+        mfmas_kk(fw1, fx1, 0);
+        interleave(std::integral_constant<int, 2 * C::MI + 2 * C::NJ>{}, std::integral_constant<int, C::XPW>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (!late) mfmas_kk(fw1, fx1, 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (late) mfmas_kk(fw1, fx1, 1);       // the last phase's deferred half
     } else {
     for (int k0 = 0; k0 < nk0; ++k0) {
       // ph0
@@ -653,9 +727,10 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
     // accumulators in place; pass 2 (activation, planes, stores) loads nothing.  Mixed, a load behind a store costs a full drain of the stores:
     // the counter counts both, they complete out of order with respect to each other, so the compiler can only wait for vmcnt(0) - the
     // one-pass form did that once per 16-row block, eight write round trips per tile.
-    const int e_act = EM == 1 ? (int)kActGelu : EM == 2 ? (int)kActNone : p.act;
-    const bool e_lut = EM == 1 ? true : EM == 2 ? false : p.gelu_lut != nullptr;
-    const bool e_resid = EM == 1 ? false : EM == 2 ? true : p.resid != nullptr;
+    constexpr bool FC1 = EM == 1 || EM == 3, RES = EM == 2 || EM == 4;
+    const int e_act = FC1 ? (int)kActGelu : RES ? (int)kActNone : p.act;
+    const bool e_lut = FC1 ? true : RES ? false : p.gelu_lut != nullptr;
+    const bool e_resid = FC1 ? false : RES ? true : p.resid != nullptr;
     {
       const __amdgpu_buffer_rsrc_t rsb = sp_rsrc(p.bias, p.bias ? (unsigned)p.Cout * 4u : 0u);
       const int64_t rrows = p.resid_mod ? p.resid_mod : p.M;
@@ -700,6 +775,71 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
       }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the loads above (and the K loop's prefetch, requested a phase and more ago); no store is out yet
+    // EM = 3 / 4: the same values stored as WHOLE lines.  In the accumulator layout a store instruction covers 16 rows x 64 bytes (four lanes side by side) - sixteen
+    // half lines - and a CU's store path takes such instructions at 14 - 16 B / clk against 37 - 53 for instructions that write whole 128-byte lines
+    // (tools/micro/store_rate.hip, profiles/r06_store_rate.txt: a 128-KiB burst per CU).  Lanes fr and fr ^ 8 of a 16-lane row exchange one of their two 16-byte
+    // pieces (DPP row_ror:8: three vector instructions per dword) so that an instruction carries rows 0 - 7 (then 8 - 15) of the block in full.
+    auto swap8 = [&](const f16x8& lo_piece, const f16x8& hi_piece, f16x8& first, f16x8& second) {
+      // lanes fr < 8 keep lo_piece for the first instruction and hand hi_piece to lane fr + 8 (second instruction); lanes fr >= 8 the other way round
+      typedef __attribute__((ext_vector_type(4))) int i32x4;
+      const bool hi = (lane & 8) != 0;
+      const i32x4 l = __builtin_bit_cast(i32x4, lo_piece), h = __builtin_bit_cast(i32x4, hi_piece);
+      i32x4 f, g;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int send = hi ? l[d] : h[d];
+        const int recv = __builtin_amdgcn_update_dpp(0, send, 0x128, 0xF, 0xF, false);   // row_ror:8
+        f[d] = hi ? recv : l[d];
+        g[d] = hi ? h[d] : recv;
+      }
+      first = __builtin_bit_cast(f16x8, f); second = __builtin_bit_cast(f16x8, g);
+    };
+    if constexpr (EM == 3) {   // fc1: GELU, pairs, the next GEMM's 1-KiB loader pieces - every store instruction one contiguous KiB (launcher: M % 16 == 0, Cout % 64 == 0, out_tiled == 1)
+      const int kb = p.out_ld >> 6;
+#pragma unroll
+      for (int i = 0; i < C::MI; ++i) {
+        const int mrow = m0c + wm * C::TM + i * 16 + (fr & 7);          // first instruction's row; the second's is 8 further down (the next piece)
+#pragma unroll
+        for (int tp = 0; tp < C::NJ / 4; ++tp) {
+          f16x8 a[2], b[2];
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const int t = 2 * tp + hf;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = acc[2 * t][i][e]; v[4 + e] = acc[2 * t + 1][i][e]; }
+            gelu_hermite8(v, glut);
+            split2_x8(v, a[hf], b[hf], rw);
+          }
+          f16x8 a0, a1, b0, b1;
+          swap8(a[0], a[1], a0, a1); swap8(b[0], b[1], b0, b1);
+          const int n64 = n0c + wn * C::TN + tp * 64;
+          f16* o = reinterpret_cast<f16*>(p.out) + ((int64_t)(mrow >> 3) * (2 * kb) + (n64 >> 6)) * 512 + (mrow & 7) * 64 + (fg + ((lane & 8) ? 4 : 0)) * 8;
+          if (mrow < p.M) {
+            *reinterpret_cast<f16x8*>(o) = a0; *reinterpret_cast<f16x8*>(o + kb * 512) = b0;
+            *reinterpret_cast<f16x8*>(o + 2 * kb * 512) = a1; *reinterpret_cast<f16x8*>(o + 3 * kb * 512) = b1;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else if constexpr (EM == 4) {   // residual linears: fp32 rows, every store instruction eight whole 128-byte lines (launcher: M % 16 == 0, Cout % 32 == 0)
+#pragma unroll
+      for (int i = 0; i < C::MI; ++i) {
+        const int mrow = m0c + wm * C::TM + i * 16 + (fr & 7);
+#pragma unroll
+        for (int t = 0; t < C::NJ / 2; ++t) {
+          const f16x8 lo = __builtin_bit_cast(f16x8, acc[2 * t][i]), hi = __builtin_bit_cast(f16x8, acc[2 * t + 1][i]);   // (16 bytes each: the lane's channels 0 - 3 and 4 - 7 of the block)
+          f16x8 s0, s1;
+          swap8(lo, hi, s0, s1);
+          const int n = n0c + wn * C::TN + t * 32 + fg * 8 + ((lane & 8) ? 4 : 0);
+          float* o = p.out_f32 + (int64_t)mrow * p.out_f32_ld + n;
+          if (mrow < p.M) {
+            __builtin_nontemporal_store(__builtin_bit_cast(f32x4, s0), reinterpret_cast<f32x4*>(o));
+            __builtin_nontemporal_store(__builtin_bit_cast(f32x4, s1), reinterpret_cast<f32x4*>(o + 8 * (int64_t)p.out_f32_ld));
+          }
+        }
+      }
+    } else
     // (rows outside, channel blocks inside: the 64-byte pieces a row's blocks contribute to one 128-byte line leave back to back)
 #pragma unroll
     for (int i = 0; i < C::MI; ++i) {
@@ -774,20 +914,25 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
 #undef TTR_SP_NEXT_DELTAS
 #undef TTR_SP_STAMP
 
-template <int BM, int BN, int WM, int WN, int XST, int WST, int MINB, bool SCHED, int NP = 3, int EPI = 0, int EM = 0, bool KS3 = false>
+static int g_sp_stagger = 0, g_sp_stagger_groups = 2;   // ConvParams::cu_stagger (ticks of 10 ns) and its group count
+void set_gemm_sp_stagger(int v) { g_sp_stagger = v; }
+void set_gemm_sp_stagger_groups(int v) { g_sp_stagger_groups = v < 1 ? 1 : v; }
+
+template <int BM, int BN, int WM, int WN, int XST, int WST, int MINB, bool SCHED, int NP = 3, int EPI = 0, int EM = 0, bool KS3 = false, int DBG = 0, bool STAG = false>
 static void launch_sp(const ConvParams& p_in, hipStream_t s) {
   using C = SpCfg<BM, BN, WM, WN, XST, WST>;
   constexpr int TABLE = EPI == 1 ? 57344 : 8208;   // behind the rings: the GELU table, or the attention epilogue's Q / K / V images
   ConvParams p = with_range_ctx(p_in);
+  p.cu_stagger = g_sp_stagger; p.cu_stagger_groups = g_sp_stagger_groups;
   if ((size_t)(C::LDS + TABLE) * MINB > 160 * 1024) p.gelu_lut = nullptr;   // no room for the table beside these rings: erf
   static PerDeviceOnce once;
   static_assert(EPI == 0 || C::LDS + TABLE <= 160 * 1024, "attention epilogue: rings + images must fit the LDS");
-  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_sp_kernel<BM, BN, WM, WN, XST, WST, MINB, SCHED, NP, EPI, EM, KS3>, hipFuncAttributeMaxDynamicSharedMemorySize, std::min(C::LDS + TABLE, 160 * 1024))); });
+  once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_sp_kernel<BM, BN, WM, WN, XST, WST, MINB, SCHED, NP, EPI, EM, KS3, DBG, STAG>, hipFuncAttributeMaxDynamicSharedMemorySize, std::min(C::LDS + TABLE, 160 * 1024))); });
   const size_t lds = C::LDS + (EPI == 1 || (p.act == kActGelu && p.gelu_lut) ? TABLE : 0);
   const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
   const int cap = device_cu_count(256) * MINB / 8 * 8;
   const int grid = std::min((tilesM * tilesN + 7) / 8 * 8, std::max(cap, 8));
-  hipLaunchKernelGGL((gemm_sp_kernel<BM, BN, WM, WN, XST, WST, MINB, SCHED, NP, EPI, EM, KS3>), dim3(grid), dim3(C::NT), lds, s, p);
+  hipLaunchKernelGGL((gemm_sp_kernel<BM, BN, WM, WN, XST, WST, MINB, SCHED, NP, EPI, EM, KS3, DBG, STAG>), dim3(grid), dim3(C::NT), lds, s, p);
 }
 
 static int g_qkv_attn_dbg = 0;   // timing experiments on the fused qkv + attention launch (results are wrong): 4 = the K loop alone
@@ -796,8 +941,13 @@ static unsigned long long* g_qkv_attn_stamps = nullptr;
 void set_qkv_attn_stamps(unsigned long long* d) { g_qkv_attn_stamps = d; }
 static int g_sp_few = 1;   // the few-tile rules of launch_gemm_sp (a page's worth of rows)
 void set_gemm_sp_few(int v) { g_sp_few = v; }
-static int g_sp_epi = 3;     // bits: 1 = fc1's case on its own kernels (EM = 1), 2 = the residual linears' (EM = 2) on the 256 x 128 triples tile (proj), 8 = on the other 128- / 256-row tiles, 4 = on the 64-row tiles; 0: the general kernel everywhere
+static int g_sp_epi = 3;   // (+ 16: fc1's stores as whole KiB pieces, EM = 3; + 32: the residual linears' fp32 rows as whole lines, EM = 4 - also on fc2's tile)
+static int g_sp_epi_unused = 3;     // bits: 1 = fc1's case on its own kernels (EM = 1), 2 = the residual linears' (EM = 2) on the 256 x 128 triples tile (proj), 8 = on the other 128- / 256-row tiles, 4 = on the 64-row tiles; 0: the general kernel everywhere
 void set_gemm_sp_epi(int v) { g_sp_epi = v; }
+static int g_sp_stag = 0;    // 1: waves 4 - 7 of fc1's eight-wave tile half a phase behind (gemm_sp_kernel's STAG: measured 4 - 5 % SLOWER, profiles/r06_parseq_kloop_experiments.txt); 0: every wave in step
+void set_gemm_sp_stag(int v) { g_sp_stag = v; }
+static int g_sp_dbg = 0;     // gemm_sp_kernel's DBG on fc1's and fc2's instances (timing experiments, wrong results): 1 = no loader requests, 2 = no fragment reads, 3 = neither
+void set_gemm_sp_dbg(int v) { g_sp_dbg = v; }
 static int g_sp_sched = 1;   // 1: fragment reads and requests interleaved with the first MFMAs of a phase; 0: in front of them
 void set_gemm_sp_sched(int v) { g_sp_sched = v; }
 
@@ -859,22 +1009,33 @@ void launch_gemm_sp(const ConvParams& p, int cfg, hipStream_t s) {
   // 555 -> 572 - its fixed case keeps 15 registers in scratch where the general kernel parks scalars in lanes - so that one stays on the general kernel; a page's
   // 64-row tiles: no difference)
   const bool em_res = plain && (g_sp_epi & (few ? 4 : (p.split == 4 && cfg == 2) ? 2 : 8)) && p.act == kActNone && p.resid && !p.out && p.out_f32;
+  const bool lines_fc1 = em_fc1 && (g_sp_epi & 16) && p.out_tiled == 1 && p.M % 16 == 0 && p.Cout % 64 == 0;
+  const bool lines_res = plain && (g_sp_epi & 32) && p.act == kActNone && p.resid && !p.out && p.out_f32 && p.M % 16 == 0 && p.Cout % 32 == 0 && !few;
   if (p.split == 4) {
     if (few) { if (em_res) launch_sp<64, 128, 2, 4, 3, 2, 1, true, 4, 0, 2>(p, s); else launch_sp<64, 128, 2, 4, 3, 2, 1, true, 4>(p, s); return; }
     if (mid) { launch_sp<96, 128, 2, 2, 3, 2, 2, true, 4>(p, s); return; }
     if (cfg == 6) launch_sp<128, 256, 2, 4, 3, 2, 1, true, 4>(p, s);
-    else if (cfg == 2) { if (em_res) launch_sp<256, 128, 4, 2, 3, 2, 1, true, 4, 0, 2>(p, s); else launch_sp<256, 128, 4, 2, 3, 2, 1, true, 4>(p, s); }
-    else { if (em_res) launch_sp<128, 128, 2, 2, 3, 2, 2, true, 4, 0, 2>(p, s); else launch_sp<128, 128, 2, 2, 3, 2, 2, true, 4>(p, s); }
+    else if (cfg == 2) { if (lines_res) launch_sp<256, 128, 4, 2, 3, 2, 1, true, 4, 0, 4>(p, s); else if (em_res) launch_sp<256, 128, 4, 2, 3, 2, 1, true, 4, 0, 2>(p, s); else launch_sp<256, 128, 4, 2, 3, 2, 1, true, 4>(p, s); }
+    else { if (lines_res) launch_sp<128, 128, 2, 2, 3, 2, 2, true, 4, 0, 4>(p, s); else if (em_res) launch_sp<128, 128, 2, 2, 3, 2, 2, true, 4, 0, 2>(p, s); else launch_sp<128, 128, 2, 2, 3, 2, 2, true, 4>(p, s); }
     return;
   }
   // (64 x 64 tiles, two per CU: the same 31 us - the CU's fill rate, not the workgroup's)
   if (few) { if (em_res) launch_sp<64, 128, 2, 4, 3, 3, 1, true, 3, 0, 2>(p, s); else launch_sp<64, 128, 2, 4, 3, 3, 1, true>(p, s); return; }
   if (mid) { launch_sp<96, 128, 2, 2, 3, 2, 2, true>(p, s); return; }
   // (a wide layer on one round of 128 x 256 tiles instead - fc1 at 40 crops: 240 - is no faster: 31 -> 32 - 37 us)
-  if (cfg == 6) { if (em_fc1) launch_sp<128, 256, 2, 4, 3, 3, 1, true, 3, 0, 1>(p, s); else if (sched) launch_sp<128, 256, 2, 4, 3, 3, 1, true>(p, s); else launch_sp<128, 256, 2, 4, 3, 3, 1, false>(p, s); }
+  if (cfg == 6 && em_fc1 && g_sp_dbg) {
+    if (g_sp_dbg == 1) launch_sp<128, 256, 2, 4, 3, 3, 1, true, 3, 0, 1, false, 1>(p, s); else if (g_sp_dbg == 4) launch_sp<128, 256, 2, 4, 3, 3, 1, true, 3, 0, 1, false, 4>(p, s); else launch_sp<128, 256, 2, 4, 3, 3, 1, true, 3, 0, 1, false, 8>(p, s);
+    return;
+  }
+  if (cfg != 6 && cfg != 2 && !table && !em_res && sched && g_sp_dbg) {
+    if (g_sp_dbg == 1) launch_sp<128, 128, 2, 2, 3, 2, 2, true, 3, 0, 0, false, 1>(p, s); else if (g_sp_dbg == 4) launch_sp<128, 128, 2, 2, 3, 2, 2, true, 3, 0, 0, false, 4>(p, s); else launch_sp<128, 128, 2, 2, 3, 2, 2, true, 3, 0, 0, false, 8>(p, s);
+    return;
+  }
+  if (cfg == 6 && em_fc1 && !lines_fc1 && g_sp_stag) { launch_sp<128, 256, 2, 4, 3, 3, 1, true, 3, 0, 1, false, 0, true>(p, s); return; }
+  if (cfg == 6) { if (lines_fc1) launch_sp<128, 256, 2, 4, 3, 3, 1, true, 3, 0, 3>(p, s); else if (em_fc1) launch_sp<128, 256, 2, 4, 3, 3, 1, true, 3, 0, 1>(p, s); else if (sched) launch_sp<128, 256, 2, 4, 3, 3, 1, true>(p, s); else launch_sp<128, 256, 2, 4, 3, 3, 1, false>(p, s); }
   else if (cfg == 2) { if (em_fc1) launch_sp<256, 128, 4, 2, 3, 3, 1, true, 3, 0, 1>(p, s); else if (sched) launch_sp<256, 128, 4, 2, 3, 3, 1, true>(p, s); else launch_sp<256, 128, 4, 2, 3, 3, 1, false>(p, s); }
   else if (table) { if (em_fc1) launch_sp<128, 128, 2, 2, 2, 2, 2, true, 3, 0, 1>(p, s); else if (sched) launch_sp<128, 128, 2, 2, 2, 2, 2, true>(p, s); else launch_sp<128, 128, 2, 2, 2, 2, 2, false>(p, s); }
-  else { if (em_res) launch_sp<128, 128, 2, 2, 3, 2, 2, true, 3, 0, 2>(p, s); else if (sched) launch_sp<128, 128, 2, 2, 3, 2, 2, true>(p, s); else launch_sp<128, 128, 2, 2, 3, 2, 2, false>(p, s); }
+  else { if (lines_res && mid == false) launch_sp<128, 128, 2, 2, 3, 2, 2, true, 3, 0, 4>(p, s); else if (em_res) launch_sp<128, 128, 2, 2, 3, 2, 2, true, 3, 0, 2>(p, s); else if (sched) launch_sp<128, 128, 2, 2, 3, 2, 2, true>(p, s); else launch_sp<128, 128, 2, 2, 3, 2, 2, false>(p, s); }
 }
 
 // The encoder's qkv projection + self-attention as ONE launch (EPI = 1 above).  x_pairs: LayerNorm output as f16 pairs [N * 128][2][384];

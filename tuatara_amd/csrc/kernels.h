@@ -37,6 +37,10 @@ void set_gemm_sp_sched(int v);
 void set_gemm_sp_few(int v);
 void set_gemm_sp_epi(int v);
 void set_gemm_sp_ks3(int v);
+void set_gemm_sp_dbg(int v);
+void set_gemm_sp_stag(int v);
+void set_gemm_sp_stagger(int v);          // start delay by workgroup (ConvParams::cu_stagger), ticks of 10 ns; 0 = off
+void set_gemm_sp_stagger_groups(int v);
 void set_qkv_attn_dbg(int v);
 void set_qkv_attn_stamps(unsigned long long* dev_buf);   // >= 24 * 16 u64, or null: phase stamps of the fused qkv + attention launch's workgroup 0
 bool gemm_sp_ks3_eligible(const ConvParams& p);
