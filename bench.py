@@ -38,6 +38,8 @@ sys.path.insert(0, ROOT)
 CRAFT_GFLOP_PER_PAGE = 559.5      # 27 convs, 2*MACs, BN folded, 1024x768
 PARSEQ_GFLOP_PER_CROP = 6.129     # encoder 5.747 + KV-cached AR 0.190 + refine 0.191
 MFMA_16BIT_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 / f16
+HBM_PIN_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+HBM_STREAM_GBPS = 6300.0          # what a streaming kernel reaches on this chip (the guide's 6.0 - 6.3 TB/s; profiles/r06_store_rate.txt: 6.2 - 6.8 for 16-byte stores of every shape)
 MFMA_F32_PEAK_TFLOPS = 157.3
 MFMA_PER_PRODUCT = {"f16x4": 4, "bf16": 1, "f32": 1}   # matrix-pipe flops per algorithmic flop (tuatara_amd/csrc/split.h): PARSeq
 CRAFT_MFMA_PER_PRODUCT = {"f16x4": 3, "bf16": 1, "f32": 1}   # ... CRAFT runs on activation pairs: three MFMAs per product
@@ -253,7 +255,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the comparison legs after the timed region (bf16 / fp32 engines, detected boxes, latency, host buffers)")
     ap.add_argument("--latency-iters", type=int, default=20)
     ap.add_argument("--stream", type=int, default=1, help="1: feed the passes through ttr_stream_push (batch j's detector and batch j-1's recogniser are enqueued before batch j-2's results are awaited, "
-                    "host box extraction overlaps GPU work; one stream, kernels still run alone); 0: one synchronous ttr_pages_to_data_dev call per pass")
+                    "host box extraction overlaps GPU work; two streams by default: batch j-1's recogniser runs beside batch j's detector, tuning key recog_overlap); 0: one synchronous ttr_pages_to_data_dev call per pass")
     ap.add_argument("--tune", action="append", default=[], help="engine tuning knob key=value (ttr_engine_set_tuning), repeatable")
     ap.add_argument("--mode", default="throughput", choices=["throughput", "latency"], help="latency: single pages through the sharded path (rank 0 detects, the crop batch is "
                     "broadcast and recognised in shards, ids all-gathered): reports p50_page_latency_ms for N GPUs")
@@ -418,7 +420,7 @@ def main():
     stage = eng.last_stage_ms()
     # In the timed region a batch's recogniser runs on its own stream beside the next batch's detector (tuning key "recog_overlap", the engine's default: +3 % pages/s):
     # the dominant kernel's launches then share the chip with the recogniser's, and their durations say so.  The same kernel ALONE on the chip: a few passes
-    # with the overlap off, outside the timed region -> roofline.exclusive
+    # with the overlap off, outside the timed region -> roofline.*_exclusive
     kinds_excl = None
     overlap_on = not any(kv.startswith("recog_overlap=0") for kv in args.tune) and stream
     if overlap_on and not args.no_extras and world == 1:
@@ -446,7 +448,11 @@ def main():
         if grid:                                   # the fixed grid: every page of every rank contributes exactly 40 rows of 26 ids
             assert (cts == 40).all() and gathered_rows == world * P * 40, (gathered_rows, world, P)
         assert gids.shape[1] == 26 and (gids >= 0).all() and (gids < 98).all()
-        dt = float(comm.allgather_host(np.array([dt], np.float64)).max())       # MAX over ranks
+        dts = comm.allgather_host(np.array([dt], np.float64)).reshape(-1)     # every rank's own time for its K steps
+        rank_rates = [float(P * args.steps * R / t) for t in dts]               # pages/s of each rank (weak scaling: equal work per rank)
+        dt = float(dts.max())                                                    # MAX over ranks
+    if not comm:
+        rank_rates = [float(P * args.steps * R / dt)]
     res = kept[-1]
     crops_per_page = float(np.mean([len(r) for r in res]))
     lens = np.bincount([len(t) for batch in kept for r in batch for t in r.texts], minlength=27)
@@ -460,18 +466,31 @@ def main():
         def line(k):
             """one kernel kind -> its roofline figures: ALGORITHMIC flops / time is `achieved`; what the matrix pipe executes beside it"""
             sec = k["ms"] * 1e-3
-            return {"kernel": k["kind"], "launches_per_pass": k["launches"] / max(1, n_pass), "avg_launch_us": k["ms"] * 1e3 / max(1, k["launches"]),
-                    "algorithmic_gflop_per_launch": k["alg_flops"] / max(1, k["launches"]) / 1e9,
-                    "achieved": k["alg_flops"] / sec / 1e12, "frac": k["alg_flops"] / sec / 1e12 / peak,
-                    "mfma_pipe_tflops": k["exec_flops"] / sec / 1e12, "mfma_pipe_frac": k["exec_flops"] / sec / 1e12 / peak,
-                    "mfma_flops_per_algorithmic_flop": k["exec_flops"] / k["alg_flops"] if k["alg_flops"] else None}
+            d = {"kernel": k["kind"], "launches_per_pass": k["launches"] / max(1, n_pass), "avg_launch_us": k["ms"] * 1e3 / max(1, k["launches"]),
+                 "algorithmic_gflop_per_launch": k["alg_flops"] / max(1, k["launches"]) / 1e9,
+                 "achieved": k["alg_flops"] / sec / 1e12, "frac": k["alg_flops"] / sec / 1e12 / peak,
+                 "mfma_pipe_tflops": k["exec_flops"] / sec / 1e12, "mfma_pipe_frac": k["exec_flops"] / sec / 1e12 / peak,
+                 "mfma_flops_per_algorithmic_flop": k["exec_flops"] / k["alg_flops"] if k["alg_flops"] else None}
+            # which roof binds this kind, and how far it is: the matrix pipe (executed flops / dense f16 peak) against the memory (ALGORITHMIC bytes - every operand
+            # read once, every result written once, at the engine's plane sizes - / time, over the 6.3 TB/s a streaming kernel reaches on this chip,
+            # profiles/r06_store_rate.txt and MI355X_MICROARCH.md; the 8 TB/s pin rate beside it)
+            by = k.get("alg_bytes") or 0.0
+            if by > 0:
+                gbps = by / sec / 1e9
+                d.update({"algorithmic_MB_per_launch": by / max(1, k["launches"]) / 1e6, "hbm_GBps": gbps, "hbm_frac_of_6300": gbps / HBM_STREAM_GBPS, "hbm_frac_of_8000": gbps / HBM_PIN_GBPS})
+                d["bound"] = "hbm" if gbps / HBM_STREAM_GBPS > d["mfma_pipe_frac"] else "mfma"
+                d["frac_of_binding_roof"] = max(gbps / HBM_STREAM_GBPS, d["mfma_pipe_frac"])
+            else:
+                d["bound"] = "mfma"
+                d["frac_of_binding_roof"] = d["mfma_pipe_frac"]
+            return d
 
         dom = max(craft_kinds, key=lambda k: k["ms"]) if craft_kinds else None
         fam_ms = sum(k["ms"] for k in craft_kinds)
         fam_alg, fam_exec = sum(k["alg_flops"] for k in craft_kinds), sum(k["exec_flops"] for k in craft_kinds)
         # HBM bytes per launch of the dominant kernel: the two --pmc passes (FETCH_SIZE doubled, WRITE_SIZE) committed under profiles/
         traffic = traffic_src = fam_traffic = det_gb_page = None
-        for name in (("r05_pmc_craft_x4.json", "r04_pmc_craft_x4.json", "r03_pmc_craft_x4.json") if args.precision == "f16x4" else ("r02_pmc_craft_b16_v2.json",)):
+        for name in (("r06_pmc_craft_x4.json", "r05_pmc_craft_x4.json", "r04_pmc_craft_x4.json", "r03_pmc_craft_x4.json") if args.precision == "f16x4" else ("r02_pmc_craft_b16_v2.json",)):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     tj = json.load(f)
@@ -498,15 +517,24 @@ def main():
             if overlap_on:
                 roof["shares_the_chip"] = ("in the timed region this kernel's launches run while the previous batch's recogniser is on the chip too (engine default \"recog_overlap\": "
                                            "the recogniser on its own stream, +3 % pages/s): avg_launch_us / achieved / frac are what the kernel gets of a shared machine; "
-                                           "`exclusive` = the same launches alone on the chip (overlap off, passes behind the timed region)")
+                                           "the *_exclusive keys = the same launches alone on the chip (overlap off, passes behind the timed region)")
             if kinds_excl:
                 ke = [k for k in kinds_excl if k["kind"] == dom["kind"] and k["stage"] == 0 and k["ms"] > 0 and k["launches"] > 0]
                 if ke:
                     e = line(ke[0])
                     e["launches_per_pass"] = ke[0]["launches"] / 4.0          # (four passes were measured)
-                    roof["exclusive"] = {kk: e[kk] for kk in ("launches_per_pass", "avg_launch_us", "algorithmic_gflop_per_launch", "achieved", "frac", "mfma_pipe_tflops", "mfma_pipe_frac")}
+                    # (scalar keys: a nested object did not survive into the driver's parsed record in round 5)
+                    roof.update({"frac_exclusive": e["frac"], "achieved_exclusive": e["achieved"], "avg_launch_us_exclusive": e["avg_launch_us"],
+                                 "mfma_pipe_frac_exclusive": e["mfma_pipe_frac"], "mfma_pipe_tflops_exclusive": e["mfma_pipe_tflops"], "launches_per_pass_exclusive": e["launches_per_pass"]})
+        try:
+            with open(os.path.join(ROOT, ".build_hash")) as f:
+                build_now = f.read().strip()
+        except OSError:
+            build_now = None
         roof.update({"traffic": traffic, "traffic_unit": "HBM bytes per launch of this kernel (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes over one CRAFT group)",
-                     "traffic_source": traffic_src})
+                     "traffic_profile": (traffic_src or {}).get("file"), "traffic_profile_build": (traffic_src or {}).get("build"), "build_hash": build_now,
+                     "traffic_note": "--pmc cannot run inside this process: the counters come from the committed profile named here, taken on the build traffic_profile_build; "
+                                     "build_hash is the library this line was measured on"})
         out = {
             "metric": "pages/sec whole-node (1024x768, ~40 crops/page)", "value": total_pages / dt, "unit": "pages/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -518,13 +546,15 @@ def main():
                        "words_drawn_per_page": args.words, "page_layout": layout + (" (one word inside each of the 40 grid boxes)" if grid else ""), "crops_per_page": round(crops_per_page, 1), "boxes": args.boxes,
                        "ar_steps": "early exit when every crop of the batch has emitted EOS (upstream PARSeq's break, system.py); value_full_ar runs all 26 steps",
                        "decoded_string_length_histogram": lens.tolist(),
-                       "distinct_pages": NB * P, "page_buffers_rotated": NB, "weights": "seeded synthetic (designed read-outs on random CRAFT / PARSeq, tuatara_amd/weights.py)",
+                       "distinct_pages": len({sd for b in seeds for sd in b}), "page_buffers_rotated": NB, "weights": "seeded synthetic (designed read-outs on random CRAFT / PARSeq, tuatara_amd/weights.py)",
                        "precision": {"f16x4": "fp32-equivalent split-operand f16 MFMA (tuatara_amd/csrc/split.h): PARSeq on exact activation triples x weight pairs (four MFMAs per product), "
                                               "CRAFT on activation pairs (three; its heat map stays at fp32 noise level); logits within 1e-3 of the CPU fp32 reference, boxes and "
                                               "strings identical (tests/test_gpu_x4_parity.py)",
                                      "bf16": "operands rounded to bf16: NOT output-equivalent (|dlogit| up to ~1e-1..1)", "f32": "fp32 MFMA"}[args.precision],
                        "parallelism": f"dp{world}" + (" (ranks SHARE one GPU over the TCP transport: a pre-flight, not a measurement)" if share else "")},
             "gathered_id_rows_last_pass": gathered_rows,
+            "per_rank_pages_per_s": {"min": min(rank_rates), "max": max(rank_rates), "by_rank": [round(x, 2) for x in rank_rates],
+                                     "is": "each rank's own pages/s over the timed steps (value = all ranks' pages / the slowest rank's time)"},
             "ranks": rank_map,
             "stage_ms_last_pass": {k: round(v, 3) for k, v in stage.items()},
             "roofline": roof,

@@ -64,8 +64,9 @@ int ttr_pages_to_data_dev(ttr_engine* e, const uint8_t* d_pages, int n, int h, i
 /* Streamed form of ttr_pages_to_data_dev for a sequence of batches (same contract per batch, results two calls later):
  * ttr_stream_push(j) enqueues the detector of batch j, then the recogniser of batch j-1, turns batch j's components into boxes on the
  * host while the GPU works, and returns batch j-2's results in out_prev[0 .. *n_prev) (*n_prev = 0 on the first two pushes).  The
- * GPU always has a whole detector or recogniser pass queued while the host decodes, returns and comes back with the next batch; one
- * stream, kernels still run one at a time.  The pages of a batch must stay valid until its results have been returned.
+ * GPU always has a whole detector or recogniser pass queued while the host decodes, returns and comes back with the next batch.  Two
+ * streams by default (tuning key "recog_overlap"): batch j-1's recogniser runs on a stream of its own beside batch j's detector (they
+ * share no buffer); results are identical to the synchronous call's.  The pages of a batch must stay valid until its results have been returned.
  * ttr_stream_flush returns the oldest batch still in flight (*n_prev = 0: none left; call it until then).  out_prev must hold as many
  * entries as the largest batch.  The synchronous calls refuse to run while streamed batches are in flight. */
 int ttr_stream_push(ttr_engine* e, const uint8_t* d_pages, int n, int h, int w, ttr_result** out_prev, int* n_prev);
@@ -74,7 +75,10 @@ int ttr_stream_flush(ttr_engine* e, ttr_result** out_prev, int* n_prev);
  * what a caller of the reference writes as a loop over image_to_data (/root/reference/bindings/run_ocr.py:92, examples/resume.cpp:11), with the models
  * loaded once (the reference reloads both per call, tuatara.cpp:336, :428).  Images of equal size travel together as batches through the streamed path
  * above; their rows are gathered into pinned staging buffers and copied to the device on an upload stream of their own while the previous batch is on the
- * GPU.  out[i] receives image i's result - input order, whatever the batching.  Every result equals what ttr_image_to_data returns for that image. */
+ * GPU.  out[i] receives image i's result - input order, whatever the batching.  Every result equals what ttr_image_to_data returns for that image.
+ * Returns 0; -1 when the call itself could not run (out[] untouched); k > 0 when k images failed - an unreadable entry (NULL, empty, a stride shorter than
+ * a row: the reference's "Error reading image from file", tuatara.cpp:344-347) or the images of a batch that failed on the GPU: those keep EMPTY results, every
+ * other out[i] is delivered, and ttr_last_error() lists the failed indices with the first failure's message - what a loop over image_to_data gives. */
 int ttr_images_to_data(ttr_engine* e, const uint8_t* const* images, const int* hs, const int* ws, const int* row_strides, int n, ttr_result** out);
 
 int ttr_result_count(const ttr_result* r);

@@ -80,6 +80,27 @@ def test_images_list_edge_cases(eng_x4, funsd):
     assert len(eng_x4.images_to_data([funsd[:256, :256]])[0]) > 0
 
 
+def test_images_one_unreadable_entry_fails_alone(eng_x4, funsd):
+    """a NULL / empty / short-stride entry in the middle of a list is the reference's "Error reading image from file" (tuatara.cpp:344-347) for
+    THAT image - a loop over image_to_data goes on with the next one.  ttr_images_to_data returns the count of failed images, leaves their results empty and
+    delivers every other result; ttr_last_error lists the indices."""
+    import ctypes as C
+    a, b = np.ascontiguousarray(funsd[:256, :256]), np.ascontiguousarray(funsd[300:556, 100:356])
+    n = 4
+    ptrs = (C.c_void_p * n)(a.ctypes.data, None, b.ctypes.data, b.ctypes.data)
+    hs = (C.c_int32 * n)(256, 256, 256, 256)
+    ws = (C.c_int32 * n)(256, 256, 256, 256)
+    st = (C.c_int32 * n)(768, 768, 768, 100)          # entry 3: a stride shorter than a row
+    out = (C.c_void_p * n)()
+    rc = eng_x4.lib.ttr_images_to_data(eng_x4.h, ptrs, hs, ws, st, n, out)
+    msg = eng_x4.lib.ttr_last_error().decode()
+    assert rc == 2, (rc, msg)
+    assert "2 of 4 images failed (indices 1 3)" in msg and "Error reading image" in msg, msg
+    got = eng_x4._take_many(out, n)
+    assert _same(got[0], eng_x4.image_to_data(a)) and _same(got[2], eng_x4.image_to_data(b)) and len(got[0]) > 0
+    assert got[1] == [] and got[3] == []
+
+
 def test_images_row_strides_through_the_c_abi(eng_x4, funsd):
     """ttr_images_to_data with row strides: images that are windows of a larger buffer, not copied by the caller."""
     import ctypes as C

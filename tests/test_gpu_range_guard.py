@@ -136,3 +136,84 @@ def test_non_finite_weights_are_refused_at_load(tmp_path):
     with pytest.raises(EngineError) as ei:
         Engine(str(tmp_path))
     assert "non-finite" in str(ei.value) and "linear1" in str(ei.value)
+
+
+@pytest.fixture(scope="module")
+def first_layer_hot_dir(tmp_path_factory):
+    """CRAFT's first convolution scaled by 1e6 (weights only): a black page passes (its output is the folded bias), any page with light on it leaves the f16
+    range in 'craft.slice1.0' - a detector trip that depends on the INPUT, so that one batch of a stream can fail between two that do not."""
+    from tuatara_amd import weights as W
+    c, p = W.synth_craft(0, False), W.synth_parseq(0)
+    d = str(tmp_path_factory.mktemp("w_craft_first_hot"))
+    c2 = dict(c)
+    name = [conv for nm, conv, bn, cin, cout, k in W.craft_layers() if nm == "slice1.0"][0]
+    c2[name + ".weight"] = c[name + ".weight"] * np.float32(1e6)
+    W.export_craft(c2, d)
+    W.export_parseq(p, d)
+    return d
+
+
+def test_streamed_batches_the_offending_batch_fails_and_its_neighbours_survive(first_layer_hot_dir):
+    """with streamed batches the detector of batch j and the recogniser of batch j - 1 are on the GPU together; one shared sticky word blamed
+    the wrong batch.  Now every stage and slot has its own word (engine.h: kRangeDet0 ...): the detector's is verified in detect_collect, before the batch's boxes
+    are used.  Three batches through ttr_stream_push - black pages, pages of noise, black pages: the push of the noise batch fails naming craft.slice1.0, the
+    batches before and after it come back, and the engine is usable afterwards."""
+    from tuatara_amd.engine import DeviceBuffer, EngineError
+    eng = _engine(first_layer_hot_dir)
+    H, W_, n = 256, 192, 2
+    black = np.zeros((n, H, W_, 3), np.uint8)
+    noise = np.random.default_rng(7).integers(0, 256, (n, H, W_, 3), dtype=np.uint8)
+    bufs = []
+    for a in (black, noise, black):
+        d = DeviceBuffer(a.nbytes)
+        d.upload(a)
+        bufs.append(d)
+    assert eng.stream_push(bufs[0], n, H, W_) == []                    # batch 0 in
+    with pytest.raises(EngineError) as ei:
+        eng.stream_push(bufs[1], n, H, W_)                             # batch 1: its own detector trips, it never enters the pipeline
+    msg = str(ei.value)
+    print(msg)
+    assert "range guard" in msg and "craft.slice1.0" in msg and "detector" in msg
+    got = []
+    r = eng.stream_push(bufs[2], n, H, W_)                             # batch 2: healthy
+    if r:
+        got.append(r)
+    for _ in range(3):
+        r = eng.stream_flush()
+        if not r:
+            break
+        got.append(r)
+    assert len(got) == 2 and all(len(b) == n for b in got), [len(b) for b in got]      # batches 0 and 2, n pages each
+    sync = eng.pages_to_data_dev(bufs[0], n, H, W_)                    # nothing left in flight: the synchronous call runs - and gives what the streamed batches gave
+    same = lambda a, b: len(a) == len(b) and all(x["text"] == y["text"] and x["bbox"] == y["bbox"] for x, y in zip(a, b))
+    assert all(same(p, q) for b in got for p, q in zip(b, sync))
+    with pytest.raises(EngineError):
+        eng.pages_to_data_dev(bufs[1], n, H, W_)
+    # the list form (ttr_images_to_data): the noise image's batch fails, the black images are delivered, the call reports which
+    res = eng.images_to_data([black[0], np.ascontiguousarray(noise[0].transpose(1, 0, 2)), black[1], np.zeros((64, 64, 3), np.uint8)])   # (the noise image 192 x 256: a size, hence a batch, of its own)
+    assert len(res) == 4 and res[1] == [] and same(res[0], sync[0]) and same(res[2], sync[1])
+    assert eng.last_images_error and "craft.slice1.0" in eng.last_images_error and " 1" in eng.last_images_error.split("):")[0], eng.last_images_error
+    assert "1 of 4 images failed" in eng.last_images_error
+    for d in bufs:
+        d.free()
+
+
+def test_stage_entry_points_refuse_while_batches_are_in_flight(eng_x4):
+    """ttr_parseq_logits / ttr_craft_heatmap share workspaces with the batches; with the recogniser of a streamed batch on a stream of its
+    own they would race with it.  They refuse, like the synchronous page calls, until ttr_stream_flush has returned everything."""
+    from tuatara_amd.engine import DeviceBuffer, EngineError
+    pages = np.full((1, 128, 160, 3), 255, np.uint8)
+    d = DeviceBuffer(pages.nbytes)
+    d.upload(pages)
+    eng_x4.stream_push(d, 1, 128, 160)
+    crops = np.zeros((2, 32, 128, 3), np.uint8)
+    try:
+        with pytest.raises(EngineError, match="in flight"):
+            eng_x4.parseq_logits(crops)
+        with pytest.raises(EngineError, match="in flight"):
+            eng_x4.craft_heatmap(np.zeros((64, 64, 3), np.uint8))
+    finally:
+        while eng_x4.stream_flush():
+            pass
+    eng_x4.parseq_logits(crops)
+    d.free()

@@ -97,8 +97,17 @@ int ttr_images_to_data(ttr_engine* e, const uint8_t* const* images, const int* h
   std::vector<Engine::HostImage> imgs((size_t)n);
   for (int i = 0; i < n; ++i) imgs[i] = Engine::HostImage{images[i], hs[i], ws[i], row_strides ? (std::ptrdiff_t)row_strides[i] : (std::ptrdiff_t)ws[i] * 3};
   std::vector<Result> res;
-  E.run_images(imgs, res);
+  std::vector<int> failed;
+  std::string first;
+  E.run_images(imgs, res, failed, first);
   for (int i = 0; i < n; ++i) { out[i] = new ttr_result(); out[i]->r = std::move(res[i]); }
+  if (!failed.empty()) {   // partial failure: every other image's result stands; the failed ones are empty (header)
+    std::string msg = std::to_string(failed.size()) + " of " + std::to_string(n) + " images failed (indices";
+    for (size_t k = 0; k < failed.size() && k < 16; ++k) msg += " " + std::to_string(failed[k]);
+    if (failed.size() > 16) msg += " ...";
+    g_last_error = msg + "): " + first;
+    return (int)failed.size();
+  }
   return 0;
   TTR_GUARD_END(-1)
 }
@@ -152,14 +161,15 @@ int ttr_craft_heatmap(ttr_engine* e, const uint8_t* canvas, int H, int W, float*
   TTR_GUARD_BEGIN
   Engine& E = *e->e;
   EngineScope lk(E);
+  E.refuse_while_streaming("ttr_craft_heatmap");
   E.canvas.ensure((size_t)H * W * 3);
   E.heat.ensure((size_t)H * W / 4 * 2 * 4);
   TTR_HIP_CHECK(hipMemcpyAsync(E.canvas.p, canvas, (size_t)H * W * 3, hipMemcpyHostToDevice, E.stream));
   E.craft_forward(E.canvas.as<uint8_t>(), 1, H, W, E.heat.as<float>());
   TTR_HIP_CHECK(hipMemcpyAsync(heat_out, E.heat.p, (size_t)H * W / 4 * 2 * 4, hipMemcpyDeviceToHost, E.stream));
-  E.range_fetch(2);
+  E.range_fetch(Engine::kRangeStage);
   TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
-  E.range_verify(2, "ttr_craft_heatmap");
+  E.range_verify(Engine::kRangeStage, "ttr_craft_heatmap");
   return 0;
   TTR_GUARD_END(-1)
 }
@@ -168,6 +178,7 @@ int ttr_ccl_boxes(ttr_engine* e, const float* heat, int H2, int W2, float* rects
   TTR_GUARD_BEGIN
   Engine& E = *e->e;
   EngineScope lk(E);
+  E.refuse_while_streaming("ttr_ccl_boxes");
   E.heat.ensure((size_t)H2 * W2 * 2 * 4);
   TTR_HIP_CHECK(hipMemcpyAsync(E.heat.p, heat, (size_t)H2 * W2 * 2 * 4, hipMemcpyHostToDevice, E.stream));
   E.ccl_launch(E.heat.as<float>(), 0, 1, 1, 0, H2, W2);
@@ -187,6 +198,7 @@ int ttr_resize_canvas(ttr_engine* e, const uint8_t* img, int h, int w, int row_s
   TTR_GUARD_BEGIN
   Engine& E = *e->e;
   EngineScope lk(E);
+  E.refuse_while_streaming("ttr_resize_canvas");
   const CanvasGeom g = canvas_geometry(h, w, E.cfg.canvas_size, E.cfg.mag_ratio);
   *H = g.h32; *W = g.w32; *ratio = g.ratio;
   const size_t need = (size_t)g.h32 * g.w32 * 3;
@@ -206,6 +218,7 @@ int ttr_pack_crops(ttr_engine* e, const uint8_t* img, int h, int w, int row_stri
   TTR_GUARD_BEGIN
   Engine& E = *e->e;
   EngineScope lk(E);
+  E.refuse_while_streaming("ttr_pack_crops");
   if (n <= 0) return 0;
   std::vector<int> rects((size_t)n * 5, 0);
   for (int i = 0; i < n; ++i) {
@@ -233,6 +246,7 @@ int ttr_parseq_logits(ttr_engine* e, const uint8_t* crops, int n, float* logits,
   TTR_GUARD_BEGIN
   Engine& E = *e->e;
   EngineScope lk(E);
+  E.refuse_while_streaming("ttr_parseq_logits");
   if (n <= 0) return 0;
   E.crops.ensure((size_t)n * 32 * 128 * 3);
   E.logits.ensure((size_t)n * 26 * 95 * 4);
@@ -243,9 +257,9 @@ int ttr_parseq_logits(ttr_engine* e, const uint8_t* crops, int n, float* logits,
   TTR_HIP_CHECK(hipMemcpyAsync(logits, E.logits.p, (size_t)n * 26 * 95 * 4, hipMemcpyDeviceToHost, E.stream));
   if (ar_logits) TTR_HIP_CHECK(hipMemcpyAsync(ar_logits, E.ar_logits.p, (size_t)n * 26 * 95 * 4, hipMemcpyDeviceToHost, E.stream));
   if (ids) TTR_HIP_CHECK(hipMemcpyAsync(ids, E.ids_dev.p, (size_t)n * 26 * 4, hipMemcpyDeviceToHost, E.stream));
-  E.range_fetch(2);
+  E.range_fetch(Engine::kRangeStage);
   TTR_HIP_CHECK(hipStreamSynchronize(E.stream));
-  E.range_verify(2, "ttr_parseq_logits");
+  E.range_verify(Engine::kRangeStage, "ttr_parseq_logits");
   return 0;
   TTR_GUARD_END(-1)
 }
@@ -283,12 +297,13 @@ int ttr_set_profiling(ttr_engine* e, int on) {
   E.profiling = on < 0 ? 0 : (on > 2 ? 2 : on);
   E.prof_recs.clear();
   for (int i = 0; i < 3; ++i) { E.prof_ms[i] = 0; E.prof_flops[i] = 0; E.prof_launches[i] = 0; }
-  for (auto& k : E.prof_kinds) { k.ms = 0; k.alg = 0; k.exec = 0; k.launches = 0; }
+  for (auto& k : E.prof_kinds) { k.ms = 0; k.alg = 0; k.exec = 0; k.launches = 0; k.bytes = 0; }
   return 0;
   TTR_GUARD_END(-1)
 }
 
-// The same records by kernel kind, as JSON text: [{"kind": name, "stage": 0|1|2, "launches": n, "ms": t, "alg_flops": a, "exec_flops": x}, ...]
+// The same records by kernel kind, as JSON text: [{"kind": name, "stage": 0|1|2, "launches": n, "ms": t, "alg_flops": a, "exec_flops": x, "alg_bytes": b}, ...]
+// (alg_bytes: the detector layers' algorithmic HBM bytes - every operand read once, every result written once, at the engine's plane sizes; 0 where not tallied)
 // (alg_flops: 2 x MACs of the layers, SURVEY.md section 8(d)'s figure; exec_flops: what the matrix cores execute for them).  Returns the
 // text's length (without the terminator); the text is truncated to cap - 1 characters.
 int ttr_get_profile_kinds(ttr_engine* e, char* buf, size_t cap) {
@@ -307,8 +322,8 @@ int ttr_get_profile_kinds(ttr_engine* e, char* buf, size_t cap) {
       else if ((unsigned char)ch < 0x20) { char u[8]; snprintf(u, sizeof u, "\\u%04x", (unsigned)(unsigned char)ch); name += u; }
       else name += ch;
     }
-    char line[256];
-    snprintf(line, sizeof line, "\", \"stage\": %d, \"launches\": %lld, \"ms\": %.6f, \"alg_flops\": %.6e, \"exec_flops\": %.6e}", k.stage, (long long)k.launches, k.ms, k.alg, k.exec);
+    char line[320];
+    snprintf(line, sizeof line, "\", \"stage\": %d, \"launches\": %lld, \"ms\": %.6f, \"alg_flops\": %.6e, \"exec_flops\": %.6e, \"alg_bytes\": %.6e}", k.stage, (long long)k.launches, k.ms, k.alg, k.exec, k.bytes);
     s += first ? "{\"kind\": \"" : ", {\"kind\": \"";
     s += name; s += line; first = false;
   }

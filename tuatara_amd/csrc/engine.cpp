@@ -20,18 +20,18 @@ void Engine::range_tag(const std::string& layer) {
   range_ctx().tag = it->second;
 }
 
-void Engine::range_fetch(int slot) {
+void Engine::range_fetch(int w) {
   if (!range_flag_ptr()) return;
-  TTR_HIP_CHECK(hipMemcpyAsync(h_range.as<unsigned>() + slot, range_word.p, 4, hipMemcpyDeviceToHost, stream));
+  TTR_HIP_CHECK(hipMemcpyAsync(h_range.as<unsigned>() + w, range_word.as<unsigned>() + w, 4, hipMemcpyDeviceToHost, stream));
+  TTR_HIP_CHECK(hipMemsetAsync(range_word.as<unsigned>() + w, 0, 4, stream));   // cleared by the stream that wrote it: the word's next user starts clean
 }
 
-void Engine::range_verify(int slot, const char* where) {
+void Engine::range_verify(int w, const char* where) {
   if (!range_flag_ptr()) return;
-  unsigned& w = h_range.as<unsigned>()[slot];
-  if (!w) return;
-  const std::string layer = w <= range_names.size() ? range_names[w - 1] : std::string("(untagged kernel)");
-  w = 0;
-  TTR_HIP_CHECK(hipMemsetAsync(range_word.p, 0, 4, stream));       // sticky until reported; the next batch starts clean
+  unsigned& v = h_range.as<unsigned>()[w];
+  if (!v) return;
+  const std::string layer = v <= range_names.size() ? range_names[v - 1] : std::string("(untagged kernel)");
+  v = 0;
   const std::string msg = std::string("f16x4 range guard (") + where + "): an activation of layer '" + layer + "' reached |x| >= 65504 (or an infinity): the split-operand "
                           "precision cannot represent it and has saturated - these weights need TTR_PREC_F32 (tuatara_amd/csrc/split.h)";
   if (tn.range_guard == 2) { std::cerr << "warning: " << msg << std::endl; return; }
@@ -97,7 +97,7 @@ void Engine::prof_collect() {
       const ProfRec& r = prof_recs[done];
       prof_ms[r.stage] += ms; prof_flops[r.stage] += r.exec; prof_launches[r.stage] += r.launches;
       ProfKind& k = prof_kinds[r.kind];
-      k.ms += ms; k.alg += r.alg; k.exec += r.exec; k.launches += r.launches;
+      k.ms += ms; k.alg += r.alg; k.exec += r.exec; k.launches += r.launches; k.bytes += r.bytes;
     }
   }
   if (done == 0) return;

@@ -261,9 +261,10 @@ struct Result {
 struct CclBatch {   // device workspaces of the CCL stage for a batch of equally sized pages
   DevBuf tnorm, flags, parent, mm, area, bbox, maxt, cand_slot, cand, counters, rows;
   DevBuf rects, cal_pool, cal_ctr;   // GPU-side minAreaRect: per-candidate results, the hulls' scratch pool and its bump counter
-  static constexpr int kCalCap = 4 << 20;   // floats (16 MB: ~230 k hull points per CRAFT group; a group that needs more falls back to the host's calipers)
+  static constexpr int kCalCap = 4 << 20;   // floats (16 MB: ~230 k hull points per CRAFT group - half of that per lane when two detector lanes are active; a group that needs more falls back to the host's calipers)
   int pages = 0, npx = 0, max_cand = 0;
   int cal_cap_now = kCalCap;          // (tuning key gpu_calipers = 2 shrinks it to 512 floats: the host-fallback path under test)
+  bool split_pool = false;            // two detector lanes are active for this batch: each takes half of the hulls' pool (set by detect_enqueue)
   CclBuffers view(int p0 = 0, int lane = 0) {   // the slices of pages p0.. (every array is strided by the page); lane: which half of the hulls' pool (two detector lanes)
     CclBuffers b;
     const size_t o = (size_t)p0 * npx;
@@ -272,7 +273,7 @@ struct CclBatch {   // device workspaces of the CCL stage for a batch of equally
     b.cand = cand.as<int>() + (size_t)p0 * max_cand * 8; b.counters = counters.as<int>() + (size_t)p0 * 2; b.rows_packed = rows.as<int>() + o * 2;
     b.max_cand = max_cand;
     b.rects = rects.as<float>() + (size_t)p0 * max_cand * 8;
-    b.cal_pool = cal_pool.as<float>() + (size_t)lane * (kCalCap / 2); b.cal_ctr = cal_ctr.as<int>() + lane; b.cal_cap = std::min(cal_cap_now, kCalCap / 2);
+    b.cal_pool = cal_pool.as<float>() + (split_pool ? (size_t)lane * (kCalCap / 2) : 0); b.cal_ctr = cal_ctr.as<int>() + lane; b.cal_cap = std::min(cal_cap_now, split_pool ? kCalCap / 2 : kCalCap);
     return b;
   }
   void ensure(int pages_, int npx_, int max_cand_) {
@@ -403,8 +404,8 @@ struct Engine {
   std::vector<hipEvent_t> prof_pool;
   // Every timed launch carries its KIND (which kernel family / which layer role), its ALGORITHMIC flops (2 x MACs of the layer: the figure
   // SURVEY.md section 8(d) prices the roofline with) and the flops the matrix cores EXECUTE for it (x 3 or x 4 in the split-operand mode).
-  struct ProfRec { int stage; int kind; double alg, exec; int launches; };
-  struct ProfKind { std::string name; int stage = 0; double ms = 0, alg = 0, exec = 0; long launches = 0; };
+  struct ProfRec { int stage; int kind; double alg, exec; int launches; double bytes = 0; };
+  struct ProfKind { std::string name; int stage = 0; double ms = 0, alg = 0, exec = 0; long launches = 0; double bytes = 0; };   // bytes: ALGORITHMIC HBM bytes (every operand read once, every result written once), 0 = not tallied
   std::vector<ProfKind> prof_kinds;
   std::map<std::string, int> prof_kind_ids;
   int kind_id(const char* name) {   // (a kind is a name in a stage: the decoder's linears run in the batched stage and in the AR steps)
@@ -418,21 +419,21 @@ struct Engine {
   }
   bool seg_open = false;                               // profiling == 1: an event pair brackets a RUN of consecutive CRAFT conv launches of one kind
   int seg_kind = -1;                                   // (an event record between two kernels costs ~8 us of idle GPU)
-  double seg_alg = 0, seg_exec = 0; int seg_launches = 0;
+  double seg_alg = 0, seg_exec = 0, seg_bytes = 0; int seg_launches = 0;
   std::vector<ProfRec> prof_recs;
   double prof_ms[3] = {0, 0, 0}, prof_flops[3] = {0, 0, 0};
   long prof_launches[3] = {0, 0, 0};
 
-  template <class F> void timed(const char* kind, double alg_flops, double exec_flops, F&& launch) {
+  template <class F> void timed(const char* kind, double alg_flops, double exec_flops, F&& launch, double alg_bytes = 0) {
     if (!profiling || (profiling == 1 && prof_stage != 0)) { launch(); return; }
     const int k = kind_id(kind);
     if (profiling == 1) {   // the timed region of bench.py: one event pair per run of same-kind convolutions, closed by the next kind or by prof_break()
       if (seg_open && seg_kind != k) prof_break();
       const size_t i = prof_recs.size();
       while (prof_pool.size() < 2 * (i + 1)) { hipEvent_t e; TTR_HIP_CHECK(hipEventCreate(&e)); prof_pool.push_back(e); }
-      if (!seg_open) { TTR_HIP_CHECK(hipEventRecord(prof_pool[2 * i], stream)); seg_open = true; seg_kind = k; seg_alg = seg_exec = 0; seg_launches = 0; }
+      if (!seg_open) { TTR_HIP_CHECK(hipEventRecord(prof_pool[2 * i], stream)); seg_open = true; seg_kind = k; seg_alg = seg_exec = seg_bytes = 0; seg_launches = 0; }
       launch();
-      seg_alg += alg_flops; seg_exec += exec_flops; ++seg_launches;
+      seg_alg += alg_flops; seg_exec += exec_flops; seg_bytes += alg_bytes; ++seg_launches;
       return;
     }
     const size_t i = prof_recs.size();
@@ -440,12 +441,12 @@ struct Engine {
     TTR_HIP_CHECK(hipEventRecord(prof_pool[2 * i], stream));
     launch();
     TTR_HIP_CHECK(hipEventRecord(prof_pool[2 * i + 1], stream));
-    prof_recs.push_back(ProfRec{prof_stage, k, alg_flops, exec_flops, 1});
+    prof_recs.push_back(ProfRec{prof_stage, k, alg_flops, exec_flops, 1, alg_bytes});
   }
   void prof_break() {       // call before any kernel that is not a CRAFT convolution, and at the end of CRAFT
     if (!seg_open) return;
     TTR_HIP_CHECK(hipEventRecord(prof_pool[2 * prof_recs.size() + 1], stream));
-    prof_recs.push_back(ProfRec{0, seg_kind, seg_alg, seg_exec, seg_launches});
+    prof_recs.push_back(ProfRec{0, seg_kind, seg_alg, seg_exec, seg_launches, seg_bytes});
     seg_open = false;
   }
   void igemm(const ConvParams& p, double true_flops, const char* kind = "igemm");
@@ -493,15 +494,21 @@ struct Engine {
 
   bool verbose = false;
   // ---- range guard of the split-operand mode (split.h: RangeWatch; kernels.h: range_ctx)
-  DevBuf range_word;                               // the sticky flag word: 0, or the tag of the first layer whose planes left the f16 range
-  PinnedBuf h_range;                               // [3] copies of it: streamed slots 0 / 1, stage entry points 2
+  // One sticky word PER STAGE AND SLOT (a word = 0, or the tag of the first layer whose planes left the f16 range): with streamed batches the detector of batch j
+  // (main stream) and the recogniser of batch j - 1 (recog_stream) are on the GPU together, and a word shared by both blamed the wrong batch.  A word is copied to
+  // its host slot and cleared by the stream that wrote it, right behind the kernels that could set it; the detector's is verified in detect_collect, before the
+  // batch's boxes are used, the recogniser's in finish.
+  enum { kRangeDet0 = 0, kRangeDet1 = 1, kRangeRec0 = 2, kRangeRec1 = 3, kRangeStage = 4, kRangeWords = 8 };
+  DevBuf range_word;                               // [kRangeWords] device words
+  PinnedBuf h_range;                               // [kRangeWords] host copies
   std::vector<std::string> range_names;            // tag - 1 -> layer name
   std::map<std::string, unsigned> range_ids;
   std::string range_scope;                         // prefix of the tags sgemm() forms from its profile kinds ("encoder.blocks.3.", "decoder.")
-  unsigned* range_flag_ptr() { return prec == kSplit && tn.range_guard ? range_word.as<unsigned>() : nullptr; }
+  unsigned* range_flag_ptr(int w = kRangeStage) { return prec == kSplit && tn.range_guard ? range_word.as<unsigned>() + w : nullptr; }
+  void range_use(int w) { range_ctx().flag = range_flag_ptr(w); }   // this thread's launches from here on watch word w
   void range_tag(const std::string& layer);        // names the layer whose launches follow (this thread's range_ctx().tag)
-  void range_fetch(int slot);                      // enqueue the word's copy to the host behind a batch's kernels
-  void range_verify(int slot, const char* where);  // after the batch's sync: a tripped word fails the call (or warns), then is cleared
+  void range_fetch(int w);                         // on `stream`, behind the kernels that watch word w: its copy to the host, then its clear
+  void range_verify(int w, const char* where);     // after the sync that covers the copy: a tripped word fails the call (or warns)
   // ---- multi-GPU (ttr_engine_attach_comm): every batch's token ids are all-gathered on the stream, device buffer to device buffer
   Comm* comm = nullptr;
   DevBuf gath_dev[2];
@@ -591,6 +598,7 @@ struct Engine {
     std::vector<std::vector<RRect>> boxes;
     std::vector<int> rects, page_of;
     int N = 0, slot = 0, group = 16;
+    int det_groups = -1;               // CRAFT groups enqueued for it (group_ev[det_groups]: behind the copy of its detector range word)
     bool live = false, enqueued = false;
     std::vector<int32_t> all_counts;   // with a communicator: crops per page of every rank [world][n]
     int cap = 0;                       // ... and the largest rank total (rows of the gathered payload per rank)
@@ -609,6 +617,9 @@ struct Engine {
 
   void finish(PageBatch& B, std::vector<Result>& results);
 
+  // the stage entry points (ttr_craft_heatmap, ttr_parseq_logits, ...) share workspaces with the batches: with the recogniser of a streamed batch on a stream of
+  // its own they would race with it
+  void refuse_while_streaming(const char* what) const { if (q1.live || q2.live) throw std::runtime_error(std::string(what) + ": streamed batches are in flight: call ttr_stream_flush until it returns none"); }
   void run_pages(const uint8_t* d_pages, int n, int h, int w, std::vector<Result>& results);
 
   // Latency mode (the reference's 6-thread fan-out over chunks of the crop batch, tuatara.cpp:450-485, across
@@ -633,7 +644,11 @@ struct Engine {
   DevBuf stage_dev[kStageSlots];
   hipStream_t up_stream = nullptr;
   hipEvent_t up_ev[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
-  void run_images(const std::vector<HostImage>& imgs, std::vector<Result>& results);
+  // results[i] = what run_pages returns for image i alone.  An unreadable entry (null / empty / short stride: the reference's "Error reading image from file",
+  // tuatara.cpp:344-347) and every image of a batch that failed on the GPU (e.g. the range guard) keep an empty result and are listed in `failed` (input
+  // indices; first_error: the first failure's message); everything else is delivered - what a loop over image_to_data does with one bad image.
+  void run_images(const std::vector<HostImage>& imgs, std::vector<Result>& results, std::vector<int>& failed, std::string& first_error);
+  int stream_fail_age = 0;   // set by stream_push / stream_flush before they throw: 0 = the batch being pushed never entered the pipeline, 2 = the batch whose results were due failed and has left it
 };
 
 }  // namespace ttr

@@ -1,5 +1,7 @@
 // image_to_data (tuatara.cpp:314-512) over batches of device-resident pages: detector + CCL -> boxes -> crop batch -> recogniser -> strings,
 // in four phases so that several batches can be in flight; the multi-GPU exchange points; the sharded latency mode.
+#include <deque>
+
 #include "engine.h"
 
 namespace ttr {
@@ -102,6 +104,7 @@ void Engine::ccl_collect(int p0, int pages, int g, int H2, int W2, std::vector<s
 }
 
 void Engine::detect_enqueue(PageBatch& B) {
+  range_use(kRangeDet0 + (B.slot & 1));   // the detector's kernels of this batch watch its own word (engine.h)
   if (B.h <= 0 || B.w <= 0) throw std::runtime_error("Error reading image from file");  // image.empty(), tuatara.cpp:344
   B.g = canvas_geometry(B.h, B.w, cfg.canvas_size, cfg.mag_ratio);
   if (B.g.target_h <= 0 || B.g.target_w <= 0) throw std::runtime_error("image too thin to resize");
@@ -126,6 +129,7 @@ void Engine::detect_enqueue(PageBatch& B) {
   // Two detector lanes (tn.craft_lanes, engine.h): odd groups on lane_stream with their own workspaces, half a group behind the even ones, so that a lane's
   // matrix-bound full-resolution layers run beside the other lane's HBM-bound U-Net tail and head (a group alone: 9.7 ms of the one, 2.8 of the other)
   const bool two = prec == kSplit && tn.craft_lanes == 2 && groups >= 2;
+  ccl.split_pool = two;
   if (two) {
     TTR_HIP_CHECK(hipEventRecord(resize_done, stream));
     TTR_HIP_CHECK(hipStreamWaitEvent(lane_stream, resize_done, 0));     // (the canvas; and everything the main stream held before it: the previous batch's detector)
@@ -153,6 +157,10 @@ void Engine::detect_enqueue(PageBatch& B) {
     }
   }
   if (two) TTR_HIP_CHECK(hipStreamWaitEvent(stream, lane_done, 0));       // the batch's detector is complete when the main stream gets here
+  range_fetch(kRangeDet0 + (B.slot & 1));
+  while ((int)group_ev.size() <= groups) { hipEvent_t e; TTR_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); group_ev.push_back(e); }
+  TTR_HIP_CHECK(hipEventRecord(group_ev[groups], stream));                // (behind the word's copy: detect_collect_local waits for it)
+  B.det_groups = groups;
   TTR_HIP_CHECK(hipEventRecord(ev[2], stream));
 }
 
@@ -186,6 +194,8 @@ void Engine::detect_collect_local(PageBatch& B) {
   B.rects.clear(); B.page_of.clear();        // x0,y0,x1,y1,page per crop; page index per crop
   host_us[1] = host_us[2] = host_us[3] = 0.f;
   for (int gi = 0; gi < groups; ++gi) ccl_collect(gi * GP, std::min(GP, n - gi * GP), gi, B.H2, B.W2, dets);
+  // the detector's range word of THIS batch, before any of its boxes is used: a saturated heat map fails this batch and no other
+  if (range_flag_ptr() && B.det_groups == groups) { spin_event(group_ev[groups]); range_verify(kRangeDet0 + (B.slot & 1), "the detector of a batch of pages"); }
   if (tn.detector_only) for (auto& d : dets) d.clear();   // profiling (tools/prof_pages.py): the detector and CCL run, nothing goes to the recogniser
   if (tn.bench_grid_boxes) {   // benchmark workload control (tuning key "bench_grid_boxes", tuatara_hip_debug.h): the detector's work is done (and timed); 40 fixed boxes per page go on
     for (int i = 0; i < n; ++i) {
@@ -220,6 +230,7 @@ void Engine::detect_collect_local(PageBatch& B) {
 
 void Engine::recog_enqueue(PageBatch& B) {
   const int N = B.N, sl = B.slot;
+  range_use(kRangeRec0 + (sl & 1));          // the recogniser's kernels of this batch watch the slot's own word
   h_ids[sl].ensure((size_t)N * 26 * 4 + 4);
   TTR_HIP_CHECK(hipEventRecord(evr[sl][0], stream));
   if (N > 0) {
@@ -247,7 +258,7 @@ void Engine::recog_enqueue(PageBatch& B) {
     comm->tr->all_gather(ids_dev.p, gath_dev[sl].p, per * 4, false, stream);
     TTR_HIP_CHECK(hipMemcpyAsync(h_gath[sl].p, gath_dev[sl].p, per * 4 * comm->world, hipMemcpyDeviceToHost, stream));
   }
-  range_fetch(sl);
+  range_fetch(kRangeRec0 + (sl & 1));
   TTR_HIP_CHECK(hipEventRecord(done_ev[sl], stream));
   B.enqueued = true;
 }
@@ -257,7 +268,7 @@ void Engine::finish(PageBatch& B, std::vector<Result>& results) {
   results.assign(n, Result());
   const double th2 = now_us();
   spin_event(done_ev[B.slot]);
-  range_verify(B.slot, "a batch of pages");
+  range_verify(kRangeRec0 + (B.slot & 1), "the recogniser of a batch of pages");
   const double th3 = now_us();
   // stage times: detector events belong to the latest batch enqueued (complete by now: its components were collected), recogniser events to this one
   (void)hipEventElapsedTime(&stage_ms[0], ev[0], ev[1]); (void)hipEventElapsedTime(&stage_ms[1], ev[1], ev[2]);
@@ -356,15 +367,16 @@ void Engine::run_pages_sharded(const uint8_t* d_pages, int n, int h, int w, std:
   c->tr->broadcast(crops.p, (size_t)N * 32 * 128 * 3, 0, stream);
   logits.ensure((size_t)per * 26 * 95 * 4);
   ids_dev.ensure((size_t)per * 26 * 4);
+  range_use(kRangeRec0);
   if (hi > lo) parseq_forward(crops.as<uint8_t>() + (size_t)lo * 32 * 128 * 3, hi - lo, logits.as<float>(), nullptr, ids_dev.as<int>());
   gath_dev[0].ensure((size_t)world * per * 26 * 4);
   h_gath[0].ensure((size_t)world * per * 26 * 4);
   c->tr->all_gather(ids_dev.p, gath_dev[0].p, (size_t)per * 26 * 4, false, stream);
   TTR_HIP_CHECK(hipMemcpyAsync(h_gath[0].p, gath_dev[0].p, (size_t)world * per * 26 * 4, hipMemcpyDeviceToHost, stream));
-  range_fetch(0);
+  range_fetch(kRangeRec0);
   TTR_HIP_CHECK(hipEventRecord(done_ev[0], stream));
   spin_event(done_ev[0]);
-  range_verify(0, "a sharded page");
+  range_verify(kRangeRec0, "the recogniser of a sharded page");
   if (rank != 0) return;
   const int32_t* ids = h_gath[0].as<int32_t>();                // shard r occupies rows [r * per, r * per + its size): crop k = row k
   std::vector<int> first(pages + 1, 0);
@@ -391,6 +403,7 @@ void Engine::stream_push(const uint8_t* d_pages, int n, int h, int w, std::vecto
   B.d_pages = d_pages; B.n = n; B.h = h; B.w = w;
   B.slot = q1.live ? (q1.slot ^ 1) : 0;     // from the pipeline's state, not a counter: a push that throws leaves q1 / q2 and the slot parity as they were
   std::exception_ptr pre;      // (with a communicator: a failing rank still takes part in this batch's header exchange, detect_collect)
+  stream_fail_age = 0;
   { RangeScope r("ttr:detect_enqueue"); try { detect_enqueue(B); } catch (...) { if (!comm) throw; pre = std::current_exception(); } }
   host_us[0] = (float)(now_us() - th0);
   const double th1 = now_us();
@@ -405,36 +418,50 @@ void Engine::stream_push(const uint8_t* d_pages, int n, int h, int w, std::vecto
   }
   host_us[4] = (float)(now_us() - th1);
   { RangeScope r("ttr:detect_collect"); detect_collect(B, pre); }
-  if (q2.live) { RangeScope r("ttr:finish"); prev_n = q2.n; finish(q2, prev_results); }
+  // (a batch whose recogniser tripped the range guard fails HERE, once: the pipeline still advances - on every rank alike, so no rank skips a collective its
+  // peers issue - and the neighbours' results survive)
+  std::exception_ptr fin;
+  if (q2.live) { RangeScope r("ttr:finish"); prev_n = q2.n; try { finish(q2, prev_results); } catch (...) { fin = std::current_exception(); prev_results.clear(); prev_n = 0; q2.live = false; } }
   if (q1.live) q2 = std::move(q1);
   q1 = std::move(B);
   q1.live = true; q1.enqueued = false;
+  if (fin) { stream_fail_age = 2; std::rethrow_exception(fin); }
 }
 
 void Engine::stream_flush(std::vector<Result>& prev_results, int& prev_n) {
   prev_results.clear(); prev_n = 0;
+  stream_fail_age = 2;
   if (q1.live && !q1.enqueued) {
     const bool sw = tn.recog_overlap != 0;
     if (sw) std::swap(stream, recog_stream);
     try { recog_enqueue(q1); } catch (...) { if (sw) std::swap(stream, recog_stream); throw; }
     if (sw) std::swap(stream, recog_stream);
   }
-  if (q2.live) { prev_n = q2.n; finish(q2, prev_results); return; }
-  if (q1.live) { prev_n = q1.n; finish(q1, prev_results); }
+  // (a batch that fails in finish leaves the pipeline: the next flush returns the next batch)
+  if (q2.live) { prev_n = q2.n; try { finish(q2, prev_results); } catch (...) { q2.live = false; prev_results.clear(); prev_n = 0; throw; } return; }
+  if (q1.live) { prev_n = q1.n; try { finish(q1, prev_results); } catch (...) { q1.live = false; prev_results.clear(); prev_n = 0; throw; } }
 }
 
 // ---- image_to_data over a list of host images (engine.h: run_images)
-void Engine::run_images(const std::vector<HostImage>& imgs, std::vector<Result>& results) {
+void Engine::run_images(const std::vector<HostImage>& imgs, std::vector<Result>& results, std::vector<int>& failed, std::string& first_error) {
   const int n = (int)imgs.size();
   results.assign(n, Result());
+  failed.clear(); first_error.clear();
   if (n == 0) return;
   if (q1.live || q2.live) throw std::runtime_error("streamed batches are in flight: call ttr_stream_flush until it returns none");
   if (comm) throw std::runtime_error("ttr_images_to_data runs on one engine: detach the communicator (every rank takes its own list)");
-  for (const HostImage& im : imgs)
-    if (!im.data || im.h <= 0 || im.w <= 0 || (im.row_stride >= 0 && im.row_stride < (std::ptrdiff_t)im.w * 3)) throw std::runtime_error("Error reading image from file");  // tuatara.cpp:344-347
+  std::vector<char> bad(n, 0);
+  for (int i = 0; i < n; ++i) {
+    const HostImage& im = imgs[i];
+    if (!im.data || im.h <= 0 || im.w <= 0 || (im.row_stride >= 0 && im.row_stride < (std::ptrdiff_t)im.w * 3)) {   // tuatara.cpp:344-347: this image yields nothing, the others go on
+      std::cerr << "Error reading image from file";
+      bad[i] = 1; failed.push_back(i);
+      if (first_error.empty()) first_error = "Error reading image from file (image " + std::to_string(i) + ")";
+    }
+  }
   // buckets of equal (h, w), the largest canvases first (the engine's grow-only workspaces then grow once), cut into batches
   std::map<std::pair<int, int>, std::vector<int>> by_size;
-  for (int i = 0; i < n; ++i) by_size[{imgs[i].h, imgs[i].w}].push_back(i);
+  for (int i = 0; i < n; ++i) if (!bad[i]) by_size[{imgs[i].h, imgs[i].w}].push_back(i);
   std::vector<std::pair<std::pair<int, int>, std::vector<int>>> buckets(by_size.begin(), by_size.end());
   std::stable_sort(buckets.begin(), buckets.end(), [&](const auto& a, const auto& b) {
     const CanvasGeom ga = canvas_geometry(a.first.first, a.first.second, cfg.canvas_size, cfg.mag_ratio), gb = canvas_geometry(b.first.first, b.first.second, cfg.canvas_size, cfg.mag_ratio);
@@ -480,33 +507,52 @@ void Engine::run_images(const std::vector<HostImage>& imgs, std::vector<Result>&
     if (cnt != (int)batches[j].idx.size()) throw std::runtime_error("ttr_images_to_data: a batch came back with another page count");
     for (int k = 0; k < cnt; ++k) results[batches[j].idx[k]] = std::move(res[k]);
   };
-  auto drain = [&]() {                                                 // an error mid-list: nothing stays in flight behind it
+  auto fail_batch = [&](int j, const std::string& why) {               // a batch that failed on the GPU: its images keep empty results, the list goes on
+    for (int i : batches[j].idx) failed.push_back(i);
+    if (first_error.empty()) first_error = why + " (images of batch " + std::to_string(j) + ")";
+    std::cerr << "tuatara: " << why << std::endl;
+  };
+  auto drain = [&]() {                                                 // a call-level error mid-list: nothing stays in flight behind it
     std::vector<Result> r; int c = 0;
     for (int guard = 0; guard < 3 && (q1.live || q2.live); ++guard) { try { stream_flush(r, c); } catch (...) { q1 = PageBatch(); q2 = PageBatch(); } }
   };
+  if (nb == 0) { std::sort(failed.begin(), failed.end()); return; }
+  std::deque<int> inflight;                                            // batches inside the streamed pipeline, oldest first
   stage(0);
   if (stage_err) std::rethrow_exception(stage_err);
   try {
     for (int j = 0; j < nb; ++j) {
       if (helper.joinable()) helper.join();
       if (stage_err) std::rethrow_exception(stage_err);
-      if (j + 1 < nb) helper = std::thread(stage, j + 1);               // (slot (j + 1) % 4 last held batch j - 3: returned one push ago)
+      if (j + 1 < nb) helper = std::thread(stage, j + 1);               // (slot (j + 1) % 4 last held batch j - 3: returned one push ago at the latest)
       TTR_HIP_CHECK(hipStreamWaitEvent(stream, up_ev[j % kStageSlots], 0));
       std::vector<Result> prev; int np = 0;
-      stream_push(stage_dev[j % kStageSlots].as<uint8_t>(), (int)batches[j].idx.size(), batches[j].h, batches[j].w, prev, np);
-      if (np) deliver(j - 2, prev, np);
+      try {
+        stream_push(stage_dev[j % kStageSlots].as<uint8_t>(), (int)batches[j].idx.size(), batches[j].h, batches[j].w, prev, np);
+        inflight.push_back(j);
+        if (np) { deliver(inflight.front(), prev, np); inflight.pop_front(); }
+      } catch (const std::exception& ex) {
+        if (stream_fail_age == 2 && !inflight.empty()) { fail_batch(inflight.front(), ex.what()); inflight.pop_front(); inflight.push_back(j); }   // the batch whose results were due; j is in
+        else fail_batch(j, ex.what());                                                                                                            // batch j's own detector: it never entered
+      }
     }
     if (helper.joinable()) helper.join();
-    for (int j = std::max(0, nb - 2); j < nb; ++j) {
+    while (!inflight.empty()) {
       std::vector<Result> prev; int np = 0;
-      stream_flush(prev, np);
-      if (np) deliver(j, prev, np);
+      try {
+        stream_flush(prev, np);
+        if (np) deliver(inflight.front(), prev, np);
+        else throw std::runtime_error("ttr_images_to_data: the pipeline ran dry with batches outstanding");
+      } catch (const std::exception& ex) { fail_batch(inflight.front(), ex.what()); }
+      inflight.pop_front();
     }
   } catch (...) {
     if (helper.joinable()) helper.join();
     drain();
     throw;
   }
+  drain();   // (nothing should be left; a batch that failed inside a push may have left a neighbour parked)
+  std::sort(failed.begin(), failed.end());
 }
 
 }  // namespace ttr

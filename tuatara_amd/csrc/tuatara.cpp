@@ -74,15 +74,17 @@ std::vector<std::vector<OutputItem>> images_to_data(const std::vector<ImageView>
   std::vector<const uint8_t*> ptr(n);
   std::vector<int> hs(n), ws(n), st(n);
   for (int i = 0; i < n; ++i) {
-    if (!images[i].data || images[i].rows <= 0 || images[i].cols <= 0) { std::cerr << "Error reading image from file"; return {}; }   // tuatara.cpp:344-347
+    // (an unreadable entry - tuatara.cpp:344-347 - yields an empty list for that image alone: the engine prints the reference's message)
     ptr[i] = images[i].data; hs[i] = images[i].rows; ws[i] = images[i].cols;
     st[i] = images[i].row_stride ? (int)images[i].row_stride : images[i].cols * 3;
   }
   std::vector<ttr_result*> rs(n, nullptr);
-  if (n && ttr_images_to_data(e, ptr.data(), hs.data(), ws.data(), st.data(), n, rs.data()) != 0) {
+  const int rc = n ? ttr_images_to_data(e, ptr.data(), hs.data(), ws.data(), st.data(), n, rs.data()) : 0;
+  if (rc < 0) {   // the call could not run at all
     std::cerr << "tuatara: " << ttr_last_error() << std::endl;
     return {};
   }
+  if (rc > 0) std::cerr << "tuatara: " << ttr_last_error() << std::endl;   // some images failed: theirs stay empty, the rest are returned (a loop over image_to_data)
   std::vector<std::vector<OutputItem>> out(n);
   for (int i = 0; i < n; ++i) {
     out[i].resize(ttr_result_count(rs[i]));

@@ -335,7 +335,12 @@ class Engine:
         hs = (C.c_int32 * n)(*[a.shape[0] for a in arrs])
         ws = (C.c_int32 * n)(*[a.shape[1] for a in arrs])
         out = (C.c_void_p * n)()
-        self._check(self.lib.ttr_images_to_data(self.h, ptrs, hs, ws, None, n, out))
+        rc = self.lib.ttr_images_to_data(self.h, ptrs, hs, ws, None, n, out)
+        self.last_images_error = None
+        if rc < 0:
+            self._check(rc)
+        if rc > 0:                              # rc images failed: their results are empty, the others delivered (include/tuatara_hip.h)
+            self.last_images_error = self.lib.ttr_last_error().decode()
         if keep:
             return self._take_many(out, n)
         counts = []
