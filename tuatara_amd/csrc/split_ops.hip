@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void upsample2x_planes_kernel(const f16* __res
 // with split operands.  A pixel's 27 inputs are u8 / 255 in fp32 (the reference's division, tuatara.cpp:367-370): their three planes
 // come from three 256-entry tables built once per workgroup; the weights are the layer's three planes [64][3][32].
 template <int NPL>
-__global__ __launch_bounds__(256) void conv1_split_kernel(const uint8_t* __restrict__ canvas, const f16* __restrict__ wgt /*[64][3][32]*/, const float* __restrict__ bias,
+__global__ __launch_bounds__(256, NPL == 2 ? 4 : 3) void conv1_split_kernel(const uint8_t* __restrict__ canvas, const f16* __restrict__ wgt /*[64][3][32]*/, const float* __restrict__ bias,
                                                          float out_scale, f16* __restrict__ out /*[M][3*64]*/, int B, int H, int W, unsigned* range_flag, unsigned range_tag) {
   // A wave takes 64 consecutive pixels of one row (W % 32 == 0: the last segment of a row may hold 32).  The three canvas rows around them come
   // in as 51 aligned dwords each (row bytes 3 x0 - 4 .. 3 x0 + 199: one pixel of halo either side; 3 W and 3 x0 - 4 are multiples of 4) into the
@@ -167,24 +167,56 @@ __global__ __launch_bounds__(256) void conv1_split_kernel(const uint8_t* __restr
     srow[e] = k < 27 ? k / 9 : -1; soff[e] = 1 + (k % 9);
   }
   const int segs = (W + 63) >> 6;
-  const int64_t ntasks = (int64_t)B * H * segs;
-  const int64_t nwaves = (int64_t)gridDim.x * 4, wave0 = (int64_t)blockIdx.x * 4 + wave;
+  const int ntasks = B * H * segs;                       // (launcher: < 2^31)
+  const int nwaves = (int)gridDim.x * 4, wave0 = (int)blockIdx.x * 4 + wave;
   uint8_t (*st)[208] = strip[wave];
-  for (int64_t task = wave0; task < ntasks; task += nwaves) {
-    const int seg = (int)(task % segs);
-    const int64_t by = task / segs;                      // b * H + y
-    const int y = (int)(by % H), x0 = seg << 6, npx = min(64, W - x0);
+  // The canvas rows of a task are REQUESTED a task ahead, in front of the previous task's stores, and awaited with a counted s_waitcnt behind them: vmcnt counts loads and
+  // stores together in issue order, so a load behind 16 - 24 stores that is awaited with vmcnt(0) waits for every one of those stores to be acknowledged - once per
+  // task, 100 of this kernel's 430 us per 8-page group (measured with the arithmetic switched off: the stores alone 283 us, the stores behind these loads 381;
+  // profiles/r06_conv1_split.txt).  The loads are inline asm (buffer loads: lanes
+  // outside the row or the image get an out-of-range offset and read zero) so that the compiler does not put its own vmcnt(0) in front of their use.
+  typedef __attribute__((ext_vector_type(4))) int i32x4;
+  const size_t canvas_bytes = (size_t)B * H * W * 3;
+  const i32x4 rs = {(int)(unsigned)(uintptr_t)canvas, (int)(unsigned)((uintptr_t)canvas >> 32), (int)(unsigned)std::min<size_t>(canvas_bytes, 0xFFFFFFFFu), 0x00020000};
+  constexpr unsigned OOB = 0x80000000u;
+  struct Pos { int seg, by, y; };
+  auto request = [&](const Pos& q, unsigned (&v)[3]) {
+    const int x0 = q.seg << 6;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int yy = q.y - 1 + r;
+      const bool ok = lane < 51 && yy >= 0 && yy < H && !(x0 == 0 && lane == 0) && 4 * lane < 3 * (W - x0) + 4;   // (inside the row: the right halo pixel too, where there is one)
+      const unsigned off = ok ? (unsigned)(((q.by - q.y + yy) * W + x0) * 3 - 4 + 4 * lane) : OOB;                 // (launcher: the canvas is below 2 GB)
+      asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(v[r]) : "v"(off), "s"(rs) : "memory");
+    }
+  };
+  Pos pos{wave0 % segs, wave0 / segs, 0};
+  pos.y = pos.by % H;
+  const int dseg = nwaves % segs, dby = nwaves / segs, dy = dby % H;
+  unsigned cur[3] = {0u, 0u, 0u};
+  if (wave0 < ntasks) {
+    request(pos, cur);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]) : : "memory");
+  }
+  constexpr int kStores = 4 * 2 * NPL;                   // store instructions of a task with all four 16-pixel blocks inside the row
+  for (int task = wave0; task < ntasks; task += nwaves) {
+    const int seg = pos.seg, by = pos.by, y = pos.y;
+    const int x0 = seg << 6, npx = min(64, W - x0);
+    (void)y;
     if (lane < 51) {
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const int yy = y - 1 + r;
-        const bool ok = yy >= 0 && yy < H && !(x0 == 0 && lane == 0) && 4 * lane < 3 * (W - x0) + 4;   // (inside the row: the right halo pixel too, where there is one)
-        unsigned v = 0;
-        if (ok) v = *reinterpret_cast<const unsigned*>(canvas + ((by - y + yy) * W + x0) * 3 - 4 + 4 * lane);
-        *reinterpret_cast<unsigned*>(&st[r][4 * lane]) = v;
-      }
+      for (int r = 0; r < 3; ++r) *reinterpret_cast<unsigned*>(&st[r][4 * lane]) = cur[r];
     }
-    f32x4 acc[4][4];
+    // the next task's position and the request for its rows (uniform over the wave)
+    Pos nx{seg + dseg, by + dby, y + dy};
+    if (nx.seg >= segs) { nx.seg -= segs; ++nx.by; ++nx.y; }
+    if (nx.y >= H) nx.y -= H;
+    const bool has_next = task + nwaves < ntasks;
+    unsigned nxt[3] = {0u, 0u, 0u};
+    if (has_next) request(nx, nxt);
+    // (per block of 16 pixels: its 12 - 16 MFMAs, then its epilogue and stores - the accumulators of one block are live at a time, so that four workgroups share a
+    // CU: with the four blocks' MFMAs first and their epilogues behind, 64 accumulator registers put the kernel at two waves per SIMD and 3.9 TB/s of its 6.3)
+    const int64_t m0 = (int64_t)by * W + x0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int px = i * 16 + fr;
@@ -195,30 +227,34 @@ __global__ __launch_bounds__(256) void conv1_split_kernel(const uint8_t* __restr
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) fx[pl][e] = lut[pl][byte];
       }
+      f32x4 acc[4];
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[0][jj], fx[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         a = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[1][jj], fx[1], a, 0, 0, 0);
         if constexpr (NPL == 3) a = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[1][jj], fx[2], a, 0, 0, 0);
-        acc[jj][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[2][jj], fx[0], a, 0, 0, 0);
+        acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[2][jj], fx[0], a, 0, 0, 0);
       }
-    }
-    const int64_t m0 = by * W + x0;
+      if (px < npx) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int px = i * 16 + fr;
-      if (px >= npx) continue;
+        for (int t = 0; t < 2; ++t) {
+          V8 o;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        V8 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          o.v[e] = fmaxf(fmaf(acc[2 * t][i][e], out_scale, bv[t][e]), 0.f);
-          o.v[4 + e] = fmaxf(fmaf(acc[2 * t + 1][i][e], out_scale, bv[t][4 + e]), 0.f);
+          for (int e = 0; e < 4; ++e) {
+            o.v[e] = fmaxf(fmaf(acc[2 * t][e], out_scale, bv[t][e]), 0.f);
+            o.v[4 + e] = fmaxf(fmaf(acc[2 * t + 1][e], out_scale, bv[t][4 + e]), 0.f);
+          }
+          st_planes<NPL>(out + (m0 + px) * (NPL * 64) + 32 * t + fg * 8, 64, o, rw);
         }
-        st_planes<NPL>(out + (m0 + px) * (NPL * 64) + 32 * t + fg * 8, 64, o, rw);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
+    if (has_next) {   // the requested rows have landed once all but this task's stores (issued behind them) are done
+      if (npx == 64) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]) : "n"(kStores) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]) : : "memory");
+      cur[0] = nxt[0]; cur[1] = nxt[1]; cur[2] = nxt[2];
+    }
+    pos = nx;
   }
   rw.flush(range_flag, range_tag);
 }
@@ -242,6 +278,7 @@ void launch_upsample2x_planes(const void* in, void* out, int B, int H, int W, in
 void launch_conv1_split(const uint8_t* canvas, const void* wgt_planes, const float* bias, float out_scale, void* out, int B, int H, int W, hipStream_t s, int planes) {
   if (W % 32) throw std::runtime_error("conv1_split: the canvas width must be a multiple of 32");
   const int64_t tasks = (int64_t)B * H * ((W + 63) / 64);
+  if (tasks >= ((int64_t)1 << 31) || (int64_t)B * H * W * 3 >= ((int64_t)1 << 31)) throw std::runtime_error("conv1_split: the canvas batch exceeds 2 GB (32-bit offsets); the caller groups the pages");
   const int grid = (int)std::min<int64_t>((tasks + 3) / 4, 256 * 16);
   if (planes == 2) hipLaunchKernelGGL(conv1_split_kernel<2>, dim3(grid), dim3(256), 0, s, canvas, (const f16*)wgt_planes, bias, out_scale, (f16*)out, B, H, W, range_ctx().flag, range_ctx().tag);
   else hipLaunchKernelGGL(conv1_split_kernel<3>, dim3(grid), dim3(256), 0, s, canvas, (const f16*)wgt_planes, bias, out_scale, (f16*)out, B, H, W, range_ctx().flag, range_ctx().tag);

@@ -24,10 +24,23 @@ from typing import List, Optional, Sequence, Tuple
 CHILD_ENV = "TUATARA_RANK_CHILD"      # set in every rank this launcher starts (a rank never launches again)
 
 
+def free_ports(addr: str = "127.0.0.1", count: int = 1) -> List[int]:
+    """`count` free TCP ports, all DIFFERENT: the sockets are held open together while the kernel hands the numbers out (two back-to-back probes of one
+    socket each could return the same number twice - MASTER_PORT and the ranks' own rendezvous port then collided)."""
+    socks = []
+    try:
+        for _ in range(count):
+            s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            s.bind((addr, 0))
+            socks.append(s)
+        return [s.getsockname()[1] for s in socks]
+    finally:
+        for s in socks:
+            s.close()
+
+
 def free_port(addr: str = "127.0.0.1") -> int:
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind((addr, 0))
-        return s.getsockname()[1]
+    return free_ports(addr, 1)[0]
 
 
 def wants_launch(gpus: int) -> bool:
@@ -61,10 +74,14 @@ def run_ranks(script: str, argv: Sequence[str], world: int, deadline_s: float = 
     left with 0 and rank 0 printed a JSON line; 124 when the deadline passed; otherwise the first failing rank's status."""
     out = out or sys.stdout
     err = err or sys.stderr
-    port = port or free_port(addr)
     # the ranks' own rendezvous (comm.cpp: RCCL unique id / the framed-TCP transport) listens on TUATARA_COMM_PORT; its default MASTER_PORT + 1 was
-    # never probed, so another listener there (a concurrent launch) left rank 0 spinning in bind().  Reserve a second free port unless the caller chose one
-    comm_port = os.environ.get("TUATARA_COMM_PORT") or str(free_port(addr))
+    # never probed, so another listener there (a concurrent launch) left rank 0 spinning in bind().  Both ports come from one probe that holds two
+    # sockets at once, so they differ from each other; a caller-chosen TUATARA_COMM_PORT equal to MASTER_PORT is replaced
+    probed = free_ports(addr, 2)
+    port = port or probed[0]
+    comm_port = os.environ.get("TUATARA_COMM_PORT") or str(probed[1] if probed[1] != port else probed[0])
+    if int(comm_port) == int(port):
+        comm_port = str(next(p for p in free_ports(addr, 3) if p != port))
     procs: List[subprocess.Popen] = []
     lines0: List[str] = []
 
