@@ -208,15 +208,16 @@ def test_bench_starts_its_own_ranks_two_ranks_on_one_gpu(weights):
     assert len(d["per_rank_pages_per_s"]["by_rank"]) == 2 and d["per_rank_pages_per_s"]["min"] <= d["per_rank_pages_per_s"]["max"]
 
 
-def test_bench_six_ranks_share_one_gpu(weights):
-    """The same pre-flight at the widest world this pool lets one GPU carry (its process guard ends a run with more than six processes on the card, so the
-    driver's eight cannot be rehearsed here): six-rank rendezvous, the `flock`ed build, ONE /dev/shm page set with six readers, header / counts / payload gathers at
-    world 6 for every streamed pass, `ranks` and the per-rank rates with six entries.  Mirrors the six-thread fan-out of /root/reference/tuatara.cpp:461-475 one
+def test_bench_five_ranks_share_one_gpu(weights):
+    """The same pre-flight at the widest world this pool lets one GPU carry inside the test suite (its process guard ends a run with more than six processes on
+    the card - the test process holds the GPU too - so the driver's eight cannot be rehearsed here; six ranks ran from a bare shell, gpurun_out/n6_share_gpu.json):
+    five-rank rendezvous, the `flock`ed build, ONE /dev/shm page set with five readers, header / counts / payload gathers at world 5 for every streamed pass,
+    `ranks` and the per-rank rates with five entries.  Mirrors the six-thread fan-out of /root/reference/tuatara.cpp:461-475 one
     level up (whole ranks instead of threads).  The line is kept under gpurun_out/ for the record."""
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     env.update(TUATARA_BENCH_SHARE_GPU="1", TUATARA_PRELOAD_TORCH="0", TUATARA_COMM_TIMEOUT="300")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "6", "--steps", "2", "--warmup", "1", "--pages", "8", "--buffers", "3", "--deadline", "1200",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "5", "--steps", "2", "--warmup", "1", "--pages", "8", "--buffers", "3", "--deadline", "1200",
                           "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=1300, env=env)
     assert out.returncode == 0, (out.stdout[-500:], out.stderr[-3000:])
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -224,12 +225,12 @@ def test_bench_six_ranks_share_one_gpu(weights):
     d = json.loads(lines[0])
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "n6_share_gpu.json"), "w") as f:
+        with open(os.path.join(ROOT, "gpurun_out", "n5_share_gpu.json"), "w") as f:
             f.write(lines[0] + "\n")
     except OSError:
         pass
-    assert d["n_gpus"] == 6 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["gathered_id_rows_last_pass"] == 6 * 8 * 40
-    assert len(d["ranks"]) == 6 and sorted(int(r["rank"]) for r in d["ranks"]) == list(range(6))
-    assert len(d["per_rank_pages_per_s"]["by_rank"]) == 6
-    assert abs(d["value"] - 6 * 8 * 2 / (d["ms_per_step"] * 2 * 1e-3)) / d["value"] < 1e-6      # value = all ranks' pages / the slowest rank's time
+    assert d["n_gpus"] == 5 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["gathered_id_rows_last_pass"] == 5 * 8 * 40
+    assert len(d["ranks"]) == 5 and sorted(int(r["rank"]) for r in d["ranks"]) == list(range(5))
+    assert len(d["per_rank_pages_per_s"]["by_rank"]) == 5
+    assert abs(d["value"] - 5 * 8 * 2 / (d["ms_per_step"] * 2 * 1e-3)) / d["value"] < 1e-6      # value = all ranks' pages / the slowest rank's time
