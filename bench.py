@@ -583,8 +583,21 @@ def main():
         eng.set_profiling(2)
         run_passes(eng, 1)
         eng.lib.ttr_dev_sync(eng.h)
-        pk = [k for k in eng.get_profile_kinds() if k["stage"] == 1 and k["ms"] > 0]
+        allk = eng.get_profile_kinds()
+        pk = [k for k in allk if k["stage"] == 1 and k["ms"] > 0]
+        ck = [k for k in allk if k["stage"] == 0 and k["ms"] > 0 and " | " in k["kind"]]      # the detector's launches of that pass, one kind per LAYER (engine_craft.cpp)
         eng.set_profiling(0)
+        if ck:
+            def lline(k):
+                d = line(k)
+                d["layer"], d["kernel"] = k["kind"].split(" | ", 1)
+                d["launches_per_pass"] = k["launches"]
+                return d
+            out["roofline_craft_layers"] = {
+                "is": "every detector layer's own roof (VERDICT r05 next 8): one extra pass behind the timed region with EVERY launch bracketed by HIP events on the engine's stream "
+                      "(a lone batch: the detector runs without a recogniser beside it); bound = \"mfma\" (executed flops / dense f16 peak) or \"hbm\" (algorithmic bytes / time over the "
+                      "6.3 TB/s a streaming kernel reaches on this chip), frac_of_binding_roof = how far that roof is",
+                "by_layer": [lline(k) for k in ck]}
         peak = MFMA_F32_PEAK_TFLOPS if args.precision == "f32" else MFMA_16BIT_PEAK_TFLOPS
 
         def pline(k):

@@ -134,7 +134,9 @@ void Engine::sconv(const char* name, const void* in0, int C0, const void* in1, i
       tail_flops = 2.0 * p.M * (16 * 16 + 2 * 16);
     }
     if (const char* e = conv3p_check(p)) throw std::runtime_error(std::string(name) + ": " + e);
-    timed(tail_heat ? "conv3p_kernel<32,NP=2> + conv_cls.6 + conv_cls.8 (head tail)" : "conv3p_kernel<32,NP=2> (packed pairs, 32 input channels)", flops + tail_flops,
+    const char* pk = tail_heat ? "conv3p_kernel<32,NP=2> + conv_cls.6 + conv_cls.8 (head tail)" : "conv3p_kernel<32,NP=2> (packed pairs, 32 input channels)";
+    const std::string per_layer = std::string(name) + " | " + pk;
+    timed(profiling == 2 ? per_layer.c_str() : pk, flops + tail_flops,
           2.0 * p.M * L.cout * 9 * 64 * 2 + (tail_heat ? 2.0 * p.M * 16 * 32 * 6 : 0.0), [&] { launch_conv3p(p, stream); },
           (double)p.M * 128.0 + (tail_heat ? (double)p.M * 8.0 : (double)p.M * (out_planes ? 128.0 : 32.0 * 4)) + (double)L.cout * 9 * 64 * 2 * 2);   // pixel rows [x0 | x1] of 128 B in and out (or the heat map)
     return;
@@ -160,7 +162,9 @@ void Engine::sconv(const char* name, const void* in0, int C0, const void* in1, i
   const double ob = out_planes ? 2.0 * out_planes : 4.0;   // bytes per output value (planes of f16, or fp32)
   const double bytes = (double)p.M * Ct * 2.0 * (np - 1) + (out ? (double)p.M * p.Cout * ob : 0.0) + (out_relu ? (double)p.M * p.Cout * ob : 0.0) +
                        (out_pool ? (double)p.M / 4 * p.Cout * ob : 0.0) + (double)p.Cout * L.k * 2.0 * 3;
-  timed(kind, flops, flops * np, [&] { if (c3) launch_conv3p(p, stream); else launch_gemm2(p, 0, stream); }, bytes);
+  // profiling == 2 (every launch bracketed: bench.py's per-layer pass behind the timed region): the kind is "layer | kernel", so that every layer states its own roof
+  const std::string per_layer = std::string(name) + " | " + kind;
+  timed(profiling == 2 ? per_layer.c_str() : kind, flops, flops * np, [&] { if (c3) launch_conv3p(p, stream); else launch_gemm2(p, 0, stream); }, bytes);
 }
 
 // upconvN.0 = ReLU(W . cat(upsample2x(y), skip) + b), a 1x1 convolution (inside CRAFT's TorchScript module run at tuatara.cpp:376).  The bilinear upsample is a fixed
@@ -187,8 +191,9 @@ void Engine::upconv_commuted(const char* name, const void* y_lo, int C0, const v
   if (const char* e = gemm2_check(b)) throw std::runtime_error(std::string(name) + " (skip half): " + e);
   const char* kind = np == 3 ? "gemm2_kernel<SP,NP=3> (CRAFT 1x1 / dilated)" : "gemm2_kernel<SP,NP=4> (CRAFT 1x1 / dilated)";
   // algorithmic flops: the layer's own (SURVEY.md section 8(d) counts the convolution as the reference runs it); executed: what the two launches multiply
-  timed(kind, 2.0 * Mhi * Cout * C0, 2.0 * Mlo * Cout * C0 * np, [&] { launch_gemm2(a, 0, stream); }, (double)Mlo * C0 * 2.0 * (np - 1) + (double)Mlo * Cout * 4.0 + (double)Cout * C0 * 6.0);
-  timed(kind, 2.0 * Mhi * Cout * C1, 2.0 * Mhi * Cout * C1 * np, [&] { launch_gemm2(b, 0, stream); },
+  const std::string la = std::string(name) + " (W_up . y at the low resolution) | " + kind, lb = std::string(name) + " (skip half + upsample(z) in the epilogue) | " + kind;
+  timed(profiling == 2 ? la.c_str() : kind, 2.0 * Mhi * Cout * C0, 2.0 * Mlo * Cout * C0 * np, [&] { launch_gemm2(a, 0, stream); }, (double)Mlo * C0 * 2.0 * (np - 1) + (double)Mlo * Cout * 4.0 + (double)Cout * C0 * 6.0);
+  timed(profiling == 2 ? lb.c_str() : kind, 2.0 * Mhi * Cout * C1, 2.0 * Mhi * Cout * C1 * np, [&] { launch_gemm2(b, 0, stream); },
         (double)Mhi * C1 * 2.0 * (np - 1) + (double)Mlo * Cout * 4.0 + (double)Mhi * Cout * 2.0 * (np - 1) + (double)Cout * C1 * 6.0);
 }
 
@@ -210,7 +215,7 @@ void Engine::craft_forward_split(const uint8_t* d_canvas, int B, int H, int W, f
   {
     const Linear& L0 = craft.at("slice1.0");
     range_tag("craft.slice1.0");
-    timed("conv1_split_kernel", 2.0 * M0 * 64 * 27, 2.0 * M0 * 64 * 27 * (npl + 1), [&] { launch_conv1_split(d_canvas, L0.ws.p, L0.b.as<float>(), L0.inv_scale, c11, B, H, W, stream, npl); },
+    timed(profiling == 2 ? "slice1.0 | conv1_split_kernel" : "conv1_split_kernel", 2.0 * M0 * 64 * 27, 2.0 * M0 * 64 * 27 * (npl + 1), [&] { launch_conv1_split(d_canvas, L0.ws.p, L0.b.as<float>(), L0.inv_scale, c11, B, H, W, stream, npl); },
           (double)M0 * 3.0 + (double)M0 * 64 * 2.0 * npl);
   }
   void* p1 = pbuf(M1, 64);   sconv("slice1.3", c11, 64, nullptr, 0, B, H, W, nullptr, kActRelu, nullptr, p1, 0);
