@@ -380,6 +380,29 @@ def test_x4_craft_head_on_packed_pairs_equals_zero_padded_rows(eng_x4_random, we
         assert np.isfinite(h).all() and np.abs(h - ref).max() < TOL * scale
 
 
+def test_x4_craft_head_persistent_kernel_changes_nothing(eng_x4_random, eng_x4, funsd):
+    """conv_cls.0 / .2 / .4 (+ fused tail) on the persistent packed-pairs kernel (conv3h.hip: the nine taps' weights resident in LDS as MFMA fragments, one LDS-DMA
+    burst per patch; tuning key "head_persistent", the default) against conv3p.hip's per-patch tile: the same products in the same order per accumulator (the
+    second K half of the [w1 | 0] chunk, x1 times zeros, is skipped: + 0) - heat maps bit-identical on fully random weights (1024 x 768, a wide and a tall canvas,
+    with the fused tail and with the two 1x1 layers as launches of their own) and on the FUNSD page with the structured weights."""
+    from oracle import post
+    rng = np.random.default_rng(2026)
+    canvases = [rng.integers(0, 256, hw + (3,), dtype=np.uint8) for hw in ((1024, 768), (256, 512), (512, 128))]
+    for eng, cs in ((eng_x4_random, canvases), (eng_x4, [post.resize_aspect_ratio(np.ascontiguousarray(funsd[:, :, ::-1]))[0]])):
+        for tail in (1, 0):
+            try:
+                assert eng.set_tuning(b"head_tail", tail) == 0
+                for c in cs:
+                    assert eng.set_tuning(b"head_persistent", 1) == 0
+                    a = eng.craft_heatmap(c)
+                    assert eng.set_tuning(b"head_persistent", 0) == 0
+                    b = eng.craft_heatmap(c)
+                    assert np.isfinite(a).all() and np.array_equal(a, b), (c.shape, tail, float(np.abs(a - b).max()))
+            finally:
+                eng.set_tuning(b"head_persistent", 1)
+                eng.set_tuning(b"head_tail", 1)
+
+
 @pytest.mark.parametrize("hw", [(256, 192), (96, 160), (64, 96)])
 def test_x4_craft_small_canvases_random_weights(eng_x4_random, weights_random, hw):
     """Canvases that do not tile into conv3p patches at every level (gemm2's split variant serves those layers)."""

@@ -297,6 +297,8 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "ws_dbg_flags") set_gemm_ws_dbg_flags(value);
   else if (k == "ws_lean") set_gemm_ws_lean(value);
   else if (k == "store_policy") set_store_policy(value);
+  else if (k == "head_persistent") set_conv3p_head_persistent(value);
+  else if (k == "c3h_wgs_per_cu") set_conv3h_wgs_per_cu(value);
   else if (k == "g2_x_ring3") set_gemm2_x_ring3(value);
   else if (k == "g2_split_reuse") set_gemm2_split_reuse(value);
   else if (k == "g2_split_cfg") set_gemm2_split_cfg(value);
@@ -334,6 +336,7 @@ int ttr_set_tuning(const char* key, int value) {
     set_conv3p_stamps(value == 4 ? g_dec_dbg : nullptr);    // 4: ... or conv3p_first2 stamps
     set_mlp_stamps(value == 3 ? g_dec_dbg : nullptr);
     set_qkv_attn_stamps(value == 5 ? g_dec_dbg : nullptr);   // 5: ... or the fused qkv + attention launch's
+    set_conv3h_stamps(value == 6 ? g_dec_dbg : nullptr);     // 6: ... or the persistent head kernel's (conv3h.hip)
     // 3: ... or mlp_fused stamps   // 2: the same buffer takes gemm_ws stamps instead
   }
   else return -1;

@@ -1196,6 +1196,8 @@ int conv3p_split_bn(const ConvParams& p) {
   return narrow ? 64 : 128;
 }
 
+static int g_head_persistent = 1;   // packed-pairs head layers on conv3h.hip's persistent kernel (tuning key head_persistent; 0: this file's per-patch tile)
+void set_conv3p_head_persistent(int v) { g_head_persistent = v; }
 void launch_conv3p(const ConvParams& p, hipStream_t s) {
   if (const char* e = conv3p_check(p)) throw std::runtime_error(e);
   if (p.split) {   // the one-patch-stage tiles (two workgroups per CU)
@@ -1214,6 +1216,7 @@ void launch_conv3p(const ConvParams& p, hipStream_t s) {
     return narrow ? launch_c3<64, 4, 2, false, 1, 5, NPV>(p, s) : launch_c3<128, 4, 2, false, 1, 5, NPV>(p, s);
     if (p.split == 2) {   // packed pairs (the 32-channel head layers): one 128-byte row [x0 (32) | x1 (32)] per pixel, two virtual chunks
       if (!wide) return launch_c3<64, 4, 2, false, 1, 4, 2>(p, s);
+      if (g_head_persistent && conv3h_eligible(p)) return launch_conv3h(p, s);   // the persistent form (conv3h.hip): weights resident, one burst per patch; bit-identical
       return launch_c3<32, 4, 1, false, 1, 5, 2>(p, s);
     }
     if (p.split == 3) {

@@ -76,6 +76,12 @@ void set_conv3p_stamps(unsigned long long* dev_buf);    // >= 2*24*8 u64, or nul
 void set_gemm_ws_stamps(unsigned long long* dev_buf);   // >= 2*24*8 u64, or null: phase stamps of gemm_ws workgroup 0
 extern int g_store_policy;          // cache policy of the big streaming output stores: 0 default, 1 nt, 2 sc0 sc1 nt
 void set_store_policy(int v);
+// ---- conv3h.hip (CRAFT's packed-pairs head layers, persistent)
+bool conv3h_eligible(const ConvParams& p);
+void launch_conv3h(const ConvParams& p, hipStream_t s);
+void set_conv3h_wgs_per_cu(int v);
+void set_conv3h_stamps(unsigned long long* dev_buf);   // >= 24 * 8 u64 or null: phase stamps of workgroup 0, wave 0
+void set_conv3p_head_persistent(int v);
 void set_gemm_ws_dbg_flags(int f);
 void set_gemm_ws_lean(int v);      // 0: always the run-time-activation epilogue (A/B and tests)
 int skinny_max_rows();             // the current threshold (0 when gemm_sk is not in use)
