@@ -403,6 +403,26 @@ def test_x4_craft_head_persistent_kernel_changes_nothing(eng_x4_random, eng_x4, 
                 eng.set_tuning(b"head_tail", 1)
 
 
+def test_x4_craft_upconv4_skip_half_persistent_kernel_changes_nothing(eng_x4_random, eng_x4, funsd):
+    """upconv4.0's skip half (1x1 over the 128-channel skip tensor + the upsampled half-resolution addend) on conv1u.hip's persistent kernel (weights resident as MFMA
+    fragments, one LDS-DMA burst per 64-pixel tile, the z gather issued in front of the wait for it; tuning key "up_resident", the default) against gemm2.hip's tile:
+    the same products in the same order and the same epilogue arithmetic - heat maps bit-identical on fully random weights (1024 x 768, a wide and a tall canvas, a
+    small one) and on the FUNSD page with the structured weights."""
+    from oracle import post
+    rng = np.random.default_rng(2027)
+    canvases = [rng.integers(0, 256, hw + (3,), dtype=np.uint8) for hw in ((1024, 768), (256, 512), (512, 128), (64, 96))]
+    for eng, cs in ((eng_x4_random, canvases), (eng_x4, [post.resize_aspect_ratio(np.ascontiguousarray(funsd[:, :, ::-1]))[0]])):
+        try:
+            for c in cs:
+                assert eng.set_tuning(b"up_resident", 1) == 0
+                a = eng.craft_heatmap(c)
+                assert eng.set_tuning(b"up_resident", 0) == 0
+                b = eng.craft_heatmap(c)
+                assert np.isfinite(a).all() and np.array_equal(a, b), (c.shape, float(np.abs(a - b).max()))
+        finally:
+            eng.set_tuning(b"up_resident", 1)
+
+
 @pytest.mark.parametrize("hw", [(256, 192), (96, 160), (64, 96)])
 def test_x4_craft_small_canvases_random_weights(eng_x4_random, weights_random, hw):
     """Canvases that do not tile into conv3p patches at every level (gemm2's split variant serves those layers)."""

@@ -674,8 +674,11 @@ const char* gemm2_check(const ConvParams& p) {
 }
 
 // cfg: 0 auto, 1 = 256x256/8w, 2 = 256x128/8w, 3 = 128x128/4w, 4 = 256x64/4w, 5 = 128x64/4w, 6 = 128x256/8w
+static int g_up_resident = 1;   // the skip half of CRAFT's upconv4.0 (128 -> 64 channels + the half-resolution addend) on conv1u.hip's persistent kernel (tuning key up_resident)
+void set_gemm2_up_resident(int v) { g_up_resident = v; }
 void launch_gemm2(const ConvParams& p_in, int cfg, hipStream_t s) {
   if (const char* e = gemm2_check(p_in)) throw std::runtime_error(e);
+  if (g_up_resident && cfg == 0 && conv1u_eligible(p_in)) return launch_conv1u(p_in, s);   // bit-identical (test)
   ConvParams p = p_in;
   const int Ctot = p.C0 + p.C1;
   p.gelu_lut = p.act == kActGelu ? (p.split ? gelu_hermite_lut_for_current_device() : gelu_lut_for_current_device()) : nullptr;

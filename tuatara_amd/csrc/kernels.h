@@ -76,6 +76,10 @@ void set_conv3p_stamps(unsigned long long* dev_buf);    // >= 2*24*8 u64, or nul
 void set_gemm_ws_stamps(unsigned long long* dev_buf);   // >= 2*24*8 u64, or null: phase stamps of gemm_ws workgroup 0
 extern int g_store_policy;          // cache policy of the big streaming output stores: 0 default, 1 nt, 2 sc0 sc1 nt
 void set_store_policy(int v);
+// ---- conv1u.hip (CRAFT's upconv4.0 skip half: 1x1 over 128 channels + upsampled addend, persistent, weights resident)
+bool conv1u_eligible(const ConvParams& p);
+void launch_conv1u(const ConvParams& p, hipStream_t s);
+void set_gemm2_up_resident(int v);
 // ---- conv3h.hip (CRAFT's packed-pairs head layers, persistent)
 bool conv3h_eligible(const ConvParams& p);
 void launch_conv3h(const ConvParams& p, hipStream_t s);

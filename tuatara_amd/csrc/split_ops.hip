@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void upsample2x_planes_kernel(const f16* __res
 // CRAFT's conv1_1 (3 -> 64, 3x3, ReLU) from the u8 canvas straight into planes: conv1_direct_kernel's structure (craft_ops.hip)
 // with split operands.  A pixel's 27 inputs are u8 / 255 in fp32 (the reference's division, tuatara.cpp:367-370): their three planes
 // come from three 256-entry tables built once per workgroup; the weights are the layer's three planes [64][3][32].
-template <int NPL>
+// FULL: the canvas width is a multiple of 64 - every task stores all four 16-pixel blocks (the counted wait below relies on the number of store instructions)
+template <int NPL, bool FULL>
 __global__ __launch_bounds__(256, NPL == 2 ? 4 : 3) void conv1_split_kernel(const uint8_t* __restrict__ canvas, const f16* __restrict__ wgt /*[64][3][32]*/, const float* __restrict__ bias,
                                                          float out_scale, f16* __restrict__ out /*[M][3*64]*/, int B, int H, int W, unsigned* range_flag, unsigned range_tag) {
   // A wave takes 64 consecutive pixels of one row (W % 32 == 0: the last segment of a row may hold 32).  The three canvas rows around them come
@@ -180,12 +181,12 @@ __global__ __launch_bounds__(256, NPL == 2 ? 4 : 3) void conv1_split_kernel(cons
   const i32x4 rs = {(int)(unsigned)(uintptr_t)canvas, (int)(unsigned)((uintptr_t)canvas >> 32), (int)(unsigned)std::min<size_t>(canvas_bytes, 0xFFFFFFFFu), 0x00020000};
   constexpr unsigned OOB = 0x80000000u;
   struct Pos { int seg, by, y; };
-  auto request = [&](const Pos& q, unsigned (&v)[3]) {
+  auto request = [&](const Pos& q, unsigned (&v)[3], bool live) {   // (not live - no next task -: three out-of-range loads, so that every task runs the same code path)
     const int x0 = q.seg << 6;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const int yy = q.y - 1 + r;
-      const bool ok = lane < 51 && yy >= 0 && yy < H && !(x0 == 0 && lane == 0) && 4 * lane < 3 * (W - x0) + 4;   // (inside the row: the right halo pixel too, where there is one)
+      const bool ok = live && lane < 51 && yy >= 0 && yy < H && !(x0 == 0 && lane == 0) && 4 * lane < 3 * (W - x0) + 4;   // (inside the row: the right halo pixel too, where there is one)
       const unsigned off = ok ? (unsigned)(((q.by - q.y + yy) * W + x0) * 3 - 4 + 4 * lane) : OOB;                 // (launcher: the canvas is below 2 GB)
       asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(v[r]) : "v"(off), "s"(rs) : "memory");
     }
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256, NPL == 2 ? 4 : 3) void conv1_split_kernel(cons
   const int dseg = nwaves % segs, dby = nwaves / segs, dy = dby % H;
   unsigned cur[3] = {0u, 0u, 0u};
   if (wave0 < ntasks) {
-    request(pos, cur);
+    request(pos, cur, true);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]) : : "memory");
   }
   constexpr int kStores = 4 * 2 * NPL;                   // store instructions of a task with all four 16-pixel blocks inside the row
@@ -212,8 +213,8 @@ __global__ __launch_bounds__(256, NPL == 2 ? 4 : 3) void conv1_split_kernel(cons
     if (nx.seg >= segs) { nx.seg -= segs; ++nx.by; ++nx.y; }
     if (nx.y >= H) nx.y -= H;
     const bool has_next = task + nwaves < ntasks;
-    unsigned nxt[3] = {0u, 0u, 0u};
-    if (has_next) request(nx, nxt);
+    unsigned nxt[3];
+    request(nx, nxt, has_next);
     // (per block of 16 pixels: its 12 - 16 MFMAs, then its epilogue and stores - the accumulators of one block are live at a time, so that four workgroups share a
     // CU: with the four blocks' MFMAs first and their epilogues behind, 64 accumulator registers put the kernel at two waves per SIMD and 3.9 TB/s of its 6.3)
     const int64_t m0 = (int64_t)by * W + x0;
@@ -249,11 +250,12 @@ __global__ __launch_bounds__(256, NPL == 2 ? 4 : 3) void conv1_split_kernel(cons
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (has_next) {   // the requested rows have landed once all but this task's stores (issued behind them) are done
-      if (npx == 64) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]) : "n"(kStores) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]) : : "memory");
-      cur[0] = nxt[0]; cur[1] = nxt[1]; cur[2] = nxt[2];
-    }
+    // the requested rows have landed once all but this task's stores (issued behind them) are done.  ONE wait on ONE code path - with a branch around the wait the
+    // compiler may copy the rows' registers on the way into the branch, before the data is there (conv1u.hip's last tile came out wrong that way) - so the count is the
+    // smaller of the two a task can have where the width is not a multiple of 64 (a last segment of 32 pixels issues half the stores: W % 32 == 0; a count below the
+    // real one only waits for more), and the full count in the kernel compiled for widths that are (FULL)
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]) : "n"(FULL ? kStores : kStores / 2) : "memory");
+    cur[0] = nxt[0]; cur[1] = nxt[1]; cur[2] = nxt[2];
     pos = nx;
   }
   rw.flush(range_flag, range_tag);
@@ -280,8 +282,11 @@ void launch_conv1_split(const uint8_t* canvas, const void* wgt_planes, const flo
   const int64_t tasks = (int64_t)B * H * ((W + 63) / 64);
   if (tasks >= ((int64_t)1 << 31) || (int64_t)B * H * W * 3 >= ((int64_t)1 << 31)) throw std::runtime_error("conv1_split: the canvas batch exceeds 2 GB (32-bit offsets); the caller groups the pages");
   const int grid = (int)std::min<int64_t>((tasks + 3) / 4, 256 * 16);
-  if (planes == 2) hipLaunchKernelGGL(conv1_split_kernel<2>, dim3(grid), dim3(256), 0, s, canvas, (const f16*)wgt_planes, bias, out_scale, (f16*)out, B, H, W, range_ctx().flag, range_ctx().tag);
-  else hipLaunchKernelGGL(conv1_split_kernel<3>, dim3(grid), dim3(256), 0, s, canvas, (const f16*)wgt_planes, bias, out_scale, (f16*)out, B, H, W, range_ctx().flag, range_ctx().tag);
+  const bool full = W % 64 == 0;
+#define TTR_C1_LAUNCH(NPLV, FULLV) hipLaunchKernelGGL((conv1_split_kernel<NPLV, FULLV>), dim3(grid), dim3(256), 0, s, canvas, (const f16*)wgt_planes, bias, out_scale, (f16*)out, B, H, W, range_ctx().flag, range_ctx().tag)
+  if (planes == 2) { if (full) TTR_C1_LAUNCH(2, true); else TTR_C1_LAUNCH(2, false); }
+  else { if (full) TTR_C1_LAUNCH(3, true); else TTR_C1_LAUNCH(3, false); }
+#undef TTR_C1_LAUNCH
 }
 
 }  // namespace ttr
