@@ -423,6 +423,28 @@ def test_x4_craft_upconv4_skip_half_persistent_kernel_changes_nothing(eng_x4_ran
             eng.set_tuning(b"up_resident", 1)
 
 
+def test_x4_craft_upconv_skip_halves_on_2d_tiles_change_nothing(eng_x4_random):
+    """The skip halves of the commuted up-convolutions (upconv2.0 / 3.0, and 4.0 where conv1u.hip does not take it) with a tile's rows a 2-D block of (BM / 16) x 16
+    pixels instead of BM consecutive ones (ConvParams::up_2d, tuning key "up_2d": the four-tap gather of z re-uses its rows inside the workgroup): a row-to-pixel map,
+    the arithmetic per pixel untouched - heat maps bit-identical on fully random weights at 1024 x 768, a wide, a tall and a small canvas, with conv1u on and off.
+    (Measured 2 % slower - the gather is not bound by its locality -: off by default.)"""
+    rng = np.random.default_rng(2028)
+    eng = eng_x4_random
+    canvases = [rng.integers(0, 256, hw + (3,), dtype=np.uint8) for hw in ((1024, 768), (256, 512), (512, 128), (128, 256))]
+    try:
+        for res in (1, 0):
+            assert eng.set_tuning(b"up_resident", res) == 0
+            for c in canvases:
+                assert eng.set_tuning(b"up_2d", 1) == 0
+                a = eng.craft_heatmap(c)
+                assert eng.set_tuning(b"up_2d", 0) == 0
+                b = eng.craft_heatmap(c)
+                assert np.isfinite(a).all() and np.array_equal(a, b), (c.shape, res, float(np.abs(a - b).max()))
+    finally:
+        eng.set_tuning(b"up_2d", 0)
+        eng.set_tuning(b"up_resident", 1)
+
+
 @pytest.mark.parametrize("hw", [(256, 192), (96, 160), (64, 96)])
 def test_x4_craft_small_canvases_random_weights(eng_x4_random, weights_random, hw):
     """Canvases that do not tile into conv3p patches at every level (gemm2's split variant serves those layers)."""

@@ -299,6 +299,7 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "store_policy") set_store_policy(value);
   else if (k == "head_persistent") set_conv3p_head_persistent(value);
   else if (k == "up_resident") set_gemm2_up_resident(value);
+  else if (k == "up_2d") set_gemm2_up_2d(value);
   else if (k == "c3h_wgs_per_cu") set_conv3h_wgs_per_cu(value);
   else if (k == "g2_x_ring3") set_gemm2_x_ring3(value);
   else if (k == "g2_split_reuse") set_gemm2_split_reuse(value);

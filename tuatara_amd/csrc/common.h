@@ -65,6 +65,9 @@ struct ConvParams {
   // cat(upsample(y), skip): a 1x1 convolution commutes with the upsample, so W_up . y runs at the low resolution (a quarter of the rows) and arrives here,
   // and the upsampled tensor is never written (engine_craft.cpp: upconv_commuted)
   const float* up_z; int up_ld;
+  // ... with up_2d (set by launch_gemm2): a tile's BM rows are a 2-D block of (BM / 16) x 16 pixels instead of BM consecutive ones, so that the four-tap gather of z
+  // re-uses its rows inside the workgroup (a 16 x 16 block touches 9 x 9 low-resolution pixels; 256 pixels of an image row touch 2 x 129)
+  int up_2d;
   // split-operand mode: the engine's sticky range word and this layer's tag (split.h: RangeWatch); null = not watched.  The launchers fill them from
   // range_ctx() (kernels.h) when the caller left them empty
   unsigned* range_flag; unsigned range_tag;

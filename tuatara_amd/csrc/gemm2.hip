@@ -123,6 +123,13 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
   // tile is BM/4 consecutive *pooled* pixels: row r is sub-pixel (dy, dx) = (r>>1 & 1, r & 1) of pooled pixel r>>2,
   // so the four partners of a pool window sit in four neighbouring lanes of one MFMA tile.
   auto row_to_pixel = [&](int grow) -> int {
+    if (p.up_2d) {   // (ConvParams::up_2d: tile t = block (ty, tx) of image b, row r = pixel (r >> 4, r & 15) of the block; launcher: W % 16 == 0, H % (BM / 16) == 0)
+      constexpr int BH = BM / 16;
+      const int t = grow / BM, r = grow - t * BM;
+      const int bw = p.W >> 4, bh = p.H / BH;
+      const int tx = t % bw, tq = t / bw, ty = tq % bh, b = tq / bh;
+      return (b * p.H + ty * BH + (r >> 4)) * p.W + tx * 16 + (r & 15);
+    }
     if (!p.out_pool) return grow;
     const int q = grow >> 2, sub = grow & 3, Wo = p.W >> 1, Ho = p.H >> 1;
     const int xo = q % Wo, t = q / Wo, yo = t % Ho, b = t / Ho;
@@ -427,7 +434,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm2_kernel(ConvParams p)
   #pragma unroll
         for (int i = 0; i < C::MI; ++i) {
           const int grow = m0c + wm * C::TM + i * 16 + fr;
-          const int m = grow < p.M ? grow : 0;
+          const int m = row_to_pixel(grow < p.M ? grow : 0);
           const int xo = m % p.W, tq = m / p.W, yo = tq % p.H, bq = tq / p.H;
           const float sy = fmaxf(0.5f * ((float)yo + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * ((float)xo + 0.5f) - 0.5f, 0.f);
           const int y0 = (int)sy, x0 = (int)sx;
@@ -674,6 +681,8 @@ const char* gemm2_check(const ConvParams& p) {
 }
 
 // cfg: 0 auto, 1 = 256x256/8w, 2 = 256x128/8w, 3 = 128x128/4w, 4 = 256x64/4w, 5 = 128x64/4w, 6 = 128x256/8w
+static int g_up_2d = 0;         // the skip halves of the commuted up-convolutions on 2-D tiles (ConvParams::up_2d; tuning key up_2d): bit-identical, measured 2 % SLOWER (the gather is not bound by its locality) - off
+void set_gemm2_up_2d(int v) { g_up_2d = v; }
 static int g_up_resident = 1;   // the skip half of CRAFT's upconv4.0 (128 -> 64 channels + the half-resolution addend) on conv1u.hip's persistent kernel (tuning key up_resident)
 void set_gemm2_up_resident(int v) { g_up_resident = v; }
 void launch_gemm2(const ConvParams& p_in, int cfg, hipStream_t s) {
@@ -710,6 +719,10 @@ void launch_gemm2(const ConvParams& p_in, int cfg, hipStream_t s) {
   const bool deep = g_x_ring3 && p.act != kActGelu;
   if (p.split) p.dbg_flags = g_split_dbg;
   if (p.up_z && cfg == 1) cfg = 2;                 // (the half-resolution addend's epilogue is not compiled into the 256 x 256 tile)
+  {
+    const int bm = (cfg == 1 || cfg == 2 || cfg == 4) ? 256 : 128;   // (cfg 3 may still become 5 below: 128 rows either way)
+    p.up_2d = (g_up_2d && p.up_z && !p.out_pool && p.W % 16 == 0 && p.H % (bm / 16) == 0 && p.M % bm == 0 && p.M == p.B * p.H * p.W) ? 1 : 0;
+  }
   if (p.split && cfg == 1) p.gelu_lut = nullptr;   // 256 x 256 tiles fill the LDS: erf instead of the table
   if (p.split == 4 && (cfg == 2 || cfg == 3 || cfg == 6) && g_split_stream && g_split_stream4 && gemm_sp_eligible(p)) return launch_gemm_sp(p, cfg, s);   // triples
   if (p.split == 3 && (cfg == 2 || cfg == 3 || cfg == 6) && g_split_stream && gemm_sp_eligible(p)) {

@@ -80,6 +80,7 @@ void set_store_policy(int v);
 bool conv1u_eligible(const ConvParams& p);
 void launch_conv1u(const ConvParams& p, hipStream_t s);
 void set_gemm2_up_resident(int v);
+void set_gemm2_up_2d(int v);
 // ---- conv3h.hip (CRAFT's packed-pairs head layers, persistent)
 bool conv3h_eligible(const ConvParams& p);
 void launch_conv3h(const ConvParams& p, hipStream_t s);
