@@ -5,7 +5,7 @@ profiler), bytes fetched (KiB x 2: gfx950 tallies 128-B requests at 64 B) and wr
 import csv, json, sys
 
 fetch_csv, write_csv, pages, out, build = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
-CONV = ("conv3p", "conv3h", "gemm2_kernel", "gemm_sp_kernel", "conv1_direct", "conv1_split", "igemm_kernel", "conv3s")   # (detector-only runs: every such launch is CRAFT's)
+CONV = ("conv3p", "conv3h", "conv1u", "gemm2_kernel", "gemm_sp_kernel", "conv1_direct", "conv1_split", "igemm_kernel", "conv3s")   # (detector-only runs: every such launch is CRAFT's)
 LAYERS = ["slice1.0+slice1.3 +pool", "slice1.7", "slice1.10 (skip relu2_2 + pooled)", "slice2.14", "slice2.17 (skip relu3_2 + relu copy)", "slice3.20 +pool",
           "slice3.24", "slice3.27 (skip relu4_3 + pooled)", "slice4.30", "slice4.34", "slice4.37 (skip relu5_3 + relu copy)", "slice5.1 (dil 6)", "slice5.2",
           "upconv1.0", "upconv1.3", "upconv2.0", "upconv2.3", "upconv3.0", "upconv3.3", "upconv4.0", "upconv4.3", "conv_cls.0", "conv_cls.2", "conv_cls.4+.6+.8"]

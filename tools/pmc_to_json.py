@@ -4,7 +4,7 @@ HBM bytes per launch for every kernel and for the CRAFT convolution kernels as a
 import collections, csv, json, sys
 
 fetch_csv, write_csv, pages, steps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-CONV = ("conv3p", "conv3h", "gemm2_kernel", "gemm_sp_kernel", "conv1_direct", "conv1_split", "igemm_kernel", "conv3s")   # (detector-only runs: every such launch is CRAFT's)
+CONV = ("conv3p", "conv3h", "conv1u", "gemm2_kernel", "gemm_sp_kernel", "conv1_direct", "conv1_split", "igemm_kernel", "conv3s")   # (detector-only runs: every such launch is CRAFT's)
 
 
 def fold(path, counter):
