@@ -68,6 +68,8 @@ int ttr_dbg_mlp(ttr_engine* e, const float* x, int M, const float* ln_g, const f
  * shader-clock stamps into a 416-entry buffer ([26 steps][16 phases], [2 waves][24 panels][8], [48 chunks][8]); this copies them out.
  * Returns -1 when stamps are off. */
 int ttr_dbg_dec_stamps(unsigned long long* out);
+/* the first n (<= 4096) words of the same buffer: qkv_attn4.hip also records where and when each workgroup ran (words 512 + 4 b ..: start, end in 100 MHz ticks, HW_ID | XCC_ID << 32, shader clocks) */
+int ttr_dbg_dec_stamps_ext(unsigned long long* out, int n);
 /* Times one conv / linear layer on device-generated random data (no host traffic): average
  * microseconds per launch over `iters` back-to-back launches.  f32_resid != 0 selects the PARSeq
  * residual form (f32 residual in, f32 out) instead of a bf16/T output. */

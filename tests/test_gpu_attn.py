@@ -112,6 +112,58 @@ def test_x4_qkv_attn_one_launch_against_float64(eng_x4, N):
     assert np.delete(err, 1, 0).mean() < 2e-6 if N > 1 else err.mean() < 2e-6
 
 
+@pytest.mark.parametrize("N", [1, 7, 43, 300])
+def test_x4_qkv_attn_four_wave_tiles_against_float64(eng_x4, N):
+    """qkv_attn4.hip (tuning key qkv_attn4, off by default): the same tile on four-wave workgroups, two per CU, tiles handed out by counter - the bars of the eight-wave
+    form above, bit-identical reruns, and the SAME BITS as the eight-wave kernel (same MFMAs per accumulator in the same order).  How the tiles
+    are handed out and how the two workgroups of a CU take turns is not arithmetic: equal shares by stride (+ 2), no issue priority (+ 4), the per-CU
+    matrix-phase token (+ 64) give the same bits."""
+    rng = np.random.default_rng(100 + N)
+    x = rng.standard_normal((N, 128, 384)).astype(np.float32)
+    if N > 1:
+        x[1] *= 3.0
+    w = (rng.standard_normal((1152, 384)) / np.sqrt(384)).astype(np.float32) * 1.5
+    b = (0.3 * rng.standard_normal(1152)).astype(np.float32)
+    outs = {}
+    try:
+        for v in (0, 1, 3, 5, 65):
+            assert eng_x4.set_tuning(b"qkv_attn4", v) == 0
+            outs[v] = eng_x4.dbg_qkv_attn(x, w, b)
+        assert eng_x4.set_tuning(b"qkv_attn4", 1) == 0
+        out2 = eng_x4.dbg_qkv_attn(x, w, b)
+    finally:
+        eng_x4.set_tuning(b"qkv_attn4", 0)
+    base, out = outs[0], outs[1]
+    assert np.array_equal(out, out2)
+    for v in (3, 5, 65):
+        assert np.array_equal(out, outs[v]), v
+    assert np.isfinite(out).all()
+    ref = _ref_qkv_attn_f64(x, w, b)
+    err = np.abs(out - ref)
+    per_crop = err.reshape(N, -1).max(1)
+    tol = np.full(N, 4e-5)
+    if N > 1:
+        tol[1] = 6e-4
+    assert (per_crop < tol).all(), per_crop.tolist()[:8]
+    assert np.delete(err, 1, 0).mean() < 2e-6 if N > 1 else err.mean() < 2e-6
+    assert np.array_equal(out, base)          # every accumulator sees the eight-wave kernel's MFMAs in its order
+
+
+def test_x4_encoder_on_four_wave_qkv_attention_tiles(eng_x4):
+    """whole recogniser, 200 crops (tiled activation planes in and out of the launch): qkv_attn4.hip against the eight-wave tile - the same logits, bit for bit"""
+    rng = np.random.default_rng(6)
+    crops = rng.integers(0, 256, (200, 32, 128, 3), dtype=np.uint8)
+    try:
+        assert eng_x4.set_tuning(b"qkv_attn4", 0) == 0
+        la, ia = eng_x4.parseq_logits(crops)
+        assert eng_x4.set_tuning(b"qkv_attn4", 1) == 0
+        lb, ib = eng_x4.parseq_logits(crops)
+    finally:
+        eng_x4.set_tuning(b"qkv_attn4", 0)
+    assert np.array_equal(ia, ib)
+    assert np.array_equal(la, lb)
+
+
 def test_x4_encoder_with_and_without_the_fused_qkv_attention(eng_x4):
     """whole recogniser, 200 crops: the one-launch qkv + attention against the separate GEMM + attention kernels (same arithmetic up to
     the rounding of K / V to pairs: round-to-nearest in the epilogue, truncation in the stored triples) - logits within fp32 noise, ids equal"""

@@ -24,7 +24,7 @@ LIB = os.path.join(LIBDIR, "libtuatara_hip.so")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
-SOURCES = ["igemm.hip", "gemm2.hip", "gemm_sp.hip", "split_ops.hip", "attn_split.hip", "attn_cross_split.hip", "conv3p.hip", "conv3h.hip", "conv1u.hip", "conv3s.hip", "gemm_sk.hip", "gemm_skx.hip", "gemm_ws.hip", "mlp_fused.hip", "attn_enc2.hip", "attn_dec2.hip", "qkv_attn.hip", "craft_ops.hip", "parseq_ops.hip", "dec_fused.hip", "post_ops.hip",
+SOURCES = ["igemm.hip", "gemm2.hip", "gemm_sp.hip", "split_ops.hip", "attn_split.hip", "attn_cross_split.hip", "conv3p.hip", "conv3h.hip", "conv1u.hip", "qkv_attn4.hip", "conv3s.hip", "gemm_sk.hip", "gemm_skx.hip", "gemm_ws.hip", "mlp_fused.hip", "attn_enc2.hip", "attn_dec2.hip", "qkv_attn.hip", "craft_ops.hip", "parseq_ops.hip", "dec_fused.hip", "post_ops.hip",
            "engine.cpp", "engine_craft.cpp", "engine_parseq.cpp", "engine_pages.cpp", "comm.cpp", "capi.cpp", "capi_debug.cpp", "geometry.cpp", "tuatara.cpp"]
 HIP_HOST_SOURCES = {"engine.cpp", "engine_craft.cpp", "engine_parseq.cpp", "engine_pages.cpp", "comm.cpp", "capi.cpp", "capi_debug.cpp"}   # host code that sees HIP types: -x hip
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]

@@ -274,6 +274,7 @@ void ttr_set_decoder_mode(int mode) { g_tuning_default.decoder_mode = mode; }
 
 void ttr_last_host_us(ttr_engine* e, float out[8]) { for (int i = 0; i < 8; ++i) out[i] = e ? e->e->host_us[i] : 0.f; }
 
+int ttr_dbg_dec_stamps_ext(unsigned long long* out, int n) { return g_dec_dbg && n >= 0 && n <= 4096 && hipMemcpy(out, g_dec_dbg, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
 int ttr_dbg_dec_stamps(unsigned long long* out) { return g_dec_dbg && hipMemcpy(out, g_dec_dbg, 26 * 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
 
 // process-wide: the kernel files' variant switches and diagnostics; engine-level keys set the default of engines created afterwards
@@ -318,6 +319,7 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "gsp_stag") set_gemm_sp_stag(value);
   else if (k == "gsp_stagger_groups") set_gemm_sp_stagger_groups(value);
   else if (k == "qkv_attn_dbg") set_qkv_attn_dbg(value);
+  else if (k == "qkv_attn4") set_qkv_attn4(value);
   else if (k == "skx_ln_max_rows") set_gemm_skx_ln_max_rows(value);
   else if (k == "c3_xs1_max_cin") set_conv3p_single_stage_max_cin(value);
   else if (k == "c3_force_bn128") set_conv3p_force_bn128(value);
@@ -332,12 +334,13 @@ int ttr_set_tuning(const char* key, int value) {
   else if (k == "sk_max_rows") set_skinny_max_rows(value);
   else if (k == "ws_min_rows") set_gemm_ws_min_rows(value);
   else if (k == "dec_stamps") {   // value != 0: allocate the stamp buffer; read it back with ttr_dev_download via ttr_dbg_dec_stamps
-    if (value && !g_dec_dbg) { void* d = nullptr; if (hipMalloc(&d, 26 * 16 * 8) != hipSuccess) return -1; (void)hipMemset(d, 0, 26 * 16 * 8); g_dec_dbg = (unsigned long long*)d; }
+    if (value && !g_dec_dbg) { void* d = nullptr; if (hipMalloc(&d, 4096 * 8) != hipSuccess) return -1; (void)hipMemset(d, 0, 4096 * 8); g_dec_dbg = (unsigned long long*)d; }
     if (!value) g_dec_dbg = nullptr;
     set_gemm_ws_stamps(value == 2 ? g_dec_dbg : nullptr);
     set_conv3p_stamps(value == 4 ? g_dec_dbg : nullptr);    // 4: ... or conv3p_first2 stamps
     set_mlp_stamps(value == 3 ? g_dec_dbg : nullptr);
-    set_qkv_attn_stamps(value == 5 ? g_dec_dbg : nullptr);   // 5: ... or the fused qkv + attention launch's
+    set_qkv_attn_stamps(value == 5 ? g_dec_dbg : nullptr);
+    set_qkv_attn4_stamps(value == 5 ? g_dec_dbg : nullptr);   // 5: ... or the fused qkv + attention launch's
     set_conv3h_stamps(value == 6 ? g_dec_dbg : nullptr);     // 6: ... or the persistent head kernel's (conv3h.hip)
     // 3: ... or mlp_fused stamps   // 2: the same buffer takes gemm_ws stamps instead
   }

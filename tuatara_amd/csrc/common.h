@@ -74,6 +74,10 @@ struct ConvParams {
   // gemm_sp.hip: workgroup (blockIdx.x >> 3) % cu_stagger_groups waits that many cu_stagger_groups-ths of cu_stagger ticks (s_memrealtime, 10 ns) before its first
   // tile, so that the CUs do not reach their epilogues - every CU's store burst - together (0 = off; set by the launcher from the tuning keys)
   int cu_stagger, cu_stagger_groups;
+  // persistent kernels with two workgroups per CU (qkv_attn4.hip): tiles handed out by counter instead of by stride - the older workgroup of a CU wins the
+  // issue arbitration and runs ahead, so equal shares end unequally.  tile_ctr[xcd] counts the tiles of that XCD's range handed out beyond each workgroup's
+  // first, tile_ctr[8] the workgroups that are through; the last one zeroes all nine for the next launch on the stream (tile_counters(), launch.h).
+  unsigned* tile_ctr;
 };
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

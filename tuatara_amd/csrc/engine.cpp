@@ -1,5 +1,7 @@
 // Engine construction: weights to the device (BN-folded fp32, bf16 images, f16 weight planes), workspaces, the per-launch profile.
 #include "engine.h"
+#include <map>
+#include <mutex>
 
 namespace ttr {
 
@@ -12,6 +14,24 @@ void hip_fail(const char* what, hipError_t e, const char* file, int line) {
 Tuning g_tuning_default;
 
 RangeCtx& range_ctx() { static thread_local RangeCtx c; return c; }
+
+// ConvParams::tile_ctr: zeroed words per (device, stream), allocated on first use and never freed (a handful of streams per process).  Launches on one
+// stream run in order and each leaves the words zero, so a stream's launches share them; two streams never do.
+unsigned* tile_counters(hipStream_t s) {
+  static std::mutex m;
+  static std::map<std::pair<int, hipStream_t>, unsigned*> table;
+  int dev = 0;
+  TTR_HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(m);
+  unsigned*& d = table[{dev, s}];
+  if (!d) {
+    void* q = nullptr;
+    TTR_HIP_CHECK(hipMalloc(&q, (16 + 2048) * 4));   // (+ one word per CU: qkv_attn4.hip's matrix-phase token)
+    TTR_HIP_CHECK(hipMemset(q, 0, (16 + 2048) * 4));   // (synchronous: done before any launch that follows)
+    d = (unsigned*)q;
+  }
+  return d;
+}
 
 void Engine::range_tag(const std::string& layer) {
   if (prec != kSplit) return;

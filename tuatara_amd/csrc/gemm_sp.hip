@@ -328,6 +328,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void gemm_sp_kernel(ConvParams 
 #define TTR_SP_STAMP(ph) do { if (EPI == 1 && p.dbg && blockIdx.x == 0 && tid == 0 && stamp_tile < 24) p.dbg[stamp_tile * 16 + (ph)] = __builtin_readcyclecounter(); } while (0)
   while (true) {
     TTR_SP_STAMP(0);
+    if constexpr (EPI == 1) { if (p.dbg && blockIdx.x == 0 && tid == 0 && stamp_tile < 24) p.dbg[stamp_tile * 16 + 11] = __builtin_amdgcn_s_memrealtime(); }   // (100 MHz: the shader clock the kernel ran at)
     f32x4 acc[C::NJ][C::MI];
 #pragma unroll
     for (int j = 0; j < C::NJ; ++j)
@@ -1044,6 +1045,7 @@ void launch_gemm_sp(const ConvParams& p, int cfg, hipStream_t s) {
 void launch_qkv_attn_split(const void* x_pairs, const void* w_planes, const float* bias, float inv_scale, void* out_planes, int N, hipStream_t s, const void* w_tiled,
                            int x_tiled, int out_tiled) {
   if (N <= 0) return;
+  if (qkv_attn4_enabled()) return launch_qkv_attn4(x_pairs, w_planes, bias, inv_scale, out_planes, N, s, w_tiled, x_tiled, out_tiled);   // (experiment, off by default)
   if (((uintptr_t)x_pairs | (uintptr_t)w_planes | (uintptr_t)bias | (uintptr_t)out_planes) & 15) throw std::runtime_error("qkv_attn_split: operands must be 16-byte aligned");
   if ((size_t)N * 128 * 384 * 6 >= ((size_t)1 << 31)) throw std::runtime_error("qkv_attn_split: too many crops for 32-bit buffer offsets (the caller groups them)");
   ConvParams p{};

@@ -16,6 +16,7 @@ inline ConvParams with_range_ctx(const ConvParams& p) {  // a launcher's copy of
   return q;
 }
 
+unsigned* tile_counters(hipStream_t s);                  // engine.cpp: ConvParams::tile_ctr for launches on that stream
 
 // ---- igemm.hip
 const char* igemm_check(const ConvParams& p);
@@ -79,6 +80,12 @@ void set_store_policy(int v);
 // ---- conv1u.hip (CRAFT's upconv4.0 skip half: 1x1 over 128 channels + upsampled addend, persistent, weights resident)
 bool conv1u_eligible(const ConvParams& p);
 void launch_conv1u(const ConvParams& p, hipStream_t s);
+// ---- qkv_attn4.hip (the fused qkv + attention tile as four-wave workgroups, two per CU; tuning key "qkv_attn4", off by default)
+void set_qkv_attn4(int v);
+int qkv_attn4_enabled();
+void set_qkv_attn4_stamps(unsigned long long* dev_buf);
+void launch_qkv_attn4(const void* x_pairs, const void* w_planes, const float* bias, float inv_scale, void* out_planes, int N, hipStream_t s, const void* w_tiled, int x_tiled,
+                      int out_tiled);
 void set_gemm2_up_resident(int v);
 void set_gemm2_up_2d(int v);
 // ---- conv3h.hip (CRAFT's packed-pairs head layers, persistent)

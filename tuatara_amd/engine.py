@@ -79,6 +79,7 @@ SYMBOLS = [
     ("ttr_dbg_qkv_attn", _I, [_VP, _PF, _I, _PF, _PF, _PF]),
     ("ttr_dbg_mlp", _I, [_VP, _PF, _I, _PF, _PF, C.c_float, _PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF, _PF]),
     ("ttr_dbg_dec_stamps", _I, [C.POINTER(C.c_ulonglong)]),
+    ("ttr_dbg_dec_stamps_ext", _I, [C.POINTER(C.c_ulonglong), _I]),
     ("ttr_bench_conv", _I, [_VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _PF]),
     ("ttr_get_profile", _I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     ("ttr_get_profile_kinds", _I, [_VP, C.c_char_p, C.c_size_t]),
