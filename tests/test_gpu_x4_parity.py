@@ -423,6 +423,28 @@ def test_x4_craft_upconv4_skip_half_persistent_kernel_changes_nothing(eng_x4_ran
             eng.set_tuning(b"up_resident", 1)
 
 
+def test_x4_craft_first_layer_fused_into_the_second_changes_nothing(eng_x4_random, eng_x4, funsd):
+    """conv1_1 evaluated inside conv1_2's kernel on every halo patch (conv3p.hip: FIRST on pairs; tuning key "first_fused", the default) against the two launches
+    (conv1_split_kernel writes the 64-channel tensor at full resolution, the plain tile reads it back): the same tables, the same MFMAs in the same order, the same
+    epilogue - heat maps bit-identical on fully random weights (1024 x 768; a wide, a tall and two small canvases - every canvas the engine takes, a multiple of 32 each
+    way, tiles into 8 x 32 patches -; black and white canvases: the image border's zero padding and saturated bytes) and on the FUNSD page with the structured weights."""
+    from oracle import post
+    rng = np.random.default_rng(2029)
+    canvases = [rng.integers(0, 256, hw + (3,), dtype=np.uint8) for hw in ((1024, 768), (256, 512), (512, 128), (64, 96), (32, 32))]
+    canvases += [np.zeros((128, 256, 3), np.uint8), np.full((128, 256, 3), 255, np.uint8)]
+    for eng, cs in ((eng_x4_random, canvases), (eng_x4, [post.resize_aspect_ratio(np.ascontiguousarray(funsd[:, :, ::-1]))[0]])):
+        try:
+            for c in cs:
+                assert eng.set_tuning(b"first_fused", 1) == 0
+                a = eng.craft_heatmap(c)
+                a2 = eng.craft_heatmap(c)
+                assert eng.set_tuning(b"first_fused", 0) == 0
+                b = eng.craft_heatmap(c)
+                assert np.isfinite(a).all() and np.array_equal(a, a2) and np.array_equal(a, b), (c.shape, float(np.abs(a - b).max()))
+        finally:
+            eng.set_tuning(b"first_fused", 1)
+
+
 def test_x4_craft_upconv_skip_halves_on_2d_tiles_change_nothing(eng_x4_random):
     """The skip halves of the commuted up-convolutions (upconv2.0 / 3.0, and 4.0 where conv1u.hip does not take it) with a tile's rows a 2-D block of (BM / 16) x 16
     pixels instead of BM consecutive ones (ConvParams::up_2d, tuning key "up_2d": the four-tap gather of z re-uses its rows inside the workgroup): a row-to-pixel map,

@@ -35,7 +35,11 @@ def rows(path, counter):
 f, w = rows(fetch_csv, "FETCH_SIZE"), rows(write_csv, "WRITE_SIZE")
 n = len(LAYERS)
 per_step = len(f) // 3 if len(f) % 3 == 0 else n
-if f and "conv1_split" in f[-per_step]["Kernel_Name"]:       # the f16x4 engine's group (its first launch is conv1_split)
+LAYERS_X4_FIRST_FUSED = ["slice1.0 + slice1.3 +pool (conv1_1 inside conv1_2's kernel, u8 canvas in)"] + LAYERS_X4_COMMUTED[2:]   # (round 6: conv3p.hip FIRST on pairs)
+if f and per_step == len(LAYERS_X4_FIRST_FUSED) and "conv3p_kernel<64, 4, 2, true" in f[-per_step]["Kernel_Name"]:   # (its first launch is the fused pair)
+    LAYERS = LAYERS_X4_FIRST_FUSED
+    n = len(LAYERS)
+elif f and "conv1_split" in f[-per_step]["Kernel_Name"]:       # the f16x4 engine's group (its first launch is conv1_split)
     LAYERS = LAYERS_X4_COMMUTED if per_step == len(LAYERS_X4_COMMUTED) else LAYERS_X4 if per_step == len(LAYERS_X4) else LAYERS_X4_UNFUSED
     n = len(LAYERS)
 f, w = f[-per_step:], w[-per_step:]

@@ -35,7 +35,9 @@ struct ConvParams {
   void* out_pool; int pool_relu;   // gemm2 only: optional 2x2/stride-2 max-pooled T output [B][H/2][W/2][Cout] (row stride out_ld), ReLU first if pool_relu
   const float* resid; int resid_ld; int resid_mod;  // f32 residual added before act; row = m % resid_mod if resid_mod
   int Cout, M, act;
-  const void* pre_wgt; const float* pre_bias;   // conv3p only: fuse CRAFT's conv1_1 in front (in0 = u8 canvas [B][H][W][3], pre_wgt = T [64][32])
+  const void* pre_wgt; const float* pre_bias;   // conv3p only: fuse CRAFT's conv1_1 in front (in0 = u8 canvas [B][H][W][3], pre_wgt = T [64][32]; split: the layer's planes [64][3][32])
+  float pre_scale;                              // ... split: conv1_1's output scale (Linear::inv_scale)
+  unsigned pre_range_tag;                       // ... split: the range guard's tag for the fused layer's own planes (split.h: RangeWatch; the kernel's range_tag names the layer behind it)
   // gemm_sk only: take the activation rows from LayerNorm(ln_in) instead of in0 (f32 [M][384] rows, stride ln_ld)
   const float* ln_in; int ln_ld; const float* ln_gamma; const float* ln_beta; float ln_eps;
   // gemm_sk + LayerNorm prologue only, PARSeq AR step (tok != null): the row to normalise is emb[token] (+ tok_pos), token =

@@ -77,11 +77,11 @@ struct C3 {
 // workgroups on 256 CUs) waits out one L2 / Infinity-Cache round trip per tap with them, ~0.65 us x 216 taps for 512 input channels, and takes four (eight: no further gain).
 template <int BN, int WM, int WN, bool FIRST, int XS, int LPW, int NP = 0, int NWS = 2>   // NP: 0 = bf16, 4 = triples, 3 = pairs, 2 = packed pairs (split.h).  XS: patch stages (1 when Cin = 64: a single chunk, and two workgroups fit a CU)
 __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 && !(BN == 128 && WN == 1) ? 4 : 2)) void conv3p_kernel(ConvParams p) {   // (second number: waves per SIMD the register budget allows)
-  static_assert(NWS == 2 || ((NWS == 4 || NWS == 8) && XS == 1 && BN <= 64 && !FIRST), "more than two weight stages: the static-address loop's");
+  static_assert(NWS == 2 || ((NWS == 4 || NWS == 8) && XS == 1 && BN <= 64 && (!FIRST || NP == 3)), "more than two weight stages: the static-address loop's");
   using C = C3<BN, WM, WN, LPW>;
   using G = Geo<LPW>;
   constexpr bool SP = NP != 0;
-  static_assert(!SP || (XS == 1 && !FIRST), "split mode: single patch stage, no fused first layer");
+  static_assert(!SP || (XS == 1 && (!FIRST || (NP == 3 && BN == 64 && WM == 4 && WN == 2))), "split mode: single patch stage; the fused first layer on pairs and the 64-wide eight-wave tile only");
   using frag_t = typename std::conditional<SP, f16x8, bf16x8>::type;
   constexpr int PL = NP == 4 ? 3 : NP == 3 ? 2 : 1;      // activation planes per pixel
   constexpr int VC = SP ? NP : 1;                         // virtual chunks per 64-channel chunk: (x0, w0) (x0, w1) (x1, w0b) [(x2, w0b)]
@@ -180,12 +180,101 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 && !(BN == 128 
     for (int i = 0; i < C::MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   stage_w(0, 0, 0);
+  // (FIRST on pairs: the x1 plane of the halo patch, kept in registers until the third virtual chunk wants it in the one patch stage: [16-slot block of this wave][channel half])
+  constexpr int X1R = (FIRST && SP) ? (XSLOTS / 16 + C::NW - 1) / C::NW : 1;
+  f16x8 x1k[X1R][2];
   if constexpr (!FIRST) {
     stage_x(0);
     if constexpr (NWS > 2) {   // taps 1 .. NWS - 2 of chunk 0 (NWS - 1 <= 7 < 9 taps)
 #pragma unroll
       for (int t = 1; t < NWS - 1; ++t) stage_w(0, t, t);
     }
+  } else if constexpr (SP) {
+    // ---- conv1_1 on the halo patch in split arithmetic, exactly as conv1_split_kernel (split_ops.hip) evaluates it - the same tables, the same three MFMAs per
+    // accumulator in the same order, the same epilogue - so the patch holds the planes that kernel would have written and the layer's result is bit-identical to the
+    // two-launch form.  x0 goes to the patch stage, x1 stays in registers (x1k).  CRAFT's largest tensor (64 channels at full resolution: 1.6 GB per eight pages,
+    // written once and read once) does not exist.
+    if constexpr (NWS > 2) {
+#pragma unroll
+      for (int t = 1; t < NWS - 1; ++t) stage_w(0, t, t);
+    }
+    // the canvas rows around the halo as aligned dwords, one per thread: row bytes 3 x0 - 8 .. 3 x0 + 107 (3 x0 and 3 W are multiples of 4: a dword lies inside the row
+    // or outside it), of which bytes + 2 .. + 109 are the 36 pixels x0 - 2 .. x0 + 33; zero outside the image
+    unsigned char* cv = smem + XS * XSTAGE + NWS * C::WSTAGE;   // [12][29 dwords]
+    f16x2* lut = reinterpret_cast<f16x2*>(cv + 1536);           // [256]: the two planes of v / 255, side by side (one read per input)
+    const uint8_t* canvas = reinterpret_cast<const uint8_t*>(p.in0);
+    if (tid < 12 * 29) {
+      const int rr = tid / 29, j = tid - rr * 29;
+      const int y = y0 - 2 + rr, byte0 = 3 * x0 - 8 + 4 * j;
+      const bool ok = y >= 0 && y < p.H && byte0 >= 0 && byte0 < 3 * p.W;
+      reinterpret_cast<unsigned*>(cv)[tid] = ok ? *reinterpret_cast<const unsigned*>(canvas + ((int64_t)b * p.H + y) * p.W * 3 + byte0) : 0u;
+    }
+    RangeWatch rw1;
+    if (tid < 256) {
+      f16x2 a, bq;
+      split2_pair((float)tid / 255.0f, 0.f, a, bq, rw1);
+      lut[tid] = f16x2{a[0], bq[0]};
+    }
+    const f16* w1p = reinterpret_cast<const f16*>(p.pre_wgt);   // [64][3][32]: w0 | w0 / 2^11 | w1
+    f16x8 f1[3][4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int n = 32 * (jj >> 1) + (fr >> 2) * 8 + (jj & 1) * 4 + (fr & 3);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) f1[pl][jj] = *reinterpret_cast<const f16x8*>(w1p + n * 96 + pl * 32 + fg * 8);
+    }
+    float b1[2][8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) b1[t][e] = p.pre_bias[32 * t + fg * 8 + e];
+    int koff[8];                                       // byte offset of this lane's 8 inputs k = (ky * 3 + kx) * 3 + c inside the canvas patch
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = fg * 8 + e;
+      koff[e] = k < 27 ? (k / 9) * 116 + (k % 9) : -1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < X1R; ++r) {
+      const int mt = wave + r * C::NW;
+      const int pi = mt * 16 + fr;
+      const int pr = pi / HW2, pc = pi - pr * HW2;
+      const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+      const bool inside = pi < NHALO && y >= 0 && y < p.H && x >= 0 && x < p.W;
+      const unsigned char* base = cv + 2 + (pi < NHALO ? pr * 116 + pc * 3 : 0);   // canvas pixel (y - 1, x - 1)
+      f16x8 fx0, fx1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int byte = koff[e] >= 0 ? base[koff[e]] : 0;   // table entry 0 = (0, 0)
+        const f16x2 q2 = lut[byte];
+        fx0[e] = q2[0]; fx1[e] = q2[1];
+      }
+      f32x4 a1[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1[0][jj], fx0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1[1][jj], fx1, a, 0, 0, 0);
+        a1[jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1[2][jj], fx0, a, 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = fmaxf(fmaf(a1[2 * t][e], p.pre_scale, b1[t][e]), 0.f);
+          v[4 + e] = fmaxf(fmaf(a1[2 * t + 1][e], p.pre_scale, b1[t][4 + e]), 0.f);
+        }
+        f16x8 o0, o1;
+        split2_x8(v, o0, o1, rw1);
+        const f16x8 zero = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+        if (!inside) { o0 = zero; o1 = zero; }         // outside the image: conv1_2's zero padding (and the patch's padding slots)
+        x1k[r][t] = o1;
+        if (pi < XSLOTS) *reinterpret_cast<f16x8*>(xs + pi * 128 + (((4 * t + fg) ^ (pi & 7)) << 4)) = o0;   // (the last block reaches past the patch: the weight stages begin there)
+      }
+    }
+    rw1.flush(p.range_flag, p.pre_range_tag);
+    __syncthreads();   // the patch is written with ds_write: the K loop's raw s_barrier would not wait for it
   } else {
     // ---- conv1_1 on the halo patch -> xs stage 0 (the LDS behind the operand stages holds the u8 canvas patch and a u8/255 table)
     unsigned char* cv = smem + XS * XSTAGE + NWS * C::WSTAGE;  // [12][36*3] canvas bytes around the halo (zero outside the image)
@@ -250,7 +339,7 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 && !(BN == 128 
   // the runtime-tap loop below.
   // BN = 128 on FOUR waves (WN = 1: wave tiles of 64 pixels x all 128 channels, 64 MFMAs per tap and wave, 24 fragment reads instead of 32 per 64 MFMAs; two
   // workgroups per CU = two waves per SIMD with 256 registers each) takes this loop too: the experiment behind the tuning key c3_c128_waves.
-  constexpr bool STATIC_ADDR = XS == 1 && (BN <= 64 || (BN == 128 && WN == 1)) && C::TM == 64 && !FIRST;
+  constexpr bool STATIC_ADDR = XS == 1 && (BN <= 64 || (BN == 128 && WN == 1)) && C::TM == 64 && (!FIRST || SP);
   if constexpr (STATIC_ADDR) {
     const int pib = ((wm * C::TM) >> LPW) * HW2 + fr;
     int xbase[8];                                          // byte offsets from smem (32-bit LDS arithmetic)
@@ -264,9 +353,22 @@ __global__ __launch_bounds__(WM * WN * 64, (XS == 1 && BN <= 128 && !(BN == 128 
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NWS - 2) * C::WPW) : "memory");   // the taps requested after this one may still be on their way
         __builtin_amdgcn_s_barrier();
         if (tap == 0 && chunk > 0 && (!SP || chunk % VC != 1)) {   // single patch stage: the next chunk's patch can only be fetched now
+          if constexpr (FIRST && SP) {                              // ... or, fused first layer, written from the registers that hold its x1 plane
+#pragma unroll
+            for (int r = 0; r < X1R; ++r) {
+              const int mt = wave + r * C::NW, pi = mt * 16 + fr;
+              if (pi < XSLOTS) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) *reinterpret_cast<f16x8*>(xs + pi * 128 + (((4 * t + fg) ^ (pi & 7)) << 4)) = x1k[r][t];
+              }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+          } else {
           stage_x(chunk);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
+          }
         }
         const int wbuf = wb0 + par * C::WSTAGE;
         const int tapoff = (tap / 3) * HW2 + (tap % 3);
@@ -1101,7 +1203,7 @@ static void launch_c3(const ConvParams& p_in, hipStream_t s) {
   using C = C3<BN, WM, WN, LPW>;
   using G = Geo<LPW>;
   const int tilesM = p.B * (p.H / G::PH) * (p.W / G::PW), tilesN = (p.Cout + BN - 1) / BN;
-  constexpr int lds = XS * G::XSTAGE + NWS * C::WSTAGE + (FIRST ? 2048 : 0);
+  constexpr int lds = XS * G::XSTAGE + NWS * C::WSTAGE + (FIRST ? (NP ? 2560 : 2048) : 0);   // (the canvas patch and the u8 tables of the fused first layer)
   static PerDeviceOnce once;
   once.run([&] { TTR_HIP_CHECK(hipFuncSetAttribute((const void*)conv3p_kernel<BN, WM, WN, FIRST, XS, LPW, NP, NWS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); });
   hipLaunchKernelGGL((conv3p_kernel<BN, WM, WN, FIRST, XS, LPW, NP, NWS>), dim3(tilesM * tilesN), dim3(C::NT), lds, s, p);
@@ -1130,7 +1232,9 @@ void set_conv3p_single_stage_max_cin(int c) { g_xs1_max_cin = c; }
 
 const char* conv3p_check(const ConvParams& p) {
   if (p.split) {   // f16 planes in; fp32 or planes out
-    if (p.ks != 3 || p.dil != 1 || p.C1 || p.relu0 || p.relu1 || p.pre_wgt) return "conv3p: 3x3, dilation 1, single source";
+    if (p.ks != 3 || p.dil != 1 || p.C1 || p.relu0 || p.relu1) return "conv3p: 3x3, dilation 1, single source";
+    if (p.pre_wgt && (p.split != 3 || p.C0 != 64 || p.Cout != 64 || !p.pre_bias || !(p.pre_scale > 0.f) || p.H % 8 || p.W % 32 || ((uintptr_t)p.pre_wgt & 15) || (size_t)p.M * 3 >= ((size_t)1 << 31)))
+      return "conv3p: the fused first layer (split) is conv1_1 in front of conv1_2 on pairs, 8 x 32 patches";
     if (p.C0 % 64 || p.Cout % 8) return "conv3p: Cin % 64, Cout % 8";
     if (!((p.H % 8 == 0 && p.W % 32 == 0) || (p.H % 16 == 0 && p.W % 16 == 0))) return "conv3p: the map must tile into 8x32 or 16x16 patches";
     if (p.resid || p.out_f32 || p.act == kActGelu) return "conv3p: conv epilogues only";
@@ -1141,7 +1245,7 @@ const char* conv3p_check(const ConvParams& p) {
     if (!p.out && !p.out_pool && !(p.split == 2 && p.tail_heat)) return "conv3p: no output";
     if (p.tail_heat && (p.split != 2 || p.Cout != 32 || !p.tail_w6 || !p.tail_w8 || !p.tail_b6 || !p.tail_b8 || (((uintptr_t)p.tail_w6 | (uintptr_t)p.tail_w8 | (uintptr_t)p.tail_b6) & 15)))
       return "conv3p: the fused head tail belongs to conv_cls.4 on packed pairs (32 output channels)";
-    if ((p.bias && ((uintptr_t)p.bias & 15)) || ((uintptr_t)p.in0 & 15) || ((uintptr_t)p.wgt & 15)) return "conv3p: operand alignment";
+    if ((p.bias && ((uintptr_t)p.bias & 15)) || (!p.pre_wgt && ((uintptr_t)p.in0 & 15)) || ((uintptr_t)p.wgt & 15)) return "conv3p: operand alignment";
     const size_t lim = (size_t)1 << 31;
     if (p.split != 2 && p.split != 3 && p.split != 4) return "conv3p: split must be 2 (packed pairs), 3 or 4";
     if (p.split == 2 && (p.C0 != 64 || p.Cout > 32)) return "conv3p: packed pairs are the 32-channel layers' form (64 halves per pixel, Cout <= 32)";
@@ -1202,6 +1306,7 @@ void launch_conv3p(const ConvParams& p, hipStream_t s) {
   if (const char* e = conv3p_check(p)) throw std::runtime_error(e);
   if (p.split) {   // the one-patch-stage tiles (two workgroups per CU)
     const bool wide = p.H % 8 == 0 && p.W % 32 == 0;
+    if (p.pre_wgt) return launch_c3<64, 4, 2, true, 1, 5, 3, 4>(p, s);   // conv1_1 fused in front of conv1_2 (conv3p_check: pairs, 64 -> 64 channels, 8 x 32 patches)
     const int tiles128 = p.B * (wide ? (p.H / 8) * (p.W / 32) : (p.H / 16) * (p.W / 16)) * ((p.Cout + 127) / 128);
     const bool narrow = tiles128 < g_narrow_frac * device_cu_count(256) / 4 && (!wide || g_narrow_wide);   // fewer 128-wide tiles than workgroup slots: 64-wide tiles fill the chip (a single page)
     const bool narrowest = c3_narrowest(p, wide);

@@ -90,6 +90,8 @@ struct Tuning {
   int up_commute = 1;         // split engines, CRAFT's upconv2.0 / 3.0 / 4.0 (1x1 over cat(upsample(y), skip)): W_up . y at the low resolution, its bilinear upsample added in the
                               // epilogue of the skip half's 1x1 (gemm2.hip, ConvParams::up_z) - the upsampled tensors are never written; 0 = upsample kernel + two-source 1x1
   int head_tail = 1;          // ... and the two 1x1 layers behind conv_cls.4 inside its epilogue (no 16-channel tensors, two launches less); 0 = fp32 MFMA launches
+  int first_fused = 1;        // pairs, pages that tile into 8 x 32 patches: conv1_1 evaluated inside conv1_2's kernel on the halo patch (conv3p.hip, FIRST on pairs) - the
+                              // 64-channel full-resolution tensor is neither written nor read; bit-identical to the two launches (0: conv1_split_kernel + the plain tile)
   int head_packed = 1;        // ... with pairs: the 32-channel head tensors as 128-byte pixel rows [x0 | x1] and conv_cls.0 / .2 / .4 on packed pairs (two virtual
                               // chunks instead of three over zero-padded 64-channel rows: two thirds of the MFMAs, half the bytes); 0 = zero-padded rows
   int detector_only = 0;      // profiling: drop every detected box, so that a batch runs the detector + CCL only
@@ -142,6 +144,7 @@ struct Tuning {
     else if (k == "detector_only") detector_only = value;
     else if (k == "craft_products") craft_products = value == 4 ? 4 : 3;
     else if (k == "head_packed") head_packed = value;
+    else if (k == "first_fused") first_fused = value;
     else if (k == "head_tail") head_tail = value;
     else if (k == "enc_ln_pairs") enc_ln_pairs = value;
     else if (k == "enc_fc2_pairs") enc_fc2_pairs = value;
@@ -533,6 +536,7 @@ struct Engine {
   // value); the convolutions' epilogues write them (bias, ReLU, ReLU copy, 2x2 max-pool fused), so no fp32 tensor and no separate
   // split pass exists up to the 32-channel head, which stays on the fp32 MFMA kernel (thin layers: 3 % of the FLOPs).
   void upconv_commuted(const char* name, const void* y_lo, int C0, const void* skip, int C1, int B, int H, int W, float* z, void* out);
+  const uint8_t* sconv_canvas = nullptr;   // set around the sconv of slice1.3: its input tensor does not exist, conv1_1 is evaluated from this canvas inside the kernel (tn.first_fused)
   void sconv(const char* name, const void* in0, int C0, const void* in1, int C1, int B, int H, int W, void* out, int act,
              void* out_relu = nullptr, void* out_pool = nullptr, int pool_relu = 0, int out_planes = -1, int out_ld = 0, bool packed = false, float* tail_heat = nullptr);
   void craft_forward_split(const uint8_t* d_canvas, int B, int H, int W, float* d_heat);

@@ -152,6 +152,20 @@ void Engine::sconv(const char* name, const void* in0, int C0, const void* in1, i
   p.Cout = L.cout; p.M = B * H * W; p.act = act;
   double flops = 0;
   for (const auto& c : craft_convs()) if (std::string(c.name) == name) flops = 2.0 * p.M * c.cout * c.ks * c.ks * c.cin;
+  const bool fused_first = sconv_canvas != nullptr;
+  if (fused_first) {   // conv1_1 inside this layer's kernel (conv3p.hip: FIRST on pairs): in0 is the u8 canvas
+    const Linear& L0 = craft.at("slice1.0");
+    p.in0 = sconv_canvas; p.pre_wgt = L0.ws.p; p.pre_bias = L0.b.as<float>(); p.pre_scale = L0.inv_scale;
+    range_tag("craft.slice1.0"); p.pre_range_tag = range_ctx().tag;   // a trip inside the fused layer keeps its own name
+    range_tag(std::string("craft.") + name);
+    if (const char* e = conv3p_check(p)) throw std::runtime_error(std::string(name) + " (fused first layer): " + e);
+    flops += 2.0 * p.M * 64 * 27;
+    const char* fk = "conv3p_kernel<64,NP=3> + conv1_1 (fused first layer)";
+    const std::string fl = std::string("slice1.0 + ") + name + " | " + fk;
+    timed(profiling == 2 ? fl.c_str() : fk, flops, flops * np, [&] { launch_conv3p(p, stream); },
+          (double)p.M * 3.0 + (out ? (double)p.M * p.Cout * 2.0 * out_planes : 0.0) + (out_pool ? (double)p.M / 4 * p.Cout * 2.0 * out_planes : 0.0) + (double)p.Cout * L.k * 6.0);
+    return;
+  }
   const bool c3 = tn.split_conv3p && p.Cout >= 32 && conv3p_check(p) == nullptr;
   if (!c3) { if (const char* e = gemm2_check(p)) throw std::runtime_error(std::string(name) + ": " + e); }
   // kinds by kernel: the patch-stationary 3x3 kernel by its tile width (conv3p.hip picks it), everything else on gemm2's split loop
@@ -211,14 +225,22 @@ void Engine::craft_forward_split(const uint8_t* d_canvas, int B, int H, int W, f
   }
   auto pbuf = [&](size_t rows, int C) -> void* { return ws(k++, rows * C * 2 * npl).p; };   // planes
   auto fbuf = [&](size_t rows, int C) -> void* { return ws(k++, rows * C * 4).p; };   // fp32
-  void* c11 = pbuf(M0, 64);
-  {
+  // conv1_1: a launch of its own (conv1_split_kernel: the 64-channel tensor at full resolution goes out and comes back), or - pairs, 8 x 32 patches, the split
+  // 3x3 tiles on - evaluated inside conv1_2's kernel on each halo patch: same arithmetic, same bits, the tensor never exists (tuning key first_fused)
+  const bool fuse_first = tn.first_fused && npl == 2 && tn.split_conv3p && H % 8 == 0 && W % 32 == 0 && M0 * 3 < ((size_t)1 << 31);
+  void* c11 = fuse_first ? nullptr : pbuf(M0, 64);
+  if (!fuse_first) {
     const Linear& L0 = craft.at("slice1.0");
     range_tag("craft.slice1.0");
     timed(profiling == 2 ? "slice1.0 | conv1_split_kernel" : "conv1_split_kernel", 2.0 * M0 * 64 * 27, 2.0 * M0 * 64 * 27 * (npl + 1), [&] { launch_conv1_split(d_canvas, L0.ws.p, L0.b.as<float>(), L0.inv_scale, c11, B, H, W, stream, npl); },
           (double)M0 * 3.0 + (double)M0 * 64 * 2.0 * npl);
+  } else k++;   // (the workspace slot stays reserved: the slots behind it keep their sizes whichever way this page goes)
+  void* p1 = pbuf(M1, 64);
+  {
+    struct CanvasScope { Engine& E; ~CanvasScope() { E.sconv_canvas = nullptr; } } scope{*this};
+    sconv_canvas = fuse_first ? d_canvas : nullptr;
+    sconv("slice1.3", c11, 64, nullptr, 0, B, H, W, nullptr, kActRelu, nullptr, p1, 0);
   }
-  void* p1 = pbuf(M1, 64);   sconv("slice1.3", c11, 64, nullptr, 0, B, H, W, nullptr, kActRelu, nullptr, p1, 0);
   void* c21 = pbuf(M1, 128); sconv("slice1.7", p1, 64, nullptr, 0, B, H1, W1, c21, kActRelu);
   void* c22 = pbuf(M1, 128); void* p2 = pbuf(M2, 128);
   sconv("slice1.10", c21, 128, nullptr, 0, B, H1, W1, c22, kActNone, nullptr, p2, 1);                    // relu2_2 skip (pre-ReLU) + pooled ReLU
